@@ -1,0 +1,234 @@
+"""ORACLE (test infrastructure, not product code): fp32 CPU restatement of the reference's
+message-passing layers in plain torch ops (autograd gives the reference gradients).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this.  The product path never does.
+
+Parity status
+  * SI ``RGINLayer`` / ``RGCNLayer``: PINNED -- checked against outputs + all gradients of the
+    reference's own modules (run under the stand-ins of tests/golden/_ref_standins.py) for the
+    regulariser x activation x self_loop x edge_norm grid in tests/golden/si_layers_*.npz.
+  * GC ``GINConv`` / ``RGCNConv`` arithmetic: the algorithm lives in torch-geometric==2.0.2
+    (README.md:26), which is NOT under /root/reference and not installed: **parity unpinned**
+    for those two; restated from the published layer definitions (GIN: nn((1+eps) x_i + sum_j x_j);
+    RGCNConv: sum_r aggr_{j in N_r(i)} x_j W_r + x_i root + b) and anchored on the reference's
+    call sites gconv.py:197,212 and rgconv.py:17-18,40-41,96,121.
+"""
+import math
+
+import torch as th
+import torch.nn.functional as F
+
+LEAKY_RELU_A = 1 / 5.5  # reference: SI constants.py:10, utils/act.py:27
+
+
+def act_fn(name):
+    """reference: SI utils/act.py:457-474 (subset reachable from RGIN/RGCN configs)."""
+    if name == "none":
+        return lambda x: x
+    if name == "relu":
+        return F.relu
+    if name == "leaky_relu":
+        return lambda x: F.leaky_relu(x, LEAKY_RELU_A)
+    if name == "tanh":
+        return th.tanh
+    if name == "sigmoid":
+        return th.sigmoid
+    if name == "gelu":
+        return F.gelu
+    if name == "elu":
+        return F.elu
+    raise NotImplementedError(name)
+
+
+def segment_sum(rows, index, num_segments):
+    """sum rows by destination -- DGL fn.sum / torch_scatter 'sum'."""
+    out = th.zeros((num_segments,) + tuple(rows.shape[1:]), dtype=rows.dtype)
+    return out.index_add(0, index, rows)
+
+
+def relation_weights(weight, w_comp, regularizer, num_rels, num_bases, in_dim, out_dim):
+    """Materialise dense [R, in, out] weights.  reference: SI models/rgin.py:103-108, 114-117."""
+    if regularizer in ("none", "basis"):
+        if w_comp is not None:
+            return th.matmul(w_comp, weight.view(num_bases, in_dim * out_dim)).view(num_rels, in_dim, out_dim)
+        return weight
+    # bdd: block-diagonal with num_bases blocks
+    si, so = in_dim // num_bases, out_dim // num_bases
+    blocks = weight.view(num_rels, num_bases, si, so)
+    dense = th.zeros(num_rels, in_dim, out_dim, dtype=weight.dtype)
+    for b in range(num_bases):
+        dense[:, b * si:(b + 1) * si, b * so:(b + 1) * so] = blocks[:, b]
+    return dense
+
+
+def _messages(x, src, etype, p, regularizer, num_rels, num_bases):
+    """Per-edge transform-then-aggregate message, exactly the reference's formulation.
+    reference: SI models/rgin.py:102-120 (== rgcn.py:100-122 before the norm)."""
+    in_dim = x.shape[1]
+    if regularizer in ("none", "basis"):
+        out_dim = p["weight"].shape[2]
+        W = relation_weights(p["weight"], p.get("w_comp"), regularizer, num_rels, num_bases, in_dim, out_dim)
+        Wg = W.index_select(0, etype)
+        return th.bmm(x[src].unsqueeze(1), Wg).squeeze(1)
+    si = in_dim // num_bases
+    so = p["weight"].shape[1] // (num_bases * si)
+    Wg = p["weight"].index_select(0, etype).view(-1, si, so)
+    return th.bmm(x[src].reshape(-1, 1, si), Wg).view(-1, num_bases * so)
+
+
+def rgin_layer(x, src, dst, etype, p, regularizer="basis", num_rels=1, num_bases=-1,
+               num_mlp_layers=2, act="relu", mlp_bn=None):
+    """reference: SI models/rgin.py:137-160.  p: dict with weight, (w_comp), (loop_weight), (bias),
+    mlp.{0,2,..}.{weight,bias}.  Activation after the MLP; twice if the MLP is empty (:147-151)."""
+    if regularizer == "none" or num_bases is None or num_bases > num_rels or num_bases <= 0:
+        num_bases = num_rels                                                   # (:38-41)
+    f = act_fn(act)
+    msg = _messages(x, src, etype, p, regularizer, num_rels, num_bases)
+    out = segment_sum(msg, dst, x.shape[0])                                    # fn.sum (:98)
+    if p.get("loop_weight") is not None:
+        out = out + th.matmul(x, p["loop_weight"])                             # (:140-142)
+    if p.get("bias") is not None:
+        out = out + p["bias"]                                                  # (:145-146)
+    if num_mlp_layers > 0:
+        # Sequential(Linear, [BN], act, Linear, ...): module index steps by 2 (3 with BN) (:50-57)
+        step = 3 if mlp_bn else 2
+        for i in range(num_mlp_layers):
+            out = F.linear(out, p["mlp.%d.weight" % (i * step)], p["mlp.%d.bias" % (i * step)])
+            if i != num_mlp_layers - 1:
+                if mlp_bn:
+                    out = mlp_bn[i](out)
+                out = f(out)
+    else:
+        out = f(out)
+    return f(out)                                                              # (:151)
+
+
+def rgcn_norms(src, dst, num_nodes, edge_norm, self_loop):
+    """reference: SI models/rgcn.py:132-165."""
+    in_deg = th.bincount(dst, minlength=num_nodes)
+    out_deg = th.bincount(src, minlength=num_nodes)
+    in_norm = out_norm = enorm = None
+    if edge_norm in ("in", "both"):
+        if self_loop:
+            in_norm = (1.0 / (in_deg.float() + 1)).view(-1, 1)
+        else:
+            in_norm = (1.0 / in_deg.float()).masked_fill_(in_deg == 0, 0.0).view(-1, 1)
+    if edge_norm in ("out", "both"):
+        if self_loop:
+            out_norm = (1.0 / (out_deg.float() + 1)).view(-1, 1)
+        else:
+            out_norm = (1.0 / out_deg.float()).masked_fill_(out_deg == 0, 0.0).view(-1, 1)
+    if edge_norm == "in":
+        enorm = in_norm[dst]
+    elif edge_norm == "both":
+        enorm = (out_norm[src] * in_norm[dst]) ** 0.5
+    return in_norm, out_norm, enorm
+
+
+def rgcn_layer(x, src, dst, etype, p, regularizer="basis", num_rels=1, num_bases=-1,
+               edge_norm="in", act="relu", bn=None):
+    """reference: SI models/rgcn.py:100-197."""
+    if regularizer == "none" or num_bases is None or num_bases > num_rels or num_bases <= 0:
+        num_bases = num_rels
+    self_loop = p.get("loop_weight") is not None
+    in_norm, out_norm, enorm = rgcn_norms(src, dst, x.shape[0], edge_norm, self_loop)
+    msg = _messages(x, src, etype, p, regularizer, num_rels, num_bases)
+    if edge_norm != "none":
+        msg = msg * enorm                                                      # (:110-111)
+    out = segment_sum(msg, dst, x.shape[0])
+    if self_loop:
+        loop_msg = th.matmul(x, p["loop_weight"])
+        if edge_norm == "in":
+            out = out + loop_msg * in_norm                                     # (:174-175)
+        elif edge_norm == "both":
+            out = out + loop_msg * (in_norm * out_norm) ** 0.5                 # (:178-179)
+        else:
+            out = out + loop_msg
+    if p.get("bias") is not None:
+        out = out + p["bias"]
+    if bn is not None:
+        out = bn(out)
+    return act_fn(act)(out)
+
+
+# ---- aggregate-then-transform form: same math, no [E,H,H] temporary; used for
+# ---- the CPU baseline timing at sizes where the reference's own formulation cannot allocate.
+def rgin_layer_agg_first(x, src, dst, etype, p, num_rels, act="relu", num_mlp_layers=2):
+    N, H = x.shape
+    f = act_fn(act)
+    seg = dst * num_rels + etype
+    A = segment_sum(x[src], seg, N * num_rels).view(N, num_rels * H)          # [N, R*H]
+    out = A @ p["weight"].reshape(num_rels * H, -1)                            # sum_r A_r W_r
+    if p.get("loop_weight") is not None:
+        out = out + x @ p["loop_weight"]
+    if p.get("bias") is not None:
+        out = out + p["bias"]
+    for i in range(num_mlp_layers):
+        out = F.linear(out, p["mlp.%d.weight" % (2 * i)], p["mlp.%d.bias" % (2 * i)])
+        if i != num_mlp_layers - 1:
+            out = f(out)
+    if num_mlp_layers == 0:
+        out = f(out)
+    return f(out)
+
+
+# --------------------------------------------------------------------------------------
+# GC side (PyG 2.0.2 layer definitions; parity unpinned, see module docstring)
+# --------------------------------------------------------------------------------------
+def gin_conv(x, src, dst, eps, nn):
+    """GINConv: nn((1 + eps) * x_i + sum_{j->i} x_j).  call site: gconv.py:197,212."""
+    return nn((1.0 + eps) * x + segment_sum(x[src], dst, x.shape[0]))
+
+
+def rgcn_conv(x, src, dst, etype, weight, root, bias, aggr="mean"):
+    """RGCNConv (no bases/blocks): sum_r aggr_{j in N_r(i)} x_j @ W_r + x_i @ root + bias.
+    call sites: rgconv.py:17-18,40-41 (mean) and :96,121 (add)."""
+    N = x.shape[0]
+    R = weight.shape[0]
+    out = th.zeros(N, weight.shape[2], dtype=x.dtype)
+    for r in range(R):
+        m = etype == r
+        h = segment_sum(x[src[m]], dst[m], N)
+        if aggr == "mean":
+            cnt = th.bincount(dst[m], minlength=N).clamp(min=1).to(x.dtype).view(-1, 1)
+            h = h / cnt
+        out = out + h @ weight[r]
+    out = out + x @ root
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def global_pool(x, batch, num_graphs, kind="add"):
+    """global_add_pool / global_mean_pool / global_max_pool.  call sites gconv.py:53,95,148,210,213."""
+    if kind == "add":
+        return segment_sum(x, batch, num_graphs)
+    if kind == "mean":
+        cnt = th.bincount(batch, minlength=num_graphs).clamp(min=1).to(x.dtype).view(-1, 1)
+        return segment_sum(x, batch, num_graphs) / cnt
+    if kind == "max":
+        out = th.full((num_graphs, x.shape[1]), -math.inf, dtype=x.dtype)
+        out = out.scatter_reduce(0, batch.view(-1, 1).expand_as(x), x, reduce="amax", include_self=True)
+        return out.masked_fill(out == -math.inf, 0.0)
+    raise ValueError(kind)
+
+
+def xavier_uniform_bound(shape, act):
+    """Bound 'a' of the reference's custom Xavier-uniform.  reference: SI utils/init.py:52-75."""
+    shape = tuple(shape) if len(shape) >= 2 else tuple(shape) + (1,)
+    rf = 1
+    for s in shape[2:]:
+        rf *= s
+    fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    if act in ("none",):
+        gain = 1.0
+    elif act in ("relu", "relu6", "elu", "selu", "celu", "gelu"):
+        gain = math.sqrt(2.0)
+    elif act in ("leaky_relu", "prelu"):
+        gain = math.sqrt(2.0 / (1 + LEAKY_RELU_A ** 2))
+    elif act == "tanh":
+        gain = 5.0 / 3
+    else:  # sigmoid / softmax family
+        gain = 1.0
+    return 1.7320508075688772 * gain * math.sqrt(2.0 / float(fan_in + fan_out))

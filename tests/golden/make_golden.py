@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE'S OWN CODE.
+
+Runs only in the authoring container (needs /root/reference; the GPU box never runs this).
+The reference's Python is imported unmodified, with the absent third-party modules
+(igraph, dgl, numba, torch._six, torch_geometric, tensorboardX) replaced by the stand-ins in
+``_ref_standins.py``.  Outputs (committed, data only -- inputs and expected outputs):
+
+  gc_transforms.json   a-1 load_graph_data_from_TUDatadir(with_dummy) + a-2
+                       convert_conjugate_graph_forward  (tu_data_processing.py:125-338)
+                       incl. KAT-1 = the paper's figure/edge2vertex.png example
+  si_transforms.json   a-4 add_dummy_nodes_edges (SI train.py:404-474) + a-5
+                       convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
+  si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
+                       all gradients over the regulariser x act x self_loop x edge_norm grid
+
+usage: python tests/golden/make_golden.py
+"""
+import importlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch as th
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+import _ref_standins as S  # noqa: E402
+
+S.install()
+
+
+# ------------------------------------------------------------------------------- GC
+def _write_tu(d, name, A, gi, nl, el):
+    with open(os.path.join(d, name + "_A.txt"), "w") as f:
+        for a, b in A:
+            f.write("%d, %d\n" % (a, b))
+    with open(os.path.join(d, name + "_graph_indicator.txt"), "w") as f:
+        f.writelines("%d\n" % x for x in gi)
+    if nl is not None:
+        with open(os.path.join(d, name + "_node_labels.txt"), "w") as f:
+            f.writelines("%d\n" % x for x in nl)
+    if el is not None:
+        with open(os.path.join(d, name + "_edge_labels.txt"), "w") as f:
+            f.writelines("%d\n" % x for x in el)
+
+
+def _dump_ig(g):
+    out = {"vcount": g.vcount(), "edges": [list(e) for e in g.get_edgelist()]}
+    for k in g.vertex_attributes():
+        out["v_" + k] = g.vs[k]
+    for k in g.edge_attributes():
+        out["e_" + k] = g.es[k]
+    return out
+
+
+def _random_tu(rng, num_graphs, nl_min, el_mode, max_n=12):
+    """TU-shaped raw files: 1-based global node ids, graphs contiguous, multi-edges and isolated
+    vertices allowed, some graphs with zero edges (never the last one: the reference drops those)."""
+    A, gi, nl = [], [], []
+    base = 0
+    for g in range(num_graphs):
+        n = int(rng.integers(1, max_n + 1))
+        if g != num_graphs - 1 and rng.random() < 0.15:
+            m = 0
+        else:
+            m = int(rng.integers(1, 3 * n + 1))
+        for _ in range(m):
+            u, v = int(rng.integers(0, n)), int(rng.integers(0, n))
+            A.append((base + u + 1, base + v + 1))
+        gi.extend([g + 1] * n)
+        nl.extend(int(x) for x in rng.integers(nl_min, nl_min + 4, size=n))
+        base += n
+    if el_mode == "none":
+        el = None
+    else:
+        lo = {"zero": 0, "one": 1, "three": 3}[el_mode]
+        el = [int(x) for x in rng.integers(lo, lo + 3, size=len(A))]
+        if len(el) > 0:
+            el[0] = lo  # make sure the minimum is present (label shift rule :165-169)
+    if len(nl) > 0:
+        nl[0] = nl_min
+    return A, gi, nl, el
+
+
+def make_gc():
+    sys.path.insert(0, os.path.join(REF, "graph_classification", "data_processing"))
+    T = importlib.import_module("tu_data_processing")
+    cases = []
+    specs = [("KAT1_figure", None)]
+    specs += [("rand%d" % i, i) for i in range(4)]
+    for name, seed in specs:
+        if seed is None:
+            A, gi, nl, el = [(2, 1), (1, 3), (1, 4)], [1, 1, 1, 1], [1, 2, 3, 4], [1, 2, 3]
+        else:
+            rng = np.random.default_rng(100 + seed)
+            A, gi, nl, el = _random_tu(rng, 10, nl_min=[0, 1, 2, 0][seed],
+                                       el_mode=["zero", "one", "three", "none"][seed])
+        with tempfile.TemporaryDirectory() as d:
+            _write_tu(d, "X", A, gi, nl, el)
+            case = {"name": name, "A": [list(a) for a in A], "graph_indicator": gi,
+                    "node_labels": nl, "edge_labels": el}
+            for wd in (False, True):
+                graphs = T.load_graph_data_from_TUDatadir(d, with_dummy=wd)
+                conj = [T.convert_conjugate_graph_forward(g) for g in graphs]
+                key = "dummy" if wd else "plain"
+                case[key] = [_dump_ig(g) for g in graphs]
+                case[key + "_conj"] = [_dump_ig(g) for g in conj]
+        cases.append(case)
+    with open(os.path.join(HERE, "gc_transforms.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+    print("gc_transforms.json: %d cases" % len(cases))
+
+
+# ------------------------------------------------------------------------------- SI
+def _si_modules():
+    SI = os.path.join(REF, "subgraph_isomorphism")
+    sys.path.insert(0, SI)
+    if "models" not in sys.modules:
+        pkg = types.ModuleType("models")
+        pkg.__path__ = [os.path.join(SI, "models")]  # skip models/__init__ (pulls every rep net)
+        sys.modules["models"] = pkg
+    return SI
+
+
+def _dump_dgl(g):
+    out = {"num_nodes": g.number_of_nodes(), "u": g._u.tolist(), "v": g._v.tolist()}
+    for k, v in g.ndata.items():
+        out["n_" + k] = v.long().tolist()
+    for k, v in g.edata.items():
+        out["e_" + k] = v.long().tolist()
+    return out
+
+
+def _to_ig(d):
+    g = S.Graph(directed=True)
+    g.add_vertices(d["num_nodes"])
+    g.vs["id"] = d["n_id"]
+    g.vs["label"] = d["n_label"]
+    g.add_edges(list(zip(d["u"], d["v"])))
+    g.es["id"] = d["e_id"]
+    g.es["label"] = d["e_label"]
+    return g
+
+
+def make_si_transforms():
+    _si_modules()
+    T = importlib.import_module("train")
+    D = importlib.import_module("dataset")
+    ug = importlib.import_module("utils.graph")
+    rng = np.random.default_rng(7)
+
+    def rand_graph(n, m, nvl, nel):
+        g = S.FakeDGLGraph(rng.integers(0, n, size=m), rng.integers(0, n, size=m), n)
+        g.ndata["id"] = th.arange(n)
+        g.ndata["label"] = th.from_numpy(rng.integers(0, nvl, size=n))
+        g.edata["id"] = th.arange(m)
+        g.edata["label"] = th.from_numpy(rng.integers(0, nel, size=m))
+        return g
+
+    vocab = dict(max_npv=4, max_npvl=3, max_npe=8, max_npel=2, max_ngv=12, max_ngvl=4, max_nge=40, max_ngel=5)
+    ds = D.GraphAdjDataset()
+    items = []
+    for i in range(8):
+        pn = int(rng.integers(2, vocab["max_npv"] + 1))
+        gn = int(rng.integers(1, vocab["max_ngv"] + 1))
+        p = rand_graph(pn, int(rng.integers(0 if i == 3 else 1, vocab["max_npe"] + 1)), vocab["max_npvl"], vocab["max_npel"])
+        g = rand_graph(gn, int(rng.integers(0 if i == 5 else 1, vocab["max_nge"] + 1)), vocab["max_ngvl"], vocab["max_ngel"])
+        counts = int(rng.integers(0, 3))
+        sub = th.from_numpy(rng.integers(0, gn, size=(counts, pn)))
+        items.append({"id": "x%d" % i, "pattern": p, "graph": g, "counts": counts, "subisomorphisms": sub})
+    ds.data = items
+    before = [{"pattern": _dump_dgl(x["pattern"]), "graph": _dump_dgl(x["graph"]),
+               "counts": x["counts"], "subisomorphisms": x["subisomorphisms"].tolist()} for x in ds.data]
+    T.add_dummy_nodes_edges(ds, **vocab)
+    after = [{"pattern": _dump_dgl(x["pattern"]), "graph": _dump_dgl(x["graph"]),
+              "counts": x["counts"], "subisomorphisms": x["subisomorphisms"].tolist()} for x in ds.data]
+    conj = []
+    for x in after:
+        row = {}
+        for k in ("pattern", "graph"):
+            row[k] = _dump_ig(ug.convert_conjugate_graph(_to_ig(x[k])))
+        conj.append(row)
+    # conj of the un-augmented graphs too (unique edge ids; exercises the no-merge path)
+    conj_plain = []
+    for x in before:
+        row = {}
+        for k in ("pattern", "graph"):
+            row[k] = _dump_ig(ug.convert_conjugate_graph(_to_ig(x[k])))
+        conj_plain.append(row)
+    # KAT-2
+    g = S.Graph(directed=True)
+    g.add_vertices(5)
+    g.vs["id"] = [0, 1, 2, 3, 10]
+    g.vs["label"] = [1, 2, 3, 4, 5]
+    g.add_edges([(1, 0), (0, 2), (0, 3), (0, 4), (1, 4), (2, 4), (3, 4), (4, 0), (4, 1), (4, 2), (4, 3)])
+    g.es["id"] = [0, 1, 2, 20, 20, 20, 20, 21, 21, 21, 21]
+    g.es["label"] = [1, 2, 3, 4, 4, 4, 4, 5, 5, 5, 5]
+    kat2 = {"in": _dump_ig(g), "out": _dump_ig(ug.convert_conjugate_graph(g))}
+    with open(os.path.join(HERE, "si_transforms.json"), "w") as f:
+        json.dump({"vocab": vocab, "before": before, "after": after, "conj": conj,
+                   "conj_plain": conj_plain, "kat2": kat2}, f, separators=(",", ":"))
+    print("si_transforms.json: %d items" % len(items))
+
+
+def make_si_layers():
+    _si_modules()
+    rgin = importlib.import_module("models.rgin")
+    rgcn = importlib.import_module("models.rgcn")
+    out = {}
+    meta = []
+    rng = np.random.default_rng(11)
+
+    def graph(N, E, R):
+        u = rng.integers(0, N, size=E)
+        v = rng.integers(0, N, size=E)
+        v[: E // 8] = 0            # one high in-degree vertex (dummy-like skew)
+        t = rng.integers(0, R, size=E)
+        return u.astype(np.int64), v.astype(np.int64), t.astype(np.int64)
+
+    def run(tag, layer_cls, kw, N, E, H_in, seed):
+        R = kw["num_rels"]
+        th.manual_seed(seed)
+        layer = layer_cls(H_in, kw.pop("hidden_dim"), **kw)
+        u, v, t = graph(N, E, R)
+        x = th.from_numpy(rng.standard_normal((N, H_in)).astype(np.float32)).requires_grad_(True)
+        coef = th.from_numpy(rng.standard_normal((N, layer.hidden_dim)).astype(np.float32))
+        g = S.FakeDGLGraph(u, v, N)
+        layer.train()
+        o, _ = layer(g, x, th.from_numpy(t))
+        (o * coef).sum().backward()
+        out[tag + "/u"], out[tag + "/v"], out[tag + "/t"] = u, v, t
+        out[tag + "/x"], out[tag + "/coef"] = x.detach().numpy(), coef.numpy()
+        out[tag + "/out"] = o.detach().numpy()
+        out[tag + "/grad_x"] = x.grad.numpy()
+        for k, p in layer.named_parameters():
+            out[tag + "/param/" + k] = p.detach().numpy()
+            out[tag + "/grad/" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+
+    cid = 0
+    for reg, nb, R in (("none", -1, 3), ("basis", -1, 6), ("basis", 2, 6), ("bdd", 4, 6)):
+        for act in ("relu", "leaky_relu", "tanh"):
+            for self_loop in (True, False):
+                for nmlp in (2, 0):
+                    if not (act == "relu" or (self_loop and nmlp == 2)):
+                        continue  # keep the grid small: full grid only for relu
+                    tag = "rgin%02d" % cid
+                    kw = dict(hidden_dim=16, num_rels=R, regularizer=reg, num_bases=nb, num_mlp_layers=nmlp,
+                              self_loop=self_loop, act_func=act)
+                    meta.append(dict(tag=tag, kind="rgin", input_dim=16, seed=1000 + cid, N=24, E=96, **kw))
+                    run(tag, rgin.RGINLayer, dict(kw), 24, 96, 16, 1000 + cid)
+                    cid += 1
+    for reg, nb, R in (("basis", -1, 4), ("basis", 2, 5), ("bdd", 2, 4)):
+        for norm in ("none", "in", "both"):
+            for self_loop in (True, False):
+                tag = "rgcn%02d" % cid
+                kw = dict(hidden_dim=16, num_rels=R, regularizer=reg, num_bases=nb, edge_norm=norm,
+                          self_loop=self_loop, act_func="leaky_relu" if norm == "both" else "relu")
+                meta.append(dict(tag=tag, kind="rgcn", input_dim=16, seed=1000 + cid, N=24, E=96, **kw))
+                run(tag, rgcn.RGCNLayer, dict(kw), 24, 96, 16, 1000 + cid)
+                cid += 1
+    # a larger, config-3-shaped sample (R=8, H=64) for the fp32 tolerance check on the GPU
+    for reg, nb in (("basis", -1), ("bdd", 4)):
+        tag = "rgin%02d" % cid
+        kw = dict(hidden_dim=64, num_rels=8, regularizer=reg, num_bases=nb, num_mlp_layers=2,
+                  self_loop=True, act_func="relu")
+        meta.append(dict(tag=tag, kind="rgin", input_dim=64, seed=1000 + cid, N=500, E=2000, **kw))
+        run(tag, rgin.RGINLayer, dict(kw), 500, 2000, 64, 1000 + cid)
+        cid += 1
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "si_layers.npz"), **out)
+    print("si_layers.npz: %d cases" % len(meta))
+
+
+if __name__ == "__main__":
+    make_gc()
+    make_si_transforms()
+    make_si_layers()

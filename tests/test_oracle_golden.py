@@ -1,0 +1,228 @@
+"""Pin the oracle (oracle/*.py) against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import layers as OL
+from oracle import transforms as OT
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _batch_from_dumps(dumps, vkeys=(), ekeys=()):
+    """Concatenate per-graph igraph dumps into the batched layout the oracle uses."""
+    node_ptr, edge_ptr, src, dst = [0], [0], [], []
+    vattr = {k: [] for k in vkeys}
+    eattr = {k: [] for k in ekeys}
+    for d in dumps:
+        base = node_ptr[-1]
+        for u, v in d["edges"]:
+            src.append(base + u)
+            dst.append(base + v)
+        node_ptr.append(base + d["vcount"])
+        edge_ptr.append(len(src))
+        for k in vkeys:
+            vattr[k].extend(d.get("v_" + k, []))
+        for k in ekeys:
+            eattr[k].extend(d.get("e_" + k, []))
+    return dict(node_ptr=np.array(node_ptr), edge_ptr=np.array(edge_ptr), src=np.array(src, dtype=np.int64),
+                dst=np.array(dst, dtype=np.int64), v=vattr, e=eattr)
+
+
+def test_gc_dummy_and_conjugate_match_reference(golden_dir):
+    cases = _load(golden_dir, "gc_transforms.json")
+    assert cases[0]["name"] == "KAT1_figure"
+    for case in cases:
+        raw = OT.tu_raw_to_batch(case["A"], case["graph_indicator"], case["node_labels"], case["edge_labels"])
+        # plain graphs (with_dummy=False)
+        ref = _batch_from_dumps(case["plain"], ("LABEL", "ID"), ("LABEL", "ID"))
+        for k in ("node_ptr", "edge_ptr", "src", "dst"):
+            np.testing.assert_array_equal(raw[k], ref[k], err_msg=case["name"] + " plain " + k)
+        np.testing.assert_array_equal(raw["node_label"], ref["v"]["LABEL"])
+        np.testing.assert_array_equal(raw["edge_label"], ref["e"]["LABEL"])
+        # a-1 dummy augmentation
+        aug = OT.dummy_augment_gc(raw["node_ptr"], raw["edge_ptr"], raw["src"], raw["dst"],
+                                  raw["node_label"], raw["edge_label"])
+        ref = _batch_from_dumps(case["dummy"], ("LABEL", "ID", "IS_DUMMY"), ("LABEL", "ID", "IS_DUMMY"))
+        for k in ("node_ptr", "edge_ptr", "src", "dst"):
+            np.testing.assert_array_equal(aug[k], ref[k], err_msg=case["name"] + " dummy " + k)
+        np.testing.assert_array_equal(aug["node_label"], ref["v"]["LABEL"])
+        np.testing.assert_array_equal(aug["is_dummy_node"], ref["v"]["IS_DUMMY"])
+        np.testing.assert_array_equal(aug["node_id"], ref["v"]["ID"])
+        np.testing.assert_array_equal(aug["edge_label"], ref["e"]["LABEL"])
+        np.testing.assert_array_equal(aug["is_dummy_edge"], ref["e"]["IS_DUMMY"])
+        np.testing.assert_array_equal(aug["edge_id"], ref["e"]["ID"])
+        # a-2 conjugate of the plain graphs ("line") and of the dummy graphs ("gc")
+        for tag, b, mode, dflag in (("plain", raw, "line", None), ("dummy", aug, "gc", aug["is_dummy_edge"])):
+            cj = OT.conjugate(b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], b["node_label"],
+                              is_dummy_edge=dflag, mode=mode)
+            ref = _batch_from_dumps(case[tag + "_conj"], ("LABEL", "ID", "IS_DUMMY"), ("LABEL", "ID", "IS_DUMMY"))
+            msg = case["name"] + " conj " + tag
+            np.testing.assert_array_equal(cj["cnode_ptr"], ref["node_ptr"], err_msg=msg)
+            np.testing.assert_array_equal(cj["cedge_ptr"], ref["edge_ptr"], err_msg=msg)
+            np.testing.assert_array_equal(cj["csrc"], ref["src"], err_msg=msg)
+            np.testing.assert_array_equal(cj["cdst"], ref["dst"], err_msg=msg)
+            # conj-vertex attrs = attrs of the representative edge; conj-edge attrs = attrs of the shared vertex
+            np.testing.assert_array_equal(b["edge_label"][cj["rep_edge"]], ref["v"]["LABEL"], err_msg=msg)
+            local_eid = np.arange(len(b["src"])) - np.repeat(b["edge_ptr"][:-1], np.diff(b["edge_ptr"]))
+            np.testing.assert_array_equal(local_eid[cj["rep_edge"]], ref["v"]["ID"], err_msg=msg)
+            np.testing.assert_array_equal(b["node_label"][cj["shared_node"]], ref["e"]["LABEL"], err_msg=msg)
+            local_nid = np.arange(b["node_ptr"][-1]) - np.repeat(b["node_ptr"][:-1], np.diff(b["node_ptr"]))
+            np.testing.assert_array_equal(local_nid[cj["shared_node"]], ref["e"]["ID"], err_msg=msg)
+            if tag == "dummy":
+                np.testing.assert_array_equal(aug["is_dummy_edge"][cj["rep_edge"]], ref["v"]["IS_DUMMY"], err_msg=msg)
+                np.testing.assert_array_equal(aug["is_dummy_node"][cj["shared_node"]], ref["e"]["IS_DUMMY"], err_msg=msg)
+
+
+def test_kat1_figure_literal(golden_dir):
+    """The paper's figure, spelled out."""
+    raw = OT.tu_raw_to_batch([(2, 1), (1, 3), (1, 4)], [1, 1, 1, 1], [1, 2, 3, 4], [1, 2, 3])
+    aug = OT.dummy_augment_gc(raw["node_ptr"], raw["edge_ptr"], raw["src"], raw["dst"], raw["node_label"], raw["edge_label"])
+    assert list(zip(aug["src"], aug["dst"])) == [(1, 0), (0, 2), (0, 3), (4, 0), (0, 4), (4, 1), (1, 4), (4, 2), (2, 4), (4, 3), (3, 4)]
+    cj = OT.conjugate(aug["node_ptr"], aug["edge_ptr"], aug["src"], aug["dst"], aug["node_label"],
+                      is_dummy_edge=aug["is_dummy_edge"], mode="gc")
+    assert cj["cnode_ptr"].tolist() == [0, 4]
+    assert list(zip(cj["csrc"], cj["cdst"])) == [(3, 0), (0, 1), (3, 1), (0, 2), (3, 2), (0, 3), (1, 3), (2, 3)]
+    assert aug["node_label"][cj["shared_node"]].tolist() == [2, 1, 1, 1, 1, 1, 3, 4]
+    assert aug["edge_label"][cj["rep_edge"]].tolist() == [1, 2, 3, 0]
+
+
+def _dgl_batch(items, key):
+    node_ptr, edge_ptr, src, dst = [0], [0], [], []
+    nd = {}
+    ed = {}
+    for x in items:
+        d = x[key]
+        base = node_ptr[-1]
+        src.extend(base + u for u in d["u"])
+        dst.extend(base + v for v in d["v"])
+        node_ptr.append(base + d["num_nodes"])
+        edge_ptr.append(len(src))
+        for k, v in d.items():
+            if k.startswith("n_"):
+                nd.setdefault(k[2:], []).extend(v)
+            elif k.startswith("e_"):
+                ed.setdefault(k[2:], []).extend(v)
+    return dict(node_ptr=np.array(node_ptr), edge_ptr=np.array(edge_ptr), src=np.array(src, dtype=np.int64),
+                dst=np.array(dst, dtype=np.int64), n=nd, e=ed)
+
+
+def test_si_dummy_and_conjugate_match_reference(golden_dir):
+    g = _load(golden_dir, "si_transforms.json")
+    vocab = g["vocab"]
+    for key, mv, mvl, me, mel in (("graph", "max_ngv", "max_ngvl", "max_nge", "max_ngel"),
+                                  ("pattern", "max_npv", "max_npvl", "max_npe", "max_npel")):
+        b = _dgl_batch(g["before"], key)
+        a = _dgl_batch(g["after"], key)
+        aug = OT.dummy_augment_si(b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], b["n"]["id"], b["n"]["label"],
+                                  b["e"].get("id", []), b["e"].get("label", []),
+                                  vocab[mv], vocab[mvl], vocab[me], vocab[mel])
+        for k in ("node_ptr", "edge_ptr", "src", "dst"):
+            np.testing.assert_array_equal(aug[k], a[k], err_msg=key + " " + k)
+        np.testing.assert_array_equal(aug["node_id"], a["n"]["id"])
+        np.testing.assert_array_equal(aug["node_label"], a["n"]["label"])
+        np.testing.assert_array_equal(aug["is_dummy_node"], a["n"]["is_dummy"])
+        np.testing.assert_array_equal(aug["edge_id"], a["e"]["id"])
+        np.testing.assert_array_equal(aug["edge_label"], a["e"]["label"])
+        np.testing.assert_array_equal(aug["is_dummy_edge"], a["e"]["is_dummy"])
+        np.testing.assert_array_equal(aug["is_reversed"], a["e"]["is_reversed"])
+        # a-5 conjugate (igraph branch) of augmented and plain graphs
+        for tag, bb, eid, nl in (("conj", aug, aug["edge_id"], aug["node_label"]),
+                                 ("conj_plain", b, np.array(b["e"].get("id", []), dtype=np.int64),
+                                  np.array(b["n"]["label"]))):
+            cj = OT.conjugate(bb["node_ptr"], bb["edge_ptr"], bb["src"], bb["dst"], nl, edge_id=eid, mode="si")
+            ref = _batch_from_dumps([row[key] for row in g[tag]], ("id", "label"), ("id", "label"))
+            msg = "%s %s" % (key, tag)
+            np.testing.assert_array_equal(cj["cnode_ptr"], ref["node_ptr"], err_msg=msg)
+            np.testing.assert_array_equal(cj["cedge_ptr"], ref["edge_ptr"], err_msg=msg)
+            np.testing.assert_array_equal(cj["csrc"], ref["src"], err_msg=msg)
+            np.testing.assert_array_equal(cj["cdst"], ref["dst"], err_msg=msg)
+            el = aug["edge_label"] if tag == "conj" else np.array(b["e"].get("label", []), dtype=np.int64)
+            nid = aug["node_id"] if tag == "conj" else np.array(b["n"]["id"])
+            np.testing.assert_array_equal(eid[cj["rep_edge"]], ref["v"]["id"], err_msg=msg)
+            np.testing.assert_array_equal(el[cj["rep_edge"]], ref["v"]["label"], err_msg=msg)
+            np.testing.assert_array_equal(nid[cj["shared_node"]], ref["e"]["id"], err_msg=msg)
+            np.testing.assert_array_equal(nl[cj["shared_node"]], ref["e"]["label"], err_msg=msg)
+
+
+def test_kat2_literal(golden_dir):
+    g = _load(golden_dir, "si_transforms.json")["kat2"]
+    i, o = g["in"], g["out"]
+    u = np.array([e[0] for e in i["edges"]])
+    v = np.array([e[1] for e in i["edges"]])
+    cj = OT.conjugate([0, 5], [0, len(u)], u, v, i["v_label"], edge_id=i["e_id"], mode="si")
+    assert cj["cnode_ptr"].tolist() == [0, 5]
+    assert [list(x) for x in zip(cj["csrc"].tolist(), cj["cdst"].tolist())] == o["edges"]
+    assert len(o["edges"]) == 13
+    assert np.array(i["e_id"])[cj["rep_edge"]].tolist() == [0, 1, 2, 20, 21]
+    assert np.array(i["v_label"])[cj["shared_node"]].tolist() == o["e_label"]
+
+
+def _layer_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "si_layers.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return z, meta
+
+
+def test_si_layers_match_reference_outputs_and_grads(golden_dir):
+    z, meta = _layer_cases(golden_dir)
+    assert len(meta) >= 40
+    for m in meta:
+        tag = m["tag"]
+        p = {}
+        for k in z.files:
+            if k.startswith(tag + "/param/"):
+                p[k[len(tag) + 7:]] = th.from_numpy(z[k]).clone().requires_grad_(True)
+        x = th.from_numpy(z[tag + "/x"]).clone().requires_grad_(True)
+        u, v, t = (th.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
+        if m["kind"] == "rgin":
+            out = OL.rgin_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"],
+                                num_bases=m["num_bases"], num_mlp_layers=m["num_mlp_layers"], act=m["act_func"])
+        else:
+            out = OL.rgcn_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"],
+                                num_bases=m["num_bases"], edge_norm=m["edge_norm"], act=m["act_func"])
+        (out * th.from_numpy(z[tag + "/coef"])).sum().backward()
+        # same ops in the same order as the reference -> agreement to fp32 rounding
+        th.testing.assert_close(out.detach(), th.from_numpy(z[tag + "/out"]), rtol=1e-5, atol=1e-5, msg=tag)
+        th.testing.assert_close(x.grad, th.from_numpy(z[tag + "/grad_x"]), rtol=1e-5, atol=1e-5, msg=tag)
+        for k, t_ in p.items():
+            ref = z[tag + "/grad/" + k]
+            if ref.size == 0:
+                continue
+            th.testing.assert_close(t_.grad, th.from_numpy(ref), rtol=1e-4, atol=1e-5, msg=tag + " " + k)
+
+
+def test_agg_first_form_equals_reference_formulation(golden_dir):
+    """aggregate-then-transform == the reference's per-edge transform (basis, full)."""
+    z, meta = _layer_cases(golden_dir)
+    done = 0
+    for m in meta:
+        if m["kind"] != "rgin" or m["regularizer"] != "basis" or m["num_bases"] != -1 or not m["self_loop"]:
+            continue
+        tag = m["tag"]
+        p = {k[len(tag) + 7:]: th.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}
+        x = th.from_numpy(z[tag + "/x"])
+        u, v, t = (th.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
+        out = OL.rgin_layer_agg_first(x, u, v, t, p, m["num_rels"], act=m["act_func"], num_mlp_layers=m["num_mlp_layers"])
+        th.testing.assert_close(out, th.from_numpy(z[tag + "/out"]), rtol=1e-4, atol=1e-5, msg=tag)
+        done += 1
+    assert done >= 3
+
+
+def test_init_bound_matches_reference_weights(golden_dir):
+    """Custom Xavier-uniform bound (SI utils/init.py:52-75): the golden initial weights must lie inside
+    (-a, a) and fill most of it."""
+    z, meta = _layer_cases(golden_dir)
+    for m in meta:
+        w = z[m["tag"] + "/param/weight"]
+        a = OL.xavier_uniform_bound(w.shape, m["act_func"])
+        assert np.abs(w).max() <= a * (1 + 1e-6), m["tag"]
+        if w.size >= 512:
+            assert np.abs(w).max() >= 0.95 * a, m["tag"]
