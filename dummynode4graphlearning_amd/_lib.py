@@ -1,0 +1,117 @@
+"""ctypes binding of libdn_hip.so (the C-ABI HIP library, include/dn_hip.h).
+
+PyTorch is imported FIRST so that the library's `libamdhip64.so.7` dependency resolves to the HIP
+runtime PyTorch already loaded (one runtime per process: device pointers and streams are only
+meaningful inside the runtime that created them; `dn_runtime_probe` double-checks at first use).
+There is no CPU fallback: if the library is missing or a tensor is not on a GPU, calls raise.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdn_hip.so")
+
+c_i32, c_i64, c_f32, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+P = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/dn_hip.h one to one
+_SIGS = {
+    "dn_version": (ctypes.c_int, []),
+    "dn_last_error": (ctypes.c_char_p, []),
+    "dn_runtime_probe": (ctypes.c_int, [P]),
+    "dn_gather_segsum_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
+    "dn_gather_segsum_bf16": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
+    "dn_segment_sum_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
+    "dn_segment_sum_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
+    "dn_segment_mean_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
+    "dn_segment_mean_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
+    "dn_segment_max_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P, P]),
+    "dn_segment_max_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P, P]),
+    "dn_segment_max_bwd_f32": (ctypes.c_int, [P, P, c_i32, P, c_i64, P, P]),
+    "dn_segment_max_bwd_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i64, P, P]),
+    "dn_csr_build_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dn_csr_build_i32": (ctypes.c_int, [P, c_i64, c_i64, P, P, P, c_sz, P]),
+    "dn_dummy_augment_gc_i32": (ctypes.c_int, [c_i64, c_i64, c_i64] + [P] * 16 + [P]),
+    "dn_dummy_augment_si_i32": (ctypes.c_int, [c_i64, c_i64, c_i64] + [P] * 9 + [c_i32] * 4 + [P] * 11 + [P]),
+    "dn_conjugate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    "dn_conjugate_count_i32": (ctypes.c_int, [c_i64, c_i64, P, P, ctypes.POINTER(c_i64), P, c_sz, P]),
+    "dn_conjugate_build_i32": (ctypes.c_int, [c_i32, c_i64, c_i64, c_i64, c_i64] + [P] * 7 + [P] * 6 +
+                               [ctypes.POINTER(c_i64), P, c_sz, P]),
+    "dn_rel_index_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "dn_rel_index_build_i32": (ctypes.c_int, [c_i64, c_i64, c_i64] + [P] * 3 + [P] * 10 +
+                               [ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), P, c_sz, P]),
+    "dn_edge_norm_f32": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i64] + [P] * 7 + [P]),
+    "dn_degrees_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P]),
+}
+
+_lib = None
+_probed = False
+
+
+class DnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DnHipError(
+                "libdn_hip.so not found at %s -- build it with `python -m dummynode4graphlearning_amd.csrc.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS.keys())
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dn_last_error()
+        raise DnHipError("%s failed (rc=%d): %s" % (what or "dn_hip call", rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    """The product path runs on the GPU only; fail loudly otherwise."""
+    global _probed
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DnHipError("dummynode4graphlearning_amd kernels need GPU tensors (got device %s); "
+                             "there is no CPU fallback" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise DnHipError("tensors on different devices: %s vs %s" % (t.device, dev))
+        if not t.is_contiguous():
+            raise DnHipError("non-contiguous tensor passed to a dn_hip kernel")
+    if not _probed and dev is not None:
+        for t in tensors:
+            if t is not None and t.numel() > 0:
+                check(lib().dn_runtime_probe(ptr(t)), "dn_runtime_probe")
+                _probed = True
+                break
+    return dev

@@ -1,0 +1,46 @@
+// Shared helpers for the dn_hip C-ABI library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define DN_OK 0
+#define DN_ERR_ARG (-1)
+#define DN_ERR_HIP (-2)
+#define DN_ERR_WORKSPACE (-3)
+#define DN_ERR_UNSUPPORTED (-4)
+
+// thread-local last-error string (dn_error.cpp)
+void dn_set_error(const char* fmt, ...);
+
+#define DN_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t dn_e_ = (expr);                                                      \
+        if (dn_e_ != hipSuccess) {                                                      \
+            dn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                  \
+                         hipGetErrorString(dn_e_));                                     \
+            return DN_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define DN_REQUIRE(cond, ...)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            dn_set_error(__VA_ARGS__);                                                  \
+            return DN_ERR_ARG;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define DN_CHECK_LAUNCH() DN_CHECK_HIP(hipGetLastError())
+
+static inline int64_t dn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t dn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// MI355X: 8 XCDs, workgroups are dealt round-robin over them (blocks b and b+8 share an XCD's L2).
+// Map the hardware block id to a logical chunk id so that the blocks of one XCD walk a CONTIGUOUS
+// range of chunks (neighbouring graphs -> same L2).  Speed only, never correctness.
+#define DN_NUM_XCD 8
+__device__ __forceinline__ int64_t dn_xcd_chunk(int64_t b, int64_t nblocks) {
+    const int64_t per = (nblocks + DN_NUM_XCD - 1) / DN_NUM_XCD;
+    return (b % DN_NUM_XCD) * per + b / DN_NUM_XCD;
+}

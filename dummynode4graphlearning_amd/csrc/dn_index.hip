@@ -1,0 +1,783 @@
+// One-shot device-side index builds (gfx950): CSR grouping, dummy-node augmentation, and the
+// edge-to-vertex ("conjugate") transform L_Phi.  Integer work only; results are bit-exact with the
+// reference's nested Python loops, including OUTPUT ORDER, because every "first occurrence" rule of the
+// reference is restated as a STABLE radix sort + head flag + order-preserving compaction.
+// Device-wide sort / scan primitives come from rocPRIM (AMD's own, compiled here for gfx950).
+#include <cstring>
+#include <cstdlib>
+
+#include "dn_common.h"
+#include "../../include/dn_hip.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int kBlock = 256;
+typedef unsigned long long u64;
+
+struct Arena {
+    char* base;
+    size_t off;
+    size_t cap;
+    explicit Arena(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+    template <typename T> T* take(int64_t n) {
+        off = dn_align_up(off, 256);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (size_t)(n > 0 ? n : 1) * sizeof(T);
+        return r;
+    }
+    void* take_bytes(size_t n) {
+        off = dn_align_up(off, 256);
+        void* r = base ? base + off : nullptr;
+        off += n > 0 ? n : 1;
+        return r;
+    }
+    bool ok() const { return base == nullptr || off <= cap; }
+};
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)(n > 0 ? dn_cdiv(n, kBlock) : 1); }
+static inline int bits_for(u64 max_value) {
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+// ----- rocPRIM wrappers: size query (temp == nullptr) or run --------------------------------------
+template <typename K>
+hipError_t sort_pairs(void* temp, size_t& bytes, const K* kin, K* kout, const int32_t* vin, int32_t* vout, int64_t n,
+                      int end_bit, hipStream_t st) {
+    return rocprim::radix_sort_pairs(temp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, st);
+}
+hipError_t excl_scan(void* temp, size_t& bytes, const int32_t* in, int32_t* out, int64_t n, hipStream_t st) {
+    return rocprim::exclusive_scan(temp, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st);
+}
+
+// ----- small kernels ------------------------------------------------------------------------------
+__global__ void iota_kernel(int32_t* v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+// ptr[k] = first sorted position whose key >= k  (fills runs of empty keys too)
+__global__ void ptr_from_sorted_kernel(const int32_t* __restrict__ skey, int64_t M, int64_t num_keys,
+                                       int32_t* __restrict__ ptr) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > M) return;
+    const int64_t kprev = (i == 0) ? -1 : skey[i - 1];
+    const int64_t kcur = (i == M) ? num_keys : skey[i];
+    for (int64_t k = kprev + 1; k <= kcur; ++k) ptr[k] = (int32_t)i;
+}
+
+// largest g with p[g] <= x, p non-decreasing, p[0] <= x < p[G]
+template <typename F> __device__ __forceinline__ int64_t find_graph(F p, int64_t G, int64_t x) {
+    int64_t lo = 0, hi = G;  // invariant p(lo) <= x < p(hi)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (p(mid) <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void degrees_kernel(int64_t E, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                               int32_t* in_deg, int32_t* out_deg) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    if (in_deg) atomicAdd(&in_deg[dst[e]], 1);
+    if (out_deg) atomicAdd(&out_deg[src[e]], 1);
+}
+
+__global__ void node_norm_kernel(int32_t self_loop, int64_t N, const int32_t* __restrict__ in_deg,
+                                 const int32_t* __restrict__ out_deg, float* in_norm, float* out_norm) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= N) return;
+    if (in_norm) {
+        const int d = in_deg[v];
+        in_norm[v] = self_loop ? 1.0f / ((float)d + 1.0f) : (d == 0 ? 0.0f : 1.0f / (float)d);
+    }
+    if (out_norm) {
+        const int d = out_deg[v];
+        out_norm[v] = self_loop ? 1.0f / ((float)d + 1.0f) : (d == 0 ? 0.0f : 1.0f / (float)d);
+    }
+}
+
+__global__ void edge_norm_kernel(int32_t mode, int64_t E, const int32_t* __restrict__ src,
+                                 const int32_t* __restrict__ dst, const float* __restrict__ in_norm,
+                                 const float* __restrict__ out_norm, float* __restrict__ edge_norm) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    if (mode == 1) edge_norm[e] = in_norm[dst[e]];
+    else edge_norm[e] = __fsqrt_rn(out_norm[src[e]] * in_norm[dst[e]]);
+}
+
+// ----- dummy augmentation -------------------------------------------------------------------------
+__global__ void dummy_ptr_kernel(int64_t G, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
+                                 int32_t* out_node_ptr, int32_t* out_edge_ptr) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g > G) return;
+    out_node_ptr[g] = node_ptr[g] + (int32_t)g;
+    out_edge_ptr[g] = edge_ptr[g] + 2 * node_ptr[g];
+}
+
+// si == 0: GC layout (labels 0, ids = local index); si == 1: SI layout (ids/labels from the vocabulary)
+__global__ void dummy_nodes_kernel(int32_t si, int64_t G, int64_t Nout, const int32_t* __restrict__ node_ptr,
+                                   const int32_t* __restrict__ node_id, const int32_t* __restrict__ node_label,
+                                   int32_t max_nv, int32_t max_nvl, int32_t* out_node_id, int32_t* out_node_label,
+                                   uint8_t* out_is_dummy) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= Nout) return;
+    const int64_t g = find_graph([&](int64_t k) { return (int64_t)node_ptr[k] + k; }, G, i);
+    const int64_t local = i - (node_ptr[g] + g);
+    const int64_t n = node_ptr[g + 1] - node_ptr[g];
+    const bool dummy = local >= n;
+    const int64_t o = node_ptr[g] + local;
+    out_is_dummy[i] = dummy ? 1 : 0;
+    if (si) {
+        out_node_id[i] = dummy ? max_nv : node_id[o];
+        out_node_label[i] = dummy ? max_nvl : node_label[o];
+    } else {
+        out_node_id[i] = (int32_t)local;
+        out_node_label[i] = dummy ? 0 : node_label[o];
+    }
+}
+
+__global__ void dummy_edges_kernel(int32_t si, int64_t G, int64_t Eout, const int32_t* __restrict__ node_ptr,
+                                   const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ src,
+                                   const int32_t* __restrict__ dst, const int32_t* __restrict__ edge_id,
+                                   const int32_t* __restrict__ edge_label, const uint8_t* __restrict__ in_rev,
+                                   int32_t max_ne, int32_t max_nel, int32_t* out_src, int32_t* out_dst,
+                                   int32_t* out_edge_id, int32_t* out_edge_label, uint8_t* out_is_dummy,
+                                   uint8_t* out_rev) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= Eout) return;
+    const int64_t g = find_graph([&](int64_t k) { return (int64_t)edge_ptr[k] + 2 * (int64_t)node_ptr[k]; }, G, j);
+    const int64_t local = j - ((int64_t)edge_ptr[g] + 2 * (int64_t)node_ptr[g]);
+    const int64_t m = edge_ptr[g + 1] - edge_ptr[g];
+    const int64_t n = node_ptr[g + 1] - node_ptr[g];
+    const int64_t base = node_ptr[g] + g;  // first output node of graph g
+    if (local < m) {
+        const int64_t e = edge_ptr[g] + local;
+        out_src[j] = src[e] + (int32_t)g;
+        out_dst[j] = dst[e] + (int32_t)g;
+        out_edge_label[j] = edge_label[e];
+        out_edge_id[j] = si ? edge_id[e] : (int32_t)local;
+        out_is_dummy[j] = 0;
+        if (out_rev) out_rev[j] = in_rev ? in_rev[e] : 0;
+        return;
+    }
+    const int64_t t = local - m;
+    out_is_dummy[j] = 1;
+    if (si) {
+        // blocked: all (u -> dummy), then all (dummy -> u)
+        const bool second = t >= n;
+        const int64_t u = second ? t - n : t;
+        out_src[j] = (int32_t)(second ? base + n : base + u);
+        out_dst[j] = (int32_t)(second ? base + u : base + n);
+        out_edge_id[j] = max_ne + (second ? 1 : 0);
+        out_edge_label[j] = max_nel + (second ? 1 : 0);
+        if (out_rev) out_rev[j] = second ? 1 : 0;
+    } else {
+        // interleaved: (n, v), (v, n)
+        const int64_t v = t >> 1;
+        const bool second = (t & 1) != 0;
+        out_src[j] = (int32_t)(second ? base + v : base + n);
+        out_dst[j] = (int32_t)(second ? base + n : base + v);
+        out_edge_id[j] = (int32_t)local;
+        out_edge_label[j] = 0;
+    }
+}
+
+// ----- conjugate ----------------------------------------------------------------------------------
+__global__ void edge_graph_kernel(int64_t G, int64_t E, const int32_t* __restrict__ edge_ptr, int32_t* egraph) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    egraph[e] = (int32_t)find_graph([&](int64_t k) { return (int64_t)edge_ptr[k]; }, G, e);
+}
+
+__global__ void first_dummy_kernel(int64_t E, const int32_t* __restrict__ egraph, const int32_t* __restrict__ edge_ptr,
+                                   const uint8_t* __restrict__ is_dummy, int32_t* first_dummy) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E || !is_dummy[e]) return;
+    const int g = egraph[e];
+    atomicMin(&first_dummy[g], (int32_t)(e - edge_ptr[g]));
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// key = (graph << 32) | conj id of the edge inside its graph
+__global__ void vertex_key_kernel(int32_t mode, int64_t E, const int32_t* __restrict__ egraph,
+                                  const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ edge_id,
+                                  const uint8_t* __restrict__ is_dummy, const int32_t* __restrict__ first_dummy,
+                                  u64* key) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    const int g = egraph[e];
+    int32_t cid;
+    if (mode == DN_CONJ_SI) cid = edge_id[e];
+    else if (mode == DN_CONJ_GC && is_dummy[e]) cid = first_dummy[g];
+    else cid = edge_id ? edge_id[e] : (int32_t)(e - edge_ptr[g]);
+    key[e] = ((u64)(uint32_t)g << 32) | (u64)(uint32_t)cid;
+}
+
+__global__ void head_flag_u64_kernel(const u64* __restrict__ skey, int64_t n, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+}
+
+// after exclusive scan of head flags: vertex index of sorted position p = scan[p] + flag[p] - 1
+__global__ void vertex_assign_kernel(int64_t E, const u64* __restrict__ skey, const int32_t* __restrict__ sval,
+                                     const int32_t* __restrict__ flag, const int32_t* __restrict__ scan,
+                                     int32_t* vmap, int32_t* rep_edge, int32_t* vgraph_count) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= E) return;
+    const int32_t k = scan[p] + flag[p] - 1;
+    vmap[sval[p]] = k;
+    if (flag[p]) {
+        rep_edge[k] = sval[p];  // stable sort => first (lowest) edge carrying that id
+        atomicAdd(&vgraph_count[(int32_t)(skey[p] >> 32)], 1);
+    }
+}
+
+__global__ void raw_count_kernel(int64_t E, const int32_t* __restrict__ src, const int32_t* __restrict__ in_ptr,
+                                 int32_t* cnt) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    const int s = src[e];
+    cnt[e] = in_ptr[s + 1] - in_ptr[s];
+}
+
+// raw conj edge t = (i -> e): e ascending, i ascending over the in-edges of src(e)
+__global__ void raw_fill_kernel(int64_t E, int64_t T, const int32_t* __restrict__ raw_off,
+                                const int32_t* __restrict__ src, const int32_t* __restrict__ in_ptr,
+                                const int32_t* __restrict__ in_perm, const int32_t* __restrict__ vmap,
+                                const int32_t* __restrict__ node_label, u64* key, int32_t* label, int32_t* shared) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    const int64_t e = find_graph([&](int64_t k) { return (int64_t)raw_off[k]; }, E, t);
+    const int s = src[e];
+    const int i = in_perm[in_ptr[s] + (int)(t - raw_off[e])];
+    key[t] = ((u64)(uint32_t)vmap[i] << 32) | (u64)(uint32_t)vmap[e];
+    shared[t] = s;
+    if (label) label[t] = node_label[s];
+}
+
+__global__ void gather_u64_kernel(const u64* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, u64* out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+
+// keep[t] for the element at sorted position p (original raw index sval[p])
+__global__ void keep_flag_kernel(int32_t mode, int64_t T, const u64* __restrict__ skey, const int32_t* __restrict__ sval,
+                                 const int32_t* __restrict__ label /* original order, may be NULL */,
+                                 const int32_t* __restrict__ rep_edge, const uint8_t* __restrict__ is_dummy,
+                                 int32_t* keep) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= T) return;
+    const int t = sval[p];
+    bool head = true;
+    if (p > 0 && skey[p] == skey[p - 1]) {
+        head = false;
+        if (mode == DN_CONJ_SI && label[t] != label[sval[p - 1]]) head = true;
+    }
+    if (mode == DN_CONJ_GC && head) {
+        const uint32_t cu = (uint32_t)(skey[p] >> 32), cv = (uint32_t)skey[p];
+        if (cu == cv && is_dummy[rep_edge[cu]]) head = false;  // the (Phi, Phi) self loop
+    }
+    keep[t] = head ? 1 : 0;
+}
+
+__global__ void compact_kernel(int64_t T, const u64* __restrict__ key, const int32_t* __restrict__ shared,
+                               const int32_t* __restrict__ keep, const int32_t* __restrict__ kscan, int32_t* csrc,
+                               int32_t* cdst, int32_t* out_shared) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T || !keep[t]) return;
+    const int o = kscan[t];
+    csrc[o] = (int32_t)(key[t] >> 32);
+    cdst[o] = (int32_t)(uint32_t)key[t];
+    out_shared[o] = shared[t];
+}
+
+__global__ void cedge_ptr_kernel(int64_t G, int64_t E, int64_t T, const int32_t* __restrict__ edge_ptr,
+                                 const int32_t* __restrict__ raw_off, const int32_t* __restrict__ kscan,
+                                 const int32_t* __restrict__ keep, int32_t* cedge_ptr) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g > G) return;
+    const int64_t t = raw_off[edge_ptr[g]];  // raw_off has E+1 entries, raw_off[E] == T
+    cedge_ptr[g] = (t >= T) ? (T > 0 ? kscan[T - 1] + keep[T - 1] : 0) : kscan[t];
+}
+
+int csr_build(const int32_t* key, int64_t M, int64_t num_keys, int32_t* ptr, int32_t* perm, void* ws, size_t ws_bytes,
+              hipStream_t st, size_t* need_out) {
+    Arena a(ws, ws_bytes);
+    int32_t* skey = a.take<int32_t>(M);
+    int32_t* vin = a.take<int32_t>(M);
+    size_t tb = 0;
+    const int end_bit = bits_for((u64)(num_keys > 0 ? num_keys - 1 : 0));
+    if (M > 0) {
+        hipError_t e = sort_pairs<int32_t>(nullptr, tb, key, skey, vin, perm, M, end_bit, st);
+        if (e != hipSuccess) { dn_set_error("rocprim size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    }
+    void* temp = a.take_bytes(tb);
+    if (need_out) { *need_out = a.off; return DN_OK; }
+    if (!a.ok()) { dn_set_error("dn_csr_build: workspace too small (%zu < %zu)", ws_bytes, a.off); return DN_ERR_WORKSPACE; }
+    if (M > 0) {
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(M)), dim3(kBlock), 0, st, vin, M);
+        DN_CHECK_HIP(sort_pairs<int32_t>(temp, tb, key, skey, vin, perm, M, end_bit, st));
+    }
+    hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(grid_for(M + 1)), dim3(kBlock), 0, st, skey, M, num_keys, ptr);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+struct ConjWs {
+    // shared by count and build
+    int32_t *in_ptr, *in_perm, *cnt, *raw_off;
+    void* csr_ws; size_t csr_ws_bytes;
+    void* scan_tmp; size_t scan_tmp_bytes;
+    // build only
+    int32_t *egraph, *first_dummy, *vflag, *vscan, *vmap, *vcount, *sval_e, *iota_e;
+    u64 *vkey, *vkey_s;
+    void* sortE_tmp; size_t sortE_tmp_bytes;
+    u64 *rkey, *rkey_s, *rkey_g;
+    int32_t *rlabel, *rlabel_s, *rshared, *rval, *rval_s, *rval_s2, *keep, *kscan;
+    void* sortT_tmp; size_t sortT_tmp_bytes;
+    void* sortL_tmp; size_t sortL_tmp_bytes;
+    void* scanT_tmp; size_t scanT_tmp_bytes;
+    void* scanG_tmp; size_t scanG_tmp_bytes;
+};
+
+// Lays out the workspace; with base == nullptr only sizes are computed.  T < 0 => count-phase only.
+int conj_layout(Arena& a, ConjWs& w, int64_t G, int64_t N, int64_t E, int64_t T, hipStream_t st) {
+    memset(&w, 0, sizeof(w));
+    hipError_t e;
+    w.in_ptr = a.take<int32_t>(N + 1);
+    w.in_perm = a.take<int32_t>(E);
+    w.cnt = a.take<int32_t>(E + 1);
+    w.raw_off = a.take<int32_t>(E + 1);
+    size_t need = 0;
+    int rc = csr_build(nullptr, E, N, nullptr, nullptr, nullptr, 0, st, &need);
+    if (rc != DN_OK) return rc;
+    w.csr_ws_bytes = need;
+    w.csr_ws = a.take_bytes(need);
+    e = excl_scan(nullptr, w.scan_tmp_bytes, w.cnt, w.raw_off, E + 1, st);
+    if (e != hipSuccess) { dn_set_error("rocprim scan size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    w.scan_tmp = a.take_bytes(w.scan_tmp_bytes);
+    if (T < 0) return DN_OK;
+    w.egraph = a.take<int32_t>(E);
+    w.first_dummy = a.take<int32_t>(G + 1);
+    w.vflag = a.take<int32_t>(E);
+    w.vscan = a.take<int32_t>(E);
+    w.vmap = a.take<int32_t>(E);
+    w.vcount = a.take<int32_t>(G + 1);
+    w.sval_e = a.take<int32_t>(E);
+    w.iota_e = a.take<int32_t>(E);
+    w.vkey = a.take<u64>(E);
+    w.vkey_s = a.take<u64>(E);
+    if (E > 0) {
+        e = sort_pairs<u64>(nullptr, w.sortE_tmp_bytes, w.vkey, w.vkey_s, w.iota_e, w.sval_e, E, 64, st);
+        if (e != hipSuccess) { dn_set_error("rocprim size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    }
+    w.sortE_tmp = a.take_bytes(w.sortE_tmp_bytes);
+    e = excl_scan(nullptr, w.scanG_tmp_bytes, w.vcount, w.first_dummy, G + 1, st);
+    if (e != hipSuccess) { dn_set_error("rocprim scan size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    w.scanG_tmp = a.take_bytes(w.scanG_tmp_bytes);
+    w.rkey = a.take<u64>(T);
+    w.rkey_s = a.take<u64>(T);
+    w.rkey_g = a.take<u64>(T);
+    w.rlabel = a.take<int32_t>(T);
+    w.rlabel_s = a.take<int32_t>(T);
+    w.rshared = a.take<int32_t>(T);
+    w.rval = a.take<int32_t>(T);
+    w.rval_s = a.take<int32_t>(T);
+    w.rval_s2 = a.take<int32_t>(T);
+    w.keep = a.take<int32_t>(T);
+    w.kscan = a.take<int32_t>(T);
+    if (T > 0) {
+        e = sort_pairs<u64>(nullptr, w.sortT_tmp_bytes, w.rkey, w.rkey_s, w.rval, w.rval_s, T, 64, st);
+        if (e == hipSuccess) e = sort_pairs<int32_t>(nullptr, w.sortL_tmp_bytes, w.rlabel, w.rlabel_s, w.rval, w.rval_s, T, 32, st);
+        if (e == hipSuccess) e = excl_scan(nullptr, w.scanT_tmp_bytes, w.keep, w.kscan, T, st);
+        if (e != hipSuccess) { dn_set_error("rocprim size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    }
+    w.sortT_tmp = a.take_bytes(w.sortT_tmp_bytes);
+    w.sortL_tmp = a.take_bytes(w.sortL_tmp_bytes);
+    w.scanT_tmp = a.take_bytes(w.scanT_tmp_bytes);
+    return DN_OK;
+}
+
+// in-CSR by dst + raw offsets; leaves raw_off[E] = T on the device
+int conj_count_phase(ConjWs& w, int64_t N, int64_t E, const int32_t* src, const int32_t* dst, hipStream_t st) {
+    int rc = csr_build(dst, E, N, w.in_ptr, w.in_perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+    if (rc != DN_OK) return rc;
+    DN_CHECK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)(E + 1), st));
+    if (E > 0) hipLaunchKernelGGL(raw_count_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, src, w.in_ptr, w.cnt);
+    DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.cnt, w.raw_off, E + 1, st));
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+// ----- relation-aware segment index ((rel, dst) segments) -------------------------------------------
+__global__ void rel_key_kernel(int64_t E, int64_t N, const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
+                               int32_t* key) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e < E) key[e] = (int32_t)((int64_t)etype[e] * N + dst[e]);
+}
+__global__ void head_flag_i32_kernel(const int32_t* __restrict__ skey, int64_t n, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+}
+__global__ void rel_segments_kernel(int64_t E, int64_t N, const int32_t* __restrict__ skey, const int32_t* __restrict__ perm1,
+                                    const int32_t* __restrict__ flag, const int32_t* __restrict__ scan,
+                                    const int32_t* __restrict__ src, int32_t* src1, int32_t* seg_ptr, int32_t* seg_dst,
+                                    int32_t* seg_rel, int32_t* seg_of_edge) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p > E) return;
+    if (p == E) {  // sentinel: seg_ptr[P] = E
+        const int32_t P = E > 0 ? scan[E - 1] + flag[E - 1] : 0;
+        seg_ptr[P] = (int32_t)E;
+        return;
+    }
+    const int32_t k = scan[p] + flag[p] - 1;
+    const int32_t e = perm1[p];
+    src1[p] = src[e];
+    seg_of_edge[e] = k;
+    if (flag[p]) {
+        seg_ptr[k] = (int32_t)p;
+        seg_dst[k] = (int32_t)(skey[p] % N);
+        seg_rel[k] = (int32_t)(skey[p] / N);
+    }
+}
+__global__ void gather_i32_kernel(const int32_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+
+struct RelWs {
+    int32_t *key, *skey, *iota, *flag, *scan, *seg_rel, *seg_of_edge;
+    void* sort_tmp; size_t sort_tmp_bytes;
+    void* scan_tmp; size_t scan_tmp_bytes;
+    void* csr_ws; size_t csr_ws_bytes;
+};
+int rel_layout(Arena& a, RelWs& w, int64_t N, int64_t R, int64_t E, hipStream_t st) {
+    memset(&w, 0, sizeof(w));
+    w.key = a.take<int32_t>(E);
+    w.skey = a.take<int32_t>(E);
+    w.iota = a.take<int32_t>(E);
+    w.flag = a.take<int32_t>(E);
+    w.scan = a.take<int32_t>(E);
+    w.seg_rel = a.take<int32_t>(E);
+    w.seg_of_edge = a.take<int32_t>(E);
+    hipError_t e = hipSuccess;
+    if (E > 0) {
+        e = sort_pairs<int32_t>(nullptr, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.flag, E, 32, st);
+        if (e == hipSuccess) e = excl_scan(nullptr, w.scan_tmp_bytes, w.flag, w.scan, E, st);
+        if (e != hipSuccess) { dn_set_error("rocprim size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    }
+    w.sort_tmp = a.take_bytes(w.sort_tmp_bytes);
+    w.scan_tmp = a.take_bytes(w.scan_tmp_bytes);
+    size_t need = 0;
+    int rc = csr_build(nullptr, E, N, nullptr, nullptr, nullptr, 0, st, &need);
+    if (rc != DN_OK) return rc;
+    w.csr_ws_bytes = need;
+    w.csr_ws = a.take_bytes(need);
+    (void)R;
+    return DN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dn_csr_build_workspace_bytes(int64_t M, int64_t num_keys) {
+    if (M < 0 || num_keys < 0) { dn_set_error("dn_csr_build_workspace_bytes: negative size"); return 0; }
+    size_t need = 0;
+    if (csr_build(nullptr, M, num_keys, nullptr, nullptr, nullptr, 0, nullptr, &need) != DN_OK) return 0;
+    return need;
+}
+
+int dn_csr_build_i32(const int32_t* key, int64_t M, int64_t num_keys, int32_t* ptr, int32_t* perm, void* workspace,
+                     size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(M >= 0 && num_keys >= 0, "dn_csr_build: negative size");
+    DN_REQUIRE(M < 0x7fffffffLL && num_keys < 0x7fffffffLL, "dn_csr_build: sizes must fit int32");
+    DN_REQUIRE(ptr != nullptr, "dn_csr_build: ptr is NULL");
+    DN_REQUIRE(M == 0 || (key && perm && workspace), "dn_csr_build: NULL pointer");
+    return csr_build(key, M, num_keys, ptr, perm, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+int dn_degrees_i32(int64_t N, int64_t E, const int32_t* src, const int32_t* dst, int32_t* in_deg, int32_t* out_deg,
+                   dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && E >= 0, "dn_degrees: negative size");
+    hipStream_t st = (hipStream_t)stream;
+    if (in_deg) DN_CHECK_HIP(hipMemsetAsync(in_deg, 0, sizeof(int32_t) * (size_t)N, st));
+    if (out_deg) DN_CHECK_HIP(hipMemsetAsync(out_deg, 0, sizeof(int32_t) * (size_t)N, st));
+    if (E > 0) {
+        DN_REQUIRE(src && dst, "dn_degrees: NULL pointer");
+        hipLaunchKernelGGL(degrees_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, src, dst, in_deg, out_deg);
+        DN_CHECK_LAUNCH();
+    }
+    return DN_OK;
+}
+
+int dn_edge_norm_f32(int32_t mode, int32_t self_loop, int64_t N, int64_t E, const int32_t* src, const int32_t* dst,
+                     const int32_t* in_deg, const int32_t* out_deg, float* in_norm, float* out_norm, float* edge_norm,
+                     dn_stream_t stream) {
+    DN_REQUIRE(mode == 1 || mode == 2, "dn_edge_norm: mode must be 1 (in) or 2 (both)");
+    DN_REQUIRE(N >= 0 && E >= 0, "dn_edge_norm: negative size");
+    DN_REQUIRE(in_norm == nullptr || in_deg != nullptr, "dn_edge_norm: in_norm needs in_deg");
+    DN_REQUIRE(out_norm == nullptr || out_deg != nullptr, "dn_edge_norm: out_norm needs out_deg");
+    DN_REQUIRE(edge_norm == nullptr || (in_norm && (mode == 1 || out_norm)), "dn_edge_norm: edge_norm needs node norms");
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 0 && (in_norm || out_norm))
+        hipLaunchKernelGGL(node_norm_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, self_loop, N, in_deg, out_deg, in_norm,
+                           out_norm);
+    if (E > 0 && edge_norm) {
+        DN_REQUIRE(src && dst, "dn_edge_norm: NULL pointer");
+        hipLaunchKernelGGL(edge_norm_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, mode, E, src, dst, in_norm, out_norm,
+                           edge_norm);
+    }
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+static int dummy_augment(int32_t si, int64_t G, int64_t N, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                         const int32_t* src, const int32_t* dst, const int32_t* node_id, const int32_t* node_label,
+                         const int32_t* edge_id, const int32_t* edge_label, const uint8_t* in_rev, int32_t max_nv,
+                         int32_t max_nvl, int32_t max_ne, int32_t max_nel, int32_t* out_node_ptr, int32_t* out_edge_ptr,
+                         int32_t* out_src, int32_t* out_dst, int32_t* out_node_id, int32_t* out_node_label,
+                         int32_t* out_edge_id, int32_t* out_edge_label, uint8_t* out_dn, uint8_t* out_de, uint8_t* out_rev,
+                         hipStream_t st) {
+    DN_REQUIRE(G >= 0 && N >= 0 && E >= 0, "dn_dummy_augment: negative size");
+    DN_REQUIRE(E + 2 * N < 0x7fffffffLL && N + G < 0x7fffffffLL, "dn_dummy_augment: output sizes must fit int32");
+    DN_REQUIRE(node_ptr && edge_ptr && out_node_ptr && out_edge_ptr, "dn_dummy_augment: NULL ptr array");
+    hipLaunchKernelGGL(dummy_ptr_kernel, dim3(grid_for(G + 1)), dim3(kBlock), 0, st, G, node_ptr, edge_ptr, out_node_ptr,
+                       out_edge_ptr);
+    if (G > 0 && N + G > 0) {
+        DN_REQUIRE(node_label && out_node_id && out_node_label && out_dn, "dn_dummy_augment: NULL node array");
+        hipLaunchKernelGGL(dummy_nodes_kernel, dim3(grid_for(N + G)), dim3(kBlock), 0, st, si, G, N + G, node_ptr, node_id,
+                           node_label, max_nv, max_nvl, out_node_id, out_node_label, out_dn);
+    }
+    if (G > 0 && E + 2 * N > 0) {
+        DN_REQUIRE(out_src && out_dst && out_edge_id && out_edge_label && out_de, "dn_dummy_augment: NULL edge array");
+        DN_REQUIRE(E == 0 || (src && dst && edge_label), "dn_dummy_augment: NULL input edge array");
+        hipLaunchKernelGGL(dummy_edges_kernel, dim3(grid_for(E + 2 * N)), dim3(kBlock), 0, st, si, G, E + 2 * N, node_ptr,
+                           edge_ptr, src, dst, edge_id, edge_label, in_rev, max_ne, max_nel, out_src, out_dst, out_edge_id,
+                           out_edge_label, out_de, out_rev);
+    }
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_dummy_augment_gc_i32(int64_t G, int64_t N, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                            const int32_t* src, const int32_t* dst, const int32_t* node_label, const int32_t* edge_label,
+                            int32_t* out_node_ptr, int32_t* out_edge_ptr, int32_t* out_src, int32_t* out_dst,
+                            int32_t* out_node_label, int32_t* out_edge_label, uint8_t* out_is_dummy_node,
+                            uint8_t* out_is_dummy_edge, int32_t* out_node_id, int32_t* out_edge_id, dn_stream_t stream) {
+    return dummy_augment(0, G, N, E, node_ptr, edge_ptr, src, dst, nullptr, node_label, nullptr, edge_label, nullptr, 0, 0,
+                         0, 0, out_node_ptr, out_edge_ptr, out_src, out_dst, out_node_id, out_node_label, out_edge_id,
+                         out_edge_label, out_is_dummy_node, out_is_dummy_edge, nullptr, (hipStream_t)stream);
+}
+
+int dn_dummy_augment_si_i32(int64_t G, int64_t N, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                            const int32_t* src, const int32_t* dst, const int32_t* node_id, const int32_t* node_label,
+                            const int32_t* edge_id, const int32_t* edge_label, const uint8_t* in_is_reversed,
+                            int32_t max_nv, int32_t max_nvl, int32_t max_ne, int32_t max_nel, int32_t* out_node_ptr,
+                            int32_t* out_edge_ptr, int32_t* out_src, int32_t* out_dst, int32_t* out_node_id,
+                            int32_t* out_node_label, int32_t* out_edge_id, int32_t* out_edge_label,
+                            uint8_t* out_is_dummy_node, uint8_t* out_is_dummy_edge, uint8_t* out_is_reversed,
+                            dn_stream_t stream) {
+    DN_REQUIRE(N == 0 || node_id != nullptr, "dn_dummy_augment_si: node_id is NULL");
+    DN_REQUIRE(E == 0 || edge_id != nullptr, "dn_dummy_augment_si: edge_id is NULL");
+    DN_REQUIRE(out_is_reversed != nullptr || (E + 2 * N) == 0, "dn_dummy_augment_si: out_is_reversed is NULL");
+    return dummy_augment(1, G, N, E, node_ptr, edge_ptr, src, dst, node_id, node_label, edge_id, edge_label, in_is_reversed,
+                         max_nv, max_nvl, max_ne, max_nel, out_node_ptr, out_edge_ptr, out_src, out_dst, out_node_id,
+                         out_node_label, out_edge_id, out_edge_label, out_is_dummy_node, out_is_dummy_edge, out_is_reversed,
+                         (hipStream_t)stream);
+}
+
+size_t dn_conjugate_workspace_bytes(int64_t G, int64_t N, int64_t E, int64_t num_raw) {
+    if (G < 0 || N < 0 || E < 0) { dn_set_error("dn_conjugate_workspace_bytes: negative size"); return 0; }
+    Arena a(nullptr, 0);
+    ConjWs w;
+    if (conj_layout(a, w, G, N, E, num_raw, nullptr) != DN_OK) return 0;
+    return a.off + 256;
+}
+
+int dn_conjugate_count_i32(int64_t N, int64_t E, const int32_t* src, const int32_t* dst, int64_t* host_num_raw,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && E >= 0 && host_num_raw, "dn_conjugate_count: bad arguments");
+    DN_REQUIRE(E < 0x7fffffffLL && N < 0x7fffffffLL, "dn_conjugate_count: sizes must fit int32");
+    hipStream_t st = (hipStream_t)stream;
+    if (E == 0) { *host_num_raw = 0; return DN_OK; }
+    DN_REQUIRE(src && dst && workspace, "dn_conjugate_count: NULL pointer");
+    Arena a(workspace, workspace_bytes);
+    ConjWs w;
+    int rc = conj_layout(a, w, 0, N, E, -1, st);
+    if (rc != DN_OK) return rc;
+    if (!a.ok()) { dn_set_error("dn_conjugate_count: workspace too small (%zu < %zu)", workspace_bytes, a.off); return DN_ERR_WORKSPACE; }
+    rc = conj_count_phase(w, N, E, src, dst, st);
+    if (rc != DN_OK) return rc;
+    int32_t total = 0;
+    DN_CHECK_HIP(hipMemcpyAsync(&total, w.raw_off + E, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    // NB: a 32-bit scan; overflow shows up as a negative total
+    DN_REQUIRE(total >= 0, "dn_conjugate_count: raw 2-path count overflows int32");
+    *host_num_raw = total;
+    return DN_OK;
+}
+
+int dn_conjugate_build_i32(int32_t mode, int64_t G, int64_t N, int64_t E, int64_t T, const int32_t* node_ptr,
+                           const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* node_label,
+                           const int32_t* edge_id, const uint8_t* is_dummy_edge, int32_t* out_cnode_ptr,
+                           int32_t* out_cedge_ptr, int32_t* out_csrc, int32_t* out_cdst, int32_t* out_rep_edge,
+                           int32_t* out_shared_node, int64_t* host_counts, void* workspace, size_t workspace_bytes,
+                           dn_stream_t stream) {
+    DN_REQUIRE(mode == DN_CONJ_GC || mode == DN_CONJ_SI || mode == DN_CONJ_LINE, "dn_conjugate_build: bad mode %d", mode);
+    DN_REQUIRE(G >= 0 && N >= 0 && E >= 0 && T >= 0, "dn_conjugate_build: negative size");
+    DN_REQUIRE(E < 0x7fffffffLL && N < 0x7fffffffLL && T < 0x7fffffffLL, "dn_conjugate_build: sizes must fit int32");
+    DN_REQUIRE(node_ptr && edge_ptr && out_cnode_ptr && out_cedge_ptr && host_counts, "dn_conjugate_build: NULL pointer");
+    DN_REQUIRE(mode != DN_CONJ_SI || E == 0 || (edge_id && node_label), "dn_conjugate_build: SI mode needs edge_id and node_label");
+    DN_REQUIRE(mode != DN_CONJ_GC || E == 0 || is_dummy_edge, "dn_conjugate_build: GC mode needs is_dummy_edge");
+    hipStream_t st = (hipStream_t)stream;
+    host_counts[0] = host_counts[1] = 0;
+    if (E == 0) {
+        DN_CHECK_HIP(hipMemsetAsync(out_cnode_ptr, 0, sizeof(int32_t) * (size_t)(G + 1), st));
+        DN_CHECK_HIP(hipMemsetAsync(out_cedge_ptr, 0, sizeof(int32_t) * (size_t)(G + 1), st));
+        return DN_OK;
+    }
+    DN_REQUIRE(src && dst && workspace && out_rep_edge, "dn_conjugate_build: NULL pointer");
+    DN_REQUIRE(T == 0 || (out_csrc && out_cdst && out_shared_node), "dn_conjugate_build: NULL output");
+    Arena a(workspace, workspace_bytes);
+    ConjWs w;
+    int rc = conj_layout(a, w, G, N, E, T, st);
+    if (rc != DN_OK) return rc;
+    if (!a.ok()) { dn_set_error("dn_conjugate_build: workspace too small (%zu < %zu)", workspace_bytes, a.off); return DN_ERR_WORKSPACE; }
+
+    // (1) in-incidence CSR + raw offsets
+    rc = conj_count_phase(w, N, E, src, dst, st);
+    if (rc != DN_OK) return rc;
+
+    // (2) conj vertices: distinct (graph, conj id), ascending id; representative = first edge with that id
+    hipLaunchKernelGGL(edge_graph_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, G, E, edge_ptr, w.egraph);
+    if (mode == DN_CONJ_GC) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(G + 1)), dim3(kBlock), 0, st, w.first_dummy, G + 1, 0x7fffffff);
+        hipLaunchKernelGGL(first_dummy_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, w.egraph, edge_ptr, is_dummy_edge,
+                           w.first_dummy);
+    }
+    hipLaunchKernelGGL(vertex_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, mode, E, w.egraph, edge_ptr, edge_id,
+                       is_dummy_edge, w.first_dummy, w.vkey);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.iota_e, E);
+    DN_CHECK_HIP(sort_pairs<u64>(w.sortE_tmp, w.sortE_tmp_bytes, w.vkey, w.vkey_s, w.iota_e, w.sval_e, E, 64, st));
+    hipLaunchKernelGGL(head_flag_u64_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.vkey_s, E, w.vflag);
+    {
+        size_t tb = w.scan_tmp_bytes;  // sized for E+1 >= E elements
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, tb, w.vflag, w.vscan, E, st));
+    }
+    DN_CHECK_HIP(hipMemsetAsync(w.vcount, 0, sizeof(int32_t) * (size_t)(G + 1), st));
+    hipLaunchKernelGGL(vertex_assign_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, w.vkey_s, w.sval_e, w.vflag, w.vscan,
+                       w.vmap, out_rep_edge, w.vcount);
+    DN_CHECK_HIP(excl_scan(w.scanG_tmp, w.scanG_tmp_bytes, w.vcount, out_cnode_ptr, G + 1, st));
+
+    // (3) raw conj edges, (4) first-occurrence dedupe, (5) order-preserving compaction
+    if (T > 0) {
+        hipLaunchKernelGGL(raw_fill_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, E, T, w.raw_off, src, w.in_ptr, w.in_perm,
+                           w.vmap, node_label, w.rkey, mode == DN_CONJ_SI ? w.rlabel : nullptr, w.rshared);
+        if (mode == DN_CONJ_LINE) {
+            hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, w.keep, T, 1);
+        } else {
+            hipLaunchKernelGGL(iota_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, w.rval, T);
+            const int32_t* order = w.rval;
+            const u64* keys_in = w.rkey;
+            if (mode == DN_CONJ_SI) {
+                // LSD: stable sort by label first, then by (cu, cv)
+                DN_CHECK_HIP(sort_pairs<int32_t>(w.sortL_tmp, w.sortL_tmp_bytes, w.rlabel, w.rlabel_s, w.rval, w.rval_s2, T, 32, st));
+                hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, w.rkey, w.rval_s2, T, w.rkey_g);
+                order = w.rval_s2;
+                keys_in = w.rkey_g;
+            }
+            DN_CHECK_HIP(sort_pairs<u64>(w.sortT_tmp, w.sortT_tmp_bytes, keys_in, w.rkey_s, order, w.rval_s, T, 64, st));
+            hipLaunchKernelGGL(keep_flag_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, mode, T, w.rkey_s, w.rval_s,
+                               mode == DN_CONJ_SI ? w.rlabel : nullptr, out_rep_edge, is_dummy_edge, w.keep);
+        }
+        DN_CHECK_HIP(excl_scan(w.scanT_tmp, w.scanT_tmp_bytes, w.keep, w.kscan, T, st));
+        hipLaunchKernelGGL(compact_kernel, dim3(grid_for(T)), dim3(kBlock), 0, st, T, w.rkey, w.rshared, w.keep, w.kscan,
+                           out_csrc, out_cdst, out_shared_node);
+    }
+    hipLaunchKernelGGL(cedge_ptr_kernel, dim3(grid_for(G + 1)), dim3(kBlock), 0, st, G, E, T, edge_ptr, w.raw_off, w.kscan,
+                       w.keep, out_cedge_ptr);
+    DN_CHECK_LAUNCH();
+    int32_t counts[2] = {0, 0};
+    DN_CHECK_HIP(hipMemcpyAsync(&counts[0], out_cnode_ptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipMemcpyAsync(&counts[1], out_cedge_ptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    host_counts[0] = counts[0];
+    host_counts[1] = counts[1];
+    return DN_OK;
+}
+
+size_t dn_rel_index_workspace_bytes(int64_t N, int64_t R, int64_t E) {
+    if (N < 0 || R < 0 || E < 0) { dn_set_error("dn_rel_index_workspace_bytes: negative size"); return 0; }
+    Arena a(nullptr, 0);
+    RelWs w;
+    if (rel_layout(a, w, N, R, E, nullptr) != DN_OK) return 0;
+    return a.off + 256;
+}
+
+int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, const int32_t* dst, const int32_t* etype,
+                           int32_t* perm1, int32_t* src1, int32_t* seg_ptr, int32_t* seg_dst, int32_t* rel_ptr,
+                           int32_t* dptr, int32_t* sperm, int32_t* optr, int32_t* operm, int32_t* seg_by_src,
+                           int64_t* host_P, int32_t* host_rel_ptr, void* workspace, size_t workspace_bytes,
+                           dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && R >= 1 && E >= 0, "dn_rel_index_build: bad sizes");
+    DN_REQUIRE(N * R < 0x7fffffffLL && E < 0x7fffffffLL, "dn_rel_index_build: N*R and E must fit int32");
+    DN_REQUIRE(seg_ptr && rel_ptr && dptr && optr && host_P && host_rel_ptr, "dn_rel_index_build: NULL pointer");
+    DN_REQUIRE(E == 0 || (src && dst && etype && perm1 && src1 && seg_dst && sperm && operm && seg_by_src && workspace),
+               "dn_rel_index_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(workspace, workspace_bytes);
+    RelWs w;
+    int rc = rel_layout(a, w, N, R, E, st);
+    if (rc != DN_OK) return rc;
+    if (workspace && !a.ok()) { dn_set_error("dn_rel_index_build: workspace too small (%zu < %zu)", workspace_bytes, a.off); return DN_ERR_WORKSPACE; }
+    *host_P = 0;
+    if (E == 0) {
+        DN_CHECK_HIP(hipMemsetAsync(seg_ptr, 0, sizeof(int32_t), st));
+        DN_CHECK_HIP(hipMemsetAsync(rel_ptr, 0, sizeof(int32_t) * (size_t)(R + 1), st));
+        DN_CHECK_HIP(hipMemsetAsync(dptr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+        DN_CHECK_HIP(hipMemsetAsync(optr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+        memset(host_rel_ptr, 0, sizeof(int32_t) * (size_t)(R + 1));
+        return DN_OK;
+    }
+    // (1) stable sort of edges by (rel, dst)
+    hipLaunchKernelGGL(rel_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, dst, etype, w.key);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.iota, E);
+    DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, perm1, E,
+                                     bits_for((u64)(N * R > 0 ? N * R - 1 : 0)), st));
+    // (2) segments = runs of equal key
+    hipLaunchKernelGGL(head_flag_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.skey, E, w.flag);
+    DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.flag, w.scan, E, st));
+    hipLaunchKernelGGL(rel_segments_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, st, E, N, w.skey, perm1, w.flag, w.scan,
+                       src, src1, seg_ptr, seg_dst, w.seg_rel, w.seg_of_edge);
+    int32_t last[2] = {0, 0};
+    DN_CHECK_HIP(hipMemcpyAsync(&last[0], w.scan + (E - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipMemcpyAsync(&last[1], w.flag + (E - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    const int64_t P = (int64_t)last[0] + last[1];
+    *host_P = P;
+    // (3) relation ranges over segments, (4) segments grouped by dst, (5) edges grouped by src
+    hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(grid_for(P + 1)), dim3(kBlock), 0, st, w.seg_rel, P, R, rel_ptr);
+    rc = csr_build(seg_dst, P, N, dptr, sperm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+    if (rc != DN_OK) return rc;
+    rc = csr_build(src, E, N, optr, operm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+    if (rc != DN_OK) return rc;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.seg_of_edge, operm, E, seg_by_src);
+    DN_CHECK_LAUNCH();
+    DN_CHECK_HIP(hipMemcpyAsync(host_rel_ptr, rel_ptr, sizeof(int32_t) * (size_t)(R + 1), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    return DN_OK;
+}
+
+}  // extern "C"

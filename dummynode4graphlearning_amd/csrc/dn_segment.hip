@@ -1,0 +1,340 @@
+// Gather + segment-reduce kernels (gfx950 / CDNA4): the message-passing core of the GIN / RGCN / RGIN
+// layers and the per-graph readouts.  HBM/L2-bound row traffic, no matrix work, no atomics.
+//
+// Layout: feature matrices row-major [rows, H].  A "row group" of LPR lanes (power of two, 16 bytes per
+// lane) owns one destination segment at a time: the group walks the segment's element list, each lane
+// loading one 16-byte piece of every gathered row (a 64-lane wave covers 64/LPR segments), accumulates
+// in fp32 registers and writes the finished row once.  Gather indices are fetched coalesced, LPR at a
+// time, and broadcast inside the group with ds_bpermute (__shfl), so the dependent index->row load
+// chain is paid once per LPR elements, and four row loads are kept in flight per group.
+// Workgroups take CONTIGUOUS chunks of segments, and the block->chunk map is XCD-aware
+// (dn_common.h): batched graphs are block-diagonal, so a chunk's source rows sit in the same few KB
+// and are re-read from that XCD's L2 rather than from HBM.
+#include "dn_common.h"
+#include "../../include/dn_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kSegsPerGroup = 8;  // segments a row group walks per block (chunk = groups * this)
+
+typedef __bf16 bf16_t;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        *reinterpret_cast<bf16x8*>(p) = o;
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// ---------------------------------------------------------------------------------------------
+// Vector path: H % Vec<T>::N == 0, rows 16-byte aligned.  LPR lanes x 16 B cover one pass of a row;
+// rows wider than LPR*16 B are covered in ceil(H / (LPR*VN)) column passes.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int LPR, bool HAS_SCALE>
+__global__ __launch_bounds__(kBlock) void gather_segsum_vec_kernel(
+    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+    const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, const T* __restrict__ self_in,
+    float self_coef, int32_t mean, int64_t nchunks) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int GPB = kBlock / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int group = threadIdx.x / LPR;
+    const int64_t chunk = dn_xcd_chunk(blockIdx.x, gridDim.x);
+    if (chunk >= nchunks) return;
+    const int64_t seg0 = chunk * (GPB * kSegsPerGroup);
+
+    for (int col0 = 0; col0 < H; col0 += LPR * VN) {
+        const int col = col0 + lane * VN;
+        const bool colok = col < H;
+#pragma unroll 1
+        for (int it = 0; it < kSegsPerGroup; ++it) {
+            // interleave groups over the chunk so that a wave's groups touch neighbouring segments
+            const int64_t s = seg0 + (int64_t)it * GPB + group;
+            if (s >= S) break;
+            int beg, end;
+            if (ptr != nullptr) { beg = ptr[s]; end = ptr[s + 1]; } else { beg = (int)s; end = (int)s + 1; }
+            float acc[VN];
+#pragma unroll
+            for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+            for (int base = beg; base < end; base += LPR) {
+                const int n = min(LPR, end - base);
+                int my = 0;
+                float mysc = 1.f;
+                if (lane < n) {
+                    my = idx != nullptr ? idx[base + lane] : base + lane;
+                    if (HAS_SCALE) mysc = scale[base + lane];
+                }
+                for (int j = 0; j < n; j += 4) {
+                    float v[4][VN];
+                    float w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int jj = (j + k) & (LPR - 1);
+                        const int r = __shfl(my, jj, LPR);
+                        w[k] = HAS_SCALE ? __shfl(mysc, jj, LPR) : 1.f;
+                        if (j + k < n && colok) {
+                            Vec<T>::load(in + (size_t)r * H + col, v[k]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VN; ++i) v[k][i] = 0.f;
+                            w[k] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) {
+                            if (HAS_SCALE) acc[i] = fmaf(w[k], v[k][i], acc[i]);
+                            else acc[i] += v[k][i];
+                        }
+                    }
+                }
+            }
+            if (colok) {
+                if (mean) {
+                    const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) acc[i] *= inv;
+                }
+                if (self_in != nullptr) {
+                    float sv[VN];
+                    Vec<T>::load(self_in + (size_t)s * H + col, sv);
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) acc[i] = fmaf(self_coef, sv[i], acc[i]);
+                }
+                Vec<T>::store(out + (size_t)s * H + col, acc);
+            }
+        }
+    }
+}
+
+// Scalar path: any H (one element per lane per pass); used for narrow / unaligned rows
+// (e.g. the [N, num_classes] readout of gconv.py:210).
+template <typename T, int LPR, bool HAS_SCALE>
+__global__ __launch_bounds__(kBlock) void gather_segsum_scalar_kernel(
+    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+    const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, const T* __restrict__ self_in,
+    float self_coef, int32_t mean, int64_t nchunks) {
+    constexpr int GPB = kBlock / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int group = threadIdx.x / LPR;
+    const int64_t chunk = dn_xcd_chunk(blockIdx.x, gridDim.x);
+    if (chunk >= nchunks) return;
+    const int64_t seg0 = chunk * (GPB * kSegsPerGroup);
+    for (int it = 0; it < kSegsPerGroup; ++it) {
+        const int64_t s = seg0 + (int64_t)it * GPB + group;
+        if (s >= S) break;
+        int beg, end;
+        if (ptr != nullptr) { beg = ptr[s]; end = ptr[s + 1]; } else { beg = (int)s; end = (int)s + 1; }
+        for (int col = lane; col < H; col += LPR) {
+            float acc = 0.f;
+            for (int i = beg; i < end; ++i) {
+                const int r = idx != nullptr ? idx[i] : i;
+                const float x = to_f32<T>(in[(size_t)r * H + col]);
+                if (HAS_SCALE) acc = fmaf(scale[i], x, acc);
+                else acc += x;
+            }
+            if (mean) acc *= end > beg ? 1.f / (float)(end - beg) : 0.f;
+            if (self_in != nullptr) acc = fmaf(self_coef, to_f32<T>(self_in[(size_t)s * H + col]), acc);
+            out[(size_t)s * H + col] = from_f32<T>(acc);
+        }
+    }
+}
+
+template <typename T, int LPR, bool VECP>
+int launch_lpr(const T* in, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S, int32_t H, T* out,
+               const T* self_in, float self_coef, int32_t mean, hipStream_t st) {
+    constexpr int GPB = kBlock / LPR;
+    const int64_t nchunks = dn_cdiv(S, (int64_t)GPB * kSegsPerGroup);
+    const int64_t grid = dn_cdiv(nchunks, DN_NUM_XCD) * DN_NUM_XCD;
+    if (grid > 0x7fffffffLL) { dn_set_error("dn_gather_segsum: grid too large"); return DN_ERR_ARG; }
+#define DN_LAUNCH(SC)                                                                                         \
+    do {                                                                                                      \
+        if (VECP)                                                                                             \
+            hipLaunchKernelGGL((gather_segsum_vec_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, in, \
+                               idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);                \
+        else                                                                                                  \
+            hipLaunchKernelGGL((gather_segsum_scalar_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, \
+                               in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);            \
+    } while (0)
+    if (scale != nullptr) DN_LAUNCH(true);
+    else DN_LAUNCH(false);
+#undef DN_LAUNCH
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <typename T>
+int gather_segsum(const T* in, int64_t in_rows, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
+                  int64_t S, int64_t M, T* out, const T* self_in, float self_coef, int32_t mean, hipStream_t st) {
+    DN_REQUIRE(H > 0, "dn_gather_segsum: H must be > 0 (got %d)", H);
+    DN_REQUIRE(S >= 0 && M >= 0 && in_rows >= 0, "dn_gather_segsum: negative size");
+    DN_REQUIRE(S < 0x7fffffffLL && M < 0x7fffffffLL && in_rows < 0x7fffffffLL, "dn_gather_segsum: sizes must fit int32");
+    DN_REQUIRE(ptr != nullptr || S == M, "dn_gather_segsum: ptr == NULL requires S == M");
+    DN_REQUIRE(idx != nullptr || M <= in_rows, "dn_gather_segsum: idx == NULL requires M <= in_rows");
+    if (S == 0) return DN_OK;
+    DN_REQUIRE(in != nullptr || M == 0, "dn_gather_segsum: in is NULL");
+    DN_REQUIRE(out != nullptr, "dn_gather_segsum: out is NULL");
+    constexpr int VN = Vec<T>::N;
+    const bool vec = (H % VN == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+                                        reinterpret_cast<uintptr_t>(self_in)) % 16 == 0);
+    const int pieces = vec ? H / VN : H;
+    if (vec) {
+        if (pieces <= 4) return launch_lpr<T, 4, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 8) return launch_lpr<T, 8, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 16) return launch_lpr<T, 16, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 32) return launch_lpr<T, 32, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+        return launch_lpr<T, 64, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+    }
+    if (pieces <= 8) return launch_lpr<T, 8, false>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+    return launch_lpr<T, 64, false>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment max (+argmax) over contiguous rows and its backward
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void segment_max_kernel(const T* __restrict__ in, int32_t H,
+                                                             const int32_t* __restrict__ ptr, int64_t S,
+                                                             T* __restrict__ out, int32_t* __restrict__ argmax) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= S * H) return;
+    const int64_t s = t / H;
+    const int h = (int)(t % H);
+    const int beg = ptr[s], end = ptr[s + 1];
+    float best = 0.f;
+    int arg = -1;
+    for (int i = beg; i < end; ++i) {
+        const float x = to_f32<T>(in[(size_t)i * H + h]);
+        if (arg < 0 || x > best) { best = x; arg = i; }
+    }
+    out[t] = from_f32<T>(best);
+    argmax[t] = arg;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(const T* __restrict__ gout,
+                                                                 const int32_t* __restrict__ argmax, int32_t H,
+                                                                 const int32_t* __restrict__ ptr, int64_t S,
+                                                                 T* __restrict__ gin) {
+    // one thread per (segment, column): walk the segment's rows, writing g or 0
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= S * H) return;
+    const int64_t s = t / H;
+    const int h = (int)(t % H);
+    const int beg = ptr[s], end = ptr[s + 1];
+    const int arg = argmax[t];
+    const T g = gout[t];
+    for (int i = beg; i < end; ++i) gin[(size_t)i * H + h] = (i == arg) ? g : from_f32<T>(0.f);
+}
+
+template <typename T>
+int segment_max(const T* in, int32_t H, const int32_t* ptr, int64_t S, T* out, int32_t* argmax, hipStream_t st) {
+    DN_REQUIRE(H > 0 && S >= 0, "dn_segment_max: bad sizes");
+    if (S == 0) return DN_OK;
+    DN_REQUIRE(ptr && out && argmax, "dn_segment_max: NULL pointer");
+    const int64_t grid = dn_cdiv(S * H, kBlock);
+    DN_REQUIRE(grid <= 0x7fffffffLL, "dn_segment_max: grid too large");
+    hipLaunchKernelGGL((segment_max_kernel<T>), dim3((unsigned)grid), dim3(kBlock), 0, st, in, H, ptr, S, out, argmax);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <typename T>
+int segment_max_bwd(const T* gout, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S, T* gin,
+                    hipStream_t st) {
+    DN_REQUIRE(H > 0 && S >= 0, "dn_segment_max_bwd: bad sizes");
+    if (S == 0) return DN_OK;
+    DN_REQUIRE(gout && argmax && ptr && gin, "dn_segment_max_bwd: NULL pointer");
+    const int64_t grid = dn_cdiv(S * H, kBlock);
+    DN_REQUIRE(grid <= 0x7fffffffLL, "dn_segment_max_bwd: grid too large");
+    hipLaunchKernelGGL((segment_max_bwd_kernel<T>), dim3((unsigned)grid), dim3(kBlock), 0, st, gout, argmax, H, ptr, S,
+                       gin);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dn_gather_segsum_f32(const float* in, int64_t in_rows, int32_t H, const int32_t* idx, const float* scale,
+                         const int32_t* ptr, int64_t S, int64_t M, float* out, const float* self_in, float self_coef,
+                         int32_t mean, dn_stream_t stream) {
+    return gather_segsum<float>(in, in_rows, H, idx, scale, ptr, S, M, out, self_in, self_coef, mean, (hipStream_t)stream);
+}
+int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int32_t* idx, const float* scale,
+                          const int32_t* ptr, int64_t S, int64_t M, void* out, const void* self_in, float self_coef,
+                          int32_t mean, dn_stream_t stream) {
+    return gather_segsum<bf16_t>((const bf16_t*)in, in_rows, H, idx, scale, ptr, S, M, (bf16_t*)out,
+                                 (const bf16_t*)self_in, self_coef, mean, (hipStream_t)stream);
+}
+
+static int64_t dn_rows_unknown() { return 0x7ffffffeLL; }
+
+int dn_segment_sum_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, dn_stream_t stream) {
+    DN_REQUIRE(ptr != nullptr || S == 0, "dn_segment_sum: ptr is NULL");
+    return gather_segsum<float>(in, dn_rows_unknown(), H, nullptr, nullptr, ptr, S, 0, out, nullptr, 0.f, 0,
+                                (hipStream_t)stream);
+}
+int dn_segment_sum_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, dn_stream_t stream) {
+    DN_REQUIRE(ptr != nullptr || S == 0, "dn_segment_sum: ptr is NULL");
+    return gather_segsum<bf16_t>((const bf16_t*)in, dn_rows_unknown(), H, nullptr, nullptr, ptr, S, 0, (bf16_t*)out,
+                                 nullptr, 0.f, 0, (hipStream_t)stream);
+}
+int dn_segment_mean_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, dn_stream_t stream) {
+    DN_REQUIRE(ptr != nullptr || S == 0, "dn_segment_mean: ptr is NULL");
+    return gather_segsum<float>(in, dn_rows_unknown(), H, nullptr, nullptr, ptr, S, 0, out, nullptr, 0.f, 1,
+                                (hipStream_t)stream);
+}
+int dn_segment_mean_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, dn_stream_t stream) {
+    DN_REQUIRE(ptr != nullptr || S == 0, "dn_segment_mean: ptr is NULL");
+    return gather_segsum<bf16_t>((const bf16_t*)in, dn_rows_unknown(), H, nullptr, nullptr, ptr, S, 0, (bf16_t*)out,
+                                 nullptr, 0.f, 1, (hipStream_t)stream);
+}
+int dn_segment_max_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, int32_t* argmax,
+                       dn_stream_t stream) {
+    return segment_max<float>(in, H, ptr, S, out, argmax, (hipStream_t)stream);
+}
+int dn_segment_max_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, int32_t* argmax,
+                        dn_stream_t stream) {
+    return segment_max<bf16_t>((const bf16_t*)in, H, ptr, S, (bf16_t*)out, argmax, (hipStream_t)stream);
+}
+int dn_segment_max_bwd_f32(const float* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
+                           float* grad_in, dn_stream_t stream) {
+    return segment_max_bwd<float>(grad_out, argmax, H, ptr, S, grad_in, (hipStream_t)stream);
+}
+int dn_segment_max_bwd_bf16(const void* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
+                            void* grad_in, dn_stream_t stream) {
+    return segment_max_bwd<bf16_t>((const bf16_t*)grad_out, argmax, H, ptr, S, (bf16_t*)grad_in, (hipStream_t)stream);
+}
+
+}  // extern "C"

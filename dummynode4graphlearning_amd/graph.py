@@ -1,0 +1,232 @@
+"""Batched-graph containers handed to the hot path (the boundary objects of SURVEY.md 8b).
+
+* ``BatchedGraph`` offers the subset of the DGL graph API that ``GraphAdjModel.forward`` and the
+  training loop touch (subgraph_isomorphism/models/basemodel.py:888-930, train.py:753-754,
+  dataset.py:1605-1611): ``.to()``, ``.batch_size``, ``.batch_num_nodes()``, ``.ndata/.edata`` with the key
+  strings of constants.py:12-35, ``number_of_nodes()``, ``in_degrees()`` ...  DGL itself is not used.
+* ``GraphBatch`` is the PyG-style batch the GC models read (graph_neural_networks/main.py:39-41,
+  dataset.py:130-137): ``x, edge_index, edge_attr, batch, y, is_dummy_node, is_dummy_edge``.
+
+Both cache the device-side CSR/segment indices (ops.EdgeIndex / ops.RelIndex) built once per batch.
+"""
+import torch
+
+from . import ops
+
+
+class _IndexCache:
+    def __init__(self):
+        self._edge_index = None
+        self._rel = []  # [(etype tensor, version, num_rels, RelIndex)]
+
+    def clear(self):
+        self._edge_index = None
+        self._rel = []
+
+
+class BatchedGraph:
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, batch_num_edges=None, ndata=None, edata=None):
+        self._src = torch.as_tensor(src).reshape(-1)
+        self._dst = torch.as_tensor(dst).reshape(-1)
+        self._n = int(num_nodes)
+        dev = self._src.device
+        self._bnn = (torch.as_tensor([self._n]) if batch_num_nodes is None else torch.as_tensor(batch_num_nodes)).to(dev).long()
+        self._bne = (torch.as_tensor([self._src.numel()]) if batch_num_edges is None
+                     else torch.as_tensor(batch_num_edges)).to(dev).long()
+        self.ndata = dict(ndata or {})
+        self.edata = dict(edata or {})
+        self._cache = _IndexCache()
+
+    # ---- DGL-like surface ---------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._src.device
+
+    @property
+    def batch_size(self):
+        return int(self._bnn.numel())
+
+    def batch_num_nodes(self):
+        return self._bnn
+
+    def batch_num_edges(self):
+        return self._bne
+
+    def number_of_nodes(self):
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self):
+        return int(self._src.numel())
+
+    num_edges = number_of_edges
+
+    def all_edges(self, form="uv", order="eid"):
+        if order != "eid":
+            raise NotImplementedError("only eid order is kept")
+        if form == "uv":
+            return self._src, self._dst
+        return self._src, self._dst, torch.arange(self._src.numel(), device=self.device)
+
+    edges = all_edges
+
+    def in_degrees(self):
+        if self._src.is_cuda:
+            return ops.degrees(self._src.to(torch.int32), self._dst.to(torch.int32), self._n)[0].long()
+        return torch.bincount(self._dst.long(), minlength=self._n)
+
+    def out_degrees(self):
+        if self._src.is_cuda:
+            return ops.degrees(self._src.to(torch.int32), self._dst.to(torch.int32), self._n)[1].long()
+        return torch.bincount(self._src.long(), minlength=self._n)
+
+    def to(self, device, non_blocking=False):
+        g = BatchedGraph(self._src.to(device, non_blocking=non_blocking), self._dst.to(device, non_blocking=non_blocking),
+                         self._n, self._bnn.to(device), self._bne.to(device),
+                         {k: v.to(device, non_blocking=non_blocking) for k, v in self.ndata.items()},
+                         {k: v.to(device, non_blocking=non_blocking) for k, v in self.edata.items()})
+        return g
+
+    def local_var(self):
+        return self
+
+    # ---- index structures consumed by the kernels -----------------------------------------------
+    def node_ptr(self):
+        z = torch.zeros(1, dtype=torch.long, device=self._bnn.device)
+        return torch.cat([z, torch.cumsum(self._bnn, 0)]).to(torch.int32)
+
+    def edge_ptr(self):
+        z = torch.zeros(1, dtype=torch.long, device=self._bne.device)
+        return torch.cat([z, torch.cumsum(self._bne, 0)]).to(torch.int32)
+
+    def edge_index(self):
+        if self._cache._edge_index is None:
+            self._cache._edge_index = ops.EdgeIndex(self._src, self._dst, self._n)
+        return self._cache._edge_index
+
+    def rel_index(self, etype, num_rels):
+        for t, ver, r, ix in self._cache._rel:
+            if t is etype and ver == etype._version and r == num_rels:
+                return ix
+        ix = ops.RelIndex(self._src, self._dst, etype, self._n, num_rels)
+        self._cache._rel.append((etype, etype._version, num_rels, ix))
+        if len(self._cache._rel) > 4:
+            self._cache._rel.pop(0)
+        return ix
+
+    # ---- dgl.batch (dataset.py:1321-1328, 1609-1610) ----------------------------------------------
+    @staticmethod
+    def batch(graphs):
+        """Disjoint union: concat features, offset node ids, keep per-graph sizes."""
+        srcs, dsts, bnn, bne = [], [], [], []
+        off = 0
+        for g in graphs:
+            srcs.append(g._src.long() + off)
+            dsts.append(g._dst.long() + off)
+            bnn.append(g._bnn)
+            bne.append(g._bne)
+            off += g._n
+        nd = {k: torch.cat([g.ndata[k] for g in graphs], 0) for k in graphs[0].ndata} if graphs else {}
+        ed = {k: torch.cat([g.edata[k] for g in graphs], 0) for k in graphs[0].edata} if graphs else {}
+        return BatchedGraph(torch.cat(srcs), torch.cat(dsts), off, torch.cat(bnn), torch.cat(bne), nd, ed)
+
+
+class GraphBatch:
+    """PyG-style mini-batch (torch_geometric.data.Batch look-alike) for the GC models."""
+
+    def __init__(self, x, edge_index, batch=None, edge_attr=None, y=None, is_dummy_node=None, is_dummy_edge=None,
+                 ptr=None, num_graphs=None):
+        self.x, self.edge_index, self.edge_attr, self.y = x, edge_index, edge_attr, y
+        self.is_dummy_node, self.is_dummy_edge = is_dummy_node, is_dummy_edge
+        if batch is None:
+            batch = torch.zeros(x.shape[0], dtype=torch.long, device=x.device)
+        self.batch = batch
+        if ptr is None:
+            ng = int(num_graphs) if num_graphs is not None else (int(batch.max().item()) + 1 if batch.numel() else 0)
+            cnt = torch.bincount(batch, minlength=ng)
+            ptr = torch.cat([torch.zeros(1, dtype=torch.long, device=cnt.device), torch.cumsum(cnt, 0)])
+        self.ptr = ptr
+        self._cache = _IndexCache()
+
+    @property
+    def num_graphs(self):
+        return int(self.ptr.numel() - 1)
+
+    @property
+    def num_nodes(self):
+        return int(self.x.shape[0])
+
+    def to(self, device, non_blocking=False):
+        mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
+        return GraphBatch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.edge_attr), mv(self.y),
+                          mv(self.is_dummy_node), mv(self.is_dummy_edge), mv(self.ptr))
+
+    @staticmethod
+    def collate(items):
+        """PyG DataLoader collate (main.py:245-247): concat x, offset edge_index, build batch/ptr."""
+        xs, eis, eas, ys, dn, de, bs = [], [], [], [], [], [], []
+        off = 0
+        ptr = [0]
+        for i, d in enumerate(items):
+            n = d.x.shape[0]
+            xs.append(d.x)
+            eis.append(d.edge_index + off)
+            if d.edge_attr is not None:
+                eas.append(d.edge_attr)
+            if d.y is not None:
+                ys.append(d.y.reshape(-1))
+            if d.is_dummy_node is not None:
+                dn.append(d.is_dummy_node)
+            if d.is_dummy_edge is not None:
+                de.append(d.is_dummy_edge)
+            bs.append(torch.full((n,), i, dtype=torch.long))
+            off += n
+            ptr.append(off)
+        cat = lambda l, dim=0: torch.cat(l, dim) if l else None  # noqa: E731
+        return GraphBatch(cat(xs), cat(eis, 1), cat(bs), cat(eas), cat(ys), cat(dn), cat(de),
+                          torch.tensor(ptr, dtype=torch.long))
+
+
+def graph_ptr_i32(data):
+    """int32 node ranges per graph of a PyG-style batch (uses .ptr when present, else derives it from .batch)."""
+    p = getattr(data, "ptr", None)
+    if p is None:
+        b = data.batch
+        ng = int(b.max().item()) + 1 if b.numel() else 0
+        cnt = torch.bincount(b, minlength=ng)
+        p = torch.cat([torch.zeros(1, dtype=torch.long, device=cnt.device), torch.cumsum(cnt, 0)])
+    return p.to(device=data.x.device, dtype=torch.int32)
+
+
+def edge_index_of(data):
+    """Cached ops.EdgeIndex of a PyG-style batch (edge_index row 0 = src, row 1 = dst)."""
+    cache = getattr(data, "_cache", None)
+    if cache is None:
+        cache = _IndexCache()
+        try:
+            data._cache = cache
+        except Exception:
+            pass
+    if cache._edge_index is None or cache._edge_index.num_edges != data.edge_index.shape[1]:
+        cache._edge_index = ops.EdgeIndex(data.edge_index[0], data.edge_index[1], data.x.shape[0])
+    return cache._edge_index
+
+
+def rel_index_of(data, etype, num_rels):
+    cache = getattr(data, "_cache", None)
+    if cache is None:
+        cache = _IndexCache()
+        try:
+            data._cache = cache
+        except Exception:
+            pass
+    for t, ver, r, ix in cache._rel:
+        if (t is etype or (t.data_ptr() == etype.data_ptr() and t.numel() == etype.numel())) and ver == etype._version \
+                and r == num_rels:
+            return ix
+    ix = ops.RelIndex(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels)
+    cache._rel.append((etype, etype._version, num_rels, ix))
+    if len(cache._rel) > 4:
+        cache._rel.pop(0)
+    return ix

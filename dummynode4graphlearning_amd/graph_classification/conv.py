@@ -1,0 +1,103 @@
+"""Conv / readout building blocks the GC models take from torch-geometric 2.0.2, re-implemented on the
+MI355X hot path (torch-geometric is a third-party dependency that is not part of the reference tree:
+README.md:26; layer definitions restated from its published documentation -- see oracle/layers.py).
+
+  GINConv   x_i' = nn((1 + eps) x_i + sum_{j->i} x_j)                    call site gconv.py:197,212
+  RGCNConv  x_i' = sum_r aggr_{j in N_r(i)} x_j W_r + x_i root + bias      call sites rgconv.py:17-18,96
+  global_add_pool / global_mean_pool / global_max_pool                    call sites gconv.py:53,95,148,210,213
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..graph import edge_index_of, graph_ptr_i32, rel_index_of
+
+
+def _reset(module):
+    """torch_geometric.nn.inits.reset: re-initialise every child that has reset_parameters (GINConv does this to
+    its nn at construction, which consumes RNG a second time -- mimicked for initial-weight parity)."""
+    children = list(module.children()) if hasattr(module, "children") else []
+    for item in (children if children else [module]):
+        if hasattr(item, "reset_parameters"):
+            item.reset_parameters()
+
+
+class GINConv(nn.Module):
+    def __init__(self, nn_module, eps=0.0, train_eps=False):
+        super().__init__()
+        self.nn = nn_module
+        self.initial_eps = float(eps)
+        if train_eps:
+            self.eps = nn.Parameter(torch.tensor([float(eps)]))
+        else:
+            self.register_buffer("eps", torch.tensor([float(eps)]))
+        self.train_eps = bool(train_eps)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _reset(self.nn)
+        with torch.no_grad():
+            self.eps.fill_(self.initial_eps)
+
+    def forward(self, x, data):
+        index = edge_index_of(data)
+        if self.train_eps:
+            # gradient w.r.t. eps flows through the torch add; neighbours through the HIP gather
+            out = ops.neighbor_sum(x, index, 0.0) + (1.0 + self.eps.to(x.dtype)) * x
+        else:
+            out = ops.neighbor_sum(x, index, 1.0 + float(self.initial_eps))
+        return self.nn(out)
+
+
+class RGCNConv(nn.Module):
+    def __init__(self, in_channels, out_channels, num_relations, aggr="mean", root_weight=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_relations, self.aggr = in_channels, out_channels, num_relations, aggr
+        self.weight = nn.Parameter(torch.empty(num_relations, in_channels, out_channels))
+        if root_weight:
+            self.root = nn.Parameter(torch.empty(in_channels, out_channels))
+        else:
+            self.register_parameter("root", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for w in (self.weight, self.root):  # glorot: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))
+            if w is not None:
+                a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
+                nn.init.uniform_(w, -a, a)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, x, data, edge_type):
+        index = rel_index_of(data, edge_type, self.num_relations)
+        scale = None
+        if self.aggr == "mean":
+            # mean over the (rel, dst) segment == constant per-edge weight 1 / |segment|
+            cnt = (index.seg_ptr[1:] - index.seg_ptr[:-1]).to(torch.float32)
+            seg_of_edge = torch.empty(index.num_edges, dtype=torch.long, device=x.device)
+            seg_of_edge[index.operm.long()] = index.seg_by_src.long()
+            scale = (1.0 / cnt).index_select(0, seg_of_edge)
+        out = ops.rel_agg_transform(x, self.weight, index, edge_scale=scale)
+        if self.root is not None:
+            out = out + x @ self.root
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+def global_add_pool(x, data):
+    return ops.segment_reduce(x, graph_ptr_i32(data), "sum")
+
+
+def global_mean_pool(x, data):
+    return ops.segment_reduce(x, graph_ptr_i32(data), "mean")
+
+
+def global_max_pool(x, data):
+    return ops.segment_reduce(x, graph_ptr_i32(data), "max")

@@ -1,0 +1,158 @@
+"""GIN / RGCN / RGIN graph classifiers with the reference's constructor (``Model(args)``), attribute and
+state_dict names and ``forward(data) -> log-probs`` surface, running their message passing and readouts on
+the MI355X HIP path.
+
+reference: graph_classification/graph_neural_networks/models/gconv.py:154-215 (GIN) and
+rgconv.py:6-126 (RGCN, RGIN; not exported there and reading ``args.nhid`` -- here ``nhid`` falls back to
+``args.hidden_dim``).
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn import BatchNorm1d, Linear, ReLU, Sequential
+
+from .conv import GINConv, RGCNConv, global_add_pool, global_mean_pool
+
+
+def _pooling(config):
+    kind = config.get("aggregation", "sum")
+    if kind == "sum":
+        return global_add_pool
+    if kind == "mean":
+        return global_mean_pool
+    raise ValueError("aggregation must be 'sum' or 'mean'")
+
+
+def _mlp(in_dim, out_dim):
+    return Sequential(Linear(in_dim, out_dim), BatchNorm1d(out_dim), ReLU(),
+                      Linear(out_dim, out_dim), BatchNorm1d(out_dim), ReLU())
+
+
+def _edge_type(data, x):
+    edge_attr = getattr(data, "edge_attr", None)
+    if edge_attr is not None:
+        return edge_attr.max(dim=1)[1]                              # rgconv.py:35-36,110-111
+    return torch.zeros(data.edge_index.size(1), dtype=torch.long, device=x.device)
+
+
+class GIN(torch.nn.Module):
+    def __init__(self, args):
+        super(GIN, self).__init__()
+        self.args = args
+        self.num_features = args.num_features
+        self.hidden_dim = args.hidden_dim
+        self.num_classes = args.num_classes
+        self.dropout = args.dropout_ratio
+
+        if getattr(args, "additional", None):
+            config = args.additional
+        else:
+            config = {"train_eps": False, "num_layers": 2, "aggregation": "sum"}
+        self.pooling = _pooling(config)
+        train_eps = config.get("train_eps", getattr(args, "epochs", False))      # gconv.py:179 (sic)
+
+        self.embeddings_dim = [self.hidden_dim for _ in range(config.get("num_layers", 2))]
+        self.no_layers = len(self.embeddings_dim)
+        nns, convs, linears = [], [], []
+        for layer, out_emb_dim in enumerate(self.embeddings_dim):
+            if layer == 0:
+                self.first_h = _mlp(self.num_features, out_emb_dim)
+                linears.append(Linear(out_emb_dim, self.num_classes))
+            else:
+                nns.append(_mlp(self.embeddings_dim[layer - 1], out_emb_dim))
+                convs.append(GINConv(nns[-1], train_eps=bool(train_eps)))
+                linears.append(Linear(out_emb_dim, self.num_classes))
+        self.nns = torch.nn.ModuleList(nns)
+        self.convs = torch.nn.ModuleList(convs)
+        self.linears = torch.nn.ModuleList(linears)
+
+    def forward(self, data):
+        x = data.x
+        out = 0
+        for layer in range(self.no_layers):
+            if layer == 0:
+                x = self.first_h(x)
+                out = out + F.dropout(self.pooling(self.linears[layer](x), data), p=self.dropout)   # always on (sic)
+            else:
+                x = self.convs[layer - 1](x, data)
+                out = out + F.dropout(self.linears[layer](self.pooling(x, data)), p=self.dropout, training=self.training)
+        return F.log_softmax(out, dim=-1)
+
+
+class RGCN(torch.nn.Module):
+    def __init__(self, args):
+        super(RGCN, self).__init__()
+        self.args = args
+        self.num_features = args.num_features
+        self.nhid = getattr(args, "nhid", None) or args.hidden_dim
+        self.num_classes = args.num_classes
+        self.dropout_ratio = args.dropout_ratio
+        self.num_relations = args.num_relations
+
+        self.conv1 = RGCNConv(self.num_features, self.nhid, self.num_relations)
+        self.conv2 = RGCNConv(self.nhid, self.nhid, self.num_relations)
+        config = getattr(args, "additional", None)
+        if config and "weight_reg" in config and config["weight_reg"] > 1.1:
+            with torch.no_grad():
+                self.conv1.weight.div_(config["weight_reg"])
+                self.conv2.weight.div_(config["weight_reg"])
+        self.lin1 = Linear(self.nhid, self.nhid)
+        self.lin2 = Linear(self.nhid, self.nhid // 2)
+        self.lin3 = Linear(self.nhid // 2, self.num_classes)
+
+    def forward(self, data):
+        x = data.x
+        edge_type = _edge_type(data, x)
+        x = F.relu(self.conv1(x, data, edge_type))
+        x = F.relu(self.conv2(x, data, edge_type))
+        x = global_mean_pool(x, data)
+        x = F.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+        x = F.relu(self.lin2(x))
+        x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+        return F.log_softmax(self.lin3(x), dim=-1)
+
+
+class RGIN(torch.nn.Module):
+    def __init__(self, args):
+        super(RGIN, self).__init__()
+        self.args = args
+        self.num_features = args.num_features
+        self.nhid = getattr(args, "nhid", None) or args.hidden_dim
+        self.num_classes = args.num_classes
+        self.dropout = args.dropout_ratio
+        self.num_relations = args.num_relations
+
+        config = args.additional if getattr(args, "additional", None) else {"num_layers": 2}
+        self.pooling = _pooling(config)
+        self.embeddings_dim = [self.nhid for _ in range(config.get("num_layers", 2))]
+        self.no_layers = len(self.embeddings_dim)
+        nns, convs, linears = [], [], []
+        for layer, out_emb_dim in enumerate(self.embeddings_dim):
+            if layer == 0:
+                self.first_h = _mlp(self.num_features, out_emb_dim)
+                linears.append(Linear(out_emb_dim, self.num_classes))
+            else:
+                nns.append(_mlp(self.embeddings_dim[layer - 1], out_emb_dim))
+                convs.append(RGCNConv(self.nhid, self.nhid, self.num_relations, aggr="add"))      # rgconv.py:96
+                linears.append(Linear(out_emb_dim, self.num_classes))
+        if "weight_reg" in config and config["weight_reg"] > 1.1:
+            with torch.no_grad():
+                for conv in convs:
+                    conv.weight.div_(config["weight_reg"])
+        self.nns = torch.nn.ModuleList(nns)
+        self.convs = torch.nn.ModuleList(convs)
+        self.linears = torch.nn.ModuleList(linears)
+
+    def forward(self, data):
+        x = data.x
+        edge_type = _edge_type(data, x)
+        out = 0
+        for layer in range(self.no_layers):
+            if layer == 0:
+                x = self.first_h(x)
+                out = out + F.dropout(self.pooling(self.linears[layer](x), data), p=self.dropout)
+            else:
+                x = self.convs[layer - 1](x, data, edge_type)
+                x = self.nns[layer - 1](x)
+                out = out + F.dropout(self.linears[layer](self.pooling(x, data)), p=self.dropout, training=self.training)
+        return F.log_softmax(out, dim=-1)

@@ -1,0 +1,2 @@
+from .rgcn import RGCNLayer, RGCNRepNet  # noqa: F401
+from .rgin import RGINLayer, RGINRepNet  # noqa: F401

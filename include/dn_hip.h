@@ -1,0 +1,180 @@
+/* dn_hip.h -- C ABI of libdn_hip.so: the MI355X (gfx950) hot path of
+ * HKUST-KnowComp/DummyNode4GraphLearning (dummy-node / edge-to-vertex index builds and the
+ * gather -> segment-reduce message passing of the GIN / RGCN / RGIN layers).
+ *
+ * The reference has NO C/FFI interface for this path: the arithmetic runs inside third-party
+ * engines (DGL update_all / torch-scatter) behind Python nn.Modules.  The entry
+ * points below are therefore exactly what a ctypes binding on the reference side would bind in
+ * place of those engine calls; each one cites the reference call site it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*.
+ *   - the caller (PyTorch) owns every buffer: inputs, outputs and workspace; the library never
+ *     allocates, frees or retains a pointer.  Workspace sizes come from *_workspace_bytes().
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing else orders it.
+ *   - return 0 on success, <0 on error (DN_ERR_*); dn_last_error() gives the thread-local message.
+ *   - re-entrant, no global mutable state, deterministic: no floating-point atomics anywhere,
+ *     every sum has a fixed order (bitwise reproducible run to run).
+ *   - node / edge ids are int32 on the device (N, E < 2^31); the Python boundary converts the
+ *     reference's int64 ids.
+ *   - feature matrices are row-major [rows, H]; `_f32` = float, `_bf16` = bfloat16 storage with
+ *     fp32 accumulation.
+ */
+#ifndef DN_HIP_H
+#define DN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_OK 0
+#define DN_ERR_ARG (-1)
+#define DN_ERR_HIP (-2)
+#define DN_ERR_WORKSPACE (-3)
+#define DN_ERR_UNSUPPORTED (-4)
+
+typedef void* dn_stream_t; /* hipStream_t */
+
+int dn_version(void);
+const char* dn_last_error(void);
+/* Returns 0 iff `device_ptr` is device memory known to the HIP runtime this library resolved to
+ * (guards against a second libamdhip64 being loaded next to PyTorch's). */
+int dn_runtime_probe(const void* device_ptr);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather + segment-sum (the message-passing core).
+ *   out[s,:] = self_coef * self_in[s,:] + sum_{i in [ptr[s], ptr[s+1])} scale[i] * in[idx[i],:]
+ * idx == NULL -> idx[i] = i;  ptr == NULL -> segment s = {s} (pure row gather, S == M);
+ * scale == NULL -> 1;  self_in == NULL -> no self term.  M = number of gathered elements.
+ * mean != 0 divides the gathered sum (not the self term) by the segment length (0 for empty segments).
+ * Replaces: PyG GINConv.propagate / RGCNConv.propagate = x.index_select(0, src) + torch_scatter
+ *   (graph_classification/graph_neural_networks/models/gconv.py:212, rgconv.py:40-41,121) and
+ *   DGL update_all(msg, fn.sum) (subgraph_isomorphism/models/rgin.py:159, rgcn.py:196).
+ * The backward of this operator w.r.t. `in` is the same call on the transposed index.
+ * ------------------------------------------------------------------------------------------ */
+int dn_gather_segsum_f32(const float* in, int64_t in_rows, int32_t H, const int32_t* idx,
+                         const float* scale, const int32_t* ptr, int64_t S, int64_t M, float* out,
+                         const float* self_in, float self_coef, int32_t mean, dn_stream_t stream);
+int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int32_t* idx,
+                          const float* scale, const int32_t* ptr, int64_t S, int64_t M, void* out,
+                          const void* self_in, float self_coef, int32_t mean, dn_stream_t stream);
+
+/* Per-graph readouts over CONTIGUOUS rows: out[g,:] = reduce_{v in [ptr[g], ptr[g+1])} in[v,:].
+ * Replaces: torch_geometric global_add_pool / global_mean_pool / global_max_pool
+ *   (gconv.py:53,95,148,210,213; rgconv.py:42,119,124) and SI SumPredictNet's sum over the padded
+ *   node dimension (subgraph_isomorphism/models/pred.py:215-216).
+ * mean: empty segments give 0.  max: empty segments give 0 and argmax -1; ties keep the lowest row
+ *   (argmax [S,H] int32 is the row index, used by dn_segment_max_bwd_*). */
+int dn_segment_sum_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, dn_stream_t stream);
+int dn_segment_sum_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, dn_stream_t stream);
+int dn_segment_mean_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, dn_stream_t stream);
+int dn_segment_mean_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, dn_stream_t stream);
+int dn_segment_max_f32(const float* in, int32_t H, const int32_t* ptr, int64_t S, float* out, int32_t* argmax,
+                       dn_stream_t stream);
+int dn_segment_max_bf16(const void* in, int32_t H, const int32_t* ptr, int64_t S, void* out, int32_t* argmax,
+                        dn_stream_t stream);
+/* grad_in[v,h] = (argmax[g(v),h] == v) ? grad_out[g(v),h] : 0, rows of segment g contiguous. */
+int dn_segment_max_bwd_f32(const float* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
+                           float* grad_in, dn_stream_t stream);
+int dn_segment_max_bwd_bf16(const void* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
+                            void* grad_in, dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot device-side index builds.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Stable grouping of element indices by integer key in [0, num_keys):
+ *   ptr[k] .. ptr[k+1] = positions in `perm` of the elements with key k, ascending element index.
+ * This is the CSR/CSC build DGL / torch-scatter perform internally for the call sites above. */
+size_t dn_csr_build_workspace_bytes(int64_t M, int64_t num_keys);
+int dn_csr_build_i32(const int32_t* key, int64_t M, int64_t num_keys, int32_t* ptr /*[num_keys+1]*/,
+                     int32_t* perm /*[M]*/, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
+/* Dummy-node augmentation of a batched graph (disjoint union; node_ptr/edge_ptr [G+1]; src/dst global
+ * ids; edges of a graph contiguous in eid order).  Outputs: N' = N + G nodes, E' = E + 2N edges.
+ * GC layout -- replaces load_graph_data_from_TUDatadir(with_dummy=True)'s per-graph igraph build
+ *   (graph_classification/data_processing/tu_data_processing.py:186-200,213-214): dummy vertex n with
+ *   label 0; edges = m originals then INTERLEAVED (n,v),(v,n), label 0, IS_DUMMY 1; ids = local index. */
+int dn_dummy_augment_gc_i32(int64_t G, int64_t N, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                            const int32_t* src, const int32_t* dst, const int32_t* node_label,
+                            const int32_t* edge_label, int32_t* out_node_ptr, int32_t* out_edge_ptr,
+                            int32_t* out_src, int32_t* out_dst, int32_t* out_node_label, int32_t* out_edge_label,
+                            uint8_t* out_is_dummy_node, uint8_t* out_is_dummy_edge, int32_t* out_node_id,
+                            int32_t* out_edge_id, dn_stream_t stream);
+/* SI layout -- replaces add_dummy_nodes_edges, GraphAdj branch (subgraph_isomorphism/train.py:404-474):
+ *   dummy node (id = max_nv, label = max_nvl); 2n edges BLOCKED: all (u -> dummy) then all (dummy -> u);
+ *   edge id max_ne / max_ne+1; relation max_nel / max_nel+1; is_dummy 1; is_reversed 0 / 1.
+ *   in_is_reversed may be NULL (treated as 0). */
+int dn_dummy_augment_si_i32(int64_t G, int64_t N, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                            const int32_t* src, const int32_t* dst, const int32_t* node_id,
+                            const int32_t* node_label, const int32_t* edge_id, const int32_t* edge_label,
+                            const uint8_t* in_is_reversed, int32_t max_nv, int32_t max_nvl, int32_t max_ne,
+                            int32_t max_nel, int32_t* out_node_ptr, int32_t* out_edge_ptr, int32_t* out_src,
+                            int32_t* out_dst, int32_t* out_node_id, int32_t* out_node_label,
+                            int32_t* out_edge_id, int32_t* out_edge_label, uint8_t* out_is_dummy_node,
+                            uint8_t* out_is_dummy_edge, uint8_t* out_is_reversed, dn_stream_t stream);
+
+/* Edge-to-vertex ("conjugate") transform L_Phi of a batched graph.
+ * Replaces convert_conjugate_graph_forward (tu_data_processing.py:223-338; mode DN_CONJ_GC, and
+ * DN_CONJ_LINE for graphs without the IS_DUMMY attribute) and convert_conjugate_graph, igraph branch
+ * (subgraph_isomorphism/utils/graph.py:177-267; mode DN_CONJ_SI).  Bit-exact incl. output order.
+ *   step 1  dn_conjugate_count_i32: *host_num_raw = sum_e in_deg(src(e)) (synchronises the stream).
+ *   step 2  dn_conjugate_build_i32: outputs sized by the upper bounds N'<=E, E'<=num_raw;
+ *           host_counts[0] = N' (conj vertices), host_counts[1] = E' (conj edges) (synchronises).
+ *   rep_edge[k]    input edge whose attributes conj-vertex k copies (first edge carrying that id)
+ *   shared_node[t] input vertex whose attributes conj-edge t copies (the vertex the 2-path goes through)
+ *   edge_id: per-graph edge ids (SI: edata["id"], dummies share ids); NULL = local edge index (GC). */
+#define DN_CONJ_GC 0
+#define DN_CONJ_SI 1
+#define DN_CONJ_LINE 2
+/* num_raw = -1 sizes the workspace for the count step only. */
+size_t dn_conjugate_workspace_bytes(int64_t G, int64_t N, int64_t E, int64_t num_raw);
+int dn_conjugate_count_i32(int64_t N, int64_t E, const int32_t* src, const int32_t* dst, int64_t* host_num_raw,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_conjugate_build_i32(int32_t mode, int64_t G, int64_t N, int64_t E, int64_t num_raw,
+                           const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* src,
+                           const int32_t* dst, const int32_t* node_label, const int32_t* edge_id,
+                           const uint8_t* is_dummy_edge, int32_t* out_cnode_ptr /*[G+1]*/,
+                           int32_t* out_cedge_ptr /*[G+1]*/, int32_t* out_csrc /*[num_raw]*/,
+                           int32_t* out_cdst /*[num_raw]*/, int32_t* out_rep_edge /*[E]*/,
+                           int32_t* out_shared_node /*[num_raw]*/, int64_t* host_counts /*[2]*/,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
+/* Relation-aware segment index for the aggregate-then-transform form of the RGCN/RGIN message pass
+ *   sum_e x[src_e] W[etype_e]  ==  sum_r ( sum_{e in r, dst=v} x[src_e] ) W_r      
+ * which replaces the reference's per-edge weight gather + bmm (subgraph_isomorphism/models/rgin.py:102-120,
+ * rgcn.py:100-122) and PyG RGCNConv's per-relation mask/propagate loop (rgconv.py:17-18,96).
+ * Segments p = distinct (rel, dst) pairs, ordered by (rel, dst); P = number of segments (<= E).
+ *   perm1 [E]      edge ids sorted by (rel, dst), stable;  src1 [E] = src[perm1]
+ *   seg_ptr [P+1]  (allocate E+1) edge range of each segment in perm1 order;  seg_dst [P] (allocate E)
+ *   rel_ptr [R+1]  segment range of each relation (also copied to host_rel_ptr)
+ *   dptr [N+1], sperm [P] (allocate E)   segments grouped by destination, ascending relation
+ *   optr [N+1], operm [E]                edges grouped by source, ascending edge id
+ *   seg_by_src [E]                       segment of edge operm[i]
+ * Synchronises the stream (P and rel_ptr are returned to the host). */
+size_t dn_rel_index_workspace_bytes(int64_t N, int64_t R, int64_t E);
+int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, const int32_t* dst,
+                           const int32_t* etype, int32_t* perm1, int32_t* src1, int32_t* seg_ptr,
+                           int32_t* seg_dst, int32_t* rel_ptr, int32_t* dptr, int32_t* sperm, int32_t* optr,
+                           int32_t* operm, int32_t* seg_by_src, int64_t* host_P, int32_t* host_rel_ptr,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
+/* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
+ * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg
+ * (0 for isolated), same for out; edge norm = in_norm[dst] ("in", mode 1) or
+ * sqrt(out_norm[src]*in_norm[dst]) ("both", mode 2).  Any output may be NULL. */
+int dn_edge_norm_f32(int32_t mode, int32_t self_loop, int64_t N, int64_t E, const int32_t* src,
+                     const int32_t* dst, const int32_t* in_deg, const int32_t* out_deg, float* in_norm,
+                     float* out_norm, float* edge_norm, dn_stream_t stream);
+/* in_deg / out_deg by counting (graph.in_degrees() / out_degrees(), rgcn.py:134,144). */
+int dn_degrees_i32(int64_t N, int64_t E, const int32_t* src, const int32_t* dst, int32_t* in_deg,
+                   int32_t* out_deg, dn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DN_HIP_H */

@@ -1,0 +1,152 @@
+"""GPU parity of the segment kernels and CSR build against the oracle (CPU torch / numpy), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as OL
+from oracle import transforms as OT
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from dummynode4graphlearning_amd import ops
+    return ops
+
+
+def _rand_csr(rng, S, M_avg, in_rows, skew=True):
+    deg = rng.poisson(M_avg, size=S)
+    deg[rng.integers(0, S, size=max(1, S // 10))] = 0          # empty segments
+    if skew and S > 2:
+        deg[rng.integers(0, S)] = 40 * max(M_avg, 1) + 3            # one dummy-like long segment
+    ptr = np.zeros(S + 1, dtype=np.int64)
+    np.cumsum(deg, out=ptr[1:])
+    idx = rng.integers(0, in_rows, size=int(ptr[-1]))
+    return ptr, idx
+
+
+def _ref_gather_segsum(x, idx, ptr, scale=None, self_in=None, self_coef=0.0, mean=False):
+    S = len(ptr) - 1
+    seg = torch.repeat_interleave(torch.arange(S), torch.as_tensor(np.diff(ptr)))
+    rows = x[torch.as_tensor(idx)] if idx is not None else x[: int(ptr[-1])]
+    if scale is not None:
+        rows = rows * scale.view(-1, 1)
+    out = OL.segment_sum(rows.double(), seg, S)
+    if mean:
+        cnt = torch.as_tensor(np.diff(ptr)).clamp(min=1).double().view(-1, 1)
+        out = out / cnt
+    if self_in is not None:
+        out = out + self_coef * self_in.double()
+    return out
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("H", [2, 5, 8, 64, 128, 256, 260, 520])
+def test_gather_segsum_matches_oracle(dtype, tol, H):
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    rows, S = 300, 257
+    ptr, idx = _rand_csr(rng, S, 3, rows)
+    x = torch.from_numpy(rng.standard_normal((rows, H)).astype(np.float32)).to(dtype)
+    scale = torch.from_numpy(rng.uniform(0.2, 1.5, size=len(idx)).astype(np.float32))
+    self_in = torch.from_numpy(rng.standard_normal((S, H)).astype(np.float32)).to(dtype)
+    xd, idxd, ptrd = x.to(DEV), torch.from_numpy(idx).to(DEV, torch.int32), torch.from_numpy(ptr).to(DEV, torch.int32)
+    for use_scale, use_self, mean in [(False, False, False), (True, False, False), (False, True, False),
+                                      (True, True, True), (False, False, True)]:
+        got = ops.gather_segsum(xd, idxd, ptrd, scale=scale.to(DEV) if use_scale else None,
+                                self_in=self_in.to(DEV) if use_self else None, self_coef=1.25 if use_self else 0.0,
+                                mean=mean)
+        ref = _ref_gather_segsum(x.float(), idx, ptr, scale if use_scale else None,
+                                 self_in.float() if use_self else None, 1.25, mean)
+        # tolerance: fp32 accumulate; bf16 differs only by the final rounding of the stored row (2^-8 rel)
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())) * 0.5)
+
+
+def test_gather_rows_and_contiguous_segments():
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((100, 64)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 100, size=333)).to(torch.int32)
+    got = ops.gather_segsum(x.to(DEV), idx.to(DEV), None)                        # ptr == NULL: pure row gather
+    torch.testing.assert_close(got.cpu(), x[idx.long()], rtol=0, atol=0)
+    ptr = torch.tensor([0, 10, 10, 55, 100], dtype=torch.int32)
+    got = ops.gather_segsum(x.to(DEV), None, ptr.to(DEV))                        # idx == NULL: contiguous rows
+    ref = torch.stack([x[0:10].sum(0), torch.zeros(64), x[10:55].sum(0), x[55:100].sum(0)])
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_segsum_is_bitwise_deterministic():
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    ptr, idx = _rand_csr(rng, 5000, 4, 4000)
+    x = torch.from_numpy(rng.standard_normal((4000, 128)).astype(np.float32)).to(DEV)
+    idxd, ptrd = torch.from_numpy(idx).to(DEV, torch.int32), torch.from_numpy(ptr).to(DEV, torch.int32)
+    a = ops.gather_segsum(x, idxd, ptrd)
+    for _ in range(3):
+        b = ops.gather_segsum(x, idxd, ptrd)
+        assert torch.equal(a, b)
+
+
+def test_empty_inputs():
+    ops = _ops()
+    x = torch.zeros((0, 64), device=DEV)
+    ptr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert ops.gather_segsum(x, torch.zeros(0, dtype=torch.int32, device=DEV), ptr).shape == (0, 64)
+    ptr = torch.zeros(4, dtype=torch.int32, device=DEV)                          # 3 empty segments
+    out = ops.gather_segsum(torch.ones((5, 8), device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV), ptr)
+    assert torch.equal(out.cpu(), torch.zeros(3, 8))
+
+
+@pytest.mark.parametrize("M,K", [(0, 7), (1, 1), (1000, 37), (50000, 1200), (4096, 100000)])
+def test_csr_build_bit_exact(M, K):
+    ops = _ops()
+    rng = np.random.default_rng(M + K)
+    key = rng.integers(0, K, size=M)
+    ptr, perm = ops.csr_build(torch.from_numpy(key).to(DEV, torch.int32), K)
+    rptr, rperm = OT.csr_by_key(key, K)
+    np.testing.assert_array_equal(ptr.cpu().numpy(), rptr)
+    np.testing.assert_array_equal(perm.cpu().numpy(), rperm)
+
+
+@pytest.mark.parametrize("kind", ["sum", "mean", "max"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H", [2, 7, 64])
+def test_segment_readouts_forward_backward(kind, dtype, H):
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    sizes = np.array([3, 0, 17, 1, 40, 0, 9])
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    N, B = int(ptr[-1]), len(sizes)
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dtype)
+    coef = torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)).to(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.segment_reduce(xd, torch.from_numpy(ptr).to(DEV, torch.int32), kind)
+    (out.float() * coef.to(DEV).float()).sum().backward()
+    xr = x.float().requires_grad_(True)
+    batch = torch.repeat_interleave(torch.arange(B), torch.from_numpy(sizes))
+    ref = OL.global_pool(xr, batch, B, {"sum": "add"}.get(kind, kind))
+    (ref * coef.float()).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 1.6e-2
+    torch.testing.assert_close(out.detach().cpu().float(), ref.detach(), rtol=tol, atol=tol)
+    torch.testing.assert_close(xd.grad.cpu().float(), xr.grad, rtol=tol, atol=tol)
+
+
+def test_neighbor_sum_autograd_matches_oracle():
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    N, E, H = 200, 900, 64
+    src, dst = rng.integers(0, N, size=E), rng.integers(0, N, size=E)
+    dst[:150] = 7                                                                # dummy-like hub
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+    coef = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+    index = ops.EdgeIndex(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV), N)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.neighbor_sum(xd, index, 1.5)
+    (out * coef.to(DEV)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref = OL.gin_conv(xr, torch.from_numpy(src), torch.from_numpy(dst), 0.5, lambda t: t)
+    (ref * coef).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,188 @@
+"""GPU parity (bit-exact) of the device-side index builds against the golden fixtures captured from the
+reference and against the oracle on larger random batches.  All calls go through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transforms as OT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _T():
+    from dummynode4graphlearning_amd import transforms
+    return transforms
+
+
+def _d(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.int64)).to(DEV)
+
+
+def _eq(got, ref, msg=""):
+    np.testing.assert_array_equal(got.cpu().numpy().astype(np.int64), np.asarray(ref, dtype=np.int64), err_msg=msg)
+
+
+def _check_conj(cj, ref, msg):
+    for k in ("cnode_ptr", "cedge_ptr", "csrc", "cdst", "rep_edge", "shared_node"):
+        _eq(cj[k], ref[k], msg + " " + k)
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _batch_from_dumps(dumps):
+    node_ptr, edge_ptr, src, dst = [0], [0], [], []
+    for d in dumps:
+        base = node_ptr[-1]
+        src.extend(base + u for u, _ in d["edges"])
+        dst.extend(base + v for _, v in d["edges"])
+        node_ptr.append(base + d["vcount"])
+        edge_ptr.append(len(src))
+    return np.array(node_ptr), np.array(edge_ptr), np.array(src, dtype=np.int64), np.array(dst, dtype=np.int64)
+
+
+def test_gc_pipeline_matches_reference_goldens(golden_dir):
+    T = _T()
+    for case in _load(golden_dir, "gc_transforms.json"):
+        raw = OT.tu_raw_to_batch(case["A"], case["graph_indicator"], case["node_labels"], case["edge_labels"])
+        aug = T.dummy_augment_gc(*(_d(raw[k]) for k in ("node_ptr", "edge_ptr", "src", "dst", "node_label", "edge_label")))
+        # against the reference's dumped igraph objects
+        rn, re, rs, rd = _batch_from_dumps(case["dummy"])
+        _eq(aug["node_ptr"], rn), _eq(aug["edge_ptr"], re), _eq(aug["src"], rs), _eq(aug["dst"], rd)
+        _eq(aug["node_label"], sum((d["v_LABEL"] for d in case["dummy"]), []))
+        _eq(aug["edge_label"], sum((d["e_LABEL"] for d in case["dummy"]), []))
+        _eq(aug["is_dummy_edge"], sum((d["e_IS_DUMMY"] for d in case["dummy"]), []))
+        _eq(aug["is_dummy_node"], sum((d["v_IS_DUMMY"] for d in case["dummy"]), []))
+        _eq(aug["edge_id"], sum((d["e_ID"] for d in case["dummy"]), []))
+        _eq(aug["node_id"], sum((d["v_ID"] for d in case["dummy"]), []))
+        for tag, b, mode in (("plain", {k: _d(v) for k, v in raw.items()}, "line"), ("dummy", aug, "gc")):
+            cj = T.conjugate(b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], b["node_label"],
+                             is_dummy_edge=b.get("is_dummy_edge"), mode=mode)
+            rn, re, rs, rd = _batch_from_dumps(case[tag + "_conj"])
+            msg = "%s %s" % (case["name"], tag)
+            _eq(cj["cnode_ptr"], rn, msg), _eq(cj["cedge_ptr"], re, msg), _eq(cj["csrc"], rs, msg), _eq(cj["cdst"], rd, msg)
+            el = b["edge_label"].cpu().numpy()
+            nl = b["node_label"].cpu().numpy()
+            np.testing.assert_array_equal(el[cj["rep_edge"].cpu().numpy()],
+                                          sum((d["v_LABEL"] for d in case[tag + "_conj"]), []), err_msg=msg)
+            np.testing.assert_array_equal(nl[cj["shared_node"].cpu().numpy()],
+                                          sum((d.get("e_LABEL", []) for d in case[tag + "_conj"]), []), err_msg=msg)
+
+
+def _dgl_batch(items, key):
+    node_ptr, edge_ptr, src, dst, nd, ed = [0], [0], [], [], {}, {}
+    for x in items:
+        d = x[key]
+        base = node_ptr[-1]
+        src.extend(base + u for u in d["u"])
+        dst.extend(base + v for v in d["v"])
+        node_ptr.append(base + d["num_nodes"])
+        edge_ptr.append(len(src))
+        for k, v in d.items():
+            if k.startswith("n_"):
+                nd.setdefault(k[2:], []).extend(v)
+            elif k.startswith("e_"):
+                ed.setdefault(k[2:], []).extend(v)
+    return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, src=src, dst=dst, n=nd, e=ed)
+
+
+def test_si_pipeline_matches_reference_goldens(golden_dir):
+    T = _T()
+    g = _load(golden_dir, "si_transforms.json")
+    vocab = g["vocab"]
+    for key, mv, mvl, me, mel in (("graph", "max_ngv", "max_ngvl", "max_nge", "max_ngel"),
+                                  ("pattern", "max_npv", "max_npvl", "max_npe", "max_npel")):
+        b, a = _dgl_batch(g["before"], key), _dgl_batch(g["after"], key)
+        aug = T.dummy_augment_si(_d(b["node_ptr"]), _d(b["edge_ptr"]), _d(b["src"]), _d(b["dst"]), _d(b["n"]["id"]),
+                                 _d(b["n"]["label"]), _d(b["e"].get("id", [])), _d(b["e"].get("label", [])),
+                                 vocab[mv], vocab[mvl], vocab[me], vocab[mel])
+        for k in ("node_ptr", "edge_ptr", "src", "dst"):
+            _eq(aug[k], a[k], key + " " + k)
+        _eq(aug["node_id"], a["n"]["id"]), _eq(aug["node_label"], a["n"]["label"])
+        _eq(aug["is_dummy_node"], a["n"]["is_dummy"]), _eq(aug["edge_id"], a["e"]["id"])
+        _eq(aug["edge_label"], a["e"]["label"]), _eq(aug["is_dummy_edge"], a["e"]["is_dummy"])
+        _eq(aug["is_reversed"], a["e"]["is_reversed"])
+        cj = T.conjugate(aug["node_ptr"], aug["edge_ptr"], aug["src"], aug["dst"], aug["node_label"],
+                         edge_id=aug["edge_id"], mode="si")
+        rn, re, rs, rd = _batch_from_dumps([row[key] for row in g["conj"]])
+        _eq(cj["cnode_ptr"], rn, key), _eq(cj["cedge_ptr"], re, key), _eq(cj["csrc"], rs, key), _eq(cj["cdst"], rd, key)
+        eid = aug["edge_id"].cpu().numpy()
+        np.testing.assert_array_equal(eid[cj["rep_edge"].cpu().numpy()], sum((row[key]["v_id"] for row in g["conj"]), []))
+        nl = aug["node_label"].cpu().numpy()
+        np.testing.assert_array_equal(nl[cj["shared_node"].cpu().numpy()],
+                                      sum((row[key].get("e_label", []) for row in g["conj"]), []))
+    # KAT-2 literal
+    i, o = g["kat2"]["in"], g["kat2"]["out"]
+    cj = T.conjugate(_d([0, 5]), _d([0, len(i["edges"])]), _d([e[0] for e in i["edges"]]), _d([e[1] for e in i["edges"]]),
+                     _d(i["v_label"]), edge_id=_d(i["e_id"]), mode="si")
+    assert [list(x) for x in zip(cj["csrc"].tolist(), cj["cdst"].tolist())] == o["edges"]
+
+
+def _random_batch(rng, G, max_n, multi=True, empty_frac=0.1):
+    node_ptr, edge_ptr, src, dst = [0], [0], [], []
+    for g in range(G):
+        n = int(rng.integers(0 if rng.random() < 0.05 else 1, max_n + 1))
+        m = 0 if (n == 0 or rng.random() < empty_frac) else int(rng.integers(1, 3 * n + 1))
+        base = node_ptr[-1]
+        if m > 0:
+            src.extend((base + rng.integers(0, n, size=m)).tolist())
+            dst.extend((base + rng.integers(0, n, size=m)).tolist())
+        node_ptr.append(base + n)
+        edge_ptr.append(len(src))
+    N, E = node_ptr[-1], len(src)
+    return dict(node_ptr=np.array(node_ptr), edge_ptr=np.array(edge_ptr), src=np.array(src, dtype=np.int64),
+                dst=np.array(dst, dtype=np.int64), node_label=rng.integers(1, 5, size=N),
+                edge_label=rng.integers(1, 4, size=E))
+
+
+@pytest.mark.parametrize("seed,G,max_n", [(0, 1, 6), (1, 64, 14), (2, 400, 30)])
+def test_gc_random_batches_match_oracle(seed, G, max_n):
+    T = _T()
+    rng = np.random.default_rng(seed)
+    b = _random_batch(rng, G, max_n)
+    ref = OT.dummy_augment_gc(b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], b["node_label"], b["edge_label"])
+    got = T.dummy_augment_gc(*(_d(b[k]) for k in ("node_ptr", "edge_ptr", "src", "dst", "node_label", "edge_label")))
+    for k in ref:
+        _eq(got[k], ref[k], k)
+    for mode, bb, dflag in (("gc", ref, ref["is_dummy_edge"]), ("line", b, None)):
+        rcj = OT.conjugate(bb["node_ptr"], bb["edge_ptr"], bb["src"], bb["dst"], bb["node_label"], is_dummy_edge=dflag, mode=mode)
+        gcj = T.conjugate(_d(bb["node_ptr"]), _d(bb["edge_ptr"]), _d(bb["src"]), _d(bb["dst"]), _d(bb["node_label"]),
+                          is_dummy_edge=None if dflag is None else _d(dflag), mode=mode)
+        _check_conj(gcj, rcj, "seed %d mode %s" % (seed, mode))
+
+
+@pytest.mark.parametrize("seed,G,max_n", [(3, 1, 5), (4, 50, 12), (5, 300, 20)])
+def test_si_random_batches_match_oracle(seed, G, max_n):
+    T = _T()
+    rng = np.random.default_rng(seed)
+    b = _random_batch(rng, G, max_n)
+    N, E = b["node_ptr"][-1], len(b["src"])
+    nid = np.arange(N) - np.repeat(b["node_ptr"][:-1], np.diff(b["node_ptr"]))
+    eid = np.arange(E) - np.repeat(b["edge_ptr"][:-1], np.diff(b["edge_ptr"]))
+    # duplicate some edge ids inside graphs (reversed-edge style sharing) to exercise the vertex merge
+    dup = rng.random(E) < 0.15
+    eid = np.where(dup, np.maximum(eid - 1, 0), eid)
+    rev = (rng.random(E) < 0.3).astype(np.int64)
+    args = (b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], nid, b["node_label"], eid, b["edge_label"])
+    ref = OT.dummy_augment_si(*args, 99, 7, 500, 9, is_reversed=rev)
+    got = T.dummy_augment_si(*(_d(a) for a in args), 99, 7, 500, 9, is_reversed=_d(rev))
+    for k in ref:
+        _eq(got[k], ref[k], k)
+    rcj = OT.conjugate(ref["node_ptr"], ref["edge_ptr"], ref["src"], ref["dst"], ref["node_label"],
+                       edge_id=ref["edge_id"], mode="si")
+    gcj = T.conjugate(got["node_ptr"], got["edge_ptr"], got["src"], got["dst"], got["node_label"],
+                      edge_id=got["edge_id"], mode="si")
+    _check_conj(gcj, rcj, "seed %d" % seed)
+
+
+def test_conjugate_of_empty_batch():
+    T = _T()
+    z = _d([])
+    cj = T.conjugate(_d([0, 3, 3]), _d([0, 0, 0]), z, z, _d([1, 1, 1]), mode="line")
+    assert cj["cnode_ptr"].tolist() == [0, 0, 0] and cj["csrc"].numel() == 0
