@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- edges/s forward+backward of one dummy-augmented RGIN conv layer on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): BASELINE.json configs[4] = SURVEY.md 8(d) config 5, the one the metric is quoted on
+(fits one GPU): synthetic SI-style batch of 32 768 graphs x (30+1) nodes, 62 real + 60 dummy edges, R = 16
+=> N = 1 015 808, E = 3 997 696 per GPU; RGINLayer(256, 256, basis, full) in bf16 storage / fp32 accumulate.
+Weak scaling: every rank processes its own batch of that size (seed 5 + rank); the only collective is the flat
+gradient all-reduce (RCCL).  A step = layer forward + backward (dx and all parameter gradients) + all-reduce,
+inputs resident in HBM; the one-shot index build of the batch is outside the timed region and reported separately.
+
+Rank 0 prints ONE JSON line with `roofline` (gather/segment-sum kernel, HIP events on the launch stream) and
+`cpu_baseline` (oracle port timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_batch(dev, seed, graphs, workload):
+    from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
+    raw = synthetic.config5(seed, graphs) if workload == "config5" else synthetic.config3(seed, graphs)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    aug = transforms.dummy_augment_si(t["node_ptr"], t["edge_ptr"], t["src"], t["dst"], t["node_id"], t["node_label"],
+                                      t["edge_id"], t["edge_label"], raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    torch.cuda.synchronize()
+    aug_ms = (time.perf_counter() - t0) * 1e3
+    N = int(aug["node_label"].numel())
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, ndata={"id": aug["node_id"], "label": aug["node_label"]},
+                     edata={"id": aug["edge_id"], "label": aug["edge_label"]})
+    return g, raw, aug_ms
+
+
+def cpu_baseline(raw, H, R, budget_s=12.0, sample_graphs=1024):
+    """Oracle port (aggregate-then-transform restatement of RGINLayer, fp32, torch CPU) on a bounded sample."""
+    from oracle import layers as OL
+    from oracle import transforms as OT
+    G = min(sample_graphs, len(raw["node_ptr"]) - 1)
+    n1, e1 = int(raw["node_ptr"][G]), int(raw["edge_ptr"][G])
+    aug = OT.dummy_augment_si(raw["node_ptr"][:G + 1], raw["edge_ptr"][:G + 1], raw["src"][:e1], raw["dst"][:e1],
+                              raw["node_id"][:n1], raw["node_label"][:n1], raw["edge_id"][:e1], raw["edge_label"][:e1],
+                              raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N, E = len(aug["node_label"]), len(aug["src"])
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, H, generator=g).requires_grad_(True)
+    p = {"weight": (torch.randn(R, H, H, generator=g) * 0.05).requires_grad_(True),
+         "loop_weight": (torch.randn(H, H, generator=g) * 0.05).requires_grad_(True),
+         "bias": torch.zeros(H, requires_grad=True),
+         "mlp.0.weight": (torch.randn(H, H, generator=g) * 0.05).requires_grad_(True), "mlp.0.bias": torch.zeros(H, requires_grad=True),
+         "mlp.2.weight": (torch.randn(H, H, generator=g) * 0.05).requires_grad_(True), "mlp.2.bias": torch.zeros(H, requires_grad=True)}
+    src, dst, et = (torch.from_numpy(aug[k]) for k in ("src", "dst", "edge_label"))
+    gout = torch.randn(N, H, generator=g)
+
+    def one():
+        out = OL.rgin_layer_agg_first(x, src, dst, et, p, R, act="relu", num_mlp_layers=2)
+        out.backward(gout)
+        x.grad = None
+        for t in p.values():
+            t.grad = None
+
+    one()
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        one()
+        it += 1
+        if time.perf_counter() - t0 > budget_s or it >= 50:
+            break
+    dt = (time.perf_counter() - t0) / it
+    return {"value": E / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "first %d graphs of the same batch (N=%d, E=%d), fp32, %d iterations of oracle.layers.rgin_layer_agg_first "
+                      "fwd+bwd" % (G, N, E, it)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config5", choices=["config5", "config3"])
+    ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (0 = the workload's own size)")
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dummynode4graphlearning_amd import ops
+    from dummynode4graphlearning_amd.parallel import FlatGradBucket
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+
+    if args.workload == "config5":
+        H, R, graphs, dtype = 256, 16, args.graphs or 32768, torch.bfloat16
+    else:
+        H, R, graphs, dtype = 64, 8, args.graphs or 512, torch.float32
+    if args.dtype:
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    s = 2 if dtype == torch.bfloat16 else 4
+
+    g, raw, aug_ms = build_batch(dev, {"config5": 5, "config3": 3}[args.workload] + rank, graphs, args.workload)
+    N, E = g.number_of_nodes(), g.number_of_edges()
+    etype = g.edata["label"]
+    torch.manual_seed(1234)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(dev).to(dtype)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    x = torch.randn(N, H, device=dev, generator=gen).to(dtype).requires_grad_(True)
+    gout = torch.randn(N, H, device=dev, generator=gen).to(dtype)
+    bucket = FlatGradBucket(layer.parameters())
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = g.rel_index(etype, R)
+    torch.cuda.synchronize()
+    index_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        bucket.zero()
+        x.grad = None
+        out, _ = layer(g, x, etype)
+        out.backward(gout)
+        bucket.all_reduce()
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.kernel_timer = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # roofline of the gather/segment-sum kernel: algorithmic bytes of the layer's gather-scatter forward+backward
+    # (2*(E*H*s + N*H*s + 8*E)) over the time all its launches take per step (HIP events)
+    ksum = timer.summary().get("gather_segsum", (0, 0.0))
+    launches_per_step = ksum[0] / max(args.steps, 1)
+    alg_bytes_step = 2.0 * (E * H * s + N * H * s + 8.0 * E)
+    kernel_ms_step = ksum[1] / max(args.steps, 1)
+    achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": world * E / (ms_per_step * 1e-3),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd on %d graphs/GPU (N=%d, E=%d per GPU), "
+                                   "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
+                       "global_edges": world * E, "parallelism": "dp%d" % world,
+                       "segments_P": index.num_segments, "index_build_ms": index_ms, "dummy_augment_ms": aug_ms,
+                       "grad_bucket_bytes": bucket.bytes()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gather_segsum_vec_kernel", "launches_per_step": launches_per_step,
+                         "kernel_ms_per_step": kernel_ms_step, "alg_bytes_per_step": alg_bytes_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(raw, H, R)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,51 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
     return in_norm.view(-1, 1), (out_norm.view(-1, 1) if out_norm is not None else None), en
 
 
+WGRAD_CHUNK_ROWS = 4096
+
+
+def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
+    """Split relation-major rows into chunks for dn_rows_wgrad_bf16: (chunks [C,4] int32, chunk_ptr [R+1] int32)."""
+    chunk_rows = chunk_rows or WGRAD_CHUNK_ROWS
+    chunks, cptr = [], [0]
+    for r in range(len(rel_ptr_host) - 1):
+        a, b = rel_ptr_host[r], rel_ptr_host[r + 1]
+        while a < b:
+            e = min(a + chunk_rows, b)
+            chunks.append((r, a, e, 0))
+            a = e
+        cptr.append(len(chunks))
+    ch = torch.tensor(chunks if chunks else [(0, 0, 0, 0)], dtype=I32).reshape(-1, 4)
+    return ch.to(device), torch.tensor(cptr, dtype=I32).to(device), len(chunks)
+
+
+def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None):
+    """out[r] = sum_{p in relation r} A[idx_a[p]]^T G[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 inputs, fp32 accumulate)."""
+    chunks, chunk_ptr, nchunks = chunk_table
+    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr)
+    assert A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
+    Hi, Ho = A.shape[1], G.shape[1]
+    out_dtype = out_dtype or A.dtype
+    out = torch.empty((num_rels, Hi, Ho), dtype=out_dtype, device=A.device)
+    ws = _ws(lib().dn_rows_wgrad_workspace_bytes(nchunks, Hi, Ho), A.device)
+
+    def _launch():
+        check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(idx_a), ptr(G), ptr(idx_g), Hi, Ho, num_rels, ptr(chunks), nchunks,
+                                       ptr(chunk_ptr), ptr(out), 1 if out_dtype == torch.float32 else 0, ptr(ws),
+                                       ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
+
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_wgrad", _launch)
+    else:
+        _launch()
+    return out
+
+
+def wgrad_supported(A, G):
+    return (A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16 and A.shape[1] == G.shape[1]
+            and A.shape[1] in (64, 128, 256))
+
+
 # ----------------------------------------------------------------------------------------------
 # index structures
 # ----------------------------------------------------------------------------------------------
@@ -193,6 +238,7 @@ class RelIndex:
         self.rel_ptr_host = [int(v) for v in host_rel]
         self.perm1, self.src1 = self.perm1[:E], self.src1[:E]
         self.operm, self.seg_by_src = self.operm[:E], self.seg_by_src[:E]
+        self.chunk_table = make_row_chunks(self.rel_ptr_host, dev)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -269,11 +315,15 @@ class _RelAggTransform(torch.autograd.Function):
             gA = _grouped_mm(gY, W, ix.rel_ptr_host, transpose_w=True)                  # [P, in]
             gx = gather_segsum(gA, ix.seg_by_src, ix.optr, ix.num_nodes, scale=ctx.sc_src)
         if ctx.needs_input_grad[1]:
-            gW = torch.zeros_like(W)
-            for r in range(W.shape[0]):
-                a, b = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
-                if b > a:
-                    torch.mm(A[a:b].t(), gY[a:b], out=gW[r])
+            if wgrad_supported(A, g):
+                # MFMA split-K kernel; gathers the g rows itself (idx_g = segment destinations)
+                gW = rows_wgrad(A, g, ix.chunk_table, W.shape[0], idx_g=ix.seg_dst, out_dtype=W.dtype)
+            else:
+                gW = torch.zeros_like(W)
+                for r in range(W.shape[0]):
+                    a, b = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
+                    if b > a:
+                        torch.mm(A[a:b].t(), gY[a:b], out=gW[r])
         return gx, gW, None, None
 
 

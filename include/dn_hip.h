@@ -163,6 +163,20 @@ int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
                            int32_t* operm, int32_t* seg_by_src, int64_t* host_P, int32_t* host_rel_ptr,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
+ *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
+ * Replaces autograd's backward of the reference's per-edge `th.bmm(x[src], W[etype])`
+ * (subgraph_isomorphism/models/rgin.py:109-110,117-118) / PyG RGCNConv's `h @ weight[i]` (rgconv.py:96).
+ * Rows are relation-major; the caller splits them into row chunks {rel, beg, end, 0} (int32 x4 each, any chunk
+ * inside one relation, chunks of a relation contiguous: chunk_ptr [R+1]).  One workgroup per chunk accumulates the
+ * whole Hi x Ho tile; partials (workspace, fp32 [num_chunks, Hi, Ho]) are then added in chunk order: deterministic.
+ * idx_a / idx_g may be NULL (row p itself).  Supported: Hi == Ho in {64, 128, 256}.  out is fp32 or bf16. */
+size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
+int dn_rows_wgrad_bf16(const void* A, const int32_t* idx_a, const void* G, const int32_t* idx_g, int32_t Hi,
+                       int32_t Ho, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                       const int32_t* chunk_ptr, void* out, int32_t out_is_f32, void* workspace,
+                       size_t workspace_bytes, dn_stream_t stream);
+
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg
  * (0 for isolated), same for out; edge norm = in_norm[dst] ("in", mode 1) or

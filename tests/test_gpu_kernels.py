@@ -150,3 +150,34 @@ def test_neighbor_sum_autograd_matches_oracle():
     (ref * coef).sum().backward()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_rows_wgrad_matches_reference(H):
+    """MFMA split-K weight gradient: out[r] = sum_p A[ia[p]]^T G[ig[p]] (asymmetric data: catches transposed tiles)."""
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    R = 5
+    sizes = [0, 37, 5000, 1, 9001]                      # empty relation, tiny, multi-chunk, single row, ragged tail
+    rel_ptr = [0] + list(np.cumsum(sizes))
+    P, NA, NG = rel_ptr[-1], 3000, 2500
+    A = torch.from_numpy(rng.standard_normal((NA, H)).astype(np.float32)).to(torch.bfloat16)
+    G = torch.from_numpy(rng.standard_normal((NG, H)).astype(np.float32)).to(torch.bfloat16)
+    ia = torch.from_numpy(rng.integers(0, NA, size=P)).to(torch.int32)
+    ig = torch.from_numpy(rng.integers(0, NG, size=P)).to(torch.int32)
+    table = ops.make_row_chunks([int(v) for v in rel_ptr], DEV, chunk_rows=2048)
+    got = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), out_dtype=torch.float32)
+    ref = torch.zeros(R, H, H, dtype=torch.float64)
+    for r in range(R):
+        a, b = rel_ptr[r], rel_ptr[r + 1]
+        ref[r] = A[ia[a:b].long()].double().t() @ G[ig[a:b].long()].double()
+    # bf16 products are exact in fp32; only the fp32 accumulation order differs
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-3)
+    got2 = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), out_dtype=torch.float32)
+    assert torch.equal(got, got2)                        # deterministic
+    # contiguous rows (no index) + bf16 output
+    P2 = min(P, NA, NG)
+    t2 = ops.make_row_chunks([0, P2], DEV, chunk_rows=1024)
+    got3 = ops.rows_wgrad(A[:P2].contiguous().to(DEV), G[:P2].contiguous().to(DEV), t2, 1)
+    ref3 = A[:P2].double().t() @ G[:P2].double()
+    torch.testing.assert_close(got3[0].cpu().double(), ref3, rtol=1e-2, atol=0.5)
