@@ -136,7 +136,7 @@ def main():
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    index = g.rel_index(etype, R)
+    index = g.row_index(etype, R, True) if dtype == torch.bfloat16 else g.rel_index(etype, R)
     torch.cuda.synchronize()
     index_ms = (time.perf_counter() - t0) * 1e3
 
@@ -170,8 +170,10 @@ def main():
 
     # roofline of the gather/segment-sum kernel: algorithmic bytes of the layer's gather-scatter forward+backward
     # (2*(E*H*s + N*H*s + 8*E)) over the time all its launches take per step (HIP events)
-    ksum = timer.summary().get("gather_segsum", (0, 0.0))
+    summ = timer.summary()
+    ksum = summ.get("gather_segsum", (0, 0.0))
     launches_per_step = ksum[0] / max(args.steps, 1)
+    other = {k: v[1] / max(args.steps, 1) for k, v in summ.items() if k != "gather_segsum"}
     alg_bytes_step = 2.0 * (E * H * s + N * H * s + 8.0 * E)
     kernel_ms_step = ksum[1] / max(args.steps, 1)
     achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
@@ -185,12 +187,13 @@ def main():
             "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd on %d graphs/GPU (N=%d, E=%d per GPU), "
                                    "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
                        "global_edges": world * E, "parallelism": "dp%d" % world,
-                       "segments_P": index.num_segments, "index_build_ms": index_ms, "dummy_augment_ms": aug_ms,
+                       "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms, "dummy_augment_ms": aug_ms,
                        "grad_bucket_bytes": bucket.bytes()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "gather_segsum_vec_kernel", "launches_per_step": launches_per_step,
-                         "kernel_ms_per_step": kernel_ms_step, "alg_bytes_per_step": alg_bytes_step},
+                         "kernel_ms_per_step": kernel_ms_step, "alg_bytes_per_step": alg_bytes_step,
+                         "other_hip_kernels_ms_per_step": other},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw, H, R)

@@ -20,7 +20,7 @@ typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWgThreads = 512;  // 8 waves: 2 (rows of the output tile) x 4 (columns)
-constexpr int kTileRows = 32;    // K-step of one MFMA 16x16x32
+constexpr int kTileRows = 64;    // rows staged per iteration (two MFMA 16x16x32 K-steps)
 constexpr int kPad = 8;          // bf16 elements of row padding in LDS
 
 struct Chunk {
@@ -41,11 +41,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int stride, int co
 // partial[chunk][k][n] = sum_{p in chunk} A[ia[p]][k] * G[ig[p]][n]
 template <int HI, int HO>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __restrict__ A,
+                                                                const bf16_t* __restrict__ A2, int32_t na1,
                                                                 const int32_t* __restrict__ ia,
                                                                 const bf16_t* __restrict__ G,
+                                                                const bf16_t* __restrict__ G2, int32_t ng1,
                                                                 const int32_t* __restrict__ ig,
                                                                 const Chunk* __restrict__ chunks,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, int32_t colsum_of,
+                                                                float* __restrict__ colsum_partial) {
     constexpr int SA = HI + kPad, SG = HO + kPad;
     constexpr int MT = HI / 2 / 16, NT = HO / 4 / 16;           // 16x16 tiles per wave
     constexpr int NPA = kTileRows * HI / 8, NPG = kTileRows * HO / 8;   // 16-byte pieces per tile
@@ -69,6 +72,15 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[PA], rg[PG];
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of my 8 columns (colsum_of != 0)
+    auto add_cs = [&](const uint4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cs[2 * i] += __uint_as_float(w[i] << 16);
+            cs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+        }
+    };
     auto load_tile = [&](int t) {
         const int row0 = ch.beg + t * kTileRows;
 #pragma unroll
@@ -77,8 +89,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
             const int p = row0 + r;
             ra[j] = make_uint4(0, 0, 0, 0);
             if (piece < NPA && p < ch.end) {
-                const size_t src = ia ? (size_t)ia[p] : (size_t)p;
-                ra[j] = *reinterpret_cast<const uint4*>(A + src * HI + c * 8);
+                const int src = ia ? ia[p] : p;
+                const bf16_t* base = src < na1 ? A + (size_t)src * HI : A2 + (size_t)(src - na1) * HI;
+                ra[j] = *reinterpret_cast<const uint4*>(base + c * 8);
             }
         }
 #pragma unroll
@@ -87,8 +100,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
             const int p = row0 + r;
             rg[j] = make_uint4(0, 0, 0, 0);
             if (piece < NPG && p < ch.end) {
-                const size_t src = ig ? (size_t)ig[p] : (size_t)p;
-                rg[j] = *reinterpret_cast<const uint4*>(G + src * HO + c * 8);
+                const int src = ig ? ig[p] : p;
+                const bf16_t* base = src < ng1 ? G + (size_t)src * HO : G2 + (size_t)(src - ng1) * HO;
+                rg[j] = *reinterpret_cast<const uint4*>(base + c * 8);
             }
         }
     };
@@ -97,11 +111,13 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
         for (int j = 0; j < PA; ++j) {
             const int piece = tid + j * kWgThreads, r = piece / (HI / 8), c = piece % (HI / 8);
             if (piece < NPA) *reinterpret_cast<uint4*>(bufA(b) + r * SA + c * 8) = ra[j];
+            if (colsum_of == 1 && piece < NPA) add_cs(ra[j]);
         }
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const int piece = tid + j * kWgThreads, r = piece / (HO / 8), c = piece % (HO / 8);
             if (piece < NPG) *reinterpret_cast<uint4*>(bufG(b) + r * SG + c * 8) = rg[j];
+            if (colsum_of == 2 && piece < NPG) add_cs(rg[j]);
         }
     };
 
@@ -113,14 +129,18 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
     for (int t = 0; t < ntiles; ++t) {
         const int b = t & 1;
         if (t + 1 < ntiles) load_tile(t + 1);                    // global loads in flight under the MFMAs
-        bf16x8 fb[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[n] = tr_frag(bufG(b), SG, n0 + n * 16, lane);
+        for (int kk = 0; kk < kTileRows / 32; ++kk) {
+            bf16x8 fb[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bf16x8 fa = tr_frag(bufA(b), SA, k0 + m * 16, lane);
+            for (int n = 0; n < NT; ++n) fb[n] = tr_frag(bufG(b) + kk * 32 * SG, SG, n0 + n * 16, lane);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 fa = tr_frag(bufA(b) + kk * 32 * SA, SA, k0 + m * 16, lane);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+            }
         }
         if (t + 1 < ntiles) store_tile(b ^ 1);
         __syncthreads();
@@ -136,15 +156,211 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                 const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
                 out[(size_t)k * HO + c] = acc[m][n][i];
             }
+    if (colsum_of != 0) {
+        // every thread owns column chunk (tid % (H/8)) in all of its pieces: fold the threads of a chunk through LDS
+        constexpr int HC = HI;                                  // square: HI == HO
+        constexpr int TPC = kWgThreads / (HC / 8);              // threads per column chunk
+        float* red = reinterpret_cast<float*>(lds);             // tile buffers are dead after the last barrier
+        const int cchunk = tid % (HC / 8), slot = tid / (HC / 8);
+        if (kTileRows * HC / 8 >= kWgThreads || tid < kTileRows * HC / 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[(slot * HC) + cchunk * 8 + i] = cs[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[(slot * HC) + cchunk * 8 + i] = 0.f;
+        }
+        __syncthreads();
+        if (tid < HC) {
+            float sum = 0.f;
+            for (int sl = 0; sl < TPC; ++sl) sum += red[sl * HC + tid];
+            colsum_partial[(size_t)blockIdx.x * HC + tid] = sum;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dn_rows_transform_bf16:   Y[p, :] = epi( X[idx[p], :] @ Wn[rel(p)]^T )          (rows p relation-major)
+//   Wn[r] is [HO][HI] (k contiguous), i.e. Y[p][n] = sum_k X[idx[p]][k] * Wn[r][n][k].
+//   One workgroup (4 waves) walks a contiguous range of 32-row tiles (tile table: {rel, beg, end}); each wave
+//   owns a 64-column slice of the output and keeps ITS slice of Wn[rel] in registers (128 VGPRs), reloading it
+//   only when the relation changes.  Per tile: the 32 gathered rows (16 B per lane, 32 lanes per row) are staged
+//   registers -> LDS one tile ahead (the gather of tile t+1 is in flight under tile t's MFMAs, its row indices
+//   two tiles ahead), fragments come from LDS with ds_read_b128 (rows padded by 16 B: conflict-free), the MFMA
+//   computes the TRANSPOSED tile (A operand = weights, B operand = rows) so that each lane ends up with 4
+//   consecutive output columns of one row, and the finished tile goes through LDS to be written as whole
+//   512-byte rows.
+// -------------------------------------------------------------------------------------------------
+constexpr int kTfThreads = 512;   // 8 waves, each owning HO/8 output columns
+constexpr int kTfRows = 32;
+
+template <int HI, int HO>
+__global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
+    const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const Chunk* __restrict__ tiles,
+    int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
+    constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
+    constexpr int SY = HO + kPad;                   // ... of the output tile
+    constexpr int KS = HI / 32;                     // k-steps
+    constexpr int NT = (HO / 8 + 15) / 16;          // 16-col tiles per wave (waves beyond HO/16 idle in the MFMA part)
+    constexpr int MT = kTfRows / 16;
+    constexpr int NPX = kTfRows * HI / 8;           // 16-byte pieces of an input tile
+    constexpr int PX = (NPX + kTfThreads - 1) / kTfThreads;
+    constexpr int NPY = kTfRows * HO / 8;
+    constexpr int PY = (NPY + kTfThreads - 1) / kTfThreads;
+    static_assert(NT >= 1 && KS >= 1, "unsupported width");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kTfRows * SX + kTfRows * SY];
+    auto bufX = [&](int b) -> bf16_t* { return lds + b * (kTfRows * SX); };
+    bf16_t* bufY = lds + 2 * kTfRows * SX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * (NT * 16);
+    const bool wave_active = n0 < HO;
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    bf16x8 wf[KS][NT];                              // this wave's slice of Wn[rel]: A operand fragments
+    int cur_rel = -1;
+    int32_t nidx[PX];                               // source row of each of my pieces, for the tile being loaded
+    uint4 rx[PX];
+
+    auto load_idx = [&](int t) {
+        if (t >= t_end) return;
+        const Chunk tl = tiles[t];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int piece = tid + j * kTfThreads, r = piece / (HI / 8);
+            const int p = tl.beg + r;
+            nidx[j] = -1;
+            if (piece < NPX && p < tl.end) nidx[j] = idx ? idx[p] : p;
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int piece = tid + j * kTfThreads, c = piece % (HI / 8);
+            rx[j] = make_uint4(0, 0, 0, 0);
+            if (nidx[j] >= 0) {
+                const bf16_t* base = nidx[j] < n1 ? X + (size_t)nidx[j] * HI : X2 + (size_t)(nidx[j] - n1) * HI;
+                rx[j] = *reinterpret_cast<const uint4*>(base + c * 8);
+            }
+        }
+    };
+    auto store_rows = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int piece = tid + j * kTfThreads, r = piece / (HI / 8), c = piece % (HI / 8);
+            if (piece < NPX) *reinterpret_cast<uint4*>(bufX(b) + r * SX + c * 8) = rx[j];
+        }
+    };
+
+    load_idx(t_beg);
+    load_rows();
+    store_rows(0);
+    load_idx(t_beg + 1);
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        const Chunk tl = tiles[t];
+        if (t + 1 < t_end) load_rows();             // gather of tile t+1 (indices were fetched one tile earlier)
+        if (tl.rel != cur_rel && wave_active) {     // (re)load this wave's weight slice: wave-uniform branch
+            cur_rel = tl.rel;
+            const bf16_t* w = Wn + (size_t)cur_rel * HO * HI;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[ks][nt] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * HI + ks * 32 +
+                                                                  8 * (lane >> 4));
+        }
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xt = bufX(b);
+        if (wave_active) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 xf[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                xf[m] = *reinterpret_cast<const bf16x8*>(xt + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], xf[m], acc[m][n], 0, 0, 0);
+        }
+        // D = Wn_slice x rows^T : lane holds row m = mt*16 + (lane&15), columns n0 + nt*16 + 4*(lane>>4) + i
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = n0 + n * 16 + 4 * (lane >> 4);
+                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (bias) {
+                    const bf16_t* bp = bias + (size_t)cur_rel * HO + col;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bp[i];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+                *reinterpret_cast<bf16x4*>(bufY + (m * 16 + (lane & 15)) * SY + col) = o;
+            }
+        }
+        if (t + 1 < t_end) store_rows(b ^ 1);
+        load_idx(t + 2);
+        __syncthreads();
+        // whole rows out: 16 B per lane, HO/8 lanes per row
+#pragma unroll
+        for (int j = 0; j < PY; ++j) {
+            const int piece = tid + j * kTfThreads, r = piece / (HO / 8), c = piece % (HO / 8);
+            const int p = tl.beg + r;
+            if (piece < NPY && p < tl.end)
+                *reinterpret_cast<uint4*>(Y + (size_t)p * HO + c * 8) = *reinterpret_cast<const uint4*>(bufY + r * SY + c * 8);
+        }
+        // bufY is rewritten only after the next tile's MFMAs and its barrier-separated store: add a barrier here so no
+        // wave overwrites bufY (next iteration's epilogue) while a slower wave still reads it
+        __syncthreads();
+    }
+}
+
+template <int HI, int HO>
+int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_t* idx, const bf16_t* Wn, const bf16_t* bias,
+                     int32_t relu, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
+    // ~2 workgroups per CU; contiguous tile ranges keep a workgroup inside one relation most of the time
+    const int64_t max_wg = 256 * 2;
+    const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
+    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    hipLaunchKernelGGL((rows_transform_kernel<HI, HO>), dim3((unsigned)grid), dim3(kTfThreads), 0, st, X, X2, n1, idx, Wn, bias,
+                       relu, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
 }
 
 // out[r] = sum of the partials of relation r's chunks, in chunk order
 template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
-                                                           TO* __restrict__ out) {
+                                                           TO* __restrict__ out, const float* __restrict__ cs_partial,
+                                                           int32_t H, float* __restrict__ out_colsum) {
     const int r = blockIdx.y;
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (cs_partial != nullptr && blockIdx.x == 0) {
+        for (int h = threadIdx.x; h < H; h += 256) {
+            float sum = 0.f;
+            for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) sum += cs_partial[(size_t)c * H + h];
+            out_colsum[(size_t)r * H + h] = sum;
+        }
+    }
     if (i >= tile_elems) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) {
@@ -156,10 +372,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <int HI, int HO>
-int launch_wgrad(const bf16_t* A, const int32_t* ia, const bf16_t* G, const int32_t* ig, const Chunk* chunks,
-                 int64_t num_chunks, float* partial, hipStream_t st) {
-    hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, ia, G, ig, chunks,
-                       partial);
+int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
+                 int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
+                 float* cs_partial, hipStream_t st) {
+    hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia, G, G2,
+                       ng1, ig, chunks, partial, colsum_of, cs_partial);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -170,37 +387,66 @@ extern "C" {
 
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho) {
     if (num_chunks < 0 || Hi <= 0 || Ho <= 0) { dn_set_error("dn_rows_wgrad_workspace_bytes: bad sizes"); return 0; }
-    return (size_t)(num_chunks > 0 ? num_chunks : 1) * Hi * Ho * sizeof(float);
+    return (size_t)(num_chunks > 0 ? num_chunks : 1) * ((size_t)Hi * Ho + Hi) * sizeof(float);
 }
 
-int dn_rows_wgrad_bf16(const void* A, const int32_t* idx_a, const void* G, const int32_t* idx_g, int32_t Hi, int32_t Ho,
-                       int64_t R, const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
-                       int32_t out_is_f32, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G, const void* G2,
+                       int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
+                       int64_t num_chunks, const int32_t* chunk_ptr, void* out, int32_t out_is_f32, int32_t colsum_of,
+                       float* out_colsum, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
+    DN_REQUIRE(A2 != nullptr || na1 == 0x7fffffff, "dn_rows_wgrad: A2 == NULL requires na1 == INT32_MAX");
+    DN_REQUIRE(G2 != nullptr || ng1 == 0x7fffffff, "dn_rows_wgrad: G2 == NULL requires ng1 == INT32_MAX");
     DN_REQUIRE(R >= 0 && num_chunks >= 0, "dn_rows_wgrad: negative size");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_wgrad: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
     if (R == 0) return DN_OK;
     DN_REQUIRE(out && chunk_ptr, "dn_rows_wgrad: NULL pointer");
     DN_REQUIRE(num_chunks == 0 || (A && G && chunks && workspace), "dn_rows_wgrad: NULL pointer");
-    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * Hi * Ho * sizeof(float), "dn_rows_wgrad: workspace too small");
+    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * ((size_t)Hi * Ho + Hi) * sizeof(float), "dn_rows_wgrad: workspace too small");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G)) % 16 == 0, "dn_rows_wgrad: unaligned input");
     hipStream_t st = (hipStream_t)stream;
     const Chunk* ch = reinterpret_cast<const Chunk*>(chunks);
     int rc = DN_OK;
     if (num_chunks > 0) {
-        if (Hi == 256) rc = launch_wgrad<256, 256>((const bf16_t*)A, idx_a, (const bf16_t*)G, idx_g, ch, num_chunks, (float*)workspace, st);
-        else if (Hi == 128) rc = launch_wgrad<128, 128>((const bf16_t*)A, idx_a, (const bf16_t*)G, idx_g, ch, num_chunks, (float*)workspace, st);
-        else rc = launch_wgrad<64, 64>((const bf16_t*)A, idx_a, (const bf16_t*)G, idx_g, ch, num_chunks, (float*)workspace, st);
+        const bf16_t *a = (const bf16_t*)A, *a2 = (const bf16_t*)A2, *g = (const bf16_t*)G, *g2 = (const bf16_t*)G2;
+        float* ws = (float*)workspace;
+        float* csp = ws + (size_t)num_chunks * Hi * Ho;
+        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
+        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
+        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
     dim3 grid((unsigned)dn_cdiv(tile, 1024), (unsigned)R);
+    const float* csp = colsum_of ? (const float*)workspace + (size_t)num_chunks * tile : nullptr;
     if (out_is_f32)
-        hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile, (float*)out);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
+                           (float*)out, csp, Hi, out_colsum);
     else
-        hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile, (bf16_t*)out);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
+                           (bf16_t*)out, csp, Hi, out_colsum);
     DN_CHECK_LAUNCH();
     return DN_OK;
+}
+
+int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
+                           const void* Wn, const void* bias, int32_t relu, const int32_t* tiles, int64_t num_tiles,
+                           void* Y, dn_stream_t stream) {
+    DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform: bad tile count");
+    DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform: unsupported widths %d x %d "
+               "(square 64/128/256 only)", Hi, Ho);
+    if (num_tiles == 0) return DN_OK;
+    DN_REQUIRE(X && Wn && tiles && Y, "dn_rows_transform: NULL pointer");
+    DN_REQUIRE(X2 != nullptr || n1 == 0x7fffffff, "dn_rows_transform: X2 == NULL requires n1 == INT32_MAX");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Wn) |
+                reinterpret_cast<uintptr_t>(Y)) % 16 == 0, "dn_rows_transform: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
+    const bf16_t *x = (const bf16_t*)X, *x2 = (const bf16_t*)X2, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias;
+    if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
+    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
+    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
 }
 
 }  // extern "C"

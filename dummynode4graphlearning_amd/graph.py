@@ -115,6 +115,16 @@ class BatchedGraph:
             self._cache._rel.pop(0)
         return ix
 
+    def row_index(self, etype, num_rels, self_loop):
+        for t, ver, r, ix in self._cache._rel:
+            if t is etype and ver == etype._version and r == ("row", num_rels, self_loop):
+                return ix
+        ix = ops.RowIndex(self._src, self._dst, etype, self._n, num_rels, self_loop=self_loop)
+        self._cache._rel.append((etype, etype._version, ("row", num_rels, self_loop), ix))
+        if len(self._cache._rel) > 4:
+            self._cache._rel.pop(0)
+        return ix
+
     # ---- dgl.batch (dataset.py:1321-1328, 1609-1610) ----------------------------------------------
     @staticmethod
     def batch(graphs):

@@ -159,26 +159,69 @@ def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
     return ch.to(device), torch.tensor(cptr, dtype=I32).to(device), len(chunks)
 
 
-def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None):
-    """out[r] = sum_{p in relation r} A[idx_a[p]]^T G[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 inputs, fp32 accumulate)."""
+INT32_MAX = 0x7fffffff
+
+
+def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0):
+    """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
+    Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
+    column sums [R, H] of operand A|G (the bias gradient)."""
     chunks, chunk_ptr, nchunks = chunk_table
-    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr)
+    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2)
     assert A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
     Hi, Ho = A.shape[1], G.shape[1]
     out_dtype = out_dtype or A.dtype
     out = torch.empty((num_rels, Hi, Ho), dtype=out_dtype, device=A.device)
     ws = _ws(lib().dn_rows_wgrad_workspace_bytes(nchunks, Hi, Ho), A.device)
+    colsum = torch.empty((num_rels, Hi), dtype=torch.float32, device=A.device) if colsum_of else None
 
     def _launch():
-        check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(idx_a), ptr(G), ptr(idx_g), Hi, Ho, num_rels, ptr(chunks), nchunks,
-                                       ptr(chunk_ptr), ptr(out), 1 if out_dtype == torch.float32 else 0, ptr(ws),
-                                       ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
+        check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), A.shape[0] if A2 is not None else INT32_MAX, ptr(idx_a),
+                                       ptr(G), ptr(G2), G.shape[0] if G2 is not None else INT32_MAX, ptr(idx_g),
+                                       Hi, Ho, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
+                                       1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(ws),
+                                       ws.numel(), stream_ptr()),
+              "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_wgrad", _launch)
     else:
         _launch()
-    return out
+    return (out, colsum) if colsum_of else out
+
+
+def make_row_tiles(rel_ptr_host, device, tile_rows=32):
+    """Tile table for dn_rows_transform_bf16: [T,4] int32 rows {rel, beg, end, 0}, tiles never cross relations."""
+    import numpy as np
+    parts = []
+    for r in range(len(rel_ptr_host) - 1):
+        a, b = rel_ptr_host[r], rel_ptr_host[r + 1]
+        if b > a:
+            beg = np.arange(a, b, tile_rows, dtype=np.int64)
+            parts.append(np.stack([np.full_like(beg, r), beg, np.minimum(beg + tile_rows, b), np.zeros_like(beg)], 1))
+    tl = np.concatenate(parts, 0) if parts else np.zeros((0, 4), dtype=np.int64)
+    return torch.from_numpy(tl.astype(np.int32)).to(device), int(tl.shape[0])
+
+
+def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False):
+    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T)  (dn_rows_transform_bf16)."""
+    tiles, ntiles = tile_table
+    require_gpu(X, Wn, tiles, idx, X2, bias)
+    assert X.dtype == torch.bfloat16 and Wn.dtype == torch.bfloat16 and Wn.dim() == 3
+    Ho, Hi = Wn.shape[1], Wn.shape[2]
+    assert X.shape[1] == Hi
+    Y = torch.empty((num_rows, Ho), dtype=X.dtype, device=X.device)
+
+    def _launch():
+        check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho,
+                                           ptr(Wn), ptr(bias), 1 if relu else 0, ptr(tiles), ntiles, ptr(Y),
+                                           stream_ptr()), "dn_rows_transform_bf16")
+
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_transform", _launch)
+    else:
+        _launch()
+    return Y
 
 
 def wgrad_supported(A, G):
@@ -381,3 +424,240 @@ def segment_reduce(x, graph_ptr, kind="sum"):
     """global_add_pool / global_mean_pool / global_max_pool over the batch's contiguous node ranges."""
     assert kind in ("sum", "mean", "max")
     return _SegmentReduce.apply(x, graph_ptr, kind)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused relation-wise message pass on the matrix cores (bf16): row factorisation + MFMA kernels
+# ----------------------------------------------------------------------------------------------
+class RowIndex:
+    """Relation-major ROW FACTORISATION of  out[v] = sum_{e: dst(e)=v} x[src(e)] W[etype(e)]  (+ x[v] W_loop).
+
+    Every row p has ONE input row and its product Y[p] = in_row(p) @ W[rel(p)] is added to one or more outputs:
+      EDGE relation (few shared endpoints):  one row per edge          in = x[src],            out -> dst
+      AGG  relation (few distinct dst, e.g. u -> dummy):  row per dst   in = sum_e x[src_e] (aux, pre-aggregated), out -> dst
+      TF   relation (few distinct src, e.g. dummy -> u):  row per src   in = x[src],            out -> every dst_e
+      self loop (optional, relation id R):   row per node              in = x[v],              out -> v
+    so the matrix cores transform min(#edges, #distinct dst, #distinct src) rows per relation, and the dummy
+    relations (2n of the m+2n edges of a dummy-augmented graph) collapse to one row per graph each.
+    The backward pass is the mirror image (in <-> out lists, W transposed)."""
+
+    EDGE, AGG, TF = 0, 1, 2
+
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75):
+        require_gpu(src, dst, etype)
+        dev = src.device
+        N, R, E = int(num_nodes), int(num_rels), int(src.numel())
+        self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
+        s64, d64, t64 = src.long(), dst.long(), etype.long()
+        if E > 0:
+            D = torch.bincount(torch.unique(t64 * N + d64) // N, minlength=R)
+            S = torch.bincount(torch.unique(t64 * N + s64) // N, minlength=R)
+            Er = torch.bincount(t64, minlength=R)
+            D, S, Er = (v.tolist() for v in (D, S, Er))
+        else:
+            D = S = Er = [0] * R
+        modes = []
+        for r in range(R):
+            if Er[r] == 0 or min(D[r], S[r]) > edge_frac * Er[r]:
+                modes.append(self.EDGE)
+            else:
+                modes.append(self.AGG if D[r] <= S[r] else self.TF)
+        self.modes = modes
+        mode_t = torch.tensor(modes, dtype=torch.long, device=dev)
+        emode = mode_t[t64] if E > 0 else t64
+        node_key = torch.where(emode == self.TF, s64, d64)
+        key = t64 * N + node_key
+        order = torch.sort(key, stable=True).indices if E > 0 else key       # relation-major, by node, by edge id
+        k_s, m_s = key[order], emode[order]
+        head = torch.ones(E, dtype=torch.bool, device=dev)
+        if E > 1:
+            head[1:] = (m_s[1:] == self.EDGE) | (k_s[1:] != k_s[:-1])
+        row_s = torch.cumsum(head.long(), 0) - 1                             # row of each sorted edge
+        head_pos = torch.nonzero(head).reshape(-1)
+        P = int(head_pos.numel())
+        row_of_edge = torch.empty(E, dtype=torch.long, device=dev)
+        row_of_edge[order] = row_s
+        first_edge = order[head_pos]
+        row_rel, row_mode, row_node = t64[first_edge], m_s[head_pos], node_key[first_edge]
+        rel_cnt = torch.bincount(row_rel, minlength=R).tolist() if P > 0 else [0] * R
+        rel_ptr = [0]
+        for c in rel_cnt:
+            rel_ptr.append(rel_ptr[-1] + c)
+        is_agg, is_tf = row_mode == self.AGG, row_mode == self.TF
+        aux_f_id, aux_b_id = torch.cumsum(is_agg.long(), 0) - 1, torch.cumsum(is_tf.long(), 0) - 1
+        self.num_aux_f, self.num_aux_b = int(is_agg.sum()), int(is_tf.sum())
+        row_in = torch.where(is_agg, N + aux_f_id, torch.where(is_tf, row_node, s64[first_edge]))
+        row_out = torch.where(is_tf, N + aux_b_id, torch.where(is_agg, row_node, d64[first_edge]))
+        rows = torch.arange(P, device=dev)
+        # pre-aggregation lists (K1): sorted order already groups the edges of a row
+        e_agg, e_tf = order[m_s == self.AGG], order[m_s == self.TF]
+        self.aux_f_idx = s64[e_agg].to(I32)
+        self.aux_f_ptr = self._ptr(aux_f_id[row_of_edge[e_agg]], self.num_aux_f, dev)
+        self.aux_b_idx = d64[e_tf].to(I32)
+        self.aux_b_ptr = self._ptr(aux_b_id[row_of_edge[e_tf]], self.num_aux_b, dev)
+        # final per-node lists of contributing rows
+        ee = emode == self.AGG
+        f_dst = [d64[~ee], row_node[is_agg]]
+        f_row = [row_of_edge[~ee], rows[is_agg]]
+        et = emode == self.TF
+        b_src = [s64[~et], row_node[is_tf]]
+        b_row = [row_of_edge[~et], rows[is_tf]]
+        P_all = P
+        if self_loop:
+            ar = torch.arange(N, device=dev)
+            f_dst.append(ar), f_row.append(P + ar), b_src.append(ar), b_row.append(P + ar)
+            row_in, row_out = torch.cat([row_in, ar]), torch.cat([row_out, ar])
+            rel_ptr.append(P + N)
+            P_all = P + N
+        f_dst, f_row, b_src, b_row = (torch.cat(v) for v in (f_dst, f_row, b_src, b_row))
+        self.dst_ptr, perm = csr_build(f_dst.to(I32), N)
+        self.dst_rows = f_row.to(I32).index_select(0, perm.long())
+        self.src_ptr, perm = csr_build(b_src.to(I32), N)
+        self.src_rows = b_row.to(I32).index_select(0, perm.long())
+        self.row_in, self.row_out = row_in.to(I32).contiguous(), row_out.to(I32).contiguous()
+        self.num_rows, self.num_edge_rows = P_all, P
+        self.num_all_rels = R + (1 if self_loop else 0)
+        self.rel_ptr_host = rel_ptr
+        self.tile_table = make_row_tiles(rel_ptr, dev)
+        self.chunk_table = make_row_chunks(rel_ptr, dev)
+        self.colsum_ptr = colsum_levels(N, dev)
+
+    @staticmethod
+    def _ptr(ids, n, dev):
+        cnt = torch.bincount(ids, minlength=n) if ids.numel() else torch.zeros(n, dtype=torch.long, device=dev)
+        return torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt, 0)]).to(I32)
+
+
+COLSUM_CHUNK = 128
+
+
+def colsum_levels(n, dev):
+    """Segment pointers for a tree column sum: level i sums COLSUM_CHUNK-row chunks of level i-1."""
+    levels = []
+    while n > COLSUM_CHUNK:
+        p = torch.arange(0, n + COLSUM_CHUNK, COLSUM_CHUNK, device=dev).clamp(max=n).to(I32)
+        p = p[: (n + COLSUM_CHUNK - 1) // COLSUM_CHUNK + 1].contiguous()
+        levels.append(p)
+        n = p.numel() - 1
+    return levels
+
+
+def column_sum(g, levels):
+    """Sum over the rows of a tall matrix (bias gradient): a short tree of contiguous segment sums on the HIP kernel
+    (fixed order: deterministic), finished by a <=128-row sum."""
+    cur = g
+    for p in levels:
+        cur = gather_segsum(cur if cur.dtype == torch.float32 else cur, None, p)
+    return cur.float().sum(0)
+
+
+class _RowTransformFn(torch.autograd.Function):
+    """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop)."""
+
+    @staticmethod
+    def forward(ctx, x, W_all, bias, index):
+        ix = index
+        x = x.contiguous()
+        aux = gather_segsum(x, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+        Wn = W_all.transpose(1, 2).contiguous()                              # [R', out, in]
+        bias_all = None
+        if bias is not None:
+            bias_all = torch.zeros((W_all.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
+            bias_all[-1] = bias                                              # only self-loop rows carry the bias
+        Y = rows_transform(x, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all)
+        out = gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes)
+        ctx.index, ctx.has_bias = ix, bias is not None
+        ctx.save_for_backward(x, W_all, aux if aux is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ix = ctx.index
+        g = g.contiguous()
+        x, W_all, aux = ctx.saved_tensors
+        aux = aux if aux.numel() else None
+        aux_b = gather_segsum(g, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gA = rows_transform(g, W_all.contiguous(), ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b)
+            gx = gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
+            gW, cs = rows_wgrad(x, g, ix.chunk_table, W_all.shape[0], idx_a=ix.row_in, idx_g=ix.row_out, A2=aux, G2=aux_b,
+                                out_dtype=W_all.dtype, colsum_of=2)
+            if ctx.has_bias:
+                gb = cs[-1].to(g.dtype)
+        return gx, gW, gb, None
+
+
+def fused_path_supported(x, W):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.dim() == 3
+            and W.shape[1] == W.shape[2] and W.shape[1] in (64, 128, 256) and x.shape[1] == W.shape[1])
+
+
+def rel_transform_fused(x, W_all, bias, index):
+    """Fused bf16 path.  W_all: [R(+1), in, out] with the self-loop weight last when index.self_loop; bias is added on the
+    self-loop rows (requires index.self_loop)."""
+    assert bias is None or index.self_loop
+    assert W_all.shape[0] == index.num_all_rels
+    return _RowTransformFn.apply(x, W_all, bias, index)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense Linear(+ReLU) of the post-aggregate MLP on the same MFMA kernels (bf16)
+# ----------------------------------------------------------------------------------------------
+_dense_tables = {}
+
+
+def _dense_table(n_rows, dev):
+    """Tile / chunk tables of a single-relation, identity-indexed row set (cached per size and device)."""
+    key = (int(n_rows), str(dev))
+    t = _dense_tables.get(key)
+    if t is None:
+        t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev), colsum_levels(int(n_rows), dev))
+        if len(_dense_tables) > 8:
+            _dense_tables.clear()
+        _dense_tables[key] = t
+    return t
+
+
+class _LinearActFn(torch.autograd.Function):
+    """y = relu?(x @ weight^T + bias) with weight [out, in] (nn.Linear layout): forward and both backward products on
+    dn_rows_transform_bf16 / dn_rows_wgrad_bf16, bias and ReLU fused in the forward epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        tiles, _, _ = _dense_table(x.shape[0], x.device)
+        y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
+                           bias=None if bias is None else bias.contiguous().view(1, -1), relu=relu)
+        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        ctx.save_for_backward(x, weight, y if relu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))     # ReLU backward mask
+        tiles, chunks, levels = _dense_table(x.shape[0], x.device)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = rows_transform(g, weight.t().contiguous().unsqueeze(0), tiles, x.shape[0])  # g @ weight
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, cs = rows_wgrad(g, x, chunks, 1, out_dtype=weight.dtype, colsum_of=1)        # g^T x -> [out, in]; colsum(g)
+            gw = gw[0]
+            if ctx.has_bias:
+                gb = cs[0].to(g.dtype)
+        return gx, gw, gb, None
+
+
+def linear_act(x, weight, bias=None, relu=False):
+    """nn.Linear (+ ReLU) on the MFMA kernels when supported (bf16, square 64/128/256), else torch."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 2
+            and weight.shape[0] == weight.shape[1] and weight.shape[0] in (64, 128, 256) and x.shape[1] == weight.shape[1]
+            and x.shape[0] > 0):
+        return _LinearActFn.apply(x, weight, bias, relu)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else y

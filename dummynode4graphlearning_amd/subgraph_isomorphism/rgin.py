@@ -106,20 +106,50 @@ class RGINLayer(nn.Module):
         # side effects on the graph as in rgin.py:126-135,160
         g.ndata[NODEFEAT] = node_feat
         g.edata[EDGETYPE] = edge_type
-        index = g.rel_index(edge_type, self.num_rels)
         W = dense_relation_weights(self)
-        out = ops.rel_agg_transform(node_feat, W, index)            # sum_e x[src] W[etype]  (rgin.py:102-120 + fn.sum)
-        if self.self_loop:
-            out = out + th.matmul(node_feat, self.loop_weight)      # rgin.py:140-142
-        if self.bias is not None:
-            out = out + self.bias
-        if len(self.mlp) > 0:
-            out = self.mlp(out)
+        if ops.fused_path_supported(node_feat, W):
+            # bf16: message pass, self loop (rgin.py:140-142) and bias in ONE row-factorised MFMA pipeline
+            index = g.row_index(edge_type, self.num_rels, self.self_loop)
+            W_all = th.cat([W, self.loop_weight.unsqueeze(0)], 0) if self.self_loop else W
+            out = ops.rel_transform_fused(node_feat, W_all, self.bias if self.self_loop else None, index)
+            if self.bias is not None and not self.self_loop:
+                out = out + self.bias
         else:
-            out = self.act(out)
-        out = self.act(out)                                         # activation after the MLP (twice if MLP empty)
+            index = g.rel_index(edge_type, self.num_rels)
+            out = ops.rel_agg_transform(node_feat, W, index)        # sum_e x[src] W[etype]  (rgin.py:102-120 + fn.sum)
+            if self.self_loop:
+                out = out + th.matmul(node_feat, self.loop_weight)  # rgin.py:140-142
+            if self.bias is not None:
+                out = out + self.bias
+        if len(self.mlp) > 0:
+            out, act_done = self._run_mlp(out)
+        else:
+            out, act_done = self.act(out), False
+        if not act_done:
+            out = self.act(out)                                     # activation after the MLP (twice if MLP empty)
         out = self.drop(out)
         return out, edge_type
+
+    def _run_mlp(self, out):
+        """self.mlp(out), with every Linear (and a ReLU that follows it -- including the layer's final activation) sent
+        through the fused MFMA Linear+bias+ReLU kernel when the dtype/width allow it.  Returns (out, final_act_applied)."""
+        mods = list(self.mlp)
+        i, act_done = 0, False
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                nxt = mods[i + 1] if i + 1 < len(mods) else self.act
+                fuse = isinstance(nxt, nn.ReLU)
+                out = ops.linear_act(out, m.weight, m.bias, relu=fuse)
+                if fuse:
+                    if i + 1 < len(mods):
+                        i += 1
+                    else:
+                        act_done = True
+            else:
+                out = m(out)
+            i += 1
+        return out, act_done
 
     def get_output_dim(self):
         return self.hidden_dim

@@ -170,12 +170,29 @@ int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * Rows are relation-major; the caller splits them into row chunks {rel, beg, end, 0} (int32 x4 each, any chunk
  * inside one relation, chunks of a relation contiguous: chunk_ptr [R+1]).  One workgroup per chunk accumulates the
  * whole Hi x Ho tile; partials (workspace, fp32 [num_chunks, Hi, Ho]) are then added in chunk order: deterministic.
- * idx_a / idx_g may be NULL (row p itself).  Supported: Hi == Ho in {64, 128, 256}.  out is fp32 or bf16. */
+ * idx_a / idx_g may be NULL (row p itself); A2/na1 and G2/ng1 give each operand a second row source exactly as
+ * in dn_rows_transform_bf16.  Supported: Hi == Ho in {64, 128, 256}.  out is fp32 or bf16.
+ * colsum_of = 1 (A) or 2 (G) also returns out_colsum[r, :] = sum over relation r's rows of that operand (fp32 [R, H]):
+ * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL). */
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
-int dn_rows_wgrad_bf16(const void* A, const int32_t* idx_a, const void* G, const int32_t* idx_g, int32_t Hi,
-                       int32_t Ho, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                       const int32_t* chunk_ptr, void* out, int32_t out_is_f32, void* workspace,
+int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G,
+                       const void* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
+                       const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
+                       int32_t out_is_f32, int32_t colsum_of, float* out_colsum, void* workspace,
                        size_t workspace_bytes, dn_stream_t stream);
+
+/* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
+ *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
+ * Xcat is the virtual concatenation of X (rows [0, n1)) and X2 (rows n1, n1+1, ...): an index i >= n1 reads
+ * X2[i - n1]; pass X2 = NULL with n1 = INT32_MAX for a single source.  idx == NULL means row p itself.
+ * Wn[r] is [Ho][Hi] with k contiguous (i.e. W_r transposed for Y = X W_r).  Rows are relation-major and the caller
+ * provides the tile table {rel, beg, end, 0} (int32 x4; a tile has at most 32 rows and lies inside one relation).
+ * Replaces the reference's per-edge `weight.index_select(0, etype)` + `th.bmm` message function
+ * (subgraph_isomorphism/models/rgin.py:102-120, rgcn.py:100-122), its self-loop matmul (rgin.py:141) and, in the
+ * backward direction (X = grad rows, Wn = W_r), autograd's transposed product.  Ho == Hi in {64, 128, 256}. */
+int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
+                           const void* Wn, const void* bias, int32_t relu, const int32_t* tiles,
+                           int64_t num_tiles, void* Y, dn_stream_t stream);
 
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg

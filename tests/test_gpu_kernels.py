@@ -173,11 +173,89 @@ def test_rows_wgrad_matches_reference(H):
         ref[r] = A[ia[a:b].long()].double().t() @ G[ig[a:b].long()].double()
     # bf16 products are exact in fp32; only the fp32 accumulation order differs
     torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-3)
-    got2 = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), out_dtype=torch.float32)
+    got2, cs = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), out_dtype=torch.float32,
+                              colsum_of=2)
     assert torch.equal(got, got2)                        # deterministic
+    cs_ref = torch.stack([G[ig[rel_ptr[r]:rel_ptr[r + 1]].long()].double().sum(0) for r in range(R)])
+    torch.testing.assert_close(cs.cpu().double(), cs_ref, rtol=1e-4, atol=1e-3)
+    _, cs_a = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), colsum_of=1)
+    cs_ref = torch.stack([A[ia[rel_ptr[r]:rel_ptr[r + 1]].long()].double().sum(0) for r in range(R)])
+    torch.testing.assert_close(cs_a.cpu().double(), cs_ref, rtol=1e-4, atol=1e-3)
     # contiguous rows (no index) + bf16 output
     P2 = min(P, NA, NG)
     t2 = ops.make_row_chunks([0, P2], DEV, chunk_rows=1024)
     got3 = ops.rows_wgrad(A[:P2].contiguous().to(DEV), G[:P2].contiguous().to(DEV), t2, 1)
     ref3 = A[:P2].double().t() @ G[:P2].double()
     torch.testing.assert_close(got3[0].cpu().double(), ref3, rtol=1e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_rows_transform_matches_reference(H):
+    """Gathered-row MFMA transform: Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T) with asymmetric weights."""
+    ops = _ops()
+    rng = np.random.default_rng(10 + H)
+    sizes = [0, 37, 1500, 1, 33, 64]
+    rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
+    R, P, N1, N2 = len(sizes), rel_ptr[-1], 700, 90
+    X = torch.from_numpy(rng.standard_normal((N1, H)).astype(np.float32)).to(torch.bfloat16)
+    X2 = torch.from_numpy(rng.standard_normal((N2, H)).astype(np.float32)).to(torch.bfloat16)
+    Wn = torch.from_numpy((rng.standard_normal((R, H, H)) / np.sqrt(H)).astype(np.float32)).to(torch.bfloat16)
+    bias = torch.from_numpy(rng.standard_normal((R, H)).astype(np.float32)).to(torch.bfloat16)
+    idx = torch.from_numpy(rng.integers(0, N1 + N2, size=P)).to(torch.int32)
+    tiles = ops.make_row_tiles(rel_ptr, DEV)
+    Xcat = torch.cat([X, X2]).double()
+    rel_of_row = torch.repeat_interleave(torch.arange(R), torch.tensor(sizes))
+    for use_bias, relu in [(False, False), (True, True)]:
+        got = ops.rows_transform(X.to(DEV), Wn.to(DEV), tiles, P, idx=idx.to(DEV), X2=X2.to(DEV),
+                                 bias=bias.to(DEV) if use_bias else None, relu=relu)
+        ref = torch.einsum("pk,pnk->pn", Xcat[idx.long()], Wn.double()[rel_of_row])
+        if use_bias:
+            ref = ref + bias.double()[rel_of_row]
+        if relu:
+            ref = ref.clamp(min=0)
+        # fp32 accumulate of exact bf16 products, one bf16 rounding of the stored result
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-2, atol=2e-2)
+    # identity rows, single source
+    t1 = ops.make_row_tiles([0, N1], DEV)
+    got = ops.rows_transform(X.to(DEV), Wn[2:3].contiguous().to(DEV), t1, N1)
+    torch.testing.assert_close(got.cpu().double(), X.double() @ Wn[2].double().t(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("self_loop", [True, False])
+def test_fused_row_factorisation_forward_backward(self_loop):
+    """bf16 fused path (EDGE / AGG / TF relations + self loop) against the fp32 per-edge formulation."""
+    ops = _ops()
+    from dummynode4graphlearning_amd import synthetic
+    raw = synthetic.config3(seed=7, graphs=24)
+    aug = OT.dummy_augment_si(*(raw[k] for k in ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id",
+                                                  "edge_label")), raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    src, dst, et = (torch.from_numpy(aug[k]) for k in ("src", "dst", "edge_label"))
+    N, R, H = len(aug["node_label"]), raw["num_rels"], 64
+    rng = np.random.default_rng(1)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x = bf(rng.standard_normal((N, H)))
+    W = bf(rng.standard_normal((R + (1 if self_loop else 0), H, H)) / np.sqrt(H))
+    b = bf(rng.standard_normal(H)) if self_loop else None
+    coef = bf(rng.standard_normal((N, H)))
+    index = ops.RowIndex(src.to(DEV), dst.to(DEV), et.to(DEV), N, R, self_loop=self_loop)
+    assert sorted(set(index.modes)) == [ops.RowIndex.EDGE, ops.RowIndex.AGG, ops.RowIndex.TF]
+    xd, Wd = x.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if self_loop else None
+    out = ops.rel_transform_fused(xd, Wd, bd, index)
+    out.backward(coef.to(DEV))
+    xr, Wr = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if self_loop else None
+    msg = torch.bmm(xr[src].unsqueeze(1), Wr[et]).squeeze(1)
+    ref = torch.zeros(N, H, dtype=torch.float64).index_add(0, dst, msg)
+    if self_loop:
+        ref = ref + xr @ Wr[R] + br
+    ref.backward(coef.double())
+
+    def rel(a, r):
+        return float((a.detach().cpu().double() - r.detach()).abs().max() / r.detach().abs().max())
+    # bf16 storage of every intermediate (2^-8 relative each): 2e-2 of the tensor range end to end
+    assert rel(out, ref) < 2e-2
+    assert rel(xd.grad, xr.grad) < 2e-2
+    assert rel(Wd.grad, Wr.grad) < 2e-2
+    if self_loop:
+        assert rel(bd.grad, br.grad) < 2e-2
