@@ -81,27 +81,36 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
             cs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
         }
     };
-    auto load_tile = [&](int t) {
+    int32_t sa[PA], sg[PG];                                   // source rows of my pieces (fetched one tile ahead)
+    auto load_idx = [&](int t) {
         const int row0 = ch.beg + t * kTileRows;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const int piece = tid + j * kWgThreads, r = piece / (HI / 8), c = piece % (HI / 8);
-            const int p = row0 + r;
+            const int piece = tid + j * kWgThreads, p = row0 + piece / (HI / 8);
+            sa[j] = (piece < NPA && p < ch.end) ? (ia ? ia[p] : p) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int piece = tid + j * kWgThreads, p = row0 + piece / (HO / 8);
+            sg[j] = (piece < NPG && p < ch.end) ? (ig ? ig[p] : p) : -1;
+        }
+    };
+    auto load_tile = [&](int) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int c = (tid + j * kWgThreads) % (HI / 8);
             ra[j] = make_uint4(0, 0, 0, 0);
-            if (piece < NPA && p < ch.end) {
-                const int src = ia ? ia[p] : p;
-                const bf16_t* base = src < na1 ? A + (size_t)src * HI : A2 + (size_t)(src - na1) * HI;
+            if (sa[j] >= 0) {
+                const bf16_t* base = sa[j] < na1 ? A + (size_t)sa[j] * HI : A2 + (size_t)(sa[j] - na1) * HI;
                 ra[j] = *reinterpret_cast<const uint4*>(base + c * 8);
             }
         }
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
-            const int piece = tid + j * kWgThreads, r = piece / (HO / 8), c = piece % (HO / 8);
-            const int p = row0 + r;
+            const int c = (tid + j * kWgThreads) % (HO / 8);
             rg[j] = make_uint4(0, 0, 0, 0);
-            if (piece < NPG && p < ch.end) {
-                const int src = ig ? ig[p] : p;
-                const bf16_t* base = src < ng1 ? G + (size_t)src * HO : G2 + (size_t)(src - ng1) * HO;
+            if (sg[j] >= 0) {
+                const bf16_t* base = sg[j] < ng1 ? G + (size_t)sg[j] * HO : G2 + (size_t)(sg[j] - ng1) * HO;
                 rg[j] = *reinterpret_cast<const uint4*>(base + c * 8);
             }
         }
@@ -122,13 +131,18 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
     };
 
     if (ntiles > 0) {
+        load_idx(0);
         load_tile(0);
         store_tile(0);
+        load_idx(1);
     }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int b = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);                    // global loads in flight under the MFMAs
+        if (t + 1 < ntiles) {
+            load_tile(t + 1);                                    // global loads in flight under the MFMAs
+            load_idx(t + 2);                                     // (rows past the chunk end give -1)
+        }
 #pragma unroll
         for (int kk = 0; kk < kTileRows / 32; ++kk) {
             bf16x8 fb[NT];
@@ -196,8 +210,8 @@ constexpr int kTfRows = 32;
 template <int HI, int HO>
 __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
-    const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const Chunk* __restrict__ tiles,
-    int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
+    const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const bf16_t* __restrict__ mask_pos,
+    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
     constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
     constexpr int SY = HO + kPad;                   // ... of the output tile
     constexpr int KS = HI / 32;                     // k-steps
@@ -324,8 +338,24 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
         for (int j = 0; j < PY; ++j) {
             const int piece = tid + j * kTfThreads, r = piece / (HO / 8), c = piece % (HO / 8);
             const int p = tl.beg + r;
-            if (piece < NPY && p < tl.end)
-                *reinterpret_cast<uint4*>(Y + (size_t)p * HO + c * 8) = *reinterpret_cast<const uint4*>(bufY + r * SY + c * 8);
+            if (piece < NPY && p < tl.end) {
+                uint4 v = *reinterpret_cast<const uint4*>(bufY + r * SY + c * 8);
+                if (mask_pos) {                                  // ReLU backward: keep where the saved activation is > 0
+                    const uint4 mk = *reinterpret_cast<const uint4*>(mask_pos + (size_t)p * HO + c * 8);
+                    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                    uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // bf16 > 0  <=>  sign clear and magnitude non-zero (NaN counts as "not > 0" only if signed)
+                        const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
+                        const uint32_t keep_lo = (lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u;
+                        const uint32_t keep_hi = (hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u;
+                        vw[i] &= (keep_lo | keep_hi);
+                    }
+                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+                *reinterpret_cast<uint4*>(Y + (size_t)p * HO + c * 8) = v;
+            }
         }
         // bufY is rewritten only after the next tile's MFMAs and its barrier-separated store: add a barrier here so no
         // wave overwrites bufY (next iteration's epilogue) while a slower wave still reads it
@@ -335,13 +365,13 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
 
 template <int HI, int HO>
 int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_t* idx, const bf16_t* Wn, const bf16_t* bias,
-                     int32_t relu, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
+                     int32_t relu, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
     // ~2 workgroups per CU; contiguous tile ranges keep a workgroup inside one relation most of the time
     const int64_t max_wg = 256 * 2;
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     hipLaunchKernelGGL((rows_transform_kernel<HI, HO>), dim3((unsigned)grid), dim3(kTfThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                       relu, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+                       relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -363,7 +393,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     if (i >= tile_elems) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) {
+    const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
+    int c = cb;
+    for (; c + 8 <= ce; c += 8) {                       // 8 independent loads in flight, summed in chunk order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(c + u) * tile_elems + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; c < ce; ++c) {
         const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * tile_elems + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -381,9 +420,39 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
     return DN_OK;
 }
 
+// out = (y > 0) ? g : 0, 8 bf16 per lane
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y,
+                                                       uint4* __restrict__ out, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const uint4 gv = g[i], yv = y[i];
+        const uint32_t mw[4] = {yv.x, yv.y, yv.z, yv.w};
+        uint32_t vw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = mw[k] & 0xffffu, hi = mw[k] >> 16;
+            vw[k] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+        }
+        out[i] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream) {
+    DN_REQUIRE(numel >= 0 && numel % 8 == 0, "dn_relu_bwd: numel must be a non-negative multiple of 8");
+    if (numel == 0) return DN_OK;
+    DN_REQUIRE(g && y && out, "dn_relu_bwd: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) % 16 == 0,
+               "dn_relu_bwd: unaligned pointer");
+    const int64_t n16 = numel / 8;
+    const int64_t grid = dn_cdiv(n16, 256) < 256 * 16 ? dn_cdiv(n16, 256) : 256 * 16;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (const uint4*)y,
+                       (uint4*)out, n16);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
 
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho) {
     if (num_chunks < 0 || Hi <= 0 || Ho <= 0) { dn_set_error("dn_rows_wgrad_workspace_bytes: bad sizes"); return 0; }
@@ -431,8 +500,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
 }
 
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
-                           const void* Wn, const void* bias, int32_t relu, const int32_t* tiles, int64_t num_tiles,
-                           void* Y, dn_stream_t stream) {
+                           const void* Wn, const void* bias, int32_t relu, const void* mask_pos, const int32_t* tiles,
+                           int64_t num_tiles, void* Y, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform: bad tile count");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
@@ -444,9 +513,11 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     hipStream_t st = (hipStream_t)stream;
     const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
     const bf16_t *x = (const bf16_t*)X, *x2 = (const bf16_t*)X2, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias;
-    if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
-    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
-    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, tl, num_tiles, (bf16_t*)Y, st);
+    const bf16_t* mk = (const bf16_t*)mask_pos;
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(mk) % 16 == 0, "dn_rows_transform: unaligned mask");
+    if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
+    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
+    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
 }
 
 }  // extern "C"

@@ -203,10 +203,10 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
     return torch.from_numpy(tl.astype(np.int32)).to(device), int(tl.shape[0])
 
 
-def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False):
-    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T)  (dn_rows_transform_bf16)."""
+def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None):
+    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16)."""
     tiles, ntiles = tile_table
-    require_gpu(X, Wn, tiles, idx, X2, bias)
+    require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
     assert X.dtype == torch.bfloat16 and Wn.dtype == torch.bfloat16 and Wn.dim() == 3
     Ho, Hi = Wn.shape[1], Wn.shape[2]
     assert X.shape[1] == Hi
@@ -214,8 +214,8 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
 
     def _launch():
         check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho,
-                                           ptr(Wn), ptr(bias), 1 if relu else 0, ptr(tiles), ntiles, ptr(Y),
-                                           stream_ptr()), "dn_rows_transform_bf16")
+                                           ptr(Wn), ptr(bias), 1 if relu else 0, ptr(mask_pos), ptr(tiles), ntiles,
+                                           ptr(Y), stream_ptr()), "dn_rows_transform_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_transform", _launch)
@@ -651,6 +651,68 @@ class _LinearActFn(torch.autograd.Function):
             if ctx.has_bias:
                 gb = cs[0].to(g.dtype)
         return gx, gw, gb, None
+
+
+def relu_bwd(g, y):
+    """(y > 0) ? g : 0  (dn_relu_bwd_bf16)."""
+    require_gpu(g, y)
+    out = torch.empty_like(g)
+    check(lib().dn_relu_bwd_bf16(ptr(g), ptr(y), ptr(out), g.numel(), stream_ptr()), "dn_relu_bwd_bf16")
+    return out
+
+
+class _ReluMlpFn(torch.autograd.Function):
+    """y_L = relu(lin_L(... relu(lin_1(x)))) with every Linear followed by ReLU (the reference MLP + final activation
+    when act_func == "relu", rgin.py:50-57,147-151).  Forward: one fused Linear+bias+ReLU MFMA launch per layer.
+    Backward per layer: weight/bias gradient in one launch, input gradient in one launch whose epilogue already applies
+    the ReLU mask of the layer below; only the outermost mask needs its own elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        n = len(wb) // 2
+        tiles, _, _ = _dense_table(x.shape[0], x.device)
+        acts = [x.contiguous()]
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
+                                       bias=None if b is None else b.contiguous().view(1, -1), relu=True))
+        ctx.n = n
+        ctx.has_bias = [wb[2 * i + 1] is not None for i in range(n)]
+        ctx.save_for_backward(*acts, *[wb[2 * i] for i in range(n)])
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, ws = saved[:n + 1], saved[n + 1:]
+        tiles, chunks, _ = _dense_table(acts[0].shape[0], acts[0].device)
+        g = relu_bwd(gout.contiguous(), acts[n])                       # outermost ReLU
+        grads = [None] * (1 + 2 * n)
+        for i in range(n - 1, -1, -1):
+            w = ws[i]
+            gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1)   # g^T a_{i} ; colsum(g)
+            grads[1 + 2 * i] = gw[0]
+            if ctx.has_bias[i]:
+                grads[2 + 2 * i] = cs[0].to(g.dtype)
+            if i > 0 or ctx.needs_input_grad[0]:
+                g = rows_transform(g, w.t().contiguous().unsqueeze(0), tiles, g.shape[0],
+                                   mask_pos=acts[i] if i > 0 else None)                # masked for the ReLU below
+        grads[0] = g if ctx.needs_input_grad[0] else None
+        return tuple(grads)
+
+
+def relu_mlp_supported(x, linears):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] > 0 and len(linears) > 0
+            and all(l.weight.dtype == torch.bfloat16 and l.weight.shape[0] == l.weight.shape[1] == x.shape[1]
+                    and x.shape[1] in (64, 128, 256) for l in linears))
+
+
+def relu_mlp(x, linears):
+    args = []
+    for l in linears:
+        args += [l.weight, l.bias]
+    return _ReluMlpFn.apply(x, *args)
 
 
 def linear_act(x, weight, bias=None, relu=False):

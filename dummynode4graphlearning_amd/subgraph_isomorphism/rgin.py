@@ -134,6 +134,10 @@ class RGINLayer(nn.Module):
         """self.mlp(out), with every Linear (and a ReLU that follows it -- including the layer's final activation) sent
         through the fused MFMA Linear+bias+ReLU kernel when the dtype/width allow it.  Returns (out, final_act_applied)."""
         mods = list(self.mlp)
+        linears = [m for m in mods if isinstance(m, nn.Linear)]
+        if (isinstance(self.act, nn.ReLU) and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in mods)
+                and ops.relu_mlp_supported(out, linears)):
+            return ops.relu_mlp(out, linears), True                 # Linear-ReLU chain + final ReLU, fused end to end
         i, act_done = 0, False
         while i < len(mods):
             m = mods[i]

@@ -189,10 +189,17 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
  * provides the tile table {rel, beg, end, 0} (int32 x4; a tile has at most 32 rows and lies inside one relation).
  * Replaces the reference's per-edge `weight.index_select(0, etype)` + `th.bmm` message function
  * (subgraph_isomorphism/models/rgin.py:102-120, rgcn.py:100-122), its self-loop matmul (rgin.py:141) and, in the
- * backward direction (X = grad rows, Wn = W_r), autograd's transposed product.  Ho == Hi in {64, 128, 256}. */
+ * backward direction (X = grad rows, Wn = W_r), autograd's transposed product.  Ho == Hi in {64, 128, 256}.
+ * mask_pos (may be NULL): after epi, elements where mask_pos[p, n] <= 0 are zeroed. */
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
-                           const void* Wn, const void* bias, int32_t relu, const int32_t* tiles,
-                           int64_t num_tiles, void* Y, dn_stream_t stream);
+                           const void* Wn, const void* bias, int32_t relu, const void* mask_pos,
+                           const int32_t* tiles, int64_t num_tiles, void* Y, dn_stream_t stream);
+
+/* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
+ * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the
+ * `mask_pos` epilogue of dn_rows_transform_bf16 ([rows, Ho] saved activations), so a Linear's input gradient comes
+ * out already masked for the ReLU in front of it. */
+int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream);
 
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg
