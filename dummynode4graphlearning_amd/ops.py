@@ -203,7 +203,7 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
     return torch.from_numpy(tl.astype(np.int32)).to(device), int(tl.shape[0])
 
 
-def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None):
+def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense"):
     """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16)."""
     tiles, ntiles = tile_table
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
@@ -218,7 +218,7 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
                                            ptr(Y), stream_ptr()), "dn_rows_transform_bf16")
 
     if kernel_timer is not None:
-        kernel_timer.launch("rows_transform", _launch)
+        kernel_timer.launch("rows_transform:" + tag, _launch)
     else:
         _launch()
     return Y
@@ -564,7 +564,7 @@ class _RowTransformFn(torch.autograd.Function):
         if bias is not None:
             bias_all = torch.zeros((W_all.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
             bias_all[-1] = bias                                              # only self-loop rows carry the bias
-        Y = rows_transform(x, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all)
+        Y = rows_transform(x, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all, tag="conv")
         out = gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes)
         ctx.index, ctx.has_bias = ix, bias is not None
         ctx.save_for_backward(x, W_all, aux if aux is not None else x.new_empty(0))
@@ -579,7 +579,7 @@ class _RowTransformFn(torch.autograd.Function):
         aux_b = gather_segsum(g, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            gA = rows_transform(g, W_all.contiguous(), ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b)
+            gA = rows_transform(g, W_all.contiguous(), ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b, tag="conv")
             gx = gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel

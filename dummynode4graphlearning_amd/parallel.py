@@ -18,7 +18,8 @@ def shard_graphs(batch_num_nodes, batch_num_edges, world_size):
     bounds = [0]
     for r in range(1, world_size):
         target = total * r / world_size
-        g = int(torch.searchsorted(csum, torch.tensor([target], dtype=csum.dtype), right=False)) if G else 0
+        # first graph whose cumulative weight reaches the target closes the shard
+        g = int(torch.searchsorted(csum.double(), torch.tensor([target], dtype=torch.float64), right=False)) + 1 if G else 0
         bounds.append(min(max(g, bounds[-1]), G))
     bounds.append(G)
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]

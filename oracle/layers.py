@@ -232,3 +232,31 @@ def xavier_uniform_bound(shape, act):
     else:  # sigmoid / softmax family
         gain = 1.0
     return 1.7320508075688772 * gain * math.sqrt(2.0 / float(fan_in + fan_out))
+
+
+def rgin_layer_rel_grouped(x, src, dst, etype, p, num_rels, act="relu", num_mlp_layers=2):
+    """CPU-baseline port: the reference's per-edge `x[src] @ W[etype]` message (rgin.py:102-112) evaluated relation by
+    relation (one [E_r, H] x [H, H] GEMM per relation instead of the [E, H, H] weight gather + bmm, which cannot be
+    allocated at the benchmark size), summed by destination (fn.sum), then the reference's node update (rgin.py:137-154)."""
+    N = x.shape[0]
+    f = act_fn(act)
+    order = th.argsort(etype, stable=True)
+    counts = th.bincount(etype, minlength=num_rels).tolist()
+    out = th.zeros(N, p["weight"].shape[2], dtype=x.dtype)
+    pos = 0
+    for r in range(num_rels):
+        e = order[pos:pos + counts[r]]
+        pos += counts[r]
+        if e.numel():
+            out = out.index_add(0, dst[e], x[src[e]] @ p["weight"][r])
+    if p.get("loop_weight") is not None:
+        out = out + x @ p["loop_weight"]
+    if p.get("bias") is not None:
+        out = out + p["bias"]
+    for i in range(num_mlp_layers):
+        out = F.linear(out, p["mlp.%d.weight" % (2 * i)], p["mlp.%d.bias" % (2 * i)])
+        if i != num_mlp_layers - 1:
+            out = f(out)
+    if num_mlp_layers == 0:
+        out = f(out)
+    return f(out)

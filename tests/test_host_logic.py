@@ -1,0 +1,143 @@
+"""Host-side logic on the CPU: module surface (names, shapes, initial weights), containers, partitioner,
+and the rule that the product path refuses to run without the GPU (no CPU fallback)."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as OL
+
+
+def _cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "si_layers.npz"))
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def _build(m):
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGCNLayer, RGINLayer
+    kw = dict(num_rels=m["num_rels"], regularizer=m["regularizer"], num_bases=m["num_bases"],
+              self_loop=m["self_loop"], act_func=m["act_func"])
+    if m["kind"] == "rgin":
+        return RGINLayer(m["input_dim"], m["hidden_dim"], num_mlp_layers=m["num_mlp_layers"], **kw)
+    return RGCNLayer(m["input_dim"], m["hidden_dim"], edge_norm=m["edge_norm"], **kw)
+
+
+def test_initial_weights_are_bit_identical_to_the_reference(golden_dir):
+    """Same torch.manual_seed => same RNG stream => same initial parameters as the reference modules
+    (custom Xavier of SI utils/init.py:52-75, creation order of rgin.py:42-88 / rgcn.py:44-86)."""
+    z, meta = _cases(golden_dir)
+    for m in meta:
+        torch.manual_seed(m["seed"])
+        layer = _build(m)
+        sd = layer.state_dict()
+        ref_keys = sorted(k[len(m["tag"]) + 7:] for k in z.files if k.startswith(m["tag"] + "/param/"))
+        assert sorted(sd.keys()) == ref_keys, m["tag"]
+        for k in ref_keys:
+            ref = z["%s/param/%s" % (m["tag"], k)]
+            assert tuple(sd[k].shape) == ref.shape, (m["tag"], k)
+            assert np.array_equal(sd[k].numpy(), ref), (m["tag"], k)
+
+
+def test_gc_model_state_dict_names():
+    from dummynode4graphlearning_amd.graph_classification import GIN, RGCN, RGIN
+    args = SimpleNamespace(num_features=7, hidden_dim=16, num_classes=3, dropout_ratio=0.5, num_relations=4,
+                           additional={"num_layers": 3}, epochs=5, device="cpu", dummy_weight=0)
+    gin = GIN(args)
+    keys = set(gin.state_dict().keys())
+    for k in ("first_h.0.weight", "first_h.1.running_mean", "first_h.3.bias", "first_h.4.weight", "nns.0.0.weight",
+              "convs.0.nn.0.weight", "convs.0.eps", "convs.1.nn.4.bias", "linears.2.weight"):
+        assert k in keys, k
+    assert gin.convs[0].nn is gin.nns[0]                       # shared module, as in gconv.py:195-197
+    assert gin.convs[0].train_eps is True                      # gconv.py:179 quirk: falls back to args.epochs (truthy)
+    rgin = RGIN(args)
+    assert tuple(rgin.state_dict()["convs.0.weight"].shape) == (4, 16, 16)
+    assert tuple(rgin.state_dict()["convs.1.root"].shape) == (16, 16)
+    rgcn = RGCN(args)
+    assert {"conv1.weight", "conv2.root", "conv1.bias", "lin3.weight"} <= set(rgcn.state_dict().keys())
+    assert tuple(rgcn.state_dict()["conv1.weight"].shape) == (4, 7, 16)
+
+
+def test_layer_validation_matches_reference():
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    with pytest.raises(ValueError):
+        RGINLayer(64, 64, num_rels=3, regularizer="bdd", num_bases=4)      # 64 % 3 != 0
+    with pytest.raises(AssertionError):
+        RGINLayer(8, 8, regularizer="diag")
+    layer = RGINLayer(8, 8, num_rels=3, regularizer="basis", num_bases=7)
+    assert layer.num_bases == 3 and layer.w_comp is None
+    repr(layer)                                                              # the reference's extra_repr raises
+
+
+def test_product_path_refuses_cpu_tensors():
+    from dummynode4graphlearning_amd import BatchedGraph, ops
+    from dummynode4graphlearning_amd._lib import DnHipError
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    x = torch.randn(4, 8)
+    with pytest.raises(DnHipError):
+        ops.gather_segsum(x, torch.zeros(2, dtype=torch.int32), torch.tensor([0, 1, 2], dtype=torch.int32))
+    g = BatchedGraph(torch.tensor([0, 1]), torch.tensor([1, 2]), 4)
+    with pytest.raises(DnHipError):
+        RGINLayer(8, 8, num_rels=2)(g, x, torch.tensor([0, 1]))
+
+
+def test_batched_graph_container():
+    from dummynode4graphlearning_amd import BatchedGraph
+    g1 = BatchedGraph(torch.tensor([0, 1]), torch.tensor([1, 2]), 3, ndata={"id": torch.arange(3)},
+                      edata={"label": torch.tensor([0, 1])})
+    g2 = BatchedGraph(torch.tensor([1]), torch.tensor([0]), 2, ndata={"id": torch.arange(2)},
+                      edata={"label": torch.tensor([2])})
+    b = BatchedGraph.batch([g1, g2])
+    assert b.batch_size == 2 and b.number_of_nodes() == 5 and b.number_of_edges() == 3
+    assert b.batch_num_nodes().tolist() == [3, 2] and b.batch_num_edges().tolist() == [2, 1]
+    u, v = b.all_edges()
+    assert u.tolist() == [0, 1, 4] and v.tolist() == [1, 2, 3]
+    assert b.ndata["id"].tolist() == [0, 1, 2, 0, 1] and b.edata["label"].tolist() == [0, 1, 2]
+    assert b.in_degrees().tolist() == [0, 1, 1, 1, 0] and b.out_degrees().tolist() == [1, 1, 0, 0, 1]
+    assert b.node_ptr().tolist() == [0, 3, 5] and b.edge_ptr().tolist() == [0, 2, 3]
+
+
+def test_graph_batch_collate():
+    from dummynode4graphlearning_amd import GraphBatch
+    items = [SimpleNamespace(x=torch.ones(2, 3), edge_index=torch.tensor([[0, 1], [1, 0]]), edge_attr=torch.eye(2),
+                             y=torch.tensor([1]), is_dummy_node=torch.tensor([False, True]),
+                             is_dummy_edge=torch.tensor([True, True])),
+             SimpleNamespace(x=torch.zeros(3, 3), edge_index=torch.tensor([[2], [0]]), edge_attr=torch.tensor([[0., 1.]]),
+                             y=torch.tensor([0]), is_dummy_node=torch.tensor([False, False, True]),
+                             is_dummy_edge=torch.tensor([False]))]
+    b = GraphBatch.collate(items)
+    assert b.num_graphs == 2 and b.x.shape == (5, 3)
+    assert b.edge_index.tolist() == [[0, 1, 4], [1, 0, 2]]
+    assert b.batch.tolist() == [0, 0, 1, 1, 1] and b.ptr.tolist() == [0, 2, 5] and b.y.tolist() == [1, 0]
+
+
+def test_cpu_baseline_port_equals_reference_formulation(golden_dir):
+    """bench.py's CPU baseline (relation-grouped messages) is the same math as the reference's per-edge bmm."""
+    z, meta = _cases(golden_dir)
+    done = 0
+    for m in meta:
+        if m["kind"] != "rgin" or m["regularizer"] != "basis" or m["num_bases"] != -1 or not m["self_loop"]:
+            continue
+        tag = m["tag"]
+        p = {k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}
+        u, v, t = (torch.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
+        out = OL.rgin_layer_rel_grouped(torch.from_numpy(z[tag + "/x"]), u, v, t, p, m["num_rels"], act=m["act_func"],
+                                        num_mlp_layers=m["num_mlp_layers"])
+        torch.testing.assert_close(out, torch.from_numpy(z[tag + "/out"]), rtol=1e-4, atol=1e-5, msg=tag)
+        done += 1
+    assert done >= 3
+
+
+def test_synthetic_configs_have_the_survey_shapes():
+    from dummynode4graphlearning_amd import synthetic
+    from oracle import transforms as OT
+    c3 = synthetic.config3()
+    aug = OT.dummy_augment_si(*(c3[k] for k in ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id",
+                                                 "edge_label")), c3["max_nv"], c3["max_nvl"], c3["max_ne"], c3["max_nel"])
+    assert len(aug["node_label"]) == 25600 and len(aug["src"]) == 102400 and aug["edge_label"].max() == 7
+    c5 = synthetic.config5(graphs=64)
+    assert len(c5["src"]) == 64 * 62 and c5["num_rels"] == 16
+    c1 = synthetic.config1()
+    assert len(c1["node_ptr"]) == 33 and 400 < c1["node_ptr"][-1] < 800
