@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (0 = the workload's own size)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,17 +142,43 @@ def main():
     torch.cuda.synchronize()
     index_ms = (time.perf_counter() - t0) * 1e3
 
-    def step():
+    def compute():
         bucket.zero()
         x.grad = None
         out, _ = layer(g, x, etype)
         out.backward(gout)
+
+    def step_eager():
+        compute()
         bucket.all_reduce()
+
+    # The step is launch-bound from Python (a few hundred small launches): capture it once into a HIP graph and replay it.
+    # The gradient all-reduce (RCCL) stays outside the graph, on the same stream right after the replay.
+    use_graph = not args.no_graph
+    for _ in range(max(args.warmup, 2)):
+        step_eager()
+    torch.cuda.synchronize()
+    graph = None
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            compute()                                   # warm the private pool on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            compute()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            bucket.all_reduce()
+        else:
+            step_eager()
 
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer()
-    ops.kernel_timer = timer
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,23 +189,60 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.kernel_timer = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # roofline leg: the conv's gather-scatter launches alone (gather/segment-sum + gathered-row transform of the forward
+    # and of the input-gradient pass, exactly the launches the step makes), replayed as their own HIP graph and timed with
+    # HIP events on the launch stream
+    def conv_gather_scatter():
+        with torch.no_grad():
+            W = layer.weight
+            if dtype == torch.bfloat16:
+                W_all = torch.cat([W, layer.loop_weight.unsqueeze(0)], 0)
+                Wn = W_all.transpose(1, 2).contiguous()
+                ybuf = index.ybuf(H, dtype, dev)
+                for n0, n1, ix in index.parts:
+                    for src_t, wmat, idx_rows, lst, ptr_, aux_i, aux_p, n_aux in (
+                            (x, Wn, ix.row_in, ix.dst_rows, ix.dst_ptr, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f),
+                            (gout, W_all, ix.row_out, ix.src_rows, ix.src_ptr, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)):
+                        xs = src_t[n0:n1]
+                        aux = ops.gather_segsum(xs, aux_i, aux_p, n_aux) if n_aux else None
+                        Y = ops.rows_transform(xs, wmat, ix.tile_table, ix.num_rows, idx=idx_rows, X2=aux, out=ybuf)
+                        ops.gather_segsum(Y, lst, ptr_, ix.num_nodes)
+            else:
+                A = ops.gather_segsum(x, index.src1, index.seg_ptr, index.num_segments)
+                ops.gather_segsum(A, index.sperm, index.dptr, N)
+                gy = ops.gather_segsum(gout, index.seg_dst, None)
+                ops.gather_segsum(gy, index.seg_by_src, index.optr, N)
+
+    conv_gather_scatter()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    conv_gather_scatter()                               # eager pass: counts the launches (times include launch gaps)
+    ops.kernel_timer = None
+    n_launch = len(timer.records)
+    cgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cgraph):
+        conv_gather_scatter()
+    cgraph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(args.steps, 5)
+    e0.record()
+    for _ in range(reps):
+        cgraph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms_step = e0.elapsed_time(e1) / reps
     ms_per_step = dt / args.steps * 1e3
 
-    # roofline of the gather/segment-sum kernel: algorithmic bytes of the layer's gather-scatter forward+backward
-    # (2*(E*H*s + N*H*s + 8*E)) over the time all its launches take per step (HIP events)
-    summ = timer.summary()
-    per_step = {k: (v[0] / max(args.steps, 1), v[1] / max(args.steps, 1)) for k, v in summ.items()}
-    # the conv's gather-scatter = the gather/segment-sum launches + (bf16 path) the gathered-row transform launches that
-    # read x[src] / g[dst]; their time is charged in full although the transform also does the relation GEMM
-    conv_tags = [k for k in per_step if k in ("gather_segsum", "rows_transform:conv")]
-    launches_per_step = sum(per_step[k][0] for k in conv_tags)
-    kernel_ms_step = sum(per_step[k][1] for k in conv_tags)
-    other = {k: v[1] for k, v in per_step.items()}
+    # roofline: algorithmic bytes of the layer's gather-scatter forward+backward (SURVEY.md 8d:
+    # 2*(E*H*s + N*H*s + 8*E)) over the time of the launches that implement it
+    launches_per_step = n_launch
     alg_bytes_step = 2.0 * (E * H * s + N * H * s + 8.0 * E)
     achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
 
@@ -192,12 +256,13 @@ def main():
                                    "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
                        "global_edges": world * E, "parallelism": "dp%d" % world,
                        "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms, "dummy_augment_ms": aug_ms,
-                       "grad_bucket_bytes": bucket.bytes()},
+                       "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,
+                       "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "gather_segsum_vec_kernel + rows_transform_kernel (conv launches)",
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
-                         "alg_bytes_per_step": alg_bytes_step, "hip_kernels_ms_per_step": other},
+                         "alg_bytes_per_step": alg_bytes_step},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw, H, R)

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSegsPerGroup = 8;  // segments a row group walks per block (chunk = groups * this)
+constexpr int kSegsPerGroup = 2;  // segments a row group walks per block (chunk = groups * this)
 
 typedef __bf16 bf16_t;
 

@@ -14,6 +14,15 @@ import torch
 from . import ops
 
 
+import os as _os
+
+# nodes per sub-batch of the fused bf16 path (ops.RowIndexSet); 0 = never split.  Measured on MI355X (config 5,
+# HIP-graph replay): 1 / 4 / 8 / 16 / 32 sub-batches -> 5.17 / 5.92 / 6.76 / 8.23 / 11.2 ms per step, i.e. keeping the
+# intermediate rows "cache resident" by shrinking the launches loses more to under-filled launches than the 256 MiB
+# Infinity Cache gives back, so the default is one full-size launch per kernel.
+ROW_SUBBATCH_NODES = int(_os.environ.get("DN_SUBBATCH_NODES", "0"))
+
+
 class _IndexCache:
     def __init__(self):
         self._edge_index = None
@@ -119,7 +128,9 @@ class BatchedGraph:
         for t, ver, r, ix in self._cache._rel:
             if t is etype and ver == etype._version and r == ("row", num_rels, self_loop):
                 return ix
-        ix = ops.RowIndex(self._src, self._dst, etype, self._n, num_rels, self_loop=self_loop)
+        ix = ops.RowIndexSet(self._src, self._dst, etype, self._n, num_rels, self_loop,
+                             node_ptr=self.node_ptr(), edge_ptr=self.edge_ptr(),
+                             target_nodes=ROW_SUBBATCH_NODES if ROW_SUBBATCH_NODES > 0 else 1 << 62)
         self._cache._rel.append((etype, etype._version, ("row", num_rels, self_loop), ix))
         if len(self._cache._rel) > 4:
             self._cache._rel.pop(0)

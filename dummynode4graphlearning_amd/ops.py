@@ -203,14 +203,19 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
     return torch.from_numpy(tl.astype(np.int32)).to(device), int(tl.shape[0])
 
 
-def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense"):
+def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense",
+                   out=None):
     """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16)."""
     tiles, ntiles = tile_table
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
     assert X.dtype == torch.bfloat16 and Wn.dtype == torch.bfloat16 and Wn.dim() == 3
     Ho, Hi = Wn.shape[1], Wn.shape[2]
     assert X.shape[1] == Hi
-    Y = torch.empty((num_rows, Ho), dtype=X.dtype, device=X.device)
+    if out is None:
+        Y = torch.empty((num_rows, Ho), dtype=X.dtype, device=X.device)
+    else:
+        assert out.is_contiguous() and out.dtype == X.dtype and out.shape[0] >= num_rows and out.shape[1] == Ho
+        Y = out[:num_rows]
 
     def _launch():
         check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho,
@@ -519,8 +524,8 @@ class RowIndex:
         self.num_all_rels = R + (1 if self_loop else 0)
         self.rel_ptr_host = rel_ptr
         self.tile_table = make_row_tiles(rel_ptr, dev)
-        self.chunk_table = make_row_chunks(rel_ptr, dev)
-        self.colsum_ptr = colsum_levels(N, dev)
+        # ~1.5 workgroups per CU for the split-K weight gradient whatever the sub-batch size
+        self.chunk_table = make_row_chunks(rel_ptr, dev, chunk_rows=max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)))
 
     @staticmethod
     def _ptr(ids, n, dev):
@@ -551,42 +556,100 @@ def column_sum(g, levels):
     return cur.float().sum(0)
 
 
+class RowIndexSet:
+    """Row factorisations of CONTIGUOUS GRAPH RANGES of one batch ("sub-batches"), each small enough that its x rows,
+    its transformed rows Y and its output rows stay resident in the 256 MiB Infinity Cache / the XCD L2s between the
+    kernels that produce and consume them.  The kernels below are HBM-bound (rocprof: 4.3-5.5 TB/s), so the win comes
+    from not sending the Y round trip (and the repeated x / g gathers) to HBM at all: every sub-batch reuses ONE Y
+    buffer.  A batch is a disjoint union of graphs, so sub-batches are independent."""
+
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop, node_ptr=None, edge_ptr=None,
+                 target_nodes=32768):
+        dev = src.device
+        N, E = int(num_nodes), int(src.numel())
+        self.num_nodes, self.num_rels, self.self_loop = N, int(num_rels), bool(self_loop)
+        bounds = [(0, N, 0, E)]
+        if node_ptr is not None and edge_ptr is not None and N > target_nodes:
+            npt, ept = node_ptr.tolist(), edge_ptr.tolist()
+            bounds, g0, G = [], 0, len(npt) - 1
+            while g0 < G:
+                g1 = g0 + 1
+                while g1 < G and npt[g1 + 1] - npt[g0] <= target_nodes:
+                    g1 += 1
+                bounds.append((npt[g0], npt[g1], ept[g0], ept[g1]))
+                g0 = g1
+        self.parts = []
+        s64, d64 = src.long(), dst.long()
+        for n0, n1, e0, e1 in bounds:
+            ix = RowIndex(s64[e0:e1] - n0, d64[e0:e1] - n0, etype[e0:e1], n1 - n0, num_rels, self_loop=self_loop)
+            self.parts.append((n0, n1, ix))
+        self.max_rows = max(ix.num_rows for _, _, ix in self.parts)
+        self.num_rows = sum(ix.num_rows for _, _, ix in self.parts)
+        self.num_all_rels = self.num_rels + (1 if self_loop else 0)
+        self._ybuf = {}
+
+    def ybuf(self, H, dtype, dev):
+        key = (H, dtype, str(dev))
+        b = self._ybuf.get(key)
+        if b is None:
+            b = torch.empty((self.max_rows, H), dtype=dtype, device=dev)
+            self._ybuf[key] = b
+        return b
+
+
 class _RowTransformFn(torch.autograd.Function):
-    """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop)."""
+    """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop), evaluated
+    sub-batch by sub-batch (RowIndexSet) so the intermediate rows never leave the on-die caches."""
 
     @staticmethod
-    def forward(ctx, x, W_all, bias, index):
-        ix = index
+    def forward(ctx, x, W_all, bias, index_set):
         x = x.contiguous()
-        aux = gather_segsum(x, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
         Wn = W_all.transpose(1, 2).contiguous()                              # [R', out, in]
         bias_all = None
         if bias is not None:
             bias_all = torch.zeros((W_all.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
             bias_all[-1] = bias                                              # only self-loop rows carry the bias
-        Y = rows_transform(x, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all, tag="conv")
-        out = gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes)
-        ctx.index, ctx.has_bias = ix, bias is not None
-        ctx.save_for_backward(x, W_all, aux if aux is not None else x.new_empty(0))
+        out = torch.empty((x.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
+        ybuf = index_set.ybuf(W_all.shape[2], x.dtype, x.device)
+        for n0, n1, ix in index_set.parts:
+            xs = x[n0:n1]
+            aux = gather_segsum(xs, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+            Y = rows_transform(xs, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all, tag="conv",
+                               out=ybuf)
+            gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes, out=out[n0:n1])
+        ctx.index_set, ctx.has_bias = index_set, bias is not None
+        ctx.save_for_backward(x, W_all)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ix = ctx.index
+        iset = ctx.index_set
         g = g.contiguous()
-        x, W_all, aux = ctx.saved_tensors
-        aux = aux if aux.numel() else None
-        aux_b = gather_segsum(g, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
-        gx = gW = gb = None
-        if ctx.needs_input_grad[0]:
-            gA = rows_transform(g, W_all.contiguous(), ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b, tag="conv")
-            gx = gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
-            gW, cs = rows_wgrad(x, g, ix.chunk_table, W_all.shape[0], idx_a=ix.row_in, idx_g=ix.row_out, A2=aux, G2=aux_b,
-                                out_dtype=W_all.dtype, colsum_of=2)
+        x, W_all = ctx.saved_tensors
+        Wc = W_all.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gx = torch.empty_like(x) if need_x else None
+        gW32 = cs32 = None
+        ybuf = iset.ybuf(W_all.shape[1], g.dtype, g.device)
+        single = len(iset.parts) == 1
+        for n0, n1, ix in iset.parts:
+            gs, xs = g[n0:n1], x[n0:n1]
+            aux_b = gather_segsum(gs, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
+            if need_x:
+                gA = rows_transform(gs, Wc, ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b, tag="conv", out=ybuf)
+                gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes, out=gx[n0:n1])
+            if need_w:
+                aux = gather_segsum(xs, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+                # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
+                gw, cs = rows_wgrad(xs, gs, ix.chunk_table, W_all.shape[0], idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
+                                    G2=aux_b, out_dtype=W_all.dtype if single else torch.float32, colsum_of=2)
+                gW32 = gw if gW32 is None else gW32.add_(gw)
+                cs32 = cs if cs32 is None else cs32.add_(cs)
+        gW = gb = None
+        if need_w:
+            gW = gW32.to(W_all.dtype)
             if ctx.has_bias:
-                gb = cs[-1].to(g.dtype)
+                gb = cs32[-1].to(g.dtype)
         return gx, gW, gb, None
 
 
@@ -595,12 +658,18 @@ def fused_path_supported(x, W):
             and W.shape[1] == W.shape[2] and W.shape[1] in (64, 128, 256) and x.shape[1] == W.shape[1])
 
 
-def rel_transform_fused(x, W_all, bias, index):
-    """Fused bf16 path.  W_all: [R(+1), in, out] with the self-loop weight last when index.self_loop; bias is added on the
-    self-loop rows (requires index.self_loop)."""
-    assert bias is None or index.self_loop
-    assert W_all.shape[0] == index.num_all_rels
-    return _RowTransformFn.apply(x, W_all, bias, index)
+def rel_transform_fused(x, W_all, bias, index_set):
+    """Fused bf16 path.  W_all: [R(+1), in, out] with the self-loop weight last when index_set.self_loop; bias is added on
+    the self-loop rows (requires the self loop).  index_set: RowIndexSet (or a single RowIndex)."""
+    if isinstance(index_set, RowIndex):
+        one = index_set
+        index_set = RowIndexSet.__new__(RowIndexSet)
+        index_set.num_nodes, index_set.num_rels, index_set.self_loop = one.num_nodes, one.num_rels, one.self_loop
+        index_set.parts, index_set.max_rows, index_set.num_rows = [(0, one.num_nodes, one)], one.num_rows, one.num_rows
+        index_set.num_all_rels, index_set._ybuf = one.num_all_rels, {}
+    assert bias is None or index_set.self_loop
+    assert W_all.shape[0] == index_set.num_all_rels
+    return _RowTransformFn.apply(x, W_all, bias, index_set)
 
 
 # ----------------------------------------------------------------------------------------------
