@@ -246,6 +246,17 @@ def main():
     alg_bytes_step = 2.0 * (E * H * s + N * H * s + 8.0 * E)
     achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
 
+    # HBM traffic of those launches comes from PMC counters, which cannot be read from inside the process: it is taken
+    # from the committed rocprofv3 measurement of this exact workload (profiles/r01_traffic.json), else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f)
+        if (tj["workload"], tj["N"], tj["E"], tj["H"], tj["dtype"]) == (args.workload, N, E, H, "bf16" if dtype == torch.bfloat16 else "f32"):
+            traffic = tj["conv_gather_scatter_hbm_bytes_per_step"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         line = {
             "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": world * E / (ms_per_step * 1e-3),
@@ -259,7 +270,7 @@ def main():
                        "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "gather_segsum_vec_kernel + rows_transform_kernel (conv launches)",
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step},
