@@ -611,35 +611,38 @@ class _RowTransformFn(torch.autograd.Function):
             bias_all[-1] = bias                                              # only self-loop rows carry the bias
         out = torch.empty((x.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
         ybuf = index_set.ybuf(W_all.shape[2], x.dtype, x.device)
+        auxs = []
         for n0, n1, ix in index_set.parts:
             xs = x[n0:n1]
             aux = gather_segsum(xs, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+            auxs.append(aux if aux is not None else x.new_empty(0))      # a few MB: kept for the weight gradient
             Y = rows_transform(xs, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all, tag="conv",
                                out=ybuf)
             gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes, out=out[n0:n1])
         ctx.index_set, ctx.has_bias = index_set, bias is not None
-        ctx.save_for_backward(x, W_all)
+        ctx.save_for_backward(x, W_all, *auxs)
         return out
 
     @staticmethod
     def backward(ctx, g):
         iset = ctx.index_set
         g = g.contiguous()
-        x, W_all = ctx.saved_tensors
+        x, W_all = ctx.saved_tensors[:2]
+        auxs = ctx.saved_tensors[2:]
         Wc = W_all.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         gx = torch.empty_like(x) if need_x else None
         gW32 = cs32 = None
         ybuf = iset.ybuf(W_all.shape[1], g.dtype, g.device)
         single = len(iset.parts) == 1
-        for n0, n1, ix in iset.parts:
+        for part, (n0, n1, ix) in enumerate(iset.parts):
             gs, xs = g[n0:n1], x[n0:n1]
             aux_b = gather_segsum(gs, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
             if need_x:
                 gA = rows_transform(gs, Wc, ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b, tag="conv", out=ybuf)
                 gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes, out=gx[n0:n1])
             if need_w:
-                aux = gather_segsum(xs, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+                aux = auxs[part] if ix.num_aux_f else None
                 # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
                 gw, cs = rows_wgrad(xs, gs, ix.chunk_table, W_all.shape[0], idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
                                     G2=aux_b, out_dtype=W_all.dtype if single else torch.float32, colsum_of=2)
