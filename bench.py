@@ -111,7 +111,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # torch.distributed.run (even with one rank)
+    if world > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
 
     from dummynode4graphlearning_amd import ops
@@ -278,7 +279,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw, H, R)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -237,6 +237,61 @@ def wgrad_supported(A, G):
 # ----------------------------------------------------------------------------------------------
 # index structures
 # ----------------------------------------------------------------------------------------------
+HUB_SPLIT = 64   # segments longer than this are split into chunks summed by separate lane groups
+
+
+class _SplitCSR:
+    """CSR whose long segments ("hubs": the dummy node of a big graph has in-degree n) are taken out of the main pass and
+    summed in HUB_SPLIT-entry chunks by separate lane groups, then folded in chunk order (deterministic).  One lane group
+    walking a 600-entry segment would otherwise outlast the whole launch (cdna_hip_programming.md, scatter/gather:
+    'split lists longer than ... into chunks summed by separate waves')."""
+
+    def __init__(self, ptr, idx, num_segments):
+        self.ptr, self.idx, self.num_segments = ptr, idx, int(num_segments)
+        self.hub_ids = None
+        if idx.numel() == 0:
+            return
+        deg = (ptr[1:] - ptr[:-1]).long()
+        if int(deg.max()) <= HUB_SPLIT:
+            return
+        dev = ptr.device
+        hub = deg > HUB_SPLIT
+        hub_ids = torch.nonzero(hub).reshape(-1)
+        seg_of_entry = torch.repeat_interleave(torch.arange(self.num_segments, device=dev), deg)
+        keep = ~hub[seg_of_entry]
+        # main pass: hubs become empty segments
+        deg_main = torch.where(hub, torch.zeros_like(deg), deg)
+        self.ptr_main = torch.cat([deg_main.new_zeros(1), torch.cumsum(deg_main, 0)]).to(I32)
+        self.keep = keep
+        self.idx_main = idx[keep].contiguous()
+        # hub pass: entries of hub h in HUB_SPLIT-sized chunks
+        hdeg = deg[hub_ids]
+        nchunk = (hdeg + HUB_SPLIT - 1) // HUB_SPLIT
+        self.idx_hub = idx[~keep].contiguous()
+        hub_base = torch.cat([hdeg.new_zeros(1), torch.cumsum(hdeg, 0)])[:-1]
+        chunk_hub = torch.repeat_interleave(torch.arange(hub_ids.numel(), device=dev), nchunk)
+        first_chunk = torch.cat([nchunk.new_zeros(1), torch.cumsum(nchunk, 0)])
+        chunk_in_hub = torch.arange(int(first_chunk[-1]), device=dev) - first_chunk[:-1][chunk_hub]
+        cbeg = hub_base[chunk_hub] + chunk_in_hub * HUB_SPLIT
+        cend = torch.minimum(cbeg + HUB_SPLIT, (hub_base + hdeg)[chunk_hub])
+        self.chunk_ptr = torch.cat([cbeg, cend[-1:]]).to(I32)                 # chunks are contiguous in idx_hub
+        self.fold_ptr = first_chunk.to(I32)                                   # chunk ranges per hub
+        self.hub_ids = hub_ids
+
+    def segsum(self, x, scale=None, self_in=None, self_coef=0.0):
+        if self.hub_ids is None:
+            return gather_segsum(x, self.idx, self.ptr, self.num_segments, scale=scale, self_in=self_in, self_coef=self_coef)
+        sc_main = sc_hub = None
+        if scale is not None:
+            sc_main, sc_hub = scale[self.keep].contiguous(), scale[~self.keep].contiguous()
+        out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
+                            self_coef=self_coef)
+        part = gather_segsum(x, self.idx_hub, self.chunk_ptr, self.chunk_ptr.numel() - 1, scale=sc_hub)
+        hub = gather_segsum(part, None, self.fold_ptr)                        # per-hub sum of its chunk partials
+        out.index_add_(0, self.hub_ids, hub)                                  # distinct rows: order-independent
+        return out
+
+
 class EdgeIndex:
     """CSR by destination + CSC by source of one batched COO (int32, device resident).
     The one-shot build DGL / torch-scatter hide behind update_all / scatter."""
@@ -251,6 +306,8 @@ class EdgeIndex:
         # neighbour id lists in segment order (row gather of an int column == index_select plumbing)
         self.src_by_dst = gather_rows_i32(src, self.in_perm)
         self.dst_by_src = gather_rows_i32(dst, self.out_perm)
+        self.fwd = _SplitCSR(self.in_ptr, self.src_by_dst, num_nodes)
+        self.bwd = _SplitCSR(self.out_ptr, self.dst_by_src, num_nodes)
 
 
 def gather_rows_i32(values, perm):
@@ -304,15 +361,13 @@ class _NeighborSum(torch.autograd.Function):
             sc_in = edge_scale.index_select(0, index.in_perm.long())
             sc_out = edge_scale.index_select(0, index.out_perm.long())
         ctx.sc_out = sc_out
-        return gather_segsum(x, index.src_by_dst, index.in_ptr, index.num_nodes, scale=sc_in,
-                             self_in=x if self_coef != 0.0 else None, self_coef=self_coef)
+        return index.fwd.segsum(x, scale=sc_in, self_in=x if self_coef != 0.0 else None, self_coef=self_coef)
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         ix = ctx.index
-        gx = gather_segsum(g, ix.dst_by_src, ix.out_ptr, ix.num_nodes, scale=ctx.sc_out,
-                           self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
+        gx = ix.bwd.segsum(g, scale=ctx.sc_out, self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
         return gx, None, None, None
 
 

@@ -47,9 +47,9 @@ class FlatGradBucket:
         self.flat.zero_()
 
     def all_reduce(self, async_op=False):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return None
-        if self.average:
+        if self.average and dist.get_world_size() > 1:
             self.flat.div_(dist.get_world_size())
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 

@@ -259,3 +259,31 @@ def test_fused_row_factorisation_forward_backward(self_loop):
     assert rel(Wd.grad, Wr.grad) < 2e-2
     if self_loop:
         assert rel(bd.grad, br.grad) < 2e-2
+
+
+def test_neighbor_sum_with_hub_splitting():
+    """Dummy-node hubs (in- and out-degree ~600, as in PROTEINS-sized graphs) go through the split path; same result."""
+    ops = _ops()
+    rng = np.random.default_rng(6)
+    N, H = 1500, 128
+    src, dst = list(rng.integers(0, N, size=4000)), list(rng.integers(0, N, size=4000))
+    for hub, n in ((7, 620), (900, 65), (1499, 300)):
+        others = rng.choice(N, size=n, replace=False)
+        src += list(others) + [hub] * n
+        dst += [hub] * n + list(others)
+    src, dst = np.array(src), np.array(dst)
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(0.5, 1.5, size=len(src)).astype(np.float32))
+    coef = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+    index = ops.EdgeIndex(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV), N)
+    assert index.fwd.hub_ids is not None and index.fwd.hub_ids.numel() == 3 and index.bwd.hub_ids.numel() == 3
+    for scale in (None, w):
+        xd = x.to(DEV).requires_grad_(True)
+        out = ops.neighbor_sum(xd, index, 1.0, edge_scale=None if scale is None else scale.to(DEV))
+        (out * coef.to(DEV)).sum().backward()
+        xr = x.double().requires_grad_(True)
+        rows = xr[torch.from_numpy(src)] * (1.0 if scale is None else scale.double().view(-1, 1))
+        ref = xr + torch.zeros(N, H, dtype=torch.float64).index_add(0, torch.from_numpy(dst), rows)
+        (ref * coef.double()).sum().backward()
+        torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-4)

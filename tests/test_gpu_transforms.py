@@ -186,3 +186,63 @@ def test_conjugate_of_empty_batch():
     z = _d([])
     cj = T.conjugate(_d([0, 3, 3]), _d([0, 0, 0]), z, z, _d([1, 1, 1]), mode="line")
     assert cj["cnode_ptr"].tolist() == [0, 0, 0] and cj["csrc"].numel() == 0
+
+
+def test_full_size_config5_dummy_augmentation_and_conjugate():
+    """BASELINE config 5 at full size (32,768 graphs -> N = 1,015,808, E = 3,997,696): device build == C oracle,
+    bit for bit; the conjugate transform of the augmented batch on a quarter of it (9.6 M raw 2-paths)."""
+    import time
+    from dummynode4graphlearning_amd import synthetic
+    from oracle import c_oracle as OC
+    T = _T()
+    raw = synthetic.config5()
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    vocab = (raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    ref = OC.dummy_augment_si(*(raw[k] for k in keys), *vocab)
+    dev_in = [_d(raw[k]) for k in keys]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = T.dummy_augment_si(*dev_in, *vocab)
+    torch.cuda.synchronize()
+    print("dummy augmentation of config 5 on the device: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+    assert got["src"].numel() == 3997696 and got["node_label"].numel() == 1015808
+    for k in ref:
+        _eq(got[k], ref[k], k)
+    # conjugate (SI rule: dummy edges share two ids) of the first 8192 graphs
+    G = 8192
+    n1, e1 = int(ref["node_ptr"][G]), int(ref["edge_ptr"][G])
+    sub = dict(node_ptr=ref["node_ptr"][:G + 1], edge_ptr=ref["edge_ptr"][:G + 1], src=ref["src"][:e1], dst=ref["dst"][:e1],
+               node_label=ref["node_label"][:n1], edge_id=ref["edge_id"][:e1])
+    rcj = OC.conjugate(sub["node_ptr"], sub["edge_ptr"], sub["src"], sub["dst"], sub["node_label"], edge_id=sub["edge_id"], mode="si")
+    dsub = {k: _d(v) for k, v in sub.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gcj = T.conjugate(dsub["node_ptr"], dsub["edge_ptr"], dsub["src"], dsub["dst"], dsub["node_label"], edge_id=dsub["edge_id"],
+                      mode="si")
+    torch.cuda.synchronize()
+    print("conjugate of %d graphs (%d raw 2-paths -> %d conj edges) on the device: %.2f ms"
+          % (G, gcj["num_raw"], gcj["csrc"].numel(), (time.perf_counter() - t0) * 1e3))
+    assert gcj["num_raw"] == rcj["num_raw"]
+    _check_conj(gcj, rcj, "config5 si")
+
+
+def test_full_size_proteins_shaped_gc_pipeline():
+    """Config 2 shape (512 PROTEINS-like graphs, dummy in-degree up to several hundred): GC augmentation + L_Phi."""
+    from dummynode4graphlearning_amd import synthetic
+    from oracle import c_oracle as OC
+    T = _T()
+    raw = synthetic.config2()
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_label", "edge_label")
+    ref = OC.dummy_augment_gc(*(raw[k] for k in keys))
+    got = T.dummy_augment_gc(*(_d(raw[k]) for k in keys))
+    for k in ref:
+        _eq(got[k], ref[k], k)
+    rcj = OC.conjugate(ref["node_ptr"], ref["edge_ptr"], ref["src"], ref["dst"], ref["node_label"],
+                       is_dummy_edge=ref["is_dummy_edge"], mode="gc")
+    gcj = T.conjugate(got["node_ptr"], got["edge_ptr"], got["src"], got["dst"], got["node_label"],
+                      is_dummy_edge=got["is_dummy_edge"], mode="gc")
+    _check_conj(gcj, rcj, "config2 gc")
+    # idempotence-style property at full size: every real edge becomes exactly one conj vertex, plus one Phi per graph
+    nreal = int((ref["is_dummy_edge"] == 0).sum())
+    ngraphs_with_dummy = int((np.diff(ref["node_ptr"]) > 1).sum())
+    assert gcj["rep_edge"].numel() == nreal + ngraphs_with_dummy

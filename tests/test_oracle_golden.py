@@ -226,3 +226,55 @@ def test_init_bound_matches_reference_weights(golden_dir):
         assert np.abs(w).max() <= a * (1 + 1e-6), m["tag"]
         if w.size >= 512:
             assert np.abs(w).max() >= 0.95 * a, m["tag"]
+
+
+def _random_batch(rng, G, max_n):
+    node_ptr, edge_ptr, src, dst = [0], [0], [], []
+    for _ in range(G):
+        n = int(rng.integers(0 if rng.random() < 0.05 else 1, max_n + 1))
+        m = 0 if (n == 0 or rng.random() < 0.1) else int(rng.integers(1, 3 * n + 1))
+        base = node_ptr[-1]
+        if m:
+            src.extend((base + rng.integers(0, n, size=m)).tolist())
+            dst.extend((base + rng.integers(0, n, size=m)).tolist())
+        node_ptr.append(base + n)
+        edge_ptr.append(len(src))
+    N, E = node_ptr[-1], len(src)
+    return dict(node_ptr=np.array(node_ptr), edge_ptr=np.array(edge_ptr), src=np.array(src, dtype=np.int64),
+                dst=np.array(dst, dtype=np.int64), node_label=rng.integers(1, 5, size=N), edge_label=rng.integers(1, 4, size=E))
+
+
+def test_c_oracle_equals_python_oracle_and_goldens(golden_dir):
+    """oracle/dn_oracle.c (used for full-size checks) == oracle/transforms.py (pinned to the reference above)."""
+    from oracle import c_oracle as OC
+    rng = np.random.default_rng(42)
+    for G, max_n in ((1, 5), (40, 12), (150, 25)):
+        b = _random_batch(rng, G, max_n)
+        args = (b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], b["node_label"], b["edge_label"])
+        ref, got = OT.dummy_augment_gc(*args), OC.dummy_augment_gc(*args)
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="gc " + k)
+        for mode, bb, flag in (("gc", ref, ref["is_dummy_edge"]), ("line", b, None)):
+            r = OT.conjugate(bb["node_ptr"], bb["edge_ptr"], bb["src"], bb["dst"], bb["node_label"], is_dummy_edge=flag, mode=mode)
+            c = OC.conjugate(bb["node_ptr"], bb["edge_ptr"], bb["src"], bb["dst"], bb["node_label"], is_dummy_edge=flag, mode=mode)
+            for k in r:
+                np.testing.assert_array_equal(c[k], r[k], err_msg="%s %s" % (mode, k))
+        N, E = b["node_ptr"][-1], len(b["src"])
+        nid = np.arange(N) - np.repeat(b["node_ptr"][:-1], np.diff(b["node_ptr"]))
+        eid = np.arange(E) - np.repeat(b["edge_ptr"][:-1], np.diff(b["edge_ptr"]))
+        eid = np.where(rng.random(E) < 0.15, np.maximum(eid - 1, 0), eid)
+        rev = (rng.random(E) < 0.3).astype(np.int64)
+        sargs = (b["node_ptr"], b["edge_ptr"], b["src"], b["dst"], nid, b["node_label"], eid, b["edge_label"], 99, 7, 500, 9)
+        ref, got = OT.dummy_augment_si(*sargs, is_reversed=rev), OC.dummy_augment_si(*sargs, is_reversed=rev)
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="si " + k)
+        r = OT.conjugate(ref["node_ptr"], ref["edge_ptr"], ref["src"], ref["dst"], ref["node_label"], edge_id=ref["edge_id"], mode="si")
+        c = OC.conjugate(ref["node_ptr"], ref["edge_ptr"], ref["src"], ref["dst"], ref["node_label"], edge_id=ref["edge_id"], mode="si")
+        for k in r:
+            np.testing.assert_array_equal(c[k], r[k], err_msg="si conj " + k)
+    # KAT-1 through the C oracle
+    raw = OT.tu_raw_to_batch([(2, 1), (1, 3), (1, 4)], [1, 1, 1, 1], [1, 2, 3, 4], [1, 2, 3])
+    aug = OC.dummy_augment_gc(raw["node_ptr"], raw["edge_ptr"], raw["src"], raw["dst"], raw["node_label"], raw["edge_label"])
+    cj = OC.conjugate(aug["node_ptr"], aug["edge_ptr"], aug["src"], aug["dst"], aug["node_label"],
+                      is_dummy_edge=aug["is_dummy_edge"], mode="gc")
+    assert list(zip(cj["csrc"], cj["cdst"])) == [(3, 0), (0, 1), (3, 1), (0, 2), (3, 2), (0, 3), (1, 3), (2, 3)]
