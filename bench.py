@@ -137,11 +137,16 @@ def main():
     gout = torch.randn(N, H, device=dev, generator=gen).to(dtype)
     bucket = FlatGradBucket(layer.parameters())
 
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    index = g.row_index(etype, R, True) if dtype == torch.bfloat16 else g.rel_index(etype, R)
-    torch.cuda.synchronize()
-    index_ms = (time.perf_counter() - t0) * 1e3
+    def build_index():
+        g._cache.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix = g.row_index(etype, R, True) if dtype == torch.bfloat16 else g.rel_index(etype, R)
+        torch.cuda.synchronize()
+        return ix, (time.perf_counter() - t0) * 1e3
+
+    index, index_first_ms = build_index()       # first call: allocator growth + code-object load
+    index, index_ms = build_index()             # steady state (what a training loop pays per new batch)
 
     def compute():
         bucket.zero()
@@ -267,7 +272,7 @@ def main():
             "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd on %d graphs/GPU (N=%d, E=%d per GPU), "
                                    "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
                        "global_edges": world * E, "parallelism": "dp%d" % world,
-                       "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms, "dummy_augment_ms": aug_ms,
+                       "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms, "index_build_first_call_ms": index_first_ms, "dummy_augment_ms": aug_ms,
                        "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

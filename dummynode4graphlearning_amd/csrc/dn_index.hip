@@ -488,6 +488,161 @@ int rel_layout(Arena& a, RelWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
     return DN_OK;
 }
 
+// ----- row factorisation index (bf16 fused RGIN/RGCN path; see dn_hip.h dn_row_index_build_i32) -----------------
+constexpr int kModeEdge = 0, kModeAgg = 1, kModeTf = 2;
+
+__global__ void ri_key_kernel(int64_t E, int64_t N, const int32_t* __restrict__ node, const int32_t* __restrict__ etype,
+                              int32_t* key) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    key[e] = (int32_t)((int64_t)etype[e] * N + node[e]);
+}
+// per relation: #edges and #distinct (rel, node) pairs, read off the sorted keys + the exclusive scan of their run heads
+// (binary searches for the relation boundaries: no atomics, a 16-address histogram would serialise 4 M of them)
+__global__ void ri_rel_stats_kernel(int64_t R, int64_t N, int64_t E, const int32_t* __restrict__ skey,
+                                    const int32_t* __restrict__ head, const int32_t* __restrict__ head_scan, int32_t* out_E,
+                                    int32_t* out_distinct) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    auto lower = [&](int64_t k) {
+        int64_t lo = 0, hi = E;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)skey[mid] < k) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    auto heads_before = [&](int64_t p) { return p >= E ? head_scan[E - 1] + head[E - 1] : head_scan[p]; };
+    const int64_t lo = lower(r * N), hi = lower((r + 1) * N);
+    if (out_E) out_E[r] = (int32_t)(hi - lo);
+    out_distinct[r] = heads_before(hi) - heads_before(lo);
+}
+__global__ void ri_mode_kernel(int64_t R, float edge_frac, const int32_t* __restrict__ Er, const int32_t* __restrict__ Dr,
+                               const int32_t* __restrict__ Sr, int32_t* mode) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const int mn = Dr[r] < Sr[r] ? Dr[r] : Sr[r];
+    if (Er[r] == 0 || (float)mn > edge_frac * (float)Er[r]) mode[r] = kModeEdge;
+    else mode[r] = Dr[r] <= Sr[r] ? kModeAgg : kModeTf;
+}
+__global__ void ri_rowkey_kernel(int64_t E, int64_t N, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                 const int32_t* __restrict__ etype, const int32_t* __restrict__ mode, int32_t* key) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    const int r = etype[e];
+    key[e] = (int32_t)((int64_t)r * N + (mode[r] == kModeTf ? src[e] : dst[e]));
+}
+// flags over the sorted edges: row head, AGG-row head, TF-row head, AGG edge, TF edge
+__global__ void ri_flags_kernel(int64_t E, int64_t N, const int32_t* __restrict__ skey, const int32_t* __restrict__ mode,
+                                int32_t* head, int32_t* agg_head, int32_t* tf_head, int32_t* agg_edge, int32_t* tf_edge) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= E) return;
+    const int m = mode[skey[i] / N];
+    const int h = (m == kModeEdge || i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+    head[i] = h;
+    agg_head[i] = (h && m == kModeAgg) ? 1 : 0;
+    tf_head[i] = (h && m == kModeTf) ? 1 : 0;
+    agg_edge[i] = m == kModeAgg ? 1 : 0;
+    tf_edge[i] = m == kModeTf ? 1 : 0;
+}
+// per sorted edge i (row = rows[i] = inclusive head count - 1): fill row tables at heads, aux lists, list entries
+__global__ void ri_fill_kernel(int64_t E, int64_t N, int64_t P_bound, const int32_t* __restrict__ skey,
+                               const int32_t* __restrict__ order, const int32_t* __restrict__ mode,
+                               const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                               const int32_t* __restrict__ head, const int32_t* __restrict__ head_scan,
+                               const int32_t* __restrict__ aggh_scan, const int32_t* __restrict__ tfh_scan,
+                               const int32_t* __restrict__ agge_scan, const int32_t* __restrict__ tfe_scan,
+                               int32_t* row_in, int32_t* row_out, int32_t* row_rel, int32_t* aux_f_idx, int32_t* aux_f_ptr,
+                               int32_t* aux_b_idx, int32_t* aux_b_ptr, int32_t* f_key, int32_t* f_row, int32_t* b_key,
+                               int32_t* b_row) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= E) return;
+    const int rel = skey[i] / (int32_t)N, node = skey[i] % (int32_t)N;
+    const int m = mode[rel], e = order[i], h = head[i];
+    const int row = head_scan[i] + h - 1;                       // exclusive scan + own flag - 1
+    if (h) {
+        row_rel[row] = rel;
+        if (m == kModeAgg) {
+            const int a = aggh_scan[i];
+            row_in[row] = (int32_t)N + a; row_out[row] = node;
+            aux_f_ptr[a] = agge_scan[i];
+            f_key[E + row] = node; f_row[E + row] = row;       // one forward entry per AGG row
+            b_key[E + row] = (int32_t)N;                        // (invalid: key N is the discard segment)
+        } else if (m == kModeTf) {
+            const int a = tfh_scan[i];
+            row_in[row] = node; row_out[row] = (int32_t)N + a;
+            aux_b_ptr[a] = tfe_scan[i];
+            b_key[E + row] = node; b_row[E + row] = row;
+            f_key[E + row] = (int32_t)N;
+        } else {
+            row_in[row] = src[e]; row_out[row] = dst[e];
+            f_key[E + row] = (int32_t)N; b_key[E + row] = (int32_t)N;
+        }
+    }
+    // per-edge entries
+    if (m == kModeAgg) {
+        aux_f_idx[agge_scan[i]] = src[e];
+        f_key[i] = (int32_t)N;                                  // covered by the row entry
+        b_key[i] = src[e]; b_row[i] = row;
+    } else if (m == kModeTf) {
+        aux_b_idx[tfe_scan[i]] = dst[e];
+        f_key[i] = dst[e]; f_row[i] = row;
+        b_key[i] = (int32_t)N;
+    } else {
+        f_key[i] = dst[e]; f_row[i] = row;
+        b_key[i] = src[e]; b_row[i] = row;
+    }
+    (void)P_bound;
+}
+__global__ void ri_tail_kernel(int64_t E, int64_t N, int64_t P, int64_t n_agg, int64_t n_tf, int64_t n_agg_e, int64_t n_tf_e,
+                               int32_t self_loop, int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_b_ptr,
+                               int32_t* f_key, int32_t* f_row, int32_t* b_key, int32_t* b_row) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v == 0) { aux_f_ptr[n_agg] = (int32_t)n_agg_e; aux_b_ptr[n_tf] = (int32_t)n_tf_e; }
+    // entry slots [E + P, 2E) are unused row slots: discard them
+    if (E + P + v < 2 * E) { f_key[E + P + v] = (int32_t)N; b_key[E + P + v] = (int32_t)N; }
+    if (v >= N) return;
+    if (self_loop) {
+        row_in[P + v] = (int32_t)v; row_out[P + v] = (int32_t)v;
+        f_key[2 * E + v] = (int32_t)v; f_row[2 * E + v] = (int32_t)(P + v);
+        b_key[2 * E + v] = (int32_t)v; b_row[2 * E + v] = (int32_t)(P + v);
+    } else {
+        f_key[2 * E + v] = (int32_t)N; b_key[2 * E + v] = (int32_t)N;
+    }
+}
+
+struct RowWs {
+    int32_t *key, *skey, *iota, *order, *Er, *Dr, *Sr, *mode;
+    int32_t *head, *aggh, *tfh, *agge, *tfe, *head_s, *aggh_s, *tfh_s, *agge_s, *tfe_s, *row_rel;
+    int32_t *f_key, *f_row, *b_key, *b_row, *perm, *rel_ptr;
+    void* sort_tmp; size_t sort_tmp_bytes;
+    void* scan_tmp; size_t scan_tmp_bytes;
+    void* csr_ws; size_t csr_ws_bytes;
+};
+int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t st) {
+    memset(&w, 0, sizeof(w));
+    const int64_t L = 2 * E + N;                        // list-entry slots: E edges + E row slots + N self loops
+    w.key = a.take<int32_t>(E); w.skey = a.take<int32_t>(E); w.iota = a.take<int32_t>(E); w.order = a.take<int32_t>(E);
+    w.Er = a.take<int32_t>(R); w.Dr = a.take<int32_t>(R); w.Sr = a.take<int32_t>(R); w.mode = a.take<int32_t>(R);
+    w.head = a.take<int32_t>(E); w.aggh = a.take<int32_t>(E); w.tfh = a.take<int32_t>(E); w.agge = a.take<int32_t>(E);
+    w.tfe = a.take<int32_t>(E); w.head_s = a.take<int32_t>(E); w.aggh_s = a.take<int32_t>(E); w.tfh_s = a.take<int32_t>(E);
+    w.agge_s = a.take<int32_t>(E); w.tfe_s = a.take<int32_t>(E); w.row_rel = a.take<int32_t>(E);
+    w.f_key = a.take<int32_t>(L); w.f_row = a.take<int32_t>(L); w.b_key = a.take<int32_t>(L); w.b_row = a.take<int32_t>(L);
+    w.perm = a.take<int32_t>(L);
+    w.rel_ptr = a.take<int32_t>(R + 2);
+    hipError_t e = hipSuccess;
+    if (E > 0) {
+        e = sort_pairs<int32_t>(nullptr, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, 32, st);
+        if (e == hipSuccess) e = excl_scan(nullptr, w.scan_tmp_bytes, w.head, w.head_s, E, st);
+        if (e != hipSuccess) { dn_set_error("rocprim size query failed: %s", hipGetErrorString(e)); return DN_ERR_HIP; }
+    }
+    w.sort_tmp = a.take_bytes(w.sort_tmp_bytes);
+    w.scan_tmp = a.take_bytes(w.scan_tmp_bytes);
+    size_t need = 0;
+    int rc = csr_build(nullptr, L, N + 1, nullptr, nullptr, nullptr, 0, st, &need);
+    if (rc != DN_OK) return rc;
+    w.csr_ws_bytes = need;
+    w.csr_ws = a.take_bytes(need);
+    return DN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -777,6 +932,103 @@ int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(hipMemcpyAsync(host_rel_ptr, rel_ptr, sizeof(int32_t) * (size_t)(R + 1), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
+    return DN_OK;
+}
+
+size_t dn_row_index_workspace_bytes(int64_t N, int64_t R, int64_t E) {
+    if (N < 0 || R < 0 || E < 0) { dn_set_error("dn_row_index_workspace_bytes: negative size"); return 0; }
+    Arena a(nullptr, 0);
+    RowWs w;
+    if (row_layout(a, w, N, R, E, nullptr) != DN_OK) return 0;
+    return a.off + 256;
+}
+
+int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, const int32_t* dst, const int32_t* etype,
+                           int32_t self_loop, float edge_frac, int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr,
+                           int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows,
+                           int32_t* src_ptr, int32_t* src_rows, int64_t* host_counts, int32_t* host_rel_ptr,
+                           int32_t* host_modes, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && R >= 1 && E >= 0, "dn_row_index_build: bad sizes");
+    DN_REQUIRE(N * R < 0x7fffffffLL && 2 * E + N < 0x7fffffffLL, "dn_row_index_build: N*R and 2E+N must fit int32");
+    DN_REQUIRE(row_in && row_out && aux_f_ptr && aux_b_ptr && dst_ptr && dst_rows && src_ptr && src_rows && host_counts &&
+               host_rel_ptr && host_modes && workspace, "dn_row_index_build: NULL pointer");
+    DN_REQUIRE(E == 0 || (src && dst && etype && aux_f_idx && aux_b_idx), "dn_row_index_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(workspace, workspace_bytes);
+    RowWs w;
+    int rc = row_layout(a, w, N, R, E, st);
+    if (rc != DN_OK) return rc;
+    if (!a.ok()) { dn_set_error("dn_row_index_build: workspace too small (%zu < %zu)", workspace_bytes, a.off); return DN_ERR_WORKSPACE; }
+    const int kb = bits_for((u64)(N * R > 0 ? N * R - 1 : 0));
+    DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, sizeof(int32_t) * (size_t)R, st));
+    DN_CHECK_HIP(hipMemsetAsync(w.Dr, 0, sizeof(int32_t) * (size_t)R, st));
+    DN_CHECK_HIP(hipMemsetAsync(w.Sr, 0, sizeof(int32_t) * (size_t)R, st));
+    int64_t P = 0, n_agg = 0, n_tf = 0, n_agg_e = 0, n_tf_e = 0;
+    if (E > 0) {
+        // (1) per relation: #edges, #distinct destinations, #distinct sources -> EDGE / AGG / TF
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.iota, E);
+        hipLaunchKernelGGL(ri_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, dst, etype, w.key);
+        DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, kb, st));
+        hipLaunchKernelGGL(head_flag_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.skey, E, w.head);
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.head, w.head_s, E, st));
+        hipLaunchKernelGGL(ri_rel_stats_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, N, E, w.skey, w.head, w.head_s, w.Er, w.Dr);
+        hipLaunchKernelGGL(ri_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, src, etype, w.key);
+        DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, kb, st));
+        hipLaunchKernelGGL(head_flag_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.skey, E, w.head);
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.head, w.head_s, E, st));
+        hipLaunchKernelGGL(ri_rel_stats_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, N, E, w.skey, w.head, w.head_s,
+                           (int32_t*)nullptr, w.Sr);
+    }
+    hipLaunchKernelGGL(ri_mode_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, edge_frac, w.Er, w.Dr, w.Sr, w.mode);
+    if (E > 0) {
+        // (2) rows: stable sort by (rel, dst | src), heads, scans
+        hipLaunchKernelGGL(ri_rowkey_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, src, dst, etype, w.mode, w.key);
+        DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, kb, st));
+        hipLaunchKernelGGL(ri_flags_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, w.skey, w.mode, w.head, w.aggh, w.tfh,
+                           w.agge, w.tfe);
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.head, w.head_s, E, st));
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.aggh, w.aggh_s, E, st));
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.tfh, w.tfh_s, E, st));
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.agge, w.agge_s, E, st));
+        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.tfe, w.tfe_s, E, st));
+        int32_t last[10];
+        int32_t* srcs[10] = {w.head_s, w.head, w.aggh_s, w.aggh, w.tfh_s, w.tfh, w.agge_s, w.agge, w.tfe_s, w.tfe};
+        for (int k = 0; k < 10; ++k)
+            DN_CHECK_HIP(hipMemcpyAsync(&last[k], srcs[k] + (E - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        DN_CHECK_HIP(hipStreamSynchronize(st));
+        P = (int64_t)last[0] + last[1]; n_agg = (int64_t)last[2] + last[3]; n_tf = (int64_t)last[4] + last[5];
+        n_agg_e = (int64_t)last[6] + last[7]; n_tf_e = (int64_t)last[8] + last[9];
+        hipLaunchKernelGGL(ri_fill_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, P, w.skey, w.order, w.mode, src, dst,
+                           w.head, w.head_s, w.aggh_s, w.tfh_s, w.agge_s, w.tfe_s, row_in, row_out, w.row_rel, aux_f_idx,
+                           aux_f_ptr, aux_b_idx, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
+    }
+    {
+        const int64_t work = (N > E ? N : E) + 1;
+        hipLaunchKernelGGL(ri_tail_kernel, dim3(grid_for(work)), dim3(kBlock), 0, st, E, N, P, n_agg, n_tf, n_agg_e, n_tf_e,
+                           self_loop, row_in, row_out, aux_f_ptr, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
+    }
+    // (3) per-node lists of contributing rows (key N = discard segment)
+    const int64_t L = 2 * E + N;
+    if (L > 0) {
+        // N + 1 keys (the last one collects the discarded slots), so dst_ptr / src_ptr receive N + 2 entries
+        rc = csr_build(w.f_key, L, N + 1, dst_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+        if (rc != DN_OK) return rc;
+        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(L)), dim3(kBlock), 0, st, w.f_row, w.perm, L, dst_rows);
+        rc = csr_build(w.b_key, L, N + 1, src_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+        if (rc != DN_OK) return rc;
+        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(L)), dim3(kBlock), 0, st, w.b_row, w.perm, L, src_rows);
+    } else {
+        DN_CHECK_HIP(hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (size_t)(N + 2), st));
+        DN_CHECK_HIP(hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (size_t)(N + 2), st));
+    }
+    // (4) relation ranges over rows (edge rows are relation-major; the caller appends the self-loop rows as relation R)
+    int32_t* rel_ptr_dev = w.rel_ptr;
+    hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(grid_for(P + 1)), dim3(kBlock), 0, st, w.row_rel, P, R, rel_ptr_dev);
+    DN_CHECK_LAUNCH();
+    DN_CHECK_HIP(hipMemcpyAsync(host_rel_ptr, rel_ptr_dev, sizeof(int32_t) * (size_t)(R + 1), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipMemcpyAsync(host_modes, w.mode, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    host_counts[0] = P; host_counts[1] = n_agg; host_counts[2] = n_tf; host_counts[3] = n_agg_e; host_counts[4] = n_tf_e;
     return DN_OK;
 }
 

@@ -504,82 +504,46 @@ class RowIndex:
     EDGE, AGG, TF = 0, 1, 2
 
     def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75):
+        """One C-ABI call (dn_row_index_build_i32: stable radix sorts + scans on the device) + host-side tile tables."""
         require_gpu(src, dst, etype)
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
         self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
-        s64, d64, t64 = src.long(), dst.long(), etype.long()
-        if E > 0:
-            D = torch.bincount(torch.unique(t64 * N + d64) // N, minlength=R)
-            S = torch.bincount(torch.unique(t64 * N + s64) // N, minlength=R)
-            Er = torch.bincount(t64, minlength=R)
-            D, S, Er = (v.tolist() for v in (D, S, Er))
-        else:
-            D = S = Er = [0] * R
-        modes = []
-        for r in range(R):
-            if Er[r] == 0 or min(D[r], S[r]) > edge_frac * Er[r]:
-                modes.append(self.EDGE)
-            else:
-                modes.append(self.AGG if D[r] <= S[r] else self.TF)
-        self.modes = modes
-        mode_t = torch.tensor(modes, dtype=torch.long, device=dev)
-        emode = mode_t[t64] if E > 0 else t64
-        node_key = torch.where(emode == self.TF, s64, d64)
-        key = t64 * N + node_key
-        order = torch.sort(key, stable=True).indices if E > 0 else key       # relation-major, by node, by edge id
-        k_s, m_s = key[order], emode[order]
-        head = torch.ones(E, dtype=torch.bool, device=dev)
-        if E > 1:
-            head[1:] = (m_s[1:] == self.EDGE) | (k_s[1:] != k_s[:-1])
-        row_s = torch.cumsum(head.long(), 0) - 1                             # row of each sorted edge
-        head_pos = torch.nonzero(head).reshape(-1)
-        P = int(head_pos.numel())
-        row_of_edge = torch.empty(E, dtype=torch.long, device=dev)
-        row_of_edge[order] = row_s
-        first_edge = order[head_pos]
-        row_rel, row_mode, row_node = t64[first_edge], m_s[head_pos], node_key[first_edge]
-        rel_cnt = torch.bincount(row_rel, minlength=R).tolist() if P > 0 else [0] * R
-        rel_ptr = [0]
-        for c in rel_cnt:
-            rel_ptr.append(rel_ptr[-1] + c)
-        is_agg, is_tf = row_mode == self.AGG, row_mode == self.TF
-        aux_f_id, aux_b_id = torch.cumsum(is_agg.long(), 0) - 1, torch.cumsum(is_tf.long(), 0) - 1
-        self.num_aux_f, self.num_aux_b = int(is_agg.sum()), int(is_tf.sum())
-        row_in = torch.where(is_agg, N + aux_f_id, torch.where(is_tf, row_node, s64[first_edge]))
-        row_out = torch.where(is_tf, N + aux_b_id, torch.where(is_agg, row_node, d64[first_edge]))
-        rows = torch.arange(P, device=dev)
-        # pre-aggregation lists (K1): sorted order already groups the edges of a row
-        e_agg, e_tf = order[m_s == self.AGG], order[m_s == self.TF]
-        self.aux_f_idx = s64[e_agg].to(I32)
-        self.aux_f_ptr = self._ptr(aux_f_id[row_of_edge[e_agg]], self.num_aux_f, dev)
-        self.aux_b_idx = d64[e_tf].to(I32)
-        self.aux_b_ptr = self._ptr(aux_b_id[row_of_edge[e_tf]], self.num_aux_b, dev)
-        # final per-node lists of contributing rows
-        ee = emode == self.AGG
-        f_dst = [d64[~ee], row_node[is_agg]]
-        f_row = [row_of_edge[~ee], rows[is_agg]]
-        et = emode == self.TF
-        b_src = [s64[~et], row_node[is_tf]]
-        b_row = [row_of_edge[~et], rows[is_tf]]
-        P_all = P
+        src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))
+        e32 = lambda n: torch.empty(max(int(n), 1), dtype=I32, device=dev)  # noqa: E731
+        row_in, row_out = e32(E + N), e32(E + N)
+        aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx = e32(E + 1), e32(E), e32(E + 1), e32(E)
+        dst_ptr, dst_rows, src_ptr, src_rows = e32(N + 2), e32(2 * E + N), e32(N + 2), e32(2 * E + N)
+        nbytes = lib().dn_row_index_workspace_bytes(N, R, E)
+        if nbytes == 0:
+            check(-2, "dn_row_index_workspace_bytes")
+        ws = _ws(nbytes, dev)
+        counts = (ctypes.c_int64 * 5)()
+        host_rel = (ctypes.c_int32 * (R + 1))()
+        host_modes = (ctypes.c_int32 * R)()
+        check(lib().dn_row_index_build_i32(N, R, E, ptr(src), ptr(dst), ptr(etype), 1 if self_loop else 0, float(edge_frac),
+                                           ptr(row_in), ptr(row_out), ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr),
+                                           ptr(aux_b_idx), ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts,
+                                           host_rel, host_modes, ptr(ws), ws.numel(), stream_ptr()), "dn_row_index_build_i32")
+        P, n_agg, n_tf, n_agg_e, n_tf_e = (int(v) for v in counts)
+        self.modes = [int(m) for m in host_modes]
+        rel_ptr = [int(v) for v in host_rel]
+        P_all = P + (N if self_loop else 0)
         if self_loop:
-            ar = torch.arange(N, device=dev)
-            f_dst.append(ar), f_row.append(P + ar), b_src.append(ar), b_row.append(P + ar)
-            row_in, row_out = torch.cat([row_in, ar]), torch.cat([row_out, ar])
-            rel_ptr.append(P + N)
-            P_all = P + N
-        f_dst, f_row, b_src, b_row = (torch.cat(v) for v in (f_dst, f_row, b_src, b_row))
-        self.dst_ptr, perm = csr_build(f_dst.to(I32), N)
-        self.dst_rows = f_row.to(I32).index_select(0, perm.long())
-        self.src_ptr, perm = csr_build(b_src.to(I32), N)
-        self.src_rows = b_row.to(I32).index_select(0, perm.long())
-        self.row_in, self.row_out = row_in.to(I32).contiguous(), row_out.to(I32).contiguous()
+            rel_ptr.append(P_all)
+        self.num_aux_f, self.num_aux_b = n_agg, n_tf
+        self.aux_f_ptr, self.aux_f_idx = aux_f_ptr[:n_agg + 1], aux_f_idx[:max(n_agg_e, 1)][:n_agg_e]
+        self.aux_b_ptr, self.aux_b_idx = aux_b_ptr[:n_tf + 1], aux_b_idx[:max(n_tf_e, 1)][:n_tf_e]
+        n_f = (E - n_agg_e) + n_agg + (N if self_loop else 0)      # forward list entries; the rest sits in the discard segment
+        n_b = (E - n_tf_e) + n_tf + (N if self_loop else 0)
+        self.dst_ptr, self.dst_rows = dst_ptr[:N + 1], dst_rows[:n_f]
+        self.src_ptr, self.src_rows = src_ptr[:N + 1], src_rows[:n_b]
+        self.row_in, self.row_out = row_in[:P_all], row_out[:P_all]
         self.num_rows, self.num_edge_rows = P_all, P
         self.num_all_rels = R + (1 if self_loop else 0)
         self.rel_ptr_host = rel_ptr
         self.tile_table = make_row_tiles(rel_ptr, dev)
-        # ~1.5 workgroups per CU for the split-K weight gradient whatever the sub-batch size
+        # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
         self.chunk_table = make_row_chunks(rel_ptr, dev, chunk_rows=max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)))
 
     @staticmethod

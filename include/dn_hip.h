@@ -163,6 +163,29 @@ int dn_rel_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
                            int32_t* operm, int32_t* seg_by_src, int64_t* host_P, int32_t* host_rel_ptr,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* Row factorisation of the relation-wise message pass for the bf16 matrix-core path:
+ *   out[v] = sum_{e: dst(e)=v} x[src(e)] W[etype(e)]   ==   sum over rows p with v in out(p) of  in_row(p) @ W[rel(p)]
+ * Every row has ONE input row.  Per relation r (E_r edges, D_r distinct destinations, S_r distinct sources):
+ *   EDGE (min(D_r,S_r) > edge_frac*E_r): one row per edge, in = x[src], out -> dst
+ *   AGG  (D_r <= S_r): one row per distinct dst, in = N + a (a-th pre-aggregated row: sum of x[src] over the segment), out -> dst
+ *   TF   (else):       one row per distinct src, in = x[src], out = N + b (the b-th backward pre-aggregated row) and the
+ *                       product is added to every dst of that (rel, src)
+ * Edge rows are relation-major (host_rel_ptr [R+1]); with self_loop != 0, N more rows (relation R, in = out = v) follow.
+ * Outputs (device, caller-allocated upper bounds): row_in / row_out [E+N]; aux_f_ptr [E+1], aux_f_idx [E] (lists of x
+ * rows per AGG row); aux_b_ptr [E+1], aux_b_idx [E] (lists of destination rows per TF row); dst_ptr [N+2], dst_rows [2E+N]
+ * (rows contributing to each node, forward); src_ptr [N+2], src_rows [2E+N] (rows contributing to each node's input
+ * gradient); only the first N+1 ptr entries are meaningful.  host_counts[5] = {#edge rows P, #AGG rows, #TF rows,
+ * #AGG edges, #TF edges}; host_modes [R] (0 EDGE, 1 AGG, 2 TF).  Synchronises the stream.
+ * This is the index the reference's DGL path never needs because it materialises a per-edge [E,H,H] weight tensor instead
+ * (subgraph_isomorphism/models/rgin.py:109-110). */
+size_t dn_row_index_workspace_bytes(int64_t N, int64_t R, int64_t E);
+int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, const int32_t* dst,
+                           const int32_t* etype, int32_t self_loop, float edge_frac, int32_t* row_in,
+                           int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr,
+                           int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr,
+                           int32_t* src_rows, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
  * Replaces autograd's backward of the reference's per-edge `th.bmm(x[src], W[etype])`
