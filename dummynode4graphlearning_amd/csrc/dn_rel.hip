@@ -48,7 +48,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                                                                 const int32_t* __restrict__ ig,
                                                                 const Chunk* __restrict__ chunks,
                                                                 float* __restrict__ partial, int32_t colsum_of,
-                                                                float* __restrict__ colsum_partial) {
+                                                                float* __restrict__ colsum_partial,
+                                                                const bf16_t* __restrict__ maskA,
+                                                                bf16_t* __restrict__ A_out) {
     constexpr int SA = HI + kPad, SG = HO + kPad;
     constexpr int MT = HI / 2 / 16, NT = HO / 4 / 16;           // 16x16 tiles per wave
     constexpr int NPA = kTileRows * HI / 8, NPG = kTileRows * HO / 8;   // 16-byte pieces per tile
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[PA], rg[PG];
+    uint4 ra[PA], rg[PG], rm[PA];                             // rm: ReLU mask pieces of A (maskA != NULL)
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of my 8 columns (colsum_of != 0)
     auto add_cs = [&](const uint4& v) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
         }
     };
     int32_t sa[PA], sg[PG];                                   // source rows of my pieces (fetched one tile ahead)
+    int32_t sa_cur[PA];                                       // source rows of the pieces currently held in ra
     auto load_idx = [&](int t) {
         const int row0 = ch.beg + t * kTileRows;
 #pragma unroll
@@ -99,10 +102,12 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int c = (tid + j * kWgThreads) % (HI / 8);
+            sa_cur[j] = sa[j];
             ra[j] = make_uint4(0, 0, 0, 0);
             if (sa[j] >= 0) {
                 const bf16_t* base = sa[j] < na1 ? A + (size_t)sa[j] * HI : A2 + (size_t)(sa[j] - na1) * HI;
                 ra[j] = *reinterpret_cast<const uint4*>(base + c * 8);
+                if (maskA) rm[j] = *reinterpret_cast<const uint4*>(maskA + (size_t)sa[j] * HI + c * 8);
             }
         }
 #pragma unroll
@@ -119,6 +124,17 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int piece = tid + j * kWgThreads, r = piece / (HI / 8), c = piece % (HI / 8);
+            if (maskA && sa_cur[j] >= 0) {                       // A <- A where mask > 0 (ReLU backward), optionally saved
+                const uint32_t mw[4] = {rm[j].x, rm[j].y, rm[j].z, rm[j].w};
+                uint32_t vw[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
+                    vw[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+                }
+                ra[j] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                if (A_out) *reinterpret_cast<uint4*>(A_out + (size_t)sa_cur[j] * HI + c * 8) = ra[j];
+            }
             if (piece < NPA) *reinterpret_cast<uint4*>(bufA(b) + r * SA + c * 8) = ra[j];
             if (colsum_of == 1 && piece < NPA) add_cs(ra[j]);
         }
@@ -376,46 +392,43 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     return DN_OK;
 }
 
-// out[r] = sum of the partials of relation r's chunks, in chunk order
+// out[r] = sum of the partials of relation r's chunks, in chunk order (one output element per thread: 256 workgroups per
+// relation tile keep enough loads in flight; the partial slabs are read exactly once)
 template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
                                                            int32_t H, float* __restrict__ out_colsum) {
     const int r = blockIdx.y;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
     if (cs_partial != nullptr && blockIdx.x == 0) {
         for (int h = threadIdx.x; h < H; h += 256) {
             float sum = 0.f;
-            for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) sum += cs_partial[(size_t)c * H + h];
+            for (int c = cb; c < ce; ++c) sum += cs_partial[(size_t)c * H + h];
             out_colsum[(size_t)r * H + h] = sum;
         }
     }
     if (i >= tile_elems) return;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
+    float s = 0.f;
     int c = cb;
-    for (; c + 8 <= ce; c += 8) {                       // 8 independent loads in flight, summed in chunk order
-        float4 v[8];
+    for (; c + 16 <= ce; c += 16) {                     // 16 independent loads in flight, summed in chunk order
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(c + u) * tile_elems + i);
+        for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(c + u) * tile_elems + i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; c < ce; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * tile_elems + i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    TO* o = out + (size_t)r * tile_elems + i;
-    o[0] = (TO)s.x; o[1] = (TO)s.y; o[2] = (TO)s.z; o[3] = (TO)s.w;
+    for (; c < ce; ++c) s += partial[(size_t)c * tile_elems + i];
+    out[(size_t)r * tile_elems + i] = (TO)s;
 }
 
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
-                 float* cs_partial, hipStream_t st) {
+                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, hipStream_t st) {
     hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia, G, G2,
-                       ng1, ig, chunks, partial, colsum_of, cs_partial);
+                       ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -462,7 +475,11 @@ size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho)
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G, const void* G2,
                        int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                        int64_t num_chunks, const int32_t* chunk_ptr, void* out, int32_t out_is_f32, int32_t colsum_of,
-                       float* out_colsum, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                       float* out_colsum, const void* mask_a, void* a_out, void* workspace, size_t workspace_bytes,
+                       dn_stream_t stream) {
+    DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad: mask_a needs a single A source");
+    DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad: a_out needs mask_a and idx_a == NULL");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0, "dn_rows_wgrad: unaligned mask");
     DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
     DN_REQUIRE(A2 != nullptr || na1 == 0x7fffffff, "dn_rows_wgrad: A2 == NULL requires na1 == INT32_MAX");
     DN_REQUIRE(G2 != nullptr || ng1 == 0x7fffffff, "dn_rows_wgrad: G2 == NULL requires ng1 == INT32_MAX");
@@ -481,13 +498,15 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
         const bf16_t *a = (const bf16_t*)A, *a2 = (const bf16_t*)A2, *g = (const bf16_t*)G, *g2 = (const bf16_t*)G2;
         float* ws = (float*)workspace;
         float* csp = ws + (size_t)num_chunks * Hi * Ho;
-        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
-        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
-        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, st);
+        const bf16_t* mk = (const bf16_t*)mask_a;
+        bf16_t* ao = (bf16_t*)a_out;
+        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
+        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
+        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
-    dim3 grid((unsigned)dn_cdiv(tile, 1024), (unsigned)R);
+    dim3 grid((unsigned)dn_cdiv(tile, 256), (unsigned)R);
     const float* csp = colsum_of ? (const float*)workspace + (size_t)num_chunks * tile : nullptr;
     if (out_is_f32)
         hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,

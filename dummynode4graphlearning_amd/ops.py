@@ -162,12 +162,13 @@ def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
 INT32_MAX = 0x7fffffff
 
 
-def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0):
+def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0,
+               mask_a=None, a_out=None):
     """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
     Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
     column sums [R, H] of operand A|G (the bias gradient)."""
     chunks, chunk_ptr, nchunks = chunk_table
-    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2)
+    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out)
     assert A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
     Hi, Ho = A.shape[1], G.shape[1]
     out_dtype = out_dtype or A.dtype
@@ -179,8 +180,8 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
         check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), A.shape[0] if A2 is not None else INT32_MAX, ptr(idx_a),
                                        ptr(G), ptr(G2), G.shape[0] if G2 is not None else INT32_MAX, ptr(idx_g),
                                        Hi, Ho, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
-                                       1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(ws),
-                                       ws.numel(), stream_ptr()),
+                                       1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
+                                       ptr(a_out), ptr(ws), ws.numel(), stream_ptr()),
               "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
@@ -778,11 +779,18 @@ class _ReluMlpFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         acts, ws = saved[:n + 1], saved[n + 1:]
         tiles, chunks, _ = _dense_table(acts[0].shape[0], acts[0].device)
-        g = relu_bwd(gout.contiguous(), acts[n])                       # outermost ReLU
+        g = gout.contiguous()
         grads = [None] * (1 + 2 * n)
         for i in range(n - 1, -1, -1):
             w = ws[i]
-            gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1)   # g^T a_{i} ; colsum(g)
+            if i == n - 1:
+                # outermost ReLU: masked while the rows are staged for the weight gradient, masked rows saved for the
+                # input-gradient launch -- no separate elementwise pass
+                gm = torch.empty_like(g)
+                gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1, mask_a=acts[n], a_out=gm)
+                g = gm
+            else:
+                gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1)   # g^T a_{i} ; colsum(g)
             grads[1 + 2 * i] = gw[0]
             if ctx.has_bias[i]:
                 grads[2 + 2 * i] = cs[0].to(g.dtype)

@@ -196,13 +196,15 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * idx_a / idx_g may be NULL (row p itself); A2/na1 and G2/ng1 give each operand a second row source exactly as
  * in dn_rows_transform_bf16.  Supported: Hi == Ho in {64, 128, 256}.  out is fp32 or bf16.
  * colsum_of = 1 (A) or 2 (G) also returns out_colsum[r, :] = sum over relation r's rows of that operand (fp32 [R, H]):
- * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL). */
+ * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL).
+ * mask_a (may be NULL; needs A2 == NULL): A rows are first zeroed where mask_a[row, k] <= 0 (ReLU backward folded into the
+ * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears. */
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G,
                        const void* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                        const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
-                       int32_t out_is_f32, int32_t colsum_of, float* out_colsum, void* workspace,
-                       size_t workspace_bytes, dn_stream_t stream);
+                       int32_t out_is_f32, int32_t colsum_of, float* out_colsum, const void* mask_a, void* a_out,
+                       void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
