@@ -263,6 +263,43 @@ def main():
     except Exception:
         traffic = None
 
+    # secondary line (rank 0, N = 1): the pure gather -> segment-sum kernel on a GIN conv (no relation transform), forward
+    # + backward, on a PROTEINS-shaped dummy-augmented batch (SURVEY 8d config 2 x 32 graphs, fp32 H = 128)
+    gin = None
+    if rank == 0 and world == 1:
+        from dummynode4graphlearning_amd import synthetic as syn, transforms as tr
+        r2 = syn.config2(graphs=16384)
+        t2 = {k: torch.from_numpy(v).to(dev) for k, v in r2.items()}
+        a2 = tr.dummy_augment_gc(t2["node_ptr"], t2["edge_ptr"], t2["src"], t2["dst"], t2["node_label"], t2["edge_label"])
+        N2, E2, H2 = int(a2["node_label"].numel()), int(a2["src"].numel()), 128
+        ei = ops.EdgeIndex(a2["src"], a2["dst"], N2)
+        x2 = torch.randn(N2, H2, device=dev, requires_grad=True)
+        go2 = torch.randn(N2, H2, device=dev)
+
+        def gin_fb():
+            x2.grad = None
+            ops.neighbor_sum(x2, ei, 1.0).backward(go2)
+
+        gin_fb()
+        torch.cuda.synchronize()
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            gin_fb()
+        gg.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            gg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        gms = e0.elapsed_time(e1) / 20
+        galg = 2.0 * (E2 * H2 * 4 + N2 * H2 * 4 + 8.0 * E2)
+        gin = {"workload": "GIN conv gather+segment-sum fwd+bwd, 16384 PROTEINS-shaped dummy graphs, N=%d E=%d H=128 fp32" % (N2, E2),
+               "ms": gms, "edges_per_s": E2 / (gms * 1e-3), "alg_GBps": galg / (gms * 1e-3) / 1e9,
+               "frac_of_hbm_peak": galg / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "note": "graph-local source rows are re-read from L2, so the algorithmic rate can exceed the HBM peak"}
+        del x2, go2, ei, gg
+
     if rank == 0:
         line = {
             "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": world * E / (ms_per_step * 1e-3),
@@ -281,6 +318,8 @@ def main():
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step},
         }
+        if gin is not None:
+            line["secondary"] = {"gin_conv_gather": gin}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw, H, R)
         print(json.dumps(line), flush=True)

@@ -8,6 +8,8 @@
 //
 // LDS image: row-major [32 rows][H + 8] bf16 tiles (16-byte row pad); both MFMA operands are K-strided in that
 // image, so fragments are fetched with ds_read_b64_tr_b16 (hardware transpose read, cdna_hip_programming.md T10).
+#include <cstdlib>
+
 #include "dn_common.h"
 #include "../../include/dn_hip.h"
 
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 constexpr int kTfThreads = 512;   // 8 waves, each owning HO/8 output columns
 constexpr int kTfRows = 32;
 
-template <int HI, int HO>
-__global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
+template <int HI, int HO, int D>
+__global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const bf16_t* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
     bf16x8 wf[KS][NT];                              // this wave's slice of Wn[rel]: A operand fragments
     int cur_rel = -1;
     int32_t nidx[PX];                               // source row of each of my pieces, for the tile being loaded
-    uint4 rx[PX];
+    uint4 rx[D][PX];                                // D gathered tiles in flight (tile k lives in slot k % D)
 
     auto load_idx = [&](int t) {
         if (t >= t_end) return;
@@ -265,35 +267,43 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
             if (piece < NPX && p < tl.end) nidx[j] = idx ? idx[p] : p;
         }
     };
-    auto load_rows = [&]() {
+    auto load_rows = [&](uint4 (&r)[PX]) {
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             const int piece = tid + j * kTfThreads, c = piece % (HI / 8);
-            rx[j] = make_uint4(0, 0, 0, 0);
+            r[j] = make_uint4(0, 0, 0, 0);
             if (nidx[j] >= 0) {
                 const bf16_t* base = nidx[j] < n1 ? X + (size_t)nidx[j] * HI : X2 + (size_t)(nidx[j] - n1) * HI;
-                rx[j] = *reinterpret_cast<const uint4*>(base + c * 8);
+                r[j] = *reinterpret_cast<const uint4*>(base + c * 8);
             }
         }
     };
-    auto store_rows = [&](int b) {
+    auto store_rows = [&](int b, const uint4 (&r)[PX]) {
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const int piece = tid + j * kTfThreads, r = piece / (HI / 8), c = piece % (HI / 8);
-            if (piece < NPX) *reinterpret_cast<uint4*>(bufX(b) + r * SX + c * 8) = rx[j];
+            const int piece = tid + j * kTfThreads, rr = piece / (HI / 8), c = piece % (HI / 8);
+            if (piece < NPX) *reinterpret_cast<uint4*>(bufX(b) + rr * SX + c * 8) = r[j];
         }
     };
 
-    load_idx(t_beg);
-    load_rows();
-    store_rows(0);
-    load_idx(t_beg + 1);
+    // prologue: tiles 0 .. D-1 in flight, tile 0 in LDS, indices of tile D fetched
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        load_idx(t_beg + u);
+        if (t_beg + u < t_end) load_rows(rx[u]);
+    }
+    store_rows(0, rx[0]);
+    load_idx(t_beg + D);
     __syncthreads();
 
-    for (int t = t_beg; t < t_end; ++t) {
+    for (int t0 = t_beg; t0 < t_end; t0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int t = t0 + u;
+        if (t >= t_end) break;
         const int b = (t - t_beg) & 1;
         const Chunk tl = tiles[t];
-        if (t + 1 < t_end) load_rows();             // gather of tile t+1 (indices were fetched one tile earlier)
+        if (t + D < t_end) load_rows(rx[u]);        // gather of tile t+D into the slot tile t just left
         if (tl.rel != cur_rel && wave_active) {     // (re)load this wave's weight slice: wave-uniform branch
             cur_rel = tl.rel;
             const bf16_t* w = Wn + (size_t)cur_rel * HO * HI;
@@ -346,8 +356,8 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
                 *reinterpret_cast<bf16x4*>(bufY + (m * 16 + (lane & 15)) * SY + col) = o;
             }
         }
-        if (t + 1 < t_end) store_rows(b ^ 1);
-        load_idx(t + 2);
+        if (t + 1 < t_end) store_rows(b ^ 1, rx[(u + 1) % D]);
+        load_idx(t + D + 1);
         __syncthreads();
         // whole rows out: 16 B per lane, HO/8 lanes per row
 #pragma unroll
@@ -377,17 +387,41 @@ __global__ __launch_bounds__(kTfThreads, 4) void rows_transform_kernel(
         // wave overwrites bufY (next iteration's epilogue) while a slower wave still reads it
         __syncthreads();
     }
+    }
+}
+
+static int tf_depth() {
+    static int d = -1;
+    if (d < 0) {
+        const char* e = getenv("DN_TF_DEPTH");
+        d = e ? atoi(e) : 1;
+        if (d != 1 && d != 2 && d != 3 && d != 4) d = 1;
+    }
+    return d;
+}
+static int tf_wg_per_cu() {
+    static int d = -1;
+    if (d < 0) { const char* e = getenv("DN_TF_WGS"); d = e ? atoi(e) : 0; }
+    return d;
 }
 
 template <int HI, int HO>
 int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_t* idx, const bf16_t* Wn, const bf16_t* bias,
                      int32_t relu, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
-    // ~2 workgroups per CU; contiguous tile ranges keep a workgroup inside one relation most of the time
-    const int64_t max_wg = 256 * 2;
+    // contiguous tile ranges keep a workgroup inside one relation most of the time
+    const int depth = tf_depth();
+    const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? 2 : 1);
+    const int64_t max_wg = 256 * per_cu;
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    hipLaunchKernelGGL((rows_transform_kernel<HI, HO>), dim3((unsigned)grid), dim3(kTfThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                       relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+#define DN_TF_LAUNCH(DEPTH)                                                                                                  \
+    hipLaunchKernelGGL((rows_transform_kernel<HI, HO, DEPTH>), dim3((unsigned)grid), dim3(kTfThreads), 0, st, X, X2, n1, idx, \
+                       Wn, bias, relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y)
+    if (depth == 1) DN_TF_LAUNCH(1);
+    else if (depth == 2) DN_TF_LAUNCH(2);
+    else if (depth == 3) DN_TF_LAUNCH(3);
+    else DN_TF_LAUNCH(4);
+#undef DN_TF_LAUNCH
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

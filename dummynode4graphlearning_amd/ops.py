@@ -141,7 +141,9 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
     return in_norm.view(-1, 1), (out_norm.view(-1, 1) if out_norm is not None else None), en
 
 
-WGRAD_CHUNK_ROWS = 4096
+import os as _os
+
+WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
 
 
 def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
