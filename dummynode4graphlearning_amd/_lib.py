@@ -31,6 +31,12 @@ _SIGS = {
     "dn_segment_max_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P, P]),
     "dn_segment_max_bwd_f32": (ctypes.c_int, [P, P, c_i32, P, c_i64, P, P]),
     "dn_segment_max_bwd_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i64, P, P]),
+    "dn_edge_dot_f32": (ctypes.c_int, [P, P, P, P, c_i32, c_i64, P, P]),
+    "dn_edge_dot_bf16": (ctypes.c_int, [P, P, P, P, c_i32, c_i64, P, P]),
+    "dn_gather_segmax_f32": (ctypes.c_int, [P, P, P, c_i64, c_i32, P, P, P]),
+    "dn_gather_segmax_bf16": (ctypes.c_int, [P, P, P, c_i64, c_i32, P, P, P]),
+    "dn_gather_segmax_bwd_f32": (ctypes.c_int, [P, P, P, P, P, c_i64, c_i32, P, P]),
+    "dn_gather_segmax_bwd_bf16": (ctypes.c_int, [P, P, P, P, P, c_i64, c_i32, P, P]),
     "dn_csr_build_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dn_csr_build_i32": (ctypes.c_int, [P, c_i64, c_i64, P, P, P, c_sz, P]),
     "dn_dummy_augment_gc_i32": (ctypes.c_int, [c_i64, c_i64, c_i64] + [P] * 16 + [P]),

@@ -282,6 +282,112 @@ int segment_max_bwd(const T* gout, const int32_t* argmax, int32_t H, const int32
     return DN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Edge dot product (SDDMM):  out[e] = < a[ia[e], :], b[ib[e], :] >    (gradient of a per-edge scalar weight)
+// Gather + segment MAX over gathered rows and its backward (SAGEConv aggr='max').
+// One lane group per edge / segment, lanes stride the feature dimension; fp32 math; no atomics.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void edge_dot_kernel(const T* __restrict__ a, const int32_t* __restrict__ ia,
+                                                          const T* __restrict__ b, const int32_t* __restrict__ ib, int32_t H,
+                                                          int64_t E, float* __restrict__ out) {
+    const int lane = threadIdx.x % G;
+    const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    if (e >= E) return;                                   // whole groups leave together (E is checked per group)
+    const T* ra = a + (size_t)(ia ? ia[e] : e) * H;
+    const T* rb = b + (size_t)(ib ? ib[e] : e) * H;
+    float acc = 0.f;
+    for (int h = lane; h < H; h += G) acc = fmaf(to_f32<T>(ra[h]), to_f32<T>(rb[h]), acc);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
+    if (lane == 0) out[e] = acc;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void gather_segmax_kernel(const T* __restrict__ in, const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ ptr, int64_t S, int32_t H,
+                                                               T* __restrict__ out, int32_t* __restrict__ argmax) {
+    const int lane = threadIdx.x % G;
+    const int64_t s = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    if (s >= S) return;
+    const int beg = ptr[s], end = ptr[s + 1];
+    for (int h = lane; h < H; h += G) {
+        float best = 0.f;
+        int arg = -1;
+        for (int i = beg; i < end; ++i) {
+            const float x = to_f32<T>(in[(size_t)idx[i] * H + h]);
+            if (arg < 0 || x > best) { best = x; arg = i; }   // ties keep the first (lowest slot)
+        }
+        out[(size_t)s * H + h] = from_f32<T>(best);
+        argmax[(size_t)s * H + h] = arg;
+    }
+}
+
+// grad_in[u, h] = sum over the slots i that gathered row u of (argmax[seg(i), h] == i ? gout[seg(i), h] : 0)
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void gather_segmax_bwd_kernel(const T* __restrict__ gout, const int32_t* __restrict__ argmax,
+                                                                   const int32_t* __restrict__ tptr,
+                                                                   const int32_t* __restrict__ tslot,
+                                                                   const int32_t* __restrict__ seg_of_slot, int64_t rows,
+                                                                   int32_t H, T* __restrict__ gin) {
+    const int lane = threadIdx.x % G;
+    const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    if (u >= rows) return;
+    const int beg = tptr[u], end = tptr[u + 1];
+    for (int h = lane; h < H; h += G) {
+        float acc = 0.f;
+        for (int k = beg; k < end; ++k) {
+            const int i = tslot[k], s = seg_of_slot[i];
+            if (argmax[(size_t)s * H + h] == i) acc += to_f32<T>(gout[(size_t)s * H + h]);
+        }
+        gin[(size_t)u * H + h] = from_f32<T>(acc);
+    }
+}
+
+template <typename T>
+int edge_dot(const T* a, const int32_t* ia, const T* b, const int32_t* ib, int32_t H, int64_t E, float* out, hipStream_t st) {
+    DN_REQUIRE(H > 0 && E >= 0, "dn_edge_dot: bad sizes");
+    if (E == 0) return DN_OK;
+    DN_REQUIRE(a && b && out, "dn_edge_dot: NULL pointer");
+    if (H <= 16) {
+        hipLaunchKernelGGL((edge_dot_kernel<T, 16>), dim3((unsigned)dn_cdiv(E * 16, kBlock)), dim3(kBlock), 0, st, a, ia, b, ib, H, E, out);
+    } else {
+        hipLaunchKernelGGL((edge_dot_kernel<T, 64>), dim3((unsigned)dn_cdiv(E * 64, kBlock)), dim3(kBlock), 0, st, a, ia, b, ib, H, E, out);
+    }
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <typename T>
+int gather_segmax(const T* in, const int32_t* idx, const int32_t* ptr, int64_t S, int32_t H, T* out, int32_t* argmax,
+                  hipStream_t st) {
+    DN_REQUIRE(H > 0 && S >= 0, "dn_gather_segmax: bad sizes");
+    if (S == 0) return DN_OK;
+    DN_REQUIRE(ptr && out && argmax, "dn_gather_segmax: NULL pointer");
+    if (H <= 16) {
+        hipLaunchKernelGGL((gather_segmax_kernel<T, 16>), dim3((unsigned)dn_cdiv(S * 16, kBlock)), dim3(kBlock), 0, st, in, idx, ptr, S, H, out, argmax);
+    } else {
+        hipLaunchKernelGGL((gather_segmax_kernel<T, 64>), dim3((unsigned)dn_cdiv(S * 64, kBlock)), dim3(kBlock), 0, st, in, idx, ptr, S, H, out, argmax);
+    }
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <typename T>
+int gather_segmax_bwd(const T* gout, const int32_t* argmax, const int32_t* tptr, const int32_t* tslot,
+                      const int32_t* seg_of_slot, int64_t rows, int32_t H, T* gin, hipStream_t st) {
+    DN_REQUIRE(H > 0 && rows >= 0, "dn_gather_segmax_bwd: bad sizes");
+    if (rows == 0) return DN_OK;
+    DN_REQUIRE(tptr && gin, "dn_gather_segmax_bwd: NULL pointer");
+    if (H <= 16) {
+        hipLaunchKernelGGL((gather_segmax_bwd_kernel<T, 16>), dim3((unsigned)dn_cdiv(rows * 16, kBlock)), dim3(kBlock), 0, st, gout, argmax, tptr, tslot, seg_of_slot, rows, H, gin);
+    } else {
+        hipLaunchKernelGGL((gather_segmax_bwd_kernel<T, 64>), dim3((unsigned)dn_cdiv(rows * 64, kBlock)), dim3(kBlock), 0, st, gout, argmax, tptr, tslot, seg_of_slot, rows, H, gin);
+    }
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -335,6 +441,34 @@ int dn_segment_max_bwd_f32(const float* grad_out, const int32_t* argmax, int32_t
 int dn_segment_max_bwd_bf16(const void* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
                             void* grad_in, dn_stream_t stream) {
     return segment_max_bwd<bf16_t>((const bf16_t*)grad_out, argmax, H, ptr, S, (bf16_t*)grad_in, (hipStream_t)stream);
+}
+
+int dn_edge_dot_f32(const float* a, const int32_t* ia, const float* b, const int32_t* ib, int32_t H, int64_t E, float* out,
+                    dn_stream_t stream) {
+    return edge_dot<float>(a, ia, b, ib, H, E, out, (hipStream_t)stream);
+}
+int dn_edge_dot_bf16(const void* a, const int32_t* ia, const void* b, const int32_t* ib, int32_t H, int64_t E, float* out,
+                     dn_stream_t stream) {
+    return edge_dot<bf16_t>((const bf16_t*)a, ia, (const bf16_t*)b, ib, H, E, out, (hipStream_t)stream);
+}
+int dn_gather_segmax_f32(const float* in, const int32_t* idx, const int32_t* ptr, int64_t S, int32_t H, float* out,
+                         int32_t* argmax, dn_stream_t stream) {
+    DN_REQUIRE(idx != nullptr || S == 0, "dn_gather_segmax: idx is NULL");
+    return gather_segmax<float>(in, idx, ptr, S, H, out, argmax, (hipStream_t)stream);
+}
+int dn_gather_segmax_bf16(const void* in, const int32_t* idx, const int32_t* ptr, int64_t S, int32_t H, void* out,
+                          int32_t* argmax, dn_stream_t stream) {
+    DN_REQUIRE(idx != nullptr || S == 0, "dn_gather_segmax: idx is NULL");
+    return gather_segmax<bf16_t>((const bf16_t*)in, idx, ptr, S, H, (bf16_t*)out, argmax, (hipStream_t)stream);
+}
+int dn_gather_segmax_bwd_f32(const float* grad_out, const int32_t* argmax, const int32_t* tptr, const int32_t* tslot,
+                             const int32_t* seg_of_slot, int64_t rows, int32_t H, float* grad_in, dn_stream_t stream) {
+    return gather_segmax_bwd<float>(grad_out, argmax, tptr, tslot, seg_of_slot, rows, H, grad_in, (hipStream_t)stream);
+}
+int dn_gather_segmax_bwd_bf16(const void* grad_out, const int32_t* argmax, const int32_t* tptr, const int32_t* tslot,
+                              const int32_t* seg_of_slot, int64_t rows, int32_t H, void* grad_in, dn_stream_t stream) {
+    return gather_segmax_bwd<bf16_t>((const bf16_t*)grad_out, argmax, tptr, tslot, seg_of_slot, rows, H, (bf16_t*)grad_in,
+                                     (hipStream_t)stream);
 }
 
 }  // extern "C"

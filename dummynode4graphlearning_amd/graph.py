@@ -234,6 +234,27 @@ def edge_index_of(data):
     return cache._edge_index
 
 
+def gcn_edge_index_of(data):
+    """ops.EdgeIndex of the batch with GCN self loops (existing self loops dropped, one per node appended) + the boolean
+    mask of kept edges.  Cached on the batch object."""
+    cache = getattr(data, "_cache", None)
+    if cache is None:
+        cache = _IndexCache()
+        try:
+            data._cache = cache
+        except Exception:
+            pass
+    hit = getattr(cache, "_gcn", None)
+    if hit is None or hit[2] != data.edge_index.shape[1]:
+        src, dst = data.edge_index[0], data.edge_index[1]
+        keep = src != dst
+        ar = torch.arange(data.x.shape[0], device=src.device, dtype=src.dtype)
+        ix = ops.EdgeIndex(torch.cat([src[keep], ar]), torch.cat([dst[keep], ar]), data.x.shape[0])
+        hit = (ix, keep, data.edge_index.shape[1])
+        cache._gcn = hit
+    return hit[0], hit[1]
+
+
 def rel_index_of(data, etype, num_rels):
     cache = getattr(data, "_cache", None)
     if cache is None:

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..graph import edge_index_of, graph_ptr_i32, rel_index_of
+from ..graph import edge_index_of, gcn_edge_index_of, graph_ptr_i32, rel_index_of
 
 
 def _reset(module):
@@ -89,6 +89,70 @@ class RGCNConv(nn.Module):
         if self.bias is not None:
             out = out + self.bias
         return out
+
+
+class GCNConv(nn.Module):
+    """x_i' = sum_j norm_ij (x_j W) + b with the symmetric GCN normalisation over weighted edges + self loops
+    (torch_geometric GCNConv 2.0.2 defaults; call sites gconv.py:36-37,51-52,78-79).  `edge_weight` may require grad (the
+    trainable dummy-edge weight): the normalisation is [E]-sized scalar arithmetic in torch, the feature traffic and the
+    per-edge gradient <x_j W, g_i> run on the HIP kernels."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = math.sqrt(6.0 / (self.lin.weight.size(-2) + self.lin.weight.size(-1)))     # glorot
+        nn.init.uniform_(self.lin.weight, -a, a)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, x, data, edge_weight=None):
+        index, keep = gcn_edge_index_of(data)
+        N = x.shape[0]
+        if edge_weight is None:
+            w = torch.ones(index.num_edges, dtype=torch.float32, device=x.device)
+        else:
+            ew = edge_weight.to(torch.float32)
+            loop_w = torch.ones(N, dtype=torch.float32, device=x.device)
+            if not bool(keep.all()):
+                loop_w = loop_w.index_put((data.edge_index[0][~keep],), ew[~keep])
+            w = torch.cat([ew[keep], loop_w])
+        deg = torch.zeros(N, dtype=torch.float32, device=x.device).index_add(0, index.dst.long(), w)
+        dis = deg.pow(-0.5)
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+        norm = dis[index.src.long()] * w * dis[index.dst.long()]
+        out = ops.neighbor_sum(self.lin(x), index, 0.0, edge_scale=norm)
+        return out + self.bias if self.bias is not None else out
+
+
+class SAGEConv(nn.Module):
+    """x_i' = lin_l(aggr_{j->i} x_j) + lin_r(x_i), aggr = mean | max | add (settable after construction through `.aggr`,
+    as gconv.py:131 does).  torch_geometric SAGEConv 2.0.2 defaults (root_weight, no normalisation)."""
+
+    def __init__(self, in_channels, out_channels, aggr="mean"):
+        super().__init__()
+        self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, data):
+        index = edge_index_of(data)
+        if self.aggr == "max":
+            agg = ops.neighbor_max(x, index)
+        else:
+            scale = None
+            if self.aggr == "mean":
+                deg = (index.in_ptr[1:] - index.in_ptr[:-1]).to(torch.float32).clamp(min=1.0)
+                scale = (1.0 / deg).index_select(0, index.dst.long())
+            agg = ops.neighbor_sum(x, index, 0.0, edge_scale=scale)
+        return self.lin_l(agg) + self.lin_r(x)
 
 
 def global_add_pool(x, data):

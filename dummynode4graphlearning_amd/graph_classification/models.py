@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d, Linear, ReLU, Sequential
 
-from .conv import GINConv, RGCNConv, global_add_pool, global_mean_pool
+from .conv import GCNConv, GINConv, RGCNConv, SAGEConv, global_add_pool, global_max_pool, global_mean_pool
 
 
 def _pooling(config):
@@ -32,6 +32,106 @@ def _edge_type(data, x):
     if edge_attr is not None:
         return edge_attr.max(dim=1)[1]                              # rgconv.py:35-36,110-111
     return torch.zeros(data.edge_index.size(1), dtype=torch.long, device=x.device)
+
+
+def _dummy_edge_weight(model, data, device):
+    """gconv.py:46-49: ones, with the (gradient-carrying) dummy weight on the dummy edges."""
+    if not model.use_edge_weight:
+        return None
+    flag = data.is_dummy_edge.to(device)
+    edge_attr = torch.ones(flag.size(), device=device)
+    return torch.where(flag, model.dummy_weight.to(device), edge_attr)
+
+
+class _GCNBase(torch.nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.num_features, self.hidden_dim = args.num_features, args.hidden_dim
+        self.num_classes, self.dropout_ratio = args.num_classes, args.dropout_ratio
+        # gconv.py:29-34: a plain tensor with requires_grad (NOT an nn.Parameter: the reference's optimiser never sees it;
+        # its gradient is still produced, through dn_edge_dot_*)
+        if getattr(args, "dummy_weight", 0) > 0:
+            self.dummy_weight = torch.tensor(float(args.dummy_weight), requires_grad=True, device=args.device)
+            self.use_edge_weight = True
+        else:
+            self.use_edge_weight = False
+        self.conv1 = GCNConv(self.num_features, self.hidden_dim)
+        self.conv2 = GCNConv(self.hidden_dim, self.hidden_dim)
+
+    def _convs(self, data):
+        x = data.x
+        w = _dummy_edge_weight(self, data, x.device)
+        x = F.relu(self.conv1(x, data, w))
+        return F.relu(self.conv2(x, data, w))
+
+    def _head(self, x):
+        x = F.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+        x = F.relu(self.lin2(x))
+        x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+        return F.log_softmax(self.lin3(x), dim=-1)
+
+
+class GCN(_GCNBase):
+    """reference: gconv.py:20-60."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.lin1 = Linear(self.hidden_dim, self.hidden_dim)
+        self.lin2 = Linear(self.hidden_dim, self.hidden_dim // 2)
+        self.lin3 = Linear(self.hidden_dim // 2, self.num_classes)
+
+    def forward(self, data):
+        return self._head(global_mean_pool(self._convs(data), data))
+
+
+class GCN_concat_readout(_GCNBase):
+    """reference: gconv.py:62-104 (max and mean readouts concatenated)."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.lin1 = Linear(self.hidden_dim * 2, self.hidden_dim)
+        self.lin2 = Linear(self.hidden_dim, self.hidden_dim // 2)
+        self.lin3 = Linear(self.hidden_dim // 2, self.num_classes)
+
+    def forward(self, data):
+        x = self._convs(data)
+        return self._head(torch.cat([global_max_pool(x, data), global_mean_pool(x, data)], dim=1))
+
+
+class GraphSAGE(torch.nn.Module):
+    """reference: gconv.py:106-152."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.num_features, self.hidden_dim = args.num_features, args.hidden_dim
+        self.num_classes, self.dropout_ratio = args.num_classes, args.dropout_ratio
+        config = args.additional if getattr(args, "additional", None) else {"num_layers": 2, "aggregation": "mean"}
+        if config.get("aggregation", "mean") == "max":
+            self.fc_max = Linear(self.hidden_dim, self.hidden_dim)
+        num_layers = config.get("num_layers", 2)
+        self.aggregation = config.get("aggregation", "mean")
+        self.layers = torch.nn.ModuleList([])
+        for i in range(num_layers):
+            conv = SAGEConv(self.num_features if i == 0 else self.hidden_dim, self.hidden_dim)
+            conv.aggr = self.aggregation
+            self.layers.append(conv)
+        self.fc1 = Linear(num_layers * self.hidden_dim, self.hidden_dim)
+        self.fc2 = Linear(self.hidden_dim, self.num_classes)
+
+    def forward(self, data):
+        x = data.x
+        x_all = []
+        for layer in self.layers:
+            x = layer(x, data)
+            if self.aggregation == "max":
+                x = torch.relu(self.fc_max(x))
+            x_all.append(x)
+        x = global_max_pool(torch.cat(x_all, dim=1), data)
+        x = F.relu(self.fc1(x))
+        return F.log_softmax(self.fc2(x), dim=-1)
 
 
 class GIN(torch.nn.Module):

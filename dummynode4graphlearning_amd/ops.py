@@ -311,6 +311,17 @@ class EdgeIndex:
         self.dst_by_src = gather_rows_i32(dst, self.out_perm)
         self.fwd = _SplitCSR(self.in_ptr, self.src_by_dst, num_nodes)
         self.bwd = _SplitCSR(self.out_ptr, self.dst_by_src, num_nodes)
+        self._max_bwd = None
+
+    def max_backward_index(self):
+        """(tptr, tslot, seg_of_slot): CSR slots grouped by the row they gather, and each slot's destination."""
+        if self._max_bwd is None:
+            tptr, tslot = csr_build(self.src_by_dst, self.num_nodes)
+            deg = (self.in_ptr[1:] - self.in_ptr[:-1]).long()
+            seg = torch.repeat_interleave(torch.arange(self.num_nodes, device=deg.device, dtype=I32), deg,
+                                          output_size=self.num_edges)
+            self._max_bwd = (tptr, tslot, seg.contiguous())
+        return self._max_bwd
 
 
 def gather_rows_i32(values, perm):
@@ -364,19 +375,69 @@ class _NeighborSum(torch.autograd.Function):
             sc_in = edge_scale.index_select(0, index.in_perm.long())
             sc_out = edge_scale.index_select(0, index.out_perm.long())
         ctx.sc_out = sc_out
+        ctx.save_for_backward(x if (edge_scale is not None and ctx.needs_input_grad[3]) else x.new_empty(0))
         return index.fwd.segsum(x, scale=sc_in, self_in=x if self_coef != 0.0 else None, self_coef=self_coef)
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         ix = ctx.index
-        gx = ix.bwd.segsum(g, scale=ctx.sc_out, self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
-        return gx, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ix.bwd.segsum(g, scale=ctx.sc_out, self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
+        gs = None
+        if ctx.needs_input_grad[3]:
+            (x,) = ctx.saved_tensors
+            gs = edge_dot(x, ix.src, g, ix.dst)                 # d out / d w_e = < x[src_e], g[dst_e] >
+        return gx, None, None, gs
 
 
 def neighbor_sum(x, index, self_coef=0.0, edge_scale=None):
-    """GIN aggregation (gconv.py:212): (self_coef) x_i + sum_{j->i} x_j; edge_scale is a constant weight."""
+    """(self_coef) x_i + sum_{j->i} w_ij x_j  (GIN aggregation gconv.py:212; GCN propagate with w = gcn norm).
+    edge_scale [E] fp32 in original edge order; it receives a gradient (dn_edge_dot_*) when it requires one."""
     return _NeighborSum.apply(x, index, self_coef, edge_scale)
+
+
+def edge_dot(a, ia, b, ib):
+    """out[e] = <a[ia[e]], b[ib[e]]>  (dn_edge_dot_*), fp32."""
+    require_gpu(a, ia, b, ib)
+    E = ia.numel() if ia is not None else a.shape[0]
+    out = torch.empty(E, dtype=torch.float32, device=a.device)
+    check(getattr(lib(), "dn_edge_dot_" + _suffix(a))(ptr(a), ptr(ia), ptr(b), ptr(ib), a.shape[1], E, ptr(out), stream_ptr()),
+          "dn_edge_dot")
+    return out
+
+
+class _NeighborMax(torch.autograd.Function):
+    """out[v, h] = max_{j->v} x[j, h] (0 for isolated v); backward routes each gradient entry to its arg-max source."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        x = x.contiguous()
+        N, H = index.num_nodes, x.shape[1]
+        out = torch.empty((N, H), dtype=x.dtype, device=x.device)
+        arg = torch.empty((N, H), dtype=I32, device=x.device)
+        check(getattr(lib(), "dn_gather_segmax_" + _suffix(x))(ptr(x), ptr(index.src_by_dst), ptr(index.in_ptr), N, H,
+                                                               ptr(out), ptr(arg), stream_ptr()), "dn_gather_segmax")
+        ctx.index, ctx.rows = index, x.shape[0]
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        (arg,) = ctx.saved_tensors
+        tptr, tslot, seg = ctx.index.max_backward_index()
+        gin = torch.empty((ctx.rows, g.shape[1]), dtype=g.dtype, device=g.device)
+        check(getattr(lib(), "dn_gather_segmax_bwd_" + _suffix(g))(ptr(g), ptr(arg), ptr(tptr), ptr(tslot), ptr(seg),
+                                                                   ctx.rows, g.shape[1], ptr(gin), stream_ptr()),
+              "dn_gather_segmax_bwd")
+        return gin, None
+
+
+def neighbor_max(x, index):
+    require_gpu(x)
+    return _NeighborMax.apply(x, index)
 
 
 def _grouped_mm(A, W, rel_ptr_host, transpose_w=False):

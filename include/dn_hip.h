@@ -83,6 +83,29 @@ int dn_segment_max_bwd_f32(const float* grad_out, const int32_t* argmax, int32_t
 int dn_segment_max_bwd_bf16(const void* grad_out, const int32_t* argmax, int32_t H, const int32_t* ptr, int64_t S,
                             void* grad_in, dn_stream_t stream);
 
+/* Per-edge dot product (SDDMM): out[e] = < a[ia[e], :], b[ib[e], :] >, fp32 out; ia / ib may be NULL (row e).
+ * The gradient of a per-edge scalar weight w_e in  out[dst] += w_e * x[src]  is < x[src_e], grad_out[dst_e] >: this
+ * is what lets the reference's trainable dummy-edge weight (gconv.py:29-34,46-49: edge_attr[is_dummy_edge] =
+ * dummy_weight, passed to GCNConv) receive its gradient without PyG's autograd through index_select / scatter. */
+int dn_edge_dot_f32(const float* a, const int32_t* ia, const float* b, const int32_t* ib, int32_t H, int64_t E,
+                    float* out, dn_stream_t stream);
+int dn_edge_dot_bf16(const void* a, const int32_t* ia, const void* b, const int32_t* ib, int32_t H, int64_t E,
+                     float* out, dn_stream_t stream);
+
+/* Gather + segment MAX: out[s, h] = max_{i in [ptr[s], ptr[s+1])} in[idx[i], h]; argmax[s, h] = that slot i (-1 and
+ * out 0 for an empty segment; ties keep the lowest slot).  Replaces PyG SAGEConv's 'max' neighbour aggregation
+ * (gconv.py:130-132 `conv.aggr = self.aggregation`).  Backward: grad_in[u, h] = sum over the slots i that gathered
+ * row u (tptr [rows+1], tslot: slots grouped by gathered row; seg_of_slot [M]) of
+ * (argmax[seg(i), h] == i ? grad_out[seg(i), h] : 0) -- a gather over the transposed index, no atomics. */
+int dn_gather_segmax_f32(const float* in, const int32_t* idx, const int32_t* ptr, int64_t S, int32_t H, float* out,
+                         int32_t* argmax, dn_stream_t stream);
+int dn_gather_segmax_bf16(const void* in, const int32_t* idx, const int32_t* ptr, int64_t S, int32_t H, void* out,
+                          int32_t* argmax, dn_stream_t stream);
+int dn_gather_segmax_bwd_f32(const float* grad_out, const int32_t* argmax, const int32_t* tptr, const int32_t* tslot,
+                             const int32_t* seg_of_slot, int64_t rows, int32_t H, float* grad_in, dn_stream_t stream);
+int dn_gather_segmax_bwd_bf16(const void* grad_out, const int32_t* argmax, const int32_t* tptr, const int32_t* tslot,
+                              const int32_t* seg_of_slot, int64_t rows, int32_t H, void* grad_in, dn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * One-shot device-side index builds.
  * ------------------------------------------------------------------------------------------ */

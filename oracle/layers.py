@@ -260,3 +260,45 @@ def rgin_layer_rel_grouped(x, src, dst, etype, p, num_rels, act="relu", num_mlp_
     if num_mlp_layers == 0:
         out = f(out)
     return f(out)
+
+
+def gcn_norm(src, dst, edge_weight, num_nodes):
+    """torch_geometric.nn.conv.gcn_conv.gcn_norm (improved=False, add_self_loops=True, fill_value=1): existing self loops
+    keep their weight, every other node gets a weight-1 self loop; norm_e = deg^-1/2[src] * w_e * deg^-1/2[dst] with
+    deg = sum of weights INTO each node.  Returns (src', dst', norm) with the self loops appended.  (parity unpinned)"""
+    if edge_weight is None:
+        edge_weight = th.ones(src.numel(), dtype=th.float32)
+    keep = src != dst
+    loop_w = th.ones(num_nodes, dtype=edge_weight.dtype)
+    if (~keep).any():
+        loop_w = loop_w.index_put((src[~keep],), edge_weight[~keep])
+    ar = th.arange(num_nodes)
+    s2, d2 = th.cat([src[keep], ar]), th.cat([dst[keep], ar])
+    w2 = th.cat([edge_weight[keep], loop_w])
+    deg = th.zeros(num_nodes, dtype=w2.dtype).index_add(0, d2, w2)
+    dis = deg.pow(-0.5)
+    dis = th.where(th.isinf(dis), th.zeros_like(dis), dis)
+    return s2, d2, dis[s2] * w2 * dis[d2]
+
+
+def gcn_conv(x, src, dst, edge_weight, weight, bias):
+    """GCNConv: sum_j norm_ij (x_j W) + b, W applied first (lin has no bias).  call sites gconv.py:36-37,51-52."""
+    s2, d2, norm = gcn_norm(src, dst, edge_weight, x.shape[0])
+    xl = x @ weight.t()
+    out = segment_sum(xl[s2] * norm.view(-1, 1), d2, x.shape[0])
+    return out + bias if bias is not None else out
+
+
+def sage_conv(x, src, dst, lin_l_w, lin_l_b, lin_r_w, aggr="mean"):
+    """SAGEConv: lin_l(aggr_{j->i} x_j) + lin_r(x_i); aggr in mean | max | add; empty neighbourhoods give 0.
+    call site gconv.py:129-132.  (parity unpinned)"""
+    N = x.shape[0]
+    if aggr == "max":
+        agg = th.full((N, x.shape[1]), -math.inf, dtype=x.dtype)
+        agg = agg.scatter_reduce(0, dst.view(-1, 1).expand(-1, x.shape[1]), x[src], reduce="amax", include_self=True)
+        agg = th.where(th.isinf(agg), th.zeros_like(agg), agg)
+    else:
+        agg = segment_sum(x[src], dst, N)
+        if aggr == "mean":
+            agg = agg / th.bincount(dst, minlength=N).clamp(min=1).to(x.dtype).view(-1, 1)
+    return F.linear(agg, lin_l_w, lin_l_b) + F.linear(x, lin_r_w)

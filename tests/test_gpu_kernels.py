@@ -287,3 +287,35 @@ def test_neighbor_sum_with_hub_splitting():
         (ref * coef.double()).sum().backward()
         torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-4)
         torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H", [3, 16, 64, 200])
+def test_edge_dot_and_neighbor_max(dtype, H):
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    N, E = 300, 1500
+    src, dst = rng.integers(0, N, size=E), rng.integers(0, N, size=E)
+    dst[dst == 5] = 6                                            # node 5 has no in-edge -> max gives 0
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dtype)
+    g = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dtype)
+    s, d = torch.from_numpy(src).to(DEV, torch.int32), torch.from_numpy(dst).to(DEV, torch.int32)
+    got = ops.edge_dot(x.to(DEV), s, g.to(DEV), d)
+    ref = (x.double()[src] * g.double()[dst]).sum(1)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+    index = ops.EdgeIndex(s, d, N)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.neighbor_max(xd, index)
+    out.backward(g.to(DEV))
+    xr = x.double().requires_grad_(True)
+    want = OL.sage_conv(xr, torch.from_numpy(src), torch.from_numpy(dst), torch.eye(H, dtype=torch.float64), None,
+                        torch.zeros(H, H, dtype=torch.float64), aggr="max")
+    want.backward(g.double())
+    assert float(out.detach()[5].abs().max()) == 0.0
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=0, atol=0)      # max is exact
+    # ties (duplicate edges / equal bf16 values) may route the gradient to a different but equal-valued source; compare
+    # the per-destination totals, which are unambiguous
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(xd.grad.cpu().double().sum(0), xr.grad.sum(0), rtol=tol, atol=tol * 10)
+    if dtype == torch.float32:
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-5)
