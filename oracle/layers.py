@@ -302,3 +302,24 @@ def sage_conv(x, src, dst, lin_l_w, lin_l_b, lin_r_w, aggr="mean"):
         if aggr == "mean":
             agg = agg / th.bincount(dst, minlength=N).clamp(min=1).to(x.dtype).view(-1, 1)
     return F.linear(agg, lin_l_w, lin_l_b) + F.linear(x, lin_r_w)
+
+
+def split_and_batchify_graph_feats(batched_graph_feats, graph_sizes, pre_pad=False):
+    """reference: subgraph_isomorphism/utils/dl.py:51-81 (restated; th.cat of per-graph slices and zero pads)."""
+    bsz = graph_sizes.size(0)
+    sizes = graph_sizes.view(-1).tolist()
+    mx = max(sizes)
+    if min(sizes) == mx:
+        return batched_graph_feats.view(bsz, mx, -1), th.ones((bsz, mx), dtype=th.bool)
+    feats, mask = [], th.zeros((bsz, mx), dtype=th.bool)
+    idx = 0
+    for i, l in enumerate(sizes):
+        pad = th.zeros((mx - l,) + tuple(batched_graph_feats.shape[1:]), dtype=batched_graph_feats.dtype)
+        rows = batched_graph_feats[idx:idx + l]
+        feats.extend([pad, rows] if pre_pad else [rows, pad])
+        if pre_pad:
+            mask[i, mx - l:] = True
+        else:
+            mask[i, :l] = True
+        idx += l
+    return th.cat(feats, 0).view(bsz, mx, -1), mask

@@ -297,3 +297,25 @@ def test_gcn_sage_models_match_oracle(kind, additional, dummy_weight):
     if dummy_weight > 0:
         # the scalar dummy-edge weight receives its gradient through the per-edge dot-product kernel
         assert abs(float(model.dummy_weight.grad) - float(ref.dummy_weight.grad)) < 1e-4 * max(1.0, abs(float(ref.dummy_weight.grad)))
+
+
+@pytest.mark.parametrize("pre_pad", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_and_batchify_graph_feats(pre_pad, dtype):
+    from dummynode4graphlearning_amd.subgraph_isomorphism.dl import split_and_batchify_graph_feats
+    rng = np.random.default_rng(3)
+    sizes = torch.tensor([5, 1, 9, 3, 9, 2])
+    N, H = int(sizes.sum()), 64
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dtype)
+    coef = torch.from_numpy(rng.standard_normal((6, 9, H)).astype(np.float32)).to(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    feats, mask = split_and_batchify_graph_feats(xd, sizes.to(DEV), pre_pad=pre_pad)
+    (feats.float() * coef.to(DEV).float()).sum().backward()
+    xr = x.float().requires_grad_(True)
+    rf, rm = OL.split_and_batchify_graph_feats(xr, sizes, pre_pad=pre_pad)
+    (rf * coef.float()).sum().backward()
+    assert torch.equal(mask.cpu(), rm)
+    torch.testing.assert_close(feats.detach().cpu().float(), rf.detach(), rtol=0, atol=0)
+    torch.testing.assert_close(xd.grad.cpu().float(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 0, atol=1e-2 if dtype == torch.bfloat16 else 0)
+    same = split_and_batchify_graph_feats(torch.ones(8, 4, device=DEV), torch.tensor([4, 4], device=DEV))
+    assert same[0].shape == (2, 4, 4) and bool(same[1].all())
