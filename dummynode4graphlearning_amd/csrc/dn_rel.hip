@@ -426,35 +426,44 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     return DN_OK;
 }
 
-// out[r] = sum of the partials of relation r's chunks, in chunk order (one output element per thread: 256 workgroups per
-// relation tile keep enough loads in flight; the partial slabs are read exactly once)
+// out[r] = sum of the partials of relation r's chunks.  The sum is latency-bound (a few hundred 256 KB slabs, each element
+// read once), so 8 threads share an output element: thread `slice` adds chunks slice, slice+8, ... with 4 loads in flight,
+// the 8 slice sums are then folded through LDS in slice order.  Fixed association -> bitwise reproducible.
 template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
                                                            int32_t H, float* __restrict__ out_colsum) {
+    constexpr int SL = 8, EL = 256 / SL;
+    __shared__ float red[SL][EL];
     const int r = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int elem = threadIdx.x % EL, slice = threadIdx.x / EL;
     const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
-    if (cs_partial != nullptr && blockIdx.x == 0) {
-        for (int h = threadIdx.x; h < H; h += 256) {
-            float sum = 0.f;
-            for (int c = cb; c < ce; ++c) sum += cs_partial[(size_t)c * H + h];
-            out_colsum[(size_t)r * H + h] = sum;
-        }
-    }
-    if (i >= tile_elems) return;
+    // blocks past the tile handle the column sums (bias gradient) the same way
+    const int64_t tile_blocks = (tile_elems + EL - 1) / EL;
+    const bool is_cs = (int64_t)blockIdx.x >= tile_blocks;
+    const float* src = is_cs ? cs_partial : partial;
+    const int64_t stride = is_cs ? (int64_t)H : tile_elems;
+    const int64_t i = (is_cs ? (int64_t)blockIdx.x - tile_blocks : (int64_t)blockIdx.x) * EL + elem;
     float s = 0.f;
-    int c = cb;
-    for (; c + 16 <= ce; c += 16) {                     // 16 independent loads in flight, summed in chunk order
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(c + u) * tile_elems + i];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+    if (i < stride) {
+        int c = cb + slice;
+        for (; c + 3 * SL < ce; c += 4 * SL) {
+            const float v0 = src[(size_t)c * stride + i], v1 = src[(size_t)(c + SL) * stride + i];
+            const float v2 = src[(size_t)(c + 2 * SL) * stride + i], v3 = src[(size_t)(c + 3 * SL) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < ce; c += SL) s += src[(size_t)c * stride + i];
     }
-    for (; c < ce; ++c) s += partial[(size_t)c * tile_elems + i];
-    out[(size_t)r * tile_elems + i] = (TO)s;
+    red[slice][elem] = s;
+    __syncthreads();
+    if (slice == 0 && i < stride) {
+        float t = red[0][elem];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) t += red[k][elem];
+        if (is_cs) out_colsum[(size_t)r * H + i] = t;
+        else out[(size_t)r * tile_elems + i] = (TO)t;
+    }
 }
 
 template <int HI, int HO>
@@ -540,8 +549,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
-    dim3 grid((unsigned)dn_cdiv(tile, 256), (unsigned)R);
     const float* csp = colsum_of ? (const float*)workspace + (size_t)num_chunks * tile : nullptr;
+    dim3 grid((unsigned)(dn_cdiv(tile, 32) + (csp ? dn_cdiv(Hi, 32) : 0)), (unsigned)R);
     if (out_is_f32)
         hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
                            (float*)out, csp, Hi, out_colsum);
