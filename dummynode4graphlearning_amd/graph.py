@@ -234,6 +234,27 @@ def edge_index_of(data):
     return cache._edge_index
 
 
+def row_index_of(data, etype, num_rels, self_loop):
+    """Cached ops.RowIndexSet (bf16 matrix-core path) of a PyG-style batch."""
+    cache = getattr(data, "_cache", None)
+    if cache is None:
+        cache = _IndexCache()
+        try:
+            data._cache = cache
+        except Exception:
+            pass
+    tag = ("row", num_rels, self_loop)
+    for t, ver, r, ix in cache._rel:
+        if (t is etype or (t.data_ptr() == etype.data_ptr() and t.numel() == etype.numel())) and ver == etype._version \
+                and r == tag:
+            return ix
+    ix = ops.RowIndexSet(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels, self_loop)
+    cache._rel.append((etype, etype._version, tag, ix))
+    if len(cache._rel) > 4:
+        cache._rel.pop(0)
+    return ix
+
+
 def gcn_edge_index_of(data):
     """ops.EdgeIndex of the batch with GCN self loops (existing self loops dropped, one per node appended) + the boolean
     mask of kept edges.  Cached on the batch object."""

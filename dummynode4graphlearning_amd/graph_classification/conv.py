@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..graph import edge_index_of, gcn_edge_index_of, graph_ptr_i32, rel_index_of
+from ..graph import edge_index_of, gcn_edge_index_of, graph_ptr_i32, rel_index_of, row_index_of
 
 
 def _reset(module):
@@ -75,6 +75,11 @@ class RGCNConv(nn.Module):
             nn.init.zeros_(self.bias)
 
     def forward(self, x, data, edge_type):
+        if self.aggr == "add" and self.root is not None and ops.fused_path_supported(x, self.weight):
+            # bf16: relation transform + root weight + bias in the row-factorised MFMA pipeline (as SI RGINLayer)
+            index = row_index_of(data, edge_type, self.num_relations, True)
+            W_all = torch.cat([self.weight, self.root.unsqueeze(0)], 0)
+            return ops.rel_transform_fused(x, W_all, self.bias, index)
         index = rel_index_of(data, edge_type, self.num_relations)
         scale = None
         if self.aggr == "mean":

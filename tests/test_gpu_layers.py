@@ -385,3 +385,32 @@ def test_empty_and_degenerate_batches():
         ref = OL.rgin_layer(x.detach().cpu().double(), z.cpu(), z.cpu(), z.cpu(), p, num_rels=3, act="relu")
         assert _rel_l2(out, ref) < (1e-5 if dtype == torch.float32 else 2e-2)
         assert x.grad is not None and torch.isfinite(x.grad.float()).all()
+
+
+def test_gc_rgin_bf16_runs_on_the_fused_path():
+    """GC RGIN in bf16 (RGCNConv aggr='add' -> row factorisation) against the fp32 oracle forward."""
+    from dummynode4graphlearning_amd import graph_classification as GC, ops
+    rng = np.random.default_rng(8)
+    F_, R, H, C = 8, 5, 64, 2
+    data = _gc_batch(rng, 32, F_, R)
+    args = SimpleNamespace(num_features=F_, hidden_dim=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
+                           additional={"num_layers": 2}, epochs=1, device=DEV, dummy_weight=0)
+    torch.manual_seed(0)
+    model = GC.RGIN(args)
+    ref = GC.RGIN(args)
+    ref.load_state_dict(model.state_dict())
+    model = model.to(DEV).to(torch.bfloat16).train()
+    ref.train()
+    d = data.to(DEV)
+    d.x = d.x.to(torch.bfloat16)
+    calls = []
+    orig = ops.rel_transform_fused
+    ops.rel_transform_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = model(d)
+    finally:
+        ops.rel_transform_fused = orig
+    assert calls, "bf16 RGCNConv(aggr='add') did not take the fused path"
+    out.float().sum().backward()
+    want = _oracle_gc_forward(ref, data, "RGIN")
+    assert _rel_l2(out.float().exp(), want.exp()) < 5e-2          # class probabilities after two bf16 layers + BN
