@@ -1,0 +1,435 @@
+// fp32 twins of the relation-wise matrix-core kernels (dn_rel.hip) on the exact-f32 MFMA of gfx950
+// (v_mfma_f32_16x16x4_f32: f32 in / f32 accumulate, bit-for-bit an fmaf chain, 1/16 of the bf16 rate).
+// The reference is fp32 only, so this is the path that keeps its numerics (1e-4 parity) while still replacing the
+// per-edge [E,H,H] weight gather (subgraph_isomorphism/models/rgin.py:109-110) by the row factorisation.
+//
+// Same structure as the bf16 kernels; what changes is the fragment shape: an MFMA step reduces over 4 values, lane
+// (r = lane & 15, g = lane >> 4) supplies one f32 of row r.  Four consecutive steps are fed from ONE 16-byte load per
+// lane by letting step j use k = 16*blk + 4*g + j on BOTH operands (the sum over k does not care about the order), so
+// LDS and weight reads stay 128-bit.
+#include "dn_common.h"
+#include "../../include/dn_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kRows = 32;
+
+struct Chunk {
+    int32_t rel, beg, end, pad;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient:  partial[chunk][k][n] = sum_{p in chunk} A[ia[p]][k] * G[ig[p]][n]
+// ---------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(kThreads) void rows_wgrad_f32_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                                  int32_t na1, const int32_t* __restrict__ ia,
+                                                                  const float* __restrict__ G, const float* __restrict__ G2,
+                                                                  int32_t ng1, const int32_t* __restrict__ ig,
+                                                                  const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                  int32_t colsum_of, float* __restrict__ colsum_partial,
+                                                                  const float* __restrict__ maskA, float* __restrict__ A_out) {
+    constexpr int S = H + 16;                                   // LDS row stride in floats: rows p, p+1 land 16 banks apart
+    constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
+    constexpr int NP = kRows * H / 4;                           // 16-byte pieces per operand tile
+    constexpr int P = (NP + kThreads - 1) / kThreads;
+    static_assert(MT >= 1 && NT >= 1, "unsupported width");
+    __shared__ __attribute__((aligned(16))) float lds[4 * kRows * S];
+    auto bufA = [&](int b) -> float* { return lds + b * (kRows * S); };
+    auto bufG = [&](int b) -> float* { return lds + 2 * kRows * S + b * (kRows * S); };
+
+    const Chunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = (wave >> 2) * (H / 2), n0 = (wave & 3) * (H / 4);
+    const int ntiles = (ch.end - ch.beg + kRows - 1) / kRows;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[P], rg[P], rm[P];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    int32_t sa[P], sg[P], sa_cur[P];
+    auto load_idx = [&](int t) {
+        const int row0 = ch.beg + t * kRows;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, p = row0 + piece / (H / 4);
+            const bool ok = piece < NP && p < ch.end;
+            sa[j] = ok ? (ia ? ia[p] : p) : -1;
+            sg[j] = ok ? (ig ? ig[p] : p) : -1;
+        }
+    };
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int c = (tid + j * kThreads) % (H / 4);
+            sa_cur[j] = sa[j];
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sa[j] >= 0) {
+                const float* base = sa[j] < na1 ? A + (size_t)sa[j] * H : A2 + (size_t)(sa[j] - na1) * H;
+                ra[j] = *reinterpret_cast<const float4*>(base + c * 4);
+                if (maskA) rm[j] = *reinterpret_cast<const float4*>(maskA + (size_t)sa[j] * H + c * 4);
+            }
+            if (sg[j] >= 0) {
+                const float* base = sg[j] < ng1 ? G + (size_t)sg[j] * H : G2 + (size_t)(sg[j] - ng1) * H;
+                rg[j] = *reinterpret_cast<const float4*>(base + c * 4);
+            }
+        }
+    };
+    auto store_tile = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            if (maskA && sa_cur[j] >= 0) {
+                ra[j].x = rm[j].x > 0.f ? ra[j].x : 0.f; ra[j].y = rm[j].y > 0.f ? ra[j].y : 0.f;
+                ra[j].z = rm[j].z > 0.f ? ra[j].z : 0.f; ra[j].w = rm[j].w > 0.f ? ra[j].w : 0.f;
+                if (A_out) *reinterpret_cast<float4*>(A_out + (size_t)sa_cur[j] * H + c * 4) = ra[j];
+            }
+            if (piece < NP) {
+                *reinterpret_cast<float4*>(bufA(b) + r * S + c * 4) = ra[j];
+                *reinterpret_cast<float4*>(bufG(b) + r * S + c * 4) = rg[j];
+                const float4 v = colsum_of == 1 ? ra[j] : rg[j];
+                if (colsum_of != 0) { cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w; }
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        load_idx(0);
+        load_tile();
+        store_tile(0);
+        load_idx(1);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int b = t & 1;
+        if (t + 1 < ntiles) {
+            load_tile();
+            load_idx(t + 2);
+        }
+        const float* ta = bufA(b) + (lane >> 4) * S + (lane & 15);
+        const float* tg = bufG(b) + (lane >> 4) * S + (lane & 15);
+#pragma unroll
+        for (int pb = 0; pb < kRows / 4; ++pb) {                 // 4 rows (reduction index) per MFMA step
+            float fb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) fb[n] = tg[pb * 4 * S + n0 + n * 16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float fa = ta[pb * 4 * S + k0 + m * 16];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) store_tile(b ^ 1);
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * H * H;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
+                out[(size_t)k * H + c] = acc[m][n][i];
+            }
+    if (colsum_of != 0) {
+        constexpr int TPC = kThreads / (H / 4);                  // threads sharing a 4-column chunk
+        float* red = lds;
+        const int cchunk = tid % (H / 4), slot = tid / (H / 4);
+        const bool has = (NP >= kThreads) || tid < NP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[slot * H + cchunk * 4 + i] = has ? cs[i] : 0.f;
+        __syncthreads();
+        if (tid < H) {
+            float sum = 0.f;
+            for (int sl = 0; sl < TPC; ++sl) sum += red[sl * H + tid];
+            colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
+        }
+    }
+}
+
+// out[r] = sum of chunk partials (same slice-parallel fixed-order fold as the bf16 library's reducer)
+__global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __restrict__ partial,
+                                                               const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
+                                                               float* __restrict__ out, const float* __restrict__ cs_partial,
+                                                               int32_t H, float* __restrict__ out_colsum) {
+    constexpr int SL = 8, EL = 256 / SL;
+    __shared__ float red[SL][EL];
+    const int r = blockIdx.y;
+    const int elem = threadIdx.x % EL, slice = threadIdx.x / EL;
+    const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
+    const int64_t tile_blocks = (tile_elems + EL - 1) / EL;
+    const bool is_cs = (int64_t)blockIdx.x >= tile_blocks;
+    const float* src = is_cs ? cs_partial : partial;
+    const int64_t stride = is_cs ? (int64_t)H : tile_elems;
+    const int64_t i = (is_cs ? (int64_t)blockIdx.x - tile_blocks : (int64_t)blockIdx.x) * EL + elem;
+    float s = 0.f;
+    if (i < stride) {
+        int c = cb + slice;
+        for (; c + 3 * SL < ce; c += 4 * SL) {
+            const float v0 = src[(size_t)c * stride + i], v1 = src[(size_t)(c + SL) * stride + i];
+            const float v2 = src[(size_t)(c + 2 * SL) * stride + i], v3 = src[(size_t)(c + 3 * SL) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < ce; c += SL) s += src[(size_t)c * stride + i];
+    }
+    red[slice][elem] = s;
+    __syncthreads();
+    if (slice == 0 && i < stride) {
+        float t = red[0][elem];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) t += red[k][elem];
+        if (is_cs) out_colsum[(size_t)r * H + i] = t;
+        else out[(size_t)r * tile_elems + i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// transform:  Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] )
+// ---------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
+    const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
+    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, const float* __restrict__ mask_pos,
+    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
+    constexpr int S = H + 4;                                    // 16-byte row pad: conflict-free ds_read_b128 fragments
+    constexpr int KB = H / 16;                                  // 16-wide k blocks (4 MFMA steps each)
+    constexpr int NT = (H / 8 + 15) / 16;
+    constexpr int MT = kRows / 16;
+    constexpr int NP = kRows * H / 4;
+    constexpr int P = (NP + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) float lds[3 * kRows * S];
+    auto bufX = [&](int b) -> float* { return lds + b * (kRows * S); };
+    float* bufY = lds + 2 * kRows * S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * (NT * 16);
+    const bool wave_active = n0 < H;
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    float4 wf[KB][NT];
+    int cur_rel = -1;
+    int32_t nidx[P];
+    float4 rx[P];
+    auto load_idx = [&](int t) {
+        if (t >= t_end) return;
+        const Chunk tl = tiles[t];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, p = tl.beg + piece / (H / 4);
+            nidx[j] = (piece < NP && p < tl.end) ? (idx ? idx[p] : p) : -1;
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int c = (tid + j * kThreads) % (H / 4);
+            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nidx[j] >= 0) {
+                const float* base = nidx[j] < n1 ? X + (size_t)nidx[j] * H : X2 + (size_t)(nidx[j] - n1) * H;
+                rx[j] = *reinterpret_cast<const float4*>(base + c * 4);
+            }
+        }
+    };
+    auto store_rows = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            if (piece < NP) *reinterpret_cast<float4*>(bufX(b) + r * S + c * 4) = rx[j];
+        }
+    };
+
+    load_idx(t_beg);
+    load_rows();
+    store_rows(0);
+    load_idx(t_beg + 1);
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        const Chunk tl = tiles[t];
+        if (t + 1 < t_end) load_rows();
+        if (tl.rel != cur_rel && wave_active) {
+            cur_rel = tl.rel;
+            const float* w = Wn + (size_t)cur_rel * H * H;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[kb][nt] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * H + kb * 16 +
+                                                                  4 * (lane >> 4));
+        }
+        if (wave_active) {
+            f32x4 acc[MT][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xt = bufX(b) + (lane & 15) * S + 4 * (lane >> 4);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                float4 xf[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xf[m] = *reinterpret_cast<const float4*>(xt + m * 16 * S + kb * 16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb][n].x, xf[m].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb][n].y, xf[m].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb][n].z, xf[m].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb][n].w, xf[m].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = n0 + n * 16 + 4 * (lane >> 4);
+                    float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+                    if (bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(bufY + (m * 16 + (lane & 15)) * S + col) = v;
+                }
+        }
+        if (t + 1 < t_end) store_rows(b ^ 1);
+        load_idx(t + 2);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            const int p = tl.beg + r;
+            if (piece < NP && p < tl.end) {
+                float4 v = *reinterpret_cast<const float4*>(bufY + r * S + c * 4);
+                if (mask_pos) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mask_pos + (size_t)p * H + c * 4);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(Y + (size_t)p * H + c * 4) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
+                                                           float4* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 gv = g[i], yv = y[i];
+        out[i] = make_float4(yv.x > 0.f ? gv.x : 0.f, yv.y > 0.f ? gv.y : 0.f, yv.z > 0.f ? gv.z : 0.f, yv.w > 0.f ? gv.w : 0.f);
+    }
+}
+
+template <int H>
+int launch_wgrad(const float* A, const float* A2, int32_t na1, const int32_t* ia, const float* G, const float* G2, int32_t ng1,
+                 const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of, float* csp,
+                 const float* maskA, float* A_out, hipStream_t st) {
+    hipLaunchKernelGGL((rows_wgrad_f32_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2, ng1,
+                       ig, chunks, partial, colsum_of, csp, maskA, A_out);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <int H>
+int launch_transform(const float* X, const float* X2, int32_t n1, const int32_t* idx, const float* Wn, const float* bias,
+                     int32_t relu, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, hipStream_t st) {
+    const int64_t max_wg = 256 * (H == 256 ? 1 : 2);             // LDS: one 100 KB workgroup per CU at H = 256
+    const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
+    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    hipLaunchKernelGGL((rows_transform_f32_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias, relu,
+                       mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, dn_stream_t stream) {
+    DN_REQUIRE(numel >= 0 && numel % 4 == 0, "dn_relu_bwd_f32: numel must be a non-negative multiple of 4");
+    if (numel == 0) return DN_OK;
+    DN_REQUIRE(g && y && out, "dn_relu_bwd_f32: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) % 16 == 0,
+               "dn_relu_bwd_f32: unaligned pointer");
+    const int64_t n4 = numel / 4;
+    const int64_t grid = dn_cdiv(n4, 256) < 256 * 16 ? dn_cdiv(n4, 256) : 256 * 16;
+    hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4*)g,
+                       (const float4*)y, (float4*)out, n4);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G, const float* G2,
+                      int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
+                      int64_t num_chunks, const int32_t* chunk_ptr, float* out, int32_t colsum_of, float* out_colsum,
+                      const float* mask_a, float* a_out, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(R >= 0 && num_chunks >= 0, "dn_rows_wgrad_f32: negative size");
+    DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_wgrad_f32: unsupported widths %d x %d "
+               "(square 64/128/256 only)", Hi, Ho);
+    DN_REQUIRE(A2 != nullptr || na1 == 0x7fffffff, "dn_rows_wgrad_f32: A2 == NULL requires na1 == INT32_MAX");
+    DN_REQUIRE(G2 != nullptr || ng1 == 0x7fffffff, "dn_rows_wgrad_f32: G2 == NULL requires ng1 == INT32_MAX");
+    DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad_f32: bad colsum arguments");
+    DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad_f32: mask_a needs a single A source");
+    DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad_f32: a_out needs mask_a and idx_a == NULL");
+    if (R == 0) return DN_OK;
+    DN_REQUIRE(out && chunk_ptr, "dn_rows_wgrad_f32: NULL pointer");
+    DN_REQUIRE(num_chunks == 0 || (A && G && chunks && workspace), "dn_rows_wgrad_f32: NULL pointer");
+    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * ((size_t)Hi * Ho + Hi) * sizeof(float), "dn_rows_wgrad_f32: workspace too small");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(A2) | reinterpret_cast<uintptr_t>(G) |
+                reinterpret_cast<uintptr_t>(G2) | reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0,
+               "dn_rows_wgrad_f32: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const Chunk* ch = reinterpret_cast<const Chunk*>(chunks);
+    float* ws = (float*)workspace;
+    float* csp = ws + (size_t)num_chunks * Hi * Ho;
+    int rc = DN_OK;
+    if (num_chunks > 0) {
+        if (Hi == 256) rc = launch_wgrad<256>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
+        else if (Hi == 128) rc = launch_wgrad<128>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
+        else rc = launch_wgrad<64>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
+        if (rc != DN_OK) return rc;
+    }
+    const int64_t tile = (int64_t)Hi * Ho;
+    const float* cspc = colsum_of ? csp : nullptr;
+    dim3 grid((unsigned)(dn_cdiv(tile, 32) + (cspc ? dn_cdiv(Hi, 32) : 0)), (unsigned)R);
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, grid, dim3(256), 0, st, (const float*)ws, chunk_ptr, tile, out, cspc, Hi, out_colsum);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
+                          const float* Wn, const float* bias, int32_t relu, const float* mask_pos, const int32_t* tiles,
+                          int64_t num_tiles, float* Y, dn_stream_t stream) {
+    DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform_f32: bad tile count");
+    DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform_f32: unsupported widths %d x %d "
+               "(square 64/128/256 only)", Hi, Ho);
+    if (num_tiles == 0) return DN_OK;
+    DN_REQUIRE(X && Wn && tiles && Y, "dn_rows_transform_f32: NULL pointer");
+    DN_REQUIRE(X2 != nullptr || n1 == 0x7fffffff, "dn_rows_transform_f32: X2 == NULL requires n1 == INT32_MAX");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Wn) |
+                reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(mask_pos)) % 16 == 0,
+               "dn_rows_transform_f32: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
+    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
+    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
+    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
+}
+
+}  // extern "C"

@@ -171,7 +171,10 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     column sums [R, H] of operand A|G (the bias gradient)."""
     chunks, chunk_ptr, nchunks = chunk_table
     require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out)
-    assert A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
+    assert A.dtype == G.dtype and A.dtype in (torch.bfloat16, torch.float32)
+    is_f32 = A.dtype == torch.float32
+    if is_f32:
+        out_dtype = torch.float32
     Hi, Ho = A.shape[1], G.shape[1]
     out_dtype = out_dtype or A.dtype
     out = torch.empty((num_rels, Hi, Ho), dtype=out_dtype, device=A.device)
@@ -179,12 +182,17 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     colsum = torch.empty((num_rels, Hi), dtype=torch.float32, device=A.device) if colsum_of else None
 
     def _launch():
-        check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), A.shape[0] if A2 is not None else INT32_MAX, ptr(idx_a),
-                                       ptr(G), ptr(G2), G.shape[0] if G2 is not None else INT32_MAX, ptr(idx_g),
-                                       Hi, Ho, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
-                                       1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
-                                       ptr(a_out), ptr(ws), ws.numel(), stream_ptr()),
-              "dn_rows_wgrad_bf16")
+        na1 = A.shape[0] if A2 is not None else INT32_MAX
+        ng1 = G.shape[0] if G2 is not None else INT32_MAX
+        if is_f32:
+            check(lib().dn_rows_wgrad_f32(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
+                                          ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out), int(colsum_of), ptr(colsum),
+                                          ptr(mask_a), ptr(a_out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_f32")
+        else:
+            check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
+                                           ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
+                                           1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
+                                           ptr(a_out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_wgrad", _launch)
@@ -211,7 +219,8 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
     """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16)."""
     tiles, ntiles = tile_table
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
-    assert X.dtype == torch.bfloat16 and Wn.dtype == torch.bfloat16 and Wn.dim() == 3
+    assert X.dtype == Wn.dtype and X.dtype in (torch.bfloat16, torch.float32) and Wn.dim() == 3
+    assert bias is None or bias.dtype == X.dtype
     Ho, Hi = Wn.shape[1], Wn.shape[2]
     assert X.shape[1] == Hi
     if out is None:
@@ -221,9 +230,9 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
         Y = out[:num_rows]
 
     def _launch():
-        check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho,
-                                           ptr(Wn), ptr(bias), 1 if relu else 0, ptr(mask_pos), ptr(tiles), ntiles,
-                                           ptr(Y), stream_ptr()), "dn_rows_transform_bf16")
+        fn = lib().dn_rows_transform_f32 if X.dtype == torch.float32 else lib().dn_rows_transform_bf16
+        check(fn(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias),
+                 1 if relu else 0, ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), stream_ptr()), "dn_rows_transform")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_transform:" + tag, _launch)
@@ -232,9 +241,11 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
     return Y
 
 
+MFMA_DTYPES = (torch.bfloat16, torch.float32)
+
+
 def wgrad_supported(A, G):
-    return (A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16 and A.shape[1] == G.shape[1]
-            and A.shape[1] in (64, 128, 256))
+    return A.dtype == G.dtype and A.dtype in MFMA_DTYPES and A.shape[1] == G.shape[1] and A.shape[1] in (64, 128, 256)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -740,7 +751,9 @@ class _RowTransformFn(torch.autograd.Function):
 
 
 def fused_path_supported(x, W):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.dim() == 3
+    """bf16 (storage bf16 / fp32 accumulate) and fp32 (exact-f32 MFMA) run the row-factorised matrix-core pipeline when the
+    layer is square with H in {64, 128, 256}; everything else takes the generic two-pass path."""
+    return (x.is_cuda and x.dtype == W.dtype and x.dtype in MFMA_DTYPES and W.dim() == 3
             and W.shape[1] == W.shape[2] and W.shape[1] in (64, 128, 256) and x.shape[1] == W.shape[1])
 
 
@@ -812,7 +825,8 @@ def relu_bwd(g, y):
     """(y > 0) ? g : 0  (dn_relu_bwd_bf16)."""
     require_gpu(g, y)
     out = torch.empty_like(g)
-    check(lib().dn_relu_bwd_bf16(ptr(g), ptr(y), ptr(out), g.numel(), stream_ptr()), "dn_relu_bwd_bf16")
+    fn = lib().dn_relu_bwd_f32 if g.dtype == torch.float32 else lib().dn_relu_bwd_bf16
+    check(fn(ptr(g), ptr(y), ptr(out), g.numel(), stream_ptr()), "dn_relu_bwd")
     return out
 
 
@@ -865,8 +879,8 @@ class _ReluMlpFn(torch.autograd.Function):
 
 
 def relu_mlp_supported(x, linears):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] > 0 and len(linears) > 0
-            and all(l.weight.dtype == torch.bfloat16 and l.weight.shape[0] == l.weight.shape[1] == x.shape[1]
+    return (x.is_cuda and x.dtype in MFMA_DTYPES and x.dim() == 2 and x.shape[0] > 0 and len(linears) > 0
+            and all(l.weight.dtype == x.dtype and l.weight.shape[0] == l.weight.shape[1] == x.shape[1]
                     and x.shape[1] in (64, 128, 256) for l in linears))
 
 
@@ -879,7 +893,7 @@ def relu_mlp(x, linears):
 
 def linear_act(x, weight, bias=None, relu=False):
     """nn.Linear (+ ReLU) on the MFMA kernels when supported (bf16, square 64/128/256), else torch."""
-    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 2
+    if (x.is_cuda and x.dtype == weight.dtype and x.dtype in MFMA_DTYPES and x.dim() == 2
             and weight.shape[0] == weight.shape[1] and weight.shape[0] in (64, 128, 256) and x.shape[1] == weight.shape[1]
             and x.shape[0] > 0):
         return _LinearActFn.apply(x, weight, bias, relu)

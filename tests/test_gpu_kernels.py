@@ -152,8 +152,9 @@ def test_neighbor_sum_autograd_matches_oracle():
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("H", [64, 128, 256])
-def test_rows_wgrad_matches_reference(H):
+def test_rows_wgrad_matches_reference(H, dt):
     """MFMA split-K weight gradient: out[r] = sum_p A[ia[p]]^T G[ig[p]] (asymmetric data: catches transposed tiles)."""
     ops = _ops()
     rng = np.random.default_rng(H)
@@ -161,8 +162,8 @@ def test_rows_wgrad_matches_reference(H):
     sizes = [0, 37, 5000, 1, 9001]                      # empty relation, tiny, multi-chunk, single row, ragged tail
     rel_ptr = [0] + list(np.cumsum(sizes))
     P, NA, NG = rel_ptr[-1], 3000, 2500
-    A = torch.from_numpy(rng.standard_normal((NA, H)).astype(np.float32)).to(torch.bfloat16)
-    G = torch.from_numpy(rng.standard_normal((NG, H)).astype(np.float32)).to(torch.bfloat16)
+    A = torch.from_numpy(rng.standard_normal((NA, H)).astype(np.float32)).to(dt)
+    G = torch.from_numpy(rng.standard_normal((NG, H)).astype(np.float32)).to(dt)
     ia = torch.from_numpy(rng.integers(0, NA, size=P)).to(torch.int32)
     ig = torch.from_numpy(rng.integers(0, NG, size=P)).to(torch.int32)
     table = ops.make_row_chunks([int(v) for v in rel_ptr], DEV, chunk_rows=2048)
@@ -186,21 +187,23 @@ def test_rows_wgrad_matches_reference(H):
     t2 = ops.make_row_chunks([0, P2], DEV, chunk_rows=1024)
     got3 = ops.rows_wgrad(A[:P2].contiguous().to(DEV), G[:P2].contiguous().to(DEV), t2, 1)
     ref3 = A[:P2].double().t() @ G[:P2].double()
-    torch.testing.assert_close(got3[0].cpu().double(), ref3, rtol=1e-2, atol=0.5)
+    torch.testing.assert_close(got3[0].cpu().double(), ref3, rtol=1e-2, atol=0.5 if dt == torch.bfloat16 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("H", [64, 128, 256])
-def test_rows_transform_matches_reference(H):
+def test_rows_transform_matches_reference(H, dt):
     """Gathered-row MFMA transform: Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T) with asymmetric weights."""
     ops = _ops()
+    tol = dict(rtol=1e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
     rng = np.random.default_rng(10 + H)
     sizes = [0, 37, 1500, 1, 33, 64]
     rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
     R, P, N1, N2 = len(sizes), rel_ptr[-1], 700, 90
-    X = torch.from_numpy(rng.standard_normal((N1, H)).astype(np.float32)).to(torch.bfloat16)
-    X2 = torch.from_numpy(rng.standard_normal((N2, H)).astype(np.float32)).to(torch.bfloat16)
-    Wn = torch.from_numpy((rng.standard_normal((R, H, H)) / np.sqrt(H)).astype(np.float32)).to(torch.bfloat16)
-    bias = torch.from_numpy(rng.standard_normal((R, H)).astype(np.float32)).to(torch.bfloat16)
+    X = torch.from_numpy(rng.standard_normal((N1, H)).astype(np.float32)).to(dt)
+    X2 = torch.from_numpy(rng.standard_normal((N2, H)).astype(np.float32)).to(dt)
+    Wn = torch.from_numpy((rng.standard_normal((R, H, H)) / np.sqrt(H)).astype(np.float32)).to(dt)
+    bias = torch.from_numpy(rng.standard_normal((R, H)).astype(np.float32)).to(dt)
     idx = torch.from_numpy(rng.integers(0, N1 + N2, size=P)).to(torch.int32)
     tiles = ops.make_row_tiles(rel_ptr, DEV)
     Xcat = torch.cat([X, X2]).double()
@@ -213,17 +216,22 @@ def test_rows_transform_matches_reference(H):
             ref = ref + bias.double()[rel_of_row]
         if relu:
             ref = ref.clamp(min=0)
-        # fp32 accumulate of exact bf16 products, one bf16 rounding of the stored result
-        torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-2, atol=2e-2)
+        # fp32 accumulate of exact products; bf16 adds one rounding of the stored result
+        torch.testing.assert_close(got.cpu().double(), ref, **tol)
+        mask = torch.from_numpy(rng.standard_normal((P, H)).astype(np.float32)).to(dt)
+        gotm = ops.rows_transform(X.to(DEV), Wn.to(DEV), tiles, P, idx=idx.to(DEV), X2=X2.to(DEV),
+                                  bias=bias.to(DEV) if use_bias else None, relu=relu, mask_pos=mask.to(DEV))
+        torch.testing.assert_close(gotm.cpu().double(), ref * (mask.double() > 0), **tol)
     # identity rows, single source
     t1 = ops.make_row_tiles([0, N1], DEV)
     got = ops.rows_transform(X.to(DEV), Wn[2:3].contiguous().to(DEV), t1, N1)
-    torch.testing.assert_close(got.cpu().double(), X.double() @ Wn[2].double().t(), rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(got.cpu().double(), X.double() @ Wn[2].double().t(), **tol)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("self_loop", [True, False])
-def test_fused_row_factorisation_forward_backward(self_loop):
-    """bf16 fused path (EDGE / AGG / TF relations + self loop) against the fp32 per-edge formulation."""
+def test_fused_row_factorisation_forward_backward(self_loop, dt):
+    """Fused path (EDGE / AGG / TF relations + self loop), bf16 and exact-f32 MFMA, against the fp64 per-edge formulation."""
     ops = _ops()
     from dummynode4graphlearning_amd import synthetic
     raw = synthetic.config3(seed=7, graphs=24)
@@ -232,7 +240,7 @@ def test_fused_row_factorisation_forward_backward(self_loop):
     src, dst, et = (torch.from_numpy(aug[k]) for k in ("src", "dst", "edge_label"))
     N, R, H = len(aug["node_label"]), raw["num_rels"], 64
     rng = np.random.default_rng(1)
-    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(dt)  # noqa: E731
     x = bf(rng.standard_normal((N, H)))
     W = bf(rng.standard_normal((R + (1 if self_loop else 0), H, H)) / np.sqrt(H))
     b = bf(rng.standard_normal(H)) if self_loop else None
@@ -253,12 +261,13 @@ def test_fused_row_factorisation_forward_backward(self_loop):
 
     def rel(a, r):
         return float((a.detach().cpu().double() - r.detach()).abs().max() / r.detach().abs().max())
-    # bf16 storage of every intermediate (2^-8 relative each): 2e-2 of the tensor range end to end
-    assert rel(out, ref) < 2e-2
-    assert rel(xd.grad, xr.grad) < 2e-2
-    assert rel(Wd.grad, Wr.grad) < 2e-2
+    # bf16 storage of every intermediate (2^-8 relative each): 2e-2 of the tensor range end to end; fp32: 1e-5
+    lim = 2e-2 if dt == torch.bfloat16 else 1e-5
+    assert rel(out, ref) < lim
+    assert rel(xd.grad, xr.grad) < lim
+    assert rel(Wd.grad, Wr.grad) < lim
     if self_loop:
-        assert rel(bd.grad, br.grad) < 2e-2
+        assert rel(bd.grad, br.grad) < lim
 
 
 def test_neighbor_sum_with_hub_splitting():

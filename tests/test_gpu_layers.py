@@ -193,13 +193,14 @@ def test_rep_net_residual_and_gate(golden_dir):
     assert _rel_max(got, cur) < RTOL
 
 
-def test_relu_mlp_matches_torch_autograd():
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_relu_mlp_matches_torch_autograd(dt):
     """Fused Linear+ReLU chain (forward epilogues, masked input-gradient epilogue, fused bias sums) vs torch in fp64 on
-    the same bf16-rounded operands."""
+    the same (bf16-rounded) operands; fp32 runs on the exact-f32 MFMA."""
     from dummynode4graphlearning_amd import ops
     rng = np.random.default_rng(4)
     N, H = 3000, 128
-    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(dt)  # noqa: E731
     x = bf(rng.standard_normal((N, H)))
     lins = []
     for _ in range(3):
@@ -208,7 +209,7 @@ def test_relu_mlp_matches_torch_autograd():
         lin.bias.data = bf(rng.standard_normal(H) * 0.5).float()
         lins.append(lin)
     gout = bf(rng.standard_normal((N, H)))
-    dl = [torch.nn.Linear(H, H).to(DEV).to(torch.bfloat16) for _ in lins]
+    dl = [torch.nn.Linear(H, H).to(DEV).to(dt) for _ in lins]
     for d, l in zip(dl, lins):
         d.weight.data.copy_(l.weight.data)
         d.bias.data.copy_(l.bias.data)
@@ -217,7 +218,7 @@ def test_relu_mlp_matches_torch_autograd():
     y.backward(gout.to(DEV))
     # reference: same chain in fp64 with the kernel's storage points (every activation / gradient tensor kept in bf16),
     # so both sides see the same ReLU masks; backward written out by hand (rounding treated as identity)
-    rb = lambda t: t.to(torch.bfloat16).double()  # noqa: E731
+    rb = lambda t: t.to(dt).double()  # noqa: E731
     acts = [x.double()]
     for l in lins:
         acts.append(rb(torch.relu(acts[-1] @ l.weight.double().t() + l.bias.double())))
@@ -230,11 +231,12 @@ def test_relu_mlp_matches_torch_autograd():
         if i > 0:
             g = g * (acts[i] > 0)
         g = rb(g)
-    assert _rel_l2(y, acts[-1]) < 5e-3
-    assert _rel_l2(xd.grad, g) < 5e-3
+    lim = 5e-3 if dt == torch.bfloat16 else 2e-5
+    assert _rel_l2(y, acts[-1]) < lim
+    assert _rel_l2(xd.grad, g) < lim
     for i, d in enumerate(dl):
-        assert _rel_l2(d.weight.grad, ref_gw[i]) < 5e-3
-        assert _rel_l2(d.bias.grad, ref_gb[i]) < 5e-3
+        assert _rel_l2(d.weight.grad, ref_gw[i]) < lim
+        assert _rel_l2(d.bias.grad, ref_gb[i]) < lim
 
 
 # ------------------------------------------------------------------------------------------------------------------
