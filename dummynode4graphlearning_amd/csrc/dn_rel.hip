@@ -240,9 +240,10 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
     constexpr int NPY = kTfRows * HO / 8;
     constexpr int PY = (NPY + kTfThreads - 1) / kTfThreads;
     static_assert(NT >= 1 && KS >= 1, "unsupported width");
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kTfRows * SX + kTfRows * SY];
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kTfRows * SX + kTfRows * SY + HO];
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kTfRows * SX); };
     bf16_t* bufY = lds + 2 * kTfRows * SX;
+    bf16_t* biasL = lds + 2 * kTfRows * SX + kTfRows * SY;   // bias[rel]: each wave keeps ITS column slice here (no barrier)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = wave * (NT * 16);
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                 for (int nt = 0; nt < NT; ++nt)
                     wf[ks][nt] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * HI + ks * 32 +
                                                                   8 * (lane >> 4));
+            if (bias && lane < NT * 16) biasL[n0 + lane] = bias[(size_t)cur_rel * HO + n0 + lane];
         }
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -341,9 +343,10 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                 const int col = n0 + n * 16 + 4 * (lane >> 4);
                 float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
                 if (bias) {
-                    const bf16_t* bp = bias + (size_t)cur_rel * HO + col;
+                    typedef bf16_t bf16x4b __attribute__((ext_vector_type(4)));
+                    const bf16x4b bv = *reinterpret_cast<const bf16x4b*>(biasL + col);   // written by this wave: in order
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bp[i];
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bv[i];
                 }
                 if (relu) {
 #pragma unroll
