@@ -129,3 +129,42 @@ def test_config3_rgin_stack_training_step_matches_oracle():
         assert abs(loss.item() - lr_.item()) / lr_.item() < 1e-4
     for (k, p), (_, q) in zip(net.state_dict().items(), ref.state_dict().items()):
         torch.testing.assert_close(p.cpu(), q, rtol=2e-3, atol=2e-5, msg=k)
+
+
+def test_conjugate_batch_feeds_the_layers_like_the_reference_pipeline():
+    """CONJ_* pipeline end to end on the device: dummy augmentation -> L_Phi (vertices = edges, vertex labels = edge labels,
+    edge labels = labels of the shared vertex) -> RGIN layer over the conjugate batch; compared with the same pipeline on
+    the oracle (tu_data_processing.py:436-451 writes exactly these graphs for the trainer)."""
+    from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config1(seed=9)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_label", "edge_label")
+    aug = transforms.dummy_augment_gc(*(torch.from_numpy(raw[k]).to(DEV) for k in keys))
+    cj = transforms.conjugate(aug["node_ptr"], aug["edge_ptr"], aug["src"], aug["dst"], aug["node_label"],
+                              is_dummy_edge=aug["is_dummy_edge"], mode="gc")
+    raug = OT.dummy_augment_gc(*(raw[k] for k in keys))
+    rcj = OT.conjugate(raug["node_ptr"], raug["edge_ptr"], raug["src"], raug["dst"], raug["node_label"],
+                       is_dummy_edge=raug["is_dummy_edge"], mode="gc")
+    for k in ("csrc", "cdst", "rep_edge", "shared_node"):
+        assert np.array_equal(cj[k].cpu().numpy(), rcj[k]), k
+    # conj-vertex features: one-hot of the edge label of the representative edge (dummy label 0 -> column 0);
+    # conj-edge relation: label of the shared vertex
+    v_lab = aug["edge_label"].long()[cj["rep_edge"].long()]
+    e_lab = aug["node_label"].long()[cj["shared_node"].long()]
+    Nc, R = int(v_lab.numel()), int(e_lab.max()) + 1
+    assert Nc == int((raug["is_dummy_edge"] == 0).sum()) + len(raug["node_ptr"]) - 1
+    x = F.one_hot(v_lab, 5).float()
+    x = torch.cat([x, torch.zeros(Nc, 64 - 5, device=DEV)], 1)
+    torch.manual_seed(4)
+    layer = RGINLayer(64, 64, num_rels=R, regularizer="basis", act_func="relu").to(DEV)
+    g = BatchedGraph(cj["csrc"], cj["cdst"], Nc, edata={"label": e_lab})
+    xd = x.clone().requires_grad_(True)
+    out, _ = layer(g, xd, e_lab)
+    out.sum().backward()
+    p = {k: v.detach().cpu() for k, v in layer.named_parameters()}
+    xr = x.cpu().clone().requires_grad_(True)
+    ref = OL.rgin_layer(xr, torch.from_numpy(rcj["csrc"]), torch.from_numpy(rcj["cdst"]), e_lab.cpu(), p,
+                        regularizer="basis", num_rels=R, num_bases=-1, act="relu")
+    ref.sum().backward()
+    assert float((out.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-4
+    assert float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-4
