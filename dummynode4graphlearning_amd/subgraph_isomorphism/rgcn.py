@@ -2,7 +2,9 @@
 
 Mirror of subgraph_isomorphism/models/rgcn.py:16-300 (constructor, parameter names, forward surface, the
 in/out-degree normalisation and its side effects on the graph object); message passing runs through
-ops.rel_agg_transform with the per-edge norm folded into the first gather.  GPU only.
+the row-factorised matrix-core pipeline (square H in {64,128,256}, fp32/bf16; the edge norm is separable into a
+per-source and a per-destination factor) or ops.rel_agg_transform with the per-edge norm folded into the first gather.
+GPU only.
 """
 import torch as th
 import torch.nn as nn
@@ -108,17 +110,33 @@ class RGCNLayer(nn.Module):
         g.ndata[NODEFEAT] = node_feat
         g.edata[EDGETYPE] = edge_type
         norm = self._norms(g)
-        index = g.rel_index(edge_type, self.num_rels)
         W = dense_relation_weights(self)
-        out = ops.rel_agg_transform(node_feat, W, index, edge_scale=None if norm is None else norm.view(-1))
-        if self.self_loop:
-            loop_msg = th.matmul(node_feat, self.loop_weight)
+        if ops.fused_path_supported(node_feat, W):
+            # the reference's edge norm is separable (rgcn.py:148-165): 'in' = in_norm[dst]; 'both' =
+            # sqrt(out_norm[src]) * sqrt(in_norm[dst]), and the self-loop message carries the same two factors at u = v
+            # (rgcn.py:174-179) -- so the whole layer is  s_in * rowpipeline(s_out * x, [W; W_loop])  on the matrix cores.
+            s_in = s_out = None
             if self.edge_norm == "in":
-                out = out + loop_msg * g.ndata[INNORM].to(loop_msg.dtype)                       # rgcn.py:174-175
+                s_in = g.ndata[INNORM]
             elif self.edge_norm == "both":
-                out = out + loop_msg * ((g.ndata[INNORM] * g.ndata[OUTNORM]) ** 0.5).to(loop_msg.dtype)
-            else:
-                out = out + loop_msg
+                s_in, s_out = g.ndata[INNORM].sqrt(), g.ndata[OUTNORM].sqrt()
+            xin = node_feat if s_out is None else node_feat * s_out.to(node_feat.dtype)
+            index = g.row_index(edge_type, self.num_rels, self.self_loop)
+            W_all = th.cat([W, self.loop_weight.unsqueeze(0)], 0) if self.self_loop else W
+            out = ops.rel_transform_fused(xin, W_all, None, index)
+            if s_in is not None:
+                out = out * s_in.to(out.dtype)
+        else:
+            index = g.rel_index(edge_type, self.num_rels)
+            out = ops.rel_agg_transform(node_feat, W, index, edge_scale=None if norm is None else norm.view(-1))
+            if self.self_loop:
+                loop_msg = th.matmul(node_feat, self.loop_weight)
+                if self.edge_norm == "in":
+                    out = out + loop_msg * g.ndata[INNORM].to(loop_msg.dtype)                       # rgcn.py:174-175
+                elif self.edge_norm == "both":
+                    out = out + loop_msg * ((g.ndata[INNORM] * g.ndata[OUTNORM]) ** 0.5).to(loop_msg.dtype)
+                else:
+                    out = out + loop_msg
         if self.bias is not None:
             out = out + self.bias
         if self.bn is not None:

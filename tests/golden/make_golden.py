@@ -271,6 +271,14 @@ def make_si_layers():
         meta.append(dict(tag=tag, kind="rgin", input_dim=64, seed=1000 + cid, N=500, E=2000, **kw))
         run(tag, rgin.RGINLayer, dict(kw), 500, 2000, 64, 1000 + cid)
         cid += 1
+    # RGCN at a matrix-core width (H=64): every edge-norm mode the fused path factorises into per-node scales
+    for norm, self_loop in (("in", True), ("both", True), ("both", False), ("none", True)):
+        tag = "rgcn%02d" % cid
+        kw = dict(hidden_dim=64, num_rels=8, regularizer="basis", num_bases=-1, edge_norm=norm,
+                  self_loop=self_loop, act_func="relu")
+        meta.append(dict(tag=tag, kind="rgcn", input_dim=64, seed=1000 + cid, N=500, E=2000, **kw))
+        run(tag, rgcn.RGCNLayer, dict(kw), 500, 2000, 64, 1000 + cid)
+        cid += 1
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "si_layers.npz"), **out)
     print("si_layers.npz: %d cases" % len(meta))

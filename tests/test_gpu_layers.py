@@ -327,12 +327,14 @@ def test_split_and_batchify_graph_feats(pre_pad, dtype):
     ("rgin", dict(act_func="leaky_relu", num_mlp_layers=2, self_loop=True)),     # fused conv, generic (non-ReLU) MLP path
     ("rgin", dict(act_func="relu", num_mlp_layers=0, self_loop=False)),           # no self loop: bias added outside the kernel
     ("rgin", dict(act_func="relu", num_mlp_layers=2, self_loop=True, regularizer="bdd", num_bases=4)),
-    ("rgcn", dict(act_func="relu", edge_norm="in", self_loop=True)),              # scaled messages: two-pass path in bf16
+    ("rgcn", dict(act_func="relu", edge_norm="in", self_loop=True)),              # per-destination norm around the fused pipeline
+    ("rgcn", dict(act_func="relu", edge_norm="both", self_loop=True)),            # separable sqrt(out_norm[src]) sqrt(in_norm[dst])
+    ("rgcn", dict(act_func="relu", edge_norm="both", self_loop=False)),           # zero-degree nodes masked to 0
     ("rgcn", dict(act_func="tanh", edge_norm="none", self_loop=False)),
 ])
 def test_bf16_layer_variants_match_fp64_on_same_operands(kind, kw):
     """Every bf16 code path of the SI layers (fused row factorisation with / without self loop, generic MLP, block-diagonal
-    weights, RGCN with edge norm on the two-pass path) against the oracle in fp64 on the same bf16-rounded parameters."""
+    weights, RGCN with its separable edge norms around the same pipeline) against the oracle in fp64 on the same bf16-rounded parameters."""
     from dummynode4graphlearning_amd import BatchedGraph, synthetic
     from dummynode4graphlearning_amd.subgraph_isomorphism import RGCNLayer, RGINLayer
     raw = synthetic.config3(seed=21, graphs=16)
