@@ -621,34 +621,6 @@ class RowIndex:
         # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
         self.chunk_table = make_row_chunks(rel_ptr, dev, chunk_rows=max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)))
 
-    @staticmethod
-    def _ptr(ids, n, dev):
-        cnt = torch.bincount(ids, minlength=n) if ids.numel() else torch.zeros(n, dtype=torch.long, device=dev)
-        return torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt, 0)]).to(I32)
-
-
-COLSUM_CHUNK = 128
-
-
-def colsum_levels(n, dev):
-    """Segment pointers for a tree column sum: level i sums COLSUM_CHUNK-row chunks of level i-1."""
-    levels = []
-    while n > COLSUM_CHUNK:
-        p = torch.arange(0, n + COLSUM_CHUNK, COLSUM_CHUNK, device=dev).clamp(max=n).to(I32)
-        p = p[: (n + COLSUM_CHUNK - 1) // COLSUM_CHUNK + 1].contiguous()
-        levels.append(p)
-        n = p.numel() - 1
-    return levels
-
-
-def column_sum(g, levels):
-    """Sum over the rows of a tall matrix (bias gradient): a short tree of contiguous segment sums on the HIP kernel
-    (fixed order: deterministic), finished by a <=128-row sum."""
-    cur = g
-    for p in levels:
-        cur = gather_segsum(cur if cur.dtype == torch.float32 else cur, None, p)
-    return cur.float().sum(0)
-
 
 class RowIndexSet:
     """Row factorisations of CONTIGUOUS GRAPH RANGES of one batch ("sub-batches"), each small enough that its x rows,
@@ -782,7 +754,7 @@ def _dense_table(n_rows, dev):
     key = (int(n_rows), str(dev))
     t = _dense_tables.get(key)
     if t is None:
-        t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev), colsum_levels(int(n_rows), dev))
+        t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev))
         if len(_dense_tables) > 8:
             _dense_tables.clear()
         _dense_tables[key] = t
@@ -796,7 +768,7 @@ class _LinearActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x = x.contiguous()
-        tiles, _, _ = _dense_table(x.shape[0], x.device)
+        tiles, _ = _dense_table(x.shape[0], x.device)
         y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
                            bias=None if bias is None else bias.contiguous().view(1, -1), relu=relu)
         ctx.relu, ctx.has_bias = bool(relu), bias is not None
@@ -807,17 +779,23 @@ class _LinearActFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.relu:
-            g = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))     # ReLU backward mask
-        tiles, chunks, levels = _dense_table(x.shape[0], x.device)
+        tiles, chunks = _dense_table(x.shape[0], x.device)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = rows_transform(g, weight.t().contiguous().unsqueeze(0), tiles, x.shape[0])  # g @ weight
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, cs = rows_wgrad(g, x, chunks, 1, out_dtype=weight.dtype, colsum_of=1)        # g^T x -> [out, in]; colsum(g)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if ctx.relu and not need_w:
+            g = relu_bwd(g, y)
+        if need_w:
+            # g^T x -> [out, in] and colsum(g); the ReLU mask is applied while the rows are staged and the masked rows are
+            # written out for the input-gradient launch (no separate elementwise pass)
+            gm = torch.empty_like(g) if ctx.relu else None
+            gw, cs = rows_wgrad(g, x, chunks, 1, out_dtype=weight.dtype, colsum_of=1, mask_a=y if ctx.relu else None,
+                                a_out=gm)
+            g = gm if ctx.relu else g
             gw = gw[0]
             if ctx.has_bias:
                 gb = cs[0].to(g.dtype)
+        if ctx.needs_input_grad[0]:
+            gx = rows_transform(g, weight.t().contiguous().unsqueeze(0), tiles, x.shape[0])  # g @ weight
         return gx, gw, gb, None
 
 
@@ -839,7 +817,7 @@ class _ReluMlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *wb):
         n = len(wb) // 2
-        tiles, _, _ = _dense_table(x.shape[0], x.device)
+        tiles, _ = _dense_table(x.shape[0], x.device)
         acts = [x.contiguous()]
         for i in range(n):
             w, b = wb[2 * i], wb[2 * i + 1]
@@ -855,7 +833,7 @@ class _ReluMlpFn(torch.autograd.Function):
         n = ctx.n
         saved = ctx.saved_tensors
         acts, ws = saved[:n + 1], saved[n + 1:]
-        tiles, chunks, _ = _dense_table(acts[0].shape[0], acts[0].device)
+        tiles, chunks = _dense_table(acts[0].shape[0], acts[0].device)
         g = gout.contiguous()
         grads = [None] * (1 + 2 * n)
         for i in range(n - 1, -1, -1):
