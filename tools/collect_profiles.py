@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Collect the round's rocprofv3 evidence on the GPU box and write the summaries bench.py / DESIGN.md cite.
+
+    python tools/collect_profiles.py --tag r01 [--out gpurun_out/profiles]
+
+Runs (each as a child process, the profiled program directly after `--`):
+  1. python bench.py                                             -> <tag>_bench_line.json
+  2. rocprofv3 --kernel-trace --stats        -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+                                                                 -> <tag>_kernel_stats.csv
+  3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph
+  4. rocprofv3 --kernel-trace --pmc WRITE_SIZE  -- (same)       -> <tag>_hbm_traffic_per_launch.csv, <tag>_traffic.json
+  5. rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- (same)
+                                                                 -> <tag>_lds_bank_conflicts.csv
+PMC passes never share a run with --stats or any API trace (pool rule).  gfx950 correction (MI355X_MICROARCH.md, HBM
+section): FETCH_SIZE (KB) counts half of a wide coalesced read, so hbm_read = 2 * FETCH_SIZE; WRITE_SIZE is exact.
+Copy the files from the output directory into profiles/ and commit them.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# launches of ONE eager step of bench.py's config-5 workload, in order (kernel-name fragment, role)
+STEP = [
+    ("gather_segsum_vec_kernel", "aux pre-aggregation (fwd)"),
+    ("rows_transform_kernel", "conv transform fwd (gathers x rows)"),
+    ("gather_segsum_vec_kernel", "conv final per-dst sum (fwd)"),
+    ("rows_transform_kernel", "MLP linear 1 fwd (+bias+ReLU)"),
+    ("rows_transform_kernel", "MLP linear 2 fwd (+bias+ReLU)"),
+    ("rows_wgrad_kernel", "MLP wgrad 2 (+outer ReLU mask, saves masked g)"),
+    ("wgrad_reduce_kernel", "wgrad reduce"),
+    ("rows_transform_kernel", "MLP dgrad 2 (+ReLU mask epilogue)"),
+    ("rows_wgrad_kernel", "MLP wgrad 1"),
+    ("wgrad_reduce_kernel", "wgrad reduce"),
+    ("rows_transform_kernel", "MLP dgrad 1"),
+    ("gather_segsum_vec_kernel", "aux pre-aggregation (bwd)"),
+    ("rows_transform_kernel", "conv transform bwd (gathers g rows)"),
+    ("gather_segsum_vec_kernel", "conv final per-src sum (bwd)"),
+    ("rows_wgrad_kernel", "conv wgrad (gathers x and g rows, + bias colsum)"),
+    ("wgrad_reduce_kernel", "wgrad reduce"),
+]
+CONV_ROWS = (0, 1, 2, 11, 12, 13)
+OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
+
+
+def short(name):
+    for k in OURS:
+        if k in name:
+            return k
+    return None
+
+
+def run(cmd, cwd=ROOT):
+    print("+", " ".join(cmd), flush=True)
+    return subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def one_csv(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit("no %s under %s" % (suffix, d))
+    return hits[-1]
+
+
+def counter_rows(path):
+    """dispatch-ordered list of (kernel, {counter: value}, start_ns, end_ns)."""
+    by = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            did = int(r["Dispatch_Id"])
+            e = by.setdefault(did, [r["Kernel_Name"], {}, int(r.get("Start_Timestamp", 0) or 0), int(r.get("End_Timestamp", 0) or 0)])
+            e[1][r["Counter_Name"]] = e[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [tuple(by[k]) for k in sorted(by)]
+
+
+def last_step(rows):
+    """index of the last full STEP pattern among our kernels (bf16 gather kernels only: the GIN leg is fp32)."""
+    ours = [(i, short(r[0])) for i, r in enumerate(rows) if short(r[0]) and not ("gather_segsum" in r[0] and "float" in r[0])]
+    names = [n for _, n in ours]
+    want = [n for n, _ in STEP]
+    for s in range(len(names) - len(want), -1, -1):
+        if names[s:s + len(want)] == want:
+            return [ours[s + j][0] for j in range(len(want))]
+    raise SystemExit("step pattern not found in the trace")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", default="r01")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "profiles"))
+    ap.add_argument("--skip-lds", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    tmp = os.path.join("/tmp", "dn_prof_" + a.tag)
+    os.makedirs(tmp, exist_ok=True)
+    env_note = "cd /tmp && export TMPDIR=/tmp"
+    os.environ["TMPDIR"] = "/tmp"
+    bench = os.path.join(ROOT, "bench.py")
+    eager = ["python3", bench, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-graph"]
+
+    # 2. kernel stats of the default (graph replay) run
+    d = os.path.join(tmp, "stats")
+    r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "k", "--",
+             "python3", bench, "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], cwd="/tmp")
+    stats = one_csv(d, "kernel_stats.csv")
+    with open(stats) as f:
+        body = f.read()
+    with open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w") as f:
+        f.write("# %s -- rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline\n" % a.tag)
+        f.write("# (%s first) bench line of that run: %s\n" % (env_note, r.stdout.strip().splitlines()[-1][:400] if r.stdout.strip() else "n/a"))
+        f.write(body)
+
+    # 3./4. HBM traffic per launch
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, ctr)
+        run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + eager, cwd="/tmp")
+        rows = counter_rows(one_csv(d, "counter_collection.csv"))
+        idx = last_step(rows)
+        vals[ctr] = [(rows[i][1][ctr], (rows[i][3] - rows[i][2]) / 1e3) for i in idx]
+    lines, tot, conv = [], 0.0, 0.0
+    for j, (kname, role) in enumerate(STEP):
+        rd = 2.0 * vals["FETCH_SIZE"][j][0] * 1024 / 1e6          # KB -> MB, gfx950 half-count correction
+        wr = vals["WRITE_SIZE"][j][0] * 1024 / 1e6
+        us = 0.5 * (vals["FETCH_SIZE"][j][1] + vals["WRITE_SIZE"][j][1])
+        lines.append("%s,%s,%.1f,%.1f,%.1f,%.1f,%.2f" % (kname, role, rd, wr, rd + wr, us, (rd + wr) / us if us else 0.0))
+        tot += rd + wr
+        if j in CONV_ROWS:
+            conv += rd + wr
+    N, E, H = 1015808, 3997696, 256
+    alg = 2 * (E * H * 2 + N * H * 2 + 8 * E)
+    with open(os.path.join(a.out, a.tag + "_hbm_traffic_per_launch.csv"), "w") as f:
+        f.write("# %s -- HBM traffic per launch of one eager step (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)\n" % a.tag)
+        f.write("# command: rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph\n")
+        f.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE KB (a wide coalesced read is half-counted); WRITE_SIZE exact. durations under PMC collection (us)\n")
+        f.write("kernel,role,hbm_read_MB,hbm_write_MB,hbm_total_MB,duration_us,TB_per_s\n")
+        f.write("\n".join(lines) + "\n")
+        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-3 and 12-14): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
+                % (tot, conv, alg / 1e6, conv * 1e6 / alg))
+    with open(os.path.join(a.out, a.tag + "_traffic.json"), "w") as f:
+        json.dump({"workload": "config5", "N": N, "E": E, "H": H, "dtype": "bf16",
+                   "conv_gather_scatter_hbm_bytes_per_step": conv * 1e6, "step_hbm_bytes": tot * 1e6,
+                   "source": "profiles/%s_hbm_traffic_per_launch.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md)" % a.tag},
+                  f, indent=1)
+
+    # 5. LDS bank conflicts
+    if not a.skip_lds:
+        d = os.path.join(tmp, "lds")
+        run(["rocprofv3", "--kernel-trace", "--pmc", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "--output-format", "csv",
+             "-d", d, "-o", "p", "--"] + eager, cwd="/tmp")
+        agg = {}
+        for kname, ctrs, _, _ in counter_rows(one_csv(d, "counter_collection.csv")):
+            k = short(kname)
+            if k:
+                e = agg.setdefault(k, [0.0, 0.0])
+                e[0] += ctrs.get("SQ_LDS_BANK_CONFLICT", 0.0)
+                e[1] += ctrs.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        with open(os.path.join(a.out, a.tag + "_lds_bank_conflicts.csv"), "w") as f:
+            f.write("# %s -- LDS bank conflicts (rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE), summed over all launches of the eager run\n" % a.tag)
+            f.write("kernel,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,conflict_fraction\n")
+            for k in sorted(agg):
+                c, act = agg[k]
+                f.write("%s,%d,%d,%.3f\n" % (k, c, act, c / act if act else 0.0))
+
+    # 1. the bench line itself, last so that it reads the fresh traffic.json when --out is profiles/
+    r = run(["python3", bench])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        sys.stderr.write(r.stderr[-2000:])
+        raise SystemExit("bench.py printed no JSON line")
+    with open(os.path.join(a.out, a.tag + "_bench_line.json"), "w") as f:
+        f.write(line[-1] + "\n")
+    print(line[-1][:600])
+
+
+if __name__ == "__main__":
+    main()
