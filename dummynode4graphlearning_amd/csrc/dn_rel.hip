@@ -211,6 +211,222 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 }
 
 // -------------------------------------------------------------------------------------------------
+// rows_wgrad_dma_kernel: the same product with the operand rows sent global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no staging VGPRs) into a ring of 32-row stages, NST-1 stages in flight while one is
+// multiplied.  The register-staged kernel above keeps 128 accumulator VGPRs + one 64-row tile in registers and is
+// latency-bound (<= 64 KB in flight per CU, rocprof: 3.9 TB/s of reads); the ring keeps 96 KB (H = 256) in flight.
+//   * an LDS-DMA wave-instruction writes 1 KiB lane-linearly (2 rows of 512 B): the image is unpadded, and the
+//     bank spread the transposed fragment reads need comes from an XOR swizzle of the 32-byte column slots applied
+//     to the per-lane SOURCE address (cdna_hip_programming.md 5.4 rule 21) and again on the read side:
+//         LDS row r, slot s  holds  global slot  s ^ f(r),   f(r) = (r & 3) | ((r >> 3) & 1) << 2
+//     (ds_read_b64_tr_b16 serves lanes 0-31 / 32-63 per cycle = rows {8g+q : g in {0,1} or {2,3}, q < 4}: the 8 values
+//     of f put their 32-byte reads on 8 distinct slots of the 256-byte bank row -> conflict-free)
+//   * row indices come through scalar loads (wave-uniform: a wave stages 4 consecutive rows of each operand per
+//     tile), so no VGPR-destination global load shares the vmcnt queue with the DMAs; the wait is a counted
+//     s_waitcnt vmcnt(GL * (NST - 2)) followed by ONE raw s_barrier per tile (never __syncthreads(): its fence would
+//     drain the ring).  Rows past the end of the chunk read a zero row, tiles past the end are issued as zero tiles so
+//     the count stays static; the ring is drained (vmcnt(0)) before the LDS is reused or the workgroup ends.
+//   * used when no ReLU mask is folded in (maskA == NULL); H in {128, 256}.
+// -------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_zero_row[64];        // 1 KiB of zeros (device globals are zero-initialised)
+
+// LDS-DMA issued from inline asm (cdna_hip_programming.md, inline-asm section: M0 written in the statement that reads
+// it): hipcc's s_waitcnt pass treats a builtin LDS-DMA as a pending LDS write and drains vmcnt(0) before EVERY later
+// ds_read, which would empty the ring each tile; an asm DMA is outside its bookkeeping and is counted by hand below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int H>
+__global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t* __restrict__ A,
+                                                                    const bf16_t* __restrict__ A2, int32_t na1,
+                                                                    const int32_t* __restrict__ ia,
+                                                                    const bf16_t* __restrict__ G,
+                                                                    const bf16_t* __restrict__ G2, int32_t ng1,
+                                                                    const int32_t* __restrict__ ig,
+                                                                    const Chunk* __restrict__ chunks,
+                                                                    float* __restrict__ partial, int32_t colsum_of,
+                                                                    float* __restrict__ colsum_partial) {
+    static_assert(H == 256 || H == 128, "unsupported width");
+    constexpr int TR = 32;                         // rows per stage (one MFMA K-step)
+    constexpr int NST = (H == 256) ? 4 : 8;        // ring stages (128 KiB)
+    constexpr int ROWB = 2 * H;                    // bytes per row
+    constexpr int MATB = TR * ROWB;                // bytes per operand per stage
+    constexpr int STB = 2 * MATB;
+    constexpr int LPRW = H / 8;                    // lanes (16-byte pieces) per row
+    constexpr int RPI = 64 / LPRW;                 // rows per DMA wave-instruction (2 or 4)
+    constexpr int PPW = 4 / RPI;                   // DMA instructions per wave, operand and tile (each wave stages 4 rows)
+    constexpr int GL = 2 * PPW;                    // DMA instructions per wave and tile
+    constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
+    __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    const Chunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = (ch.end - ch.beg + TR - 1) / TR;
+    const char* zero = reinterpret_cast<const char*>(g_zero_row);
+
+    // ---- DMA side: this lane's place in a piece ---------------------------------------------------------------
+    const int rin = lane / LPRW, cpos = lane % LPRW;
+    int32_t nxa[4], nxg[4];                        // wave-uniform source rows of the next tile to issue
+    auto load_idx = [&](int T) {                   // scalar loads (wave-uniform addresses), branch-free
+        const int p0 = ch.beg + T * TR + 4 * wave, pe = ch.end - 1;
+        int32_t pc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pc[k] = min(p0 + k, pe);
+        if (ia) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxa[k] = ia[pc[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxa[k] = pc[k];
+        }
+        if (ig) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxg[k] = ig[pc[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxg[k] = pc[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = p0 + k <= pe;          // rows past the chunk end (and whole tiles past it) read the zero row
+            nxa[k] = ok ? nxa[k] : -1;
+            nxg[k] = ok ? nxg[k] : -1;
+        }
+    };
+    auto issue = [&](int T) {
+        const unsigned st = lds_base + (unsigned)(T % NST) * STB;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int rl = 4 * wave + RPI * j + rin;                       // row of the stage this lane fills
+            const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
+            const int gch = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;     // source byte offset inside the row
+            int32_t ra = nxa[RPI * j], rg = nxg[RPI * j];
+#pragma unroll
+            for (int k = 1; k < RPI; ++k) {
+                ra = (rin == k) ? nxa[RPI * j + k] : ra;
+                rg = (rin == k) ? nxg[RPI * j + k] : rg;
+            }
+            const char* pa = ra < 0 ? zero : (ra < na1 ? reinterpret_cast<const char*>(A) + (size_t)ra * ROWB
+                                                       : reinterpret_cast<const char*>(A2) + (size_t)(ra - na1) * ROWB);
+            const char* pg = rg < 0 ? zero : (rg < ng1 ? reinterpret_cast<const char*>(G) + (size_t)rg * ROWB
+                                                       : reinterpret_cast<const char*>(G2) + (size_t)(rg - ng1) * ROWB);
+            const unsigned da = st + (unsigned)(4 * wave + RPI * j) * ROWB; // wave-uniform; lane l lands at + 16 l
+            glds16(pa + gch, da);
+            glds16(pg + gch, da + MATB);
+        }
+    };
+
+    // ---- MFMA side ----------------------------------------------------------------------------------------
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int fsw = fq | ((fg & 1) << 2);                                  // f(r) of the rows this lane reads
+    const int frow = (8 * fg + fq) * ROWB + 8 * fp;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    auto frag = [&](const char* mat, int slot) -> bf16x8 {
+        const char* a0 = mat + frow + ((slot ^ fsw) << 5);
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * ROWB));
+        const short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int CPT = TR * LPRW / kWgThreads;                            // column-sum pieces per thread and tile (2 or 1)
+    const int cchunk = tid % LPRW, crow = tid / LPRW;
+
+    // ---- prologue: NST-1 tiles in flight (chunk tables never hold empty chunks; guard anyway: pe must be a valid row) ----
+    if (ntiles <= 0) {
+        for (int i = tid; i < H * H; i += kWgThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
+        if (colsum_of != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
+        return;
+    }
+    load_idx(0);
+#pragma unroll 1
+    for (int T = 0; T < NST - 1; ++T) {
+        issue(T);
+        load_idx(T + 1);
+    }
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        wait_vmcnt<GL*(NST - 2)>();                                        // my pieces of tile t have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my fragment reads of tile t-1 are done
+        __builtin_amdgcn_s_barrier();                                      // everyone's have / are
+        issue(t + NST - 1);                                                // refill the stage tile t-1 used
+        load_idx(t + NST);
+        const char* sA = lds + (t % NST) * STB;
+        const char* sG = sA + MATB;
+        bf16x8 fb[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = frag(sG, wn * NT + n);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf16x8 fa = frag(sA, wm * MT + m);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+        }
+        if (colsum_of != 0) {
+            const char* M = colsum_of == 1 ? sA : sG;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int r = crow + j * (kWgThreads / LPRW);
+                const int f = (r & 3) | (((r >> 3) & 1) << 2);
+                const int pos = (((cchunk >> 1) ^ f) << 1) | (cchunk & 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(M + r * ROWB + pos * 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cs[2 * i] += __uint_as_float(w[i] << 16);
+                    cs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();                                                       // drain the zero tiles still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float* out = partial + (size_t)blockIdx.x * H * H;
+    const int k0 = wm * (H / 2), n0 = wn * (H / 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
+                out[(size_t)k * H + c] = acc[m][n][i];
+            }
+    if (colsum_of != 0) {
+        constexpr int TPC = kWgThreads / LPRW;                             // threads per column chunk
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[crow * H + cchunk * 8 + i] = cs[i];
+        __syncthreads();
+        if (tid < H) {
+            float sum = 0.f;
+            for (int sl = 0; sl < TPC; ++sl) sum += red[sl * H + tid];
+            colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // dn_rows_transform_bf16:   Y[p, :] = epi( X[idx[p], :] @ Wn[rel(p)]^T )          (rows p relation-major)
 //   Wn[r] is [HO][HI] (k contiguous), i.e. Y[p][n] = sum_k X[idx[p]][k] * Wn[r][n][k].
 //   One workgroup (4 waves) walks a contiguous range of 32-row tiles (tile table: {rel, beg, end}); each wave
@@ -469,10 +685,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+bool wgrad_dma_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DN_WGRAD_DMA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
                  float* cs_partial, const bf16_t* maskA, bf16_t* A_out, hipStream_t st) {
+    if constexpr (HI == HO && (HI == 256 || HI == 128)) {
+        if (maskA == nullptr && A_out == nullptr && wgrad_dma_enabled()) {
+            hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia,
+                               G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial);
+            DN_CHECK_LAUNCH();
+            return DN_OK;
+        }
+    }
     hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia, G, G2,
                        ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out);
     DN_CHECK_LAUNCH();
