@@ -201,12 +201,13 @@ class GraphBatch:
                 dn.append(d.is_dummy_node)
             if d.is_dummy_edge is not None:
                 de.append(d.is_dummy_edge)
-            bs.append(torch.full((n,), i, dtype=torch.long))
+            bs.append(torch.full((n,), i, dtype=torch.long, device=d.x.device))
             off += n
             ptr.append(off)
         cat = lambda l, dim=0: torch.cat(l, dim) if l else None  # noqa: E731
+        dev = xs[0].device if xs else None
         return GraphBatch(cat(xs), cat(eis, 1), cat(bs), cat(eas), cat(ys), cat(dn), cat(de),
-                          torch.tensor(ptr, dtype=torch.long))
+                          torch.tensor(ptr, dtype=torch.long, device=dev))
 
 
 def graph_ptr_i32(data):

@@ -9,6 +9,8 @@ The reference's Python is imported unmodified, with the absent third-party modul
   gc_transforms.json   a-1 load_graph_data_from_TUDatadir(with_dummy) + a-2
                        convert_conjugate_graph_forward  (tu_data_processing.py:125-338)
                        incl. KAT-1 = the paper's figure/edge2vertex.png example
+  tu_files.json        f-3 the DUMMY_/LINE_/CONJ_ dataset files written by save_graph_data /
+                       save_graph_labels (tu_data_processing.py:341-414) for three toy TU datasets
   si_transforms.json   a-4 add_dummy_nodes_edges (SI train.py:404-474) + a-5
                        convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
@@ -114,6 +116,51 @@ def make_gc():
     with open(os.path.join(HERE, "gc_transforms.json"), "w") as f:
         json.dump(cases, f, separators=(",", ":"))
     print("gc_transforms.json: %d cases" % len(cases))
+
+
+def make_tu_files():
+    """f-3: the on-disk DUMMY_/LINE_/CONJ_ datasets exactly as the reference writes them: raw TU text files in, the
+    files of save_graph_data / save_graph_labels (tu_data_processing.py:341-414) out, both kept verbatim."""
+    sys.path.insert(0, os.path.join(REF, "graph_classification", "data_processing"))
+    T = importlib.import_module("tu_data_processing")
+    out = []
+    for name, seed, nl_min, el_mode, with_attr in (("TOYA", 7, 0, "zero", False), ("TOYB", 8, 2, "none", True),
+                                                   ("TOYC", 9, 1, "three", True)):
+        rng = np.random.default_rng(300 + seed)
+        while True:
+            A, gi, nl, el = _random_tu(rng, 6, nl_min=nl_min, el_mode=el_mode, max_n=7)
+            if len(A) > len(gi):          # the reference indexes edge_attributes[pre_n] (node offset) at :197
+                break
+        ys = [int(x) for x in rng.integers(0, 2, size=6) * 2 - 1]            # graph labels in {-1, 1}
+        with tempfile.TemporaryDirectory() as root:
+            raw = os.path.join(root, name, "raw")
+            os.makedirs(raw)
+            _write_tu(raw, name, A, gi, nl, el)
+            if with_attr:
+                with open(os.path.join(raw, name + "_node_attributes.txt"), "w") as f:
+                    f.writelines("%s\n" % repr(round(float(x), 3)) for x in rng.standard_normal(len(gi)))
+                with open(os.path.join(raw, name + "_edge_attributes.txt"), "w") as f:
+                    f.writelines("%s\n" % repr(round(float(x), 3)) for x in rng.standard_normal(len(A)))
+            with open(os.path.join(raw, name + "_graph_labels.txt"), "w") as f:
+                f.writelines("%d\n" % y for y in ys)
+            inputs = {fn: open(os.path.join(raw, fn)).read() for fn in sorted(os.listdir(raw))}
+            labels = T.load_graph_labels_from_TUDatadir(raw)
+            plain = T.load_graph_data_from_TUDatadir(raw, with_dummy=False)
+            dummy = T.load_graph_data_from_TUDatadir(raw, with_dummy=True)
+            sets = {"DUMMY_": dummy, "LINE_": [T.convert_conjugate_graph_forward(g) for g in plain],
+                    "CONJ_": [T.convert_conjugate_graph_forward(g) for g in dummy]}
+            files = {}
+            for pre, graphs in sets.items():
+                d = raw.replace(name, pre + name)                            # tu_data_processing.py:440-442
+                os.makedirs(d)
+                T.save_graph_data(graphs, d)
+                T.save_graph_labels(labels, d)
+                for fn in sorted(os.listdir(d)):
+                    files[pre + name + "/raw/" + fn] = open(os.path.join(d, fn)).read()
+        out.append({"name": name, "inputs": inputs, "outputs": files})
+    with open(os.path.join(HERE, "tu_files.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("tu_files.json: %d datasets, %d output files" % (len(out), sum(len(o["outputs"]) for o in out)))
 
 
 # ------------------------------------------------------------------------------- SI
@@ -286,5 +333,6 @@ def make_si_layers():
 
 if __name__ == "__main__":
     make_gc()
+    make_tu_files()
     make_si_transforms()
     make_si_layers()

@@ -246,3 +246,87 @@ def test_full_size_proteins_shaped_gc_pipeline():
     nreal = int((ref["is_dummy_edge"] == 0).sum())
     ngraphs_with_dummy = int((np.diff(ref["node_ptr"]) > 1).sum())
     assert gcj["rep_edge"].numel() == nreal + ngraphs_with_dummy
+
+
+# ------------------------------------------------------------------------------------------------ f-3: TU files
+def _materialise_tu(tmp_path, case):
+    raw = os.path.join(str(tmp_path), case["name"], "raw")
+    os.makedirs(raw)
+    for fn, text in case["inputs"].items():
+        with open(os.path.join(raw, fn), "w") as f:
+            f.write(text)
+    return raw
+
+
+def test_process_dataset_writes_the_reference_files(golden_dir, tmp_path):
+    """raw TU text -> device batch -> HIP dummy augmentation / conjugate -> DUMMY_/LINE_/CONJ_ files, byte for byte the files
+    the reference's tu_data_processing.py wrote (tests/golden/tu_files.json)."""
+    from dummynode4graphlearning_amd import tu_io
+    with open(os.path.join(golden_dir, "tu_files.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        raw = _materialise_tu(tmp_path, case)
+        dirs = tu_io.process_dataset(raw, case["name"])
+        assert sorted(dirs) == ["CONJ_", "DUMMY_", "LINE_"]
+        for rel, text in case["outputs"].items():
+            with open(os.path.join(str(tmp_path), rel)) as f:
+                assert f.read() == text, rel
+
+
+def test_read_tu_data_and_dataset_match_the_oracle(golden_dir, tmp_path):
+    from dummynode4graphlearning_amd import tu_io
+    from oracle import tu_format as TF
+    with open(os.path.join(golden_dir, "tu_files.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        raw = _materialise_tu(tmp_path, case)
+        tu_io.process_dataset(raw, case["name"])
+        for pre in ("DUMMY_", "CONJ_", "LINE_", ""):
+            d = raw.replace(case["name"], pre + case["name"])
+            data, slices = tu_io.read_tu_data(d, pre + case["name"])
+            rdata, rslices = TF.read_tu_data(d, pre + case["name"])
+            for k in ("x", "edge_index", "edge_attr", "y"):
+                a, b = getattr(data, k), rdata[k]
+                assert (a is None) == (b is None), (pre, k)
+                if a is not None:
+                    assert np.array_equal(a.cpu().numpy(), b), (pre, k)
+            assert sorted(slices) == sorted(rslices)
+            for k in slices:
+                assert np.array_equal(slices[k].cpu().numpy(), rslices[k]), (pre, k)
+
+
+def test_pyg_dataset_mirror_feeds_the_models(tmp_path):
+    """PYGDataset over process_dataset output: dummy flags, label widths, and a GIN forward on a collated mini-batch."""
+    from types import SimpleNamespace
+    from dummynode4graphlearning_amd import graph_classification as GC, tu_io
+    from oracle import tu_format as TF
+    rng = np.random.default_rng(5)
+    name, G = "TOYS", 12
+    raw = os.path.join(str(tmp_path), name, "raw")
+    os.makedirs(raw)
+    A, gi, nl, base = [], [], [], 0
+    for g in range(G):
+        n = int(rng.integers(3, 9))
+        pairs = {(int(u), int(v)) for u, v in rng.integers(0, n, size=(3 * n, 2)) if u != v}
+        for u, v in sorted(pairs):
+            A.append((base + u + 1, base + v + 1))
+        gi += [g + 1] * n
+        nl += [int(x) for x in rng.integers(0, 3, size=n)]
+        base += n
+    nl[0] = 0
+    wr = lambda fn, rows: open(os.path.join(raw, name + "_" + fn + ".txt"), "w").write("".join(r + "\n" for r in rows))  # noqa: E731
+    wr("A", ["%d, %d" % e for e in A]); wr("graph_indicator", map(str, gi)); wr("node_labels", map(str, nl))
+    wr("graph_labels", [str(int(x)) for x in rng.integers(0, 2, size=G)])
+    tu_io.process_dataset(raw, name)
+    ds = tu_io.PYGDataset(str(tmp_path), name, add_dummy=True)
+    assert len(ds) == G and ds.num_node_labels == 4 and ds.num_edge_labels == 2 and ds.num_features == 4
+    b = TF.load_graph_data(TF.parse_tu_dir(raw), with_dummy=True)
+    assert np.array_equal(ds.data.is_dummy_node.cpu().numpy(), b["is_dummy_node"].astype(bool))
+    assert int(ds.data.is_dummy_edge.sum()) == int(b["is_dummy_edge"].sum())          # simple graphs: nothing coalesced away
+    batch = ds.batch(range(5))
+    assert batch.num_graphs == 5 and batch.x.is_cuda and batch.batch.is_cuda
+    args = SimpleNamespace(num_features=ds.num_features, hidden_dim=64, num_classes=ds.num_classes, dropout_ratio=0.0,
+                           additional={"num_layers": 2}, epochs=1, device=DEV, dummy_weight=0)
+    torch.manual_seed(0)
+    out = GC.GIN(args).to(DEV)(batch)
+    assert out.shape == (5, ds.num_classes) and bool(torch.isfinite(out).all())

@@ -278,3 +278,79 @@ def test_c_oracle_equals_python_oracle_and_goldens(golden_dir):
     cj = OC.conjugate(aug["node_ptr"], aug["edge_ptr"], aug["src"], aug["dst"], aug["node_label"],
                       is_dummy_edge=aug["is_dummy_edge"], mode="gc")
     assert list(zip(cj["csrc"], cj["cdst"])) == [(3, 0), (0, 1), (3, 1), (0, 2), (3, 2), (0, 3), (1, 3), (2, 3)]
+
+
+def _materialise(tmp_path, case):
+    raw = os.path.join(str(tmp_path), case["name"], "raw")
+    os.makedirs(raw)
+    for fn, text in case["inputs"].items():
+        with open(os.path.join(raw, fn), "w") as f:
+            f.write(text)
+    return raw
+
+
+def test_oracle_writes_the_reference_dataset_files(golden_dir, tmp_path):
+    """f-3: DUMMY_/LINE_/CONJ_ datasets, byte for byte the files the reference's save_graph_data / save_graph_labels wrote
+    (tests/golden/tu_files.json, produced by running tu_data_processing.py's own functions)."""
+    from oracle import tu_format as TF
+    with open(os.path.join(golden_dir, "tu_files.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 3
+    for case in cases:
+        raw = _materialise(tmp_path, case)
+        TF.process_dataset(raw, case["name"])
+        for rel, text in case["outputs"].items():
+            with open(os.path.join(str(tmp_path), rel)) as f:
+                assert f.read() == text, rel
+        produced = sorted(os.path.relpath(os.path.join(dp, fn), str(tmp_path))
+                          for dp, _, fns in os.walk(str(tmp_path)) for fn in fns if dp != raw)
+        assert [p for p in produced if "_" + case["name"] + "/" in p] == sorted(case["outputs"])
+
+
+def _without_multi_edges(case):
+    name = case["name"]
+    lines = case["inputs"][name + "_A.txt"].splitlines()
+    seen, keep = set(), []
+    for i, ln in enumerate(lines):
+        k = ln.replace(" ", "")
+        if k not in seen:
+            seen.add(k)
+            keep.append(i)
+    inputs = dict(case["inputs"])
+    for fn in (name + "_A.txt", name + "_edge_labels.txt", name + "_edge_attributes.txt"):
+        if fn in inputs:
+            rows = inputs[fn].splitlines()
+            inputs[fn] = "".join(rows[i] + "\n" for i in keep)
+    return {"name": name, "inputs": inputs}
+
+
+def test_oracle_read_tu_data_on_the_written_datasets(golden_dir, tmp_path):
+    """PyG 2.0.2 read_tu_data restated (oracle/tu_format.py header): structural properties on the reference-written
+    DUMMY_ files + the dummy flags of PYGDataset.set_dummy_flags agree with the IS_DUMMY the writer knew."""
+    from oracle import tu_format as TF
+    with open(os.path.join(golden_dir, "tu_files.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        case = _without_multi_edges(case)      # coalesce ADDS the one-hot rows of duplicates: PyG's label-width probe needs simple graphs
+        raw = _materialise(tmp_path, case)
+        TF.process_dataset(raw, case["name"])
+        d = raw.replace(case["name"], "DUMMY_" + case["name"])
+        data, slices = TF.read_tu_data(d, "DUMMY_" + case["name"])
+        ei = data["edge_index"]
+        G = len(slices["x"]) - 1
+        assert slices["edge_index"][-1] == ei.shape[1] and len(data["y"]) >= G
+        for g in range(G):
+            e0, e1 = slices["edge_index"][g], slices["edge_index"][g + 1]
+            n = slices["x"][g + 1] - slices["x"][g]
+            sub = ei[:, e0:e1]
+            assert sub.size == 0 or (sub.min() >= 0 and sub.max() < n)
+            assert np.all(sub[0] != sub[1])                                   # self loops removed
+            key = sub[0] * n + sub[1]
+            assert np.all(np.diff(key) > 0)                                   # sorted and duplicate-free
+        is_dn, is_de = TF.set_dummy_flags(data, add_dummy=True)
+        b = TF.load_graph_data(TF.parse_tu_dir(raw), with_dummy=True)
+        assert np.array_equal(is_dn, b["is_dummy_node"].astype(bool))
+        # every kept edge that touches the dummy vertex is flagged, no other
+        node_off = slices["x"][np.searchsorted(slices["edge_index"], np.arange(ei.shape[1]), side="right") - 1]
+        touches = is_dn[ei[0] + node_off] | is_dn[ei[1] + node_off]
+        assert np.array_equal(is_de, touches)
