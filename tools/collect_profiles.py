@@ -35,17 +35,18 @@ STEP = [
     ("rows_wgrad_kernel", "MLP wgrad 2 (+outer ReLU mask, saves masked g)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_kernel", "MLP dgrad 2 (+ReLU mask epilogue)"),
-    ("rows_wgrad_kernel", "MLP wgrad 1"),
+    ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_kernel", "MLP dgrad 1"),
     ("gather_segsum_vec_kernel", "aux pre-aggregation (bwd)"),
     ("rows_transform_kernel", "conv transform bwd (gathers g rows)"),
     ("gather_segsum_vec_kernel", "conv final per-src sum (bwd)"),
-    ("rows_wgrad_kernel", "conv wgrad (gathers x and g rows, + bias colsum)"),
+    ("rows_wgrad_dma_kernel", "conv wgrad (LDS-DMA ring; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
 CONV_ROWS = (0, 1, 2, 11, 12, 13)
-OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
+OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
+        "wgrad_reduce_kernel")
 
 
 def short(name):
