@@ -1,2 +1,3 @@
 from .rgcn import RGCNLayer, RGCNRepNet  # noqa: F401
 from .rgin import RGINLayer, RGINRepNet  # noqa: F401
+from . import bookkeeping  # noqa: F401

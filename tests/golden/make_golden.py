@@ -13,6 +13,8 @@ The reference's Python is imported unmodified, with the absent third-party modul
                        save_graph_labels (tu_data_processing.py:341-414) for three toy TU datasets
   si_transforms.json   a-4 add_dummy_nodes_edges (SI train.py:404-474) + a-5
                        convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
+  si_bookkeeping.json  f-2 get_conjugate_subisomorphisms, compute_{nodeseq,edgeseq}_subisoweights, compute_norm,
+                       compute_largest_eigenvalues, add_reversed_edges
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
                        all gradients over the regulariser x act x self_loop x edge_norm grid
 
@@ -254,6 +256,79 @@ def make_si_transforms():
     print("si_transforms.json: %d items" % len(items))
 
 
+def make_si_bookkeeping():
+    """f-2: the integer bookkeeping either side of L_Phi, produced by the reference's own functions (numba.jit replaced
+    by the identity): get_conjugate_subisomorphisms (utils/graph.py:291-330), compute_{nodeseq,edgeseq}_subisoweights
+    (dataset.py:54-108), compute_norm / compute_largest_eigenvalues (utils/graph.py:11-71), add_reversed_edges
+    (train.py:291-345, GraphAdj branch)."""
+    _si_modules()
+    T = importlib.import_module("train")
+    D = importlib.import_module("dataset")
+    ug = importlib.import_module("utils.graph")
+    rng = np.random.default_rng(23)
+    cases = []
+    for cid in range(10):
+        pn, gn = int(rng.integers(2, 5)), int(rng.integers(4, 11))
+        pm, gm = int(rng.integers(1, 9)), int(rng.integers(6, 40))
+        nel = int(rng.integers(1, 4))
+        # pattern in eid order (NOT sorted: equal (u, v) keys may come in several runs), graph sorted by (src, dst)
+        p_u, p_v = rng.integers(0, pn, size=pm), rng.integers(0, pn, size=pm)
+        if cid % 2 == 0:
+            o = np.lexsort((p_v, p_u))
+            p_u, p_v = p_u[o], p_v[o]
+        p_el = rng.integers(0, nel, size=pm)
+        S_ = int(rng.integers(1, 5))
+        sub = np.stack([rng.permutation(gn)[:pn] for _ in range(S_)])         # injective maps pattern -> graph
+        g_u, g_v = rng.integers(0, gn, size=gm), rng.integers(0, gn, size=gm)
+        g_el = rng.integers(0, nel, size=gm)
+        if cid != 3:                                                          # embed the pattern (case 3: no real match)
+            eu = np.concatenate([sub[i][p_u] for i in range(S_)])
+            ev = np.concatenate([sub[i][p_v] for i in range(S_)])
+            el = np.tile(p_el, S_)
+            dup = rng.random(len(eu)) < 0.3                                   # parallel edges with the same label
+            g_u = np.concatenate([g_u, eu, eu[dup]])
+            g_v = np.concatenate([g_v, ev, ev[dup]])
+            g_el = np.concatenate([g_el, el, el[dup]])
+        o = np.lexsort((g_v, g_u))
+        g_u, g_v, g_el = g_u[o], g_v[o], g_el[o]
+        a = [np.ascontiguousarray(x, dtype=np.int64) for x in (p_u, p_v, p_el, g_u, g_v, g_el, sub)]
+        case = dict(p_u=a[0].tolist(), p_v=a[1].tolist(), p_el=a[2].tolist(), g_u=a[3].tolist(), g_v=a[4].tolist(),
+                    g_el=a[5].tolist(), subisomorphisms=a[6].tolist(), num_nodes=gn)
+        case["conj_subisomorphisms"] = ug.get_conjugate_subisomorphisms(*a).tolist()
+        case["edgeseq_subisoweights"] = D.compute_edgeseq_subisoweights(*a).tolist()
+        case["nodeseq_subisoweights"] = D.compute_nodeseq_subisoweights(gn, a[6]).tolist()
+        for sl in (True, False):
+            g = S.FakeDGLGraph(a[3], a[4], gn)
+            nn_, en_ = ug.compute_norm(g, sl)
+            case["node_norm_%d" % sl] = nn_.reshape(-1).tolist()
+            case["edge_norm_%d" % sl] = en_.reshape(-1).tolist()
+        ne, ee = ug.compute_largest_eigenvalues(S.FakeDGLGraph(a[3], a[4], gn))
+        case["node_eigenv"], case["edge_eigenv"] = float(ne), float(ee)
+        cases.append(case)
+    # add_reversed_edges on a small GraphAdjDataset
+    vocab = dict(max_npe=8, max_npel=2, max_nge=40, max_ngel=5)
+    ds = D.GraphAdjDataset()
+    items = []
+    for i in range(4):
+        def rg(n, m, nel):
+            g = S.FakeDGLGraph(rng.integers(0, n, size=m), rng.integers(0, n, size=m), n)
+            g.ndata["id"] = th.arange(n)
+            g.ndata["label"] = th.from_numpy(rng.integers(0, 3, size=n))
+            g.edata["id"] = th.arange(m)
+            g.edata["label"] = th.from_numpy(rng.integers(0, nel, size=m))
+            return g
+        items.append({"id": "r%d" % i, "pattern": rg(3, int(rng.integers(0 if i == 1 else 1, 8)), 2),
+                      "graph": rg(7, int(rng.integers(1, 30)), 5), "counts": 0,
+                      "subisomorphisms": th.zeros((0, 3), dtype=th.long)})
+    ds.data = items
+    before = [{"pattern": _dump_dgl(x["pattern"]), "graph": _dump_dgl(x["graph"])} for x in ds.data]
+    T.add_reversed_edges(ds, **vocab)
+    after = [{"pattern": _dump_dgl(x["pattern"]), "graph": _dump_dgl(x["graph"])} for x in ds.data]
+    with open(os.path.join(HERE, "si_bookkeeping.json"), "w") as f:
+        json.dump({"cases": cases, "reversed": {"vocab": vocab, "before": before, "after": after}}, f, separators=(",", ":"))
+    print("si_bookkeeping.json: %d cases + %d reversed items" % (len(cases), len(items)))
+
+
 def make_si_layers():
     _si_modules()
     rgin = importlib.import_module("models.rgin")
@@ -335,4 +410,5 @@ if __name__ == "__main__":
     make_gc()
     make_tu_files()
     make_si_transforms()
+    make_si_bookkeeping()
     make_si_layers()

@@ -330,3 +330,55 @@ def test_pyg_dataset_mirror_feeds_the_models(tmp_path):
     torch.manual_seed(0)
     out = GC.GIN(args).to(DEV)(batch)
     assert out.shape == (5, ds.num_classes) and bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------------------------------------ f-2: SI bookkeeping
+def test_si_bookkeeping_matches_reference_goldens(golden_dir):
+    from dummynode4graphlearning_amd.subgraph_isomorphism import bookkeeping as BK
+    with open(os.path.join(golden_dir, "si_bookkeeping.json")) as f:
+        gold = json.load(f)
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64)).to(DEV)  # noqa: E731
+    for c in gold["cases"]:
+        a = [t(c[k]) for k in ("p_u", "p_v", "p_el", "g_u", "g_v", "g_el")] + [t(c["subisomorphisms"])]
+        assert BK.get_conjugate_subisomorphisms(*a).cpu().tolist() == c["conj_subisomorphisms"]
+        assert BK.compute_edgeseq_subisoweights(*a).cpu().tolist() == c["edgeseq_subisoweights"]
+        assert BK.compute_nodeseq_subisoweights(c["num_nodes"], a[6]).cpu().tolist() == c["nodeseq_subisoweights"]
+        for sl in (True, False):
+            nn_, en_ = BK.compute_norm(a[3], a[4], c["num_nodes"], sl)
+            assert np.array_equal(nn_.view(-1).cpu().numpy(), np.asarray(c["node_norm_%d" % sl], dtype=np.float32))
+            assert np.array_equal(en_.view(-1).cpu().numpy(), np.asarray(c["edge_norm_%d" % sl], dtype=np.float32))
+        ne, ee = BK.compute_largest_eigenvalues(a[3], a[4], c["num_nodes"])
+        assert (float(ne), float(ee)) == (c["node_eigenv"], c["edge_eigenv"])
+    # add_reversed_edges: the four samples as ONE batch per side, compared with the per-sample reference output
+    voc = gold["reversed"]["vocab"]
+    for side, mne, mnel in (("pattern", voc["max_npe"], voc["max_npel"]), ("graph", voc["max_nge"], voc["max_ngel"])):
+        bef = [x[side] for x in gold["reversed"]["before"]]
+        aft = [x[side] for x in gold["reversed"]["after"]]
+        ep = np.concatenate([[0], np.cumsum([len(b["u"]) for b in bef])])
+        cat = lambda key, rows: t(np.concatenate([np.asarray(r[key], dtype=np.int64) for r in rows]))  # noqa: E731
+        r = BK.add_reversed_edges(t(ep), cat("u", bef), cat("v", bef), cat("e_id", bef), cat("e_label", bef), mne, mnel)
+        assert r["edge_ptr"].cpu().tolist() == (2 * ep).tolist()
+        for key, gk in (("src", "u"), ("dst", "v"), ("edge_id", "e_id"), ("edge_label", "e_label"), ("is_reversed", "e_is_reversed")):
+            assert r[key].cpu().tolist() == cat(gk, aft).cpu().tolist(), (side, key)
+
+
+def test_si_bookkeeping_large_random_against_oracle():
+    """A bigger pair (pattern 6 edges with repeated keys, graph 4k edges, 512 subisomorphisms) against the oracle."""
+    from dummynode4graphlearning_amd.subgraph_isomorphism import bookkeeping as BK
+    from oracle import si_bookkeeping as OB
+    rng = np.random.default_rng(77)
+    pn, gn, S_ = 5, 300, 512
+    p_u = np.array([0, 0, 1, 1, 3, 0]); p_v = np.array([1, 1, 2, 2, 4, 1]); p_el = np.array([0, 1, 2, 2, 1, 3])
+    sub = np.stack([rng.permutation(gn)[:pn] for _ in range(S_)])
+    g_u, g_v = rng.integers(0, gn, size=3000), rng.integers(0, gn, size=3000)
+    g_el = rng.integers(0, 4, size=3000)
+    g_u = np.concatenate([g_u, sub[:, p_u].reshape(-1)]); g_v = np.concatenate([g_v, sub[:, p_v].reshape(-1)])
+    g_el = np.concatenate([g_el, np.tile(p_el, S_)])
+    o = np.lexsort((g_v, g_u))
+    g_u, g_v, g_el = g_u[o], g_v[o], g_el[o]
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64)).to(DEV)  # noqa: E731
+    a = [t(x) for x in (p_u, p_v, p_el, g_u, g_v, g_el, sub)]
+    assert np.array_equal(BK.get_conjugate_subisomorphisms(*a).cpu().numpy(),
+                          OB.conjugate_subisomorphisms(p_u, p_v, p_el, g_u, g_v, g_el, sub))
+    assert np.array_equal(BK.compute_edgeseq_subisoweights(*a).cpu().numpy(),
+                          OB.edgeseq_subisoweights(p_u, p_v, p_el, g_u, g_v, g_el, sub))

@@ -354,3 +354,32 @@ def test_oracle_read_tu_data_on_the_written_datasets(golden_dir, tmp_path):
         node_off = slices["x"][np.searchsorted(slices["edge_index"], np.arange(ei.shape[1]), side="right") - 1]
         touches = is_dn[ei[0] + node_off] | is_dn[ei[1] + node_off]
         assert np.array_equal(is_de, touches)
+
+
+def test_oracle_si_bookkeeping_matches_reference(golden_dir):
+    """f-2: conjugate sub-isomorphisms, match weights, norms, eigenvalue bounds and reversed edges against the outputs of the
+    reference's own (numba-free) functions."""
+    from oracle import si_bookkeeping as OB
+    with open(os.path.join(golden_dir, "si_bookkeeping.json")) as f:
+        gold = json.load(f)
+    hits = 0
+    for c in gold["cases"]:
+        a = [c[k] for k in ("p_u", "p_v", "p_el", "g_u", "g_v", "g_el", "subisomorphisms")]
+        conj = OB.conjugate_subisomorphisms(*a)
+        assert conj.tolist() == c["conj_subisomorphisms"]
+        hits += int((conj > 0).sum())
+        assert OB.edgeseq_subisoweights(*a).tolist() == c["edgeseq_subisoweights"]
+        assert OB.nodeseq_subisoweights(c["num_nodes"], c["subisomorphisms"]).tolist() == c["nodeseq_subisoweights"]
+        for sl in (True, False):
+            nn_, en_ = OB.compute_norm(c["g_u"], c["g_v"], c["num_nodes"], sl)
+            assert np.array_equal(nn_, np.asarray(c["node_norm_%d" % sl], dtype=np.float32))
+            assert np.array_equal(en_, np.asarray(c["edge_norm_%d" % sl], dtype=np.float32))
+        assert OB.largest_eigenvalues(c["g_u"], c["g_v"], c["num_nodes"]) == (c["node_eigenv"], c["edge_eigenv"])
+    assert hits > 20                                   # the fixtures embed the patterns: real matches are exercised
+    voc = gold["reversed"]["vocab"]
+    for before, after in zip(gold["reversed"]["before"], gold["reversed"]["after"]):
+        for k, mne, mnel in (("pattern", voc["max_npe"], voc["max_npel"]), ("graph", voc["max_nge"], voc["max_ngel"])):
+            r = OB.add_reversed_edges(before[k]["u"], before[k]["v"], before[k]["e_label"], mne, mnel)
+            assert r["src"].tolist() == after[k]["u"] and r["dst"].tolist() == after[k]["v"]
+            assert r["edge_id"].tolist() == after[k]["e_id"] and r["edge_label"].tolist() == after[k]["e_label"]
+            assert r["is_reversed"].tolist() == after[k]["e_is_reversed"]
