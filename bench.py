@@ -213,19 +213,15 @@ def main():
                 Wn = W_all.transpose(1, 2).contiguous()
                 ybuf = index.ybuf(H, dtype, dev)
                 for n0, n1, ix in index.parts:
-                    for src_t, wmat, idx_rows, lst, ptr_, aux_i, aux_p, n_aux in (
-                            (x, Wn, ix.row_in, ix.dst_rows, ix.dst_ptr, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f),
-                            (gout, W_all, ix.row_out, ix.src_rows, ix.src_ptr, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)):
-                        xs = src_t[n0:n1]
-                        aux = ops.gather_segsum(xs, aux_i, aux_p, n_aux) if n_aux else None
-                        Y = ops.rows_transform(xs, wmat, ix.tile_table, ix.num_rows, idx=idx_rows, X2=aux, out=ybuf)
-                        ops.gather_segsum(Y, lst, ptr_, ix.num_nodes)
+                    ops.message_pass(x[n0:n1], Wn, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
+                    ops.message_pass(gout[n0:n1], W_all, None, ix, "b", ybuf, cg_out[n0:n1])
             else:
                 A = ops.gather_segsum(x, index.src1, index.seg_ptr, index.num_segments)
                 ops.gather_segsum(A, index.sperm, index.dptr, N)
                 gy = ops.gather_segsum(gout, index.seg_dst, None)
                 ops.gather_segsum(gy, index.seg_by_src, index.optr, N)
 
+    cg_out = torch.empty((N, H), dtype=dtype, device=dev)
     conv_gather_scatter()
     torch.cuda.synchronize()
     timer = ops.KernelTimer()
@@ -316,7 +312,7 @@ def main():
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gather_segsum_vec_kernel + rows_transform_kernel (conv launches)",
+                         "kernel": "gather_segsum_vec_kernel + rows_transform_kernel + rows_selfsum_kernel (conv launches)",
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step},
         }

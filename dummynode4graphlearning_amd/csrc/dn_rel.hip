@@ -609,6 +609,151 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// dn_rows_selfsum_bf16:  out[v, :] = X[v, :] @ Wn^T (+ bias)  +  sum_{k < K} Scat[slots[v][k], :]     (slots < 0: empty)
+//   The closing launch of the row-factorised message pass: the self-loop transform of node v (rgin.py:140-142) and the
+//   per-node sum of the transformed edge rows that point at v (the reference's fn.sum reduce) in ONE pass, so the
+//   self-loop products never make the round trip through HBM and no separate per-node gather launch is needed.
+//   Every node has a fixed number of slots (K = 4); nodes with more incoming rows get their excess pre-summed into an
+//   overflow row (Scat = S followed by S2 at row n1) by the caller, so the kernel has no data-dependent loop.
+//   One workgroup = H/16 waves (1024 threads at H = 256), wave w owns 16 output columns with its slice of Wn in
+//   registers for the whole launch; a tile = 32 consecutive nodes, one 16-byte piece per thread.  Per tile: the K slot
+//   rows of my piece are requested first (their ids were read one tile ahead), then the next tile's X piece and slot
+//   ids, then the MFMAs run on the LDS image of this tile, and the epilogue adds bias tile + slot rows in fp32.
+// -------------------------------------------------------------------------------------------------
+constexpr int kSsRows = 32;
+constexpr int kSsSlots = 4;
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wn,
+                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ S,
+                                                             const bf16_t* __restrict__ S2, int32_t n1,
+                                                             const int32_t* __restrict__ slots, int32_t N,
+                                                             int32_t num_tiles, int32_t tiles_per_wg,
+                                                             bf16_t* __restrict__ out) {
+    constexpr int T = H * 4, K = kSsSlots;
+    constexpr int SX = H + kPad, SY = H + kPad;
+    constexpr int KS = H / 32, MT = kSsRows / 16;
+    constexpr int LPR = H / 8;                                   // 16-byte pieces per row
+    static_assert(kSsRows * LPR == T, "one piece per thread");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kSsRows * SX + kSsRows * SY];
+    auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
+    bf16_t* bufY = lds + 2 * kSsRows * SX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * 16;
+    const int pr = tid / LPR, pc = tid % LPR;                    // my piece: row of the tile, 16-byte column chunk
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    bf16x8 wf[KS];                                               // A operand: Wn rows n0 + (lane & 15), k = ks*32 + 8*(lane>>4)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};                          // bias of my 4 accumulator columns
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = (float)bias[n0 + 4 * (lane >> 4) + i];
+    }
+
+    auto load_x = [&](int t) -> uint4 {
+        const int p = t * kSsRows + pr;
+        return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
+    };
+    auto load_slots = [&](int t) -> int4 {
+        const int p = t * kSsRows + pr;
+        return (t < t_end && p < N) ? *reinterpret_cast<const int4*>(slots + (size_t)p * K) : make_int4(-1, -1, -1, -1);
+    };
+
+    uint4 rx = load_x(t_beg);
+    int4 sl = load_slots(t_beg);
+    *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
+    rx = load_x(t_beg + 1);
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        // (1) the slot rows of my piece
+        uint4 g[K];
+        const int sid[K] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            g[k] = make_uint4(0, 0, 0, 0);
+            if (sid[k] >= 0) {
+                const bf16_t* base = sid[k] < n1 ? S + (size_t)sid[k] * H : S2 + (size_t)(sid[k] - n1) * H;
+                g[k] = *reinterpret_cast<const uint4*>(base + pc * 8);
+            }
+        }
+        // (2) next tile's slot ids (its X piece is already in flight / in rx)
+        const int4 sl_next = load_slots(t + 1);
+        // (3) MFMAs: D = Wn_slice x rows^T, lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bv[0], bv[1], bv[2], bv[3]};
+        const bf16_t* xt = bufX(b);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+            }
+        }
+        // the tile is staged in fp32 halves?  no: bf16, like the rows it is added to (both are rounded once)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (bf16_t)acc[m][i];
+            *reinterpret_cast<bf16x4*>(bufY + (m * 16 + (lane & 15)) * SY + n0 + 4 * (lane >> 4)) = o;
+        }
+        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;
+        rx = load_x(t + 2);
+        __syncthreads();
+        // (4) epilogue: my piece of the tile + my slot rows, fp32, one rounding
+        const int p = t * kSsRows + pr;
+        if (p < N) {
+            const uint4 y = *reinterpret_cast<const uint4*>(bufY + pr * SY + pc * 8);
+            float a[8];
+            const uint32_t yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[2 * i] = __uint_as_float(yw[i] << 16);
+                a[2 * i + 1] = __uint_as_float(yw[i] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t w[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[2 * i] += __uint_as_float(w[i] << 16);
+                    a[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (bf16_t)a[i];
+            *reinterpret_cast<bf16x8*>(out + (size_t)p * H + pc * 8) = o;
+        }
+        sl = sl_next;
+        __syncthreads();                                         // bufY is rewritten by the next tile's MFMA phase
+    }
+}
+
+template <int H>
+int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const bf16_t* S, const bf16_t* S2, int32_t n1,
+                   const int32_t* slots, int64_t N, bf16_t* out, hipStream_t st) {
+    const int64_t num_tiles = dn_cdiv(N, kSsRows);
+    const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
+    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    hipLaunchKernelGGL((rows_selfsum_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
+                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, out);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 static int tf_depth() {
     static int d = -1;
     if (d < 0) {
@@ -815,6 +960,25 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
+}
+
+int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
+                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_selfsum: bad row count");
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_selfsum: unsupported width %d (64/128/256 only)", H);
+    DN_REQUIRE(num_slots == kSsSlots, "dn_rows_selfsum: the slot table must have %d columns", kSsSlots);
+    if (N == 0) return DN_OK;
+    DN_REQUIRE(X && Wn && slots && out, "dn_rows_selfsum: NULL pointer");
+    DN_REQUIRE(S2 != nullptr || n1 == 0x7fffffff, "dn_rows_selfsum: S2 == NULL requires n1 == INT32_MAX");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wn) | reinterpret_cast<uintptr_t>(S) |
+                reinterpret_cast<uintptr_t>(S2) | reinterpret_cast<uintptr_t>(slots) | reinterpret_cast<uintptr_t>(out)) % 16 == 0,
+               "dn_rows_selfsum: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,
+                 *s2 = (const bf16_t*)S2;
+    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
+    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
+    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
 }
 
 }  // extern "C"

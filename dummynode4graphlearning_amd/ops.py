@@ -244,6 +244,59 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
 MFMA_DTYPES = (torch.bfloat16, torch.float32)
 
 
+SELFSUM_SLOTS = 4
+SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
+
+
+def rows_selfsum(x, Wn, bias, S, S2, slots, out=None):
+    """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows)."""
+    require_gpu(x, Wn, bias, S, S2, slots)
+    N, H = x.shape
+    assert x.dtype == torch.bfloat16 and Wn.shape == (H, H) and slots.shape == (N, SELFSUM_SLOTS) and slots.dtype == I32
+    x, Wn, slots = x.contiguous(), Wn.contiguous(), slots.contiguous()
+    if out is None:
+        out = torch.empty((N, H), dtype=x.dtype, device=x.device)
+    n1 = int(S.shape[0]) if S2 is not None else 0x7fffffff
+
+    def _launch():
+        check(lib().dn_rows_selfsum_bf16(ptr(x), H, ptr(Wn), ptr(bias), ptr(S) if S is not None and S.numel() else None,
+                                         ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out), stream_ptr()),
+              "dn_rows_selfsum_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_selfsum", _launch)
+    else:
+        _launch()
+    return out
+
+
+def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS):
+    """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16: (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).
+    Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more than K rows keeps its first K-1 and gets the
+    id num_edge_rows + j of overflow row j in its last slot (ovf_ptr/ovf_idx: CSR of the rows to pre-sum into it)."""
+    dev = list_rows.device
+    N, P = int(num_nodes), int(num_edge_rows)
+    cnt_all = (list_ptr[1:] - list_ptr[:-1]).long()
+    seg = torch.repeat_interleave(torch.arange(N, device=dev), cnt_all)
+    keep = list_rows < P
+    seg, rows = seg[keep], list_rows[keep].long()
+    cnt = torch.bincount(seg, minlength=N)
+    start = torch.cumsum(cnt, 0) - cnt
+    pos = torch.arange(rows.numel(), device=dev) - start[seg]
+    over = cnt > K
+    in_slot = (~over[seg]) | (pos < K - 1)
+    slots = torch.full((N, K), -1, dtype=I32, device=dev)
+    slots[seg[in_slot], pos[in_slot]] = rows[in_slot].to(I32)
+    n_ovf = int(over.sum())
+    if n_ovf == 0:
+        return slots, None, None, 0
+    ovf_id = torch.cumsum(over.long(), 0) - 1
+    slots[over, K - 1] = (P + ovf_id[over]).to(I32)
+    oseg = ovf_id[seg[~in_slot]]
+    zero = torch.zeros(1, dtype=torch.long, device=dev)
+    ovf_ptr = torch.cat([zero, torch.cumsum(torch.bincount(oseg, minlength=n_ovf), 0)]).to(I32)
+    return slots, ovf_ptr, rows[~in_slot].to(I32).contiguous(), n_ovf
+
+
 def wgrad_supported(A, G):
     return A.dtype == G.dtype and A.dtype in MFMA_DTYPES and A.shape[1] == G.shape[1] and A.shape[1] in (64, 128, 256)
 
@@ -618,8 +671,23 @@ class RowIndex:
         self.num_all_rels = R + (1 if self_loop else 0)
         self.rel_ptr_host = rel_ptr
         self.tile_table = make_row_tiles(rel_ptr, dev)
+        self.edge_tile_table = make_row_tiles(rel_ptr[:R + 1], dev) if self_loop else self.tile_table
+        self._slots = {}
         # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
         self.chunk_table = make_row_chunks(rel_ptr, dev, chunk_rows=max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)))
+
+
+def _row_index_slots(ix, direction):
+    """Slot tables of a RowIndex for the fused closing launch ('f': rows into each destination, 'b': rows out of each source)."""
+    t = ix._slots.get(direction)
+    if t is None:
+        ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
+        t = build_slot_table(ptr_, rows, ix.num_nodes, ix.num_edge_rows)
+        ix._slots[direction] = t
+    return t
+
+
+RowIndex.slots = _row_index_slots
 
 
 class RowIndexSet:
@@ -663,28 +731,53 @@ class RowIndexSet:
         return b
 
 
+def _selfsum_ok(ix, x):
+    return SELFSUM_ENABLED and ix.self_loop and x.dtype == torch.bfloat16
+
+
+def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
+    """One direction of the row-factorised pass over one RowIndex -- the launches that ARE the layer's gather-scatter:
+         'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          Wmat = W^T per relation ([R', out, in])
+         'b':  out[u] = sum_{rows p <- u} (g_row(p)  @ W[rel p]^T)        Wmat = W       per relation ([R', in, out])
+       = pre-aggregation of the collapsed relations (gather_segsum) -> gathered-row transform on the matrix cores ->
+       closing launch.  With a self loop in bf16 the closing launch is dn_rows_selfsum_bf16 (self-loop transform + bias +
+       per-node sum of the edge rows in one pass); otherwise the self-loop rows go through the transform like any relation
+       and a per-node gather_segsum closes.  Returns the pre-aggregated rows (kept for the weight gradient)."""
+    if direction == "f":
+        aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
+    else:
+        aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
+    aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
+    if _selfsum_ok(ix, xs):
+        P = ix.num_edge_rows
+        Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
+        slots, optr, oidx, novf = ix.slots(direction)
+        ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
+        rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out)
+        return aux
+    bias_all = None
+    if bias is not None:
+        bias_all = torch.zeros((Wmat.shape[0], Wmat.shape[1]), dtype=xs.dtype, device=xs.device)
+        bias_all[-1] = bias                                                  # only self-loop rows carry the bias
+    Y = rows_transform(xs, Wmat, ix.tile_table, ix.num_rows, idx=idx_rows, X2=aux, bias=bias_all, tag="conv", out=ybuf)
+    gather_segsum(Y, lst, lptr, ix.num_nodes, out=out)
+    return aux
+
+
 class _RowTransformFn(torch.autograd.Function):
     """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop), evaluated
-    sub-batch by sub-batch (RowIndexSet) so the intermediate rows never leave the on-die caches."""
+    sub-batch by sub-batch (RowIndexSet; one part unless DN_SUBBATCH_NODES is set)."""
 
     @staticmethod
     def forward(ctx, x, W_all, bias, index_set):
         x = x.contiguous()
         Wn = W_all.transpose(1, 2).contiguous()                              # [R', out, in]
-        bias_all = None
-        if bias is not None:
-            bias_all = torch.zeros((W_all.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
-            bias_all[-1] = bias                                              # only self-loop rows carry the bias
         out = torch.empty((x.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
         ybuf = index_set.ybuf(W_all.shape[2], x.dtype, x.device)
         auxs = []
         for n0, n1, ix in index_set.parts:
-            xs = x[n0:n1]
-            aux = gather_segsum(xs, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if ix.num_aux_f else None
+            aux = message_pass(x[n0:n1], Wn, bias, ix, "f", ybuf, out[n0:n1])
             auxs.append(aux if aux is not None else x.new_empty(0))      # a few MB: kept for the weight gradient
-            Y = rows_transform(xs, Wn, ix.tile_table, ix.num_rows, idx=ix.row_in, X2=aux, bias=bias_all, tag="conv",
-                               out=ybuf)
-            gather_segsum(Y, ix.dst_rows, ix.dst_ptr, ix.num_nodes, out=out[n0:n1])
         ctx.index_set, ctx.has_bias = index_set, bias is not None
         ctx.save_for_backward(x, W_all, *auxs)
         return out
@@ -703,10 +796,10 @@ class _RowTransformFn(torch.autograd.Function):
         single = len(iset.parts) == 1
         for part, (n0, n1, ix) in enumerate(iset.parts):
             gs, xs = g[n0:n1], x[n0:n1]
-            aux_b = gather_segsum(gs, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
             if need_x:
-                gA = rows_transform(gs, Wc, ix.tile_table, ix.num_rows, idx=ix.row_out, X2=aux_b, tag="conv", out=ybuf)
-                gather_segsum(gA, ix.src_rows, ix.src_ptr, ix.num_nodes, out=gx[n0:n1])
+                aux_b = message_pass(gs, Wc, None, ix, "b", ybuf, gx[n0:n1])
+            else:
+                aux_b = gather_segsum(gs, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
             if need_w:
                 aux = auxs[part] if ix.num_aux_f else None
                 # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel

@@ -243,6 +243,18 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos,
                            const int32_t* tiles, int64_t num_tiles, void* Y, dn_stream_t stream);
 
+/* Closing launch of the row-factorised message pass (bf16 in, fp32 acc, bf16 out):
+ *   out[v, :] = X[v, :] @ Wn^T (+ bias)  +  sum_{k < num_slots} Scat[slots[v * num_slots + k], :]
+ * i.e. the self-loop transform `th.matmul(node_feat, self.loop_weight)` + bias (subgraph_isomorphism/models/rgin.py:
+ * 140-145, rgcn.py:168-182) fused with the per-node sum of the transformed rows (the reference's `fn.sum(msg, out)`
+ * reduce, rgin.py:137 / rgcn.py:166) -- and, in the backward direction, the same for the input gradient.
+ * Wn is [H][H] with k contiguous.  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
+ * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  Nodes with
+ * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 4.
+ * H in {64, 128, 256}. */
+int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
+                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream);
+
 /* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
  * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the
  * `mask_pos` epilogue of dn_rows_transform_bf16 ([rows, Ho] saved activations), so a Linear's input gradient comes

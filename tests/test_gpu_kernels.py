@@ -328,3 +328,38 @@ def test_edge_dot_and_neighbor_max(dtype, H):
     torch.testing.assert_close(xd.grad.cpu().double().sum(0), xr.grad.sum(0), rtol=tol, atol=tol * 10)
     if dtype == torch.float32:
         torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_rows_selfsum_matches_reference(H):
+    """dn_rows_selfsum_bf16: self-loop transform + bias + fixed-slot row sum (with overflow rows) against fp64 on the same
+    bf16 operands; slot tables built from ragged per-node lists by ops.build_slot_table."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(H + 1)
+    N, P = 1000 + H // 64, 2500                       # N not a multiple of the 32-row tile
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(torch.bfloat16)
+    W = torch.from_numpy((rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)).to(torch.bfloat16)   # Wn [out][in]
+    b = torch.from_numpy(rng.standard_normal(H).astype(np.float32)).to(torch.bfloat16)
+    Y = torch.from_numpy(rng.standard_normal((P, H)).astype(np.float32)).to(torch.bfloat16)
+    # ragged lists: most nodes 0-4 rows, some up to 12 (overflow), every list ends with the node's self row id P + v
+    cnt = rng.integers(0, 5, size=N)
+    cnt[rng.integers(0, N, size=40)] = rng.integers(5, 13, size=40)
+    lists = [np.append(rng.integers(0, P, size=c), P + v) for v, c in enumerate(cnt)]
+    ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    rows = np.concatenate(lists)
+    slots, optr, oidx, novf = ops.build_slot_table(torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int(), N, P)
+    assert novf == int((cnt > 4).sum()) and slots.shape == (N, 4)
+    Yd = Y.to(DEV)
+    ovf = ops.gather_segsum(Yd, oidx, optr, novf) if novf else None
+    for bias in (b.to(DEV), None):
+        out = ops.rows_selfsum(x.to(DEV), W.to(DEV), bias, Yd, ovf, slots)
+        ref = x.double() @ W.double().t() + (b.double() if bias is not None else 0.0)
+        for v in range(N):
+            ref[v] += Y[lists[v][:-1]].double().sum(0)
+        err = (out.cpu().double() - ref).abs().max() / ref.abs().max()
+        assert float(err) < 1.2e-2, float(err)        # two bf16 roundings (tile, overflow row) + the output rounding
+    # no incoming rows at all: out = x W^T + b
+    empty = torch.full((N, 4), -1, dtype=torch.int32, device=DEV)
+    out = ops.rows_selfsum(x.to(DEV), W.to(DEV), b.to(DEV), Yd[:0], None, empty)
+    ref = x.double() @ W.double().t() + b.double()
+    assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 6e-3
