@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
 //   The closing launch of the row-factorised message pass: the self-loop transform of node v (rgin.py:140-142) and the
 //   per-node sum of the transformed edge rows that point at v (the reference's fn.sum reduce) in ONE pass, so the
 //   self-loop products never make the round trip through HBM and no separate per-node gather launch is needed.
-//   Every node has a fixed number of slots (K = 4); nodes with more incoming rows get their excess pre-summed into an
+//   Every node has a fixed number of slots (K = 6); nodes with more incoming rows get their excess pre-summed into an
 //   overflow row (Scat = S followed by S2 at row n1) by the caller, so the kernel has no data-dependent loop.
 //   One workgroup = H/16 waves (1024 threads at H = 256), wave w owns 16 output columns with its slice of Wn in
 //   registers for the whole launch; a tile = 32 consecutive nodes, one 16-byte piece per thread.  Per tile: the K slot
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
 //   ids, then the MFMAs run on the LDS image of this tile, and the epilogue adds bias tile + slot rows in fp32.
 // -------------------------------------------------------------------------------------------------
 constexpr int kSsRows = 32;
-constexpr int kSsSlots = 4;
+constexpr int kSsSlots = 6;
 
 template <int H>
 __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wn,
@@ -661,13 +661,19 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         const int p = t * kSsRows + pr;
         return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
     };
-    auto load_slots = [&](int t) -> int4 {
+    struct Slots { int2 a, b, c; };                              // K = 6 ids, 24 bytes per node (8-byte aligned)
+    auto load_slots = [&](int t) -> Slots {
         const int p = t * kSsRows + pr;
-        return (t < t_end && p < N) ? *reinterpret_cast<const int4*>(slots + (size_t)p * K) : make_int4(-1, -1, -1, -1);
+        Slots v = {make_int2(-1, -1), make_int2(-1, -1), make_int2(-1, -1)};
+        if (t < t_end && p < N) {
+            const int2* q = reinterpret_cast<const int2*>(slots + (size_t)p * K);
+            v.a = q[0]; v.b = q[1]; v.c = q[2];
+        }
+        return v;
     };
 
     uint4 rx = load_x(t_beg);
-    int4 sl = load_slots(t_beg);
+    Slots sl = load_slots(t_beg);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
     rx = load_x(t_beg + 1);
     __syncthreads();
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         const int b = (t - t_beg) & 1;
         // (1) the slot rows of my piece
         uint4 g[K];
-        const int sid[K] = {sl.x, sl.y, sl.z, sl.w};
+        const int sid[K] = {sl.a.x, sl.a.y, sl.b.x, sl.b.y, sl.c.x, sl.c.y};
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             g[k] = make_uint4(0, 0, 0, 0);
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
             }
         }
         // (2) next tile's slot ids (its X piece is already in flight / in rx)
-        const int4 sl_next = load_slots(t + 1);
+        const Slots sl_next = load_slots(t + 1);
         // (3) MFMAs: D = Wn_slice x rows^T, lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
         f32x4 acc[MT];
 #pragma unroll
@@ -971,7 +977,7 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     DN_REQUIRE(X && Wn && slots && out, "dn_rows_selfsum: NULL pointer");
     DN_REQUIRE(S2 != nullptr || n1 == 0x7fffffff, "dn_rows_selfsum: S2 == NULL requires n1 == INT32_MAX");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wn) | reinterpret_cast<uintptr_t>(S) |
-                reinterpret_cast<uintptr_t>(S2) | reinterpret_cast<uintptr_t>(slots) | reinterpret_cast<uintptr_t>(out)) % 16 == 0,
+                reinterpret_cast<uintptr_t>(S2) | reinterpret_cast<uintptr_t>(out)) % 16 == 0 && reinterpret_cast<uintptr_t>(slots) % 8 == 0,
                "dn_rows_selfsum: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,

@@ -244,7 +244,7 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
 MFMA_DTYPES = (torch.bfloat16, torch.float32)
 
 
-SELFSUM_SLOTS = 4
+SELFSUM_SLOTS = 6
 SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 

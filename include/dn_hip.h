@@ -250,7 +250,7 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * reduce, rgin.py:137 / rgcn.py:166) -- and, in the backward direction, the same for the input gradient.
  * Wn is [H][H] with k contiguous.  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
  * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  Nodes with
- * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 4.
+ * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 6.
  * H in {64, 128, 256}. */
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream);

@@ -341,14 +341,15 @@ def test_rows_selfsum_matches_reference(H):
     W = torch.from_numpy((rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)).to(torch.bfloat16)   # Wn [out][in]
     b = torch.from_numpy(rng.standard_normal(H).astype(np.float32)).to(torch.bfloat16)
     Y = torch.from_numpy(rng.standard_normal((P, H)).astype(np.float32)).to(torch.bfloat16)
-    # ragged lists: most nodes 0-4 rows, some up to 12 (overflow), every list ends with the node's self row id P + v
-    cnt = rng.integers(0, 5, size=N)
-    cnt[rng.integers(0, N, size=40)] = rng.integers(5, 13, size=40)
+    # ragged lists: most nodes 0-K rows, some up to 3K (overflow), every list ends with the node's self row id P + v
+    K = ops.SELFSUM_SLOTS
+    cnt = rng.integers(0, K + 1, size=N)
+    cnt[rng.integers(0, N, size=40)] = rng.integers(K + 1, 3 * K, size=40)
     lists = [np.append(rng.integers(0, P, size=c), P + v) for v, c in enumerate(cnt)]
     ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
     rows = np.concatenate(lists)
     slots, optr, oidx, novf = ops.build_slot_table(torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int(), N, P)
-    assert novf == int((cnt > 4).sum()) and slots.shape == (N, 4)
+    assert novf == int((cnt > K).sum()) and slots.shape == (N, K)
     Yd = Y.to(DEV)
     ovf = ops.gather_segsum(Yd, oidx, optr, novf) if novf else None
     for bias in (b.to(DEV), None):
@@ -359,7 +360,7 @@ def test_rows_selfsum_matches_reference(H):
         err = (out.cpu().double() - ref).abs().max() / ref.abs().max()
         assert float(err) < 1.2e-2, float(err)        # two bf16 roundings (tile, overflow row) + the output rounding
     # no incoming rows at all: out = x W^T + b
-    empty = torch.full((N, 4), -1, dtype=torch.int32, device=DEV)
+    empty = torch.full((N, K), -1, dtype=torch.int32, device=DEV)
     out = ops.rows_selfsum(x.to(DEV), W.to(DEV), b.to(DEV), Yd[:0], None, empty)
     ref = x.double() @ W.double().t() + b.double()
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 6e-3

@@ -28,8 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # launches of ONE eager step of bench.py's config-5 workload, in order (kernel-name fragment, role)
 STEP = [
     ("gather_segsum_vec_kernel", "aux pre-aggregation (fwd)"),
-    ("rows_transform_kernel", "conv transform fwd (gathers x rows)"),
-    ("gather_segsum_vec_kernel", "conv final per-dst sum (fwd)"),
+    ("rows_transform_kernel", "conv transform fwd, edge rows (gathers x rows)"),
+    ("gather_segsum_vec_kernel", "overflow rows of nodes with > 6 incoming rows (fwd)"),
+    ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum"),
     ("rows_transform_kernel", "MLP linear 1 fwd (+bias+ReLU)"),
     ("rows_transform_kernel", "MLP linear 2 fwd (+bias+ReLU)"),
     ("rows_wgrad_kernel", "MLP wgrad 2 (+outer ReLU mask, saves masked g)"),
@@ -39,14 +40,15 @@ STEP = [
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_kernel", "MLP dgrad 1"),
     ("gather_segsum_vec_kernel", "aux pre-aggregation (bwd)"),
-    ("rows_transform_kernel", "conv transform bwd (gathers g rows)"),
-    ("gather_segsum_vec_kernel", "conv final per-src sum (bwd)"),
+    ("rows_transform_kernel", "conv transform bwd, edge rows (gathers g rows)"),
+    ("gather_segsum_vec_kernel", "overflow rows (bwd)"),
+    ("rows_selfsum_kernel", "closing launch bwd: self-loop transform + per-src slot sum"),
     ("rows_wgrad_dma_kernel", "conv wgrad (LDS-DMA ring; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
-CONV_ROWS = (0, 1, 2, 11, 12, 13)
-OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
-        "wgrad_reduce_kernel")
+CONV_ROWS = (0, 1, 2, 3, 12, 13, 14, 15)
+OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "rows_wgrad_dma_kernel",
+        "rows_wgrad_kernel", "wgrad_reduce_kernel")
 
 
 def short(name):
@@ -141,7 +143,7 @@ def main():
         f.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE KB (a wide coalesced read is half-counted); WRITE_SIZE exact. durations under PMC collection (us)\n")
         f.write("kernel,role,hbm_read_MB,hbm_write_MB,hbm_total_MB,duration_us,TB_per_s\n")
         f.write("\n".join(lines) + "\n")
-        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-3 and 12-14): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
+        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-4 and 13-16): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
                 % (tot, conv, alg / 1e6, conv * 1e6 / alg))
     with open(os.path.join(a.out, a.tag + "_traffic.json"), "w") as f:
         json.dump({"workload": "config5", "N": N, "E": E, "H": H, "dtype": "bf16",
@@ -168,7 +170,10 @@ def main():
                 c, act = agg[k]
                 f.write("%s,%d,%d,%.3f\n" % (k, c, act, c / act if act else 0.0))
 
-    # 1. the bench line itself, last so that it reads the fresh traffic.json when --out is profiles/
+    # 1. the bench line itself, last, with the fresh traffic.json in place (bench.py reads profiles/<tag>_traffic.json)
+    import shutil
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    shutil.copy(os.path.join(a.out, a.tag + "_traffic.json"), os.path.join(ROOT, "profiles", a.tag + "_traffic.json"))
     r = run(["python3", bench])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
