@@ -446,6 +446,8 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const bf16_t* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
+    const bool nt_store = (relu & 2) != 0;          // bit 1: streaming (non-temporal) stores of Y
+    relu &= 1;
     constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
     constexpr int SY = HO + kPad;                   // ... of the output tile
     constexpr int KS = HI / 32;                     // k-steps
@@ -599,7 +601,12 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
-                *reinterpret_cast<uint4*>(Y + (size_t)p * HO + c * 8) = v;
+                if (nt_store) {
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 vv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(Y + (size_t)p * HO + c * 8));
+                }
+                else *reinterpret_cast<uint4*>(Y + (size_t)p * HO + c * 8) = v;
             }
         }
         // bufY is rewritten only after the next tile's MFMAs and its barrier-separated store: add a barrier here so no
@@ -630,8 +637,9 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ S2, int32_t n1,
                                                              const int32_t* __restrict__ slots, int32_t N,
                                                              int32_t num_tiles, int32_t tiles_per_wg,
-                                                             bf16_t* __restrict__ out) {
+                                                             bf16_t* __restrict__ out, int32_t nt) {
     constexpr int T = H * 4, K = kSsSlots;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int SX = H + kPad, SY = H + kPad;
     constexpr int KS = H / 32, MT = kSsRows / 16;
     constexpr int LPR = H / 8;                                   // 16-byte pieces per row
@@ -741,7 +749,8 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
             bf16x8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (bf16_t)a[i];
-            *reinterpret_cast<bf16x8*>(out + (size_t)p * H + pc * 8) = o;
+            if (nt & 1) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(out + (size_t)p * H + pc * 8));
+            else *reinterpret_cast<bf16x8*>(out + (size_t)p * H + pc * 8) = o;
         }
         sl = sl_next;
         __syncthreads();                                         // bufY is rewritten by the next tile's MFMA phase
@@ -754,8 +763,9 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
     hipLaunchKernelGGL((rows_selfsum_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, out);
+                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, out, (nt >> 1) & 1);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -780,6 +790,10 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
                      int32_t relu, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
     // contiguous tile ranges keep a workgroup inside one relation most of the time
     const int depth = tf_depth();
+    // streaming (non-temporal) stores of the output rows: they are re-read only after ~1 GB of other traffic, so keeping
+    // them out of L2 / Infinity Cache is worth 1.5-2 % of the step (DN_NT=0 turns it off: bit 0 transform, bit 1 selfsum)
+    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
+    relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0);
     const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? 2 : 1);
     const int64_t max_wg = 256 * per_cu;
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
