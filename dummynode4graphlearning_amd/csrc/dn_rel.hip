@@ -770,6 +770,146 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     return DN_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// dn_rows_chain2_bf16:  Y1 = epi1(X @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)   -- two dense layers in one pass over the rows
+//   epi1 = (+ b1) -> ReLU? -> keep where mask1 > 0 ?        epi2 = (+ b2) -> ReLU?
+//   Forward of the reference's two-layer post-aggregate MLP (rgin.py:50-57: Linear-ReLU-Linear, then the layer's ReLU) and,
+//   with mask1 = the saved hidden activation and no bias/ReLU, the two input-gradient products of its backward.  Y1 is
+//   still written (the backward / the weight gradient need it) but never re-read: one [rows, H] read less per call than two
+//   dn_rows_transform_bf16 launches.  Same skeleton as rows_selfsum_kernel: H/16 waves, wave w owns 16 output columns of
+//   BOTH layers (2 x 32 VGPRs of weights for the whole launch), tile = 32 rows, one 16-byte piece per thread.
+// -------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1n,
+                                                            const bf16_t* __restrict__ b1, const bf16_t* __restrict__ W2n,
+                                                            const bf16_t* __restrict__ b2, int32_t flags,
+                                                            const bf16_t* __restrict__ mask1, int32_t N, int32_t num_tiles,
+                                                            int32_t tiles_per_wg, bf16_t* __restrict__ Y1,
+                                                            bf16_t* __restrict__ Y2) {
+    constexpr int T = H * 4;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+    constexpr int SX = H + kPad;
+    constexpr int KS = H / 32, MT = kSsRows / 16;
+    constexpr int LPR = H / 8;
+    static_assert(kSsRows * LPR == T, "one piece per thread");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * kSsRows * SX];
+    auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
+    bf16_t* buf1 = lds + 2 * kSsRows * SX;                       // stage-1 result = stage-2 input
+    bf16_t* buf2 = lds + 3 * kSsRows * SX;                       // stage-2 result
+    const bool relu1 = flags & 1, relu2 = flags & 2, nt = flags & 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * 16;
+    const int pr = tid / LPR, pc = tid % LPR;
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    bf16x8 wf1[KS], wf2[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const size_t o = (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4);
+        wf1[ks] = *reinterpret_cast<const bf16x8*>(W1n + o);
+        wf2[ks] = *reinterpret_cast<const bf16x8*>(W2n + o);
+    }
+    float bv1[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (b1) bv1[i] = (float)b1[n0 + 4 * (lane >> 4) + i];
+        if (b2) bv2[i] = (float)b2[n0 + 4 * (lane >> 4) + i];
+    }
+    auto load_x = [&](int t) -> uint4 {
+        const int p = t * kSsRows + pr;
+        return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
+    };
+    auto load_mask = [&](int t) -> uint4 {
+        const int p = t * kSsRows + pr;
+        return (mask1 && t < t_end && p < N) ? *reinterpret_cast<const uint4*>(mask1 + (size_t)p * H + pc * 8)
+                                             : make_uint4(0, 0, 0, 0);
+    };
+    // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 16 columns of all 32 rows)
+    auto stage = [&](const bf16_t* src, const bf16x8 (&wf)[KS], const float (&bv)[4], bool relu, bf16_t* dst) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(src + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(relu ? fmaxf(acc[m][i], 0.f) : acc[m][i]);
+            *reinterpret_cast<bf16x4*>(dst + (m * 16 + (lane & 15)) * SX + n0 + 4 * (lane >> 4)) = o;
+        }
+    };
+    auto put = [&](bf16_t* Yout, int p, const uint4& v) {
+        const u32x4 vv = {v.x, v.y, v.z, v.w};
+        if (nt) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(Yout + (size_t)p * H + pc * 8));
+        else *reinterpret_cast<u32x4*>(Yout + (size_t)p * H + pc * 8) = vv;
+    };
+
+    // X pieces and mask pieces two tiles ahead (the launch has no gathers: without this only 32 KB per CU are in flight)
+    uint4 rx = load_x(t_beg);
+    uint4 mk = load_mask(t_beg);
+    *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
+    rx = load_x(t_beg + 1);
+    uint4 rx2 = load_x(t_beg + 2);
+    uint4 mk1 = load_mask(t_beg + 1);
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        const int p = t * kSsRows + pr;
+        stage(bufX(b), wf1, bv1, relu1, buf1);
+        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;
+        rx = rx2;
+        rx2 = load_x(t + 3);
+        const uint4 mk2 = load_mask(t + 2);
+        __syncthreads();                                         // buf1 complete
+        {   // my piece of the stage-1 tile: mask, write out, (masked) back into the stage-2 input
+            uint4 v = *reinterpret_cast<const uint4*>(buf1 + pr * SX + pc * 8);
+            if (mask1) {
+                const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
+                    vw[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+                }
+                v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                *reinterpret_cast<uint4*>(buf1 + pr * SX + pc * 8) = v;
+            }
+            if (p < N) put(Y1, p, v);
+        }
+        if (mask1) __syncthreads();                              // masked tile visible to every wave (uniform branch)
+        stage(buf1, wf2, bv2, relu2, buf2);
+        __syncthreads();                                         // buf2 complete; buf1 free for the next tile
+        if (p < N) put(Y2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
+        mk = mk1;
+        mk1 = mk2;
+        // buf2 is rewritten only after the next tile's two barriers; bufX(b) after the next tile's stage 1 -> no extra barrier
+    }
+}
+
+template <int H>
+int launch_chain2(const bf16_t* X, const bf16_t* W1n, const bf16_t* b1, const bf16_t* W2n, const bf16_t* b2, int32_t flags,
+                  const bf16_t* mask1, int64_t N, bf16_t* Y1, bf16_t* Y2, hipStream_t st) {
+    const int64_t num_tiles = dn_cdiv(N, kSsRows);
+    const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));
+    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    hipLaunchKernelGGL((rows_chain2_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, W1n, b1, W2n, b2, flags, mask1,
+                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y1, Y2);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 static int tf_depth() {
     static int d = -1;
     if (d < 0) {
@@ -999,6 +1139,25 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
     if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
     return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
+}
+
+int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask1,
+                        const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_chain2: bad row count");
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_chain2: unsupported width %d (64/128/256 only)", H);
+    if (N == 0) return DN_OK;
+    DN_REQUIRE(X && W1n && W2n && Y1 && Y2, "dn_rows_chain2: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1n) | reinterpret_cast<uintptr_t>(W2n) |
+                reinterpret_cast<uintptr_t>(mask1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
+               "dn_rows_chain2: unaligned pointer");
+    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
+    const int32_t flags = (relu1 ? 1 : 0) | (relu2 ? 2 : 0) | ((nt & 1) ? 4 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *x = (const bf16_t*)X, *w1 = (const bf16_t*)W1n, *w2 = (const bf16_t*)W2n, *bb1 = (const bf16_t*)b1,
+                 *bb2 = (const bf16_t*)b2, *mk = (const bf16_t*)mask1;
+    if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
+    if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
+    return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
 }
 
 }  // extern "C"

@@ -269,6 +269,27 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None):
     return out
 
 
+CHAIN2_ENABLED = _os.environ.get("DN_CHAIN2", "1") != "0"
+
+
+def rows_chain2(x, W1n, b1, relu1, mask1, W2n, b2, relu2):
+    """(Y1, Y2) with Y1 = epi1(x @ W1n^T), Y2 = epi2(Y1 @ W2n^T) in one pass over the rows (dn_rows_chain2_bf16)."""
+    x, W1n, W2n = x.contiguous(), W1n.contiguous(), W2n.contiguous()
+    require_gpu(x, W1n, b1, mask1, W2n, b2)
+    N, H = x.shape
+    assert x.dtype == torch.bfloat16 and W1n.shape == (H, H) and W2n.shape == (H, H)
+    Y1, Y2 = torch.empty_like(x), torch.empty_like(x)
+
+    def _launch():
+        check(lib().dn_rows_chain2_bf16(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask1), ptr(W2n), ptr(b2),
+                                        1 if relu2 else 0, N, ptr(Y1), ptr(Y2), stream_ptr()), "dn_rows_chain2_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_chain2", _launch)
+    else:
+        _launch()
+    return Y1, Y2
+
+
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS):
     """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16: (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).
     Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more than K rows keeps its first K-1 and gets the
@@ -912,10 +933,15 @@ class _ReluMlpFn(torch.autograd.Function):
         n = len(wb) // 2
         tiles, _ = _dense_table(x.shape[0], x.device)
         acts = [x.contiguous()]
-        for i in range(n):
-            w, b = wb[2 * i], wb[2 * i + 1]
-            acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
-                                       bias=None if b is None else b.contiguous().view(1, -1), relu=True))
+        if n == 2 and CHAIN2_ENABLED and x.dtype == torch.bfloat16:
+            # both layers in one pass: the hidden activation is written (the backward needs it) but not re-read
+            h1, h2 = rows_chain2(acts[0], wb[0], wb[1], True, None, wb[2], wb[3], True)
+            acts += [h1, h2]
+        else:
+            for i in range(n):
+                w, b = wb[2 * i], wb[2 * i + 1]
+                acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
+                                           bias=None if b is None else b.contiguous().view(1, -1), relu=True))
         ctx.n = n
         ctx.has_bias = [wb[2 * i + 1] is not None for i in range(n)]
         ctx.save_for_backward(*acts, *[wb[2 * i] for i in range(n)])
@@ -929,6 +955,19 @@ class _ReluMlpFn(torch.autograd.Function):
         tiles, chunks = _dense_table(acts[0].shape[0], acts[0].device)
         g = gout.contiguous()
         grads = [None] * (1 + 2 * n)
+        if n == 2 and CHAIN2_ENABLED and g.dtype == torch.bfloat16 and ctx.needs_input_grad[0]:
+            gm = torch.empty_like(g)
+            gw2, cs2 = rows_wgrad(g, acts[1], chunks, 1, out_dtype=ws[1].dtype, colsum_of=1, mask_a=acts[2], a_out=gm)
+            # g1 = (gm @ W2) masked by h1 > 0, g0 = g1 @ W1 in one pass; g1 is only re-read by the weight gradient of layer 1
+            g1, g0 = rows_chain2(gm, ws[1].t(), None, False, acts[1], ws[0].t(), None, False)
+            gw1, cs1 = rows_wgrad(g1, acts[0], chunks, 1, out_dtype=ws[0].dtype, colsum_of=1)
+            grads[1], grads[3] = gw1[0], gw2[0]
+            if ctx.has_bias[0]:
+                grads[2] = cs1[0].to(g.dtype)
+            if ctx.has_bias[1]:
+                grads[4] = cs2[0].to(g.dtype)
+            grads[0] = g0
+            return tuple(grads)
         for i in range(n - 1, -1, -1):
             w = ws[i]
             if i == n - 1:

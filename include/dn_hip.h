@@ -255,6 +255,16 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream);
 
+/* Two dense layers in one pass over the rows (bf16 in, fp32 acc, bf16 out):
+ *   Y1 = epi1(X @ W1n^T),  epi1 = (+ b1), ReLU if relu1, then zero where mask1 <= 0 (mask1 may be NULL)
+ *   Y2 = epi2(Y1 @ W2n^T), epi2 = (+ b2), ReLU if relu2
+ * Forward of the reference's two-layer MLP after the aggregate (subgraph_isomorphism/models/rgin.py:50-57 followed by the
+ * layer activation, :147-151: Linear-ReLU-Linear-ReLU) and, with mask1 = the saved hidden activation, the two input-
+ * gradient products of its backward.  W1n / W2n are [H][H] with k contiguous (nn.Linear.weight for the forward, its
+ * transpose for the backward); b1 / b2 may be NULL.  Y1 is written but never re-read.  H in {64, 128, 256}. */
+int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask1,
+                        const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2, dn_stream_t stream);
+
 /* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
  * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the
  * `mask_pos` epilogue of dn_rows_transform_bf16 ([rows, Ho] saved activations), so a Linear's input gradient comes

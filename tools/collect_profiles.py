@@ -31,14 +31,12 @@ STEP = [
     ("rows_transform_kernel", "conv transform fwd, edge rows (gathers x rows)"),
     ("gather_segsum_vec_kernel", "overflow rows of nodes with > 6 incoming rows (fwd)"),
     ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum"),
-    ("rows_transform_kernel", "MLP linear 1 fwd (+bias+ReLU)"),
-    ("rows_transform_kernel", "MLP linear 2 fwd (+bias+ReLU)"),
+    ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass"),
     ("rows_wgrad_kernel", "MLP wgrad 2 (+outer ReLU mask, saves masked g)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
-    ("rows_transform_kernel", "MLP dgrad 2 (+ReLU mask epilogue)"),
+    ("rows_chain2_kernel", "MLP input gradients: dgrad 2 (+ReLU mask) and dgrad 1 in one pass"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
-    ("rows_transform_kernel", "MLP dgrad 1"),
     ("gather_segsum_vec_kernel", "aux pre-aggregation (bwd)"),
     ("rows_transform_kernel", "conv transform bwd, edge rows (gathers g rows)"),
     ("gather_segsum_vec_kernel", "overflow rows (bwd)"),
@@ -46,8 +44,8 @@ STEP = [
     ("rows_wgrad_dma_kernel", "conv wgrad (LDS-DMA ring; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
-CONV_ROWS = (0, 1, 2, 3, 12, 13, 14, 15)
-OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "rows_wgrad_dma_kernel",
+CONV_ROWS = (0, 1, 2, 3, 10, 11, 12, 13)
+OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "rows_chain2_kernel", "rows_wgrad_dma_kernel",
         "rows_wgrad_kernel", "wgrad_reduce_kernel")
 
 
@@ -143,7 +141,7 @@ def main():
         f.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE KB (a wide coalesced read is half-counted); WRITE_SIZE exact. durations under PMC collection (us)\n")
         f.write("kernel,role,hbm_read_MB,hbm_write_MB,hbm_total_MB,duration_us,TB_per_s\n")
         f.write("\n".join(lines) + "\n")
-        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-4 and 13-16): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
+        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-4 and 11-14): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
                 % (tot, conv, alg / 1e6, conv * 1e6 / alg))
     with open(os.path.join(a.out, a.tag + "_traffic.json"), "w") as f:
         json.dump({"workload": "config5", "N": N, "E": E, "H": H, "dtype": "bf16",

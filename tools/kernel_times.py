@@ -17,9 +17,9 @@ f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 by = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if any(k in n for k in ("wgrad", "rows_transform", "rows_selfsum", "gather_segsum_vec")):
+    if any(k in n for k in ("wgrad", "rows_transform", "rows_selfsum", "rows_chain2", "gather_segsum_vec")):
         import re
-        m = re.search(r"(rows_wgrad_dma_kernel|rows_wgrad_kernel|wgrad_reduce_kernel|rows_transform_kernel|rows_selfsum_kernel|gather_segsum_vec_kernel)(<[^>]*>)?", n)
+        m = re.search(r"(rows_wgrad_dma_kernel|rows_wgrad_kernel|wgrad_reduce_kernel|rows_transform_kernel|rows_selfsum_kernel|rows_chain2_kernel|gather_segsum_vec_kernel)(<[^>]*>)?", n)
         key = (m.group(0) if m else n[:60]) + (" f32" if ("float" in n and "segsum" in n) else "")
         by[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in sorted(by.items()):
