@@ -483,6 +483,52 @@ def neighbor_sum(x, index, self_coef=0.0, edge_scale=None):
     return _NeighborSum.apply(x, index, self_coef, edge_scale)
 
 
+class _EdgeSum(torch.autograd.Function):
+    """agg[v] = sum_{e: dst(e)=v} w_e ef[e]   (edge rows summed onto their destination: the reduce half of a dual
+    message pass, compgcn.py:272 / dmpnn.py:163); backward: g_ef[e] = w_e g[dst(e)] (a row gather)."""
+
+    @staticmethod
+    def forward(ctx, ef, index, edge_scale):
+        ef = ef.contiguous()
+        ctx.index = index
+        sc_in = edge_scale.index_select(0, index.in_perm.long()) if edge_scale is not None else None
+        ctx.save_for_backward(edge_scale if edge_scale is not None else ef.new_empty(0))
+        ctx.has_scale = edge_scale is not None
+        return gather_segsum(ef, index.in_perm, index.in_ptr, index.num_nodes, scale=sc_in)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return gather_segsum(g.contiguous(), ctx.index.dst, None, scale=scale if ctx.has_scale else None), None, None
+
+
+def edge_sum(ef, index, edge_scale=None):
+    """sum of (scaled) edge rows per destination node; edge_scale [E] fp32 (no gradient) in edge order."""
+    return _EdgeSum.apply(ef, index, edge_scale)
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[i] = x[idx[i]]; backward = deterministic segment sum over the rows that gathered each x row (CSR of idx)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, csr):
+        ctx.csr, ctx.n = csr, x.shape[0]
+        return gather_segsum(x.contiguous(), idx, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        ptr_, perm = ctx.csr
+        return gather_segsum(g.contiguous(), perm, ptr_, ctx.n), None, None
+
+
+def gather_rows(x, idx, csr=None):
+    """x[idx] with a reproducible backward.  csr = csr_build(idx, x.shape[0]) may be passed in when it is cached."""
+    idx = idx.to(I32).contiguous()
+    if csr is None:
+        csr = csr_build(idx, x.shape[0])
+    return _GatherRows.apply(x, idx, csr)
+
+
 def edge_dot(a, ia, b, ib):
     """out[e] = <a[ia[e]], b[ib[e]]>  (dn_edge_dot_*), fp32."""
     require_gpu(a, ia, b, ib)

@@ -323,3 +323,93 @@ def split_and_batchify_graph_feats(batched_graph_feats, graph_sizes, pre_pad=Fal
             mask[i, :l] = True
         idx += l
     return th.cat(feats, 0).view(bsz, mx, -1), mask
+
+
+# --------------------------------------------------------------------------------------
+# f-4  dual message passing: CompGCNLayer / DMPLayer
+# reference: subgraph_isomorphism/models/compgcn.py:104-283, models/dmpnn.py:16-187
+# --------------------------------------------------------------------------------------
+def _deg_norm(deg, self_loop):
+    """(deg + 1)^-1 with a self loop, else deg^-1 with 1.0 where deg == 0 (compgcn.py:180-196)."""
+    deg = deg.to(th.float32)
+    if self_loop:
+        return (deg + 1).reciprocal().unsqueeze(-1)
+    return deg.reciprocal().masked_fill(deg == 0, 1.0).unsqueeze(-1)
+
+
+def _circular_correlation(a, b):
+    """irfft(conj(rfft(a)) * rfft(b)) along the feature axis (compgcn.py:216-220)."""
+    n = a.shape[-1]
+    return th.fft.irfft(th.conj(th.fft.rfft(a, dim=-1)) * th.fft.rfft(b, dim=-1), n=n, dim=-1)
+
+
+def compose(head, relation, comp_opt):
+    if comp_opt == "sub":
+        return head - relation
+    if comp_opt == "mult":
+        return head * relation
+    if comp_opt == "corr":
+        return _circular_correlation(head, relation.expand_as(head) if relation.shape[0] == 1 else relation)
+    raise NotImplementedError(comp_opt)
+
+
+def compgcn_layer(x, ef, src, dst, rev, p, comp_opt="mult", edge_norm="both", act="relu"):
+    """-> (node_out, edge_out).  rev: bool [E] or None (no REVFLAG on the graph); p: parameter dict (loop_weight absent =
+    no self loop).  Messages per edge, evaluated exactly as the reference's message function."""
+    N = x.shape[0]
+    self_loop = p.get("loop_weight") is not None
+    in_deg, out_deg = th.bincount(dst, minlength=N), th.bincount(src, minlength=N)
+    comp = compose(x[src], ef, comp_opt)
+    msg = comp @ p["in_weight"]
+    if rev is not None:
+        msg = th.where(rev.view(-1, 1), comp @ p["out_weight"], msg)                         # compgcn.py:227-230
+    if edge_norm == "in":
+        msg = msg * _deg_norm(in_deg, self_loop)[dst]
+    elif edge_norm == "out":
+        msg = msg * _deg_norm(out_deg, self_loop)[src]
+    elif edge_norm == "both":
+        msg = msg * (_deg_norm(out_deg, self_loop)[src] * _deg_norm(in_deg, self_loop)[dst]) ** 0.5
+    agg = segment_sum(msg, dst, N)
+    if self_loop:
+        out = (agg + compose(x, p["loop_rel"], comp_opt) @ p["loop_weight"]) * 0.3333333      # :240-244
+    else:
+        out = agg * 0.5
+    if p.get("bias") is not None:
+        out = out + p["bias"]
+    return act_fn(act)(out), ef @ p["rel_weight"]
+
+
+def _mlp_or_act(h, p, prefix, num_mlp_layers, act):
+    """Linear(-act-Linear)* when the layer has an MLP (NO activation after the last Linear), else the activation."""
+    f = act_fn(act)
+    if num_mlp_layers == 0:
+        return f(h)
+    idx = 0
+    for i in range(num_mlp_layers):
+        h = h @ p["%s.%d.weight" % (prefix, idx)].t() + p["%s.%d.bias" % (prefix, idx)]
+        idx += 1
+        if i != num_mlp_layers - 1:
+            h = f(h)
+            idx += 1                                    # batch_norm=False: Sequential index skips only the activation
+    return h
+
+
+def dmp_layer(x, ef, src, dst, rev, p, num_mlp_layers=2, act="relu"):
+    """-> (node_out, edge_out) of DMPLayer (batch_norm=False), dmpnn.py:111-169."""
+    N = x.shape[0]
+    out_deg = th.bincount(src, minlength=N)
+    edge_msg = x[dst] @ p["dst_weight"] - x[src] @ p["src_weight"]
+    node_msg = -(ef @ p["in_weight"])
+    if rev is not None:
+        r = rev.view(-1, 1)
+        edge_msg = th.where(r, x[src] @ p["dst_weight"] - x[dst] @ p["src_weight"], edge_msg)
+        node_msg = th.where(r, ef @ p["out_weight"], node_msg)
+    h = x @ p["nloop_weight"] + segment_sum(node_msg, dst, N)
+    if p.get("nbias") is not None:
+        h = h + p["nbias"]
+    node_out = _mlp_or_act(h, p, "nmlp", num_mlp_layers, act)
+    d = (1 + out_deg[dst].unsqueeze(-1).float()).log2()
+    e = ef @ p["eloop_weight"] + 2 * (1 + d) * (ef @ (p["src_weight"] - p["dst_weight"])) + edge_msg
+    if p.get("ebias") is not None:
+        e = e + p["ebias"]
+    return node_out, _mlp_or_act(e, p, "emlp", num_mlp_layers, act)

@@ -15,6 +15,7 @@ The reference's Python is imported unmodified, with the absent third-party modul
                        convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
   si_bookkeeping.json  f-2 get_conjugate_subisomorphisms, compute_{nodeseq,edgeseq}_subisoweights, compute_norm,
                        compute_largest_eigenvalues, add_reversed_edges
+  si_dual_layers.npz   f-4 CompGCNLayer / DMPLayer: node and edge outputs + all gradients
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
                        all gradients over the regulariser x act x self_loop x edge_norm grid
 
@@ -329,6 +330,74 @@ def make_si_bookkeeping():
     print("si_bookkeeping.json: %d cases + %d reversed items" % (len(cases), len(items)))
 
 
+def make_si_dual_layers():
+    """f-4: CompGCNLayer (models/compgcn.py:104-283) and DMPLayer (models/dmpnn.py:16-187): node AND edge outputs, all
+    gradients, with and without reversed-edge flags."""
+    _si_modules()
+    compgcn = importlib.import_module("models.compgcn")
+    dmpnn = importlib.import_module("models.dmpnn")
+    rng = np.random.default_rng(41)
+    out, meta = {}, []
+
+    def run(tag, layer, N, E, H, rev):
+        u, v = rng.integers(0, N, size=E), rng.integers(0, N, size=E)
+        g = S.FakeDGLGraph(u, v, N)
+        if rev:
+            g.edata["is_reversed"] = th.from_numpy(rng.random(E) < 0.5)
+        x = th.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).requires_grad_(True)
+        ef = th.from_numpy(rng.standard_normal((E, H)).astype(np.float32)).requires_grad_(True)
+        c1 = th.from_numpy(rng.standard_normal((N, layer.hidden_dim)).astype(np.float32))
+        c2 = th.from_numpy(rng.standard_normal((E, layer.hidden_dim)).astype(np.float32))
+        layer.train()
+        no, eo = layer(g, x, ef)
+        ((no * c1).sum() + (eo * c2).sum()).backward()
+        out[tag + "/u"], out[tag + "/v"] = u.astype(np.int64), v.astype(np.int64)
+        if rev:
+            out[tag + "/rev"] = g.edata["is_reversed"].numpy()
+        for k, t in (("x", x), ("ef", ef), ("c1", c1), ("c2", c2), ("node_out", no), ("edge_out", eo)):
+            out[tag + "/" + k] = t.detach().numpy()
+        out[tag + "/grad_x"], out[tag + "/grad_ef"] = x.grad.numpy(), ef.grad.numpy()
+        for k, p in layer.named_parameters():
+            out[tag + "/param/" + k] = p.detach().numpy()
+            out[tag + "/grad/" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+
+    cid = 0
+    for comp in ("sub", "mult", "corr"):
+        for norm in ("none", "in", "out", "both"):
+            for self_loop, rev in ((True, True), (False, False)) if norm in ("none", "both") else ((True, False), (False, True)):
+                tag = "comp%02d" % cid
+                kw = dict(self_loop=self_loop, comp_opt=comp, edge_norm=norm, act_func="relu" if cid % 2 else "tanh")
+                th.manual_seed(2000 + cid)
+                layer = compgcn.CompGCNLayer(16, 16, **kw)
+                meta.append(dict(tag=tag, kind="compgcn", H=16, N=20, E=70, rev=rev, **kw))
+                run(tag, layer, 20, 70, 16, rev)
+                cid += 1
+    for nmlp, rev, act in ((2, True, "relu"), (2, False, "relu"), (0, True, "tanh"), (1, False, "leaky_relu")):
+        tag = "dmp%02d" % cid
+        kw = dict(num_mlp_layers=nmlp, batch_norm=False, act_func=act)
+        th.manual_seed(2000 + cid)
+        layer = dmpnn.DMPLayer(16, 16, **kw)
+        meta.append(dict(tag=tag, kind="dmp", H=16, N=20, E=70, rev=rev, **kw))
+        run(tag, layer, 20, 70, 16, rev)
+        cid += 1
+    # matrix-core width
+    for kind in ("compgcn", "dmp"):
+        tag = "%s%02d" % ("comp" if kind == "compgcn" else "dmp", cid)
+        th.manual_seed(2000 + cid)
+        if kind == "compgcn":
+            kw = dict(self_loop=True, comp_opt="mult", edge_norm="both", act_func="relu")
+            layer = compgcn.CompGCNLayer(64, 64, **kw)
+        else:
+            kw = dict(num_mlp_layers=2, batch_norm=False, act_func="relu")
+            layer = dmpnn.DMPLayer(64, 64, **kw)
+        meta.append(dict(tag=tag, kind=kind, H=64, N=300, E=1200, rev=True, **kw))
+        run(tag, layer, 300, 1200, 64, True)
+        cid += 1
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "si_dual_layers.npz"), **out)
+    print("si_dual_layers.npz: %d cases" % len(meta))
+
+
 def make_si_layers():
     _si_modules()
     rgin = importlib.import_module("models.rgin")
@@ -411,4 +480,5 @@ if __name__ == "__main__":
     make_tu_files()
     make_si_transforms()
     make_si_bookkeeping()
+    make_si_dual_layers()
     make_si_layers()

@@ -418,3 +418,71 @@ def test_gc_rgin_bf16_runs_on_the_fused_path():
     out.float().sum().backward()
     want = _oracle_gc_forward(ref, data, "RGIN")
     assert _rel_l2(out.float().exp(), want.exp()) < 5e-2          # class probabilities after two bf16 layers + BN
+
+
+def test_dual_layers_match_reference_goldens(golden_dir):
+    """f-4: CompGCNLayer / DMPLayer (node AND edge outputs, every gradient) against the reference's own runs, fp32 1e-4."""
+    from dummynode4graphlearning_amd import BatchedGraph
+    from dummynode4graphlearning_amd.subgraph_isomorphism import CompGCNLayer, DMPLayer
+    z = np.load(os.path.join(golden_dir, "si_dual_layers.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    worst = 0.0
+    for m in meta:
+        tag, H = m["tag"], m["H"]
+        if m["kind"] == "compgcn":
+            layer = CompGCNLayer(H, H, self_loop=m["self_loop"], comp_opt=m["comp_opt"], edge_norm=m["edge_norm"],
+                                 act_func=m["act_func"])
+        else:
+            layer = DMPLayer(H, H, num_mlp_layers=m["num_mlp_layers"], batch_norm=False, act_func=m["act_func"])
+        sd = {k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}
+        layer.load_state_dict(sd, strict=True)
+        layer = layer.to(DEV).train()
+        g = BatchedGraph(torch.from_numpy(z[tag + "/u"]).to(DEV), torch.from_numpy(z[tag + "/v"]).to(DEV), m["N"])
+        if m["rev"]:
+            g.edata["is_reversed"] = torch.from_numpy(z[tag + "/rev"]).to(DEV)
+        x = torch.from_numpy(z[tag + "/x"]).to(DEV).requires_grad_(True)
+        ef = torch.from_numpy(z[tag + "/ef"]).to(DEV).requires_grad_(True)
+        no, eo = layer(g, x, ef)
+        ((no * torch.from_numpy(z[tag + "/c1"]).to(DEV)).sum() + (eo * torch.from_numpy(z[tag + "/c2"]).to(DEV)).sum()).backward()
+        errs = {"node_out": _rel_max(no, torch.from_numpy(z[tag + "/node_out"])),
+                "edge_out": _rel_max(eo, torch.from_numpy(z[tag + "/edge_out"])),
+                "grad_x": _rel_max(x.grad, torch.from_numpy(z[tag + "/grad_x"])),
+                "grad_ef": _rel_max(ef.grad, torch.from_numpy(z[tag + "/grad_ef"]))}
+        for k, p in layer.named_parameters():
+            ref = z[tag + "/grad/" + k]
+            if ref.size and np.abs(ref).max() > 0:
+                errs["grad " + k] = _rel_max(p.grad, torch.from_numpy(ref))
+        for k, e in errs.items():
+            assert e < RTOL, "%s %s rel_max %.3e" % (tag, k, e)
+            worst = max(worst, e)
+    print("worst rel_max over %d dual-layer golden cases: %.3e" % (len(meta), worst))
+
+
+@pytest.mark.parametrize("kind", ["compgcn", "dmp"])
+def test_dual_layers_bf16_run_on_the_matrix_cores(kind):
+    """bf16 storage (H = 64: the dense products take the MFMA Linear kernels) against the oracle in fp64 on the same
+    bf16-rounded parameters and inputs."""
+    from dummynode4graphlearning_amd import BatchedGraph
+    from dummynode4graphlearning_amd.subgraph_isomorphism import CompGCNLayer, DMPLayer
+    rng = np.random.default_rng(3)
+    N, E, H = 400, 1600, 64
+    u, v = torch.from_numpy(rng.integers(0, N, size=E)), torch.from_numpy(rng.integers(0, N, size=E))
+    rev = torch.from_numpy(rng.random(E) < 0.5)
+    torch.manual_seed(1)
+    layer = (CompGCNLayer(H, H, comp_opt="mult", edge_norm="both", act_func="relu") if kind == "compgcn"
+             else DMPLayer(H, H, num_mlp_layers=2, batch_norm=False, act_func="relu")).to(torch.bfloat16)
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(torch.bfloat16)
+    ef = torch.from_numpy(rng.standard_normal((E, H)).astype(np.float32)).to(torch.bfloat16)
+    p64 = {k: t.detach().double() for k, t in layer.named_parameters()}
+    dl = layer.to(DEV)
+    g = BatchedGraph(u.to(DEV), v.to(DEV), N)
+    g.edata["is_reversed"] = rev.to(DEV)
+    xd, efd = x.to(DEV).requires_grad_(True), ef.to(DEV).requires_grad_(True)
+    no, eo = dl(g, xd, efd)
+    (no.float().sum() + eo.float().sum()).backward()
+    assert no.dtype == torch.bfloat16 and eo.dtype == torch.bfloat16 and xd.grad is not None and efd.grad is not None
+    if kind == "compgcn":
+        rn, re = OL.compgcn_layer(x.double(), ef.double(), u, v, rev, p64, comp_opt="mult", edge_norm="both", act="relu")
+    else:
+        rn, re = OL.dmp_layer(x.double(), ef.double(), u, v, rev, p64, num_mlp_layers=2, act="relu")
+    assert _rel_l2(no, rn) < 3e-2 and _rel_l2(eo, re) < 3e-2

@@ -383,3 +383,35 @@ def test_oracle_si_bookkeeping_matches_reference(golden_dir):
             assert r["src"].tolist() == after[k]["u"] and r["dst"].tolist() == after[k]["v"]
             assert r["edge_id"].tolist() == after[k]["e_id"] and r["edge_label"].tolist() == after[k]["e_label"]
             assert r["is_reversed"].tolist() == after[k]["e_is_reversed"]
+
+
+def test_oracle_dual_layers_match_reference(golden_dir):
+    """f-4: CompGCNLayer / DMPLayer restatements against the reference's outputs and gradients (fp32, 1e-5 rel-max)."""
+    import torch
+    from oracle import layers as OL
+    z = np.load(os.path.join(golden_dir, "si_dual_layers.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    worst = 0.0
+    for m in meta:
+        tag = m["tag"]
+        p = {k[len(tag) + 7:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(tag + "/param/")}
+        u, v = torch.from_numpy(z[tag + "/u"]), torch.from_numpy(z[tag + "/v"])
+        rev = torch.from_numpy(z[tag + "/rev"]) if m["rev"] else None
+        x = torch.from_numpy(z[tag + "/x"]).clone().requires_grad_(True)
+        ef = torch.from_numpy(z[tag + "/ef"]).clone().requires_grad_(True)
+        if m["kind"] == "compgcn":
+            no, eo = OL.compgcn_layer(x, ef, u, v, rev, p, comp_opt=m["comp_opt"], edge_norm=m["edge_norm"], act=m["act_func"])
+        else:
+            no, eo = OL.dmp_layer(x, ef, u, v, rev, p, num_mlp_layers=m["num_mlp_layers"], act=m["act_func"])
+        ((no * torch.from_numpy(z[tag + "/c1"])).sum() + (eo * torch.from_numpy(z[tag + "/c2"])).sum()).backward()
+        pairs = [(no, z[tag + "/node_out"]), (eo, z[tag + "/edge_out"]), (x.grad, z[tag + "/grad_x"]), (ef.grad, z[tag + "/grad_ef"])]
+        for k, t in p.items():
+            ref = z[tag + "/grad/" + k]
+            if ref.size and np.abs(ref).max() > 0:
+                pairs.append((t.grad, ref))
+        for a, b in pairs:
+            b = torch.from_numpy(np.asarray(b))
+            err = float((a.detach() - b).abs().max() / b.abs().max().clamp(min=1e-12))
+            assert err < 2e-5, (tag, err)
+            worst = max(worst, err)
+    assert len(meta) == 30
