@@ -40,5 +40,8 @@ def split_and_batchify_graph_feats(batched_graph_feats, graph_sizes, pre_pad=Fal
     row_slot = th.nonzero(flat).reshape(-1).to(th.int32)                  # padded slot of every real row (row order kept)
     slot_src = th.arange(row_slot.numel(), device=device, dtype=th.int32)
     x2 = batched_graph_feats.reshape(batched_graph_feats.shape[0], -1)
+    if not x2.is_floating_point():                                        # flags / ids (e.g. the dummy mask, basemodel.py:907)
+        feats = _PadRows.apply(x2.float(), slot_ptr, slot_src, row_slot, (bsz, max_size, x2.shape[1]))
+        return feats.to(batched_graph_feats.dtype), mask
     feats = _PadRows.apply(x2, slot_ptr, slot_src, row_slot, (bsz, max_size, x2.shape[1]))
     return feats, mask

@@ -42,12 +42,29 @@ def xavier_uniform_init(x, gain=1.0):
     return nn.init.uniform_(x, -a, a)
 
 
+def kaiming_normal_init(x, gain=1.0):
+    """init.py:75-78: N(0, gain / sqrt(fan_in)) with the reference's own fan computation."""
+    fan_in, _ = calculate_fan_in_and_fan_out(x)
+    return nn.init.normal_(x, 0, gain / math.sqrt(fan_in))
+
+
 def init_weight(x, activation="none", init="uniform"):
-    """init.py:125-143 (only the 'uniform' and 'zero' branches are reachable from RGIN/RGCN layers)."""
+    """init.py:125-143 ('uniform', 'normal' and 'zero' are the branches the built layers reach)."""
     gain = calculate_gain(activation)
     if init == "uniform":
         xavier_uniform_init(x, gain=gain)
+    elif init == "normal":
+        kaiming_normal_init(x, gain=gain)
     elif init == "zero":
         nn.init.zeros_(x)
     else:
         raise ValueError("init=%s is not supported now." % init)
+
+
+def init_module(x, activation="none", init="uniform"):
+    """init.py:146-166 for nn.Linear: weight by `init`, bias zero."""
+    if not isinstance(x, nn.Linear):
+        raise ValueError("init_module: only nn.Linear is built")
+    init_weight(x.weight, activation=activation, init=init)
+    if x.bias is not None:
+        nn.init.zeros_(x.bias)

@@ -16,6 +16,7 @@ The reference's Python is imported unmodified, with the absent third-party modul
   si_bookkeeping.json  f-2 get_conjugate_subisomorphisms, compute_{nodeseq,edgeseq}_subisoweights, compute_norm,
                        compute_largest_eigenvalues, add_reversed_edges
   si_dual_layers.npz   f-4 CompGCNLayer / DMPLayer: node and edge outputs + all gradients
+  si_pred.npz          f-4 SumPredictNet / MeanPredictNet with the dummy-masked padded inputs
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
                        all gradients over the regulariser x act x self_loop x edge_norm grid
 
@@ -398,6 +399,48 @@ def make_si_dual_layers():
     print("si_dual_layers.npz: %d cases" % len(meta))
 
 
+def make_si_pred():
+    """f-4: SumPredictNet / MeanPredictNet (models/pred.py:17-216) on padded representations, with the dummy masking of
+    basemodel.py:905-912 applied to the masks (split_and_batchify_graph_feats from utils/dl.py)."""
+    _si_modules()
+    pred = importlib.import_module("models.pred")
+    dl = importlib.import_module("utils.dl")
+    rng = np.random.default_rng(51)
+    out, meta = {}, []
+    for cid, (cls, rw, act) in enumerate((("SumPredictNet", False, "relu"), ("SumPredictNet", True, "tanh"),
+                                          ("MeanPredictNet", True, "relu"))):
+        tag = "pred%02d" % cid
+        th.manual_seed(3000 + cid)
+        net = getattr(pred, cls)(12, 16, act_func=act, return_weights=rw)
+        with th.no_grad():                       # pred_fc2 / weight_fc2 are zero-initialised: perturb so gradients flow
+            for p in net.parameters():
+                p.add_(0.05 * th.randn_like(p))
+        B = 5
+        p_len, g_len = th.from_numpy(rng.integers(2, 5, size=B)), th.from_numpy(rng.integers(3, 9, size=B))
+        p_flat = th.from_numpy(rng.standard_normal((int(p_len.sum()), 12)).astype(np.float32)).requires_grad_(True)
+        g_flat = th.from_numpy(rng.standard_normal((int(g_len.sum()), 12)).astype(np.float32)).requires_grad_(True)
+        g_dummy = th.zeros(int(g_len.sum()), dtype=th.bool)
+        g_dummy[th.cumsum(g_len, 0) - 1] = True                              # last vertex of every graph is the dummy
+        p_rep, p_mask = dl.split_and_batchify_graph_feats(p_flat, p_len, pre_pad=True)
+        g_rep, g_mask = dl.split_and_batchify_graph_feats(g_flat, g_len, pre_pad=True)
+        g_mask = g_mask.masked_fill(dl.split_and_batchify_graph_feats(g_dummy.view(-1, 1), g_len, pre_pad=True)[0].view(g_mask.shape), 0)
+        y, w = net(p_rep, p_mask, g_rep, g_mask)
+        loss = (y * th.arange(1, B + 1).view(-1, 1).float()).sum() + (w.sum() if w is not None else 0.0)
+        loss.backward()
+        for k, t in (("p_len", p_len), ("g_len", g_len), ("p_flat", p_flat), ("g_flat", g_flat), ("g_dummy", g_dummy),
+                     ("g_mask", g_mask), ("y", y), ("grad_p", p_flat.grad), ("grad_g", g_flat.grad)):
+            out[tag + "/" + k] = t.detach().numpy()
+        if w is not None:
+            out[tag + "/w"] = w.detach().numpy()
+        for k, p in net.named_parameters():
+            out[tag + "/param/" + k] = p.detach().numpy()
+            out[tag + "/grad/" + k] = p.grad.numpy()
+        meta.append(dict(tag=tag, cls=cls, return_weights=rw, act_func=act))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "si_pred.npz"), **out)
+    print("si_pred.npz: %d cases" % len(meta))
+
+
 def make_si_layers():
     _si_modules()
     rgin = importlib.import_module("models.rgin")
@@ -481,4 +524,5 @@ if __name__ == "__main__":
     make_si_transforms()
     make_si_bookkeeping()
     make_si_dual_layers()
+    make_si_pred()
     make_si_layers()

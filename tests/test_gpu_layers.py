@@ -486,3 +486,33 @@ def test_dual_layers_bf16_run_on_the_matrix_cores(kind):
     else:
         rn, re = OL.dmp_layer(x.double(), ef.double(), u, v, rev, p64, num_mlp_layers=2, act="relu")
     assert _rel_l2(no, rn) < 3e-2 and _rel_l2(eo, re) < 3e-2
+
+
+def test_predict_nets_match_reference_goldens(golden_dir):
+    """f-4: ragged -> padded (HIP gather) -> dummy masking -> Sum/MeanPredictNet against the reference's run: masks exact,
+    outputs and every gradient (through the padding op) to 1e-4."""
+    from dummynode4graphlearning_amd import subgraph_isomorphism as SI
+    z = np.load(os.path.join(golden_dir, "si_pred.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    for m in meta:
+        tag = m["tag"]
+        net = getattr(SI, m["cls"])(12, 16, act_func=m["act_func"], return_weights=m["return_weights"])
+        net.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}, strict=True)
+        net = net.to(DEV)
+        t = lambda k: torch.from_numpy(z[tag + "/" + k]).to(DEV)  # noqa: E731
+        p_flat, g_flat = t("p_flat").requires_grad_(True), t("g_flat").requires_grad_(True)
+        p_rep, p_mask = SI.split_and_batchify_graph_feats(p_flat, t("p_len"), pre_pad=True)
+        g_rep, g_mask = SI.split_and_batchify_graph_feats(g_flat, t("g_len"), pre_pad=True)
+        g_mask = SI.mask_dummy_nodes(g_mask, t("g_dummy"), t("g_len"))
+        assert np.array_equal(g_mask.cpu().numpy(), z[tag + "/g_mask"])
+        y, w = net(p_rep, p_mask, g_rep, g_mask)
+        B = y.shape[0]
+        loss = (y * torch.arange(1, B + 1, device=DEV).view(-1, 1).float()).sum() + (w.sum() if w is not None else 0.0)
+        loss.backward()
+        assert _rel_max(y, torch.from_numpy(z[tag + "/y"])) < RTOL
+        if w is not None:
+            assert _rel_max(w, torch.from_numpy(z[tag + "/w"])) < RTOL
+        assert _rel_max(p_flat.grad, torch.from_numpy(z[tag + "/grad_p"])) < RTOL
+        assert _rel_max(g_flat.grad, torch.from_numpy(z[tag + "/grad_g"])) < RTOL
+        for k, p in net.named_parameters():
+            assert _rel_max(p.grad, torch.from_numpy(z[tag + "/grad/" + k])) < RTOL, (tag, k)
