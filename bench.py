@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--workload", default="config5", choices=["config5", "config3"])
     ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (0 = the workload's own size)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
+    ap.add_argument("--hidden", type=int, default=0, help="override the workload's hidden size (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
@@ -123,6 +124,8 @@ def main():
         H, R, graphs, dtype = 256, 16, args.graphs or 32768, torch.bfloat16
     else:
         H, R, graphs, dtype = 64, 8, args.graphs or 512, torch.float32
+    if args.hidden:
+        H = args.hidden
     if args.dtype:
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     s = 2 if dtype == torch.bfloat16 else 4

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 //     s_waitcnt vmcnt(GL * (NST - 2)) followed by ONE raw s_barrier per tile (never __syncthreads(): its fence would
 //     drain the ring).  Rows past the end of the chunk read a zero row, tiles past the end are issued as zero tiles so
 //     the count stays static; the ring is drained (vmcnt(0)) before the LDS is reused or the workgroup ends.
-//   * used when no ReLU mask is folded in (maskA == NULL); H in {128, 256}.
+//   * used when no ReLU mask is folded in (maskA == NULL); H in {128, 256} (64-row stages at H = 128: same bytes per stage).
 // -------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint4 g_zero_row[64];        // 1 KiB of zeros (device globals are zero-initialised)
 
@@ -257,14 +257,15 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                                                                     float* __restrict__ partial, int32_t colsum_of,
                                                                     float* __restrict__ colsum_partial) {
     static_assert(H == 256 || H == 128, "unsupported width");
-    constexpr int TR = 32;                         // rows per stage (one MFMA K-step)
-    constexpr int NST = (H == 256) ? 4 : 8;        // ring stages (128 KiB)
+    constexpr int TR = (H == 256) ? 32 : 64;       // rows per stage: 32 KiB per stage at either width (1 or 2 MFMA K-steps)
+    constexpr int NST = 4;                         // ring stages (128 KiB)
     constexpr int ROWB = 2 * H;                    // bytes per row
     constexpr int MATB = TR * ROWB;                // bytes per operand per stage
     constexpr int STB = 2 * MATB;
     constexpr int LPRW = H / 8;                    // lanes (16-byte pieces) per row
     constexpr int RPI = 64 / LPRW;                 // rows per DMA wave-instruction (2 or 4)
-    constexpr int PPW = 4 / RPI;                   // DMA instructions per wave, operand and tile (each wave stages 4 rows)
+    constexpr int RW = TR / 8;                     // rows of each operand a wave stages per tile (4 or 8)
+    constexpr int PPW = RW / RPI;                  // DMA instructions per wave, operand and tile
     constexpr int GL = 2 * PPW;                    // DMA instructions per wave and tile
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
@@ -279,28 +280,28 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
 
     // ---- DMA side: this lane's place in a piece ---------------------------------------------------------------
     const int rin = lane / LPRW, cpos = lane % LPRW;
-    int32_t nxa[4], nxg[4];                        // wave-uniform source rows of the next tile to issue
+    int32_t nxa[RW], nxg[RW];                      // wave-uniform source rows of the next tile to issue
     auto load_idx = [&](int T) {                   // scalar loads (wave-uniform addresses), branch-free
-        const int p0 = ch.beg + T * TR + 4 * wave, pe = ch.end - 1;
-        int32_t pc[4];
+        const int p0 = ch.beg + T * TR + RW * wave, pe = ch.end - 1;
+        int32_t pc[RW];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pc[k] = min(p0 + k, pe);
+        for (int k = 0; k < RW; ++k) pc[k] = min(p0 + k, pe);
         if (ia) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxa[k] = ia[pc[k]];
+            for (int k = 0; k < RW; ++k) nxa[k] = ia[pc[k]];
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxa[k] = pc[k];
+            for (int k = 0; k < RW; ++k) nxa[k] = pc[k];
         }
         if (ig) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxg[k] = ig[pc[k]];
+            for (int k = 0; k < RW; ++k) nxg[k] = ig[pc[k]];
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxg[k] = pc[k];
+            for (int k = 0; k < RW; ++k) nxg[k] = pc[k];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RW; ++k) {
             const bool ok = p0 + k <= pe;          // rows past the chunk end (and whole tiles past it) read the zero row
             nxa[k] = ok ? nxa[k] : -1;
             nxg[k] = ok ? nxg[k] : -1;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
         const unsigned st = lds_base + (unsigned)(T % NST) * STB;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int rl = 4 * wave + RPI * j + rin;                       // row of the stage this lane fills
+            const int rl = RW * wave + RPI * j + rin;                      // row of the stage this lane fills
             const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
             const int gch = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;     // source byte offset inside the row
             int32_t ra = nxa[RPI * j], rg = nxg[RPI * j];
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                                                        : reinterpret_cast<const char*>(A2) + (size_t)(ra - na1) * ROWB);
             const char* pg = rg < 0 ? zero : (rg < ng1 ? reinterpret_cast<const char*>(G) + (size_t)rg * ROWB
                                                        : reinterpret_cast<const char*>(G2) + (size_t)(rg - ng1) * ROWB);
-            const unsigned da = st + (unsigned)(4 * wave + RPI * j) * ROWB; // wave-uniform; lane l lands at + 16 l
+            const unsigned da = st + (unsigned)(RW * wave + RPI * j) * ROWB; // wave-uniform; lane l lands at + 16 l
             glds16(pa + gch, da);
             glds16(pg + gch, da + MATB);
         }
@@ -371,14 +372,17 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
         load_idx(t + NST);
         const char* sA = lds + (t % NST) * STB;
         const char* sG = sA + MATB;
-        bf16x8 fb[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[n] = frag(sG, wn * NT + n);
+        for (int kk = 0; kk < TR / 32; ++kk) {
+            bf16x8 fb[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bf16x8 fa = frag(sA, wm * MT + m);
+            for (int n = 0; n < NT; ++n) fb[n] = frag(sG + kk * 32 * ROWB, wn * NT + n);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 fa = frag(sA + kk * 32 * ROWB, wm * MT + m);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+            }
         }
         if (colsum_of != 0) {
             const char* M = colsum_of == 1 ? sA : sG;
@@ -934,7 +938,9 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     // them out of L2 / Infinity Cache is worth 1.5-2 % of the step (DN_NT=0 turns it off: bit 0 transform, bit 1 selfsum)
     static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
     relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0);
-    const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? 2 : 1);
+    // workgroups per CU: a tile is 32 rows x 2*HI bytes, so narrower rows need more workgroups in flight to keep the same
+    // bytes per CU outstanding (H = 128: 64 VGPRs, 26 KB LDS -> 4 fit; measured 2.24 -> 2.07 ms per step at H = 128)
+    const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? (HI <= 128 ? 4 : 2) : 1);
     const int64_t max_wg = 256 * per_cu;
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
@@ -990,12 +996,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-bool wgrad_dma_enabled() {
-    static const bool on = [] {
+// DN_WGRAD_DMA: 0 = never, 1 (default) = at H = 256 (where the register-staged kernel is pinned at one workgroup per CU by
+// its 128 accumulator VGPRs), 2 = at H = 128 too (there the register-staged kernel fits two workgroups per CU and is
+// ~3 % faster than the ring: 1.95 vs 2.01 ms per step)
+int wgrad_dma_mode() {
+    static const int mode = [] {
         const char* e = getenv("DN_WGRAD_DMA");
-        return !(e && e[0] == '0');
+        return e ? atoi(e) : 1;
     }();
-    return on;
+    return mode;
 }
 
 template <int HI, int HO>
@@ -1003,7 +1012,7 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
                  float* cs_partial, const bf16_t* maskA, bf16_t* A_out, hipStream_t st) {
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
-        if (maskA == nullptr && A_out == nullptr && wgrad_dma_enabled()) {
+        if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
             hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia,
                                G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial);
             DN_CHECK_LAUNCH();
