@@ -108,7 +108,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (the raw-handle query is ~10x cheaper than building a
+    torch.cuda.Stream object per launch, which showed up in eager-mode profiles of small batches)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
