@@ -516,3 +516,63 @@ def test_predict_nets_match_reference_goldens(golden_dir):
         assert _rel_max(g_flat.grad, torch.from_numpy(z[tag + "/grad_g"])) < RTOL
         for k, p in net.named_parameters():
             assert _rel_max(p.grad, torch.from_numpy(z[tag + "/grad/" + k])) < RTOL, (tag, k)
+
+
+def test_full_size_config5_layer_through_batch_properties():
+    """BASELINE config 5 at FULL size (N = 1,015,808, E = 3,997,696, R = 16, H = 256, bf16) through properties that do not
+    need a full-size oracle: (1) a batch is a disjoint union, so the first graphs' rows of the big run must equal a run on
+    those graphs alone -- which is itself checked against the fp64 oracle; (2) data-parallel consistency: the parameter
+    gradients of the whole batch equal the sum over two half batches (what the RCCL all-reduce relies on); (3) everything
+    finite, dummy rows included."""
+    from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config5()
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    vocab = (raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    H, R, G = 256, raw["num_rels"], len(raw["node_ptr"]) - 1
+
+    def augment(g0, g1):
+        n0, n1, e0, e1 = raw["node_ptr"][g0], raw["node_ptr"][g1], raw["edge_ptr"][g0], raw["edge_ptr"][g1]
+        sub = dict(node_ptr=raw["node_ptr"][g0:g1 + 1] - n0, edge_ptr=raw["edge_ptr"][g0:g1 + 1] - e0,
+                   src=raw["src"][e0:e1] - n0, dst=raw["dst"][e0:e1] - n0, node_id=raw["node_id"][n0:n1],
+                   node_label=raw["node_label"][n0:n1], edge_id=raw["edge_id"][e0:e1], edge_label=raw["edge_label"][e0:e1])
+        return transforms.dummy_augment_si(*(torch.from_numpy(np.ascontiguousarray(sub[k])).to(DEV) for k in keys), *vocab)
+
+    torch.manual_seed(11)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    full = augment(0, G)
+    N = int(full["node_label"].numel())
+    assert N == 1015808 and int(full["src"].numel()) == 3997696
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+
+    def run(aug, rows):
+        for p in layer.parameters():
+            p.grad = None
+        xs = x[rows].clone().requires_grad_(True)
+        out, _ = layer(BatchedGraph(aug["src"], aug["dst"], int(aug["node_label"].numel())), xs, aug["edge_label"].long())
+        out.backward(coef[rows])
+        return out.detach(), xs.grad.detach(), {k: p.grad.detach().float().clone() for k, p in layer.named_parameters()}
+
+    out_f, gx_f, gw_f = run(full, slice(0, N))
+    assert bool(torch.isfinite(out_f.float()).all()) and bool(torch.isfinite(gx_f.float()).all())
+    # (1) first 64 graphs alone (31 nodes each after augmentation)
+    g_small = 64
+    n_small = g_small * 31
+    out_s, gx_s, _ = run(augment(0, g_small), slice(0, n_small))
+    assert _rel_l2(out_f[:n_small], out_s) < 2e-3 and _rel_l2(gx_f[:n_small], gx_s) < 2e-3
+    #     ... and that small run against the oracle in fp64 on the same bf16 operands
+    sm = augment(0, g_small)
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    ref = OL.rgin_layer(x[:n_small].double().cpu(), sm["src"].long().cpu(), sm["dst"].long().cpu(), sm["edge_label"].long().cpu(),
+                        p64, regularizer="basis", num_rels=R, num_bases=-1, num_mlp_layers=2, act="relu")
+    assert _rel_l2(out_s, ref) < 3e-2
+    # (2) two halves
+    half = G // 2
+    nh = half * 31
+    _, _, gw_a = run(augment(0, half), slice(0, nh))
+    _, _, gw_b = run(augment(half, G), slice(nh, N))
+    for k in gw_f:
+        if float(gw_f[k].abs().max()) > 0:
+            assert _rel_l2(gw_a[k] + gw_b[k], gw_f[k]) < 2e-2, k
