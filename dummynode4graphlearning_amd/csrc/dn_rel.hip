@@ -40,6 +40,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int stride, int co
     return __builtin_bit_cast(bf16x8, f);
 }
 
+__device__ __forceinline__ uint4 keep_bits(const uint4& v, uint32_t bits) {     // bit i of `bits` <-> bf16 element i of v
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] &= ((bits >> (2 * i)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * i + 1)) & 1u ? 0xffff0000u : 0u);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint32_t positive_bits(const uint4& v) {             // bf16 > 0: sign clear, magnitude non-zero
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = w[i] & 0xffffu, hi = w[i] >> 16;
+        bits |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * i);
+        bits |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * i + 1);
+    }
+    return bits;
+}
+
 // partial[chunk][k][n] = sum_{p in chunk} A[ia[p]][k] * G[ig[p]][n]
 template <int HI, int HO>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __restrict__ A,
@@ -52,7 +71,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                                                                 float* __restrict__ partial, int32_t colsum_of,
                                                                 float* __restrict__ colsum_partial,
                                                                 const bf16_t* __restrict__ maskA,
-                                                                bf16_t* __restrict__ A_out) {
+                                                                bf16_t* __restrict__ A_out,
+                                                                const uint8_t* __restrict__ maskBits) {
     constexpr int SA = HI + kPad, SG = HO + kPad;
     constexpr int MT = HI / 2 / 16, NT = HO / 4 / 16;           // 16x16 tiles per wave
     constexpr int NPA = kTileRows * HI / 8, NPG = kTileRows * HO / 8;   // 16-byte pieces per tile
@@ -110,6 +130,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                 const bf16_t* base = sa[j] < na1 ? A + (size_t)sa[j] * HI : A2 + (size_t)(sa[j] - na1) * HI;
                 ra[j] = *reinterpret_cast<const uint4*>(base + c * 8);
                 if (maskA) rm[j] = *reinterpret_cast<const uint4*>(maskA + (size_t)sa[j] * HI + c * 8);
+                else if (maskBits) rm[j].x = maskBits[(size_t)sa[j] * (HI / 8) + c];      // 8 ReLU-mask bits of this piece
             }
         }
 #pragma unroll
@@ -137,6 +158,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                 ra[j] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 if (A_out) *reinterpret_cast<uint4*>(A_out + (size_t)sa_cur[j] * HI + c * 8) = ra[j];
             }
+            if (maskBits && sa_cur[j] >= 0) ra[j] = keep_bits(ra[j], rm[j].x);
             if (piece < NPA) *reinterpret_cast<uint4*>(bufA(b) + r * SA + c * 8) = ra[j];
             if (colsum_of == 1 && piece < NPA) add_cs(ra[j]);
         }
@@ -246,7 +268,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int H>
+template <int H, bool MASKED>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t* __restrict__ A,
                                                                     const bf16_t* __restrict__ A2, int32_t na1,
                                                                     const int32_t* __restrict__ ia,
@@ -255,18 +277,20 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                                                                     const int32_t* __restrict__ ig,
                                                                     const Chunk* __restrict__ chunks,
                                                                     float* __restrict__ partial, int32_t colsum_of,
-                                                                    float* __restrict__ colsum_partial) {
+                                                                    float* __restrict__ colsum_partial,
+                                                                    const uint8_t* __restrict__ maskBits) {
     static_assert(H == 256 || H == 128, "unsupported width");
     constexpr int TR = (H == 256) ? 32 : 64;       // rows per stage: 32 KiB per stage at either width (1 or 2 MFMA K-steps)
     constexpr int NST = 4;                         // ring stages (128 KiB)
     constexpr int ROWB = 2 * H;                    // bytes per row
     constexpr int MATB = TR * ROWB;                // bytes per operand per stage
-    constexpr int STB = 2 * MATB;
+    constexpr int BITB = MASKED ? 1024 : 0;        // per stage: the tile's ReLU-mask bits (TR rows x H/8 bytes = 1 KiB)
+    constexpr int STB = 2 * MATB + BITB;
     constexpr int LPRW = H / 8;                    // lanes (16-byte pieces) per row
     constexpr int RPI = 64 / LPRW;                 // rows per DMA wave-instruction (2 or 4)
     constexpr int RW = TR / 8;                     // rows of each operand a wave stages per tile (4 or 8)
     constexpr int PPW = RW / RPI;                  // DMA instructions per wave, operand and tile
-    constexpr int GL = 2 * PPW;                    // DMA instructions per wave and tile
+    constexpr int GL = 2 * PPW + (MASKED ? 1 : 0); // DMA instructions per wave and tile
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -328,6 +352,17 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
             glds16(pa + gch, da);
             glds16(pg + gch, da + MATB);
         }
+        if constexpr (MASKED) {
+            // the mask bits of my RW rows: H/8 bytes per row = (H/128) 16-byte pieces; 8 active lanes, 128 bytes per wave
+            constexpr int LPB = H / 128;                                   // lanes per row of bits
+            if (lane < RW * LPB) {
+                int32_t ra = nxa[0];
+#pragma unroll
+                for (int k = 1; k < RW; ++k) ra = (lane / LPB == k) ? nxa[k] : ra;
+                const char* pb = ra < 0 ? zero : reinterpret_cast<const char*>(maskBits) + (size_t)ra * (H / 8) + (lane % LPB) * 16;
+                glds16(pb, st + 2 * MATB + (unsigned)wave * (RW * (H / 8)));
+            }
+        }
     };
 
     // ---- MFMA side ----------------------------------------------------------------------------------------
@@ -370,8 +405,22 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
         __builtin_amdgcn_s_barrier();                                      // everyone's have / are
         issue(t + NST - 1);                                                // refill the stage tile t-1 used
         load_idx(t + NST);
-        const char* sA = lds + (t % NST) * STB;
+        char* sA = lds + (t % NST) * STB;
         const char* sG = sA + MATB;
+        if constexpr (MASKED) {
+            // ReLU backward on the landed A tile, in place: piece (row r, position q) holds global chunk ((q>>1)^f(r))<<1 | (q&1)
+            const uint8_t* sB = reinterpret_cast<const uint8_t*>(sA + 2 * MATB);
+#pragma unroll
+            for (int j = 0; j < TR * LPRW / kWgThreads; ++j) {
+                const int piece = tid + j * kWgThreads, r = piece / LPRW, q = piece % LPRW;
+                const int f = (r & 3) | (((r >> 3) & 1) << 2);
+                const int gchunk = (((q >> 1) ^ f) << 1) | (q & 1);
+                uint4* pp = reinterpret_cast<uint4*>(sA + r * ROWB + q * 16);
+                *pp = keep_bits(*pp, sB[r * (H / 8) + gchunk]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll
         for (int kk = 0; kk < TR / 32; ++kk) {
             bf16x8 fb[NT];
@@ -775,27 +824,31 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
 }
 
 // -------------------------------------------------------------------------------------------------
-// dn_rows_chain2_bf16:  Y1 = epi1(X @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)   -- two dense layers in one pass over the rows
-//   epi1 = (+ b1) -> ReLU? -> keep where mask1 > 0 ?        epi2 = (+ b2) -> ReLU?
-//   Forward of the reference's two-layer post-aggregate MLP (rgin.py:50-57: Linear-ReLU-Linear, then the layer's ReLU) and,
-//   with mask1 = the saved hidden activation and no bias/ReLU, the two input-gradient products of its backward.  Y1 is
-//   still written (the backward / the weight gradient need it) but never re-read: one [rows, H] read less per call than two
-//   dn_rows_transform_bf16 launches.  Same skeleton as rows_selfsum_kernel: H/16 waves, wave w owns 16 output columns of
-//   BOTH layers (2 x 32 VGPRs of weights for the whole launch), tile = 32 rows, one 16-byte piece per thread.
+// dn_rows_chain2_bf16:  Y1 = epi1(m0(X) @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)   -- two dense layers in one pass over the rows
+//   m0   = zero the elements of X whose bit in mask0_bits is clear (optional)
+//   epi1 = (+ b1) -> ReLU? -> zero where the bit in mask1_bits is clear (optional);   epi2 = (+ b2) -> ReLU?
+//   bits1 / bits2 (optional outputs): 1 bit per element of Y1 / Y2, set where the element is > 0
+//   Forward of the reference's two-layer post-aggregate MLP (rgin.py:50-57: Linear-ReLU-Linear, then the layer's ReLU),
+//   emitting the two ReLU masks as BIT tensors (1/16 of the bf16 activation they replace in the backward), and -- with
+//   mask0 = bits of the output activation, mask1 = bits of the hidden one, no bias/ReLU -- the whole input-gradient chain
+//   of its backward (outer ReLU mask, dgrad 2, inner ReLU mask, dgrad 1).  Y1 is written (the weight gradient of layer 1 /
+//   the backward need it) but never re-read.  Same skeleton as rows_selfsum_kernel: H/16 waves, wave w owns 16 output
+//   columns of BOTH layers (2 x 32 VGPRs of weights for the whole launch), tile = 32 rows, one 16-byte piece per thread.
 // -------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1n,
                                                             const bf16_t* __restrict__ b1, const bf16_t* __restrict__ W2n,
                                                             const bf16_t* __restrict__ b2, int32_t flags,
-                                                            const bf16_t* __restrict__ mask1, int32_t N, int32_t num_tiles,
-                                                            int32_t tiles_per_wg, bf16_t* __restrict__ Y1,
-                                                            bf16_t* __restrict__ Y2) {
+                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                                            int32_t N, int32_t num_tiles, int32_t tiles_per_wg,
+                                                            bf16_t* __restrict__ Y1, bf16_t* __restrict__ Y2,
+                                                            uint8_t* __restrict__ bits1, uint8_t* __restrict__ bits2) {
     constexpr int T = H * 4;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
     constexpr int SX = H + kPad;
     constexpr int KS = H / 32, MT = kSsRows / 16;
-    constexpr int LPR = H / 8;
+    constexpr int LPR = H / 8;                                   // 16-byte pieces = mask bytes per row
     static_assert(kSsRows * LPR == T, "one piece per thread");
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * kSsRows * SX];
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
@@ -827,10 +880,9 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
         const int p = t * kSsRows + pr;
         return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
     };
-    auto load_mask = [&](int t) -> uint4 {
+    auto load_bits = [&](const uint8_t* m, int t) -> uint32_t {  // my piece's 8 mask bits (0xff when there is no mask)
         const int p = t * kSsRows + pr;
-        return (mask1 && t < t_end && p < N) ? *reinterpret_cast<const uint4*>(mask1 + (size_t)p * H + pc * 8)
-                                             : make_uint4(0, 0, 0, 0);
+        return (m && t < t_end && p < N) ? (uint32_t)m[(size_t)p * LPR + pc] : 0xffu;
     };
     // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 16 columns of all 32 rows)
     auto stage = [&](const bf16_t* src, const bf16x8 (&wf)[KS], const float (&bv)[4], bool relu, bf16_t* dst) {
@@ -853,49 +905,47 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
             *reinterpret_cast<bf16x4*>(dst + (m * 16 + (lane & 15)) * SX + n0 + 4 * (lane >> 4)) = o;
         }
     };
-    auto put = [&](bf16_t* Yout, int p, const uint4& v) {
+    auto put = [&](bf16_t* Yout, uint8_t* bout, int p, const uint4& v) {
         const u32x4 vv = {v.x, v.y, v.z, v.w};
         if (nt) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(Yout + (size_t)p * H + pc * 8));
         else *reinterpret_cast<u32x4*>(Yout + (size_t)p * H + pc * 8) = vv;
+        if (bout) bout[(size_t)p * LPR + pc] = (uint8_t)positive_bits(v);
     };
 
-    // X pieces and mask pieces two tiles ahead (the launch has no gathers: without this only 32 KB per CU are in flight)
-    uint4 rx = load_x(t_beg);
-    uint4 mk = load_mask(t_beg);
+    // X pieces (and their mask bits) two tiles ahead, stage-1 mask bits one tile ahead
+    uint4 rx = keep_bits(load_x(t_beg), load_bits(mask0, t_beg));
+    uint32_t mk = load_bits(mask1, t_beg);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
     rx = load_x(t_beg + 1);
+    uint32_t m0 = load_bits(mask0, t_beg + 1);
     uint4 rx2 = load_x(t_beg + 2);
-    uint4 mk1 = load_mask(t_beg + 1);
+    uint32_t m02 = load_bits(mask0, t_beg + 2);
+    uint32_t mk1 = load_bits(mask1, t_beg + 1);
     __syncthreads();
 
     for (int t = t_beg; t < t_end; ++t) {
         const int b = (t - t_beg) & 1;
         const int p = t * kSsRows + pr;
         stage(bufX(b), wf1, bv1, relu1, buf1);
-        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;
+        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? keep_bits(rx, m0) : rx;
         rx = rx2;
+        m0 = m02;
         rx2 = load_x(t + 3);
-        const uint4 mk2 = load_mask(t + 2);
+        m02 = load_bits(mask0, t + 3);
+        const uint32_t mk2 = load_bits(mask1, t + 2);
         __syncthreads();                                         // buf1 complete
         {   // my piece of the stage-1 tile: mask, write out, (masked) back into the stage-2 input
             uint4 v = *reinterpret_cast<const uint4*>(buf1 + pr * SX + pc * 8);
             if (mask1) {
-                const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-                uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
-                    vw[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
-                }
-                v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                v = keep_bits(v, mk);
                 *reinterpret_cast<uint4*>(buf1 + pr * SX + pc * 8) = v;
             }
-            if (p < N) put(Y1, p, v);
+            if (p < N) put(Y1, bits1, p, v);
         }
         if (mask1) __syncthreads();                              // masked tile visible to every wave (uniform branch)
         stage(buf1, wf2, bv2, relu2, buf2);
         __syncthreads();                                         // buf2 complete; buf1 free for the next tile
-        if (p < N) put(Y2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
+        if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
         mk = mk1;
         mk1 = mk2;
         // buf2 is rewritten only after the next tile's two barriers; bufX(b) after the next tile's stage 1 -> no extra barrier
@@ -904,12 +954,13 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
 
 template <int H>
 int launch_chain2(const bf16_t* X, const bf16_t* W1n, const bf16_t* b1, const bf16_t* W2n, const bf16_t* b2, int32_t flags,
-                  const bf16_t* mask1, int64_t N, bf16_t* Y1, bf16_t* Y2, hipStream_t st) {
+                  const uint8_t* mask0, const uint8_t* mask1, int64_t N, bf16_t* Y1, bf16_t* Y2, uint8_t* bits1,
+                  uint8_t* bits2, hipStream_t st) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    hipLaunchKernelGGL((rows_chain2_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, W1n, b1, W2n, b2, flags, mask1,
-                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y1, Y2);
+    hipLaunchKernelGGL((rows_chain2_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, W1n, b1, W2n, b2, flags, mask0,
+                       mask1, (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y1, Y2, bits1, bits2);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1010,17 +1061,21 @@ int wgrad_dma_mode() {
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
-                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, hipStream_t st) {
+                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, hipStream_t st) {
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
         if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
-            hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia,
-                               G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial);
+            if (maskBits)
+                hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, true>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
+                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits);
+            else
+                hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, false>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
+                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits);
             DN_CHECK_LAUNCH();
             return DN_OK;
         }
     }
     hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia, G, G2,
-                       ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out);
+                       ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out, maskBits);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1067,9 +1122,10 @@ size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho)
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G, const void* G2,
                        int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                        int64_t num_chunks, const int32_t* chunk_ptr, void* out, int32_t out_is_f32, int32_t colsum_of,
-                       float* out_colsum, const void* mask_a, void* a_out, void* workspace, size_t workspace_bytes,
-                       dn_stream_t stream) {
+                       float* out_colsum, const void* mask_a, void* a_out, const void* mask_a_bits, void* workspace,
+                       size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad: mask_a needs a single A source");
+    DN_REQUIRE(mask_a_bits == nullptr || (mask_a == nullptr && A2 == nullptr), "dn_rows_wgrad: mask_a_bits excludes mask_a / A2");
     DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad: a_out needs mask_a and idx_a == NULL");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0, "dn_rows_wgrad: unaligned mask");
     DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
@@ -1092,9 +1148,10 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
         float* csp = ws + (size_t)num_chunks * Hi * Ho;
         const bf16_t* mk = (const bf16_t*)mask_a;
         bf16_t* ao = (bf16_t*)a_out;
-        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
-        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
-        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, st);
+        const uint8_t* mb = (const uint8_t*)mask_a_bits;
+        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
+        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
+        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
@@ -1150,23 +1207,26 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
 }
 
-int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask1,
-                        const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2, dn_stream_t stream) {
+int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
+                        const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
+                        void* bits1, void* bits2, dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_chain2: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_chain2: unsupported width %d (64/128/256 only)", H);
     if (N == 0) return DN_OK;
     DN_REQUIRE(X && W1n && W2n && Y1 && Y2, "dn_rows_chain2: NULL pointer");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1n) | reinterpret_cast<uintptr_t>(W2n) |
-                reinterpret_cast<uintptr_t>(mask1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
+                reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
                "dn_rows_chain2: unaligned pointer");
     static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
     const int32_t flags = (relu1 ? 1 : 0) | (relu2 ? 2 : 0) | ((nt & 1) ? 4 : 0);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w1 = (const bf16_t*)W1n, *w2 = (const bf16_t*)W2n, *bb1 = (const bf16_t*)b1,
-                 *bb2 = (const bf16_t*)b2, *mk = (const bf16_t*)mask1;
-    if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
-    if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
-    return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, mk, N, (bf16_t*)Y1, (bf16_t*)Y2, st);
+                 *bb2 = (const bf16_t*)b2;
+    const uint8_t *m0 = (const uint8_t*)mask0_bits, *m1 = (const uint8_t*)mask1_bits;
+    uint8_t *o1 = (uint8_t*)bits1, *o2 = (uint8_t*)bits2;
+    if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
+    if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
+    return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
 }
 
 }  // extern "C"

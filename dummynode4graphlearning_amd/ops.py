@@ -165,14 +165,16 @@ INT32_MAX = 0x7fffffff
 
 
 def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0,
-               mask_a=None, a_out=None):
+               mask_a=None, a_out=None, mask_a_bits=None):
     """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
     Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
     column sums [R, H] of operand A|G (the bias gradient)."""
     chunks, chunk_ptr, nchunks = chunk_table
-    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out)
+    require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out, mask_a_bits)
     assert A.dtype == G.dtype and A.dtype in (torch.bfloat16, torch.float32)
     is_f32 = A.dtype == torch.float32
+    assert mask_a_bits is None or (not is_f32 and mask_a_bits.dtype == torch.uint8
+                                   and mask_a_bits.shape == (A.shape[0], A.shape[1] // 8))
     if is_f32:
         out_dtype = torch.float32
     Hi, Ho = A.shape[1], G.shape[1]
@@ -192,7 +194,7 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                            ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
                                            1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
-                                           ptr(a_out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
+                                           ptr(a_out), ptr(mask_a_bits), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_wgrad", _launch)
@@ -272,22 +274,29 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None):
 CHAIN2_ENABLED = _os.environ.get("DN_CHAIN2", "1") != "0"
 
 
-def rows_chain2(x, W1n, b1, relu1, mask1, W2n, b2, relu2):
-    """(Y1, Y2) with Y1 = epi1(x @ W1n^T), Y2 = epi2(Y1 @ W2n^T) in one pass over the rows (dn_rows_chain2_bf16)."""
+def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=None, want_bits=False):
+    """(Y1, Y2[, bits1, bits2]) with Y1 = epi1(m0(x) @ W1n^T), Y2 = epi2(Y1 @ W2n^T) in one pass over the rows
+    (dn_rows_chain2_bf16).  mask*_bits: uint8 [N, H/8] keep-masks (input / stage-1 output); want_bits: also return the
+    "> 0" bit tensors of Y1 and Y2 (the ReLU masks the backward needs, 1/16 of the activations)."""
     x, W1n, W2n = x.contiguous(), W1n.contiguous(), W2n.contiguous()
-    require_gpu(x, W1n, b1, mask1, W2n, b2)
+    require_gpu(x, W1n, b1, W2n, b2, mask0_bits, mask1_bits)
     N, H = x.shape
     assert x.dtype == torch.bfloat16 and W1n.shape == (H, H) and W2n.shape == (H, H)
+    for m in (mask0_bits, mask1_bits):
+        assert m is None or (m.dtype == torch.uint8 and m.shape == (N, H // 8))
     Y1, Y2 = torch.empty_like(x), torch.empty_like(x)
+    bits1 = torch.empty((N, H // 8), dtype=torch.uint8, device=x.device) if want_bits else None
+    bits2 = torch.empty((N, H // 8), dtype=torch.uint8, device=x.device) if want_bits else None
 
     def _launch():
-        check(lib().dn_rows_chain2_bf16(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask1), ptr(W2n), ptr(b2),
-                                        1 if relu2 else 0, N, ptr(Y1), ptr(Y2), stream_ptr()), "dn_rows_chain2_bf16")
+        check(lib().dn_rows_chain2_bf16(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask0_bits), ptr(mask1_bits),
+                                        ptr(W2n), ptr(b2), 1 if relu2 else 0, N, ptr(Y1), ptr(Y2), ptr(bits1), ptr(bits2),
+                                        stream_ptr()), "dn_rows_chain2_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_chain2", _launch)
     else:
         _launch()
-    return Y1, Y2
+    return (Y1, Y2, bits1, bits2) if want_bits else (Y1, Y2)
 
 
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS):
@@ -970,25 +979,30 @@ def relu_bwd(g, y):
 
 class _ReluMlpFn(torch.autograd.Function):
     """y_L = relu(lin_L(... relu(lin_1(x)))) with every Linear followed by ReLU (the reference MLP + final activation
-    when act_func == "relu", rgin.py:50-57,147-151).  Forward: one fused Linear+bias+ReLU MFMA launch per layer.
-    Backward per layer: weight/bias gradient in one launch, input gradient in one launch whose epilogue already applies
-    the ReLU mask of the layer below; only the outermost mask needs its own elementwise pass."""
+    when act_func == "relu", rgin.py:50-57,147-151).
+    Two layers in bf16 (the reference default): ONE forward launch (dn_rows_chain2_bf16) that also emits both ReLU masks
+    as bit tensors, and three backward launches: weight gradient of layer 2 (outer mask applied from its bits while the
+    rows are staged), the whole input-gradient chain (mask, dgrad 2, mask, dgrad 1), weight gradient of layer 1.
+    Otherwise: one fused Linear+bias+ReLU launch per layer forward; per layer backward a weight/bias-gradient launch and
+    an input-gradient launch whose epilogue applies the ReLU mask of the layer below."""
 
     @staticmethod
     def forward(ctx, x, *wb):
         n = len(wb) // 2
-        tiles, _ = _dense_table(x.shape[0], x.device)
-        acts = [x.contiguous()]
+        x = x.contiguous()
         if n == 2 and CHAIN2_ENABLED and x.dtype == torch.bfloat16:
-            # both layers in one pass: the hidden activation is written (the backward needs it) but not re-read
-            h1, h2 = rows_chain2(acts[0], wb[0], wb[1], True, None, wb[2], wb[3], True)
-            acts += [h1, h2]
-        else:
-            for i in range(n):
-                w, b = wb[2 * i], wb[2 * i + 1]
-                acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
-                                           bias=None if b is None else b.contiguous().view(1, -1), relu=True))
-        ctx.n = n
+            h1, h2, bits1, bits2 = rows_chain2(x, wb[0], wb[1], True, wb[2], wb[3], True, want_bits=True)
+            ctx.n, ctx.chain = n, True
+            ctx.has_bias = [wb[1] is not None, wb[3] is not None]
+            ctx.save_for_backward(x, h1, bits1, bits2, wb[0], wb[2])      # the output itself is not kept: only its sign bits
+            return h2
+        tiles, _ = _dense_table(x.shape[0], x.device)
+        acts = [x]
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
+                                       bias=None if b is None else b.contiguous().view(1, -1), relu=True))
+        ctx.n, ctx.chain = n, False
         ctx.has_bias = [wb[2 * i + 1] is not None for i in range(n)]
         ctx.save_for_backward(*acts, *[wb[2 * i] for i in range(n)])
         return acts[-1]
@@ -997,23 +1011,23 @@ class _ReluMlpFn(torch.autograd.Function):
     def backward(ctx, gout):
         n = ctx.n
         saved = ctx.saved_tensors
-        acts, ws = saved[:n + 1], saved[n + 1:]
-        tiles, chunks = _dense_table(acts[0].shape[0], acts[0].device)
         g = gout.contiguous()
         grads = [None] * (1 + 2 * n)
-        if n == 2 and CHAIN2_ENABLED and g.dtype == torch.bfloat16 and ctx.needs_input_grad[0]:
-            gm = torch.empty_like(g)
-            gw2, cs2 = rows_wgrad(g, acts[1], chunks, 1, out_dtype=ws[1].dtype, colsum_of=1, mask_a=acts[2], a_out=gm)
-            # g1 = (gm @ W2) masked by h1 > 0, g0 = g1 @ W1 in one pass; g1 is only re-read by the weight gradient of layer 1
-            g1, g0 = rows_chain2(gm, ws[1].t(), None, False, acts[1], ws[0].t(), None, False)
-            gw1, cs1 = rows_wgrad(g1, acts[0], chunks, 1, out_dtype=ws[0].dtype, colsum_of=1)
+        if ctx.chain:
+            x0, h1, bits1, bits2, w1, w2 = saved
+            _, chunks = _dense_table(x0.shape[0], x0.device)
+            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a_bits=bits2)
+            g1, g0 = rows_chain2(g, w2.t(), None, False, w1.t(), None, False, mask0_bits=bits2, mask1_bits=bits1)
+            gw1, cs1 = rows_wgrad(g1, x0, chunks, 1, out_dtype=w1.dtype, colsum_of=1)
             grads[1], grads[3] = gw1[0], gw2[0]
             if ctx.has_bias[0]:
                 grads[2] = cs1[0].to(g.dtype)
             if ctx.has_bias[1]:
                 grads[4] = cs2[0].to(g.dtype)
-            grads[0] = g0
+            grads[0] = g0 if ctx.needs_input_grad[0] else None
             return tuple(grads)
+        acts, ws = saved[:n + 1], saved[n + 1:]
+        tiles, chunks = _dense_table(acts[0].shape[0], acts[0].device)
         for i in range(n - 1, -1, -1):
             w = ws[i]
             if i == n - 1:

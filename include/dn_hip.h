@@ -221,13 +221,15 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * colsum_of = 1 (A) or 2 (G) also returns out_colsum[r, :] = sum over relation r's rows of that operand (fp32 [R, H]):
  * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL).
  * mask_a (may be NULL; needs A2 == NULL): A rows are first zeroed where mask_a[row, k] <= 0 (ReLU backward folded into the
- * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears. */
+ * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears.
+ * mask_a_bits (may be NULL; excludes mask_a and A2): the same mask as a bit tensor, uint8 [rows of A, Hi/8], bit i of byte
+ * (row, c) = keep element (row, 8c + i) -- the bits1 / bits2 outputs of dn_rows_chain2_bf16. */
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G,
                        const void* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                        const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
                        int32_t out_is_f32, int32_t colsum_of, float* out_colsum, const void* mask_a, void* a_out,
-                       void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                       const void* mask_a_bits, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
@@ -256,14 +258,20 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream);
 
 /* Two dense layers in one pass over the rows (bf16 in, fp32 acc, bf16 out):
- *   Y1 = epi1(X @ W1n^T),  epi1 = (+ b1), ReLU if relu1, then zero where mask1 <= 0 (mask1 may be NULL)
- *   Y2 = epi2(Y1 @ W2n^T), epi2 = (+ b2), ReLU if relu2
+ *   Y1 = epi1(m0(X) @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)
+ *   m0   = zero the elements of X whose bit in mask0_bits is clear (mask0_bits may be NULL)
+ *   epi1 = (+ b1), ReLU if relu1, then zero where the bit in mask1_bits is clear (mask1_bits may be NULL)
+ *   epi2 = (+ b2), ReLU if relu2
+ *   bits1 / bits2 (may be NULL): bit tensors of Y1 / Y2, bit set where the element is > 0
+ * Bit tensors are uint8 [N, H/8]: bit i of byte (p, c) belongs to element (p, 8c + i).
  * Forward of the reference's two-layer MLP after the aggregate (subgraph_isomorphism/models/rgin.py:50-57 followed by the
- * layer activation, :147-151: Linear-ReLU-Linear-ReLU) and, with mask1 = the saved hidden activation, the two input-
- * gradient products of its backward.  W1n / W2n are [H][H] with k contiguous (nn.Linear.weight for the forward, its
- * transpose for the backward); b1 / b2 may be NULL.  Y1 is written but never re-read.  H in {64, 128, 256}. */
-int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask1,
-                        const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2, dn_stream_t stream);
+ * layer activation, :147-151: Linear-ReLU-Linear-ReLU), emitting the ReLU masks as bits, and -- with mask0 = bits of the
+ * output activation, mask1 = bits of the hidden one -- the input-gradient chain of its backward.  W1n / W2n are [H][H]
+ * with k contiguous (nn.Linear.weight for the forward, its transpose for the backward); b1 / b2 may be NULL.  Y1 is
+ * written but never re-read.  H in {64, 128, 256}. */
+int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
+                        const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
+                        void* bits1, void* bits2, dn_stream_t stream);
 
 /* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
  * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the

@@ -364,3 +364,36 @@ def test_rows_selfsum_matches_reference(H):
     out = ops.rows_selfsum(x.to(DEV), W.to(DEV), b.to(DEV), Yd[:0], None, empty)
     ref = x.double() @ W.double().t() + b.double()
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 6e-3
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_rows_wgrad_with_bit_mask_and_chain2(H):
+    """ReLU masks as bit tensors: dn_rows_chain2_bf16 emits them (forward), dn_rows_wgrad_bf16(mask_a_bits) and the chain's
+    mask0 / mask1 inputs consume them (backward) -- against fp64 math on the same bf16 operands and storage points."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(10 + H)
+    N = 5000 + H // 64                                   # not a multiple of any tile size
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, g = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((N, H)))
+    W1, W2 = bf(rng.standard_normal((H, H)) / np.sqrt(H)), bf(rng.standard_normal((H, H)) / np.sqrt(H))
+    b1, b2 = bf(rng.standard_normal(H) * 0.1), bf(rng.standard_normal(H) * 0.1)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    h1, h2, bits1, bits2 = ops.rows_chain2(d(x), d(W1), d(b1), True, d(W2), d(b2), True, want_bits=True)
+    r1 = torch.relu(x.double() @ W1.double().t() + b1.double())
+    assert float((h1.cpu().double() - r1).abs().max() / r1.abs().max()) < 6e-3
+    r2 = torch.relu(h1.cpu().double() @ W2.double().t() + b2.double())            # from the stored (bf16) hidden rows
+    assert float((h2.cpu().double() - r2).abs().max() / r2.abs().max()) < 6e-3
+    unpack = lambda b: ((b.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(N, H).bool()  # noqa: E731
+    assert torch.equal(unpack(bits1), h1.cpu() > 0) and torch.equal(unpack(bits2), h2.cpu() > 0)
+    # backward: weight gradient of layer 2 with the outer mask from bits, then the input-gradient chain
+    _, chunks = ops._dense_table(N, torch.device(DEV))
+    gw2, cs2 = ops.rows_wgrad(d(g), h1, chunks, 1, out_dtype=torch.float32, colsum_of=1, mask_a_bits=bits2)
+    gm = torch.where(h2.cpu() > 0, g, torch.zeros((), dtype=g.dtype)).double()
+    ref_w2 = gm.t() @ h1.cpu().double()
+    assert float((gw2[0].cpu().double() - ref_w2).abs().max() / ref_w2.abs().max()) < 2e-3
+    assert float((cs2[0].cpu().double() - gm.sum(0)).abs().max() / gm.sum(0).abs().max()) < 2e-3
+    g1, g0 = ops.rows_chain2(d(g), d(W2).t(), None, False, d(W1).t(), None, False, mask0_bits=bits2, mask1_bits=bits1)
+    rg1 = (gm @ W2.double()) * (h1.cpu() > 0)
+    assert float((g1.cpu().double() - rg1).abs().max() / rg1.abs().max()) < 6e-3
+    rg0 = g1.cpu().double() @ W1.double()
+    assert float((g0.cpu().double() - rg0).abs().max() / rg0.abs().max()) < 6e-3
