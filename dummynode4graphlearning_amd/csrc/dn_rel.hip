@@ -832,8 +832,7 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
 //   emitting the two ReLU masks as BIT tensors (1/16 of the bf16 activation they replace in the backward), and -- with
 //   mask0 = bits of the output activation, mask1 = bits of the hidden one, no bias/ReLU -- the whole input-gradient chain
 //   of its backward (outer ReLU mask, dgrad 2, inner ReLU mask, dgrad 1).  Y1 is written (the weight gradient of layer 1 /
-//   the backward need it) but never re-read.  Same skeleton as rows_selfsum_kernel: H/16 waves, wave w owns 16 output
-//   columns of BOTH layers (2 x 32 VGPRs of weights for the whole launch), tile = 32 rows, one 16-byte piece per thread.
+//   the backward need it) but never re-read.  H/16 waves, tile = 32 rows, one 16-byte piece per thread per tile.
 // -------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1n,
@@ -843,39 +842,47 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
                                                             int32_t N, int32_t num_tiles, int32_t tiles_per_wg,
                                                             bf16_t* __restrict__ Y1, bf16_t* __restrict__ Y2,
                                                             uint8_t* __restrict__ bits1, uint8_t* __restrict__ bits2) {
+    // Wave-specialised two-stage pipeline: the first half of the waves owns layer 1 (32 output columns each, their slice of
+    // W1n in 64 VGPRs), the second half layer 2; in one iteration layer 1 works on tile t while layer 2 works on tile t-1, so
+    // the two products overlap and every wave re-reads the 32-row LDS tile for 32 columns instead of 16 (LDS fragment reads
+    // were the limiter of the one-role-per-wave version: 16 waves x 16 KB per stage).
     constexpr int T = H * 4;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
     constexpr int SX = H + kPad;
-    constexpr int KS = H / 32, MT = kSsRows / 16;
+    constexpr int KS = H / 32, MT = kSsRows / 16, NT = 2;
     constexpr int LPR = H / 8;                                   // 16-byte pieces = mask bytes per row
+    constexpr int HALF = H / 32;                                 // waves per role
     static_assert(kSsRows * LPR == T, "one piece per thread");
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * kSsRows * SX];
+    __shared__ __attribute__((aligned(16))) bf16_t lds[5 * kSsRows * SX + 4 * H];
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
-    bf16_t* buf1 = lds + 2 * kSsRows * SX;                       // stage-1 result = stage-2 input
-    bf16_t* buf2 = lds + 3 * kSsRows * SX;                       // stage-2 result
-    const bool relu1 = flags & 1, relu2 = flags & 2, nt = flags & 4;
+    auto buf1 = [&](int b) -> bf16_t* { return lds + (2 + b) * (kSsRows * SX); };   // stage-1 result = stage-2 input
+    bf16_t* buf2 = lds + 4 * kSsRows * SX;                                           // stage-2 result
+    float* biasL = reinterpret_cast<float*>(lds + 5 * kSsRows * SX);                 // [2][H] fp32: b1, b2 (0 when absent)
+    const bool nt = flags & 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = wave * 16;
+    const int role = wave / HALF;                                // 0: layer 1, 1: layer 2 (wave-uniform)
+    const int n0 = (wave % HALF) * 32;
     const int pr = tid / LPR, pc = tid % LPR;
     const int t_beg = blockIdx.x * tiles_per_wg;
     const int t_end = min(t_beg + tiles_per_wg, num_tiles);
     if (t_beg >= t_end) return;
 
-    bf16x8 wf1[KS], wf2[KS];
+    const bf16_t* Wn = role ? W2n : W1n;
+    const bool relu = role ? (flags & 2) : (flags & 1);
+    bf16x8 wf[KS][NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const size_t o = (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4);
-        wf1[ks] = *reinterpret_cast<const bf16x8*>(W1n + o);
-        wf2[ks] = *reinterpret_cast<const bf16x8*>(W2n + o);
-    }
-    float bv1[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (b1) bv1[i] = (float)b1[n0 + 4 * (lane >> 4) + i];
-        if (b2) bv2[i] = (float)b2[n0 + 4 * (lane >> 4) + i];
+        for (int n = 0; n < NT; ++n)
+            wf[ks][n] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + n * 16 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    for (int i = threadIdx.x; i < 2 * H; i += T) {
+        const bf16_t* bb = i < H ? b1 : b2;
+        biasL[i] = bb ? (float)bb[i % H] : 0.f;
     }
+    const float* myBias = biasL + role * H + n0 + 4 * (lane >> 4);   // visible after the first barrier below
+
     auto load_x = [&](int t) -> uint4 {
         const int p = t * kSsRows + pr;
         return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
@@ -884,26 +891,31 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
         const int p = t * kSsRows + pr;
         return (m && t < t_end && p < N) ? (uint32_t)m[(size_t)p * LPR + pc] : 0xffu;
     };
-    // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 16 columns of all 32 rows)
-    auto stage = [&](const bf16_t* src, const bf16x8 (&wf)[KS], const float (&bv)[4], bool relu, bf16_t* dst) {
-        f32x4 acc[MT];
+    // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 32 columns of all 32 rows)
+    auto stage = [&](const bf16_t* src, bf16_t* dst) {
+        f32x4 acc[MT][NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bv[0], bv[1], bv[2], bv[3]};
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = *reinterpret_cast<const f32x4*>(myBias + n * 16);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bf16x8 xf = *reinterpret_cast<const bf16x8*>(src + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], xf, acc[m][n], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            bf16x4 o;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(relu ? fmaxf(acc[m][i], 0.f) : acc[m][i]);
-            *reinterpret_cast<bf16x4*>(dst + (m * 16 + (lane & 15)) * SX + n0 + 4 * (lane >> 4)) = o;
-        }
+            for (int n = 0; n < NT; ++n) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(relu ? fmaxf(acc[m][n][i], 0.f) : acc[m][n][i]);
+                *reinterpret_cast<bf16x4*>(dst + (m * 16 + (lane & 15)) * SX + n0 + n * 16 + 4 * (lane >> 4)) = o;
+            }
     };
     auto put = [&](bf16_t* Yout, uint8_t* bout, int p, const uint4& v) {
         const u32x4 vv = {v.x, v.y, v.z, v.w};
@@ -912,43 +924,43 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
         if (bout) bout[(size_t)p * LPR + pc] = (uint8_t)positive_bits(v);
     };
 
-    // X pieces (and their mask bits) two tiles ahead, stage-1 mask bits one tile ahead
+    // X pieces (and their mask bits) and the stage-1 mask bits one tile ahead (in flight across the whole iteration)
     uint4 rx = keep_bits(load_x(t_beg), load_bits(mask0, t_beg));
     uint32_t mk = load_bits(mask1, t_beg);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
     rx = load_x(t_beg + 1);
     uint32_t m0 = load_bits(mask0, t_beg + 1);
-    uint4 rx2 = load_x(t_beg + 2);
-    uint32_t m02 = load_bits(mask0, t_beg + 2);
     uint32_t mk1 = load_bits(mask1, t_beg + 1);
     __syncthreads();
 
-    for (int t = t_beg; t < t_end; ++t) {
+    for (int t = t_beg; t <= t_end; ++t) {                       // layer 1 on tile t, layer 2 on tile t-1
         const int b = (t - t_beg) & 1;
-        const int p = t * kSsRows + pr;
-        stage(bufX(b), wf1, bv1, relu1, buf1);
+        if (role == 0) {
+            if (t < t_end) stage(bufX(b), buf1(b));
+        } else {
+            if (t > t_beg) stage(buf1(b ^ 1), buf2);
+        }
         if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? keep_bits(rx, m0) : rx;
-        rx = rx2;
-        m0 = m02;
-        rx2 = load_x(t + 3);
-        m02 = load_bits(mask0, t + 3);
+        rx = load_x(t + 2);
+        m0 = load_bits(mask0, t + 2);
         const uint32_t mk2 = load_bits(mask1, t + 2);
-        __syncthreads();                                         // buf1 complete
-        {   // my piece of the stage-1 tile: mask, write out, (masked) back into the stage-2 input
-            uint4 v = *reinterpret_cast<const uint4*>(buf1 + pr * SX + pc * 8);
+        __syncthreads();                                         // buf1(b) and buf2 complete
+        if (t < t_end) {   // my piece of the stage-1 tile: mask, write out, (masked) back into the stage-2 input
+            const int p = t * kSsRows + pr;
+            uint4 v = *reinterpret_cast<const uint4*>(buf1(b) + pr * SX + pc * 8);
             if (mask1) {
                 v = keep_bits(v, mk);
-                *reinterpret_cast<uint4*>(buf1 + pr * SX + pc * 8) = v;
+                *reinterpret_cast<uint4*>(buf1(b) + pr * SX + pc * 8) = v;
             }
             if (p < N) put(Y1, bits1, p, v);
         }
-        if (mask1) __syncthreads();                              // masked tile visible to every wave (uniform branch)
-        stage(buf1, wf2, bv2, relu2, buf2);
-        __syncthreads();                                         // buf2 complete; buf1 free for the next tile
-        if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
+        if (t > t_beg) {   // ... and of the stage-2 tile of the previous rows
+            const int p = (t - 1) * kSsRows + pr;
+            if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
+        }
         mk = mk1;
         mk1 = mk2;
-        // buf2 is rewritten only after the next tile's two barriers; bufX(b) after the next tile's stage 1 -> no extra barrier
+        __syncthreads();                                         // masked buf1(b) visible; buf2 / bufX(b) free again
     }
 }
 
