@@ -854,11 +854,12 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     constexpr int LPR = H / 8;                                   // 16-byte pieces = mask bytes per row
     constexpr int HALF = H / 32;                                 // waves per role
     static_assert(kSsRows * LPR == T, "one piece per thread");
-    __shared__ __attribute__((aligned(16))) bf16_t lds[5 * kSsRows * SX + 4 * H];
+    __shared__ __attribute__((aligned(16))) bf16_t lds[6 * kSsRows * SX + 4 * H + kSsRows * LPR];
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
     auto buf1 = [&](int b) -> bf16_t* { return lds + (2 + b) * (kSsRows * SX); };   // stage-1 result = stage-2 input
-    bf16_t* buf2 = lds + 4 * kSsRows * SX;                                           // stage-2 result
-    float* biasL = reinterpret_cast<float*>(lds + 5 * kSsRows * SX);                 // [2][H] fp32: b1, b2 (0 when absent)
+    auto buf2 = [&](int b) -> bf16_t* { return lds + (4 + b) * (kSsRows * SX); };   // stage-2 result
+    float* biasL = reinterpret_cast<float*>(lds + 6 * kSsRows * SX);                 // [2][H] fp32: b1, b2 (0 when absent)
+    uint8_t* bitsL = reinterpret_cast<uint8_t*>(lds + 6 * kSsRows * SX + 4 * H);     // [2][32][LPR]: mask1 bits of a tile
     const bool nt = flags & 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -892,7 +893,8 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
         return (m && t < t_end && p < N) ? (uint32_t)m[(size_t)p * LPR + pc] : 0xffu;
     };
     // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 32 columns of all 32 rows)
-    auto stage = [&](const bf16_t* src, bf16_t* dst) {
+    const int kbase = (lane & 15) * LPR + (n0 >> 3) + (lane >> 5), kshift = ((lane >> 4) & 1) * 4;
+    auto stage = [&](const bf16_t* src, bf16_t* dst, const uint8_t* keep) {   // keep: the tile's mask bits in LDS, or NULL
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -911,10 +913,16 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                const int row = m * 16 + (lane & 15), col = n0 + n * 16 + 4 * (lane >> 4);
+                uint32_t nib = 0xfu;                             // ReLU-backward mask of my 4 columns of this row
+                if (keep) nib = (uint32_t)keep[kbase + m * 16 * LPR + n * 2] >> kshift;
                 bf16x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(relu ? fmaxf(acc[m][n][i], 0.f) : acc[m][n][i]);
-                *reinterpret_cast<bf16x4*>(dst + (m * 16 + (lane & 15)) * SX + n0 + n * 16 + 4 * (lane >> 4)) = o;
+                for (int i = 0; i < 4; ++i) {
+                    const float v = relu ? fmaxf(acc[m][n][i], 0.f) : acc[m][n][i];
+                    o[i] = (bf16_t)(((nib >> i) & 1u) ? v : 0.f);
+                }
+                *reinterpret_cast<bf16x4*>(dst + row * SX + col) = o;
             }
     };
     auto put = [&](bf16_t* Yout, uint8_t* bout, int p, const uint4& v) {
@@ -926,41 +934,41 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
 
     // X pieces (and their mask bits) and the stage-1 mask bits one tile ahead (in flight across the whole iteration)
     uint4 rx = keep_bits(load_x(t_beg), load_bits(mask0, t_beg));
-    uint32_t mk = load_bits(mask1, t_beg);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
+    bitsL[pr * LPR + pc] = (uint8_t)load_bits(mask1, t_beg);
     rx = load_x(t_beg + 1);
     uint32_t m0 = load_bits(mask0, t_beg + 1);
     uint32_t mk1 = load_bits(mask1, t_beg + 1);
     __syncthreads();
 
-    for (int t = t_beg; t <= t_end; ++t) {                       // layer 1 on tile t, layer 2 on tile t-1
+    // Iteration t: (1) the finished rows of the previous iteration leave for HBM FIRST (Y1 of tile t-1 from buf1, Y2 of tile
+    // t-2 from buf2), so those stores drain under this iteration's MFMAs instead of in front of the next wait for a loaded
+    // value (hipcc waits vmcnt(0) there, which includes every earlier store); (2) layer 1 on tile t -- its epilogue applies
+    // the ReLU-backward mask from the tile's bits in LDS --, layer 2 on tile t-1; (3) the prefetched X piece and mask bits of
+    // tile t+1 go to LDS, the loads of tile t+2 are issued.  One barrier per tile.
+    for (int t = t_beg; t <= t_end + 1; ++t) {
         const int b = (t - t_beg) & 1;
-        if (role == 0) {
-            if (t < t_end) stage(bufX(b), buf1(b));
-        } else {
-            if (t > t_beg) stage(buf1(b ^ 1), buf2);
+        if (t > t_beg && t - 1 < t_end) {
+            const int p = (t - 1) * kSsRows + pr;
+            if (p < N) put(Y1, bits1, p, *reinterpret_cast<const uint4*>(buf1(b ^ 1) + pr * SX + pc * 8));
         }
-        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? keep_bits(rx, m0) : rx;
+        if (t > t_beg + 1) {
+            const int p = (t - 2) * kSsRows + pr;
+            if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2(b) + pr * SX + pc * 8));
+        }
+        if (role == 0) {
+            if (t < t_end) stage(bufX(b), buf1(b), mask1 ? bitsL + b * (kSsRows * LPR) : nullptr);
+        } else {
+            if (t > t_beg && t - 1 < t_end) stage(buf1(b ^ 1), buf2(b ^ 1), nullptr);
+        }
+        if (t + 1 < t_end) {
+            *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? keep_bits(rx, m0) : rx;
+            bitsL[(b ^ 1) * (kSsRows * LPR) + pr * LPR + pc] = (uint8_t)mk1;
+        }
         rx = load_x(t + 2);
         m0 = load_bits(mask0, t + 2);
-        const uint32_t mk2 = load_bits(mask1, t + 2);
-        __syncthreads();                                         // buf1(b) and buf2 complete
-        if (t < t_end) {   // my piece of the stage-1 tile: mask, write out, (masked) back into the stage-2 input
-            const int p = t * kSsRows + pr;
-            uint4 v = *reinterpret_cast<const uint4*>(buf1(b) + pr * SX + pc * 8);
-            if (mask1) {
-                v = keep_bits(v, mk);
-                *reinterpret_cast<uint4*>(buf1(b) + pr * SX + pc * 8) = v;
-            }
-            if (p < N) put(Y1, bits1, p, v);
-        }
-        if (t > t_beg) {   // ... and of the stage-2 tile of the previous rows
-            const int p = (t - 1) * kSsRows + pr;
-            if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2 + pr * SX + pc * 8));
-        }
-        mk = mk1;
-        mk1 = mk2;
-        __syncthreads();                                         // masked buf1(b) visible; buf2 / bufX(b) free again
+        mk1 = load_bits(mask1, t + 2);
+        __syncthreads();                                         // buf1(b), buf2(b^1), bufX(b^1), bitsL(b^1) complete
     }
 }
 
