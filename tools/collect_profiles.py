@@ -31,10 +31,10 @@ STEP = [
     ("rows_transform_kernel", "conv transform fwd, edge rows (gathers x rows)"),
     ("gather_segsum_vec_kernel", "overflow rows of nodes with > 6 incoming rows (fwd)"),
     ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum"),
-    ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass"),
-    ("rows_wgrad_kernel", "MLP wgrad 2 (+outer ReLU mask, saves masked g)"),
+    ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors)"),
+    ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
-    ("rows_chain2_kernel", "MLP input gradients: dgrad 2 (+ReLU mask) and dgrad 1 in one pass"),
+    ("rows_chain2_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("gather_segsum_vec_kernel", "aux pre-aggregation (bwd)"),
