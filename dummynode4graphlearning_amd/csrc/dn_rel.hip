@@ -684,6 +684,12 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
 constexpr int kSsRows = 32;
 constexpr int kSsSlots = 6;
 
+// DN_STRIDE (default 1): dense-row launches deal tiles round-robin over the workgroups instead of contiguous ranges
+static bool stride_tiles() {
+    static const bool on = [] { const char* e = getenv("DN_STRIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int H>
 __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wn,
                                                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ S,
@@ -704,9 +710,14 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = wave * 16;
     const int pr = tid / LPR, pc = tid % LPR;                    // my piece: row of the tile, 16-byte column chunk
-    const int t_beg = blockIdx.x * tiles_per_wg;
-    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    // tiles dealt round-robin when tiles_per_wg <= 0 (see rows_chain2_kernel), contiguous ranges otherwise
+    const bool rr = tiles_per_wg <= 0;
+    const int first = rr ? (int)blockIdx.x : (int)blockIdx.x * tiles_per_wg, step = rr ? (int)gridDim.x : 1;
+    const int t_beg = 0;
+    const int t_end = rr ? ((first < num_tiles) ? (num_tiles - first + step - 1) / step : 0)
+                         : max(min(first + tiles_per_wg, num_tiles) - first, 0);
     if (t_beg >= t_end) return;
+    auto rowbase = [&](int t) -> int { return (first + t * step) * kSsRows; };
 
     bf16x8 wf[KS];                                               // A operand: Wn rows n0 + (lane & 15), k = ks*32 + 8*(lane>>4)
 #pragma unroll
@@ -719,12 +730,12 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
     }
 
     auto load_x = [&](int t) -> uint4 {
-        const int p = t * kSsRows + pr;
+        const int p = rowbase(t) + pr;
         return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
     };
     struct Slots { int2 a, b, c; };                              // K = 6 ids, 24 bytes per node (8-byte aligned)
     auto load_slots = [&](int t) -> Slots {
-        const int p = t * kSsRows + pr;
+        const int p = rowbase(t) + pr;
         Slots v = {make_int2(-1, -1), make_int2(-1, -1), make_int2(-1, -1)};
         if (t < t_end && p < N) {
             const int2* q = reinterpret_cast<const int2*>(slots + (size_t)p * K);
@@ -780,7 +791,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         rx = load_x(t + 2);
         __syncthreads();
         // (4) epilogue: my piece of the tile + my slot rows, fp32, one rounding
-        const int p = t * kSsRows + pr;
+        const int p = rowbase(t) + pr;
         if (p < N) {
             const uint4 y = *reinterpret_cast<const uint4*>(bufY + pr * SY + pc * 8);
             float a[8];
@@ -818,7 +829,7 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
     hipLaunchKernelGGL((rows_selfsum_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                       (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, out, (nt >> 1) & 1);
+                       (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), out, (nt >> 1) & 1);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -866,9 +877,16 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     const int role = wave / HALF;                                // 0: layer 1, 1: layer 2 (wave-uniform)
     const int n0 = (wave % HALF) * 32;
     const int pr = tid / LPR, pc = tid % LPR;
-    const int t_beg = blockIdx.x * tiles_per_wg;
-    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    // tiles are dealt round-robin (tile = blockIdx.x + i * gridDim.x): at any moment the workgroups stream ADJACENT tiles, so
+    // the launch sweeps HBM like one sequential stream instead of gridDim.x streams a fixed 2 MB apart (same channels)
+    // (tiles_per_wg > 0 selects contiguous ranges instead: DN_STRIDE=0)
+    const bool rr = tiles_per_wg <= 0;
+    const int first = rr ? (int)blockIdx.x : (int)blockIdx.x * tiles_per_wg, step = rr ? (int)gridDim.x : 1;
+    const int t_beg = 0;
+    const int t_end = rr ? ((first < num_tiles) ? (num_tiles - first + step - 1) / step : 0)
+                         : max(min(first + tiles_per_wg, num_tiles) - first, 0);
     if (t_beg >= t_end) return;
+    auto rowbase = [&](int t) -> int { return (first + t * step) * kSsRows; };
 
     const bf16_t* Wn = role ? W2n : W1n;
     const bool relu = role ? (flags & 2) : (flags & 1);
@@ -885,11 +903,11 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     const float* myBias = biasL + role * H + n0 + 4 * (lane >> 4);   // visible after the first barrier below
 
     auto load_x = [&](int t) -> uint4 {
-        const int p = t * kSsRows + pr;
+        const int p = rowbase(t) + pr;
         return (t < t_end && p < N) ? *reinterpret_cast<const uint4*>(X + (size_t)p * H + pc * 8) : make_uint4(0, 0, 0, 0);
     };
     auto load_bits = [&](const uint8_t* m, int t) -> uint32_t {  // my piece's 8 mask bits (0xff when there is no mask)
-        const int p = t * kSsRows + pr;
+        const int p = rowbase(t) + pr;
         return (m && t < t_end && p < N) ? (uint32_t)m[(size_t)p * LPR + pc] : 0xffu;
     };
     // one dense stage on the LDS tile `src`: D = W_slice x rows^T -> bf16 tile `dst` (my 32 columns of all 32 rows)
@@ -949,11 +967,11 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     for (int t = t_beg; t <= t_end + 1; ++t) {
         const int b = (t - t_beg) & 1;
         if (t > t_beg && t - 1 < t_end) {
-            const int p = (t - 1) * kSsRows + pr;
+            const int p = rowbase(t - 1) + pr;
             if (p < N) put(Y1, bits1, p, *reinterpret_cast<const uint4*>(buf1(b ^ 1) + pr * SX + pc * 8));
         }
         if (t > t_beg + 1) {
-            const int p = (t - 2) * kSsRows + pr;
+            const int p = rowbase(t - 2) + pr;
             if (p < N) put(Y2, bits2, p, *reinterpret_cast<const uint4*>(buf2(b) + pr * SX + pc * 8));
         }
         if (role == 0) {
@@ -980,7 +998,7 @@ int launch_chain2(const bf16_t* X, const bf16_t* W1n, const bf16_t* b1, const bf
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     hipLaunchKernelGGL((rows_chain2_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, W1n, b1, W2n, b2, flags, mask0,
-                       mask1, (int32_t)N, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y1, Y2, bits1, bits2);
+                       mask1, (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), Y1, Y2, bits1, bits2);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
