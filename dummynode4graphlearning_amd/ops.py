@@ -300,31 +300,25 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
 
 
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS):
-    """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16: (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).
-    Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more than K rows keeps its first K-1 and gets the
-    id num_edge_rows + j of overflow row j in its last slot (ovf_ptr/ovf_idx: CSR of the rows to pre-sum into it)."""
+    """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16 (dn_slot_table_build_i32, one C-ABI call):
+    (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).  Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more
+    than K rows keeps its first K-1 and gets the id num_edge_rows + j of overflow row j in its last slot (ovf_ptr/ovf_idx:
+    CSR of the rows to pre-sum into it)."""
+    require_gpu(list_ptr, list_rows)
     dev = list_rows.device
     N, P = int(num_nodes), int(num_edge_rows)
-    cnt_all = (list_ptr[1:] - list_ptr[:-1]).long()
-    seg = torch.repeat_interleave(torch.arange(N, device=dev), cnt_all)
-    keep = list_rows < P
-    seg, rows = seg[keep], list_rows[keep].long()
-    cnt = torch.bincount(seg, minlength=N)
-    start = torch.cumsum(cnt, 0) - cnt
-    pos = torch.arange(rows.numel(), device=dev) - start[seg]
-    over = cnt > K
-    in_slot = (~over[seg]) | (pos < K - 1)
-    slots = torch.full((N, K), -1, dtype=I32, device=dev)
-    slots[seg[in_slot], pos[in_slot]] = rows[in_slot].to(I32)
-    n_ovf = int(over.sum())
+    list_ptr, list_rows = list_ptr.to(I32).contiguous(), list_rows.to(I32).contiguous()
+    slots = torch.empty((N, K), dtype=I32, device=dev)
+    ovf_ptr = torch.empty(N + 1, dtype=I32, device=dev)
+    ovf_idx = torch.empty(max(int(list_rows.numel()), 1), dtype=I32, device=dev)
+    ws = _ws(lib().dn_slot_table_workspace_bytes(N), dev)
+    counts = (ctypes.c_int64 * 2)()
+    check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), ptr(slots), ptr(ovf_ptr), ptr(ovf_idx), counts,
+                                        ptr(ws), ws.numel(), stream_ptr()), "dn_slot_table_build_i32")
+    n_ovf, n_rows = int(counts[0]), int(counts[1])
     if n_ovf == 0:
         return slots, None, None, 0
-    ovf_id = torch.cumsum(over.long(), 0) - 1
-    slots[over, K - 1] = (P + ovf_id[over]).to(I32)
-    oseg = ovf_id[seg[~in_slot]]
-    zero = torch.zeros(1, dtype=torch.long, device=dev)
-    ovf_ptr = torch.cat([zero, torch.cumsum(torch.bincount(oseg, minlength=n_ovf), 0)]).to(I32)
-    return slots, ovf_ptr, rows[~in_slot].to(I32).contiguous(), n_ovf
+    return slots, ovf_ptr[:n_ovf + 1], ovf_idx[:n_rows], n_ovf
 
 
 def wgrad_supported(A, G):

@@ -209,6 +209,18 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
                            int32_t* src_rows, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build; replaces the reference's
+ * per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`, subgraph_isomorphism/models/rgin.py:137).
+ * list_ptr [N+1] / list_rows: CSR of row ids per node (dn_row_index_build_i32's dst_ptr/dst_rows or src_ptr/src_rows).
+ * Rows >= num_edge_rows (the self-loop rows) are dropped.  slots [N, K]: the kept rows, -1 padded; a node with more than K
+ * kept rows keeps its first K-1 and gets num_edge_rows + j in slot K-1, j = its rank among such nodes, whose remaining rows
+ * form the CSR (ovf_ptr [<= N+1], ovf_idx [<= len(list_rows)]) the caller pre-sums into overflow row j.
+ * host_counts[0] = number of overflowing nodes, [1] = rows in the overflow CSR (the call synchronises the stream). */
+size_t dn_slot_table_workspace_bytes(int64_t N);
+int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
+                            int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx, int64_t* host_counts, void* workspace,
+                            size_t workspace_bytes, dn_stream_t stream);
+
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
  * Replaces autograd's backward of the reference's per-edge `th.bmm(x[src], W[etype])`

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-batch index build cost on config 5 (what a training loop pays once per mini-batch before the first layer call)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dummynode4graphlearning_amd import ops, synthetic, transforms
+dev = torch.device("cuda:0")
+raw = synthetic.config5()
+t = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
+aug = transforms.dummy_augment_si(t["node_ptr"], t["edge_ptr"], t["src"], t["dst"], t["node_id"], t["node_label"], t["edge_id"],
+                                  t["edge_label"], raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+N, R = int(aug["node_label"].numel()), raw["num_rels"]
+def timed(f, n=5):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): r = f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, r
+ms, ix = timed(lambda: ops.RowIndex(aug["src"], aug["dst"], aug["edge_label"], N, R, self_loop=True))
+print("RowIndex build          %.2f ms" % ms)
+ms_f, _ = timed(lambda: ops.build_slot_table(ix.dst_ptr, ix.dst_rows, N, ix.num_edge_rows))
+ms_b, _ = timed(lambda: ops.build_slot_table(ix.src_ptr, ix.src_rows, N, ix.num_edge_rows))
+print("slot table fwd / bwd    %.2f / %.2f ms" % (ms_f, ms_b))
