@@ -21,3 +21,9 @@ print("RowIndex build          %.2f ms" % ms)
 ms_f, _ = timed(lambda: ops.build_slot_table(ix.dst_ptr, ix.dst_rows, N, ix.num_edge_rows))
 ms_b, _ = timed(lambda: ops.build_slot_table(ix.src_ptr, ix.src_rows, N, ix.num_edge_rows))
 print("slot table fwd / bwd    %.2f / %.2f ms" % (ms_f, ms_b))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5):
+    ops.RowIndex(aug["src"], aug["dst"], aug["edge_label"], N, R, self_loop=True)
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(12)
