@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurement (not the bench.py contract line): GIN conv gather/segment-sum on TU-shaped dummy-augmented
-batches, forward + backward, HIP-graph replay, beside the CPU oracle.
+batches, forward + backward, HIP-graph replay.  (The CPU baseline of the contract lives in
+bench.py's cpu_baseline leg only: tools never touch oracle/.)
 
   python tools/bench_gin.py [--config 2|4] [--graphs 512]
 """
@@ -24,7 +25,6 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     a = ap.parse_args()
     from dummynode4graphlearning_amd import ops, synthetic, transforms
-    from oracle import layers as OL
     dev = torch.device("cuda:0")
     raw = synthetic.config2(graphs=a.graphs) if a.config == 2 else synthetic.config4(graphs=a.graphs)
     H = 128 if a.config == 2 else 256
@@ -59,23 +59,11 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     alg = 2.0 * (E * H * 4 + N * H * 4 + 8.0 * E)
-    # CPU oracle on the same batch
-    xs = x.detach().cpu().requires_grad_(True)
-    src, dst = aug["src"].cpu().long(), aug["dst"].cpu().long()
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    OL.gin_conv(xs, src, dst, 0.0, lambda v: v).backward(gout.cpu())
-    t0 = time.perf_counter()
-    it = 0
-    while time.perf_counter() - t0 < 3.0:
-        xs.grad = None
-        OL.gin_conv(xs, src, dst, 0.0, lambda v: v).backward(gout.cpu())
-        it += 1
-    cpu_ms = (time.perf_counter() - t0) / it * 1e3
     deg = np.bincount(aug["dst"].cpu().numpy(), minlength=N)
     print(json.dumps({"workload": "config%d GIN conv gather fwd+bwd, %d graphs, N=%d E=%d H=%d fp32" % (a.config, a.graphs, N, E, H),
                       "ms": ms, "edges_per_s": E / (ms * 1e-3), "alg_GBps": alg / (ms * 1e-3) / 1e9,
                       "max_in_degree": int(deg.max()), "hubs_split": 0 if index.fwd.hub_ids is None else int(index.fwd.hub_ids.numel()),
-                      "index_build_ms": build_ms, "cpu_oracle_ms": cpu_ms, "cpu_threads": torch.get_num_threads()}))
+                      "index_build_ms": build_ms}))
 
 
 if __name__ == "__main__":
