@@ -576,3 +576,34 @@ def test_full_size_config5_layer_through_batch_properties():
     for k in gw_f:
         if float(gw_f[k].abs().max()) > 0:
             assert _rel_l2(gw_a[k] + gw_b[k], gw_f[k]) < 2e-2, k
+
+
+def test_bf16_step_is_bitwise_reproducible():
+    """No atomics anywhere on the path and fixed summation orders: two runs of the same forward + backward (fused closing
+    launch, two-layer chains with bit masks, LDS-DMA weight gradients) must agree bit for bit -- which also screens the
+    hand-synchronised kernels (counted vmcnt rings, single-barrier pipelines) for races."""
+    from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config5(graphs=4096)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"],
+                                      raw["max_ne"], raw["max_nel"])
+    N, H, R = int(aug["node_label"].numel()), 256, raw["num_rels"]
+    torch.manual_seed(5)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    g = BatchedGraph(aug["src"], aug["dst"], N)
+    et = aug["edge_label"].long()
+    runs = []
+    for _ in range(4):
+        for p in layer.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out, _ = layer(g, x, et)
+        out.backward(coef)
+        runs.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
