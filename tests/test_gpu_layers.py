@@ -147,11 +147,12 @@ def _oracle_gc_forward(model, data, kind):
     return torch.log_softmax(out, dim=-1)
 
 
+@pytest.mark.parametrize("H", [64, 32])                 # 64: matrix-core pipeline; 32 (the reference's tuned width): two-pass path
 @pytest.mark.parametrize("kind", ["GIN", "RGIN", "RGCN"])
-def test_gc_models_match_oracle(kind):
+def test_gc_models_match_oracle(kind, H):
     from dummynode4graphlearning_amd import graph_classification as GC
     rng = np.random.default_rng({"GIN": 1, "RGIN": 2, "RGCN": 3}[kind])
-    F, R, H, C = 8, 5, 64, 2
+    F, R, C = 8, 5, 2
     data = _gc_batch(rng, 32, F, R)
     args = SimpleNamespace(num_features=F, hidden_dim=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
                            additional={"num_layers": 3, "train_eps": False}, epochs=1, device=DEV, dummy_weight=0)
