@@ -181,7 +181,8 @@ def main():
             compute()                                   # warm the private pool on the capture stream
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             compute()
 
     def step():
@@ -236,7 +237,7 @@ def main():
     ops.kernel_timer = None
     n_launch = len(timer.records)
     cgraph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(cgraph):
+    with torch.cuda.graph(cgraph, capture_error_mode="thread_local"):
         conv_gather_scatter()
     cgraph.replay()
     torch.cuda.synchronize()
@@ -287,7 +288,7 @@ def main():
         gin_fb()
         torch.cuda.synchronize()
         gg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gg):
+        with torch.cuda.graph(gg, capture_error_mode="thread_local"):
             gin_fb()
         gg.replay()
         torch.cuda.synchronize()
