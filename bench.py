@@ -182,8 +182,13 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            compute()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                compute()
+        except Exception as exc:                        # never lose the measurement to a capture problem: run eagerly
+            sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
+            torch.cuda.synchronize()
+            graph = None
 
     def step():
         if graph is not None:
@@ -236,16 +241,26 @@ def main():
     conv_gather_scatter()                               # eager pass: counts the launches (times include launch gaps)
     ops.kernel_timer = None
     n_launch = len(timer.records)
-    cgraph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(cgraph, capture_error_mode="thread_local"):
-        conv_gather_scatter()
-    cgraph.replay()
-    torch.cuda.synchronize()
+    def graphed(fn):
+        """fn replayed from a HIP graph; falls back to the eager callable if the capture fails."""
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            return gr.replay
+        except Exception as exc:
+            sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
+            torch.cuda.synchronize()
+            return fn
+
+    replay_conv = graphed(conv_gather_scatter)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(args.steps, 5)
     e0.record()
     for _ in range(reps):
-        cgraph.replay()
+        replay_conv()
     e1.record()
     torch.cuda.synchronize()
     kernel_ms_step = e0.elapsed_time(e1) / reps
@@ -287,14 +302,10 @@ def main():
 
         gin_fb()
         torch.cuda.synchronize()
-        gg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gg, capture_error_mode="thread_local"):
-            gin_fb()
-        gg.replay()
-        torch.cuda.synchronize()
+        replay_gin = graphed(gin_fb)
         e0.record()
         for _ in range(20):
-            gg.replay()
+            replay_gin()
         e1.record()
         torch.cuda.synchronize()
         gms = e0.elapsed_time(e1) / 20
@@ -303,7 +314,7 @@ def main():
                "ms": gms, "edges_per_s": E2 / (gms * 1e-3), "alg_GBps": galg / (gms * 1e-3) / 1e9,
                "frac_of_hbm_peak": galg / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "note": "graph-local source rows are re-read from L2, so the algorithmic rate can exceed the HBM peak"}
-        del x2, go2, ei, gg
+        del x2, go2, ei, replay_gin
 
     if rank == 0:
         line = {
