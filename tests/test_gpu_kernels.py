@@ -226,6 +226,19 @@ def test_rows_transform_matches_reference(H, dt):
     t1 = ops.make_row_tiles([0, N1], DEV)
     got = ops.rows_transform(X.to(DEV), Wn[2:3].contiguous().to(DEV), t1, N1)
     torch.testing.assert_close(got.cpu().double(), X.double() @ Wn[2].double().t(), **tol)
+    # many tiles per workgroup (steady state of the gather pipelines / the LDS-DMA ring), relation changes inside a workgroup
+    big = [70001, 3, 0, 90017, 40000]
+    bptr = [0] + [int(v) for v in np.cumsum(big)]
+    PB = bptr[-1]
+    bidx = torch.from_numpy(rng.integers(0, N1 + N2, size=PB)).to(torch.int32)
+    tb = ops.make_row_tiles(bptr, DEV)
+    got = ops.rows_transform(X.to(DEV), Wn[:5].contiguous().to(DEV), tb, PB, idx=bidx.to(DEV), X2=X2.to(DEV))
+    brel = torch.repeat_interleave(torch.arange(5), torch.tensor(big))
+    for r in range(5):
+        sel = (brel == r).nonzero().reshape(-1)
+        if sel.numel():
+            ref_r = Xcat[bidx[sel].long()] @ Wn[r].double().t()
+            torch.testing.assert_close(got[sel.to(DEV)].cpu().double(), ref_r, **tol)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
