@@ -121,3 +121,68 @@ def test_randomised_parity_sweep():
             assert err < 6e-2, (kind, H, "bf16", err)
         rounds += 1
     print("fuzz rounds:", rounds)
+
+
+def test_randomised_gc_and_dual_sweep():
+    """GIN aggregation + readouts (graph_classification) and the dual message-passing layers on random batches."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops
+    from dummynode4graphlearning_amd.subgraph_isomorphism import CompGCNLayer, DMPLayer
+    rng = np.random.default_rng(int(os.environ.get("DN_FUZZ_SEED", "12345")) + 1)
+    t_end = time.time() + BUDGET
+    rounds = 0
+    while time.time() < t_end or rounds < 3:
+        b = _rand_batch(rng)
+        N, E = int(b["node_ptr"][-1]), len(b["src"])
+        H = int(rng.choice([8, 32, 64, 128]))
+        s_t, d_t = torch.from_numpy(b["src"]), torch.from_numpy(b["dst"])
+        x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+        coef = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+        # GIN aggregation (1 + eps) x_i + sum_j x_j, with a per-edge weight half of the time
+        eps = float(rng.standard_normal()) * 0.3
+        w = torch.from_numpy(rng.random(E).astype(np.float32)) if rng.random() < 0.5 else None
+        ix = ops.EdgeIndex(s_t.to(DEV), d_t.to(DEV), N)
+        xd = x.to(DEV).requires_grad_(True)
+        agg = ops.neighbor_sum(xd, ix, 1.0 + eps, None if w is None else w.to(DEV))
+        (agg * coef.to(DEV)).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        msg = xr[s_t] * (w.view(-1, 1) if w is not None else 1.0)
+        ref = (1.0 + eps) * xr + torch.zeros(N, H).index_add(0, d_t, msg)
+        (ref * coef).sum().backward()
+        sc = float(ref.detach().abs().max().clamp(min=1e-6))
+        assert float((agg.detach().cpu() - ref.detach()).abs().max()) / sc < 1e-5
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max().clamp(min=1e-6)) < 1e-5
+        # readouts
+        gptr = torch.from_numpy(b["node_ptr"]).to(DEV).int()
+        batch = torch.repeat_interleave(torch.arange(len(b["node_ptr"]) - 1), torch.from_numpy(np.diff(b["node_ptr"])))
+        for kind, okind in (("sum", "add"), ("mean", "mean"), ("max", "max")):
+            got = ops.segment_reduce(x.to(DEV), gptr, kind)
+            refp = OL.global_pool(x, batch, len(b["node_ptr"]) - 1, okind)
+            assert float((got.cpu() - refp).abs().max()) < 1e-5 * max(1.0, float(refp.abs().max())), kind
+        # dual layers (fp32, H a matrix-core width half of the time)
+        if E > 0:
+            Hd = int(rng.choice([16, 64]))
+            kind = str(rng.choice(["compgcn", "dmp"]))
+            rev = torch.from_numpy(rng.random(E) < 0.5) if rng.random() < 0.6 else None
+            torch.manual_seed(int(rng.integers(0, 1 << 30)))
+            if kind == "compgcn":
+                comp, norm, sl = str(rng.choice(["sub", "mult", "corr"])), str(rng.choice(["none", "in", "out", "both"])), bool(rng.integers(0, 2))
+                layer = CompGCNLayer(Hd, Hd, self_loop=sl, comp_opt=comp, edge_norm=norm, act_func="tanh")
+            else:
+                nm = int(rng.choice([0, 1, 2]))
+                layer = DMPLayer(Hd, Hd, num_mlp_layers=nm, batch_norm=False, act_func="tanh")
+            xx = torch.from_numpy(rng.standard_normal((N, Hd)).astype(np.float32))
+            ef = torch.from_numpy(rng.standard_normal((E, Hd)).astype(np.float32))
+            p = {k: v.detach().clone() for k, v in layer.named_parameters()}
+            if kind == "compgcn":
+                rn, re = OL.compgcn_layer(xx, ef, s_t, d_t, rev, p, comp_opt=comp, edge_norm=norm, act="tanh")
+            else:
+                rn, re = OL.dmp_layer(xx, ef, s_t, d_t, rev, p, num_mlp_layers=nm, act="tanh")
+            g = BatchedGraph(s_t.to(DEV), d_t.to(DEV), N)
+            if rev is not None:
+                g.edata["is_reversed"] = rev.to(DEV)
+            no, eo = layer.to(DEV)(g, xx.to(DEV), ef.to(DEV))
+            for a, r_, nm_ in ((no, rn, "node"), (eo, re, "edge")):
+                err = float((a.detach().cpu() - r_.detach()).abs().max()) / float(r_.detach().abs().max().clamp(min=1e-6))
+                assert err < 1e-4, (kind, Hd, nm_, err)
+        rounds += 1
+    print("fuzz (gc + dual) rounds:", rounds)
