@@ -186,3 +186,68 @@ def test_randomised_gc_and_dual_sweep():
                 assert err < 1e-4, (kind, Hd, nm_, err)
         rounds += 1
     print("fuzz (gc + dual) rounds:", rounds)
+
+
+def test_randomised_tu_files_and_bookkeeping(tmp_path):
+    """f-2 / f-3 on random inputs: whole DUMMY_/LINE_/CONJ_ datasets byte for byte against the oracle writer (itself pinned to
+    reference-written files), and the conjugate-subisomorphism / match-weight bookkeeping against its restatement."""
+    from dummynode4graphlearning_amd import tu_io
+    from dummynode4graphlearning_amd.subgraph_isomorphism import bookkeeping as BK
+    from oracle import si_bookkeeping as OB
+    from oracle import tu_format as TF
+    rng = np.random.default_rng(int(os.environ.get("DN_FUZZ_SEED", "12345")) + 2)
+    t_end = time.time() + BUDGET
+    rounds = 0
+    while time.time() < t_end or rounds < 2:
+        name = "FZ%d" % rounds
+        raw = os.path.join(str(tmp_path), name, "raw")
+        os.makedirs(raw)
+        G = int(rng.integers(1, 9))
+        A, gi, nl, base = [], [], [], 0
+        for g in range(G):
+            n = int(rng.integers(1, 9))
+            m = int(rng.integers(1, 3 * n + 1)) if (g == G - 1 or rng.random() > 0.15) else 0
+            A += [(base + int(rng.integers(0, n)) + 1, base + int(rng.integers(0, n)) + 1) for _ in range(m)]
+            gi += [g + 1] * n
+            nl += [int(v) for v in rng.integers(0, 4, size=n)]
+            base += n
+        wr = lambda fn, rows: open(os.path.join(raw, "%s_%s.txt" % (name, fn)), "w").write("".join(str(r) + "\n" for r in rows))  # noqa: E731
+        wr("A", ["%d, %d" % e for e in A]); wr("graph_indicator", gi); wr("node_labels", nl)
+        if rng.random() < 0.6:
+            wr("edge_labels", [int(v) for v in rng.integers(0, 3, size=len(A))])
+        with_attr = rng.random() < 0.5 and len(A) > len(gi)          # the reference indexes edge attributes by a node offset
+        if with_attr:
+            wr("node_attributes", [repr(round(float(v), 3)) for v in rng.standard_normal(len(gi))])
+            wr("edge_attributes", [repr(round(float(v), 3)) for v in rng.standard_normal(len(A))])
+        wr("graph_labels", [int(v) for v in rng.integers(0, 2, size=G)])
+        tu_io.process_dataset(raw, name)
+        ref_root = os.path.join(str(tmp_path), "ref%d" % rounds)
+        ref_raw = os.path.join(ref_root, name, "raw")
+        os.makedirs(ref_raw)
+        for fn in os.listdir(raw):
+            with open(os.path.join(raw, fn)) as f, open(os.path.join(ref_raw, fn), "w") as o:
+                o.write(f.read())
+        TF.process_dataset(ref_raw, name)
+        for pre in ("DUMMY_", "LINE_", "CONJ_"):
+            d_got, d_ref = raw.replace(name, pre + name), ref_raw.replace(name, pre + name)
+            assert sorted(os.listdir(d_got)) == sorted(os.listdir(d_ref)), pre
+            for fn in os.listdir(d_ref):
+                with open(os.path.join(d_got, fn)) as f, open(os.path.join(d_ref, fn)) as r:
+                    assert f.read() == r.read(), (pre, fn)
+        # bookkeeping
+        pn, gn = int(rng.integers(2, 6)), int(rng.integers(5, 30))
+        pm = int(rng.integers(1, 10))
+        p_u, p_v, p_el = rng.integers(0, pn, size=pm), rng.integers(0, pn, size=pm), rng.integers(0, 3, size=pm)
+        S_ = int(rng.integers(1, 9))
+        sub = np.stack([rng.permutation(gn)[:pn] for _ in range(S_)])
+        g_u = np.concatenate([rng.integers(0, gn, size=40), sub[:, p_u].reshape(-1)])
+        g_v = np.concatenate([rng.integers(0, gn, size=40), sub[:, p_v].reshape(-1)])
+        g_el = np.concatenate([rng.integers(0, 3, size=40), np.tile(p_el, S_)])
+        o = np.lexsort((g_v, g_u))
+        g_u, g_v, g_el = g_u[o], g_v[o], g_el[o]
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64)).to(DEV)  # noqa: E731
+        a = [t(v) for v in (p_u, p_v, p_el, g_u, g_v, g_el, sub)]
+        assert np.array_equal(BK.get_conjugate_subisomorphisms(*a).cpu().numpy(), OB.conjugate_subisomorphisms(p_u, p_v, p_el, g_u, g_v, g_el, sub))
+        assert np.array_equal(BK.compute_edgeseq_subisoweights(*a).cpu().numpy(), OB.edgeseq_subisoweights(p_u, p_v, p_el, g_u, g_v, g_el, sub))
+        rounds += 1
+    print("fuzz (tu files + bookkeeping) rounds:", rounds)
