@@ -1,6 +1,7 @@
 """Randomised parity sweep: device transforms and layers against the oracle on random batches (degenerate shapes included).
 Runs for DN_FUZZ_SECONDS (default 15 s) so that it stays cheap in the regular suite; set it to minutes for a soak run."""
 import os
+import shutil
 import time
 
 import numpy as np
@@ -234,6 +235,8 @@ def test_randomised_tu_files_and_bookkeeping(tmp_path):
             for fn in os.listdir(d_ref):
                 with open(os.path.join(d_got, fn)) as f, open(os.path.join(d_ref, fn)) as r:
                     assert f.read() == r.read(), (pre, fn)
+        for d in [ref_root] + [os.path.join(str(tmp_path), pre + name) for pre in ("", "DUMMY_", "LINE_", "CONJ_")]:
+            shutil.rmtree(d, ignore_errors=True)                 # a soak run writes tens of thousands of datasets
         # bookkeeping
         pn, gn = int(rng.integers(2, 6)), int(rng.integers(5, 30))
         pm = int(rng.integers(1, 10))
