@@ -34,6 +34,7 @@ class GINConv(nn.Module):
         else:
             self.register_buffer("eps", torch.tensor([float(eps)]))
         self.train_eps = bool(train_eps)
+        self._eps_host = None            # (tensor id, version, value): host copy of the eps BUFFER, refreshed when it changes
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -41,13 +42,21 @@ class GINConv(nn.Module):
         with torch.no_grad():
             self.eps.fill_(self.initial_eps)
 
+    def _eps_value(self):
+        """The registered buffer's value as a host float (the self coefficient is a kernel argument).  Read back only when
+        the buffer object or its version changed (load_state_dict, in-place edits, .to()): no per-forward sync."""
+        key = (id(self.eps), self.eps._version)
+        if self._eps_host is None or self._eps_host[0] != key:
+            self._eps_host = (key, float(self.eps))
+        return self._eps_host[1]
+
     def forward(self, x, data):
         index = edge_index_of(data)
         if self.train_eps:
             # gradient w.r.t. eps flows through the torch add; neighbours through the HIP gather
             out = ops.neighbor_sum(x, index, 0.0) + (1.0 + self.eps.to(x.dtype)) * x
         else:
-            out = ops.neighbor_sum(x, index, 1.0 + float(self.initial_eps))
+            out = ops.neighbor_sum(x, index, 1.0 + self._eps_value())
         return self.nn(out)
 
 
@@ -146,6 +155,13 @@ class SAGEConv(nn.Module):
         self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # the PyG constructor re-initialises both Linears (same U(-1/sqrt(in), 1/sqrt(in)) law as nn.Linear): a second draw
+        # from the RNG stream, kept for initial-weight parity under the same seed
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
 
     def forward(self, x, data):
         index = edge_index_of(data)

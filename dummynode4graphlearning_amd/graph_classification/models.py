@@ -28,10 +28,23 @@ def _mlp(in_dim, out_dim):
 
 
 def _edge_type(data, x):
+    """rgconv.py:35-38,110-113.  The derived tensor is kept on the batch object (keyed on the edge_attr tensor and its
+    version) so that every conv of every forward over the same batch presents the SAME edge_type tensor to the index cache
+    of graph.py (a fresh tensor per forward would rebuild the relation index -- sorts and stream syncs -- each time)."""
     edge_attr = getattr(data, "edge_attr", None)
+    hit = getattr(data, "_dn_edge_type", None)
+    key = (None, 0, data.edge_index.size(1)) if edge_attr is None else (id(edge_attr), edge_attr._version, edge_attr.shape[0])
+    if hit is not None and hit[0] == key and hit[1].device == x.device:
+        return hit[1]
     if edge_attr is not None:
-        return edge_attr.max(dim=1)[1]                              # rgconv.py:35-36,110-111
-    return torch.zeros(data.edge_index.size(1), dtype=torch.long, device=x.device)
+        et = edge_attr.max(dim=1)[1]
+    else:
+        et = torch.zeros(data.edge_index.size(1), dtype=torch.long, device=x.device)
+    try:
+        data._dn_edge_type = (key, et, edge_attr)          # edge_attr kept alive so its id cannot be recycled
+    except Exception:
+        pass
+    return et
 
 
 def _dummy_edge_weight(model, data, device):

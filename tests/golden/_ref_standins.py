@@ -9,7 +9,12 @@ behaviour of
 * ``python-igraph`` 0.9 ``Graph`` (only the dozen methods the reference touches),
 * ``dgl`` (``DGLGraph.update_all/apply_edges`` for a message UDF + ``fn.sum`` reducer),
 * ``numba.jit`` (identity decorator), ``torch._six.container_abcs``,
-* the three ``torch_geometric`` names ``tu_data_processing.py`` imports.
+* the three ``torch_geometric`` names ``tu_data_processing.py`` imports,
+* ``torch_geometric.nn`` 2.0.2 (the pin of README.md:26): ``GINConv``, ``RGCNConv``/``FastRGCNConv``, ``GCNConv``,
+  ``SAGEConv``, ``global_{add,mean,max}_pool`` -- the published layer definitions in plain CPU torch, including what
+  their constructors do to the RNG stream (``reset_parameters`` runs in every constructor, GINConv re-initialises its
+  ``nn``, PyG ``Linear`` initialises itself once before the conv re-initialises it), so that the reference's GC models
+  (models/gconv.py, models/rgconv.py) can be imported and run unmodified.
 
 igraph semantics relied on (python-igraph docs): ``add_vertices``/``add_edges`` append in
 order; attribute sequences are plain per-element lists, new elements get ``None``;
@@ -20,6 +25,7 @@ once over all edges (eid order), sums messages by destination, then calls the no
 once over all nodes.
 """
 import collections.abc
+import math
 import sys
 import types
 
@@ -268,6 +274,246 @@ class FakeDGLGraph:
         self.ndata.pop(reduce_func.out)
 
 
+# --------------------------------------------------------------------------- torch_geometric.nn (2.0.2)
+def _glorot(t):
+    """torch_geometric.nn.inits.glorot: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))."""
+    if t is not None:
+        a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+        t.data.uniform_(-a, a)
+
+
+def _pyg_reset(nn):
+    """torch_geometric.nn.inits.reset (2.0.2): the DIRECT children that have reset_parameters, else the module itself."""
+    def _one(item):
+        if hasattr(item, "reset_parameters"):
+            item.reset_parameters()
+    if nn is not None:
+        if hasattr(nn, "children") and len(list(nn.children())) > 0:
+            for item in nn.children():
+                _one(item)
+        else:
+            _one(nn)
+
+
+class _PygLinear(th.nn.Module):
+    """torch_geometric.nn.dense.linear.Linear: weight [out, in]; weight_initializer None -> kaiming_uniform(fan=in,
+    a=sqrt(5)) i.e. U(-1/sqrt(in), 1/sqrt(in)); 'glorot' -> glorot; bias_initializer None -> U(-1/sqrt(in), 1/sqrt(in))."""
+
+    def __init__(self, in_channels, out_channels, bias=True, weight_initializer=None, bias_initializer=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer, self.bias_initializer = weight_initializer, bias_initializer
+        self.weight = th.nn.Parameter(th.Tensor(out_channels, in_channels))
+        if bias:
+            self.bias = th.nn.Parameter(th.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight_initializer == "glorot":
+            _glorot(self.weight)
+        else:
+            bound = math.sqrt(6.0 / ((1.0 + 5.0) * self.in_channels))
+            self.weight.data.uniform_(-bound, bound)
+        if self.bias is not None:
+            if self.bias_initializer == "zeros":
+                self.bias.data.fill_(0.0)
+            else:
+                bound = 1.0 / math.sqrt(self.in_channels)
+                self.bias.data.uniform_(-bound, bound)
+
+    def forward(self, x):
+        return th.nn.functional.linear(x, self.weight, self.bias)
+
+
+def _scatter_sum(src, index, n):
+    return th.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add(0, index, src)
+
+
+def _scatter_mean(src, index, n):
+    cnt = th.bincount(index, minlength=n).clamp(min=1).to(src.dtype)
+    return _scatter_sum(src, index, n) / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+
+class _ScatterMax(th.autograd.Function):
+    """torch_scatter.scatter_max (CPU): empty segments give 0; the gradient goes to the FIRST maximal entry."""
+
+    @staticmethod
+    def forward(ctx, src, index, n):
+        out = th.full((n,) + tuple(src.shape[1:]), float("-inf"), dtype=src.dtype)
+        arg = th.full(out.shape, -1, dtype=th.long)
+        for e in range(src.shape[0]):                      # golden sizes are tiny
+            i = int(index[e])
+            better = src[e] > out[i]
+            out[i] = th.where(better, src[e], out[i])
+            arg[i] = th.where(better, th.full_like(arg[i], e), arg[i])
+        out = th.where(arg < 0, th.zeros_like(out), out)
+        ctx.save_for_backward(arg)
+        ctx.rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        gs = th.zeros((ctx.rows + 1,) + tuple(g.shape[1:]), dtype=g.dtype)
+        gs.scatter_add_(0, th.where(arg < 0, th.full_like(arg, ctx.rows), arg), g)
+        return gs[:-1], None, None
+
+
+def _aggregate(msg, index, n, aggr):
+    if aggr == "add":
+        return _scatter_sum(msg, index, n)
+    if aggr == "mean":
+        return _scatter_mean(msg, index, n)
+    if aggr == "max":
+        return _ScatterMax.apply(msg, index, n)
+    raise ValueError(aggr)
+
+
+def global_add_pool(x, batch, size=None):
+    return _scatter_sum(x, batch, int(batch.max()) + 1 if size is None else size)
+
+
+def global_mean_pool(x, batch, size=None):
+    return _scatter_mean(x, batch, int(batch.max()) + 1 if size is None else size)
+
+
+def global_max_pool(x, batch, size=None):
+    return _ScatterMax.apply(x, batch, int(batch.max()) + 1 if size is None else size)
+
+
+class GINConv(th.nn.Module):
+    """x_i' = nn((1 + eps) x_i + sum_{j -> i} x_j); eps a Parameter iff train_eps is truthy, else a buffer."""
+
+    def __init__(self, nn, eps=0.0, train_eps=False, **kwargs):
+        super().__init__()
+        self.aggr = "add"
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = th.nn.Parameter(th.Tensor([eps]))
+        else:
+            self.register_buffer("eps", th.Tensor([eps]))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _pyg_reset(self.nn)
+        self.eps.data.fill_(self.initial_eps)
+
+    def forward(self, x, edge_index, size=None):
+        out = _aggregate(x[edge_index[0]], edge_index[1], x.shape[0], self.aggr)
+        out = out + (1 + self.eps) * x
+        return self.nn(out)
+
+
+class RGCNConv(th.nn.Module):
+    """x_i' = sum_r aggr_{j in N_r(i)} x_j W_r + x_i root + bias (no bases / blocks on the reference's call sites);
+    parameters created weight, root, bias; reset: glorot(weight), glorot(root), zeros(bias)."""
+
+    def __init__(self, in_channels, out_channels, num_relations, num_bases=None, num_blocks=None, aggr="mean",
+                 root_weight=True, bias=True, **kwargs):
+        super().__init__()
+        assert num_bases is None and num_blocks is None
+        self.aggr = aggr
+        self.in_channels, self.out_channels, self.num_relations = in_channels, out_channels, num_relations
+        self.weight = th.nn.Parameter(th.Tensor(num_relations, in_channels, out_channels))
+        if root_weight:
+            self.root = th.nn.Parameter(th.Tensor(in_channels, out_channels))
+        else:
+            self.register_parameter("root", None)
+        if bias:
+            self.bias = th.nn.Parameter(th.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _glorot(self.weight)
+        _glorot(self.root)
+        if self.bias is not None:
+            self.bias.data.fill_(0.0)
+
+    def forward(self, x, edge_index, edge_type=None):
+        n = x.shape[0]
+        out = th.zeros(n, self.out_channels, dtype=x.dtype)
+        for r in range(self.num_relations):
+            m = edge_type == r
+            h = _aggregate(x[edge_index[0][m]], edge_index[1][m], n, self.aggr)
+            out = out + h @ self.weight[r]
+        if self.root is not None:
+            out = out + x @ self.root
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+class GCNConv(th.nn.Module):
+    """x' = D^-1/2 (A + I) D^-1/2 (x W) + b over weighted edges (gcn_norm with add_remaining_self_loops, fill 1)."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, add_self_loops=True, normalize=True,
+                 bias=True, **kwargs):
+        super().__init__()
+        assert not improved and not cached and add_self_loops and normalize
+        self.aggr = "add"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = _PygLinear(in_channels, out_channels, bias=False, weight_initializer="glorot")
+        if bias:
+            self.bias = th.nn.Parameter(th.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.fill_(0.0)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        n = x.shape[0]
+        row, col = edge_index[0], edge_index[1]
+        if edge_weight is None:
+            edge_weight = th.ones(row.numel(), dtype=x.dtype)
+        # add_remaining_self_loops: existing loops are moved to the end, one per node, keeping their weight
+        keep = row != col
+        loop_w = th.ones(n, dtype=edge_weight.dtype)
+        if not bool(keep.all()):
+            loop_w = loop_w.index_put((row[~keep],), edge_weight[~keep])
+        ar = th.arange(n)
+        row, col = th.cat([row[keep], ar]), th.cat([col[keep], ar])
+        w = th.cat([edge_weight[keep], loop_w])
+        deg = _scatter_sum(w, col, n)
+        dis = deg.pow(-0.5)
+        dis = dis.masked_fill(dis == float("inf"), 0)
+        norm = dis[row] * w * dis[col]
+        h = self.lin(x)
+        out = _scatter_sum(norm.view(-1, 1) * h[row], col, n)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+class SAGEConv(th.nn.Module):
+    """x_i' = lin_l(aggr_{j -> i} x_j) + lin_r(x_i); lin_l with bias, lin_r without; the constructor re-initialises both."""
+
+    def __init__(self, in_channels, out_channels, normalize=False, root_weight=True, bias=True, **kwargs):
+        super().__init__()
+        assert not normalize and root_weight
+        self.aggr = kwargs.get("aggr", "mean")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = _PygLinear(in_channels, out_channels, bias=bias)
+        self.lin_r = _PygLinear(in_channels, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x, edge_index, size=None):
+        out = _aggregate(x[edge_index[0]], edge_index[1], x.shape[0], self.aggr)
+        return self.lin_l(out) + self.lin_r(x)
+
+
 # --------------------------------------------------------------------------- numba
 class _NumbaType:
     def __getitem__(self, k):
@@ -325,7 +571,13 @@ def install():
         pyg_data.download_url = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no network"))
         pyg_data.extract_zip = pyg_data.download_url
         pyg_ds.TUDataset = object
-        pyg.data, pyg.datasets = pyg_data, pyg_ds
+        pyg_nn = types.ModuleType("torch_geometric.nn")
+        for cls in (GINConv, RGCNConv, GCNConv, SAGEConv):
+            setattr(pyg_nn, cls.__name__, cls)
+        pyg_nn.FastRGCNConv = RGCNConv
+        pyg_nn.global_add_pool, pyg_nn.global_mean_pool, pyg_nn.global_max_pool = global_add_pool, global_mean_pool, global_max_pool
+        pyg.data, pyg.datasets, pyg.nn = pyg_data, pyg_ds, pyg_nn
         sys.modules["torch_geometric"] = pyg
         sys.modules["torch_geometric.data"] = pyg_data
         sys.modules["torch_geometric.datasets"] = pyg_ds
+        sys.modules["torch_geometric.nn"] = pyg_nn

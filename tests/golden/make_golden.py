@@ -11,6 +11,9 @@ The reference's Python is imported unmodified, with the absent third-party modul
                        incl. KAT-1 = the paper's figure/edge2vertex.png example
   tu_files.json        f-3 the DUMMY_/LINE_/CONJ_ dataset files written by save_graph_data /
                        save_graph_labels (tu_data_processing.py:341-414) for three toy TU datasets
+  gc_models.npz        a-6 / a-7 / f-1 the GC models (models/gconv.py:20-215, models/rgconv.py:6-126) run unmodified on
+                       torch_geometric.nn stand-ins: seeded initial state_dicts, log-probs, every gradient
+                       (incl. the scalar dummy-edge weight), BatchNorm buffers after the step
   si_transforms.json   a-4 add_dummy_nodes_edges (SI train.py:404-474) + a-5
                        convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
   si_bookkeeping.json  f-2 get_conjugate_subisomorphisms, compute_{nodeseq,edgeseq}_subisoweights, compute_norm,
@@ -165,6 +168,101 @@ def make_tu_files():
     with open(os.path.join(HERE, "tu_files.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("tu_files.json: %d datasets, %d output files" % (len(out), sum(len(o["outputs"]) for o in out)))
+
+
+def _gc_batch(rng, G, F, R, n_lo=3, n_hi=12, C=2):
+    """A collated DUMMY_*-style batch (PyG layout): per graph n-1 real nodes + the dummy as LAST node, connected both ways
+    to every real node with edge type 0 (one-hot edge_attr, as read_tu_data builds it); real edges with types 1..R-1,
+    multi-edges allowed, self loops removed (read_tu_data does)."""
+    xs, eis, ets, batch, ys = [], [], [], [], []
+    base = 0
+    for g in range(G):
+        n = int(rng.integers(n_lo, n_hi))
+        m = int(rng.integers(n, 3 * n))
+        s, d = rng.integers(0, n - 1, size=m), rng.integers(0, n - 1, size=m)
+        keep = s != d
+        s, d = s[keep], d[keep]
+        t = rng.integers(1, R, size=len(s))
+        real = np.arange(n - 1)
+        s = np.concatenate([s, np.full(n - 1, n - 1), real])
+        d = np.concatenate([d, real, np.full(n - 1, n - 1)])
+        t = np.concatenate([t, np.zeros(2 * (n - 1), dtype=np.int64)])
+        xs.append(rng.standard_normal((n, F)).astype(np.float32))
+        eis.append(np.stack([s, d]) + base)
+        ets.append(t)
+        batch.append(np.full(n, g))
+        ys.append(int(rng.integers(0, C)))
+        base += n
+    return dict(x=np.concatenate(xs), edge_index=np.concatenate(eis, 1).astype(np.int64),
+                edge_type=np.concatenate(ets).astype(np.int64), batch=np.concatenate(batch).astype(np.int64),
+                y=np.asarray(ys, dtype=np.int64))
+
+
+def make_gc_models():
+    """a-6 / a-7 / f-1: GIN, RGIN, RGCN, GCN, GCN_concat_readout, GraphSAGE exactly as models/gconv.py and models/rgconv.py
+    define them, imported unmodified (torch_geometric.nn = the stand-ins of _ref_standins.py), one training step each:
+    seeded construction -> state_dict, forward in train mode -> log-probs, F.nll_loss (main.py:41) -> every gradient."""
+    import importlib.util
+    from types import SimpleNamespace
+    mdir = os.path.join(REF, "graph_classification", "graph_neural_networks", "models")
+    mods = {}
+    for name in ("gconv", "rgconv"):
+        spec = importlib.util.spec_from_file_location("_ref_gc_" + name, os.path.join(mdir, name + ".py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    rng = np.random.default_rng(77)
+    out, meta = {}, []
+    #        kind, module, hidden, additional, dummy_weight, graphs, F, R, C
+    specs = [("GIN", "gconv", 32, None, 0.0, 24, 8, 5, 2),                                    # default config: 2 layers
+             ("GIN", "gconv", 32, {"num_layers": 3}, 0.0, 24, 8, 5, 2),                       # train_eps falls back to args.epochs (sic)
+             ("GIN", "gconv", 64, {"num_layers": 3, "train_eps": False, "aggregation": "mean"}, 0.0, 24, 8, 5, 3),
+             ("GIN", "gconv", 128, {"num_layers": 2, "train_eps": True}, 0.0, 16, 5, 2, 2),   # config-2 width
+             ("GIN", "gconv", 256, {"num_layers": 2, "train_eps": False}, 0.0, 16, 38, 2, 2), # config-4 width / F
+             ("RGIN", "rgconv", 32, None, 0.0, 24, 8, 5, 2),
+             ("RGIN", "rgconv", 64, {"num_layers": 3, "weight_reg": 2.0}, 0.0, 24, 8, 5, 2),
+             ("RGIN", "rgconv", 64, {"num_layers": 2, "aggregation": "mean"}, 0.0, 24, 8, 4, 3),
+             ("RGCN", "rgconv", 32, None, 0.0, 24, 8, 5, 2),
+             ("RGCN", "rgconv", 64, {"weight_reg": 3.0}, 0.0, 24, 64, 5, 2),                  # square first conv (F = H = 64)
+             ("GCN", "gconv", 32, None, 0.0, 24, 8, 5, 3),
+             ("GCN", "gconv", 32, None, 0.7, 24, 8, 5, 3),
+             ("GCN_concat_readout", "gconv", 32, None, 1.3, 24, 8, 5, 3),
+             ("GCN_concat_readout", "gconv", 64, None, 0.0, 24, 8, 5, 2),
+             ("GraphSAGE", "gconv", 32, None, 0.0, 24, 8, 5, 3),
+             ("GraphSAGE", "gconv", 32, {"num_layers": 3, "aggregation": "max"}, 0.0, 24, 8, 5, 3),
+             ("GraphSAGE", "gconv", 64, {"num_layers": 2, "aggregation": "mean"}, 0.0, 24, 8, 5, 2)]
+    for cid, (kind, mod, H, additional, dw, G, F_, R, C) in enumerate(specs):
+        tag = "gc%02d" % cid
+        d = _gc_batch(rng, G, F_, R, C=C)
+        args = SimpleNamespace(num_features=F_, hidden_dim=H, nhid=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
+                               additional=additional, epochs=3, device="cpu", dummy_weight=dw)
+        th.manual_seed(4000 + cid)
+        model = getattr(mods[mod], kind)(args)
+        for k, v in model.state_dict().items():
+            out[tag + "/init/" + k] = v.detach().numpy().copy()
+        et = th.from_numpy(d["edge_type"])
+        data = SimpleNamespace(x=th.from_numpy(d["x"]), edge_index=th.from_numpy(d["edge_index"]), batch=th.from_numpy(d["batch"]),
+                               edge_attr=th.nn.functional.one_hot(et, R).float(), y=th.from_numpy(d["y"]),
+                               is_dummy_edge=et == 0)
+        model.train()
+        logp = model(data)
+        loss = th.nn.functional.nll_loss(logp, data.y)
+        loss.backward()
+        for k, v in d.items():
+            out[tag + "/" + k] = v
+        out[tag + "/logp"] = logp.detach().numpy()
+        out[tag + "/loss"] = np.float32(loss.item())
+        for k, p in model.named_parameters():
+            out[tag + "/grad/" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+        for k, v in model.state_dict().items():                      # BatchNorm running stats after the step
+            if "running_" in k or "num_batches" in k:
+                out[tag + "/after/" + k] = v.detach().numpy().copy()
+        if dw > 0:
+            out[tag + "/grad_dummy_weight"] = np.float32(model.dummy_weight.grad.item())
+        meta.append(dict(tag=tag, kind=kind, hidden_dim=H, additional=additional, dummy_weight=dw, num_graphs=G,
+                         num_features=F_, num_relations=R, num_classes=C, seed=4000 + cid, epochs=3))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "gc_models.npz"), **out)
+    print("gc_models.npz: %d cases" % len(meta))
 
 
 # ------------------------------------------------------------------------------- SI
@@ -521,6 +619,7 @@ def make_si_layers():
 if __name__ == "__main__":
     make_gc()
     make_tu_files()
+    make_gc_models()
     make_si_transforms()
     make_si_bookkeeping()
     make_si_dual_layers()

@@ -1,5 +1,5 @@
-"""GPU parity of the nn.Module surface (RGINLayer / RGCNLayer / GIN / RGCN / RGIN) against the golden vectors
-captured from the reference's own layers and against the oracle restatement.
+"""GPU parity of the SI nn.Module surface (RGINLayer / RGCNLayer / rep nets / dual layers / predict nets) against the golden
+vectors captured from the reference's own layers and against the oracle restatement (GC models: test_gpu_gc_models.py).
 
 Tolerance (north_star): fp32 layer outputs within 1e-4 relative of the reference.  Relative error is measured
 against the tensor's max magnitude (rel_max = max|a-b| / max|b|), gradients included."""
@@ -98,82 +98,6 @@ def test_rgin_layer_bf16_close_to_fp32_reference(golden_dir):
     assert max(errs.values()) < 0.15, errs
 
 
-def _gc_batch(rng, G, F, R, n_lo=3, n_hi=12):
-    from dummynode4graphlearning_amd import GraphBatch
-    items = []
-    for _ in range(G):
-        n = int(rng.integers(n_lo, n_hi))
-        m = int(rng.integers(n, 3 * n))
-        ei = torch.from_numpy(np.stack([rng.integers(0, n, size=m), rng.integers(0, n, size=m)]))
-        # dummy node = last vertex, connected both ways to everybody (one-hot edge type 0 as in DUMMY_* files)
-        d_src = torch.cat([torch.full((n - 1,), n - 1), torch.arange(n - 1)])
-        d_dst = torch.cat([torch.arange(n - 1), torch.full((n - 1,), n - 1)])
-        ei = torch.cat([ei, torch.stack([d_src, d_dst])], 1)
-        et = torch.cat([torch.from_numpy(rng.integers(1, R, size=m)), torch.zeros(2 * (n - 1), dtype=torch.long)])
-        items.append(SimpleNamespace(
-            x=torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)), edge_index=ei,
-            edge_attr=torch.nn.functional.one_hot(et, R).float(), y=torch.tensor([int(rng.integers(0, 2))]),
-            is_dummy_node=None, is_dummy_edge=None))
-    return GraphBatch.collate(items)
-
-
-def _oracle_gc_forward(model, data, kind):
-    """The GC forward with every message-passing / readout step done by the oracle on the CPU."""
-    x = data.x
-    src, dst, batch, B = data.edge_index[0], data.edge_index[1], data.batch, data.num_graphs
-    if kind == "RGCN":
-        et = data.edge_attr.max(dim=1)[1]
-        for conv in (model.conv1, model.conv2):
-            x = torch.relu(OL.rgcn_conv(x, src, dst, et, conv.weight, conv.root, conv.bias, aggr="mean"))
-        x = OL.global_pool(x, batch, B, "mean")
-        x = torch.relu(model.lin1(x))
-        x = torch.relu(model.lin2(x))
-        return torch.log_softmax(model.lin3(x), dim=-1)
-    out = 0
-    for layer in range(model.no_layers):
-        if layer == 0:
-            x = model.first_h(x)
-            out = out + OL.global_pool(model.linears[0](x), batch, B, "add")
-        else:
-            if kind == "GIN":
-                conv = model.convs[layer - 1]
-                x = OL.gin_conv(x, src, dst, float(conv.eps), conv.nn)
-            else:
-                conv = model.convs[layer - 1]
-                et = data.edge_attr.max(dim=1)[1]
-                x = OL.rgcn_conv(x, src, dst, et, conv.weight, conv.root, conv.bias, aggr="add")
-                x = model.nns[layer - 1](x)
-            out = out + model.linears[layer](OL.global_pool(x, batch, B, "add"))
-    return torch.log_softmax(out, dim=-1)
-
-
-@pytest.mark.parametrize("H", [64, 32])                 # 64: matrix-core pipeline; 32 (the reference's tuned width): two-pass path
-@pytest.mark.parametrize("kind", ["GIN", "RGIN", "RGCN"])
-def test_gc_models_match_oracle(kind, H):
-    from dummynode4graphlearning_amd import graph_classification as GC
-    rng = np.random.default_rng({"GIN": 1, "RGIN": 2, "RGCN": 3}[kind])
-    F, R, C = 8, 5, 2
-    data = _gc_batch(rng, 32, F, R)
-    args = SimpleNamespace(num_features=F, hidden_dim=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
-                           additional={"num_layers": 3, "train_eps": False}, epochs=1, device=DEV, dummy_weight=0)
-    torch.manual_seed(0)
-    model = getattr(GC, kind)(args)
-    ref_model = getattr(GC, kind)(args)
-    ref_model.load_state_dict(model.state_dict())
-    model = model.to(DEV).train()
-    ref_model.train()
-    out = model(data.to(DEV))
-    ref = _oracle_gc_forward(ref_model, data, kind)
-    loss = torch.nn.functional.nll_loss(out, data.y.to(DEV))
-    loss.backward()
-    torch.nn.functional.nll_loss(ref, data.y).backward()
-    assert _rel_max(out, ref) < RTOL
-    for (k, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
-        # a Linear bias feeding BatchNorm has an exactly-zero true gradient (pure rounding noise): skip those
-        if q.grad is not None and q.grad.abs().max() > 1e-5:
-            assert _rel_max(p.grad, q.grad) < 5e-4, k     # BN backward amplifies rounding; 5e-4 of the grad range
-
-
 def test_rep_net_residual_and_gate(golden_dir):
     from dummynode4graphlearning_amd import BatchedGraph
     from dummynode4graphlearning_amd.subgraph_isomorphism import RGINRepNet
@@ -238,68 +162,6 @@ def test_relu_mlp_matches_torch_autograd(dt):
     for i, d in enumerate(dl):
         assert _rel_l2(d.weight.grad, ref_gw[i]) < lim
         assert _rel_l2(d.bias.grad, ref_gb[i]) < lim
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# GCN / GCN_concat_readout / GraphSAGE with the trainable dummy-edge weight (gconv.py:20-152)
-# ------------------------------------------------------------------------------------------------------------------
-def _oracle_f1_forward(model, data, kind):
-    x, src, dst, batch, B = data.x, data.edge_index[0], data.edge_index[1], data.batch, data.num_graphs
-    if kind in ("GCN", "GCN_concat_readout"):
-        w = None
-        if model.use_edge_weight:
-            w = torch.where(data.is_dummy_edge, model.dummy_weight, torch.ones(src.numel()))
-        for conv in (model.conv1, model.conv2):
-            x = torch.relu(OL.gcn_conv(x, src, dst, w, conv.lin.weight, conv.bias))
-        if kind == "GCN":
-            x = OL.global_pool(x, batch, B, "mean")
-        else:
-            x = torch.cat([OL.global_pool(x, batch, B, "max"), OL.global_pool(x, batch, B, "mean")], dim=1)
-        x = torch.relu(model.lin1(x))
-        x = torch.relu(model.lin2(x))
-        return torch.log_softmax(model.lin3(x), dim=-1)
-    xs = []
-    for conv in model.layers:
-        x = OL.sage_conv(x, src, dst, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, aggr=model.aggregation)
-        if model.aggregation == "max":
-            x = torch.relu(model.fc_max(x))
-        xs.append(x)
-    x = OL.global_pool(torch.cat(xs, dim=1), batch, B, "max")
-    return torch.log_softmax(model.fc2(torch.relu(model.fc1(x))), dim=-1)
-
-
-@pytest.mark.parametrize("kind,additional,dummy_weight", [
-    ("GCN", None, 0.0), ("GCN", None, 0.7), ("GCN_concat_readout", None, 1.3),
-    ("GraphSAGE", {"num_layers": 2, "aggregation": "mean"}, 0.0), ("GraphSAGE", {"num_layers": 3, "aggregation": "max"}, 0.0)])
-def test_gcn_sage_models_match_oracle(kind, additional, dummy_weight):
-    from dummynode4graphlearning_amd import graph_classification as GC
-    rng = np.random.default_rng(11)
-    F_, R, H, C = 8, 5, 32, 3
-    data = _gc_batch(rng, 24, F_, R)
-    # dummy flags as set_dummy_flags derives them (dataset.py:118-139): edge type 0 marks the dummy edges
-    data.is_dummy_edge = data.edge_attr[:, 0] > 0
-    data.y = torch.from_numpy(rng.integers(0, C, size=data.num_graphs))
-    mk = lambda dev: SimpleNamespace(num_features=F_, hidden_dim=H, num_classes=C, dropout_ratio=0.0, num_relations=R,  # noqa: E731
-                                     additional=additional, epochs=1, device=dev, dummy_weight=dummy_weight)
-    torch.manual_seed(2)
-    model = getattr(GC, kind)(mk(DEV))
-    ref = getattr(GC, kind)(mk("cpu"))
-    ref.load_state_dict(model.state_dict())
-    model = model.to(DEV).train()
-    ref.train()
-    d = data.to(DEV)
-    d.is_dummy_edge = data.is_dummy_edge.to(DEV)
-    out = model(d)
-    torch.nn.functional.nll_loss(out, d.y).backward()
-    want = _oracle_f1_forward(ref, data, kind)
-    torch.nn.functional.nll_loss(want, data.y).backward()
-    assert _rel_max(out, want) < RTOL
-    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        if q.grad is not None and q.grad.abs().max() > 1e-6:
-            assert _rel_max(p.grad, q.grad) < 5e-4, k
-    if dummy_weight > 0:
-        # the scalar dummy-edge weight receives its gradient through the per-edge dot-product kernel
-        assert abs(float(model.dummy_weight.grad) - float(ref.dummy_weight.grad)) < 1e-4 * max(1.0, abs(float(ref.dummy_weight.grad)))
 
 
 @pytest.mark.parametrize("pre_pad", [False, True])
@@ -390,35 +252,6 @@ def test_empty_and_degenerate_batches():
         ref = OL.rgin_layer(x.detach().cpu().double(), z.cpu(), z.cpu(), z.cpu(), p, num_rels=3, act="relu")
         assert _rel_l2(out, ref) < (1e-5 if dtype == torch.float32 else 2e-2)
         assert x.grad is not None and torch.isfinite(x.grad.float()).all()
-
-
-def test_gc_rgin_bf16_runs_on_the_fused_path():
-    """GC RGIN in bf16 (RGCNConv aggr='add' -> row factorisation) against the fp32 oracle forward."""
-    from dummynode4graphlearning_amd import graph_classification as GC, ops
-    rng = np.random.default_rng(8)
-    F_, R, H, C = 8, 5, 64, 2
-    data = _gc_batch(rng, 32, F_, R)
-    args = SimpleNamespace(num_features=F_, hidden_dim=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
-                           additional={"num_layers": 2}, epochs=1, device=DEV, dummy_weight=0)
-    torch.manual_seed(0)
-    model = GC.RGIN(args)
-    ref = GC.RGIN(args)
-    ref.load_state_dict(model.state_dict())
-    model = model.to(DEV).to(torch.bfloat16).train()
-    ref.train()
-    d = data.to(DEV)
-    d.x = d.x.to(torch.bfloat16)
-    calls = []
-    orig = ops.rel_transform_fused
-    ops.rel_transform_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    try:
-        out = model(d)
-    finally:
-        ops.rel_transform_fused = orig
-    assert calls, "bf16 RGCNConv(aggr='add') did not take the fused path"
-    out.float().sum().backward()
-    want = _oracle_gc_forward(ref, data, "RGIN")
-    assert _rel_l2(out.float().exp(), want.exp()) < 5e-2          # class probabilities after two bf16 layers + BN
 
 
 def test_dual_layers_match_reference_goldens(golden_dir):

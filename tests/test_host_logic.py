@@ -41,6 +41,27 @@ def test_initial_weights_are_bit_identical_to_the_reference(golden_dir):
             assert np.array_equal(sd[k].numpy(), ref), (m["tag"], k)
 
 
+def test_gc_initial_state_dicts_are_bit_identical_to_the_reference(golden_dir):
+    """Same torch.manual_seed => the build's GC models start from the reference's parameters bit for bit: creation order of
+    gconv.py / rgconv.py plus what the torch-geometric 2.0.2 constructors do to the RNG stream (every conv re-initialises
+    itself, GINConv re-initialises its nn, glorot / kaiming bounds), and the same state_dict names, shapes and buffers."""
+    from dummynode4graphlearning_amd import graph_classification as GC
+    z = np.load(os.path.join(golden_dir, "gc_models.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    for m in meta:
+        args = SimpleNamespace(num_features=m["num_features"], hidden_dim=m["hidden_dim"], num_classes=m["num_classes"],
+                               dropout_ratio=0.0, num_relations=m["num_relations"], additional=m["additional"],
+                               epochs=m["epochs"], device="cpu", dummy_weight=m["dummy_weight"])
+        torch.manual_seed(m["seed"])
+        sd = getattr(GC, m["kind"])(args).state_dict()
+        ref_keys = sorted(k[len(m["tag"]) + 6:] for k in z.files if k.startswith(m["tag"] + "/init/"))
+        assert sorted(sd.keys()) == ref_keys, m["tag"]
+        for k in ref_keys:
+            ref = z["%s/init/%s" % (m["tag"], k)]
+            assert tuple(sd[k].shape) == ref.shape, (m["tag"], k)
+            assert np.array_equal(sd[k].numpy(), ref), (m["tag"], m["kind"], k)
+
+
 def test_gc_model_state_dict_names():
     from dummynode4graphlearning_amd.graph_classification import GIN, RGCN, RGIN
     args = SimpleNamespace(num_features=7, hidden_dim=16, num_classes=3, dropout_ratio=0.5, num_relations=4,

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch as th
 
+from oracle import gc_models as OG
 from oracle import layers as OL
 from oracle import transforms as OT
 
@@ -415,3 +416,48 @@ def test_oracle_dual_layers_match_reference(golden_dir):
             assert err < 2e-5, (tag, err)
             worst = max(worst, err)
     assert len(meta) == 30
+
+
+def gc_case(z, m, dtype=th.float32):
+    """(params by reference state_dict name, data dict) of one gc_models.npz case."""
+    tag = m["tag"]
+    p = {k[len(tag) + 6:]: th.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/init/")}
+    p = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in p.items()}
+    for k in list(p):                              # GIN: convs.i.nn IS nns.i (gconv.py:195-197) -- one tensor, two names
+        if k.startswith("convs.") and ".nn." in k:
+            i, rest = k.split(".")[1], k.split(".nn.", 1)[1]
+            p[k] = p["nns.%s.%s" % (i, rest)]
+    data = dict(x=th.from_numpy(z[tag + "/x"]).to(dtype), edge_index=th.from_numpy(z[tag + "/edge_index"]),
+                edge_type=th.from_numpy(z[tag + "/edge_type"]), batch=th.from_numpy(z[tag + "/batch"]),
+                y=th.from_numpy(z[tag + "/y"]), num_graphs=m["num_graphs"])
+    return p, data
+
+
+def test_oracle_gc_models_match_reference(golden_dir):
+    """a-6 / a-7 / f-1: oracle/gc_models.py against the reference's gconv.py / rgconv.py run on the torch_geometric.nn
+    stand-ins: log-probs, loss, every parameter gradient and the scalar dummy-edge-weight gradient."""
+    z = np.load(os.path.join(golden_dir, "gc_models.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    assert len(meta) >= 17 and {m["kind"] for m in meta} == {"GIN", "RGIN", "RGCN", "GCN", "GCN_concat_readout", "GraphSAGE"}
+    for m in meta:
+        tag = m["tag"]
+        p, data = gc_case(z, m)
+        dw = th.tensor(m["dummy_weight"], requires_grad=True) if m["dummy_weight"] > 0 else None
+        logp = OG.forward(m["kind"], p, data, m["additional"], dw)
+        loss = th.nn.functional.nll_loss(logp, data["y"])
+        loss.backward()
+        th.testing.assert_close(logp.detach(), th.from_numpy(z[tag + "/logp"]), rtol=2e-5, atol=2e-5, msg=tag)
+        assert abs(float(loss.detach()) - float(z[tag + "/loss"])) < 1e-5, tag
+        for k, t_ in p.items():
+            if not (t_.is_floating_point() and t_.requires_grad):
+                continue
+            if tag + "/grad/" + k not in z.files:          # alias name of a shared tensor
+                continue
+            ref = z[tag + "/grad/" + k]
+            if ref.size == 0:
+                assert t_.grad is None or float(t_.grad.abs().max()) == 0, (tag, k)
+                continue
+            scale = max(float(np.abs(ref).max()), 1e-3)
+            assert float((t_.grad - th.from_numpy(ref)).abs().max()) < 2e-4 * scale + 2e-6, (tag, k)
+        if dw is not None:
+            assert abs(float(dw.grad) - float(z[tag + "/grad_dummy_weight"])) < 1e-5, tag
