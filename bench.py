@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- edges/s forward+backward of one dummy-augmented RGIN conv layer on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 and no RANK in the environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N` on itself
+      (a fresh child process tree, before this process touches the GPU) -- one rank per GPU over RCCL; launched by
+      torch.distributed.run directly (the driver's form), it checks --gpus == WORLD_SIZE.
+  python bench.py --workload config4 --gpus N            BASELINE config 4: GIN hidden 256 on NCI1-shaped dummy graphs,
+      512 graphs per GPU cut from one global batch by parallel.shard_graphs, SyncBatchNorm statistics, flat-bucket all-reduce
 
 Workload (config.workload): BASELINE.json configs[4] = SURVEY.md 8(d) config 5, the one the metric is quoted on
 (fits one GPU): synthetic SI-style batch of 32 768 graphs x (30+1) nodes, 62 real + 60 dummy edges, R = 16
@@ -92,12 +97,127 @@ def cpu_baseline(raw, H, R, budget_s=12.0, sample_graphs=2048):
                       % (G, N, E, it, cores, os.cpu_count() or 1)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        return sck.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: run N ranks of this file under torch.distributed.run as a CHILD process tree and
+    exit with its code.  Called before anything in this process has touched the GPU (no torch.cuda call yet); the ranks
+    are fresh interpreters, nothing is re-exec'ed."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """CPU-only plumbing check (tests/test_dist.py): the ranks rendezvous over gloo, prove the world with one all-reduce
+    and rank 0 prints the line's skeleton.  Nothing of the product path runs (it has no CPU fallback)."""
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if dist.is_initialized():
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps,
+                          "warmup": args.warmup, "workload": args.workload}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def run_config4(args, rank, world, dev):
+    """BASELINE config 4: NCI1-shaped graphs + dummy nodes, GIN hidden 256 (default 2 layers), data parallel.
+    One global batch of 512 x world graphs is cut into contiguous shards by parallel.shard_graphs (balanced by nodes +
+    edges); every rank augments and runs its shard; BatchNorm statistics span the global batch (SyncBatchNorm1d); one
+    flat-bucket gradient all-reduce per step.  A step = zero_grad -> forward -> nll_loss -> backward -> all-reduce."""
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    from dummynode4graphlearning_amd import GraphBatch, synthetic, transforms
+    from dummynode4graphlearning_amd import graph_classification as GC
+    from dummynode4graphlearning_amd.parallel import FlatGradBucket, convert_sync_batchnorm, dp_loss_scale, shard_graphs
+    per_gpu = args.graphs or 512
+    H = args.hidden or 256
+    raw = synthetic.config4(seed=4, graphs=per_gpu * world)                      # identical on every rank
+    bnn = raw["node_ptr"][1:] - raw["node_ptr"][:-1]
+    bne = raw["edge_ptr"][1:] - raw["edge_ptr"][:-1]
+    g0, g1 = shard_graphs(torch.from_numpy(bnn + 1), torch.from_numpy(bne + 2 * bnn), world)[rank]   # sizes after augmentation
+    n0, n1, e0, e1 = (int(raw[k][g]) for k, g in (("node_ptr", g0), ("node_ptr", g1), ("edge_ptr", g0), ("edge_ptr", g1)))
+    sub = dict(node_ptr=raw["node_ptr"][g0:g1 + 1] - n0, edge_ptr=raw["edge_ptr"][g0:g1 + 1] - e0, src=raw["src"][e0:e1] - n0,
+               dst=raw["dst"][e0:e1] - n0, node_label=raw["node_label"][n0:n1], edge_label=raw["edge_label"][e0:e1])
+    aug = transforms.dummy_augment_gc(*(torch.from_numpy(np.ascontiguousarray(sub[k])).to(dev) for k in
+                                        ("node_ptr", "edge_ptr", "src", "dst", "node_label", "edge_label")))
+    Fdim = 38                                                                     # 37 node labels + dummy label 0, one-hot
+    x = F.one_hot(aug["node_label"].long(), Fdim).float()
+    node_ptr = aug["node_ptr"].long()
+    G = g1 - g0
+    batch = torch.repeat_interleave(torch.arange(G, device=dev), node_ptr[1:] - node_ptr[:-1])
+    y = torch.from_numpy(np.random.default_rng(40).integers(0, 2, size=per_gpu * world)[g0:g1]).to(dev)
+    data = GraphBatch(x, torch.stack([aug["src"].long(), aug["dst"].long()]), batch, y=y, ptr=node_ptr)
+    N, E = int(x.shape[0]), int(aug["src"].numel())
+    margs = SimpleNamespace(num_features=Fdim, hidden_dim=H, num_classes=2, dropout_ratio=0.0, num_relations=2,
+                            additional=None, epochs=1, device=dev, dummy_weight=0)
+    torch.manual_seed(1234)                                                       # same initial replica on every rank
+    model = convert_sync_batchnorm(GC.GIN(margs)).to(dev).train()
+    bucket = FlatGradBucket(model.parameters())
+    scale = dp_loss_scale(G, per_gpu * world, world)
+
+    def step():
+        bucket.zero()
+        loss = F.nll_loss(model(data), data.y) * scale
+        loss.backward()
+        bucket.all_reduce()
+        return loss
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([float(E), float(N)], device=dev, dtype=torch.float64)
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot)
+    if rank == 0:
+        ms = float(tt.item()) / args.steps * 1e3
+        gE, gN = float(tot[0].item()), float(tot[1].item())
+        # algorithmic bytes of the model's ONE GIN conv (default config: 2 layers = first_h + one GINConv), fwd + bwd
+        alg = 2.0 * (gE * H * 4 + gN * H * 4 + 8.0 * gE)
+        print(json.dumps({
+            "metric": "edges/sec fwd+bwd on dummy-augmented GIN model step (config 4)", "value": gE / (ms * 1e-3),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config4: GIN(hidden=%d, 2 layers) training step (fwd + nll_loss + bwd + all-reduce) on "
+                                   "%d NCI1-shaped dummy graphs per GPU (global N=%d, E=%d), SyncBatchNorm, eager launches"
+                                   % (H, per_gpu, int(gN), int(gE)),
+                       "global_edges": int(gE), "parallelism": "dp%d" % world, "grad_bucket_bytes": bucket.bytes(),
+                       "shard_graphs": [g0, g1]},
+            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                         "note": "whole training step of a 16 k-node batch per GPU: launch-bound, not a kernel roofline"},
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config5", choices=["config5", "config3"])
+    ap.add_argument("--workload", default="config5", choices=["config5", "config3", "config4"])
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only launch check: rendezvous over gloo, no product code")
     ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (0 = the workload's own size)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
     ap.add_argument("--hidden", type=int, default=0, help="override the workload's hidden size (experiments only)")
@@ -105,9 +225,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))             # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -115,6 +241,11 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # torch.distributed.run (even with one rank)
     if world > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "config4":
+        run_config4(args, rank, world, dev)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     from dummynode4graphlearning_amd import ops
     from dummynode4graphlearning_amd.parallel import FlatGradBucket

@@ -1,12 +1,24 @@
-"""Data-parallel plumbing for the hot path: one process per GPU, graphs sharded across ranks, ONE collective per
-step -- a sum all-reduce of a flat gradient bucket (torch.distributed backend "nccl" == RCCL over xGMI on ROCm).
+"""Data-parallel plumbing for the hot path: one process per GPU, graphs sharded across ranks, ONE data-path-free
+collective per step -- a sum all-reduce of flat gradient buckets (torch.distributed backend "nccl" == RCCL over xGMI on
+ROCm; "gloo" in the CPU tests).
 
 The reference is single-device; a batch is a disjoint union of independent graphs, so forward and
 backward need no exchange.  Gradients of this path are a few MB, i.e. latency-bound on xGMI, so they
-travel as a single flattened bucket whose slices ARE the parameters' .grad tensors (no pack/unpack copies).
+travel as one flattened bucket per (dtype, device) whose slices ARE the parameters' .grad tensors (no pack/unpack copies).
+
+The GC models normalise with BatchNorm1d over the NODES of the batch (gconv.py:187-194, rgconv.py:85-93): under data
+parallelism each replica would see only its shard's statistics.  `SyncBatchNorm1d` restores the single-process result:
+per-rank (count, mean, M2) are gathered in one small collective and merged (Chan's parallel-variance update -- the
+numerically safe form of the [sum, sum-of-squares] reduction), and the backward all-reduces [sum dy, sum dy*xhat]
+(SURVEY.md 8e caveat 1).  `convert_sync_batchnorm(model)` swaps every BatchNorm1d in place, keeping parameter and buffer
+names, so reference state_dicts still load.
 """
 import torch
 import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def shard_graphs(batch_num_nodes, batch_num_edges, world_size):
@@ -25,33 +37,195 @@ def shard_graphs(batch_num_nodes, batch_num_edges, world_size):
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
+def dp_loss_scale(local_graphs, global_graphs, world_size=None):
+    """Factor for a rank's batch-MEAN loss (main.py:41 F.nll_loss, train.py:623-627) so that the AVERAGED gradient bucket
+    equals the gradient of the global-batch mean when shards hold different numbers of graphs: B_r * W / B (1 when equal)."""
+    if world_size is None:
+        world_size = dist.get_world_size() if _dist_on() else 1
+    return float(local_graphs) * world_size / float(global_graphs)
+
+
 class FlatGradBucket:
-    """All parameters' gradients live in one flat buffer; all_reduce() sums it across ranks in one collective."""
+    """All parameters' gradients live in flat buffers (one per dtype and device); all_reduce() sums each across ranks in
+    one collective.
+
+    The parameters' .grad tensors are views of the flat buffers, and that aliasing is RE-ESTABLISHED on every zero() and
+    all_reduce(): the reference's loops call optimizer.zero_grad() (train.py:836, main.py:38), which on torch >= 2.0 sets
+    .grad to None, after which autograd allocates fresh gradient tensors -- those are copied into their slice and .grad is
+    pointed back at it, so the collective always carries the step's gradients (never a stale buffer)."""
 
     def __init__(self, params, average=True):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
-        dt, dev = self.params[0].dtype, self.params[0].device
-        if any(p.dtype != dt or p.device != dev for p in self.params):
-            raise ValueError("FlatGradBucket needs parameters of one dtype on one device")
         self.average = average
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
-        off = 0
+        self._groups = {}                               # (dtype, device) -> [flat, [(param, offset)]]
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)     # autograd accumulates in place into the view
-            off += p.numel()
+            g = self._groups.setdefault((p.dtype, p.device), [None, []])
+            off = sum(q.numel() for q, _ in g[1])
+            g[1].append((p, off))
+        for key, g in self._groups.items():
+            n = sum(q.numel() for q, _ in g[1])
+            g[0] = torch.zeros(n, dtype=key[0], device=key[1])
+        self._meta = [(p.dtype, p.device, p.numel()) for p in self.params]
+        self._bind(copy_existing=False)
+
+    # the single-bucket accessors of round 1 (bench.py, tests): the first (usually only) flat buffer
+    @property
+    def flat(self):
+        return next(iter(self._groups.values()))[0]
+
+    @property
+    def numel(self):
+        return sum(g[0].numel() for g in self._groups.values())
+
+    def buckets(self):
+        return [g[0] for g in self._groups.values()]
+
+    def _check(self):
+        for p, (dt, dev, n) in zip(self.params, self._meta):
+            if p.dtype != dt or p.device != dev or p.numel() != n:
+                raise RuntimeError("FlatGradBucket: a parameter changed dtype / device / size after the bucket was built "
+                                   "(%s %s -> %s %s); build the bucket after .to(...)" % (dt, dev, p.dtype, p.device))
+
+    def _bind(self, copy_existing):
+        """Point every p.grad at its slice.  copy_existing: gradients that live elsewhere (fresh tensors autograd made after
+        zero_grad(set_to_none=True)) are copied in first; a missing gradient (unused parameter) becomes zeros."""
+        self._check()
+        for flat, entries in self._groups.values():
+            for p, off in entries:
+                view = flat[off:off + p.numel()].view_as(p)
+                g = p.grad
+                if g is not None and g.data_ptr() == view.data_ptr() and g.shape == view.shape and g.dtype == view.dtype:
+                    continue
+                if copy_existing:
+                    if g is None:
+                        view.zero_()
+                    else:
+                        if g.dtype != view.dtype or g.device != view.device:
+                            raise RuntimeError("FlatGradBucket: gradient dtype / device differs from its parameter's")
+                        view.copy_(g)
+                p.grad = view
 
     def zero(self):
-        self.flat.zero_()
+        """Zero all gradients and (re)alias them to the buckets: use INSTEAD of, or right after, optimizer.zero_grad()."""
+        for flat, _ in self._groups.values():
+            flat.zero_()
+        self._bind(copy_existing=False)
 
     def all_reduce(self, async_op=False):
-        if not (dist.is_available() and dist.is_initialized()):
+        """Call after loss.backward().  Returns the list of work handles (async_op) or None."""
+        self._bind(copy_existing=True)
+        if not _dist_on():
             return None
-        if self.average and dist.get_world_size() > 1:
-            self.flat.div_(dist.get_world_size())
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        works = []
+        for flat, _ in self._groups.values():
+            if self.average:
+                flat.div_(dist.get_world_size())
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op))
+        return works if async_op else None
 
     def bytes(self):
-        return self.numel * self.flat.element_size()
+        return sum(g[0].numel() * g[0].element_size() for g in self._groups.values())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BatchNorm over the nodes of a sharded batch
+# ---------------------------------------------------------------------------------------------------------------------
+def _merge_stats(cnt, mean, m2):
+    """Chan et al.: merge per-rank (count [W], mean [W,C], M2 [W,C]) into the global (count, mean, M2)."""
+    n = cnt.sum()
+    w = (cnt / n.clamp(min=1.0)).view(-1, 1)
+    gmean = (w * mean).sum(0)
+    gm2 = m2.sum(0) + (cnt.view(-1, 1) * (mean - gmean).square()).sum(0)
+    return n, gmean, gm2
+
+
+class _SyncBNFunction(torch.autograd.Function):
+    """Statistics and the normalisation run in fp32 (fp64 for fp64 inputs), whatever the storage type of x."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        ct = torch.float64 if x.dtype == torch.float64 else torch.float32
+        n_local, C = x.shape
+        xf = x.to(ct)
+        if n_local > 0:
+            mean = xf.mean(0)
+            m2 = (xf - mean).square().sum(0)
+        else:
+            mean = torch.zeros(C, dtype=ct, device=x.device)
+            m2 = torch.zeros_like(mean)
+        packed = torch.cat([torch.full((1,), float(n_local), dtype=ct, device=x.device), mean, m2])
+        W = dist.get_world_size(group)
+        allp = torch.empty(W * packed.numel(), dtype=ct, device=x.device)
+        dist.all_gather_into_tensor(allp, packed, group=group)
+        allp = allp.view(W, packed.numel())
+        n, gmean, gm2 = _merge_stats(allp[:, 0], allp[:, 1:1 + C], allp[:, 1 + C:])
+        var = gm2 / n.clamp(min=1.0)                                  # biased, as F.batch_norm normalises
+        rstd = torch.rsqrt(var + eps)
+        xhat = (xf - gmean) * rstd
+        y = xhat * weight.to(ct) + bias.to(ct) if weight is not None else xhat
+        ctx.save_for_backward(xhat, weight, rstd, n)
+        ctx.group = group
+        ctx.mark_non_differentiable(gmean, var, n)
+        return y.to(x.dtype), gmean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _gm, _gv, _gn):
+        xhat, weight, rstd, n = ctx.saved_tensors
+        ct = xhat.dtype
+        dyf = dy.to(ct)
+        C = xhat.shape[1]
+        s = torch.cat([dyf.sum(0), (dyf * xhat).sum(0)])              # local sums: also dbeta / dgamma (the gradient
+        dbeta, dgamma = s[:C].clone(), s[C:].clone()                  # all-reduce of the step sums those across ranks)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=ctx.group)
+        g = weight.to(ct) if weight is not None else torch.ones(C, dtype=ct, device=dy.device)
+        dx = (g * rstd) * (dyf - s[:C] / n - xhat * (s[C:] / n))
+        if weight is None:
+            return dx.to(dy.dtype), None, None, None, None
+        return dx.to(dy.dtype), dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None
+
+
+class SyncBatchNorm1d(torch.nn.BatchNorm1d):
+    """BatchNorm1d over [rows, C] whose training statistics cover the rows of ALL ranks (same parameters, buffers and
+    state_dict names as torch.nn.BatchNorm1d; identical to it when torch.distributed is not initialised or in eval mode).
+    Works on any backend (one all_gather of 2C+1 floats forward, one all_reduce of 2C floats backward)."""
+
+    def __init__(self, *a, process_group=None, **k):
+        super().__init__(*a, **k)
+        self.process_group = process_group
+
+    def forward(self, x):
+        if not (self.training and _dist_on()) or x.dim() != 2:
+            return super().forward(x)
+        y, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                unbiased = var * (n / (n - 1.0).clamp(min=1.0))
+                self.running_mean.mul_(1.0 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
+                self.running_var.mul_(1.0 - mom).add_(unbiased.to(self.running_var.dtype), alpha=mom)
+        return y
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """Replace every torch.nn.BatchNorm1d below `module` by SyncBatchNorm1d sharing the same Parameters and buffers
+    (names unchanged: reference state_dicts keep loading).  Returns `module` (or its replacement if it is one itself)."""
+    if isinstance(module, torch.nn.BatchNorm1d) and not isinstance(module, SyncBatchNorm1d):
+        new = SyncBatchNorm1d(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats,
+                              process_group=process_group)
+        if module.affine:
+            new.weight, new.bias = module.weight, module.bias
+        if module.track_running_stats:
+            new.running_mean, new.running_var = module.running_mean, module.running_var
+            new.num_batches_tracked = module.num_batches_tracked
+        new.training = module.training
+        return new
+    for name, child in list(module.named_children()):
+        new = convert_sync_batchnorm(child, process_group)
+        if new is not child:
+            # a module registered under several names (GIN: nns.i IS convs.i.nn) is replaced once per name below; the
+            # shared CHILD objects (the Sequential) stay shared because only their BatchNorm entries are swapped in place
+            setattr(module, name, new)
+    return module

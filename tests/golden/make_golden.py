@@ -232,19 +232,38 @@ def make_gc_models():
              ("GraphSAGE", "gconv", 64, {"num_layers": 2, "aggregation": "mean"}, 0.0, 24, 8, 5, 2)]
     for cid, (kind, mod, H, additional, dw, G, F_, R, C) in enumerate(specs):
         tag = "gc%02d" % cid
-        d = _gc_batch(rng, G, F_, R, C=C)
         args = SimpleNamespace(num_features=F_, hidden_dim=H, nhid=H, num_classes=C, dropout_ratio=0.0, num_relations=R,
                                additional=additional, epochs=3, device="cpu", dummy_weight=dw)
         th.manual_seed(4000 + cid)
         model = getattr(mods[mod], kind)(args)
-        for k, v in model.state_dict().items():
-            out[tag + "/init/" + k] = v.detach().numpy().copy()
-        et = th.from_numpy(d["edge_type"])
-        data = SimpleNamespace(x=th.from_numpy(d["x"]), edge_index=th.from_numpy(d["edge_index"]), batch=th.from_numpy(d["batch"]),
-                               edge_attr=th.nn.functional.one_hot(et, R).float(), y=th.from_numpy(d["y"]),
-                               is_dummy_edge=et == 0)
-        model.train()
-        logp = model(data)
+        init = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        # every tensor that feeds a ReLU: a pre-activation within fp32 rounding of the kink makes the gradient a coin toss
+        # (one flipped mask element moves a bias gradient by ~1/rows), so such draws are rejected and the batch redrawn
+        pre = []
+        hooks = [mm.register_forward_hook(lambda _m, _i, o: pre.append(float(o.detach().abs().min())))
+                 for name, mm in model.named_modules()
+                 if isinstance(mm, th.nn.BatchNorm1d) or name in ("conv1", "conv2", "lin1", "lin2", "fc1", "fc_max")]
+        for attempt in range(100):
+            d = _gc_batch(rng, G, F_, R, C=C)
+            et = th.from_numpy(d["edge_type"])
+            data = SimpleNamespace(x=th.from_numpy(d["x"]), edge_index=th.from_numpy(d["edge_index"]), batch=th.from_numpy(d["batch"]),
+                                   edge_attr=th.nn.functional.one_hot(et, R).float(), y=th.from_numpy(d["y"]),
+                                   is_dummy_edge=et == 0)
+            model.load_state_dict({k: th.from_numpy(v.copy()) for k, v in init.items()})      # fresh BN buffers per attempt
+            model.zero_grad()
+            if dw > 0:
+                model.dummy_weight.grad = None
+            del pre[:]
+            model.train()
+            logp = model(data)
+            if min(pre) >= 2e-5:
+                break
+        else:
+            raise RuntimeError("no well-conditioned draw for " + tag)
+        for h in hooks:
+            h.remove()
+        for k, v in init.items():
+            out[tag + "/init/" + k] = v
         loss = th.nn.functional.nll_loss(logp, data.y)
         loss.backward()
         for k, v in d.items():

@@ -1,6 +1,10 @@
-"""Data-parallel plumbing on the CPU with the gloo backend, world_size 2: graph sharding + flat gradient bucket."""
+"""Data-parallel plumbing on the CPU with the gloo backend, world_size 2: graph sharding, the flat gradient bucket across
+optimizer.zero_grad() steps, BatchNorm statistics over the global batch, and bench.py's own rank launcher."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -71,3 +75,133 @@ def test_shard_graphs_balances_nodes_plus_edges():
     sh = shard_graphs(n, torch.zeros(8, dtype=torch.long), 2)
     assert sh[0] == (0, 1) and sh[1] == (1, 8)
     assert shard_graphs(torch.tensor([5]), torch.tensor([5]), 4)[-1][1] == 1
+
+
+def _run_world(target, world=2, timeout=180):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+def _steps_worker(rank, world, port, q):
+    """the reference loop's optimizer.zero_grad() sets .grad to None (torch >= 2.0), autograd then
+    allocates fresh gradient tensors -- the bucket must carry THOSE, step after step, and the replicas must stay equal."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dummynode4graphlearning_amd.parallel import FlatGradBucket
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        model[2].to(torch.float64)                                    # mixed dtypes: one bucket per dtype
+        unused = torch.nn.Parameter(torch.ones(4))                     # never receives a gradient
+        params = list(model.parameters()) + [unused]
+        bucket = FlatGradBucket(params)
+        assert len(bucket.buckets()) == 2
+        opt = torch.optim.SGD(params, lr=0.1)
+        torch.manual_seed(1)
+        data = torch.randn(8, 6)
+        torch.manual_seed(0)
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        ref[2].to(torch.float64)
+        ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+        half = slice(0, 4) if rank == 0 else slice(4, 8)
+        for step in range(3):
+            opt.zero_grad()                                           # set_to_none=True: breaks the aliasing on purpose
+            loss = model[2](torch.relu(model[0](data[half])).double()).square().mean()
+            loss.backward()
+            assert model[0].weight.grad.data_ptr() != bucket.flat.data_ptr() or step == 0
+            bucket.all_reduce()                                       # average of the two half-batch means = global mean
+            assert model[0].weight.grad.data_ptr() == bucket.buckets()[0].data_ptr()
+            opt.step()
+            ropt.zero_grad()
+            ref[2](torch.relu(ref[0](data)).double()).square().mean().backward()
+            ropt.step()
+        err = max(float((p.double() - r.double()).abs().max()) for p, r in zip(model.parameters(), ref.parameters()))
+        flat = torch.cat([p.detach().double().reshape(-1) for p in model.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        q.put((rank, err, float((gathered[0] - gathered[1]).abs().max()), float(unused.grad.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_survives_zero_grad_and_replicas_stay_identical():
+    for rank, err, spread, unused_grad in _run_world(_steps_worker):
+        assert err < 1e-6, (rank, err)                  # 3 SGD steps == the single-process run on the whole batch
+        assert spread == 0.0                            # replicas bit-identical after the steps
+        assert unused_grad == 0.0
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dummynode4graphlearning_amd.parallel import FlatGradBucket, SyncBatchNorm1d, convert_sync_batchnorm, dp_loss_scale
+        dt = torch.float64 if os.environ.get("DN_TEST_F64") == "1" else torch.float32
+        def make():
+            torch.manual_seed(0)
+            return torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 2)).to(dt)
+        ref, model = make(), convert_sync_batchnorm(make())
+        assert isinstance(model[1], SyncBatchNorm1d) and list(model.state_dict()) == list(ref.state_dict())
+        torch.manual_seed(3)
+        rows = (torch.randn(23, 6) * 3.0 + 5.0).to(dt)                 # large mean: the naive sum-of-squares form would cancel
+        graph_of_row = torch.sort(torch.randint(0, 6, (23,)))[0]       # 6 "graphs" of uneven size; rank 0 takes 4, rank 1 takes 2
+        y = torch.randn(6, 2).to(dt)
+        def loss_of(net, sel_rows, sel_graphs):
+            h = net(rows[sel_rows])
+            pooled = torch.zeros(6, 2, dtype=dt).index_add(0, graph_of_row[sel_rows], h)[sel_graphs]
+            return (pooled - y[sel_graphs]).square().mean()            # mean over the graphs of the (sub-)batch
+        mine = [0, 1, 2, 3] if rank == 0 else [4, 5]
+        sel = torch.isin(graph_of_row, torch.tensor(mine))
+        bucket = FlatGradBucket(model.parameters())
+        model.train(), ref.train()
+        bucket.zero()
+        (loss_of(model, sel, mine) * dp_loss_scale(len(mine), 6)).backward()
+        bucket.all_reduce()
+        loss_of(ref, torch.ones(23, dtype=torch.bool), list(range(6))).backward()
+        # (the Linear bias in front of the BatchNorm has an exactly-zero true gradient: absolute floor on the scale)
+        gerr = max(float((p.grad - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-3))
+                   for p, r in zip(model.parameters(), ref.parameters()))
+        serr = max(float((model.state_dict()[k].double() - ref.state_dict()[k].double()).abs().max())
+                   for k in ("1.running_mean", "1.running_var"))
+        model.eval(), ref.eval()
+        eerr = float((model(rows) - ref(rows)).detach().abs().max())
+        q.put((rank, gerr, serr, eerr, int(model[1].num_batches_tracked)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_equals_single_process_statistics():
+    """SURVEY 8e caveat 1: the GC models' BatchNorm1d under data parallelism -- global-batch statistics, gradients (through
+    the statistics) and running buffers equal the single-process run on the whole batch, with uneven shards."""
+    for f64, tol in (("1", 1e-12), ("0", 2e-4)):        # fp64: the algebra is exact; fp32: rounding only
+        os.environ["DN_TEST_F64"] = f64                 # inherited by the spawned ranks
+        try:
+            for rank, gerr, serr, eerr, nb in _run_world(_syncbn_worker):
+                assert gerr < tol, (f64, rank, gerr)
+                assert serr < max(tol, 1e-5) and eerr < max(tol, 1e-5) and nb == 1, (f64, rank, serr, eerr, nb)
+        finally:
+            os.environ.pop("DN_TEST_F64", None)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment must create two ranks itself and report n_gpus 2
+    (--dry-run: gloo rendezvous on the CPU, no product code)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rank_sum"] == 3.0 and lines[0]["steps"] == 3
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=dict(env, RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
