@@ -170,6 +170,18 @@ class RGCNRepNet(nn.Module):
                 batch_norm=batch_norm, act_func=act_func, dropout=dropout))
         self.rgcn = layers
 
+    def get_pattern_rep(self, pattern, p_emb, mask=None):
+        """rgcn.py:254-272: with a mask the pattern side zero-fills masked rows before and after every layer (no residual)."""
+        if mask is not None:
+            p_zero_mask = ~mask
+            outputs = [p_emb.masked_fill(p_zero_mask, 0.0)]
+            etype = pattern.edata["label"]
+            for layer in self.rgcn:
+                o, etype = layer(pattern, outputs[-1], etype)
+                outputs.append(o.masked_fill(p_zero_mask, 0.0))
+            return outputs[-1]
+        return self.get_graph_rep(pattern, p_emb)
+
     def get_graph_rep(self, graph, g_emb, mask=None, gate=None):
         etype = graph.edata["label"]
         if mask is not None or gate is not None:

@@ -263,6 +263,26 @@ class FakeDGLGraph:
         else:
             self.edata.update(func(_EdgeBatch(self)))
 
+    def incidence_matrix(self, typestr):
+        """dgl incidence_matrix("in"): sparse [N, E], entry (dst(e), e) = 1, stored in eid order (so a row's _indices() list
+        the in-edges by ascending eid)."""
+        assert typestr == "in"
+        E = int(self._u.numel())
+        idx = th.stack([self._v, th.arange(E)]) if E else th.zeros((2, 0), dtype=th.long)
+        return th.sparse_coo_tensor(idx, th.ones(E), (self._n, E))
+
+    def remove_nodes(self, nids):
+        """dgl remove_nodes: drops the nodes and their incident edges, survivors renumbered compactly in order."""
+        dead = th.zeros(self._n, dtype=th.bool)
+        dead[th.as_tensor(nids, dtype=th.long)] = True
+        keep_v = ~dead
+        remap = th.cumsum(keep_v.long(), 0) - 1
+        keep_e = keep_v[self._u] & keep_v[self._v] if self._u.numel() else th.zeros(0, dtype=th.bool)
+        self.ndata = {k: v[keep_v] for k, v in self.ndata.items()}
+        self.edata = {k: v[keep_e] for k, v in self.edata.items()}
+        self._u, self._v = remap[self._u[keep_e]], remap[self._v[keep_e]]
+        self._n = int(keep_v.sum())
+
     def update_all(self, message_func, reduce_func, apply_node_func=None):
         msgs = message_func(_EdgeBatch(self))
         assert isinstance(reduce_func, _Sum)
@@ -272,6 +292,14 @@ class FakeDGLGraph:
         if apply_node_func is not None:
             self.ndata.update(apply_node_func(_NodeBatch(self)))
         self.ndata.pop(reduce_func.out)
+
+
+class DGLGraph(FakeDGLGraph):
+    """FakeDGLGraph under the class name the reference's convert_conjugate_graph dispatches on
+    (SI utils/graph.py:75-81: str(graph.__class__) == "<class 'dgl.graph.DGLGraph'>")."""
+
+
+DGLGraph.__module__ = "dgl.graph"
 
 
 # --------------------------------------------------------------------------- torch_geometric.nn (2.0.2)

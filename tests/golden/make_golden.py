@@ -16,10 +16,13 @@ The reference's Python is imported unmodified, with the absent third-party modul
                        (incl. the scalar dummy-edge weight), BatchNorm buffers after the step
   si_transforms.json   a-4 add_dummy_nodes_edges (SI train.py:404-474) + a-5
                        convert_conjugate_graph igraph branch (SI utils/graph.py:177-267), incl. KAT-2
+  si_conj_dgl.json     a-5 the OTHER branch of convert_conjugate_graph (DGL graphs, SI utils/graph.py:77-175) on the same items
   si_bookkeeping.json  f-2 get_conjugate_subisomorphisms, compute_{nodeseq,edgeseq}_subisoweights, compute_norm,
                        compute_largest_eigenvalues, add_reversed_edges
   si_dual_layers.npz   f-4 CompGCNLayer / DMPLayer: node and edge outputs + all gradients
   si_pred.npz          f-4 SumPredictNet / MeanPredictNet with the dummy-masked padded inputs
+  si_rep_nets.npz      a-11 RGIN / RGCN create_rep_net + get_pattern_rep / get_graph_rep (rgin.py:179-260, rgcn.py:219-300)
+                       called on a stub self: residual, pattern zero-mask, graph mask / gate paths, outputs + gradients
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
                        all gradients over the regulariser x act x self_loop x edge_norm grid
 
@@ -375,6 +378,40 @@ def make_si_transforms():
     print("si_transforms.json: %d items" % len(items))
 
 
+def make_si_conj_dgl():
+    """a-5, DGL branch (SI utils/graph.py:77-175) on the items of si_transforms.json (augmented, plain, KAT-2), so that the
+    two branches of the reference can be compared on identical inputs."""
+    _si_modules()
+    ug = importlib.import_module("utils.graph")
+    with open(os.path.join(HERE, "si_transforms.json")) as f:
+        gold = json.load(f)
+
+    def to_dgl(d):
+        g = S.DGLGraph(d["u"], d["v"], d["num_nodes"])
+        g.ndata["id"], g.ndata["label"] = th.tensor(d["n_id"], dtype=th.long), th.tensor(d["n_label"], dtype=th.long)
+        g.edata["id"], g.edata["label"] = th.tensor(d["e_id"], dtype=th.long), th.tensor(d["e_label"], dtype=th.long)
+        return g
+
+    def dump(g):   # same layout as _dump_ig
+        out = {"vcount": g.number_of_nodes(), "edges": [list(e) for e in zip(g._u.tolist(), g._v.tolist())]}
+        for k, v in g.ndata.items():
+            out["v_" + k] = v.long().tolist()
+        for k, v in g.edata.items():
+            out["e_" + k] = v.long().tolist()
+        return out
+
+    res = {}
+    for tag, items in (("conj", gold["after"]), ("conj_plain", gold["before"])):
+        res[tag] = [{k: dump(ug.convert_conjugate_graph(to_dgl(x[k]))) for k in ("pattern", "graph")} for x in items]
+    k2 = gold["kat2"]["in"]
+    res["kat2"] = dump(ug.convert_conjugate_graph(to_dgl(dict(
+        u=[e[0] for e in k2["edges"]], v=[e[1] for e in k2["edges"]], num_nodes=k2["vcount"], n_id=k2["v_id"],
+        n_label=k2["v_label"], e_id=k2["e_id"], e_label=k2["e_label"]))))
+    with open(os.path.join(HERE, "si_conj_dgl.json"), "w") as f:
+        json.dump(res, f, separators=(",", ":"))
+    print("si_conj_dgl.json: %d items" % len(res["conj"]))
+
+
 def make_si_bookkeeping():
     """f-2: the integer bookkeeping either side of L_Phi, produced by the reference's own functions (numba.jit replaced
     by the identity): get_conjugate_subisomorphisms (utils/graph.py:291-330), compute_{nodeseq,edgeseq}_subisoweights
@@ -558,6 +595,67 @@ def make_si_pred():
     print("si_pred.npz: %d cases" % len(meta))
 
 
+def make_si_rep_nets():
+    """a-11: the layer stacks.  RGIN.create_rep_net / get_pattern_rep / get_graph_rep (models/rgin.py:179-260) and the RGCN
+    twins (models/rgcn.py:219-300) are unbound from their classes and called on a stub `self` carrying exactly the attributes
+    they read (hid_dim, max_ngel, max_npel, share_rep_net, rep_residual, g_rep_net, p_rep_net)."""
+    from types import SimpleNamespace
+    _si_modules()
+    mods = {"rgin": importlib.import_module("models.rgin").RGIN, "rgcn": importlib.import_module("models.rgcn").RGCN}
+    rng = np.random.default_rng(61)
+    out, meta = {}, []
+    N, E, H, R = 60, 240, 16, 5
+    cid = 0
+    for kind in ("rgin", "rgcn"):
+        cls = mods[kind]
+        for mode, residual in (("graph", True), ("graph_gate", True), ("graph_mask_gate", True), ("graph_mask", False),
+                               ("pattern_mask", True), ("pattern", True), ("pattern", False)):
+            tag = "rep%02d" % cid
+            stub = SimpleNamespace(hid_dim=H, max_ngel=R, max_npel=R, share_rep_net=False, rep_residual=residual)
+            kw = {"rep_num_graph_layers": 3, "rep_num_pattern_layers": 2, "rep_act_func": "leaky_relu" if cid % 2 else "relu",
+                  "rep_rgcn_edge_norm": "both" if cid % 3 == 0 else "in"}
+            th.manual_seed(5000 + cid)
+            stub.g_rep_net = cls.create_rep_net(stub, "graph", **kw)
+            stub.p_rep_net = cls.create_rep_net(stub, "pattern", **kw)
+            u, v = rng.integers(0, N, size=E), rng.integers(0, N, size=E)
+            t = rng.integers(0, R, size=E)
+            g = S.FakeDGLGraph(u, v, N)
+            g.edata["label"] = th.from_numpy(t)
+            x = th.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).requires_grad_(True)
+            coef = th.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+            mask = th.from_numpy(rng.random((N, 1)) > 0.25)
+            gate = th.from_numpy(rng.random((N, 1)).astype(np.float32))
+            net = stub.p_rep_net if mode.startswith("pattern") else stub.g_rep_net
+            net.train()
+            if mode == "pattern_mask":
+                o = cls.get_pattern_rep(stub, g, x, mask=mask)
+            elif mode == "pattern":
+                o = cls.get_pattern_rep(stub, g, x)
+            elif mode == "graph":
+                o = cls.get_graph_rep(stub, g, x)
+            elif mode == "graph_gate":
+                o = cls.get_graph_rep(stub, g, x, gate=gate)
+            elif mode == "graph_mask":
+                o = cls.get_graph_rep(stub, g, x, mask=mask)
+            else:
+                o = cls.get_graph_rep(stub, g, x, mask=mask, gate=gate)
+            (o * coef).sum().backward()
+            for k, a in (("u", u.astype(np.int64)), ("v", v.astype(np.int64)), ("t", t.astype(np.int64)), ("x", x.detach().numpy()),
+                         ("coef", coef.numpy()), ("mask", mask.numpy()), ("gate", gate.numpy()), ("out", o.detach().numpy()),
+                         ("grad_x", x.grad.numpy())):
+                out[tag + "/" + k] = a
+            for k, p in net.named_parameters():
+                out[tag + "/param/" + k] = p.detach().numpy()
+                out[tag + "/grad/" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+            meta.append(dict(tag=tag, kind=kind, mode=mode, rep_residual=residual, N=N, H=H, R=R, seed=5000 + cid,
+                             num_layers=2 if mode.startswith("pattern") else 3, act_func=kw["rep_act_func"],
+                             edge_norm=kw["rep_rgcn_edge_norm"], name="pattern" if mode.startswith("pattern") else "graph"))
+            cid += 1
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "si_rep_nets.npz"), **out)
+    print("si_rep_nets.npz: %d cases" % len(meta))
+
+
 def make_si_layers():
     _si_modules()
     rgin = importlib.import_module("models.rgin")
@@ -640,7 +738,9 @@ if __name__ == "__main__":
     make_tu_files()
     make_gc_models()
     make_si_transforms()
+    make_si_conj_dgl()
     make_si_bookkeeping()
     make_si_dual_layers()
     make_si_pred()
+    make_si_rep_nets()
     make_si_layers()

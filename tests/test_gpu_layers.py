@@ -98,6 +98,43 @@ def test_rgin_layer_bf16_close_to_fp32_reference(golden_dir):
     assert max(errs.values()) < 0.15, errs
 
 
+def test_rep_nets_match_reference_goldens(golden_dir):
+    """a-11: RGINRepNet / RGCNRepNet (get_pattern_rep with the zero mask, get_graph_rep with residual / mask / gate) against
+    the reference's own create_rep_net + get_*_rep run (si_rep_nets.npz): outputs and every gradient to 1e-4."""
+    from dummynode4graphlearning_amd import BatchedGraph
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGCNRepNet, RGINRepNet
+    z = np.load(os.path.join(golden_dir, "si_rep_nets.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    for m in meta:
+        tag = m["tag"]
+        if m["kind"] == "rgin":
+            net = RGINRepNet(m["H"], m["R"], num_layers=m["num_layers"], rep_residual=m["rep_residual"], act_func=m["act_func"],
+                             name=m["name"])
+        else:
+            net = RGCNRepNet(m["H"], m["R"], num_layers=m["num_layers"], rep_residual=m["rep_residual"], act_func=m["act_func"],
+                             edge_norm=m["edge_norm"], name=m["name"])
+        net.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}, strict=True)
+        net = net.to(DEV).train()
+        t = lambda k: torch.from_numpy(z[tag + "/" + k]).to(DEV)  # noqa: E731
+        g = BatchedGraph(t("u"), t("v"), m["N"], edata={"label": t("t")})
+        x = t("x").requires_grad_(True)
+        mode = m["mode"]
+        if mode == "pattern_mask":
+            out = net.get_pattern_rep(g, x, mask=t("mask"))
+        elif mode == "pattern":
+            out = net.get_pattern_rep(g, x)
+        else:
+            out = net.get_graph_rep(g, x, mask=t("mask") if "mask" in mode else None, gate=t("gate") if "gate" in mode else None)
+        (out * t("coef")).sum().backward()
+        errs = {"out": _rel_max(out, t("out")), "grad_x": _rel_max(x.grad, t("grad_x"))}
+        for k, p in net.named_parameters():
+            ref = z[tag + "/grad/" + k]
+            if ref.size and np.abs(ref).max() > 0:
+                errs["grad " + k] = _rel_max(p.grad, torch.from_numpy(ref))
+        for k, e in errs.items():
+            assert e < RTOL, "%s %s %s %s rel_max %.3e" % (tag, m["kind"], mode, k, e)
+
+
 def test_rep_net_residual_and_gate(golden_dir):
     from dummynode4graphlearning_amd import BatchedGraph
     from dummynode4graphlearning_amd.subgraph_isomorphism import RGINRepNet

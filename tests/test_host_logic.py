@@ -62,6 +62,26 @@ def test_gc_initial_state_dicts_are_bit_identical_to_the_reference(golden_dir):
             assert np.array_equal(sd[k].numpy(), ref), (m["tag"], m["kind"], k)
 
 
+def test_rep_net_state_dicts_are_bit_identical_to_the_reference(golden_dir):
+    """RGINRepNet / RGCNRepNet built under the reference's seed: same module names (rgin.graph_rgin_(0) ...), same weights."""
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGCNRepNet, RGINRepNet
+    z = np.load(os.path.join(golden_dir, "si_rep_nets.npz"))
+    for m in json.loads(bytes(z["meta"]).decode()):
+        torch.manual_seed(m["seed"])
+        # the reference builds the graph net (3 layers) first, then the pattern net (2 layers): same RNG order here
+        nets = {}
+        for name, nl in (("graph", 3), ("pattern", 2)):
+            if m["kind"] == "rgin":
+                nets[name] = RGINRepNet(m["H"], m["R"], num_layers=nl, act_func=m["act_func"], name=name)
+            else:
+                nets[name] = RGCNRepNet(m["H"], m["R"], num_layers=nl, act_func=m["act_func"], edge_norm=m["edge_norm"], name=name)
+        sd = nets[m["name"]].state_dict()
+        ref_keys = sorted(k[len(m["tag"]) + 7:] for k in z.files if k.startswith(m["tag"] + "/param/"))
+        assert sorted(sd.keys()) == ref_keys, (m["tag"], sorted(sd.keys())[:3], ref_keys[:3])
+        for k in ref_keys:
+            assert np.array_equal(sd[k].numpy(), z["%s/param/%s" % (m["tag"], k)]), (m["tag"], k)
+
+
 def test_gc_model_state_dict_names():
     from dummynode4graphlearning_amd.graph_classification import GIN, RGCN, RGIN
     args = SimpleNamespace(num_features=7, hidden_dim=16, num_classes=3, dropout_ratio=0.5, num_relations=4,

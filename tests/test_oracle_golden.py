@@ -461,3 +461,77 @@ def test_oracle_gc_models_match_reference(golden_dir):
             assert float((t_.grad - th.from_numpy(ref)).abs().max()) < 2e-4 * scale + 2e-6, (tag, k)
         if dw is not None:
             assert abs(float(dw.grad) - float(z[tag + "/grad_dummy_weight"])) < 1e-5, tag
+
+
+def test_dgl_branch_of_convert_conjugate_graph_equals_igraph_branch(golden_dir):
+    """a-5: the reference's convert_conjugate_graph has a DGL branch (SI utils/graph.py:77-175) and an igraph branch
+    (:177-267).  Both were run on the same items (si_conj_dgl.json / si_transforms.json): they agree on every vertex id,
+    vertex label, edge, edge id and edge label, so the one restatement (and the device build pinned to it) covers both."""
+    dgl, ig = _load(golden_dir, "si_conj_dgl.json"), _load(golden_dir, "si_transforms.json")
+    n = 0
+    for tag in ("conj", "conj_plain"):
+        assert len(dgl[tag]) == len(ig[tag]) == 8
+        for a, b in zip(dgl[tag], ig[tag]):
+            for k in ("pattern", "graph"):
+                for f in ("vcount", "edges", "v_id", "v_label", "e_id", "e_label"):
+                    assert a[k].get(f, []) == b[k].get(f, []), (tag, k, f)
+                n += 1
+    for f in ("vcount", "edges", "v_id", "v_label", "e_id", "e_label"):
+        assert dgl["kat2"].get(f, []) == ig["kat2"]["out"].get(f, []), f
+    assert n == 32
+
+
+def rep_net_oracle(z, m, p, x, dtype=th.float32):
+    """The reference's stack semantics (rgin.py:214-260 / rgcn.py:254-300) on the oracle layers, parameters by state_dict
+    name (rgin.<name>_rgin_(i).*), for a si_rep_nets.npz case."""
+    tag = m["tag"]
+    u, v, t = (th.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
+    mask, gate = th.from_numpy(z[tag + "/mask"]), th.from_numpy(z[tag + "/gate"]).to(dtype)
+    mode = m["mode"]
+
+    def layer(i, h):
+        pre = "%s.%s_%s_(%d)." % (m["kind"], m["name"], m["kind"], i)
+        lp = {k[len(pre):]: w for k, w in p.items() if k.startswith(pre)}
+        if m["kind"] == "rgin":
+            return OL.rgin_layer(h, u, v, t, lp, regularizer="basis", num_rels=m["R"], num_bases=-1, act=m["act_func"])
+        return OL.rgcn_layer(h, u, v, t, lp, regularizer="basis", num_rels=m["R"], num_bases=-1, edge_norm=m["edge_norm"],
+                             act=m["act_func"])
+
+    if mode == "pattern_mask":
+        h = x.masked_fill(~mask, 0.0)
+        for i in range(m["num_layers"]):
+            h = layer(i, h).masked_fill(~mask, 0.0)
+        return h
+    g = None
+    if mode == "graph_gate":
+        g = gate
+    elif mode == "graph_mask":
+        g = mask.to(dtype)
+    elif mode == "graph_mask_gate":
+        g = mask.to(dtype) * gate
+    h = x if g is None else x * g
+    for i in range(m["num_layers"]):
+        o = layer(i, h)
+        if g is not None:
+            o = o * g
+        h = h + o if m["rep_residual"] else o
+    return h
+
+
+def test_oracle_rep_nets_match_reference(golden_dir):
+    """a-11: residual / pattern zero-mask / graph mask and gate paths of both stacks against the reference's own methods."""
+    z = np.load(os.path.join(golden_dir, "si_rep_nets.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    assert len(meta) == 14
+    for m in meta:
+        tag = m["tag"]
+        p = {k[len(tag) + 7:]: th.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(tag + "/param/")}
+        x = th.from_numpy(z[tag + "/x"]).clone().requires_grad_(True)
+        out = rep_net_oracle(z, m, p, x)
+        (out * th.from_numpy(z[tag + "/coef"])).sum().backward()
+        th.testing.assert_close(out.detach(), th.from_numpy(z[tag + "/out"]), rtol=1e-4, atol=1e-5, msg=tag)
+        th.testing.assert_close(x.grad, th.from_numpy(z[tag + "/grad_x"]), rtol=1e-4, atol=1e-5, msg=tag)
+        for k, w in p.items():
+            ref = z[tag + "/grad/" + k]
+            if ref.size:
+                th.testing.assert_close(w.grad, th.from_numpy(ref), rtol=2e-4, atol=2e-5, msg=tag + " " + k)
