@@ -787,6 +787,11 @@ class RowIndexSet:
         for n0, n1, e0, e1 in bounds:
             ix = RowIndex(s64[e0:e1] - n0, d64[e0:e1] - n0, etype[e0:e1], n1 - n0, num_rels, self_loop=self_loop)
             self.parts.append((n0, n1, ix))
+        if (PIPE_ENABLED and node_ptr is not None and len(self.parts) == 1 and self_loop and N > 0
+                and int(node_ptr.numel()) >= 2):
+            pipe = PipeIndex(self.parts[0][2], node_ptr)
+            if pipe.slot_rows <= PIPE_MAX_SLOT_ROWS:             # (a graph too large for a ring slot: two-launch path)
+                self.parts[0][2].pipe = pipe
         self.max_rows = max(ix.num_rows for _, _, ix in self.parts)
         self.num_rows = sum(ix.num_rows for _, _, ix in self.parts)
         self.num_all_rels = self.num_rels + (1 if self_loop else 0)
@@ -799,6 +804,248 @@ class RowIndexSet:
             b = torch.empty((self.max_rows, H), dtype=dtype, device=dev)
             self._ybuf[key] = b
         return b
+
+
+PIPE_ENABLED = _os.environ.get("DN_PIPE", "1") != "0"
+PIPE_BATCH_NODES = int(_os.environ.get("DN_PIPE_BATCH_NODES", "384"))     # nodes per batch (ring slot ~ 2x that many rows)
+PIPE_RING_DEPTH = int(_os.environ.get("DN_PIPE_DEPTH", "6"))              # batches in flight per XCD
+PIPE_ROLES = int(_os.environ.get("DN_PIPE_ROLES", "64"))                  # workgroups per XCD (2 per CU)
+PIPE_C_WEIGHT = float(_os.environ.get("DN_PIPE_CW", "1.5"))               # cost of a closing tile relative to a transform tile
+PIPE_MAX_SLOT_ROWS = int(_os.environ.get("DN_PIPE_MAX_SLOT_ROWS", "4096"))   # a batch's rows must be able to sit in L2
+PIPE_TIMEOUT_MS = 200
+
+
+class PipeIndex:
+    """Work tables of dn_rows_pipe_bf16 for one RowIndex whose batch is a disjoint union of graphs (node_ptr): the graphs
+    are cut into <= 8 contiguous groups (one per XCD) and each group into batches of consecutive graphs; the edge rows are
+    re-ordered (batch, relation)-major so that every (batch, relation) unit is one contiguous row range, the per-node row
+    lists are re-expressed relative to their batch, and every workgroup of the persistent launch gets a fixed role and tile
+    sequence.  Built once per batch (device sorts / scans by torch index ops, role and tile tables with numpy on the host);
+    both directions of the message pass share everything but the input-row table and the per-node lists."""
+
+    def __init__(self, ix, node_ptr, groups=8, roles_per_group=None, depth=None, batch_nodes=None):
+        import numpy as np
+        dev = ix.row_in.device
+        N, P, R = ix.num_nodes, ix.num_edge_rows, ix.num_rels
+        roles_per_group = roles_per_group or PIPE_ROLES
+        depth = depth or PIPE_RING_DEPTH
+        batch_nodes = batch_nodes or PIPE_BATCH_NODES
+        self.ix, self.depth, self.roles_per_group = ix, depth, roles_per_group
+        nptr_h = node_ptr.detach().to("cpu", torch.int64).numpy()
+        G = len(nptr_h) - 1
+        assert G >= 1 and int(nptr_h[-1]) == N
+        n_g = np.diff(nptr_h)
+        # ---- rows -> graphs (device) ------------------------------------------------------------------------------------
+        nptr_d = node_ptr.to(device=dev, dtype=torch.int64)
+        graph_of_node = torch.bucketize(torch.arange(N, device=dev), nptr_d[1:], right=True)
+        relp = torch.tensor(ix.rel_ptr_host[:R + 1], dtype=torch.int64)
+        row_rel = torch.repeat_interleave(torch.arange(R, dtype=torch.int64), relp[1:] - relp[:-1]).to(dev)
+        row_in, row_out = ix.row_in[:P].long(), ix.row_out[:P].long()
+        node_of_row = torch.where(row_in < N, row_in, row_out)
+        graph_of_row = graph_of_node[node_of_row] if P else torch.zeros(0, dtype=torch.int64, device=dev)
+        r_g = torch.bincount(graph_of_row, minlength=G).cpu().numpy() if P else np.zeros(G, dtype=np.int64)
+        # ---- groups (balanced by rows + nodes) and batches (fixed number of graphs per batch) on the host ---------------------
+        groups = int(max(1, min(groups, G)))
+        csum = np.cumsum(r_g + n_g)
+        gb = [0]
+        for k in range(1, groups):
+            gb.append(int(min(max(np.searchsorted(csum, csum[-1] * k / groups) + 1, gb[-1]), G)))
+        gb.append(G)
+        mean_n = max(float(N) / G, 1.0)
+        gpb = int(max(1, batch_nodes // mean_n))                     # graphs per batch
+        batch_of_graph = np.zeros(G, dtype=np.int64)
+        bfirst, bgroup, blocal = [], [], []                          # first graph, group, local index of every batch
+        nb = 0
+        for g in range(groups):
+            g0, g1 = gb[g], gb[g + 1]
+            cnt = -(-(g1 - g0) // gpb) if g1 > g0 else 0
+            k = np.arange(g1 - g0) // gpb
+            batch_of_graph[g0:g1] = nb + k
+            bfirst.extend((g0 + np.arange(cnt) * gpb).tolist())
+            bgroup.extend([g] * cnt)
+            blocal.extend(range(cnt))
+            nb += cnt
+        B = nb
+        bfirst = np.asarray(bfirst + [G], dtype=np.int64)
+        bgroup, blocal = np.asarray(bgroup, dtype=np.int64), np.asarray(blocal, dtype=np.int64)
+        bnode = nptr_h[bfirst]                                       # node range of every batch [B + 1]
+        self.num_groups, self.num_batches = groups, B
+        # ---- (batch, relation)-major row order (device) ---------------------------------------------------------------------
+        bog_d = torch.from_numpy(batch_of_graph).to(dev)
+        if P:
+            key = bog_d[graph_of_row] * R + row_rel
+            order = torch.argsort(key, stable=True)
+            inv = torch.empty(P, dtype=torch.int64, device=dev)
+            inv[order] = torch.arange(P, device=dev)
+            unit_cnt = torch.bincount(key, minlength=B * R).cpu().numpy()
+            self.row_idx = {"f": ix.row_in[:P][order].contiguous(), "b": ix.row_out[:P][order].contiguous()}
+        else:
+            inv = torch.zeros(0, dtype=torch.int64, device=dev)
+            unit_cnt = np.zeros(B * R, dtype=np.int64)
+            z = torch.zeros(1, dtype=I32, device=dev)
+            self.row_idx = {"f": z, "b": z}
+        unit_ptr = np.concatenate([[0], np.cumsum(unit_cnt)])
+        rowbase = unit_ptr[np.arange(B) * R]
+        rows_b = unit_ptr[(np.arange(B) + 1) * R] - rowbase
+        slot_rows = int(max(int(rows_b.max()) if B else 0, 1))
+        self.slot_rows, self.ring_rows = slot_rows, groups * depth * slot_rows
+        # ---- per-node lists relative to the batch's first row (device) ------------------------------------------------------------
+        rowbase_d = torch.from_numpy(rowbase).to(dev)
+        batch_of_node = bog_d[graph_of_node]
+        self.list_ptr, self.list_local = {}, {}
+        for d, (lp, lr) in (("f", (ix.dst_ptr, ix.dst_rows)), ("b", (ix.src_ptr, ix.src_rows))):
+            lp64 = lp[:N + 1].long()
+            ent = lr[:int(lp64[N])].long() if N else lr[:0].long()
+            node_of_ent = torch.repeat_interleave(torch.arange(N, device=dev), lp64[1:] - lp64[:-1], output_size=int(ent.numel()))
+            keep = ent < P
+            cnt = torch.bincount(node_of_ent[keep], minlength=N)
+            self.list_ptr[d] = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(I32).contiguous()
+            loc = inv[ent[keep]] - rowbase_d[batch_of_node[node_of_ent[keep]]]
+            self.list_local[d] = (loc.to(I32) if loc.numel() else torch.zeros(1, dtype=I32, device=dev)).contiguous()
+        # ---- tiles and roles (host) --------------------------------------------------------------------------------------------
+        TR = 32
+        ub, ur = np.divmod(np.flatnonzero(unit_cnt > 0), R)          # non-empty units in (batch, relation) order
+        ucnt = unit_cnt[ub * R + ur]
+        ubeg = unit_ptr[ub * R + ur]
+        need_t = np.bincount(ub, minlength=B)
+        cb_tiles = -(-(bnode[1:] - bnode[:-1]) // TR)                # closing tiles per batch
+        roles = np.zeros((groups * roles_per_group, 4), dtype=np.int32)
+        roles[:, 0] = 2                                              # idle unless assigned
+        tile_chunks = []
+        ntile = 0
+        S = roles_per_group
+        for g in range(groups):
+            bsel = np.flatnonzero(bgroup == g)
+            if bsel.size == 0:
+                continue
+            b0, b1 = int(bsel[0]), int(bsel[-1]) + 1
+            um = (ub >= b0) & (ub < b1)
+            gub, gur, gcnt, gbeg = ub[um], ur[um], ucnt[um], ubeg[um]
+            gtiles = -(-gcnt // TR)
+            rels = np.unique(gur)
+            t_work = np.array([gtiles[gur == r].sum() for r in rels], dtype=np.float64)
+            c_work = float(cb_tiles[b0:b1].sum()) * PIPE_C_WEIGHT
+            nq = len(rels) + 1
+            if nq <= S:
+                work = np.concatenate([t_work, [c_work]])
+                m = np.maximum(1, np.floor(work / work.sum() * S)).astype(np.int64)
+                while m.sum() > S:
+                    m[np.argmax(m)] -= 1
+                while m.sum() < S:                                   # hand the rest to whoever carries most work per role
+                    m[np.argmax(work / m)] += 1
+                m_t, m_c = m[:-1], int(m[-1])
+                role_base = np.concatenate([[0], np.cumsum(m_t)])
+                rel_slot = {int(r): (int(role_base[i]), int(m_t[i])) for i, r in enumerate(rels)}
+                c_base = int(role_base[-1])
+            else:                                                    # more relations than roles: several relations per T role
+                m_c = max(1, S // 4)
+                n_t = S - m_c
+                rel_slot = {int(r): (i % n_t, 1) for i, r in enumerate(rels)}
+                c_base = n_t
+            # T tiles of this group
+            if gub.size:
+                base = np.array([rel_slot[int(r)][0] for r in gur])
+                mm = np.array([rel_slot[int(r)][1] for r in gur])
+                urole = base + (blocal[gub] % mm)
+                t_unit = np.repeat(np.arange(gub.size), gtiles)
+                t_k = np.arange(t_unit.size) - np.repeat(np.cumsum(gtiles) - gtiles, gtiles)
+                tbeg = gbeg[t_unit] + TR * t_k
+                tend = np.minimum(tbeg + TR, gbeg[t_unit] + gcnt[t_unit])
+                flags = gur[t_unit] | ((t_k == 0).astype(np.int64) << 16) | ((t_k == gtiles[t_unit] - 1).astype(np.int64) << 17)
+                trole = urole[t_unit]
+                o = np.argsort(trole, kind="stable")                 # units are batch-major already: stays so inside a role
+                tt = np.stack([tbeg[o], tend[o], gub[t_unit][o], flags[o]], 1)
+                cnts = np.bincount(trole, minlength=S)
+                starts = ntile + np.concatenate([[0], np.cumsum(cnts)])
+                for rsl in range(S):
+                    if cnts[rsl]:
+                        roles[g * S + rsl] = (0, starts[rsl], starts[rsl + 1], 0)
+                tile_chunks.append(tt)
+                ntile += tt.shape[0]
+            # C tiles: all node tiles of the group, batch-major, dealt round-robin to the C roles
+            cbt = cb_tiles[b0:b1]
+            c_batch = np.repeat(np.arange(b0, b1), cbt)
+            c_k = np.arange(c_batch.size) - np.repeat(np.cumsum(cbt) - cbt, cbt)
+            cbeg = bnode[c_batch] + TR * c_k
+            cend = np.minimum(cbeg + TR, bnode[c_batch + 1])
+            crole = np.arange(c_batch.size) % m_c
+            o = np.argsort(crole, kind="stable")
+            cb_o, crole_o = c_batch[o], crole[o]
+            firstf = np.ones(o.size, dtype=np.int64)
+            same = (crole_o[1:] == crole_o[:-1]) & (cb_o[1:] == cb_o[:-1])
+            firstf[1:][same] = 0
+            ct = np.stack([cbeg[o], cend[o], cb_o, firstf << 16], 1)
+            cnts = np.bincount(crole, minlength=m_c)
+            starts = ntile + np.concatenate([[0], np.cumsum(cnts)])
+            for j in range(m_c):
+                if cnts[j]:
+                    roles[g * S + c_base + j] = (1, starts[j], starts[j + 1], 0)
+            tile_chunks.append(ct)
+            ntile += ct.shape[0]
+        tiles = np.concatenate(tile_chunks, 0) if tile_chunks else np.zeros((0, 4), dtype=np.int64)
+        self.num_tiles = int(tiles.shape[0])
+        self.tiles = torch.from_numpy(np.ascontiguousarray(tiles.astype(np.int32))).to(dev) if self.num_tiles else torch.zeros((1, 4), dtype=I32, device=dev)
+        self.roles = torch.from_numpy(roles).to(dev)
+        bt = np.zeros((max(B, 1), 8), dtype=np.int32)
+        if B:
+            bt[:, 0] = rowbase
+            bt[:, 1] = (bgroup * depth + blocal % depth) * slot_rows
+            bt[:, 2] = cb_tiles
+            bt[:, 3] = np.where(blocal >= depth, np.arange(B) - depth, -1)
+            bt[:, 4] = need_t
+        self.batches = torch.from_numpy(bt).to(dev)
+        self.sync = torch.zeros(int(lib().dn_rows_pipe_sync_words(B)), dtype=I32, device=dev)
+        self._ring = {}
+        self.disabled = False
+        self.checks_left = {"f": 2, "b": 2}
+
+    def ring(self, H, dtype, dev):
+        key = (H, dtype)
+        r = self._ring.get(key)
+        if r is None:
+            r = torch.empty((max(self.ring_rows, 1), H), dtype=dtype, device=dev)
+            self._ring[key] = r
+        return r
+
+    def aborted(self):
+        """Abort word of the last launch (synchronises)."""
+        return int(self.sync[2 * self.num_batches + 8].item())
+
+
+def rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):
+    """dn_rows_pipe_bf16: the whole direction in one persistent launch.  Returns False when the launch reported an abort."""
+    require_gpu(xs, aux, Wmat, bias, out)
+    N, H = xs.shape
+    ring = pipe.ring(H, xs.dtype, xs.device)
+    n1 = N if aux is not None else INT32_MAX
+
+    def _launch():
+        check(lib().dn_rows_pipe_bf16(ptr(xs), ptr(aux), n1, ptr(pipe.row_idx[direction]), H, ptr(Wmat), ptr(bias),
+                                      Wmat.shape[0] - 1, ptr(pipe.roles), pipe.num_groups, pipe.roles_per_group,
+                                      ptr(pipe.tiles), pipe.num_tiles, ptr(pipe.batches), pipe.num_batches,
+                                      ptr(pipe.list_ptr[direction]), ptr(pipe.list_local[direction]), ptr(ring), ptr(pipe.sync),
+                                      N, ptr(out), PIPE_TIMEOUT_MS, stream_ptr()), "dn_rows_pipe_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_pipe", _launch)
+    else:
+        _launch()
+    if pipe.checks_left[direction] > 0 and not torch.cuda.is_current_stream_capturing():
+        pipe.checks_left[direction] -= 1
+        code = pipe.aborted()
+        if code != 0:
+            pipe.disabled = True
+            import sys
+            sys.stderr.write("[dn_hip] dn_rows_pipe_bf16 aborted (code %d: %s); falling back to the two-launch path\n"
+                             % (code, "workgroups of a group on different XCDs" if code == 1 else "hand-off timeout"))
+            return False
+    return True
+
+
+def _pipe_of(ix, xs):
+    p = getattr(ix, "pipe", None)
+    if p is None or p.disabled or not PIPE_ENABLED or xs.dtype != torch.bfloat16 or not ix.self_loop:
+        return None
+    return p
 
 
 def _selfsum_ok(ix, x):
@@ -818,6 +1065,9 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
     aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
+    pipe = _pipe_of(ix, xs)
+    if pipe is not None and rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):
+        return aux
     if _selfsum_ok(ix, xs):
         P = ix.num_edge_rows
         Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
