@@ -61,8 +61,8 @@ _SIGS = {
     "dn_rows_chain2_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, P, P, P]),
     "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P]),
     "dn_rows_pipe_sync_words": (c_sz, [c_i64]),
-    "dn_rows_pipe_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, P, P, c_i32, P, c_i32, c_i32, P, c_i64, P, c_i64, P, P, P, P,
-                                         c_i64, P, c_i32, P]),
+    "dn_rows_pipe_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, P, P, P, c_i32, c_i32, P, c_i64, P, c_i64, P, P, P, P,
+                                         c_i64, P, c_i32, P, P]),
     "dn_rows_transform_f32": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, P]),
     "dn_rows_wgrad_f32": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P,
                                          P, c_sz, P]),

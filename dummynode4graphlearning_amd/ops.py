@@ -806,11 +806,15 @@ class RowIndexSet:
         return b
 
 
-PIPE_ENABLED = _os.environ.get("DN_PIPE", "1") != "0"
-PIPE_BATCH_NODES = int(_os.environ.get("DN_PIPE_BATCH_NODES", "384"))     # nodes per batch (ring slot ~ 2x that many rows)
-PIPE_RING_DEPTH = int(_os.environ.get("DN_PIPE_DEPTH", "6"))              # batches in flight per XCD
+# The persistent XCD-local launch (csrc/dn_pipe.hip) is correct and parity-tested but SLOWER than the two-launch path on
+# MI355X (config 5: 1.6 ms against 0.9 ms per direction): the L2 serves the ring reads (86 % hit rate,
+# HBM reads 0.65 GB instead of 3.2 GB) but writes through to HBM anyway (WRITE_SIZE 2.07 GB per launch), and one tile in
+# flight per workgroup behind two hand-offs per batch leaves the launch latency-bound.  Opt in with DN_PIPE=1.
+PIPE_ENABLED = _os.environ.get("DN_PIPE", "0") == "1"
+PIPE_BATCH_NODES = int(_os.environ.get("DN_PIPE_BATCH_NODES", "256"))     # nodes per batch (ring slot ~ 3x that many rows)
+PIPE_RING_DEPTH = int(_os.environ.get("DN_PIPE_DEPTH", "5"))              # batches in flight per XCD
 PIPE_ROLES = int(_os.environ.get("DN_PIPE_ROLES", "64"))                  # workgroups per XCD (2 per CU)
-PIPE_C_WEIGHT = float(_os.environ.get("DN_PIPE_CW", "1.5"))               # cost of a closing tile relative to a transform tile
+PIPE_C_WEIGHT = float(_os.environ.get("DN_PIPE_CW", "1.0"))               # cost of a sum tile relative to a transform tile
 PIPE_MAX_SLOT_ROWS = int(_os.environ.get("DN_PIPE_MAX_SLOT_ROWS", "4096"))   # a batch's rows must be able to sit in L2
 PIPE_TIMEOUT_MS = 200
 
@@ -826,14 +830,15 @@ class PipeIndex:
     def __init__(self, ix, node_ptr, groups=8, roles_per_group=None, depth=None, batch_nodes=None):
         import numpy as np
         dev = ix.row_in.device
-        N, P, R = ix.num_nodes, ix.num_edge_rows, ix.num_rels
+        # the self loop is relation R of the launch: one row per node (RowIndex appends those rows after the edge rows)
+        N, P, R = ix.num_nodes, ix.num_rows, ix.num_all_rels
         roles_per_group = roles_per_group or PIPE_ROLES
         depth = depth or PIPE_RING_DEPTH
         batch_nodes = batch_nodes or PIPE_BATCH_NODES
         self.ix, self.depth, self.roles_per_group = ix, depth, roles_per_group
         nptr_h = node_ptr.detach().to("cpu", torch.int64).numpy()
         G = len(nptr_h) - 1
-        assert G >= 1 and int(nptr_h[-1]) == N
+        assert G >= 1 and int(nptr_h[-1]) == N and ix.self_loop
         n_g = np.diff(nptr_h)
         # ---- rows -> graphs (device) ------------------------------------------------------------------------------------
         nptr_d = node_ptr.to(device=dev, dtype=torch.int64)
@@ -897,17 +902,15 @@ class PipeIndex:
             lp64 = lp[:N + 1].long()
             ent = lr[:int(lp64[N])].long() if N else lr[:0].long()
             node_of_ent = torch.repeat_interleave(torch.arange(N, device=dev), lp64[1:] - lp64[:-1], output_size=int(ent.numel()))
-            keep = ent < P
-            cnt = torch.bincount(node_of_ent[keep], minlength=N)
-            self.list_ptr[d] = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(I32).contiguous()
-            loc = inv[ent[keep]] - rowbase_d[batch_of_node[node_of_ent[keep]]]
+            self.list_ptr[d] = lp[:N + 1].to(I32).contiguous()
+            loc = inv[ent] - rowbase_d[batch_of_node[node_of_ent]]
             self.list_local[d] = (loc.to(I32) if loc.numel() else torch.zeros(1, dtype=I32, device=dev)).contiguous()
         # ---- tiles and roles (host) --------------------------------------------------------------------------------------------
         TR = 32
         ub, ur = np.divmod(np.flatnonzero(unit_cnt > 0), R)          # non-empty units in (batch, relation) order
         ucnt = unit_cnt[ub * R + ur]
         ubeg = unit_ptr[ub * R + ur]
-        need_t = np.bincount(ub, minlength=B)
+        need_t = np.zeros(B, dtype=np.int64)                         # T tiles per batch (every tile signals)
         cb_tiles = -(-(bnode[1:] - bnode[:-1]) // TR)                # closing tiles per batch
         roles = np.zeros((groups * roles_per_group, 4), dtype=np.int32)
         roles[:, 0] = 2                                              # idle unless assigned
@@ -942,19 +945,30 @@ class PipeIndex:
                 n_t = S - m_c
                 rel_slot = {int(r): (i % n_t, 1) for i, r in enumerate(rels)}
                 c_base = n_t
-            # T tiles of this group
+            # T tiles of this group: the tiles of a relation are dealt round-robin (batch-major) to that relation's roles, so a
+            # large unit (the self loop: one row per node) is worked on by several roles at once; every tile signals for itself
             if gub.size:
-                base = np.array([rel_slot[int(r)][0] for r in gur])
-                mm = np.array([rel_slot[int(r)][1] for r in gur])
-                urole = base + (blocal[gub] % mm)
                 t_unit = np.repeat(np.arange(gub.size), gtiles)
                 t_k = np.arange(t_unit.size) - np.repeat(np.cumsum(gtiles) - gtiles, gtiles)
                 tbeg = gbeg[t_unit] + TR * t_k
                 tend = np.minimum(tbeg + TR, gbeg[t_unit] + gcnt[t_unit])
-                flags = gur[t_unit] | ((t_k == 0).astype(np.int64) << 16) | ((t_k == gtiles[t_unit] - 1).astype(np.int64) << 17)
-                trole = urole[t_unit]
-                o = np.argsort(trole, kind="stable")                 # units are batch-major already: stays so inside a role
-                tt = np.stack([tbeg[o], tend[o], gub[t_unit][o], flags[o]], 1)
+                trel, tbatch = gur[t_unit], gub[t_unit]
+                # rank of every tile inside its relation (tiles are (batch, relation)-major here)
+                o_rel = np.argsort(trel, kind="stable")
+                rank = np.empty(t_unit.size, dtype=np.int64)
+                rel_sorted = trel[o_rel]
+                starts_rel = np.concatenate([[0], np.flatnonzero(np.diff(rel_sorted)) + 1])
+                rank[o_rel] = np.arange(t_unit.size) - np.repeat(starts_rel, np.diff(np.concatenate([starts_rel, [t_unit.size]])))
+                base = np.array([rel_slot[int(r)][0] for r in rels])[np.searchsorted(rels, trel)]
+                mm = np.array([rel_slot[int(r)][1] for r in rels])[np.searchsorted(rels, trel)]
+                trole = base + rank % mm
+                o = np.argsort(trole, kind="stable")                 # batch-major inside a role
+                tb_o, tr_o = tbatch[o], trole[o]
+                firstf = np.ones(o.size, dtype=np.int64)
+                same = (tr_o[1:] == tr_o[:-1]) & (tb_o[1:] == tb_o[:-1])
+                firstf[1:][same] = 0
+                flags = trel[o] | (firstf << 16) | (1 << 17)
+                tt = np.stack([tbeg[o], tend[o], tb_o, flags], 1)
                 cnts = np.bincount(trole, minlength=S)
                 starts = ntile + np.concatenate([[0], np.cumsum(cnts)])
                 for rsl in range(S):
@@ -962,6 +976,7 @@ class PipeIndex:
                         roles[g * S + rsl] = (0, starts[rsl], starts[rsl + 1], 0)
                 tile_chunks.append(tt)
                 ntile += tt.shape[0]
+                need_t += np.bincount(tbatch, minlength=B)
             # C tiles: all node tiles of the group, batch-major, dealt round-robin to the C roles
             cbt = cb_tiles[b0:b1]
             c_batch = np.repeat(np.arange(b0, b1), cbt)
@@ -997,6 +1012,7 @@ class PipeIndex:
         self.sync = torch.zeros(int(lib().dn_rows_pipe_sync_words(B)), dtype=I32, device=dev)
         self._ring = {}
         self.disabled = False
+        self.stats = None                                # an int64 [8 * roles_per_group, 8] tensor collects launch statistics
         self.checks_left = {"f": 2, "b": 2}
 
     def ring(self, H, dtype, dev):
@@ -1021,10 +1037,10 @@ def rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):
 
     def _launch():
         check(lib().dn_rows_pipe_bf16(ptr(xs), ptr(aux), n1, ptr(pipe.row_idx[direction]), H, ptr(Wmat), ptr(bias),
-                                      Wmat.shape[0] - 1, ptr(pipe.roles), pipe.num_groups, pipe.roles_per_group,
+                                      ptr(pipe.roles), pipe.num_groups, pipe.roles_per_group,
                                       ptr(pipe.tiles), pipe.num_tiles, ptr(pipe.batches), pipe.num_batches,
                                       ptr(pipe.list_ptr[direction]), ptr(pipe.list_local[direction]), ptr(ring), ptr(pipe.sync),
-                                      N, ptr(out), PIPE_TIMEOUT_MS, stream_ptr()), "dn_rows_pipe_bf16")
+                                      N, ptr(out), PIPE_TIMEOUT_MS, ptr(pipe.stats), stream_ptr()), "dn_rows_pipe_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_pipe", _launch)
     else:

@@ -271,31 +271,34 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
 
 /* One direction of the row-factorised message pass as ONE persistent launch in which the transformed edge rows travel from
  * their producers to their consumers through the XCD's L2 instead of HBM (csrc/dn_pipe.hip has the design note):
- *   out[v] = X[v] @ Wn[self_rel]^T (+ bias) + sum_{p in list(v)} ( Xcat[row_idx[p]] @ Wn[rel(p)]^T )
+ *   out[v] = (bias) + sum_{p in list(v)} ( Xcat[row_idx[p]] @ Wn[rel(p)]^T )      (the self loop is one more relation:
+ *   one row per node with row_idx = the node)
  * Replaces, like dn_rows_transform_bf16 + dn_rows_selfsum_bf16 together, the per-edge transform, the fn.sum reduce and the
  * self-loop / bias update of subgraph_isomorphism/models/rgin.py:102-120,137-145 (and their autograd mirror for the input
  * gradient: X = grad rows, Wn = un-transposed weights, lists by source).
  * The caller cuts the batch into `num_groups` (<= 8, one per XCD) contiguous ranges of graphs and each range into batches:
  *   tiles   [num_tiles][4]  {beg, end, batch, rel | first << 16 | last << 17}: a T tile covers edge rows [beg, end) (<= 32) of
- *           one (batch, relation) unit, a C tile covers nodes [beg, end) (<= 32) of one batch; first / last mark the role's
- *           first / last tile of that unit (C tiles: first tile of the batch in the role's sequence).
- *   roles   [num_groups * roles_per_group][4]  {kind (0 T, 1 C, else idle), tile_beg, tile_end, 0}: the tile sequence of each
+ *           one (batch, relation) unit, an S tile covers nodes [beg, end) (<= 64) of one batch; first / last mark the role's
+ *           first / last tile of that unit (S tiles: first tile of the batch in the role's sequence).
+ *   roles   [num_groups * roles_per_group][4]  {kind (0 T, 1 S, else idle), tile_beg, tile_end, 0}: the tile sequence of each
  *           workgroup, batches in increasing order.  Workgroup b of the grid serves group b % 8, role b / 8.
  *   batches [num_batches][8]  {rowbase, ringoff, need_c, wait_batch, need_t, 0, 0, 0}: first edge row of the batch, first ring
- *           row of its slot, number of C tiles, the batch whose C tiles must have finished before this batch's ring slot
+ *           row of its slot, number of S tiles, the batch whose S tiles must have finished before this batch's ring slot
  *           may be written (-1: none), number of T units that signal for it.
  *   list_ptr [N+1] / list_local: per-node CSR of the rows summed into the node, as row ids RELATIVE to the batch's rowbase.
  *   ring: [ring_rows][H] bf16 scratch (sum over groups of slots x rows per slot); sync: dn_rows_pipe_sync_words(num_batches)
  *   int32 words, zeroed by the call; after the launch sync[2*num_batches + 8] != 0 means the launch ABORTED (the workgroups
  *   of a group were not on one XCD, or a hand-off waited longer than timeout_ms): `out` is then undefined and the caller
  *   must recompute it with dn_rows_transform_bf16 + dn_rows_selfsum_bf16.  The launch cannot hang.
+ * stats (may be NULL): int64 [8 * roles_per_group][8] per workgroup {ticks in the launch, ticks waiting on a hand-off,
+ * tiles, kind, ticks in four sections of the tile loop} at 100 MHz -- a tuning aid.
  * H in {64, 128, 256}; roles_per_group <= 64 (two 512-thread workgroups per CU must be co-resident). */
 size_t dn_rows_pipe_sync_words(int64_t num_batches);
 int dn_rows_pipe_bf16(const void* X, const void* X2, int32_t n1, const int32_t* row_idx, int32_t H, const void* Wn,
-                      const void* bias, int32_t self_rel, const int32_t* roles, int32_t num_groups, int32_t roles_per_group,
+                      const void* bias, const int32_t* roles, int32_t num_groups, int32_t roles_per_group,
                       const int32_t* tiles, int64_t num_tiles, const int32_t* batches, int64_t num_batches,
                       const int32_t* list_ptr, const int32_t* list_local, void* ring, int32_t* sync, int64_t N, void* out,
-                      int32_t timeout_ms, dn_stream_t stream);
+                      int32_t timeout_ms, int64_t* stats, dn_stream_t stream);
 
 /* Two dense layers in one pass over the rows (bf16 in, fp32 acc, bf16 out):
  *   Y1 = epi1(m0(X) @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)

@@ -36,6 +36,17 @@ def _batch(rng, G, R, n_lo, n_hi, dummy=True):
             torch.tensor(et, dtype=torch.int64))
 
 
+def _index_with_pipe(src, dst, et, N, R, node_ptr):
+    """The persistent launch is opt-in (DN_PIPE=1): build the index with it switched on."""
+    from dummynode4graphlearning_amd import ops
+    old = ops.PIPE_ENABLED
+    ops.PIPE_ENABLED = True
+    try:
+        return ops.RowIndexSet(src.to(DEV), dst.to(DEV), et.to(DEV), N, R, True, node_ptr=node_ptr.to(DEV), edge_ptr=None)
+    finally:
+        ops.PIPE_ENABLED = old
+
+
 def _run(iset, x, W_all, bias, use_pipe):
     from dummynode4graphlearning_amd import ops
     ix = iset.parts[0][2]
@@ -67,7 +78,7 @@ def test_pipe_matches_two_launch_path_and_fp64(H, shape):
     else:
         node_ptr, src, dst, et = _batch(rng, 5, R, 1, 6)
     N = int(node_ptr[-1])
-    iset = ops.RowIndexSet(src.to(DEV), dst.to(DEV), et.to(DEV), N, R, True, node_ptr=node_ptr.to(DEV), edge_ptr=None)
+    iset = _index_with_pipe(src, dst, et, N, R, node_ptr)
     ix = iset.parts[0][2]
     assert getattr(ix, "pipe", None) is not None
     gen = torch.Generator().manual_seed(H)
@@ -107,8 +118,9 @@ def test_pipe_is_bitwise_reproducible_and_used_by_the_layer():
     x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
     coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
     calls = []
-    orig = ops.rows_pipe
+    orig, old_flag = ops.rows_pipe, ops.PIPE_ENABLED
     ops.rows_pipe = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    ops.PIPE_ENABLED = True
     runs = []
     try:
         for _ in range(3):
@@ -119,7 +131,7 @@ def test_pipe_is_bitwise_reproducible_and_used_by_the_layer():
             out.backward(coef)
             runs.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     finally:
-        ops.rows_pipe = orig
+        ops.rows_pipe, ops.PIPE_ENABLED = orig, old_flag
     assert len(calls) == 6, "the layer did not take the persistent launch in both directions"
     for r in runs[1:]:
         for a, b in zip(runs[0], r):
@@ -133,7 +145,7 @@ def test_pipe_abort_falls_back():
     rng = np.random.default_rng(0)
     node_ptr, src, dst, et = _batch(rng, 64, 6, 8, 20)
     N, H, R = int(node_ptr[-1]), 64, 6
-    iset = ops.RowIndexSet(src.to(DEV), dst.to(DEV), et.to(DEV), N, R, True, node_ptr=node_ptr.to(DEV), edge_ptr=None)
+    iset = _index_with_pipe(src, dst, et, N, R, node_ptr)
     ix = iset.parts[0][2]
     gen = torch.Generator().manual_seed(1)
     x = torch.randn(N, H, generator=gen).to(torch.bfloat16).to(DEV)

@@ -1,7 +1,8 @@
 """Host logic of the persistent message-pass launch (ops.PipeIndex -> dn_rows_pipe_bf16), on the CPU: the work tables are
 executed by a small SIMULATOR of the kernel's protocol (roles walking their tile sequences, the done / cdone counters, the ring
 of batch slots that is overwritten every `depth` batches) and must (1) never deadlock, (2) never overwrite a ring slot that
-still has unread rows, (3) reproduce  out[v] = x[v] W_self + b + sum_{e: dst(e) = v} x[src(e)] W[etype(e)]  exactly.
+still has unread rows, (3) reproduce  out[v] = x[v] W_self + b + sum_{e: dst(e) = v} x[src(e)] W[etype(e)]  exactly (the self
+loop travels through the ring as one more relation).
 No GPU code runs here (the table builder only uses torch index ops + numpy); the GPU parity tests are in test_gpu_pipe.py."""
 from types import SimpleNamespace
 
@@ -27,7 +28,8 @@ def _fake_row_index(src, dst, et, N, R):
 
     dp, dr = lists(dst)
     sp, sr = lists(src)
-    return SimpleNamespace(num_nodes=N, num_edge_rows=P, num_rels=R, rel_ptr_host=rel_ptr, row_in=torch.from_numpy(row_in),
+    return SimpleNamespace(num_nodes=N, num_edge_rows=P, num_rows=P + N, num_rels=R, num_all_rels=R + 1, self_loop=True,
+                           rel_ptr_host=rel_ptr, row_in=torch.from_numpy(row_in),
                            row_out=torch.from_numpy(row_out), dst_ptr=dp, dst_rows=dr, src_ptr=sp, src_rows=sr), order
 
 
@@ -59,21 +61,29 @@ def simulate(pipe, direction, x, W, bias):
     ring_owner = np.full(pipe.ring_rows, -1)          # batch whose rows currently sit in a ring row
     done, cdone = np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.int64)
     out = np.full((N, H), np.nan)
-    self_rel = W.shape[0] - 1
     cur = {r: int(roles[r, 1]) for r in range(roles.shape[0]) if roles[r, 0] in (0, 1)}
-    seen_rows, seen_nodes = np.zeros(pipe.ix.num_edge_rows, dtype=np.int64), np.zeros(N, dtype=np.int64)
+    seen_rows, seen_nodes = np.zeros(pipe.ix.num_rows, dtype=np.int64), np.zeros(N, dtype=np.int64)
+    pending = {}
     progress = True
     while progress:
         progress = False
         for r in list(cur):
             t = cur[r]
             if t >= roles[r, 2]:
+                if pending.get(r, -1) >= 0:
+                    done[pending[r]] += 1
+                    pending[r] = -1
+                    progress = True
                 del cur[r]
                 continue
             beg, end, b, rf = (int(v) for v in tiles[t])
             rel, first, last = rf & 0xffff, (rf >> 16) & 1, (rf >> 17) & 1
             rowbase, ringoff, need_c, wait_b, need_t = (int(v) for v in bt[b][:5])
             if roles[r, 0] == 0:
+                if pending.get(r, -1) >= 0:                      # the kernel signals a unit one tile late, before it may block
+                    done[pending[r]] += 1
+                    pending[r] = -1
+                    progress = True
                 if first and wait_b >= 0 and cdone[wait_b] < bt[wait_b][2]:
                     continue                                     # ring slot still being read
                 for p in range(beg, end):
@@ -85,13 +95,13 @@ def simulate(pipe, direction, x, W, bias):
                     ring_owner[rr] = b
                     seen_rows[p] += 1
                 if last:
-                    done[b] += 1
+                    pending[r] = b
             else:
                 if first and done[b] < need_t:
                     continue
                 assert done[b] >= need_t, "closing tile ran before its batch was complete"
                 for v in range(beg, end):
-                    acc = x[v] @ W[self_rel] + (bias if bias is not None else 0.0)
+                    acc = np.zeros(H) + (bias if bias is not None else 0.0)
                     for i in range(lptr[v], lptr[v + 1]):
                         rr = ringoff + int(lloc[i])
                         assert ring_owner[rr] == b, "list entry points outside its batch"
