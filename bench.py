@@ -38,13 +38,16 @@ def build_batch(dev, seed, graphs, workload):
     from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
     raw = synthetic.config5(seed, graphs) if workload == "config5" else synthetic.config3(seed, graphs)
     t = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    aug = transforms.dummy_augment_si(t["node_ptr"], t["edge_ptr"], t["src"], t["dst"], t["node_id"], t["node_label"],
-                                      t["edge_id"], t["edge_label"], raw["max_nv"], raw["max_nvl"], raw["max_ne"],
-                                      raw["max_nel"])
-    torch.cuda.synchronize()
-    aug_ms = (time.perf_counter() - t0) * 1e3
+    aug_ms = []
+    for _ in range(3):                                   # first call: code-object load + allocator growth; then steady state
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        aug = transforms.dummy_augment_si(t["node_ptr"], t["edge_ptr"], t["src"], t["dst"], t["node_id"], t["node_label"],
+                                          t["edge_id"], t["edge_label"], raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                          raw["max_nel"])
+        torch.cuda.synchronize()
+        aug_ms.append((time.perf_counter() - t0) * 1e3)
+    aug_ms = (aug_ms[0], min(aug_ms[1:]))
     N = int(aug["node_label"].numel())
     bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
     bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
@@ -456,7 +459,11 @@ def main():
             "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd on %d graphs/GPU (N=%d, E=%d per GPU), "
                                    "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
                        "global_edges": world * E, "parallelism": "dp%d" % world,
-                       "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms, "index_build_first_call_ms": index_first_ms, "dummy_augment_ms": aug_ms,
+                       "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms,
+                       "index_build_first_call_ms": index_first_ms, "dummy_augment_ms": aug_ms[1],
+                       "dummy_augment_first_call_ms": aug_ms[0],
+                       # a training loop sees a NEW batch every step: dummy augmentation + index build + step, per fresh batch
+                       "edges_per_s_incl_index_build": world * E / ((ms_per_step + index_ms + aug_ms[1]) * 1e-3),
                        "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

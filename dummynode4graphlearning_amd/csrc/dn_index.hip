@@ -608,6 +608,41 @@ __global__ void ri_tail_kernel(int64_t E, int64_t N, int64_t P, int64_t n_agg, i
     }
 }
 
+// ----- tile / chunk tables of relation-major rows, built on the device (no host loop, no device -> host sync) ----------------
+// entry i of a table = {rel, beg, end, 0}: piece k of relation r covers rows [rel_ptr[r] + k*step, min(.. + step, rel_ptr[r+1])).
+// Tables are sized by an upper bound (rows / step + relations); the unused tail is filled with empty pieces of the last
+// relation (beg == end: consumers skip them without reloading weights).
+__global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_ptr, int32_t step, int64_t max_entries,
+                                  int32_t* __restrict__ table, int32_t* __restrict__ piece_ptr) {
+    __shared__ int32_t pp[1025];                                  // pieces before relation r (Rt <= 1024)
+    if (threadIdx.x == 0) {
+        int32_t acc = 0;
+        for (int r = 0; r < Rt; ++r) {
+            pp[r] = acc;
+            const int32_t cnt = rel_ptr[r + 1] - rel_ptr[r];
+            acc += (cnt + step - 1) / step;
+        }
+        pp[Rt] = acc;
+    }
+    __syncthreads();
+    if (piece_ptr && blockIdx.x == 0)
+        for (int r = threadIdx.x; r <= Rt; r += blockDim.x) piece_ptr[r] = pp[r];
+    const int32_t total = pp[Rt];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < max_entries; i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t rel, beg, end;
+        if (i < total) {
+            int lo = 0, hi = Rt;                                  // last r with pp[r] <= i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pp[mid] <= (int32_t)i) lo = mid; else hi = mid; }
+            rel = lo;
+            beg = rel_ptr[rel] + ((int32_t)i - pp[rel]) * step;
+            end = min(beg + step, rel_ptr[rel + 1]);
+        } else {
+            rel = Rt - 1; beg = rel_ptr[Rt]; end = beg;
+        }
+        table[4 * i] = rel; table[4 * i + 1] = beg; table[4 * i + 2] = end; table[4 * i + 3] = 0;
+    }
+}
+
 struct RowWs {
     int32_t *key, *skey, *iota, *order, *Er, *Dr, *Sr, *mode;
     int32_t *head, *aggh, *tfh, *agge, *tfe, *head_s, *aggh_s, *tfh_s, *agge_s, *tfe_s, *row_rel;
@@ -1067,6 +1102,18 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
     DN_CHECK_HIP(hipMemcpyAsync(host_modes, w.mode, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
     host_counts[0] = P; host_counts[1] = n_agg; host_counts[2] = n_tf; host_counts[3] = n_agg_e; host_counts[4] = n_tf_e;
+    return DN_OK;
+}
+
+int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,
+                            int32_t* piece_ptr, dn_stream_t stream) {
+    DN_REQUIRE(num_rels >= 1 && num_rels <= 1024, "dn_row_tables_build: 1 <= num_rels <= 1024");
+    DN_REQUIRE(step >= 1 && max_entries >= 0, "dn_row_tables_build: bad sizes");
+    DN_REQUIRE(rel_ptr && (max_entries == 0 || table), "dn_row_tables_build: NULL pointer");
+    const int64_t blocks = max_entries > 0 ? dn_cdiv(max_entries, 256) : 1;
+    hipLaunchKernelGGL(row_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
+                       num_rels, rel_ptr, step, max_entries, table, piece_ptr);
+    DN_CHECK_LAUNCH();
     return DN_OK;
 }
 

@@ -203,6 +203,21 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     return (out, colsum) if colsum_of else out
 
 
+def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False):
+    """Tile (step = 32) / chunk tables of relation-major rows built ON THE DEVICE (dn_row_tables_build_i32): returns
+    (table [M, 4] int32, M) or (table, piece_ptr [num_rels + 1], M) with M = the upper bound rows / step + num_rels --
+    unused entries are empty pieces, which every consumer skips."""
+    require_gpu(rel_ptr_dev)
+    _i32(rel_ptr_dev, "rel_ptr")
+    dev = rel_ptr_dev.device
+    M = int(num_rows) // int(step) + int(num_rels) + 1
+    table = torch.empty((M, 4), dtype=I32, device=dev)
+    pptr = torch.empty(int(num_rels) + 1, dtype=I32, device=dev) if want_ptr else None
+    check(lib().dn_row_tables_build_i32(int(num_rels), ptr(rel_ptr_dev), int(step), M, ptr(table), ptr(pptr), stream_ptr()),
+          "dn_row_tables_build_i32")
+    return (table, pptr, M) if want_ptr else (table, M)
+
+
 def make_row_tiles(rel_ptr_host, device, tile_rows=32):
     """Tile table for dn_rows_transform_bf16: [T,4] int32 rows {rel, beg, end, 0}, tiles never cross relations."""
     import numpy as np
@@ -740,11 +755,14 @@ class RowIndex:
         self.num_rows, self.num_edge_rows = P_all, P
         self.num_all_rels = R + (1 if self_loop else 0)
         self.rel_ptr_host = rel_ptr
-        self.tile_table = make_row_tiles(rel_ptr, dev)
-        self.edge_tile_table = make_row_tiles(rel_ptr[:R + 1], dev) if self_loop else self.tile_table
+        # tile / chunk tables on the device (the 18 relation offsets go up in one small copy; no host loops)
+        rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
+        self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
+        self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
         self._slots = {}
         # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
-        self.chunk_table = make_row_chunks(rel_ptr, dev, chunk_rows=max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)))
+        self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all,
+                                            max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)), want_ptr=True)
 
 
 def _row_index_slots(ix, direction):

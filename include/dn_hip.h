@@ -209,6 +209,15 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
                            int32_t* src_rows, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* Tile / chunk tables of relation-major rows for dn_rows_transform_* (step = 32 rows) and dn_rows_wgrad_* (step = the
+ * split-K chunk size), built on the device from rel_ptr [num_rels + 1] (device): entry i = {rel, beg, end, 0}.  The caller
+ * sizes `table` by the upper bound max_entries >= rows / step + num_rels; unused entries become empty pieces (beg == end) of
+ * the last relation.  piece_ptr (may be NULL) receives the [num_rels + 1] piece ranges per relation (dn_rows_wgrad_*'s
+ * chunk_ptr).  Replaces the per-batch bookkeeping DGL does inside dgl.batch / update_all
+ * (subgraph_isomorphism/dataset.py:1605-1611, models/rgin.py:156-160); no device -> host synchronisation. */
+int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,
+                            int32_t* piece_ptr, dn_stream_t stream);
+
 /* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build; replaces the reference's
  * per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`, subgraph_isomorphism/models/rgin.py:137).
  * list_ptr [N+1] / list_rows: CSR of row ids per node (dn_row_index_build_i32's dst_ptr/dst_rows or src_ptr/src_rows).
