@@ -3,7 +3,15 @@
 // The reference is fp32 only, so this is the path that keeps its numerics (1e-4 parity) while still replacing the
 // per-edge [E,H,H] weight gather (subgraph_isomorphism/models/rgin.py:109-110) by the row factorisation.
 //
-// Same structure as the bf16 kernels; what changes is the fragment shape: an MFMA step reduces over 4 values, lane
+// Two arithmetic modes behind the same entry points (`precision` argument):
+//   0 (default)  3-term bf16 split on the fast matrix path: every f32 operand is cut into hi = bf16(x) and lo = bf16(x - hi)
+//                when it is staged (rows: global -> LDS; weights: global -> registers), and a product is evaluated as
+//                hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with f32 accumulation.  The dropped lo*lo term and the
+//                two roundings are O(2^-16) relative per product: 1e-5-level agreement with the reference, inside its 1e-4
+//                bar, at 3/16 of the exact path's matrix time (MI355X: exact f32 MFMA = 1/16 of the bf16 rate).
+//   1            exact f32 (v_mfma_f32_16x16x4_f32): the checker, and what the parity suite pins the split against.
+//
+// Same structure as the bf16 kernels; what changes in exact mode is the fragment shape: an MFMA step reduces over 4 values, lane
 // (r = lane & 15, g = lane >> 4) supplies one f32 of row r.  Four consecutive steps are fed from ONE 16-byte load per
 // lane by letting step j use k = 16*blk + 4*g + j on BOTH operands (the sum over k does not care about the order), so
 // LDS and weight reads stay 128-bit.
@@ -13,6 +21,39 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+
+// x = hi + lo (+ O(2^-17 |x|)): hi = bf16(x) (round to nearest even), lo = bf16(x - hi)
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (bf16_t)f[i];
+        lo[i] = (bf16_t)(f[i] - (float)hi[i]);
+    }
+}
+__device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (bf16_t)f[i];
+        lo[i] = (bf16_t)(f[i] - (float)hi[i]);
+    }
+}
+// fragment of a K-strided bf16 operand held row-major in LDS (hardware transpose read, as dn_rel.hip:tr_frag)
+__device__ __forceinline__ bf16x8 tr_frag16(const bf16_t* tile, int stride, int col0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const bf16_t* a0 = tile + (8 * g + q) * stride + col0 + 4 * p;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * stride));
+    const short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, f);
+}
 
 constexpr int kThreads = 512;
 constexpr int kRows = 32;
@@ -146,6 +187,146 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32_kernel(const float* _
         float* red = lds;
         const int cchunk = tid % (H / 4), slot = tid / (H / 4);
         const bool has = (NP >= kThreads) || tid < NP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[slot * H + cchunk * 4 + i] = has ? cs[i] : 0.f;
+        __syncthreads();
+        if (tid < H) {
+            float sum = 0.f;
+            for (int sl = 0; sl < TPC; ++sl) sum += red[sl * H + tid];
+            colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
+        }
+    }
+}
+
+// 3-term split twin of the weight gradient: the four bf16 tiles Ah, Al, Gh, Gl of a 32-row stage sit row-major in LDS
+// ([32][H + 8], as the bf16 kernel's), fragments come through the transposing LDS read, three MFMAs per (m, n) pair.
+template <int H>
+__global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                                   int32_t na1, const int32_t* __restrict__ ia,
+                                                                   const float* __restrict__ G, const float* __restrict__ G2,
+                                                                   int32_t ng1, const int32_t* __restrict__ ig,
+                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                   int32_t colsum_of, float* __restrict__ colsum_partial,
+                                                                   const float* __restrict__ maskA, float* __restrict__ A_out) {
+    constexpr int S = H + 8;                                    // bf16 elements per LDS row
+    constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
+    constexpr int NP = kRows * H / 4;                           // 4-float pieces per operand tile
+    constexpr int P = (NP + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 4 * kRows * S];
+    auto tile = [&](int b, int which) -> bf16_t* { return lds + (b * 4 + which) * (kRows * S); };   // 0 Ah, 1 Al, 2 Gh, 3 Gl
+
+    const Chunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = (wave >> 2) * (H / 2), n0 = (wave & 3) * (H / 4);
+    const int ntiles = (ch.end - ch.beg + kRows - 1) / kRows;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[P], rg[P], rm[P];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    int32_t sa[P], sg[P], sa_cur[P];
+    auto load_idx = [&](int t) {
+        const int row0 = ch.beg + t * kRows;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, p = row0 + piece / (H / 4);
+            const bool ok = piece < NP && p < ch.end;
+            sa[j] = ok ? (ia ? ia[p] : p) : -1;
+            sg[j] = ok ? (ig ? ig[p] : p) : -1;
+        }
+    };
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int c = (tid + j * kThreads) % (H / 4);
+            sa_cur[j] = sa[j];
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sa[j] >= 0) {
+                const float* base = sa[j] < na1 ? A + (size_t)sa[j] * H : A2 + (size_t)(sa[j] - na1) * H;
+                ra[j] = *reinterpret_cast<const float4*>(base + c * 4);
+                if (maskA) rm[j] = *reinterpret_cast<const float4*>(maskA + (size_t)sa[j] * H + c * 4);
+            }
+            if (sg[j] >= 0) {
+                const float* base = sg[j] < ng1 ? G + (size_t)sg[j] * H : G2 + (size_t)(sg[j] - ng1) * H;
+                rg[j] = *reinterpret_cast<const float4*>(base + c * 4);
+            }
+        }
+    };
+    auto store_tile = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            if (maskA && sa_cur[j] >= 0) {
+                ra[j].x = rm[j].x > 0.f ? ra[j].x : 0.f; ra[j].y = rm[j].y > 0.f ? ra[j].y : 0.f;
+                ra[j].z = rm[j].z > 0.f ? ra[j].z : 0.f; ra[j].w = rm[j].w > 0.f ? ra[j].w : 0.f;
+                if (A_out) *reinterpret_cast<float4*>(A_out + (size_t)sa_cur[j] * H + c * 4) = ra[j];
+            }
+            if (piece < NP) {
+                bf16x4 h, l;
+                split4(ra[j], h, l);
+                *reinterpret_cast<bf16x4*>(tile(b, 0) + r * S + c * 4) = h;
+                *reinterpret_cast<bf16x4*>(tile(b, 1) + r * S + c * 4) = l;
+                split4(rg[j], h, l);
+                *reinterpret_cast<bf16x4*>(tile(b, 2) + r * S + c * 4) = h;
+                *reinterpret_cast<bf16x4*>(tile(b, 3) + r * S + c * 4) = l;
+                const float4 v = colsum_of == 1 ? ra[j] : rg[j];
+                if (colsum_of != 0) { cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w; }
+            }
+        }
+    };
+    if (ntiles > 0) {
+        load_idx(0);
+        load_tile();
+        store_tile(0);
+        load_idx(1);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int b = t & 1;
+        if (t + 1 < ntiles) {
+            load_tile();
+            load_idx(t + 2);
+        }
+        bf16x8 gh[NT], gl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            gh[n] = tr_frag16(tile(b, 2), S, n0 + n * 16, lane);
+            gl[n] = tr_frag16(tile(b, 3), S, n0 + n * 16, lane);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf16x8 ah = tr_frag16(tile(b, 0), S, k0 + m * 16, lane);
+            const bf16x8 al = tr_frag16(tile(b, 1), S, k0 + m * 16, lane);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) store_tile(b ^ 1);
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * H * H;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
+                out[(size_t)k * H + c] = acc[m][n][i];
+            }
+    if (colsum_of != 0) {
+        constexpr int TPC = kThreads / (H / 4);
+        float* red = reinterpret_cast<float*>(lds);
+        const int cchunk = tid % (H / 4), slot = tid / (H / 4);
+        const bool has = (NP >= kThreads) || tid < NP;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[slot * H + cchunk * 4 + i] = has ? cs[i] : 0.f;
         __syncthreads();
@@ -327,6 +508,147 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
     }
 }
 
+// 3-term split twin of the transform: rows are cut into hi / lo bf16 tiles when they are staged into LDS (same LDS bytes as
+// the f32 tile), the wave's weight slice is cut into hi / lo register fragments when the relation changes.
+template <int H>
+__global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
+    const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
+    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, const float* __restrict__ mask_pos,
+    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
+    constexpr int SX = H + 8;                                   // bf16 elements per LDS row of an input tile
+    constexpr int SY = H + 4;                                   // floats per LDS row of the output tile
+    constexpr int KS = H / 32;
+    constexpr int NT = (H / 8 + 15) / 16;
+    constexpr int MT = kRows / 16;
+    constexpr int NP = kRows * H / 4;
+    constexpr int P = (NP + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) bf16_t ldx[2 * 2 * kRows * SX];
+    __shared__ __attribute__((aligned(16))) float ldy[kRows * SY];
+    auto bufX = [&](int b, int lo) -> bf16_t* { return ldx + (b * 2 + lo) * (kRows * SX); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * (NT * 16);
+    const bool wave_active = n0 < H;
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    bf16x8 wh[KS][NT], wl[KS][NT];
+    int cur_rel = -1;
+    int32_t nidx[P];
+    float4 rx[P];
+    auto load_idx = [&](int t) {
+        if (t >= t_end) return;
+        const Chunk tl = tiles[t];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, p = tl.beg + piece / (H / 4);
+            nidx[j] = (piece < NP && p < tl.end) ? (idx ? idx[p] : p) : -1;
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int c = (tid + j * kThreads) % (H / 4);
+            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nidx[j] >= 0) {
+                const float* base = nidx[j] < n1 ? X + (size_t)nidx[j] * H : X2 + (size_t)(nidx[j] - n1) * H;
+                rx[j] = *reinterpret_cast<const float4*>(base + c * 4);
+            }
+        }
+    };
+    auto store_rows = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            if (piece < NP) {
+                bf16x4 h, l;
+                split4(rx[j], h, l);
+                *reinterpret_cast<bf16x4*>(bufX(b, 0) + r * SX + c * 4) = h;
+                *reinterpret_cast<bf16x4*>(bufX(b, 1) + r * SX + c * 4) = l;
+            }
+        }
+    };
+    load_idx(t_beg);
+    load_rows();
+    store_rows(0);
+    load_idx(t_beg + 1);
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        const Chunk tl = tiles[t];
+        if (t + 1 < t_end) load_rows();
+        if (tl.rel != cur_rel && wave_active) {
+            cur_rel = tl.rel;
+            const float* w = Wn + (size_t)cur_rel * H * H;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float* wp = w + (size_t)(n0 + nt * 16 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4);
+                    split8(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wh[ks][nt], wl[ks][nt]);
+                }
+        }
+        if (wave_active) {
+            f32x4 acc[MT][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16_t* xh = bufX(b, 0);
+            const bf16_t* xl = bufX(b, 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 fh[MT], fl[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    fh[m] = *reinterpret_cast<const bf16x8*>(xh + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                    fl[m] = *reinterpret_cast<const bf16x8*>(xl + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][n], fh[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][n], fl[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][n], fh[m], acc[m][n], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = n0 + n * 16 + 4 * (lane >> 4);
+                    float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+                    if (bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(ldy + (m * 16 + (lane & 15)) * SY + col) = v;
+                }
+        }
+        if (t + 1 < t_end) store_rows(b ^ 1);
+        load_idx(t + 2);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            const int p = tl.beg + r;
+            if (piece < NP && p < tl.end) {
+                float4 v = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
+                if (mask_pos) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mask_pos + (size_t)p * H + c * 4);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(Y + (size_t)p * H + c * 4) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
                                                            float4* __restrict__ out, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -338,21 +660,30 @@ __global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float4* __restr
 template <int H>
 int launch_wgrad(const float* A, const float* A2, int32_t na1, const int32_t* ia, const float* G, const float* G2, int32_t ng1,
                  const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of, float* csp,
-                 const float* maskA, float* A_out, hipStream_t st) {
-    hipLaunchKernelGGL((rows_wgrad_f32_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2, ng1,
-                       ig, chunks, partial, colsum_of, csp, maskA, A_out);
+                 const float* maskA, float* A_out, int32_t exact, hipStream_t st) {
+    if (exact)
+        hipLaunchKernelGGL((rows_wgrad_f32_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2,
+                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out);
+    else
+        hipLaunchKernelGGL((rows_wgrad_f32s_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2,
+                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 template <int H>
 int launch_transform(const float* X, const float* X2, int32_t n1, const int32_t* idx, const float* Wn, const float* bias,
-                     int32_t relu, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, hipStream_t st) {
+                     int32_t relu, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, int32_t exact,
+                     hipStream_t st) {
     const int64_t max_wg = 256 * (H == 256 ? 1 : 2);             // LDS: one 100 KB workgroup per CU at H = 256
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    hipLaunchKernelGGL((rows_transform_f32_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias, relu,
-                       mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+    if (exact)
+        hipLaunchKernelGGL((rows_transform_f32_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
+                           relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+    else
+        hipLaunchKernelGGL((rows_transform_f32s_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
+                           relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -378,8 +709,10 @@ int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, d
 int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G, const float* G2,
                       int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                       int64_t num_chunks, const int32_t* chunk_ptr, float* out, int32_t colsum_of, float* out_colsum,
-                      const float* mask_a, float* a_out, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                      const float* mask_a, float* a_out, int32_t precision, void* workspace, size_t workspace_bytes,
+                      dn_stream_t stream) {
     DN_REQUIRE(R >= 0 && num_chunks >= 0, "dn_rows_wgrad_f32: negative size");
+    DN_REQUIRE(precision == 0 || precision == 1, "dn_rows_wgrad_f32: precision must be 0 (bf16 split) or 1 (exact f32)");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_wgrad_f32: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
     DN_REQUIRE(A2 != nullptr || na1 == 0x7fffffff, "dn_rows_wgrad_f32: A2 == NULL requires na1 == INT32_MAX");
@@ -400,9 +733,9 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
     float* csp = ws + (size_t)num_chunks * Hi * Ho;
     int rc = DN_OK;
     if (num_chunks > 0) {
-        if (Hi == 256) rc = launch_wgrad<256>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
-        else if (Hi == 128) rc = launch_wgrad<128>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
-        else rc = launch_wgrad<64>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, st);
+        if (Hi == 256) rc = launch_wgrad<256>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
+        else if (Hi == 128) rc = launch_wgrad<128>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
+        else rc = launch_wgrad<64>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
@@ -415,8 +748,9 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
 
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos, const int32_t* tiles,
-                          int64_t num_tiles, float* Y, dn_stream_t stream) {
+                          int64_t num_tiles, float* Y, int32_t precision, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform_f32: bad tile count");
+    DN_REQUIRE(precision == 0 || precision == 1, "dn_rows_transform_f32: precision must be 0 (bf16 split) or 1 (exact f32)");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform_f32: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
     if (num_tiles == 0) return DN_OK;
@@ -427,9 +761,9 @@ int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int
                "dn_rows_transform_f32: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
-    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
-    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
-    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, st);
+    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
+    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
+    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
 }
 
 }  // extern "C"

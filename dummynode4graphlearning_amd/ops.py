@@ -144,6 +144,9 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
 import os as _os
 
 WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
+# fp32 matrix products: False = 3-term bf16 split on the fast MFMA path (1e-5-level agreement with exact f32, inside the
+# reference's 1e-4 bar), True = exact f32 MFMA (1/16 of the bf16 rate; the checker).  Settable at run time.
+F32_EXACT = _os.environ.get("DN_F32_EXACT", "0") == "1"
 
 
 def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
@@ -189,7 +192,8 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
         if is_f32:
             check(lib().dn_rows_wgrad_f32(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                           ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out), int(colsum_of), ptr(colsum),
-                                          ptr(mask_a), ptr(a_out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_f32")
+                                          ptr(mask_a), ptr(a_out), 1 if F32_EXACT else 0, ptr(ws), ws.numel(), stream_ptr()),
+                  "dn_rows_wgrad_f32")
         else:
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                            ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
@@ -247,9 +251,14 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
         Y = out[:num_rows]
 
     def _launch():
-        fn = lib().dn_rows_transform_f32 if X.dtype == torch.float32 else lib().dn_rows_transform_bf16
-        check(fn(ptr(X), ptr(X2), X.shape[0] if X2 is not None else INT32_MAX, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias),
-                 1 if relu else 0, ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), stream_ptr()), "dn_rows_transform")
+        n1 = X.shape[0] if X2 is not None else INT32_MAX
+        if X.dtype == torch.float32:
+            check(lib().dn_rows_transform_f32(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
+                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, stream_ptr()),
+                  "dn_rows_transform_f32")
+        else:
+            check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
+                                               ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), stream_ptr()), "dn_rows_transform_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_transform:" + tag, _launch)

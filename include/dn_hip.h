@@ -331,17 +331,21 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
  * out already masked for the ReLU in front of it. */
 int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream);
 
-/* fp32 twins of the three entry points above on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32): same semantics and
- * argument meaning, float tensors, float partials/outputs.  This is the path that keeps the reference's fp32 numerics
- * (outputs within 1e-4) while still avoiding its [E,H,H] per-edge weight gather. */
+/* fp32 twins of the three entry points above: same semantics and argument meaning, float tensors, float partials /
+ * outputs -- the path that keeps the reference's fp32 numerics (outputs within 1e-4) while still avoiding its [E,H,H]
+ * per-edge weight gather.  `precision` selects the arithmetic:
+ *   0  3-term bf16 split on the fast matrix path: operands cut into hi = bf16(x), lo = bf16(x - hi) as they are staged,
+ *      products evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with f32 accumulation (O(2^-16) relative
+ *      per product, 1e-5-level agreement with the reference; 3/16 of the exact path's matrix time);
+ *   1  exact f32 (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain): the checker. */
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos,
-                          const int32_t* tiles, int64_t num_tiles, float* Y, dn_stream_t stream);
+                          const int32_t* tiles, int64_t num_tiles, float* Y, int32_t precision, dn_stream_t stream);
 int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G,
                       const float* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                       const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, float* out,
-                      int32_t colsum_of, float* out_colsum, const float* mask_a, float* a_out, void* workspace,
-                      size_t workspace_bytes, dn_stream_t stream);
+                      int32_t colsum_of, float* out_colsum, const float* mask_a, float* a_out, int32_t precision,
+                      void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, dn_stream_t stream);
 
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func

@@ -728,6 +728,13 @@ def make_si_layers():
         meta.append(dict(tag=tag, kind="rgcn", input_dim=64, seed=1000 + cid, N=500, E=2000, **kw))
         run(tag, rgcn.RGCNLayer, dict(kw), 500, 2000, 64, 1000 + cid)
         cid += 1
+    # the benchmark width (H = 256, config 5's layer) at the reference's own precision: one RGIN and one RGCN case
+    for kind, cls, extra in (("rgin", rgin.RGINLayer, dict(num_mlp_layers=2)), ("rgcn", rgcn.RGCNLayer, dict(edge_norm="both"))):
+        tag = "%s%02d" % (kind, cid)
+        kw = dict(hidden_dim=256, num_rels=4, regularizer="basis", num_bases=-1, self_loop=True, act_func="relu", **extra)
+        meta.append(dict(tag=tag, kind=kind, input_dim=256, seed=1000 + cid, N=160, E=640, **kw))
+        run(tag, cls, dict(kw), 160, 640, 256, 1000 + cid)
+        cid += 1
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "si_layers.npz"), **out)
     print("si_layers.npz: %d cases" % len(meta))

@@ -42,9 +42,25 @@ def _build(m):
     return RGCNLayer(m["input_dim"], m["hidden_dim"], edge_norm=m["edge_norm"], **kw)
 
 
-def test_si_layers_match_reference_goldens(golden_dir):
-    from dummynode4graphlearning_amd import BatchedGraph
+@pytest.mark.parametrize("exact", [False, True])
+def test_si_layers_match_reference_goldens(golden_dir, exact):
+    """48 + 2 reference-run cases (outputs + every gradient) at 1e-4, in both fp32 arithmetic modes of the matrix kernels:
+    the default 3-term bf16 split (fast MFMA path) and the exact-f32 MFMA checker.  Includes the benchmark width H = 256."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops
     z, meta = _cases(golden_dir)
+    assert any(m["hidden_dim"] == 256 for m in meta)
+    worst = 0.0
+    old_mode = ops.F32_EXACT
+    ops.F32_EXACT = exact
+    try:
+        worst = _run_si_goldens(z, meta, BatchedGraph)
+    finally:
+        ops.F32_EXACT = old_mode
+    print("fp32 mode %s: worst rel_max over %d golden cases: %.3e" % ("exact" if exact else "bf16x3 split", len(meta), worst))
+    assert worst < (5e-6 if exact else RTOL)
+
+
+def _run_si_goldens(z, meta, BatchedGraph):
     worst = 0.0
     for m in meta:
         tag = m["tag"]
@@ -67,7 +83,7 @@ def test_si_layers_match_reference_goldens(golden_dir):
         for k, e in errs.items():
             assert e < RTOL, "%s %s rel_max %.3e" % (tag, k, e)
             worst = max(worst, e)
-    print("worst rel_max over %d golden cases: %.3e" % (len(meta), worst))
+    return worst
 
 
 def test_rgin_layer_bf16_close_to_fp32_reference(golden_dir):
