@@ -149,6 +149,24 @@ WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
 F32_EXACT = _os.environ.get("DN_F32_EXACT", "0") == "1"
 
 
+class f32_exact:
+    """Context manager: run the fp32 matrix kernels inside it on the exact-f32 MFMA (True) or on the bf16 split (False)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global F32_EXACT
+        self.old = F32_EXACT
+        F32_EXACT = self.on
+        return self
+
+    def __exit__(self, *exc):
+        global F32_EXACT
+        F32_EXACT = self.old
+        return False
+
+
 def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
     """Split relation-major rows into chunks for dn_rows_wgrad_bf16: (chunks [C,4] int32, chunk_ptr [R+1] int32)."""
     chunk_rows = chunk_rows or WGRAD_CHUNK_ROWS
@@ -1222,17 +1240,24 @@ class _LinearActFn(torch.autograd.Function):
     dn_rows_transform_bf16 / dn_rows_wgrad_bf16, bias and ReLU fused in the forward epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, exact=None):
         x = x.contiguous()
         tiles, _ = _dense_table(x.shape[0], x.device)
-        y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
-                           bias=None if bias is None else bias.contiguous().view(1, -1), relu=relu)
+        ctx.exact = F32_EXACT if exact is None else bool(exact)
+        with f32_exact(ctx.exact):
+            y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
+                               bias=None if bias is None else bias.contiguous().view(1, -1), relu=relu)
         ctx.relu, ctx.has_bias = bool(relu), bias is not None
         ctx.save_for_backward(x, weight, y if relu else x.new_empty(0))
         return y
 
     @staticmethod
     def backward(ctx, g):
+        with f32_exact(ctx.exact):
+            return _LinearActFn._backward(ctx, g) + (None,)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         g = g.contiguous()
         tiles, chunks = _dense_table(x.shape[0], x.device)
@@ -1348,11 +1373,12 @@ def relu_mlp(x, linears):
     return _ReluMlpFn.apply(x, *args)
 
 
-def linear_act(x, weight, bias=None, relu=False):
-    """nn.Linear (+ ReLU) on the MFMA kernels when supported (bf16, square 64/128/256), else torch."""
+def linear_act(x, weight, bias=None, relu=False, exact=None):
+    """nn.Linear (+ ReLU) on the MFMA kernels when supported (bf16 / fp32, square 64/128/256), else torch.  exact: force the
+    exact-f32 MFMA (True) or the bf16 split (False) for fp32 operands; None = the module default (ops.F32_EXACT)."""
     if (x.is_cuda and x.dtype == weight.dtype and x.dtype in MFMA_DTYPES and x.dim() == 2
             and weight.shape[0] == weight.shape[1] and weight.shape[0] in (64, 128, 256) and x.shape[1] == weight.shape[1]
             and x.shape[0] > 0):
-        return _LinearActFn.apply(x, weight, bias, relu)
+        return _LinearActFn.apply(x, weight, bias, relu, exact)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y

@@ -42,7 +42,8 @@ def _edge_index(g):
 
 def _dense(x, w):
     """x @ w with w [in, out]: matrix-core Linear when the width allows it, else rocBLAS."""
-    return ops.linear_act(x, w.t()) if w.shape[0] == w.shape[1] else th.matmul(x, w)
+    # exact fp32 products here: these layers chain several products through norms and compositions, and are tiny
+    return ops.linear_act(x, w.t(), exact=True) if w.shape[0] == w.shape[1] else th.matmul(x, w)
 
 
 def _degrees(g, ix):
@@ -216,7 +217,7 @@ class DMPLayer(nn.Module):
         if len(seq) == 0:
             return self.act(h)
         for m in seq:
-            h = ops.linear_act(h, m.weight, m.bias) if isinstance(m, nn.Linear) else m(h)
+            h = ops.linear_act(h, m.weight, m.bias, exact=True) if isinstance(m, nn.Linear) else m(h)
         return h
 
     def forward(self, graph, node_feat, edge_feat):
