@@ -84,9 +84,19 @@ def test_config1_gin_training_trajectory_matches_oracle():
             torch.testing.assert_close(q.detach().cpu(), p[k].detach(), rtol=5e-3, atol=5e-4, msg=k)
 
 
-def test_config3_rgin_stack_training_step_matches_oracle():
-    """Config 3 (512 graphs x 50 nodes, E = 102,400, R = 8, H = 64, fp32, 3 RGIN layers, residual): three AdamW steps."""
-    from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
+@pytest.mark.parametrize("exact", [True, False])
+def test_config3_rgin_stack_training_step_matches_oracle(exact):
+    """Config 3 (512 graphs x 50 nodes, E = 102,400, R = 8, H = 64, fp32, 3 RGIN layers, residual): three AdamW steps, in
+    both fp32 arithmetic modes.  Exact f32: the trajectory follows the oracle to fp32 rounding.  3-term bf16 split (the
+    default): every product is good to ~1e-5, but among the 5 M ReLU inputs of a step a few dozen sit closer to 0 than that and
+    switch their gradient path, and AdamW rescales even tiny gradient differences -- so the loss is held to 5e-4 and the
+    parameters to 5e-3 in relative L2 after three steps."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    with ops.f32_exact(exact):
+        _config3_trajectory(exact, BatchedGraph, synthetic, transforms)
+
+
+def _config3_trajectory(exact, BatchedGraph, synthetic, transforms):
     from dummynode4graphlearning_amd.subgraph_isomorphism import RGINRepNet
     raw = synthetic.config3()
     keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
@@ -118,9 +128,15 @@ def test_config3_rgin_stack_training_step_matches_oracle():
         lr_ = F.mse_loss(cur, tgt)
         lr_.backward()
         opt_ref.step()
-        assert abs(loss.item() - lr_.item()) / lr_.item() < 1e-4
+        assert abs(loss.item() - lr_.item()) / lr_.item() < (1e-4 if exact else 5e-4)
     for (k, p), (_, q) in zip(net.state_dict().items(), ref.state_dict().items()):
-        torch.testing.assert_close(p.cpu(), q, rtol=2e-3, atol=2e-5, msg=k)
+        if exact:
+            torch.testing.assert_close(p.cpu(), q, rtol=2e-3, atol=2e-5, msg=k)
+        else:
+            # AdamW turns every gradient element into a step of ~lr whatever its size, so an element whose gradient is below
+            # the split's 1e-5 noise floor may walk the other way (2 * lr * steps apart): compare tensors in relative L2
+            err = float((p.cpu().double() - q.double()).norm() / q.double().norm().clamp(min=1e-12))
+            assert err < 5e-3, (k, err)
 
 
 def test_conjugate_batch_feeds_the_layers_like_the_reference_pipeline():
