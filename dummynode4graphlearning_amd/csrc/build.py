@@ -37,7 +37,12 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
+    """tuning=True (or DN_BUILD_TUNING=1): compile with -DDN_TUNING_ENV so the DN_* experiment knobs of dn_rel.hip are read
+    from the environment (tools/ab.sh); the default build has no environment access at all."""
+    global FLAGS
+    if (tuning or os.environ.get("DN_BUILD_TUNING") == "1") and "-DDN_TUNING_ENV" not in FLAGS:
+        FLAGS = FLAGS + ["-DDN_TUNING_ENV"]
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     os.makedirs(OBJDIR, exist_ok=True)
@@ -74,5 +79,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)
     print(LIB)

@@ -15,6 +15,18 @@
 
 namespace {
 
+// Experiment knobs.  The shipped library has NO environment access and no mutable global state (dn_hip.h): every knob is the
+// compile-time default below (the measured best).  A tuning build (-DDN_TUNING_ENV, `python -m
+// dummynode4graphlearning_amd.csrc.build --tuning`, used by tools/ab.sh) reads the DN_* variables once per process instead.
+#ifdef DN_TUNING_ENV
+static int dn_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static constexpr int dn_knob(const char*, int dflt) { return dflt; }
+#endif
+
 typedef __bf16 bf16_t;
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
@@ -686,7 +698,7 @@ constexpr int kSsSlots = 6;
 
 // DN_STRIDE (default 1): dense-row launches deal tiles round-robin over the workgroups instead of contiguous ranges
 static bool stride_tiles() {
-    static const bool on = [] { const char* e = getenv("DN_STRIDE"); return !(e && e[0] == '0'); }();
+    static const bool on = dn_knob("DN_STRIDE", 1) != 0;
     return on;
 }
 
@@ -827,7 +839,7 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
+    static const int nt = dn_knob("DN_NT", 3);
     hipLaunchKernelGGL((rows_selfsum_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
                        (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), out, (nt >> 1) & 1);
     DN_CHECK_LAUNCH();
@@ -1004,17 +1016,11 @@ int launch_chain2(const bf16_t* X, const bf16_t* W1n, const bf16_t* b1, const bf
 }
 
 static int tf_depth() {
-    static int d = -1;
-    if (d < 0) {
-        const char* e = getenv("DN_TF_DEPTH");
-        d = e ? atoi(e) : 1;
-        if (d != 1 && d != 2 && d != 3 && d != 4) d = 1;
-    }
+    static const int d = [] { const int v = dn_knob("DN_TF_DEPTH", 1); return (v >= 1 && v <= 4) ? v : 1; }();
     return d;
 }
 static int tf_wg_per_cu() {
-    static int d = -1;
-    if (d < 0) { const char* e = getenv("DN_TF_WGS"); d = e ? atoi(e) : 0; }
+    static const int d = dn_knob("DN_TF_WGS", 0);
     return d;
 }
 
@@ -1025,7 +1031,7 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     const int depth = tf_depth();
     // streaming (non-temporal) stores of the output rows: they are re-read only after ~1 GB of other traffic, so keeping
     // them out of L2 / Infinity Cache is worth 1.5-2 % of the step (DN_NT=0 turns it off: bit 0 transform, bit 1 selfsum)
-    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
+    static const int nt = dn_knob("DN_NT", 3);
     relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0);
     // workgroups per CU: a tile is 32 rows x 2*HI bytes, so narrower rows need more workgroups in flight to keep the same
     // bytes per CU outstanding (H = 128: 64 VGPRs, 26 KB LDS -> 4 fit; measured 2.24 -> 2.07 ms per step at H = 128)
@@ -1089,10 +1095,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // its 128 accumulator VGPRs), 2 = at H = 128 too (there the register-staged kernel fits two workgroups per CU and is
 // ~3 % faster than the ring: 1.95 vs 2.01 ms per step)
 int wgrad_dma_mode() {
-    static const int mode = [] {
-        const char* e = getenv("DN_WGRAD_DMA");
-        return e ? atoi(e) : 1;
-    }();
+    static const int mode = dn_knob("DN_WGRAD_DMA", 1);
     return mode;
 }
 
@@ -1255,7 +1258,7 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1n) | reinterpret_cast<uintptr_t>(W2n) |
                 reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
                "dn_rows_chain2: unaligned pointer");
-    static const int nt = [] { const char* e = getenv("DN_NT"); return e ? atoi(e) : 3; }();
+    static const int nt = dn_knob("DN_NT", 3);
     const int32_t flags = (relu1 ? 1 : 0) | (relu2 ? 2 : 0) | ((nt & 1) ? 4 : 0);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w1 = (const bf16_t*)W1n, *w2 = (const bf16_t*)W2n, *bb1 = (const bf16_t*)b1,

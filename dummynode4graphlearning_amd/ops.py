@@ -458,6 +458,19 @@ def gather_rows_i32(values, perm):
     return values.index_select(0, perm.long()) if values.numel() else values.clone()
 
 
+def _check_edge_types(etype, num_rels):
+    """Edge types outside [0, num_rels) would index past the mode table / alias another relation's sort key inside the
+    index builds (the reference raises IndexError from weight.index_select(0, etype), rgin.py:109): fail loudly instead.
+    One fused reduction + a single scalar read-back per index build."""
+    if etype.numel() == 0:
+        return
+    lo, hi = torch.aminmax(etype)
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= int(num_rels):
+        raise _lib.DnHipError("edge type out of [0, %d): min %d, max %d (with dummy edges the relation count grows by the "
+                              "dummy labels, e.g. max_ngel + 2 in the SI flow)" % (int(num_rels), lo, hi))
+
+
 class RelIndex:
     """(rel, dst)-segment index for aggregate-then-transform RGCN/RGIN (dn_rel_index_build_i32)."""
 
@@ -466,6 +479,7 @@ class RelIndex:
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
         self.num_nodes, self.num_rels, self.num_edges = N, R, E
+        _check_edge_types(etype, R)
         src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))
         e32 = lambda n: torch.empty(max(n, 1), dtype=I32, device=dev)  # noqa: E731
         self.perm1, self.src1, seg_ptr, seg_dst = e32(E), e32(E), e32(E + 1), e32(E)
@@ -749,6 +763,7 @@ class RowIndex:
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
         self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
+        _check_edge_types(etype, R)
         src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))
         e32 = lambda n: torch.empty(max(int(n), 1), dtype=I32, device=dev)  # noqa: E731
         row_in, row_out = e32(E + N), e32(E + N)

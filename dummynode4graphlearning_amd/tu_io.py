@@ -51,6 +51,22 @@ def _column(path, dtype):
     return np.array(txt.replace(",", " ").split(), dtype=dtype)
 
 
+def _single_column(path, dtype):
+    """One value per line, as the reference parses labels and attributes (int(line.strip()) / float(line.strip()),
+    tu_data_processing.py:140-152): a line with several columns (ENZYMES-style multi-dimensional attributes) or a blank line
+    raises ValueError there, and does here -- it must not be flattened into a longer 1-D array."""
+    conv = int if np.issubdtype(dtype, np.integer) else float
+    out = []
+    with open(path) as f:
+        for ln, line in enumerate(f, 1):
+            try:
+                out.append(conv(line.strip()))
+            except ValueError:
+                raise ValueError("%s:%d: %r is not a single %s (the reference pipeline reads one value per line; "
+                                 "multi-column attribute files are not supported)" % (path, ln, line.strip(), conv.__name__))
+    return np.array(out, dtype=dtype)
+
+
 def load_graph_labels_from_TUDatadir(data_dir):
     out = []
     for fn in sorted(os.listdir(data_dir)):
@@ -69,7 +85,8 @@ def read_raw(data_dir):
     for fn in sorted(os.listdir(data_dir)):
         for k, dt in kinds.items():
             if fn.endswith("_" + k + ".txt"):
-                parts[k].append(_column(os.path.join(data_dir, fn), dt))
+                path = os.path.join(data_dir, fn)
+                parts[k].append(_column(path, dt) if k == "A" else _single_column(path, dt))
     raw = {k: (np.concatenate(v) if v else np.zeros(0, dtype=kinds[k])) for k, v in parts.items()}
     raw["A"] = raw["A"].reshape(-1, 2)
     return raw

@@ -14,7 +14,9 @@
  *     allocates, frees or retains a pointer.  Workspace sizes come from *_workspace_bytes().
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing else orders it.
  *   - return 0 on success, <0 on error (DN_ERR_*); dn_last_error() gives the thread-local message.
- *   - re-entrant, no global mutable state, deterministic: no floating-point atomics anywhere,
+ *   - re-entrant, no global mutable state, no environment access of its own (the experiment knobs of the kernels are
+ *     compile-time constants; only a -DDN_TUNING_ENV build reads DN_* variables.  rocPRIM, which the index builds call,
+ *     consults the environment for its own target selection), deterministic: no floating-point atomics anywhere,
  *     every sum has a fixed order (bitwise reproducible run to run).
  *   - node / edge ids are int32 on the device (N, E < 2^31); the Python boundary converts the
  *     reference's int64 ids.

@@ -424,3 +424,18 @@ def test_rows_wgrad_with_bit_mask_and_chain2(H):
     assert float((g1.cpu().double() - rg1).abs().max() / rg1.abs().max()) < 6e-3
     rg0 = g1.cpu().double() @ W1.double()
     assert float((g0.cpu().double() - rg0).abs().max() / rg0.abs().max()) < 6e-3
+
+
+def test_index_builds_reject_out_of_range_edge_types():
+    """an edge type >= num_rels (easy to hit in the SI flow: the dummy labels extend the relation set) must raise,
+    not be silently grouped into another relation."""
+    ops = _ops()
+    from dummynode4graphlearning_amd._lib import DnHipError
+    src = torch.tensor([0, 1, 2], device=DEV)
+    dst = torch.tensor([1, 2, 0], device=DEV)
+    for bad in (torch.tensor([0, 3, 1], device=DEV), torch.tensor([0, -1, 1], device=DEV)):
+        with pytest.raises(DnHipError, match="edge type out of"):
+            ops.RowIndex(src, dst, bad, 3, 3)
+        with pytest.raises(DnHipError, match="edge type out of"):
+            ops.RelIndex(src, dst, bad, 3, 3)
+    ops.RowIndex(src, dst, torch.tensor([0, 2, 1], device=DEV), 3, 3)
