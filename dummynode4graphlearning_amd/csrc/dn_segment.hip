@@ -63,40 +63,69 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec_kernel(
     const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
     const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, const T* __restrict__ self_in,
     float self_coef, int32_t mean, int64_t nchunks) {
+    // A lane group walks its segments one after the other; what it needs for a segment is a chain of three dependent loads
+    // (ptr -> idx -> rows), each an L2 / HBM round trip.  The chain is software-pipelined ACROSS segments: while the rows of
+    // segment i are in flight, the first LPR indices (and scales) of segment i+1 and the bounds of segment i+2 are too, and
+    // the rows themselves go 8 at a time.  (Graph-local gathers are L2-latency-bound, not HBM-bound: DESIGN.md 4.)
     constexpr int VN = Vec<T>::N;
     constexpr int GPB = kBlock / LPR;
+    constexpr int KU = 8;                                     // row loads in flight per lane
     const int lane = threadIdx.x % LPR;
     const int group = threadIdx.x / LPR;
     const int64_t chunk = dn_xcd_chunk(blockIdx.x, gridDim.x);
     if (chunk >= nchunks) return;
     const int64_t seg0 = chunk * (GPB * kSegsPerGroup);
+    // interleave groups over the chunk so that a wave's groups touch neighbouring segments
+    auto seg_of = [&](int it) -> int64_t { return seg0 + (int64_t)it * GPB + group; };
+    auto bounds = [&](int it, int& beg, int& end) {
+        const int64_t s = seg_of(it);
+        beg = end = 0;
+        if (it < kSegsPerGroup && s < S) {
+            if (ptr != nullptr) { beg = ptr[s]; end = ptr[s + 1]; } else { beg = (int)s; end = (int)s + 1; }
+        }
+    };
+    auto first_idx = [&](int beg, int end, int& my, float& mysc) {
+        my = 0;
+        mysc = 1.f;
+        if (lane < end - beg) {
+            my = idx != nullptr ? idx[beg + lane] : beg + lane;
+            if (HAS_SCALE) mysc = scale[beg + lane];
+        }
+    };
 
     for (int col0 = 0; col0 < H; col0 += LPR * VN) {
         const int col = col0 + lane * VN;
         const bool colok = col < H;
+        int beg, end, beg1, end1, my, my1;
+        float mysc, mysc1;
+        bounds(0, beg, end);
+        bounds(1, beg1, end1);
+        first_idx(beg, end, my, mysc);
 #pragma unroll 1
         for (int it = 0; it < kSegsPerGroup; ++it) {
-            // interleave groups over the chunk so that a wave's groups touch neighbouring segments
-            const int64_t s = seg0 + (int64_t)it * GPB + group;
+            const int64_t s = seg_of(it);
             if (s >= S) break;
-            int beg, end;
-            if (ptr != nullptr) { beg = ptr[s]; end = ptr[s + 1]; } else { beg = (int)s; end = (int)s + 1; }
+            int beg2, end2;
+            first_idx(beg1, end1, my1, mysc1);                // segment it+1's indices: in flight under this segment's rows
+            bounds(it + 2, beg2, end2);
             float acc[VN];
 #pragma unroll
             for (int i = 0; i < VN; ++i) acc[i] = 0.f;
             for (int base = beg; base < end; base += LPR) {
                 const int n = min(LPR, end - base);
-                int my = 0;
-                float mysc = 1.f;
-                if (lane < n) {
-                    my = idx != nullptr ? idx[base + lane] : base + lane;
-                    if (HAS_SCALE) mysc = scale[base + lane];
+                if (base != beg) {                            // a segment longer than LPR entries (a hub): fetch as we go
+                    my = 0;
+                    mysc = 1.f;
+                    if (lane < n) {
+                        my = idx != nullptr ? idx[base + lane] : base + lane;
+                        if (HAS_SCALE) mysc = scale[base + lane];
+                    }
                 }
-                for (int j = 0; j < n; j += 4) {
-                    float v[4][VN];
-                    float w[4];
+                for (int j = 0; j < n; j += KU) {
+                    float v[KU][VN];
+                    float w[KU];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < KU; ++k) {
                         const int jj = (j + k) & (LPR - 1);
                         const int r = __shfl(my, jj, LPR);
                         w[k] = HAS_SCALE ? __shfl(mysc, jj, LPR) : 1.f;
@@ -109,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec_kernel(
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < KU; ++k) {
 #pragma unroll
                         for (int i = 0; i < VN; ++i) {
                             if (HAS_SCALE) acc[i] = fmaf(w[k], v[k][i], acc[i]);
@@ -132,8 +161,150 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec_kernel(
                 }
                 Vec<T>::store(out + (size_t)s * H + col, acc);
             }
+            beg = beg1; end = end1; my = my1; mysc = mysc1;
+            beg1 = beg2; end1 = end2;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiled variant for GRAPH-LOCAL gathers (segment s <-> input row s, neighbours mostly a few rows away: the GIN / GCN / SAGE
+// aggregation over a batch of small graphs, gconv.py:212).  A workgroup owns TN consecutive segments and first stages input
+// rows [tile_begin, tile_end) in LDS (coalesced, each row read from HBM once); a gathered row inside that window then comes
+// from LDS, the rest (edges that leave the window, a graph cut by the tile border) from global memory as before.  The
+// untiled kernel re-reads every gathered row through L2 (E*H*s bytes of L2 traffic against N*H*s compulsory bytes) and is
+// L2-latency-bound; here the L2 carries only the compulsory stream.  Same summation order as the untiled kernel (bitwise
+// identical results).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileIdxCap = 1536;   // index entries of a tile staged in LDS (the rest is read from global)
+
+template <typename T, int LPR, bool HAS_SCALE>
+__global__ __launch_bounds__(kBlock) void gather_segsum_tiled_kernel(
+    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+    const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, float self_coef, int32_t TN,
+    int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // LDS: [TN rows of the window][TN + 1 segment bounds][kTileIdxCap indices][kTileIdxCap scales]
+    T* win = reinterpret_cast<T*>(smem_raw);
+    int32_t* ptrL = reinterpret_cast<int32_t*>(smem_raw + (size_t)TN * H * sizeof(T));
+    int32_t* idxL = ptrL + (TN + 1 + 3) / 4 * 4;
+    float* scL = reinterpret_cast<float*>(idxL + kTileIdxCap);
+    constexpr int VN = Vec<T>::N;
+    constexpr int GPB = kBlock / LPR;
+    constexpr int KU = 8;
+    const int lane = threadIdx.x % LPR;
+    const int group = threadIdx.x / LPR;
+    const int64_t tile = dn_xcd_chunk(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int a = (int)(tile * TN), b = (int)min((int64_t)a + TN, S);
+    const int pieces_per_row = H / VN;
+    // phase 1: everything the tile needs arrives in one burst of independent, coalesced loads -- the window rows, the segment
+    // bounds and the first kTileIdxCap indices (+ scales): phase 2 then runs out of LDS, without a dependent global load
+    const int e0 = ptr[a], e1 = ptr[b];
+    for (int i = threadIdx.x; i <= b - a; i += kBlock) ptrL[i] = ptr[a + i];
+    for (int i = threadIdx.x; i < min(e1 - e0, kTileIdxCap); i += kBlock) {
+        idxL[i] = idx[e0 + i];
+        if (HAS_SCALE) scL[i] = scale[e0 + i];
+    }
+    for (int i = threadIdx.x; i < (b - a) * pieces_per_row; i += kBlock) {
+        const int r = i / pieces_per_row, c = i % pieces_per_row;
+        *reinterpret_cast<uint4*>(win + (size_t)r * H + c * VN) = *reinterpret_cast<const uint4*>(in + (size_t)(a + r) * H + c * VN);
+    }
+    __syncthreads();
+    const int col = lane * VN;
+    const bool colok = col < H;
+#pragma unroll 1
+    for (int s = a + group; s < b; s += GPB) {
+        const int beg = ptrL[s - a], end = ptrL[s - a + 1];
+        float acc[VN];
+#pragma unroll
+        for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+        for (int base = beg; base < end; base += LPR) {
+            const int n = min(LPR, end - base);
+            int my = 0;
+            float mysc = 1.f;
+            if (lane < n) {
+                const int e = base + lane - e0;
+                my = e < kTileIdxCap ? idxL[e] : idx[base + lane];
+                if (HAS_SCALE) mysc = e < kTileIdxCap ? scL[e] : scale[base + lane];
+            }
+            for (int j = 0; j < n; j += KU) {
+                float v[KU][VN];
+                float w[KU];
+#pragma unroll
+                for (int k = 0; k < KU; ++k) {
+                    const int jj = (j + k) & (LPR - 1);
+                    const int r = __shfl(my, jj, LPR);
+                    w[k] = HAS_SCALE ? __shfl(mysc, jj, LPR) : 1.f;
+                    if (j + k < n && colok) {
+                        if (r >= a && r < b) Vec<T>::load(win + (size_t)(r - a) * H + col, v[k]);      // LDS
+                        else Vec<T>::load(in + (size_t)r * H + col, v[k]);                            // left the window
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) v[k][i] = 0.f;
+                        w[k] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KU; ++k) {
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) {
+                        if (HAS_SCALE) acc[i] = fmaf(w[k], v[k][i], acc[i]);
+                        else acc[i] += v[k][i];
+                    }
+                }
+            }
+        }
+        if (colok) {
+            if (self_coef != 0.f) {
+                float sv[VN];
+                Vec<T>::load(win + (size_t)(s - a) * H + col, sv);
+#pragma unroll
+                for (int i = 0; i < VN; ++i) acc[i] = fmaf(self_coef, sv[i], acc[i]);
+            }
+            Vec<T>::store(out + (size_t)s * H + col, acc);
+        }
+    }
+}
+
+template <typename T, int LPR>
+int launch_tiled(const T* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S, T* out,
+                 float self_coef, hipStream_t st) {
+    // window rows per tile: <= 32 KB of LDS (+ ~13 KB of staged indices: three workgroups per CU), a multiple of the groups
+    constexpr int GPB = kBlock / LPR;
+    int TN = (int)((32 * 1024) / ((size_t)H * sizeof(T)));
+    TN = TN / GPB * GPB;
+    if (TN > 256) TN = 256;
+    if (TN < GPB) { dn_set_error("dn_gather_segsum_tiled: rows too wide for an LDS window"); return DN_ERR_UNSUPPORTED; }
+    const int64_t ntiles = dn_cdiv(S, TN);
+    const int64_t grid = dn_cdiv(ntiles, DN_NUM_XCD) * DN_NUM_XCD;
+    const size_t lds = (size_t)TN * H * sizeof(T) + (size_t)((TN + 1 + 3) / 4 * 4 + 2 * kTileIdxCap) * 4;
+    if (scale != nullptr)
+        hipLaunchKernelGGL((gather_segsum_tiled_kernel<T, LPR, true>), dim3((unsigned)grid), dim3(kBlock), lds, st, in, idx, scale,
+                           ptr, S, H, out, self_coef, TN, ntiles);
+    else
+        hipLaunchKernelGGL((gather_segsum_tiled_kernel<T, LPR, false>), dim3((unsigned)grid), dim3(kBlock), lds, st, in, idx,
+                           scale, ptr, S, H, out, self_coef, TN, ntiles);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+template <typename T>
+int gather_segsum_tiled(const T* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S, T* out,
+                        float self_coef, hipStream_t st) {
+    constexpr int VN = Vec<T>::N;
+    DN_REQUIRE(H > 0 && H % VN == 0, "dn_gather_segsum_tiled: H must be a positive multiple of %d", VN);
+    DN_REQUIRE(S >= 0 && S < 0x7fffffffLL, "dn_gather_segsum_tiled: bad segment count");
+    if (S == 0) return DN_OK;
+    DN_REQUIRE(in && idx && ptr && out, "dn_gather_segsum_tiled: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0, "dn_gather_segsum_tiled: unaligned pointer");
+    const int pieces = H / VN;
+    DN_REQUIRE(pieces <= 64, "dn_gather_segsum_tiled: rows wider than 1 KiB are not supported (use dn_gather_segsum_*)");
+    if (pieces <= 4) return launch_tiled<T, 4>(in, H, idx, scale, ptr, S, out, self_coef, st);
+    if (pieces <= 8) return launch_tiled<T, 8>(in, H, idx, scale, ptr, S, out, self_coef, st);
+    if (pieces <= 16) return launch_tiled<T, 16>(in, H, idx, scale, ptr, S, out, self_coef, st);
+    if (pieces <= 32) return launch_tiled<T, 32>(in, H, idx, scale, ptr, S, out, self_coef, st);
+    return launch_tiled<T, 64>(in, H, idx, scale, ptr, S, out, self_coef, st);
 }
 
 // Scalar path: any H (one element per lane per pass); used for narrow / unaligned rows
@@ -402,6 +573,15 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                           int32_t mean, dn_stream_t stream) {
     return gather_segsum<bf16_t>((const bf16_t*)in, in_rows, H, idx, scale, ptr, S, M, (bf16_t*)out,
                                  (const bf16_t*)self_in, self_coef, mean, (hipStream_t)stream);
+}
+
+int dn_gather_segsum_tiled_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
+                               float* out, float self_coef, dn_stream_t stream) {
+    return gather_segsum_tiled<float>(in, H, idx, scale, ptr, S, out, self_coef, (hipStream_t)stream);
+}
+int dn_gather_segsum_tiled_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
+                                void* out, float self_coef, dn_stream_t stream) {
+    return gather_segsum_tiled<bf16_t>((const bf16_t*)in, H, idx, scale, ptr, S, (bf16_t*)out, self_coef, (hipStream_t)stream);
 }
 
 static int64_t dn_rows_unknown() { return 0x7ffffffeLL; }

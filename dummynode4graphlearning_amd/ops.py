@@ -4,6 +4,7 @@ Everything here runs on the GPU through libdn_hip.so; PyTorch only supplies devi
 current stream and autograd bookkeeping.  There is deliberately no CPU path.
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -104,6 +105,38 @@ def gather_segsum(x, idx=None, ptr_=None, num_segments=None, scale=None, self_in
     return out
 
 
+# LDS-window variant of the graph-local gather (dn_gather_segsum_tiled_*): bitwise equal to the plain kernel, but measured
+# SLOWER on the PROTEINS-shaped benchmark batch (0.72 vs 0.49 ms fwd+bwd): fixed 64-row windows catch only part of a graph's
+# edges, the 40-64-entry dummy lists serialise inside a workgroup, and three 45 KB workgroups per CU hide less latency than
+# eight small ones.  Opt in with DN_TILED_GATHER=1.
+TILED_GATHER = _os.environ.get("DN_TILED_GATHER", "0") == "1"
+
+
+def gather_segsum_tiled(x, idx, ptr_, scale=None, self_coef=0.0):
+    """out[s] = self_coef*x[s] + sum_i scale[i]*x[idx[i]] with an LDS window of consecutive rows per workgroup
+    (dn_gather_segsum_tiled_*): for graph-local gathers where segment s <-> row s."""
+    require_gpu(x, idx, ptr_, scale)
+    _i32(idx, "idx"), _i32(ptr_, "ptr")
+    S, H = x.shape
+    assert ptr_.numel() == S + 1
+    out = torch.empty_like(x)
+    fn = getattr(lib(), "dn_gather_segsum_tiled_" + _suffix(x))
+
+    def _launch():
+        check(fn(ptr(x), H, ptr(idx), ptr(scale), ptr(ptr_), S, ptr(out), float(self_coef), stream_ptr()), "dn_gather_segsum_tiled")
+    if kernel_timer is not None:
+        kernel_timer.launch("gather_segsum_tiled", _launch)
+    else:
+        _launch()
+    return out
+
+
+def _tiled_ok(x, num_segments, self_in):
+    vn = 4 if x.dtype == torch.float32 else 8
+    return (TILED_GATHER and x.shape[0] == num_segments and (self_in is None or self_in is x) and x.shape[1] % vn == 0
+            and x.shape[1] * x.element_size() <= 1024 and x.data_ptr() % 16 == 0)
+
+
 def csr_build(key, num_keys):
     """Stable grouping by integer key: returns (ptr [num_keys+1], perm [M]) int32  (dn_csr_build_i32)."""
     require_gpu(key)
@@ -140,8 +173,6 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
                                  ptr(out_deg), ptr(in_norm), ptr(out_norm), ptr(en), stream_ptr()), "dn_edge_norm_f32")
     return in_norm.view(-1, 1), (out_norm.view(-1, 1) if out_norm is not None else None), en
 
-
-import os as _os
 
 WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
 # fp32 matrix products: False = 3-term bf16 split on the fast MFMA path (1e-5-level agreement with exact f32, inside the
@@ -412,13 +443,19 @@ class _SplitCSR:
         self.hub_ids = hub_ids
 
     def segsum(self, x, scale=None, self_in=None, self_coef=0.0):
+        tiled = _tiled_ok(x, self.num_segments, self_in)      # graph-local gather: LDS window per workgroup
         if self.hub_ids is None:
+            if tiled:
+                return gather_segsum_tiled(x, self.idx, self.ptr, scale=scale, self_coef=self_coef if self_in is not None else 0.0)
             return gather_segsum(x, self.idx, self.ptr, self.num_segments, scale=scale, self_in=self_in, self_coef=self_coef)
         sc_main = sc_hub = None
         if scale is not None:
             sc_main, sc_hub = scale[self.keep].contiguous(), scale[~self.keep].contiguous()
-        out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
-                            self_coef=self_coef)
+        if tiled:
+            out = gather_segsum_tiled(x, self.idx_main, self.ptr_main, scale=sc_main, self_coef=self_coef if self_in is not None else 0.0)
+        else:
+            out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
+                                self_coef=self_coef)
         part = gather_segsum(x, self.idx_hub, self.chunk_ptr, self.chunk_ptr.numel() - 1, scale=sc_hub)
         hub = gather_segsum(part, None, self.fold_ptr)                        # per-hub sum of its chunk partials
         out.index_add_(0, self.hub_ids, hub)                                  # distinct rows: order-independent

@@ -65,6 +65,17 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                           const float* scale, const int32_t* ptr, int64_t S, int64_t M, void* out,
                           const void* self_in, float self_coef, int32_t mean, dn_stream_t stream);
 
+/* Tiled variant for graph-local gathers: segment s corresponds to input row s (S rows) and most of its neighbours lie a few
+ * rows away -- the GIN / GCN / SAGE aggregation over a batch of small graphs (gconv.py:212, PyG propagate).
+ *   out[s,:] = self_coef * in[s,:] + sum_{i in [ptr[s], ptr[s+1])} scale[i] * in[idx[i],:]
+ * A workgroup stages a window of consecutive input rows in LDS (each row read from HBM once) and serves the gathered rows
+ * that fall inside the window from LDS; rows outside come from global memory, so the result never depends on locality
+ * (bitwise equal to dn_gather_segsum_* with self_in = in).  idx and ptr are required; H * sizeof(T) <= 1 KiB. */
+int dn_gather_segsum_tiled_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
+                               float* out, float self_coef, dn_stream_t stream);
+int dn_gather_segsum_tiled_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
+                                void* out, float self_coef, dn_stream_t stream);
+
 /* Per-graph readouts over CONTIGUOUS rows: out[g,:] = reduce_{v in [ptr[g], ptr[g+1])} in[v,:].
  * Replaces: torch_geometric global_add_pool / global_mean_pool / global_max_pool
  *   (gconv.py:53,95,148,210,213; rgconv.py:42,119,124) and SI SumPredictNet's sum over the padded

@@ -439,3 +439,28 @@ def test_index_builds_reject_out_of_range_edge_types():
         with pytest.raises(DnHipError, match="edge type out of"):
             ops.RelIndex(src, dst, bad, 3, 3)
     ops.RowIndex(src, dst, torch.tensor([0, 2, 1], device=DEV), 3, 3)
+
+
+@pytest.mark.parametrize("dt,H", [(torch.float32, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float32, 256)])
+def test_tiled_gather_is_bitwise_equal_to_the_untiled_kernel(dt, H):
+    """dn_gather_segsum_tiled_* (LDS window of consecutive rows) against dn_gather_segsum_*: graph-local edges, edges that
+    leave the window, empty segments, a per-edge scale, the self term -- identical bits (same summation order)."""
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    N = 5000
+    deg = rng.integers(0, 9, size=N)
+    deg[::97] = 70                                           # a few long lists (more than one index round)
+    ptr_ = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    E = int(ptr_[-1])
+    seg = np.repeat(np.arange(N), deg)
+    near = np.clip(seg + rng.integers(-40, 41, size=E), 0, N - 1)
+    far = rng.integers(0, N, size=E)
+    idx = np.where(rng.random(E) < 0.85, near, far).astype(np.int32)
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dt).to(DEV)
+    sc = torch.from_numpy(rng.random(E).astype(np.float32)).to(DEV)
+    p_d, i_d = torch.from_numpy(ptr_).to(DEV), torch.from_numpy(idx).to(DEV)
+    for scale in (None, sc):
+        for coef in (0.0, 1.3):
+            a = ops.gather_segsum_tiled(x, i_d, p_d, scale=scale, self_coef=coef)
+            b = ops.gather_segsum(x, i_d, p_d, N, scale=scale, self_in=x if coef else None, self_coef=coef)
+            assert torch.equal(a, b)
