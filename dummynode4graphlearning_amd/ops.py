@@ -538,7 +538,12 @@ class RelIndex:
         self.rel_ptr_host = [int(v) for v in host_rel]
         self.perm1, self.src1 = self.perm1[:E], self.src1[:E]
         self.operm, self.seg_by_src = self.operm[:E], self.seg_by_src[:E]
-        self.chunk_table = make_row_chunks(self.rel_ptr_host, dev)
+        # chunk / tile tables on the device: split-K chunks of the matrix-core weight gradient, and the tables of the any-width
+        # grouped products (dn_rows_gemm_* / dn_rows_wgrad_any_*)
+        rel_ptr_d = torch.tensor(self.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
+        self.chunk_table = build_row_tables(rel_ptr_d, R, P, WGRAD_CHUNK_ROWS, want_ptr=True)
+        self.gemm_tiles = build_row_tables(rel_ptr_d, R, P, 64)
+        self.gemm_chunks = build_row_tables(rel_ptr_d, R, P, 1024, want_ptr=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -667,20 +672,44 @@ def neighbor_max(x, index):
     return _NeighborMax.apply(x, index)
 
 
-def _grouped_mm(A, W, rel_ptr_host, transpose_w=False):
-    """Y[rows of relation r] = A[rows] @ W[r] (or W[r]^T): plain per-relation library GEMMs on
-    contiguous row ranges (segments are relation-major)."""
-    out_dim = W.shape[1] if transpose_w else W.shape[2]
-    Y = torch.empty((A.shape[0], out_dim), dtype=A.dtype, device=A.device)
-    for r in range(W.shape[0]):
-        a, b = rel_ptr_host[r], rel_ptr_host[r + 1]
-        if b > a:
-            torch.mm(A[a:b], W[r].t() if transpose_w else W[r], out=Y[a:b])
+def rows_gemm(A, W, tile_table, transpose_w=False):
+    """Y[rows of relation r] = A[rows] @ W[r] (or W[r]^T) for ANY widths in one launch (dn_rows_gemm_*; rows relation-major,
+    64-row tiles from build_row_tables).  W: [R, K, N], or [R, N, K] with transpose_w."""
+    tiles, ntiles = tile_table
+    A, W = A.contiguous(), W.contiguous()
+    require_gpu(A, W, tiles)
+    K = A.shape[1]
+    N = W.shape[1] if transpose_w else W.shape[2]
+    assert A.dtype == W.dtype and (W.shape[2] if transpose_w else W.shape[1]) == K
+    Y = torch.empty((A.shape[0], N), dtype=A.dtype, device=A.device)
+    if A.shape[0] == 0:
+        return Y
+
+    def _launch():
+        check(getattr(lib(), "dn_rows_gemm_" + _suffix(A))(ptr(A), ptr(W), K, N, 1 if transpose_w else 0, ptr(tiles), ntiles,
+                                                          ptr(Y), stream_ptr()), "dn_rows_gemm")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_gemm", _launch)
+    else:
+        _launch()
     return Y
 
 
+def rows_wgrad_any(A, G, chunk_table, num_rels):
+    """out[r] = sum_{p in relation r} A[p]^T G[p] for ANY widths (dn_rows_wgrad_any_*)."""
+    chunks, chunk_ptr, nchunks = chunk_table
+    A, G = A.contiguous(), G.contiguous()
+    require_gpu(A, G, chunks, chunk_ptr)
+    K, N = A.shape[1], G.shape[1]
+    out = torch.empty((num_rels, K, N), dtype=A.dtype, device=A.device)
+    ws = _ws(lib().dn_rows_wgrad_any_workspace_bytes(nchunks, K, N), A.device)
+    check(getattr(lib(), "dn_rows_wgrad_any_" + _suffix(A))(ptr(A), ptr(G), K, N, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr),
+                                                           ptr(out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_any")
+    return out
+
+
 class _RelAggTransform(torch.autograd.Function):
-    """agg[v] = sum_r ( sum_{e in r, dst=v} s_e x[src_e] ) W_r   (two gather passes + per-relation GEMMs)."""
+    """agg[v] = sum_r ( sum_{e in r, dst=v} s_e x[src_e] ) W_r   (two gather passes + one relation-grouped GEMM launch)."""
 
     @staticmethod
     def forward(ctx, x, W, index, edge_scale):
@@ -692,7 +721,7 @@ class _RelAggTransform(torch.autograd.Function):
             sc1 = edge_scale.index_select(0, ix.perm1.long())
             sc_src = edge_scale.index_select(0, ix.operm.long())
         A = gather_segsum(x, ix.src1, ix.seg_ptr, ix.num_segments, scale=sc1)          # [P, in]
-        Y = _grouped_mm(A, W, ix.rel_ptr_host)                                          # [P, out]
+        Y = rows_gemm(A, W, ix.gemm_tiles)                                              # [P, out]
         agg = gather_segsum(Y, ix.sperm, ix.dptr, ix.num_nodes)                         # [N, out]
         ctx.index, ctx.sc_src = ix, sc_src
         ctx.save_for_backward(A, W)
@@ -706,18 +735,14 @@ class _RelAggTransform(torch.autograd.Function):
         gY = gather_segsum(g, ix.seg_dst, None)                                         # [P, out] row gather
         gx = gW = None
         if ctx.needs_input_grad[0]:
-            gA = _grouped_mm(gY, W, ix.rel_ptr_host, transpose_w=True)                  # [P, in]
+            gA = rows_gemm(gY, W, ix.gemm_tiles, transpose_w=True)                      # [P, in]
             gx = gather_segsum(gA, ix.seg_by_src, ix.optr, ix.num_nodes, scale=ctx.sc_src)
         if ctx.needs_input_grad[1]:
             if wgrad_supported(A, g):
                 # MFMA split-K kernel; gathers the g rows itself (idx_g = segment destinations)
                 gW = rows_wgrad(A, g, ix.chunk_table, W.shape[0], idx_g=ix.seg_dst, out_dtype=W.dtype)
             else:
-                gW = torch.zeros_like(W)
-                for r in range(W.shape[0]):
-                    a, b = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
-                    if b > a:
-                        torch.mm(A[a:b].t(), gY[a:b], out=gW[r])
+                gW = rows_wgrad_any(A, gY, ix.gemm_chunks, W.shape[0])
         return gx, gW, None, None
 
 

@@ -361,6 +361,23 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
                       void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, dn_stream_t stream);
 
+/* Relation-grouped dense products for ANY widths (what PyG's RGCNConv computes with a Python loop over relations,
+ * `for i in range(num_relations): out += h @ weight[i]`; call sites graph_classification/graph_neural_networks/models/
+ * rgconv.py:17-18,96): rows p relation-major, pieces from dn_row_tables_build_i32 (step 64 for the tiles).
+ *   dn_rows_gemm_*       Y[p,:] = A[p,:] @ Wr,  Wr[k][n] = transposed ? W[rel][n][k] : W[rel][k][n]   (A [P,K], Y [P,N])
+ *   dn_rows_wgrad_any_*  out[r] = sum_{p in relation r} A[p,:]^T G[p,:]   ([K,N] per relation; split-K chunks, partials added
+ *                        in chunk order; workspace from dn_rows_wgrad_any_workspace_bytes)
+ * fp32 accumulation, plain FMA tiles (the widths here are the ones the matrix-core kernels do not cover). */
+int dn_rows_gemm_f32(const float* A, const float* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+                     int64_t num_tiles, float* Y, dn_stream_t stream);
+int dn_rows_gemm_bf16(const void* A, const void* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+                      int64_t num_tiles, void* Y, dn_stream_t stream);
+size_t dn_rows_wgrad_any_workspace_bytes(int64_t num_chunks, int32_t K, int32_t N);
+int dn_rows_wgrad_any_f32(const float* A, const float* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                          const int32_t* chunk_ptr, float* out, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                           const int32_t* chunk_ptr, void* out, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg
  * (0 for isolated), same for out; edge norm = in_norm[dst] ("in", mode 1) or

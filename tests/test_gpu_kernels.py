@@ -464,3 +464,32 @@ def test_tiled_gather_is_bitwise_equal_to_the_untiled_kernel(dt, H):
             a = ops.gather_segsum_tiled(x, i_d, p_d, scale=scale, self_coef=coef)
             b = ops.gather_segsum(x, i_d, p_d, N, scale=scale, self_in=x if coef else None, self_coef=coef)
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K,N", [(8, 64), (38, 256), (32, 32), (100, 7), (64, 64)])
+def test_any_width_grouped_products_match_per_relation_matmuls(K, N, dt):
+    """dn_rows_gemm_* / dn_rows_wgrad_any_*: what PyG's RGCNConv does with a Python loop over relations (rgconv.py:17-18,96),
+    as one launch each, for widths the matrix-core kernels do not take (first conv F -> H, H = 32, ...)."""
+    ops = _ops()
+    rng = np.random.default_rng(K * 1000 + N)
+    sizes = [0, 37, 3000, 1, 700]
+    rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
+    R, P = len(sizes), rel_ptr[-1]
+    A = torch.from_numpy(rng.standard_normal((P, K)).astype(np.float32)).to(dt)
+    G = torch.from_numpy(rng.standard_normal((P, N)).astype(np.float32)).to(dt)
+    W = torch.from_numpy((rng.standard_normal((R, K, N)) / np.sqrt(K)).astype(np.float32)).to(dt)
+    rp = torch.tensor(rel_ptr, dtype=torch.int32, device=DEV)
+    tiles = ops.build_row_tables(rp, R, P, 64)
+    chunks = ops.build_row_tables(rp, R, P, 512, want_ptr=True)
+    tol = dict(rtol=2e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    Y = ops.rows_gemm(A.to(DEV), W.to(DEV), tiles)
+    Yt = ops.rows_gemm(G.to(DEV), W.to(DEV), tiles, transpose_w=True)
+    gW = ops.rows_wgrad_any(A.to(DEV), G.to(DEV), chunks, R)
+    for r in range(R):
+        a, b = rel_ptr[r], rel_ptr[r + 1]
+        torch.testing.assert_close(Y[a:b].cpu().double(), A[a:b].double() @ W[r].double(), **tol)
+        torch.testing.assert_close(Yt[a:b].cpu().double(), G[a:b].double() @ W[r].double().t(), **tol)
+        ref = A[a:b].double().t() @ G[a:b].double()
+        wtol = dict(rtol=2e-2, atol=0.5) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(gW[r].cpu().double(), ref, **wtol)
