@@ -407,15 +407,17 @@ def main():
     achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
 
     # HBM traffic of those launches comes from PMC counters, which cannot be read from inside the process: it is taken
-    # from the committed rocprofv3 measurement of this exact workload (profiles/r01_traffic.json), else null
+    # from the committed rocprofv3 measurement of this exact workload (profiles/rNN_traffic.json), else null
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f)
-        if (tj["workload"], tj["N"], tj["E"], tj["H"], tj["dtype"]) == (args.workload, N, E, H, "bf16" if dtype == torch.bfloat16 else "f32"):
-            traffic = tj["conv_gather_scatter_hbm_bytes_per_step"]
-    except Exception:
-        traffic = None
+    for tag in ("r02", "r01"):                           # newest committed measurement of this exact workload
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
+                tj = json.load(f)
+            if (tj["workload"], tj["N"], tj["E"], tj["H"], tj["dtype"]) == (args.workload, N, E, H, "bf16" if dtype == torch.bfloat16 else "f32"):
+                traffic = tj["conv_gather_scatter_hbm_bytes_per_step"]
+                break
+        except Exception:
+            continue
 
     # secondary line (rank 0, N = 1): the pure gather -> segment-sum kernel on a GIN conv (no relation transform), forward
     # + backward, on a PROTEINS-shaped dummy-augmented batch (SURVEY 8d config 2 x 32 graphs, fp32 H = 128)
