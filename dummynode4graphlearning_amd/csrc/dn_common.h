@@ -36,6 +36,19 @@ void dn_set_error(const char* fmt, ...);
 static inline int64_t dn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t dn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Experiment knobs.  The shipped library has NO environment access of its own: every knob is its compile-time default (the
+// measured best).  A tuning build (-DDN_TUNING_ENV: `python -m dummynode4graphlearning_amd.csrc.build --tuning`, used by
+// tools/ab.sh) reads the DN_* variables instead.
+#ifdef DN_TUNING_ENV
+#include <stdlib.h>
+static inline int dn_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static constexpr int dn_knob(const char*, int dflt) { return dflt; }
+#endif
+
 // MI355X: 8 XCDs, workgroups are dealt round-robin over them (blocks b and b+8 share an XCD's L2).
 // Map the hardware block id to a logical chunk id so that the blocks of one XCD walk a CONTIGUOUS
 // range of chunks (neighbouring graphs -> same L2).  Speed only, never correctness.

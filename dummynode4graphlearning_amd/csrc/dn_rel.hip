@@ -15,18 +15,6 @@
 
 namespace {
 
-// Experiment knobs.  The shipped library has NO environment access and no mutable global state (dn_hip.h): every knob is the
-// compile-time default below (the measured best).  A tuning build (-DDN_TUNING_ENV, `python -m
-// dummynode4graphlearning_amd.csrc.build --tuning`, used by tools/ab.sh) reads the DN_* variables once per process instead.
-#ifdef DN_TUNING_ENV
-static int dn_knob(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-#else
-static constexpr int dn_knob(const char*, int dflt) { return dflt; }
-#endif
-
 typedef __bf16 bf16_t;
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));

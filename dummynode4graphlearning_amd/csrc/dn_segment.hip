@@ -167,6 +167,87 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec_kernel(
     }
 }
 
+// The round-1 form of the vector path (one segment at a time, 4 row loads in flight): kept for long CONTIGUOUS lists (the
+// pre-aggregation of the collapsed dummy relations), where it measures faster than the pipelined form above.
+template <typename T, int LPR, bool HAS_SCALE>
+__global__ __launch_bounds__(kBlock) void gather_segsum_vec1_kernel(
+    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+    const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, const T* __restrict__ self_in,
+    float self_coef, int32_t mean, int64_t nchunks) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int GPB = kBlock / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int group = threadIdx.x / LPR;
+    const int64_t chunk = dn_xcd_chunk(blockIdx.x, gridDim.x);
+    if (chunk >= nchunks) return;
+    const int64_t seg0 = chunk * (GPB * kSegsPerGroup);
+
+    for (int col0 = 0; col0 < H; col0 += LPR * VN) {
+        const int col = col0 + lane * VN;
+        const bool colok = col < H;
+#pragma unroll 1
+        for (int it = 0; it < kSegsPerGroup; ++it) {
+            // interleave groups over the chunk so that a wave's groups touch neighbouring segments
+            const int64_t s = seg0 + (int64_t)it * GPB + group;
+            if (s >= S) break;
+            int beg, end;
+            if (ptr != nullptr) { beg = ptr[s]; end = ptr[s + 1]; } else { beg = (int)s; end = (int)s + 1; }
+            float acc[VN];
+#pragma unroll
+            for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+            for (int base = beg; base < end; base += LPR) {
+                const int n = min(LPR, end - base);
+                int my = 0;
+                float mysc = 1.f;
+                if (lane < n) {
+                    my = idx != nullptr ? idx[base + lane] : base + lane;
+                    if (HAS_SCALE) mysc = scale[base + lane];
+                }
+                for (int j = 0; j < n; j += 4) {
+                    float v[4][VN];
+                    float w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int jj = (j + k) & (LPR - 1);
+                        const int r = __shfl(my, jj, LPR);
+                        w[k] = HAS_SCALE ? __shfl(mysc, jj, LPR) : 1.f;
+                        if (j + k < n && colok) {
+                            Vec<T>::load(in + (size_t)r * H + col, v[k]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VN; ++i) v[k][i] = 0.f;
+                            w[k] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) {
+                            if (HAS_SCALE) acc[i] = fmaf(w[k], v[k][i], acc[i]);
+                            else acc[i] += v[k][i];
+                        }
+                    }
+                }
+            }
+            if (colok) {
+                if (mean) {
+                    const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) acc[i] *= inv;
+                }
+                if (self_in != nullptr) {
+                    float sv[VN];
+                    Vec<T>::load(self_in + (size_t)s * H + col, sv);
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) acc[i] = fmaf(self_coef, sv[i], acc[i]);
+                }
+                Vec<T>::store(out + (size_t)s * H + col, acc);
+            }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Tiled variant for GRAPH-LOCAL gathers (segment s <-> input row s, neighbours mostly a few rows away: the GIN / GCN / SAGE
 // aggregation over a batch of small graphs, gconv.py:212).  A workgroup owns TN consecutive segments and first stages input
@@ -341,17 +422,25 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_scalar_kernel(
 }
 
 template <typename T, int LPR, bool VECP>
-int launch_lpr(const T* in, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S, int32_t H, T* out,
+int launch_lpr(const T* in, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S, int64_t M, int32_t H, T* out,
                const T* self_in, float self_coef, int32_t mean, hipStream_t st) {
     constexpr int GPB = kBlock / LPR;
+    // long lists (>= 16 entries per segment on average: the pre-aggregation of a collapsed dummy relation walks ~n rows per
+    // graph) keep the simple kernel; short graph-local lists take the form that is pipelined across segments
+    static const int force = dn_knob("DN_GATHER_V1", -1);
+    const bool use_v1 = force >= 0 ? force != 0 : (ptr != nullptr && S > 0 && M / S >= 16);
     const int64_t nchunks = dn_cdiv(S, (int64_t)GPB * kSegsPerGroup);
     const int64_t grid = dn_cdiv(nchunks, DN_NUM_XCD) * DN_NUM_XCD;
     if (grid > 0x7fffffffLL) { dn_set_error("dn_gather_segsum: grid too large"); return DN_ERR_ARG; }
 #define DN_LAUNCH(SC)                                                                                         \
     do {                                                                                                      \
         if (VECP)                                                                                             \
-            hipLaunchKernelGGL((gather_segsum_vec_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, in, \
-                               idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);                \
+            if (use_v1)                                                                                       \
+                hipLaunchKernelGGL((gather_segsum_vec1_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, in, \
+                                   idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);            \
+            else                                                                                              \
+                hipLaunchKernelGGL((gather_segsum_vec_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, in, \
+                                   idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);            \
         else                                                                                                  \
             hipLaunchKernelGGL((gather_segsum_scalar_kernel<T, LPR, SC>), dim3((unsigned)grid), dim3(kBlock), 0, st, \
                                in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, nchunks);            \
@@ -379,14 +468,14 @@ int gather_segsum(const T* in, int64_t in_rows, int32_t H, const int32_t* idx, c
                                         reinterpret_cast<uintptr_t>(self_in)) % 16 == 0);
     const int pieces = vec ? H / VN : H;
     if (vec) {
-        if (pieces <= 4) return launch_lpr<T, 4, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
-        if (pieces <= 8) return launch_lpr<T, 8, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
-        if (pieces <= 16) return launch_lpr<T, 16, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
-        if (pieces <= 32) return launch_lpr<T, 32, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
-        return launch_lpr<T, 64, true>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 4) return launch_lpr<T, 4, true>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 8) return launch_lpr<T, 8, true>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 16) return launch_lpr<T, 16, true>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
+        if (pieces <= 32) return launch_lpr<T, 32, true>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
+        return launch_lpr<T, 64, true>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
     }
-    if (pieces <= 8) return launch_lpr<T, 8, false>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
-    return launch_lpr<T, 64, false>(in, idx, scale, ptr, S, H, out, self_in, self_coef, mean, st);
+    if (pieces <= 8) return launch_lpr<T, 8, false>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
+    return launch_lpr<T, 64, false>(in, idx, scale, ptr, S, M, H, out, self_in, self_coef, mean, st);
 }
 
 // ---------------------------------------------------------------------------------------------
