@@ -1,0 +1,87 @@
+"""The RCCL code path on real hardware with the one GPU a test box has: a world-size-1 `nccl` process group runs the same
+collectives (flat-bucket all-reduce, SyncBatchNorm's all-gather / all-reduce) as an 8-GPU job, and the result must equal the
+plain single-process step.  (World-size-2 behaviour is covered on the CPU with gloo in tests/test_dist.py.)"""
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture
+def nccl_world_of_one():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+
+
+def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
+    from dummynode4graphlearning_amd import BatchedGraph, GraphBatch, parallel, synthetic, transforms
+    from dummynode4graphlearning_amd import graph_classification as GC
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    # ---- SI layer (HIP kernels) + flat bucket over RCCL, two steps with optimizer.zero_grad() in between
+    raw = synthetic.config3(seed=4, graphs=32)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"],
+                                      raw["max_ne"], raw["max_nel"])
+    N, R = int(aug["node_label"].numel()), raw["num_rels"]
+    g = BatchedGraph(aug["src"], aug["dst"], N)
+    et = aug["edge_label"].long()
+    torch.manual_seed(0)
+    a = RGINLayer(64, 64, num_rels=R).to(DEV)
+    b = RGINLayer(64, 64, num_rels=R).to(DEV)
+    b.load_state_dict(a.state_dict())
+    bucket = parallel.FlatGradBucket(a.parameters())
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.05), torch.optim.SGD(b.parameters(), lr=0.05)
+    x = torch.randn(N, 64, device=DEV)
+    for _ in range(2):
+        oa.zero_grad()
+        a(g, x, et)[0].square().mean().backward()
+        bucket.all_reduce()                                   # RCCL all-reduce (average over a world of one)
+        oa.step()
+        ob.zero_grad()
+        b(g, x, et)[0].square().mean().backward()
+        ob.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    # ---- GC GIN with SyncBatchNorm1d: collectives on the device, equal to torch's BatchNorm1d
+    rng = np.random.default_rng(1)
+    n_g = rng.integers(5, 20, size=24)
+    ptr = np.concatenate([[0], np.cumsum(n_g)])
+    xs = torch.from_numpy(rng.standard_normal((ptr[-1], 8)).astype(np.float32))
+    ei = np.concatenate([np.stack([rng.integers(0, n, size=3 * n) + ptr[i], rng.integers(0, n, size=3 * n) + ptr[i]]) for i, n in enumerate(n_g)], 1)
+    batch = torch.repeat_interleave(torch.arange(24), torch.from_numpy(n_g))
+    data = GraphBatch(xs, torch.from_numpy(ei).long(), batch, y=torch.from_numpy(rng.integers(0, 2, size=24))).to(DEV)
+    args = SimpleNamespace(num_features=8, hidden_dim=64, num_classes=2, dropout_ratio=0.0, additional=None, epochs=1, device=DEV,
+                           dummy_weight=0)
+    torch.manual_seed(1)
+    ref = GC.GIN(args).to(DEV).train()
+    torch.manual_seed(1)
+    syn = parallel.convert_sync_batchnorm(GC.GIN(args)).to(DEV).train()
+    assert any(isinstance(m, parallel.SyncBatchNorm1d) for m in syn.modules())
+    F.nll_loss(ref(data), data.y).backward()
+    F.nll_loss(syn(data), data.y).backward()
+    for (k, p), (_, q) in zip(ref.named_parameters(), syn.named_parameters()):
+        if p.grad is not None and float(p.grad.abs().max()) > 1e-5:
+            err = float((p.grad - q.grad).abs().max() / p.grad.abs().max())
+            assert err < 1e-3, (k, err)
+    for (k, u), (_, v) in zip(ref.state_dict().items(), syn.state_dict().items()):
+        if "running_" in k:
+            torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5, msg=k)
