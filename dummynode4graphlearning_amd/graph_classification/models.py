@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d, Linear, ReLU, Sequential
 
+from .. import ops
 from .conv import GCNConv, GINConv, RGCNConv, SAGEConv, global_add_pool, global_max_pool, global_mean_pool
 
 
@@ -22,9 +23,37 @@ def _pooling(config):
     raise ValueError("aggregation must be 'sum' or 'mean'")
 
 
+class HipLinear(Linear):
+    """torch.nn.Linear (same parameters, names and initialisation) whose forward / backward run on the HIP path for 2-D GPU
+    inputs: matrix cores for the square hidden layers, the any-width kernels for F -> H and H -> classes."""
+
+    def forward(self, x):
+        # exact fp32 products: at these batch sizes (10-20 k rows) the dense layers are a few microseconds either way, and the
+        # BatchNorm / Adam steps behind them amplify the 1e-5 noise of the bf16 split into visible trajectory differences
+        return ops.linear_any(x, self.weight, self.bias, exact=True)
+
+
+class HipBatchNorm1d(BatchNorm1d):
+    """torch.nn.BatchNorm1d (same parameters, buffers, names) whose training-mode statistics, normalisation and backward run
+    as the row-streaming kernels of dn_norm.hip; eval mode and unsupported shapes fall through to torch."""
+
+    def forward(self, x):
+        if not (self.training and ops.batch_norm_rows_supported(x) and x.shape[0] > 1):     # (one row: torch raises, as it should)
+            return super().forward(x)
+        y, mean, var = ops.batch_norm_rows(x, self.weight if self.affine else None, self.bias if self.affine else None, self.eps)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                n = x.shape[0]
+                self.running_mean.mul_(1.0 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
+                self.running_var.mul_(1.0 - mom).add_((var * (n / max(n - 1, 1))).to(self.running_var.dtype), alpha=mom)
+        return y
+
+
 def _mlp(in_dim, out_dim):
-    return Sequential(Linear(in_dim, out_dim), BatchNorm1d(out_dim), ReLU(),
-                      Linear(out_dim, out_dim), BatchNorm1d(out_dim), ReLU())
+    return Sequential(HipLinear(in_dim, out_dim), HipBatchNorm1d(out_dim), ReLU(),
+                      HipLinear(out_dim, out_dim), HipBatchNorm1d(out_dim), ReLU())
 
 
 def _edge_type(data, x):
@@ -169,11 +198,11 @@ class GIN(torch.nn.Module):
         for layer, out_emb_dim in enumerate(self.embeddings_dim):
             if layer == 0:
                 self.first_h = _mlp(self.num_features, out_emb_dim)
-                linears.append(Linear(out_emb_dim, self.num_classes))
+                linears.append(HipLinear(out_emb_dim, self.num_classes))
             else:
                 nns.append(_mlp(self.embeddings_dim[layer - 1], out_emb_dim))
                 convs.append(GINConv(nns[-1], train_eps=bool(train_eps)))
-                linears.append(Linear(out_emb_dim, self.num_classes))
+                linears.append(HipLinear(out_emb_dim, self.num_classes))
         self.nns = torch.nn.ModuleList(nns)
         self.convs = torch.nn.ModuleList(convs)
         self.linears = torch.nn.ModuleList(linears)
@@ -243,11 +272,11 @@ class RGIN(torch.nn.Module):
         for layer, out_emb_dim in enumerate(self.embeddings_dim):
             if layer == 0:
                 self.first_h = _mlp(self.num_features, out_emb_dim)
-                linears.append(Linear(out_emb_dim, self.num_classes))
+                linears.append(HipLinear(out_emb_dim, self.num_classes))
             else:
                 nns.append(_mlp(self.embeddings_dim[layer - 1], out_emb_dim))
                 convs.append(RGCNConv(self.nhid, self.nhid, self.num_relations, aggr="add"))      # rgconv.py:96
-                linears.append(Linear(out_emb_dim, self.num_classes))
+                linears.append(HipLinear(out_emb_dim, self.num_classes))
         if "weight_reg" in config and config["weight_reg"] > 1.1:
             with torch.no_grad():
                 for conv in convs:

@@ -1305,7 +1305,10 @@ def _dense_table(n_rows, dev):
     key = (int(n_rows), str(dev))
     t = _dense_tables.get(key)
     if t is None:
-        t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev))
+        # split-K chunks sized for ~1.5 workgroups per CU whatever the row count (a 20 k-row GC batch with 4096-row chunks
+        # would run its weight gradient on five workgroups)
+        chunk = max(256, min(WGRAD_CHUNK_ROWS, -(-int(n_rows) // 384 // 64) * 64))
+        t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev, chunk_rows=chunk))
         if len(_dense_tables) > 8:
             _dense_tables.clear()
         _dense_tables[key] = t
@@ -1459,3 +1462,110 @@ def linear_act(x, weight, bias=None, relu=False, exact=None):
         return _LinearActFn.apply(x, weight, bias, relu, exact)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y
+
+
+# ----------------------------------------------------------------------------------------------
+# dense side of the GC models: BatchNorm over the nodes of the batch, Linear of any width
+# ----------------------------------------------------------------------------------------------
+class _BatchNormRowsFn(torch.autograd.Function):
+    """Training-mode BatchNorm over the rows of [N, C] (dn_batchnorm_rows_*): returns (y, mean, biased var)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        N, C = x.shape
+        w32 = weight.detach().float().contiguous() if weight is not None else None
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        mean, var, rstd = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
+        ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
+        check(getattr(lib(), "dn_batchnorm_rows_" + _suffix(x))(ptr(x), N, C, ptr(w32), ptr(b32), float(eps), ptr(y), ptr(mean), ptr(var),
+                                                               ptr(rstd), ptr(ws), ws.numel(), stream_ptr()), "dn_batchnorm_rows")
+        ctx.save_for_backward(x, mean, rstd, w32 if w32 is not None else x.new_empty(0))
+        ctx.has_w, ctx.has_b = weight is not None, bias is not None
+        ctx.wdtype = weight.dtype if weight is not None else None
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, rstd, w32 = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        s1, s2 = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(2))
+        ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
+        check(getattr(lib(), "dn_batchnorm_rows_bwd_" + _suffix(x))(ptr(dy), ptr(x), N, C, ptr(mean), ptr(rstd),
+                                                                   ptr(w32) if ctx.has_w else None, ptr(dx), ptr(s1), ptr(s2), ptr(ws),
+                                                                   ws.numel(), stream_ptr()), "dn_batchnorm_rows_bwd")
+        gw = s2.to(ctx.wdtype) if ctx.has_w else None
+        gb = s1.to(ctx.wdtype if ctx.has_w else dy.dtype) if ctx.has_b else None
+        return dx, gw, gb, None
+
+
+def batch_norm_rows_supported(x):
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= 1
+            and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
+
+
+def batch_norm_rows(x, weight, bias, eps=1e-5):
+    """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x."""
+    return _BatchNormRowsFn.apply(x, weight, bias, eps)
+
+
+_single_rel_tables = {}
+
+
+def _single_rel_table(n_rows, dev):
+    """Device tile / chunk tables of ONE relation of n_rows rows for the any-width products (cached per size and device)."""
+    key = (int(n_rows), str(dev))
+    t = _single_rel_tables.get(key)
+    if t is None:
+        rp = torch.tensor([0, int(n_rows)], dtype=I32).to(dev)
+        chunk = max(128, min(2048, -(-int(n_rows) // 256 // 64) * 64))
+        t = (build_row_tables(rp, 1, n_rows, 64), build_row_tables(rp, 1, n_rows, chunk, want_ptr=True))
+        if len(_single_rel_tables) > 8:
+            _single_rel_tables.clear()
+        _single_rel_tables[key] = t
+    return t
+
+
+class _LinearAnyFn(torch.autograd.Function):
+    """y = x @ weight^T (+ bias) for any in / out widths on dn_rows_gemm_* / dn_rows_wgrad_any_* (weight [out, in], nn.Linear
+    layout).  The library GEMMs torch picks for a [20 k x 5] x [5 x 128] product and its [128 x 20 k] x [20 k x 5] weight
+    gradient take 20-80 us each; these are single small launches."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        tiles, _ = _single_rel_table(x.shape[0], x.device)
+        y = rows_gemm(x, weight.contiguous().unsqueeze(0), tiles, transpose_w=True)          # W[0] is [N, K] = [out, in]
+        if bias is not None:
+            y = y + bias
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        tiles, chunks = _single_rel_table(x.shape[0], x.device)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = rows_gemm(g, weight.contiguous().unsqueeze(0), tiles)                       # g [P, out] @ W [out, in]
+        if ctx.needs_input_grad[1]:
+            gw = rows_wgrad_any(g, x, chunks, 1)[0]                                          # [out, in]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def linear_any(x, weight, bias=None, exact=None):
+    """nn.Linear on the HIP path whatever its widths: matrix cores when square 64 / 128 / 256, the any-width kernels otherwise.
+    exact: fp32 arithmetic of the matrix-core path (None = module default, True = exact f32, False = bf16 split)."""
+    if (x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == weight.dtype and x.dtype in MFMA_DTYPES):
+        if weight.shape[0] == weight.shape[1] and weight.shape[0] in (64, 128, 256) and x.shape[1] == weight.shape[1]:
+            return _LinearActFn.apply(x, weight, bias, False, exact)
+        return _LinearAnyFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -17,8 +17,13 @@ import torch
 import torch.distributed as dist
 
 
+# With a world of one the collectives are identities and are skipped -- unless this is set (tests: it lets a single-GPU box run
+# the RCCL all-reduce / all-gather calls the multi-GPU job makes).
+RUN_COLLECTIVES_IN_A_WORLD_OF_ONE = False
+
+
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or RUN_COLLECTIVES_IN_A_WORLD_OF_ONE)
 
 
 def shard_graphs(batch_num_nodes, batch_num_edges, world_size):
@@ -41,7 +46,7 @@ def dp_loss_scale(local_graphs, global_graphs, world_size=None):
     """Factor for a rank's batch-MEAN loss (main.py:41 F.nll_loss, train.py:623-627) so that the AVERAGED gradient bucket
     equals the gradient of the global-batch mean when shards hold different numbers of graphs: B_r * W / B (1 when equal)."""
     if world_size is None:
-        world_size = dist.get_world_size() if _dist_on() else 1
+        world_size = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     return float(local_graphs) * world_size / float(global_graphs)
 
 

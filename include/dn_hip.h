@@ -378,6 +378,24 @@ int dn_rows_wgrad_any_f32(const float* A, const float* G, int32_t K, int32_t N, 
 int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
                            const int32_t* chunk_ptr, void* out, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* BatchNorm over the rows of [N, C] node features, training mode (batch statistics) -- the BatchNorm1d inside the MLPs of the GC
+ * models (graph_classification/graph_neural_networks/models/gconv.py:187-194, rgconv.py:85-93).
+ *   forward:   mean / var (biased) / rstd [C] over the rows;  Y = (X - mean) * rstd * weight + bias   (weight / bias may be NULL)
+ *   backward:  sum_dy [C] (= dbias), sum_dy_xhat [C] (= dweight);  DX = weight * rstd * (DY - sum_dy / N - xhat * sum_dy_xhat / N)
+ * fp32 statistics whatever the storage type; C a multiple of 4, <= 1024; deterministic.  The running-statistics update
+ * (momentum, unbiased variance) is host-side arithmetic on mean / var. */
+size_t dn_batchnorm_rows_workspace_bytes(int64_t N, int32_t C);
+int dn_batchnorm_rows_f32(const float* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, float* Y, float* mean,
+                          float* var, float* rstd, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_batchnorm_rows_bf16(const void* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, void* Y, float* mean,
+                           float* var, float* rstd, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_batchnorm_rows_bwd_f32(const float* DY, const float* X, int64_t N, int32_t C, const float* mean, const float* rstd,
+                              const float* weight, float* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
+                              dn_stream_t stream);
+int dn_batchnorm_rows_bwd_bf16(const void* DY, const void* X, int64_t N, int32_t C, const float* mean, const float* rstd,
+                               const float* weight, void* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
+                               dn_stream_t stream);
+
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg
  * (0 for isolated), same for out; edge norm = in_norm[dst] ("in", mode 1) or

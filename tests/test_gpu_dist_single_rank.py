@@ -25,8 +25,11 @@ def _free_port():
 def nccl_world_of_one():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from dummynode4graphlearning_amd import parallel
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    parallel.RUN_COLLECTIVES_IN_A_WORLD_OF_ONE = True            # really issue the RCCL calls
     yield
+    parallel.RUN_COLLECTIVES_IN_A_WORLD_OF_ONE = False
     dist.destroy_process_group()
     for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)
@@ -49,6 +52,9 @@ def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
     b = RGINLayer(64, 64, num_rels=R).to(DEV)
     b.load_state_dict(a.state_dict())
     bucket = parallel.FlatGradBucket(a.parameters())
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a_, **k_: (calls.append("all_reduce"), orig(*a_, **k_))[1]
     oa, ob = torch.optim.SGD(a.parameters(), lr=0.05), torch.optim.SGD(b.parameters(), lr=0.05)
     x = torch.randn(N, 64, device=DEV)
     for _ in range(2):
@@ -59,6 +65,8 @@ def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
         ob.zero_grad()
         b(g, x, et)[0].square().mean().backward()
         ob.step()
+    dist.all_reduce = orig
+    assert len(calls) == 2, "the bucket did not issue its RCCL all-reduce"
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.equal(p, q)
     # ---- GC GIN with SyncBatchNorm1d: collectives on the device, equal to torch's BatchNorm1d

@@ -493,3 +493,56 @@ def test_any_width_grouped_products_match_per_relation_matmuls(K, N, dt):
         ref = A[a:b].double().t() @ G[a:b].double()
         wtol = dict(rtol=2e-2, atol=0.5) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(gW[r].cpu().double(), ref, **wtol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C", [(2, 64), (63, 4), (5000, 128), (20181, 256), (300, 40), (129, 1024)])
+def test_batch_norm_rows_matches_torch(N, C, dt):
+    """dn_batchnorm_rows_* (training-mode BatchNorm over the nodes of a batch, gconv.py:187-194) against F.batch_norm in fp64:
+    output, batch statistics, input / weight / bias gradients; a large column mean must not cancel the variance away."""
+    ops = _ops()
+    rng = np.random.default_rng(N + C)
+    x = torch.from_numpy((rng.standard_normal((N, C)) * 2.0 + 30.0 * rng.standard_normal(C)).astype(np.float32)).to(dt)
+    w = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(dt)
+    b = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(dt)
+    coef = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32)).to(dt)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y, mean, var = ops.batch_norm_rows(xd, wd, bd, 1e-5)
+    y.backward(coef.to(DEV))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.batch_norm(xr, None, None, wr, br, training=True, eps=1e-5)
+    yr.backward(coef.double())
+    tol = dict(rtol=2e-2, atol=6e-2) if dt == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(mean.cpu().double(), x.double().mean(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(var.cpu().double(), x.double().var(0, unbiased=False), rtol=2e-4, atol=1e-5)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+    if N > 1:
+        gt = dict(rtol=3e-2, atol=0.15) if dt == torch.bfloat16 else dict(rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **gt)
+        torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=3e-2 if dt == torch.bfloat16 else 1e-3,
+                                   atol=(0.5 if dt == torch.bfloat16 else 1e-3) * max(1.0, N ** 0.5 / 10))
+        torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=3e-2 if dt == torch.bfloat16 else 1e-4,
+                                   atol=(0.5 if dt == torch.bfloat16 else 1e-3) * max(1.0, N ** 0.5 / 10))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K,N_", [(5, 128), (38, 256), (128, 128), (64, 2), (256, 256)])
+def test_linear_any_matches_torch(K, N_, dt):
+    ops = _ops()
+    rng = np.random.default_rng(K + N_)
+    P = 3001
+    x = torch.from_numpy(rng.standard_normal((P, K)).astype(np.float32)).to(dt)
+    w = torch.from_numpy((rng.standard_normal((N_, K)) / np.sqrt(K)).astype(np.float32)).to(dt)
+    b = torch.from_numpy(rng.standard_normal(N_).astype(np.float32)).to(dt)
+    coef = torch.from_numpy(rng.standard_normal((P, N_)).astype(np.float32)).to(dt)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear_any(xd, wd, bd)
+    y.backward(coef.to(DEV))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(coef.double())
+    tol = dict(rtol=2e-2, atol=5e-2) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
+    torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=2e-2 if dt == torch.bfloat16 else 1e-4, atol=1.0 if dt == torch.bfloat16 else 2e-2)
+    torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=2e-2 if dt == torch.bfloat16 else 1e-4, atol=1.0 if dt == torch.bfloat16 else 2e-2)
