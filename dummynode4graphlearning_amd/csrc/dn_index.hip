@@ -613,13 +613,13 @@ __global__ void ri_tail_kernel(int64_t E, int64_t N, int64_t P, int64_t n_agg, i
 // Tables are sized by an upper bound (rows / step + relations); the unused tail is filled with empty pieces of the last
 // relation (beg == end: consumers skip them without reloading weights).
 __global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_ptr, int32_t step, int64_t max_entries,
-                                  int32_t* __restrict__ table, int32_t* __restrict__ piece_ptr) {
+                                  int32_t* __restrict__ table, int32_t* __restrict__ piece_ptr, unsigned long long skip_mask) {
     __shared__ int32_t pp[1025];                                  // pieces before relation r (Rt <= 1024)
     if (threadIdx.x == 0) {
         int32_t acc = 0;
         for (int r = 0; r < Rt; ++r) {
             pp[r] = acc;
-            const int32_t cnt = rel_ptr[r + 1] - rel_ptr[r];
+            const int32_t cnt = (r < 64 && ((skip_mask >> r) & 1ull)) ? 0 : rel_ptr[r + 1] - rel_ptr[r];   // skipped relation: no pieces
             acc += (cnt + step - 1) / step;
         }
         pp[Rt] = acc;
@@ -685,19 +685,20 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 // padded.  cnt > K: the first K-1 rows, slot K-1 = num_edge_rows + j for the j-th overflowing node, and rows K-1 .. cnt-1 go
 // to the overflow CSR (ovf_ptr over overflowing nodes in node order, ovf_idx) the caller pre-sums.
 __global__ void slot_count_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
-                                  const int32_t* __restrict__ lrows, int32_t* __restrict__ over, int32_t* __restrict__ olen) {
+                                  const int32_t* __restrict__ lrows, int32_t* __restrict__ over, int32_t* __restrict__ olen,
+                                  int32_t drop_beg, int32_t drop_end) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v > N) return;
     if (v == N) { over[N] = 0; olen[N] = 0; return; }            // sentinel: the scans yield the totals at [N]
     int cnt = 0;
-    for (int i = lptr[v]; i < lptr[v + 1]; ++i) cnt += lrows[i] < P ? 1 : 0;
+    for (int i = lptr[v]; i < lptr[v + 1]; ++i) cnt += (lrows[i] < P && !(lrows[i] >= drop_beg && lrows[i] < drop_end)) ? 1 : 0;
     over[v] = cnt > K ? 1 : 0;
     olen[v] = cnt > K ? cnt - (K - 1) : 0;
 }
 __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lrows, const int32_t* __restrict__ over_id,
                                  const int32_t* __restrict__ ostart, int32_t* __restrict__ slots, int32_t* __restrict__ ovf_ptr,
-                                 int32_t* __restrict__ ovf_idx) {
+                                 int32_t* __restrict__ ovf_idx, int32_t drop_beg, int32_t drop_end) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v > N) return;
     if (v == N) { ovf_ptr[over_id[N]] = ostart[N]; return; }     // closing entry of the overflow CSR
@@ -706,7 +707,7 @@ __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t*
     int k = 0, o = ostart[v];
     for (int i = lptr[v]; i < lptr[v + 1]; ++i) {
         const int r = lrows[i];
-        if (r >= P) continue;
+        if (r >= P || (r >= drop_beg && r < drop_end)) continue;
         if (k < keep) slots[v * (int64_t)K + k] = r;
         else ovf_idx[o++] = r;
         ++k;
@@ -715,6 +716,78 @@ __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t*
     if (is_over) {
         slots[v * (int64_t)K + K - 1] = P + over_id[v];
         ovf_ptr[over_id[v]] = ostart[v];
+    }
+}
+
+// ---- tables of a folded pre-aggregation (dn_rows_selfsum_bf16 with local_of_node) -----------------------------------------
+// Segment j = nodes seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (a graph's nodes: the sources of its dummy node).  Valid only if every
+// segment is a non-empty contiguous ascending run and the segments ascend; then the (segment, 32-row tile) pairs that share a
+// row, numbered segment-major, are consecutive within each tile.
+constexpr int kFoldTile = 32;                                    // rows per tile of the closing launch (kSsRows in dn_rel.hip)
+
+__device__ __forceinline__ void fold_seg_span(const int32_t* ptr, const int32_t* nodes, int64_t j, int32_t& first, int32_t& last) {
+    first = nodes[ptr[j]];
+    last = nodes[ptr[j + 1] - 1];
+}
+
+__global__ void fold_count_kernel(int64_t n, int64_t N, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nodes,
+                                  int32_t* __restrict__ ntile, int32_t* __restrict__ ok) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j > n) return;
+    if (j == n) { ntile[n] = 0; return; }
+    const int32_t cnt = ptr[j + 1] - ptr[j];
+    bool good = cnt > 0;
+    int32_t nt = 1;
+    if (good) {
+        int32_t first, last;
+        fold_seg_span(ptr, nodes, j, first, last);
+        good = first >= 0 && last < N && last - first == cnt - 1;
+        if (good && j > 0 && ptr[j] > ptr[j - 1]) good = nodes[ptr[j] - 1] < first;          // segments ascend
+        if (good) nt = last / kFoldTile - first / kFoldTile + 1;
+    }
+    ntile[j] = nt;
+    if (!good) *ok = 0;
+}
+
+__global__ void fold_check_kernel(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nodes,
+                                  int32_t* __restrict__ ok) {      // inside a segment: strictly +1 (one thread per segment)
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    bool good = true;
+    for (int32_t e = ptr[j]; e + 1 < ptr[j + 1]; ++e) good &= nodes[e + 1] == nodes[e] + 1;
+    if (!good) *ok = 0;
+}
+
+__global__ void fold_fill_kernel(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nodes,
+                                 const int32_t* __restrict__ pptr, const int32_t* __restrict__ ok,
+                                 uint8_t* __restrict__ local_of_node, int32_t* __restrict__ tile_part) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n || *ok == 0) return;
+    int32_t first, last;
+    fold_seg_span(ptr, nodes, j, first, last);
+    const int32_t t0 = first / kFoldTile, t1 = last / kFoldTile, p = pptr[j];
+    // first partial row of tile t0: the earliest segment with a row in it (at most 32 steps back)
+    int32_t lo0 = p;
+    for (int64_t k = j - 1; k >= 0; --k) {
+        int32_t f, l;
+        fold_seg_span(ptr, nodes, k, f, l);
+        if (l / kFoldTile != t0) break;
+        lo0 = pptr[k] + (t0 - f / kFoldTile);
+        if (f / kFoldTile != t0) break;                          // started in an earlier tile: nothing before it is in t0
+    }
+    for (int32_t v = first; v <= last; ++v) local_of_node[v] = (uint8_t)(v / kFoldTile == t0 ? p - lo0 : 0);
+    // {first partial row, count} of a tile is written by the LAST segment with a row in it
+    for (int32_t t = t0; t <= t1; ++t) {
+        bool is_last = t < t1;
+        if (!is_last) {
+            is_last = j + 1 >= n;
+            if (!is_last) is_last = nodes[ptr[j + 1]] / kFoldTile > t1;
+        }
+        if (is_last) {
+            const int32_t mine = p + (t - t0), lo = t == t0 ? lo0 : mine;
+            tile_part[2 * t] = lo;
+            tile_part[2 * t + 1] = mine - lo + 1;
+        }
     }
 }
 
@@ -1106,13 +1179,13 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
 }
 
 int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,
-                            int32_t* piece_ptr, dn_stream_t stream) {
+                            int32_t* piece_ptr, uint64_t skip_mask, dn_stream_t stream) {
     DN_REQUIRE(num_rels >= 1 && num_rels <= 1024, "dn_row_tables_build: 1 <= num_rels <= 1024");
     DN_REQUIRE(step >= 1 && max_entries >= 0, "dn_row_tables_build: bad sizes");
     DN_REQUIRE(rel_ptr && (max_entries == 0 || table), "dn_row_tables_build: NULL pointer");
     const int64_t blocks = max_entries > 0 ? dn_cdiv(max_entries, 256) : 1;
     hipLaunchKernelGGL(row_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
-                       num_rels, rel_ptr, step, max_entries, table, piece_ptr);
+                       num_rels, rel_ptr, step, max_entries, table, piece_ptr, (unsigned long long)skip_mask);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1128,8 +1201,8 @@ size_t dn_slot_table_workspace_bytes(int64_t N) {
 }
 
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx, int64_t* host_counts, void* workspace,
-                            size_t workspace_bytes, dn_stream_t stream) {
+                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
+                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
     if (host_counts) host_counts[0] = host_counts[1] = 0;
     if (N == 0) return DN_OK;
@@ -1145,12 +1218,12 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
     void* temp = a.take_bytes(tb);
     if (!a.ok()) { dn_set_error("dn_slot_table_build: workspace too small"); return DN_ERR_WORKSPACE; }
     hipLaunchKernelGGL(slot_count_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over, olen);
+                       over, olen, drop_beg, drop_end);
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(excl_scan(temp, tb, over, over_id, N + 1, st));
     DN_CHECK_HIP(excl_scan(temp, tb, olen, ostart, N + 1, st));
     hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over_id, ostart, slots, ovf_ptr, ovf_idx);
+                       over_id, ostart, slots, ovf_ptr, ovf_idx, drop_beg, drop_end);
     DN_CHECK_LAUNCH();
     int32_t h[2] = {0, 0};
     DN_CHECK_HIP(hipMemcpyAsync(&h[0], over_id + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1158,6 +1231,52 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
     DN_CHECK_HIP(hipStreamSynchronize(st));
     host_counts[0] = h[0];                                       // overflowing nodes
     host_counts[1] = h[1];                                       // rows in the overflow CSR
+    return DN_OK;
+}
+
+size_t dn_fold_tables_workspace_bytes(int64_t num_segments) {
+    if (num_segments < 0) { dn_set_error("dn_fold_tables_workspace_bytes: negative size"); return 0; }
+    Arena a(nullptr, 0);
+    a.take<int32_t>(num_segments + 1); a.take<int32_t>(1);
+    size_t tb = 0;
+    if (excl_scan(nullptr, tb, nullptr, nullptr, num_segments + 1, nullptr) != hipSuccess) { dn_set_error("rocprim scan size query failed"); return 0; }
+    a.take_bytes(tb);
+    return a.off + 256;
+}
+
+int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                             uint8_t* local_of_node, int32_t* tile_part, int32_t* part_ptr, int32_t* host_ok, void* workspace,
+                             size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_tables_build: bad sizes");
+    DN_REQUIRE(host_ok, "dn_fold_tables_build: NULL pointer");
+    *host_ok = 0;
+    if (N == 0 || num_segments == 0) return DN_OK;
+    DN_REQUIRE(seg_ptr && seg_nodes && local_of_node && tile_part && part_ptr && workspace, "dn_fold_tables_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(workspace, workspace_bytes);
+    int32_t* ntile = a.take<int32_t>(num_segments + 1);
+    int32_t* ok = a.take<int32_t>(1);
+    size_t tb = 0;
+    DN_CHECK_HIP(excl_scan(nullptr, tb, ntile, part_ptr, num_segments + 1, st));
+    void* temp = a.take_bytes(tb);
+    if (!a.ok()) { dn_set_error("dn_fold_tables_build: workspace too small"); return DN_ERR_WORKSPACE; }
+    const int64_t tiles = dn_cdiv(N, kFoldTile);
+    DN_CHECK_HIP(hipMemsetAsync(ok, 0x01, sizeof(int32_t), st));                 // any non-zero value: "still valid"
+    DN_CHECK_HIP(hipMemsetAsync(local_of_node, 0xff, (size_t)N, st));
+    DN_CHECK_HIP(hipMemsetAsync(tile_part, 0, (size_t)tiles * 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(fold_count_kernel, dim3(grid_for(num_segments + 1)), dim3(kBlock), 0, st, num_segments, N, seg_ptr, seg_nodes,
+                       ntile, ok);
+    DN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_check_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, ok);
+    DN_CHECK_LAUNCH();
+    DN_CHECK_HIP(excl_scan(temp, tb, ntile, part_ptr, num_segments + 1, st));
+    hipLaunchKernelGGL(fold_fill_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, part_ptr,
+                       ok, local_of_node, tile_part);
+    DN_CHECK_LAUNCH();
+    int32_t h = 0;
+    DN_CHECK_HIP(hipMemcpyAsync(&h, ok, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipStreamSynchronize(st));
+    *host_ok = h != 0 ? 1 : 0;
     return DN_OK;
 }
 

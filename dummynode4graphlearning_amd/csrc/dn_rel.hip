@@ -690,13 +690,16 @@ static bool stride_tiles() {
     return on;
 }
 
-template <int H>
+template <int H, bool FOLD>
 __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wn,
                                                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ S,
                                                              const bf16_t* __restrict__ S2, int32_t n1,
                                                              const int32_t* __restrict__ slots, int32_t N,
                                                              int32_t num_tiles, int32_t tiles_per_wg,
-                                                             bf16_t* __restrict__ out, int32_t nt) {
+                                                             bf16_t* __restrict__ out, int32_t nt,
+                                                             const uint8_t* __restrict__ local_of_node,
+                                                             const int32_t* __restrict__ tile_part,
+                                                             float* __restrict__ seg_part) {
     constexpr int T = H * 4, K = kSsSlots;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int SX = H + kPad, SY = H + kPad;
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
     constexpr int LPR = H / 8;                                   // 16-byte pieces per row
     static_assert(kSsRows * LPR == T, "one piece per thread");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kSsRows * SX + kSsRows * SY];
+    __shared__ __attribute__((aligned(8))) uint8_t segB[2][kSsRows];        // FOLD: partial row of each tile row, minus p0 (255: none)
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
     bf16_t* bufY = lds + 2 * kSsRows * SX;
 
@@ -744,14 +748,28 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         return v;
     };
 
+    auto load_seg = [&](int t) -> int32_t {                       // thread r < 32: the partial row of row r of tile t relative to
+        const int p = rowbase(t) + tid;                           // the tile's first one (255: none)
+        return (FOLD && tid < kSsRows && t < t_end && p < N) ? (int32_t)local_of_node[p] : 255;
+    };
+    auto load_tp = [&](int t) -> int2 {                           // the tile's {first partial row, count}: wave-uniform (scalar loads)
+        return (FOLD && t < t_end) ? *reinterpret_cast<const int2*>(tile_part + 2 * (first + t * step)) : make_int2(0, 0);
+    };
+    auto store_seg = [&](int b, int32_t v) {
+        if (tid < kSsRows) segB[b][tid] = (uint8_t)v;
+    };
+    int2 tp = load_tp(t_beg);
     uint4 rx = load_x(t_beg);
     Slots sl = load_slots(t_beg);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
+    if (FOLD) store_seg(0, load_seg(t_beg));
     rx = load_x(t_beg + 1);
+    int32_t sg_next = load_seg(t_beg + 1);
     __syncthreads();
 
     for (int t = t_beg; t < t_end; ++t) {
         const int b = (t - t_beg) & 1;
+        const int2 tp_next = load_tp(t + 1);
         // (1) the slot rows of my piece
         uint4 g[K];
         const int sid[K] = {sl.a.x, sl.a.y, sl.b.x, sl.b.y, sl.c.x, sl.c.y};
@@ -787,8 +805,35 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
             for (int i = 0; i < 4; ++i) o[i] = (bf16_t)acc[m][i];
             *reinterpret_cast<bf16x4*>(bufY + (m * 16 + (lane & 15)) * SY + n0 + 4 * (lane >> 4)) = o;
         }
-        if (t + 1 < t_end) *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;
+        *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;          // (zeros past the last tile)
+        if (FOLD) store_seg(b ^ 1, sg_next);
+        // (3b) column sums of this tile's X rows per SEGMENT (the rows a collapsed relation pre-aggregates: all nodes of a graph
+        //      feeding its dummy node) -- the rows are in LDS anyway, so the separate pre-aggregation pass over X (0.5 GB per
+        //      direction) disappears.  One more MFMA per wave: D[s][c] = sum_r [row r belongs to the tile's s-th segment] X[r][c]
+        //      (0/1 indicator as the A operand, exact products, the matrix unit's fixed accumulation order), written as one fp32
+        //      partial row per (segment, tile); the partial rows of a tile's segments are consecutive (segments are contiguous
+        //      ascending node ranges).  A tail launch adds a segment's partials in tile order.
+        if (FOLD) {
+            const int p0 = tp.x, cnt = tp.y;
+            if (cnt > 0) {
+                const uint2 sb = *reinterpret_cast<const uint2*>(&segB[b][8 * (lane >> 4)]);    // my 8 rows' local ids
+                const bf16x8 xf = tr_frag(bufX(b), SX, n0, lane);  // element j: X[8*(lane>>4) + j][n0 + (lane & 15)]
+                for (int m0 = 0; m0 < cnt; m0 += 16) {             // (more than 16 segments in 32 rows: graphs of 1-2 nodes)
+                    const uint32_t me = (uint32_t)(m0 + (lane & 15));
+                    bf16x8 ind;                                   // element j: [row 8*(lane>>4) + j is in segment m0 + (lane & 15)]
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        ind[j] = (bf16_t)(((((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xffu) == me) ? 1.0f : 0.0f);
+                    // D[c][s] = sum_r X[r][n0 + c] ind[r][s]: lane holds columns n0 + 4*(lane>>4) + i of segment m0 + (lane&15)
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    if ((int)me < cnt)
+                        *reinterpret_cast<f32x4*>(seg_part + (size_t)(p0 + (int)me) * H + n0 + 4 * (lane >> 4)) = d;
+                }
+            }
+        }
+        tp = tp_next;
         rx = load_x(t + 2);
+        sg_next = load_seg(t + 2);
         __syncthreads();
         // (4) epilogue: my piece of the tile + my slot rows, fp32, one rounding
         const int p = rowbase(t) + pr;
@@ -823,13 +868,19 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
 
 template <int H>
 int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const bf16_t* S, const bf16_t* S2, int32_t n1,
-                   const int32_t* slots, int64_t N, bf16_t* out, hipStream_t st) {
+                   const int32_t* slots, int64_t N, bf16_t* out, const uint8_t* local_of_node, const int32_t* tile_part,
+                   float* seg_part, hipStream_t st) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     static const int nt = dn_knob("DN_NT", 3);
-    hipLaunchKernelGGL((rows_selfsum_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                       (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), out, (nt >> 1) & 1);
+    const int32_t tpw = (int32_t)(stride_tiles() ? 0 : tiles_per_wg);
+    if (local_of_node)
+        hipLaunchKernelGGL((rows_selfsum_kernel<H, true>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, local_of_node, tile_part, seg_part);
+    else
+        hipLaunchKernelGGL((rows_selfsum_kernel<H, false>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, local_of_node, tile_part, seg_part);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1125,9 +1176,101 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__
     }
 }
 
+
+// ---- tail of a folded pre-aggregation (dn_rows_selfsum_bf16 with local_of_node): per tile of 32 segments
+//        aux[j]       = bf16( sum of segment j's partial rows, tile order )          (kept: the weight gradient's operand)
+//        out[idx[j]] += aux[j] @ Wn^T                                               (fp32 product added to the bf16 row, one rounding)
+//      One workgroup per tile, H*4 threads: thread (pr, pc) sums its 8 columns of segment pr, the waves multiply like
+//      rows_selfsum_kernel (wave w: output columns 16w..16w+15), the products go through LDS in fp32 back to (pr, pc).
+template <int H>
+__global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restrict__ part, const int32_t* __restrict__ pptr,
+                                                          const bf16_t* __restrict__ Wn, const int32_t* __restrict__ idx,
+                                                          int32_t n, bf16_t* __restrict__ aux, bf16_t* __restrict__ out) {
+    constexpr int SX = H + kPad, SYF = H + 4;
+    constexpr int KS = H / 32, MT = kSsRows / 16, LPR = H / 8;
+    static_assert(kSsRows * LPR == H * 4, "one piece per thread");
+    __shared__ __attribute__((aligned(16))) bf16_t bufX[kSsRows * SX];
+    __shared__ __attribute__((aligned(16))) float bufY[kSsRows * SYF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * 16, pr = tid / LPR, pc = tid % LPR;
+    const int j = blockIdx.x * kSsRows + pr;
+    // my output row's current value: in flight under the partial sums and the MFMAs
+    int32_t orow = -1;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < n) {
+        orow = idx[j];
+        cur = *reinterpret_cast<const uint4*>(out + (size_t)orow * H + pc * 8);
+        for (int k = pptr[j]; k < pptr[j + 1]; ++k) {
+            const float4 u = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8);
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8 + 4);
+            a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w; a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+        }
+    }
+    bf16x8 xr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xr[i] = (bf16_t)a[i];
+    *reinterpret_cast<bf16x8*>(bufX + pr * SX + pc * 8) = xr;
+    if (j < n) *reinterpret_cast<bf16x8*>(aux + (size_t)j * H + pc * 8) = xr;
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    __syncthreads();
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(bufX + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)                                   // lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
+        *reinterpret_cast<f32x4*>(bufY + (m * 16 + (lane & 15)) * SYF + n0 + 4 * (lane >> 4)) = acc[m];
+    __syncthreads();
+    if (j < n) {
+        const float4 y0 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8);
+        const float4 y1 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8 + 4);
+        const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = (bf16_t)(__uint_as_float(w[i] << 16) + y[2 * i]);
+            o[2 * i + 1] = (bf16_t)(__uint_as_float(w[i] & 0xffff0000u) + y[2 * i + 1]);
+        }
+        *reinterpret_cast<bf16x8*>(out + (size_t)orow * H + pc * 8) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_segments, int32_t H, const void* Wn,
+                      const int32_t* idx, void* aux, void* out, dn_stream_t stream) {
+    DN_REQUIRE(num_segments >= 0 && num_segments < INT32_MAX, "dn_fold_tail: bad sizes");
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_fold_tail: H must be 64, 128 or 256");
+    if (num_segments == 0) return DN_OK;
+    DN_REQUIRE(part && part_ptr && Wn && idx && aux && out, "dn_fold_tail: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(Wn) | reinterpret_cast<uintptr_t>(aux) |
+                reinterpret_cast<uintptr_t>(out)) % 16 == 0, "dn_fold_tail: unaligned pointer");
+    const unsigned grid = (unsigned)dn_cdiv(num_segments, kSsRows);
+    hipStream_t st = (hipStream_t)stream;
+    const float* p = part;
+    const bf16_t *w = (const bf16_t*)Wn;
+    bf16_t *a = (bf16_t*)aux, *o = (bf16_t*)out;
+    const int32_t n = (int32_t)num_segments;
+    if (H == 256) hipLaunchKernelGGL((fold_tail_kernel<256>), dim3(grid), dim3(1024), 0, st, p, part_ptr, w, idx, n, a, o);
+    else if (H == 128) hipLaunchKernelGGL((fold_tail_kernel<128>), dim3(grid), dim3(512), 0, st, p, part_ptr, w, idx, n, a, o);
+    else hipLaunchKernelGGL((fold_tail_kernel<64>), dim3(grid), dim3(256), 0, st, p, part_ptr, w, idx, n, a, o);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
 
 int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream) {
     DN_REQUIRE(numel >= 0 && numel % 8 == 0, "dn_relu_bwd: numel must be a non-negative multiple of 8");
@@ -1218,7 +1361,9 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
 }
 
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
-                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream) {
+                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, const uint8_t* local_of_node,
+                         const int32_t* tile_part, float* seg_part, dn_stream_t stream) {
+    DN_REQUIRE(local_of_node == nullptr || (tile_part != nullptr && seg_part != nullptr), "dn_rows_selfsum: local_of_node needs tile_part and seg_part");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_selfsum: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_selfsum: unsupported width %d (64/128/256 only)", H);
     DN_REQUIRE(num_slots == kSsSlots, "dn_rows_selfsum: the slot table must have %d columns", kSsSlots);
@@ -1231,9 +1376,9 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,
                  *s2 = (const bf16_t*)S2;
-    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
-    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
-    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, st);
+    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
+    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
+    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
 }
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,

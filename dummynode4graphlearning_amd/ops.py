@@ -256,18 +256,18 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     return (out, colsum) if colsum_of else out
 
 
-def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False):
+def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False, skip_mask=0):
     """Tile (step = 32) / chunk tables of relation-major rows built ON THE DEVICE (dn_row_tables_build_i32): returns
     (table [M, 4] int32, M) or (table, piece_ptr [num_rels + 1], M) with M = the upper bound rows / step + num_rels --
-    unused entries are empty pieces, which every consumer skips."""
+    unused entries are empty pieces, which every consumer skips.  skip_mask: bit r leaves relation r out."""
     require_gpu(rel_ptr_dev)
     _i32(rel_ptr_dev, "rel_ptr")
     dev = rel_ptr_dev.device
     M = int(num_rows) // int(step) + int(num_rels) + 1
     table = torch.empty((M, 4), dtype=I32, device=dev)
     pptr = torch.empty(int(num_rels) + 1, dtype=I32, device=dev) if want_ptr else None
-    check(lib().dn_row_tables_build_i32(int(num_rels), ptr(rel_ptr_dev), int(step), M, ptr(table), ptr(pptr), stream_ptr()),
-          "dn_row_tables_build_i32")
+    check(lib().dn_row_tables_build_i32(int(num_rels), ptr(rel_ptr_dev), int(step), M, ptr(table), ptr(pptr), int(skip_mask),
+                                        stream_ptr()), "dn_row_tables_build_i32")
     return (table, pptr, M) if want_ptr else (table, M)
 
 
@@ -323,9 +323,16 @@ SELFSUM_SLOTS = 6
 SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 
-def rows_selfsum(x, Wn, bias, S, S2, slots, out=None):
-    """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows)."""
+def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None):
+    """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
+    seg = (local_of_node uint8 [N], tile_part [ceil(N/32), 2], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column
+    sums of x (the folded pre-aggregation, see the header)."""
     require_gpu(x, Wn, bias, S, S2, slots)
+    if seg is not None:
+        require_gpu(*seg)
+        assert seg[0].dtype == torch.uint8 and seg[0].numel() == x.shape[0] and seg[1].dtype == I32
+        assert seg[1].shape == ((x.shape[0] + 31) // 32, 2) and seg[1].is_contiguous()
+        assert seg[2].dtype == torch.float32 and seg[2].shape[1] == x.shape[1] and seg[2].is_contiguous()
     N, H = x.shape
     assert x.dtype == torch.bfloat16 and Wn.shape == (H, H) and slots.shape == (N, SELFSUM_SLOTS) and slots.dtype == I32
     x, Wn, slots = x.contiguous(), Wn.contiguous(), slots.contiguous()
@@ -335,8 +342,9 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None):
 
     def _launch():
         check(lib().dn_rows_selfsum_bf16(ptr(x), H, ptr(Wn), ptr(bias), ptr(S) if S is not None and S.numel() else None,
-                                         ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out), stream_ptr()),
-              "dn_rows_selfsum_bf16")
+                                         ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out),
+                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None,
+                                         ptr(seg[2]) if seg else None, stream_ptr()), "dn_rows_selfsum_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_selfsum", _launch)
     else:
@@ -372,11 +380,11 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     return (Y1, Y2, bits1, bits2) if want_bits else (Y1, Y2)
 
 
-def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS):
+def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0)):
     """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16 (dn_slot_table_build_i32, one C-ABI call):
     (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).  Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more
     than K rows keeps its first K-1 and gets the id num_edge_rows + j of overflow row j in its last slot (ovf_ptr/ovf_idx:
-    CSR of the rows to pre-sum into it)."""
+    CSR of the rows to pre-sum into it).  drop = (beg, end): rows of that range are left out too."""
     require_gpu(list_ptr, list_rows)
     dev = list_rows.device
     N, P = int(num_nodes), int(num_edge_rows)
@@ -386,8 +394,9 @@ def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SL
     ovf_idx = torch.empty(max(int(list_rows.numel()), 1), dtype=I32, device=dev)
     ws = _ws(lib().dn_slot_table_workspace_bytes(N), dev)
     counts = (ctypes.c_int64 * 2)()
-    check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), ptr(slots), ptr(ovf_ptr), ptr(ovf_idx), counts,
-                                        ptr(ws), ws.numel(), stream_ptr()), "dn_slot_table_build_i32")
+    check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), int(drop[0]), int(drop[1]), ptr(slots),
+                                        ptr(ovf_ptr), ptr(ovf_idx), counts, ptr(ws), ws.numel(), stream_ptr()),
+          "dn_slot_table_build_i32")
     n_ovf, n_rows = int(counts[0]), int(counts[1])
     if n_ovf == 0:
         return slots, None, None, 0
@@ -863,20 +872,69 @@ class RowIndex:
         rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
         self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
         self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
-        self._slots = {}
+        self._slots, self._fold = {}, {}
         # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
         self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all,
                                             max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)), want_ptr=True)
 
 
 def _row_index_slots(ix, direction):
-    """Slot tables of a RowIndex for the fused closing launch ('f': rows into each destination, 'b': rows out of each source)."""
+    """Slot tables of a RowIndex for the fused closing launch ('f': rows into each destination, 'b': rows out of each source).
+    The rows of a FOLDED relation (_row_index_fold) are left out: they are added by the tail launches."""
     t = ix._slots.get(direction)
     if t is None:
         ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
-        t = build_slot_table(ptr_, rows, ix.num_nodes, ix.num_edge_rows)
+        fold = _row_index_fold(ix, direction)
+        t = build_slot_table(ptr_, rows, ix.num_nodes, ix.num_edge_rows, drop=(fold.beg, fold.end) if fold else (0, 0))
         ix._slots[direction] = t
     return t
+
+
+# The collapsed relation of a dummy-augmented batch (u -> dummy forward, dummy -> u backward) needs the SUM of a graph's rows as
+# its input row.  As a launch of its own (gather_segsum over the aux lists) that is a second full read of x (config 5: 0.5 GB,
+# ~100 us per direction); the closing launch reads every x row anyway, so it can produce those sums on the side.
+FOLD_ENABLED = _os.environ.get("DN_FOLD", "1") != "0"
+
+
+class _Fold:
+    """Tables of one folded relation: rows [beg, end) of the row set, one per segment (graph)."""
+    __slots__ = ("rel", "beg", "end", "n", "local_of_node", "tile_part", "part_ptr", "num_parts", "main_tiles", "add_idx")
+
+
+def _row_index_fold(ix, direction):
+    """The relation whose pre-aggregation the closing launch can absorb, or None: exactly ONE collapsed relation in this
+    direction (AGG forward / TF backward), its aux lists contiguous ascending node ranges (a graph's nodes), bf16 self-loop path.
+    One device -> host read-back (the contiguity check) when the index is built."""
+    if direction in ix._fold:
+        return ix._fold[direction]
+    info = None
+    mode = RowIndex.AGG if direction == "f" else RowIndex.TF
+    aux_ptr, aux_idx, n_aux = ((ix.aux_f_ptr, ix.aux_f_idx, ix.num_aux_f) if direction == "f"
+                               else (ix.aux_b_ptr, ix.aux_b_idx, ix.num_aux_b))
+    rels = [r for r, m in enumerate(ix.modes) if m == mode and ix.rel_ptr_host[r + 1] > ix.rel_ptr_host[r]]
+    if (FOLD_ENABLED and ix.self_loop and len(rels) == 1 and ix.num_rels <= 64 and n_aux > 0
+            and getattr(ix, "pipe", None) is None):
+        r = rels[0]
+        beg, end = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
+        N, dev = ix.num_nodes, aux_idx.device
+        lon = torch.empty(N, dtype=torch.uint8, device=dev)
+        tile_part = torch.empty(((N + 31) // 32, 2), dtype=I32, device=dev)
+        part_ptr = torch.empty(n_aux + 1, dtype=I32, device=dev)
+        ws = _ws(lib().dn_fold_tables_workspace_bytes(n_aux), dev)
+        ok = ctypes.c_int32(0)
+        check(lib().dn_fold_tables_build_i32(N, n_aux, ptr(aux_ptr), ptr(aux_idx), ptr(lon), ptr(tile_part), ptr(part_ptr),
+                                             ctypes.byref(ok), ptr(ws), ws.numel(), stream_ptr()), "dn_fold_tables_build_i32")
+        if ok.value == 1 and end - beg == n_aux:
+            info = _Fold()
+            info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
+            info.local_of_node, info.tile_part, info.part_ptr = lon, tile_part, part_ptr
+            info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
+            #                                                    starts one partial row, every tile boundary inside one another
+            rel_ptr_d = torch.tensor(ix.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
+            info.main_tiles = build_row_tables(rel_ptr_d, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+            info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+    ix._fold[direction] = info
+    return info
 
 
 RowIndex.slots = _row_index_slots
@@ -1190,6 +1248,40 @@ def _selfsum_ok(ix, x):
     return SELFSUM_ENABLED and ix.self_loop and x.dtype == torch.bfloat16
 
 
+def fold_tail(part, part_ptr, num_segments, Wn, idx, out):
+    """aux[j] = sum of partial rows part_ptr[j] .. part_ptr[j+1] in order;  out[idx[j]] += aux[j] @ Wn^T  (dn_fold_tail_bf16).
+    Returns aux (bf16)."""
+    require_gpu(part, part_ptr, Wn, idx, out)
+    H = part.shape[1]
+    assert part.dtype == torch.float32 and part_ptr.dtype == I32 and idx.dtype == I32 and idx.numel() == num_segments
+    assert out.dtype == torch.bfloat16 and Wn.dtype == torch.bfloat16 and Wn.shape == (H, H) and out.shape[1] == H
+    assert out.is_contiguous() and Wn.is_contiguous() and part.is_contiguous()
+    aux = torch.empty((num_segments, H), dtype=torch.bfloat16, device=part.device)
+
+    def _launch():
+        check(lib().dn_fold_tail_bf16(ptr(part), ptr(part_ptr), int(num_segments), H, ptr(Wn), ptr(idx), ptr(aux), ptr(out),
+                                      stream_ptr()), "dn_fold_tail_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("fold_tail", _launch)
+    else:
+        _launch()
+    return aux
+
+
+def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
+    """message_pass with the collapsed relation's pre-aggregation absorbed by the closing launch: transform of every other
+    relation -> closing launch (+ per-graph column sums of xs) -> tail launch (combine the sums, transform the one row per graph,
+    add each product to its node).  Same sums as the unfolded path up to bf16 rounding of the collapsed rows."""
+    fold = _row_index_fold(ix, direction)
+    P, H = ix.num_edge_rows, xs.shape[1]
+    Y = rows_transform(xs, Wmat, fold.main_tiles, P, idx=idx_rows, tag="conv", out=ybuf)
+    slots, optr, oidx, novf = ix.slots(direction)
+    ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
+    part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
+    rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out, seg=(fold.local_of_node, fold.tile_part, part))
+    return fold_tail(part, fold.part_ptr, fold.n, Wmat[fold.rel], fold.add_idx, out)
+
+
 def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
     """One direction of the row-factorised pass over one RowIndex -- the launches that ARE the layer's gather-scatter:
          'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          Wmat = W^T per relation ([R', out, in])
@@ -1202,6 +1294,8 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
+    if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction) is not None:
+        return _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows)
     aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
     pipe = _pipe_of(ix, xs)
     if pipe is not None and rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):

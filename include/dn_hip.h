@@ -226,22 +226,24 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * split-K chunk size), built on the device from rel_ptr [num_rels + 1] (device): entry i = {rel, beg, end, 0}.  The caller
  * sizes `table` by the upper bound max_entries >= rows / step + num_rels; unused entries become empty pieces (beg == end) of
  * the last relation.  piece_ptr (may be NULL) receives the [num_rels + 1] piece ranges per relation (dn_rows_wgrad_*'s
- * chunk_ptr).  Replaces the per-batch bookkeeping DGL does inside dgl.batch / update_all
+ * chunk_ptr).  skip_mask: bit r set (r < 64) leaves relation r out of the table (no pieces) -- the relation a caller handles
+ * in a launch of its own.  Replaces the per-batch bookkeeping DGL does inside dgl.batch / update_all
  * (subgraph_isomorphism/dataset.py:1605-1611, models/rgin.py:156-160); no device -> host synchronisation. */
 int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,
-                            int32_t* piece_ptr, dn_stream_t stream);
+                            int32_t* piece_ptr, uint64_t skip_mask, dn_stream_t stream);
 
 /* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build; replaces the reference's
  * per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`, subgraph_isomorphism/models/rgin.py:137).
  * list_ptr [N+1] / list_rows: CSR of row ids per node (dn_row_index_build_i32's dst_ptr/dst_rows or src_ptr/src_rows).
- * Rows >= num_edge_rows (the self-loop rows) are dropped.  slots [N, K]: the kept rows, -1 padded; a node with more than K
+ * Rows >= num_edge_rows (the self-loop rows) and rows in [drop_beg, drop_end) (a relation the caller adds in a launch of its
+ * own; drop_beg == drop_end for none) are dropped.  slots [N, K]: the kept rows, -1 padded; a node with more than K
  * kept rows keeps its first K-1 and gets num_edge_rows + j in slot K-1, j = its rank among such nodes, whose remaining rows
  * form the CSR (ovf_ptr [<= N+1], ovf_idx [<= len(list_rows)]) the caller pre-sums into overflow row j.
  * host_counts[0] = number of overflowing nodes, [1] = rows in the overflow CSR (the call synchronises the stream). */
 size_t dn_slot_table_workspace_bytes(int64_t N);
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx, int64_t* host_counts, void* workspace,
-                            size_t workspace_bytes, dn_stream_t stream);
+                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
+                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
@@ -287,9 +289,38 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * Wn is [H][H] with k contiguous.  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
  * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  Nodes with
  * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 6.
- * H in {64, 128, 256}. */
+ * H in {64, 128, 256}.
+ * Folded pre-aggregation (local_of_node != NULL): the launch also sums the X rows it reads per SEGMENT -- the input row of a
+ * collapsed relation (all nodes of a graph -> its dummy node: one row per graph whose input is the sum of the graph's rows,
+ * the reference's per-edge messages of the dummy edge type, rgin.py:102-120 on dataset.py:1563-1603's dummy edges) -- so the
+ * separate pass over X that dn_gather_segsum_bf16 would make disappears.  Segments must be CONTIGUOUS ascending row ranges;
+ * the caller numbers the (segment, 32-row tile) pairs that share a row ("partial rows"), segment-major, so that a tile's pairs
+ * are consecutive: tile_part [ceil(N/32)][2] = {first partial row, number of partial rows} of each tile, local_of_node [N]
+ * (uint8) = a row's partial row minus its tile's first one (255: the row belongs to no segment).  The launch writes the fp32
+ * column sums of every pair to seg_part[pair * H ...] (one extra MFMA per wave with a 0/1 indicator operand);
+ * dn_fold_tail_bf16 adds a segment's partial rows in tile order: deterministic. */
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
-                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, dn_stream_t stream);
+                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out,
+                         const uint8_t* local_of_node, const int32_t* tile_part, float* seg_part, dn_stream_t stream);
+
+/* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
+ * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph
+ * that feed / are fed by its dummy node, subgraph_isomorphism/dataset.py:1563-1603).  host_ok = 1 when every segment is a
+ * non-empty contiguous ascending run of rows and the segments ascend -- otherwise the outputs are undefined and the caller keeps
+ * the separate dn_gather_segsum pass.  Outputs: local_of_node [N] uint8, tile_part [ceil(N/32)][2] as dn_rows_selfsum_bf16 reads
+ * them, part_ptr [num_segments + 1] = the partial-row range of each segment (dn_fold_tail_bf16).  The number of partial rows
+ * is at most 2 * num_segments + N / 32 + 1.  The call synchronises the stream. */
+size_t dn_fold_tables_workspace_bytes(int64_t num_segments);
+int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                             uint8_t* local_of_node, int32_t* tile_part, int32_t* part_ptr, int32_t* host_ok, void* workspace,
+                             size_t workspace_bytes, dn_stream_t stream);
+
+/* Tail of a folded pre-aggregation, one launch:  aux[j, :] = bf16( sum_{k in [part_ptr[j], part_ptr[j+1])} part[k, :] ) in k
+ * order (kept by the caller: the collapsed relation's operand of dn_rows_wgrad_bf16), then the relation's transform of those
+ * rows added to their one output row each:  out[idx[j], :] += aux[j, :] @ Wn^T   (Wn [H][H], k contiguous; idx distinct; the
+ * fp32 product is added to the bf16 row and rounded once).  H in {64, 128, 256}. */
+int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_segments, int32_t H, const void* Wn,
+                      const int32_t* idx, void* aux, void* out, dn_stream_t stream);
 
 /* One direction of the row-factorised message pass as ONE persistent launch in which the transformed edge rows travel from
  * their producers to their consumers through the XCD's L2 instead of HBM (csrc/dn_pipe.hip has the design note):

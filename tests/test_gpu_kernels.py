@@ -546,3 +546,87 @@ def test_linear_any_matches_torch(K, N_, dt):
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
     torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=2e-2 if dt == torch.bfloat16 else 1e-4, atol=1.0 if dt == torch.bfloat16 else 2e-2)
     torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=2e-2 if dt == torch.bfloat16 else 1e-4, atol=1.0 if dt == torch.bfloat16 else 2e-2)
+
+
+def _dummy_batch(rng, sizes, R, deg=2):
+    """Graphs of the given sizes, each followed by its dummy node (edges u -> dummy of type R, dummy -> u of type R + 1): the
+    layout dn_dummy_augment produces (dummy node last in its graph).  Ordinary edges are permutations of a graph's nodes, so
+    the ordinary relations have (almost) no shared endpoints and stay one-row-per-edge."""
+    src, dst, et, base = [], [], [], 0
+    for n in sizes:
+        for _ in range(deg):
+            src += list(base + np.arange(n)); dst += list(base + rng.permutation(n)); et += [int(rng.integers(0, R))] * n
+        d = base + n
+        src += list(range(base, d)) + [d] * n; dst += [d] * n + list(range(base, d)); et += [R] * n + [R + 1] * n
+        base = d + 1
+    return np.array(src), np.array(dst), np.array(et), base
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_folded_pre_aggregation_matches_the_separate_pass(H):
+    """The closing launch's per-graph column sums (dn_rows_selfsum_bf16 with seg_of_node + combine / transform / add tail) against
+    (a) the path with a separate dn_gather_segsum pass and (b) fp64 per-edge math; run twice: bitwise reproducible.  Graph sizes
+    straddle the 32-row tiles in every way (1-node graphs, graphs longer than two tiles, a boundary exactly at a tile edge)."""
+    ops = _ops()
+    rng = np.random.default_rng(H)
+    sizes = [31, 1, 1, 29, 70, 3, 31, 64, 2, 127] + list(rng.integers(1, 60, size=40))
+    R = 5
+    src, dst, et, N = _dummy_batch(rng, sizes, R)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, coef = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((N, H)))
+    W = bf(rng.standard_normal((R + 3, H, H)) / np.sqrt(H))
+    b = bf(rng.standard_normal(H))
+    s, d, t = (torch.from_numpy(a).to(DEV) for a in (src, dst, et))
+
+    def run(fold):
+        old = ops.FOLD_ENABLED
+        ops.FOLD_ENABLED = fold
+        try:
+            index = ops.RowIndex(s, d, t, N, R + 2, self_loop=True)
+            xd, Wd, bd = (v.to(DEV).requires_grad_(True) for v in (x, W, b))
+            out = ops.rel_transform_fused(xd, Wd, bd, index)
+            out.backward(coef.to(DEV))
+            folded = tuple(ops._row_index_fold(index, k) is not None for k in "fb")
+            return index, folded, [v.detach().cpu() for v in (out, xd.grad, Wd.grad, bd.grad)]
+        finally:
+            ops.FOLD_ENABLED = old
+
+    index, folded, got = run(True)
+    assert folded == (True, True)
+    assert index.modes[R] == ops.RowIndex.AGG and index.modes[R + 1] == ops.RowIndex.TF
+    _, folded0, plain = run(False)
+    assert folded0 == (False, False)
+    _, _, again = run(True)
+    for a, c in zip(got, again):
+        assert torch.equal(a, c)
+    xr, Wr, br = (v.double().requires_grad_(True) for v in (x, W, b))
+    st, dt_, tt = (torch.from_numpy(a) for a in (src, dst, et))
+    ref = torch.zeros(N, H, dtype=torch.float64).index_add(0, dt_, torch.bmm(xr[st].unsqueeze(1), Wr[tt]).squeeze(1))
+    ref = ref + xr @ Wr[R + 2] + br
+    ref.backward(coef.double())
+    for name, a, p, r in zip(("out", "gx", "gW", "gb"), got, plain, (ref, xr.grad, Wr.grad, br.grad)):
+        scale = float(r.abs().max())
+        e_ref, e_plain = float((a.double() - r.detach()).abs().max()) / scale, float((p.double() - r.detach()).abs().max()) / scale
+        assert e_ref < 2e-2, (name, e_ref)
+        assert e_ref < 2.0 * e_plain + 1e-3, (name, e_ref, e_plain)          # as accurate as the path it replaces
+
+
+def test_fold_is_refused_when_a_graph_is_not_a_contiguous_node_range():
+    """Interleaved node numbering (the dummy node's sources are every other node): the separate pass stays."""
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    N, H, R = 400, 64, 2
+    src, dst, et = list(rng.integers(0, N - 2, size=900)), list(rng.integers(0, N - 2, size=900)), list(rng.integers(0, R, size=900))
+    for dummy, members in ((N - 2, range(0, N - 2, 2)), (N - 1, range(1, N - 2, 2))):
+        src += list(members); dst += [dummy] * len(members); et += [R] * len(members)
+    s, d, t = (torch.tensor(a, device=DEV) for a in (src, dst, et))
+    index = ops.RowIndex(s, d, t, N, R + 1, self_loop=True)
+    assert index.modes[R] == ops.RowIndex.AGG
+    assert ops._row_index_fold(index, "f") is None
+    x = torch.randn(N, H, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(R + 2, H, H, device=DEV) / 8).to(torch.bfloat16)
+    out = ops.rel_transform_fused(x, W, None, index)
+    ref = torch.zeros(N, H, dtype=torch.float64).index_add(
+        0, torch.tensor(dst), torch.bmm(x.cpu().double()[torch.tensor(src)].unsqueeze(1), W.cpu().double()[torch.tensor(et)]).squeeze(1))
+    ref = ref + x.cpu().double() @ W.cpu().double()[R + 1]
+    assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-2
