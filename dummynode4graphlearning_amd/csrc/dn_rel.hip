@@ -491,6 +491,10 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
 //   consecutive output columns of one row, and the finished tile goes through LDS to be written as whole
 //   512-byte rows.
 // -------------------------------------------------------------------------------------------------
+// (An LDS-DMA ring version of this kernel -- 3 or 4 16 KB stages in flight per workgroup instead of one register-staged tile,
+//  96 KB per CU -- ran at the same 390-397 us per config-5 launch as this one: the launch moves 1.03 GB of gathered rows in and
+//  1.07 GB of Y rows out at 5.4 TB/s combined, which is what a mixed read/write stream reaches on this part (a device-to-device
+//  copy: 5.2 TB/s, torch add: 6.2), not a bytes-in-flight limit.  Not kept.)
 constexpr int kTfThreads = 512;   // 8 waves, each owning HO/8 output columns
 constexpr int kTfRows = 32;
 
