@@ -63,9 +63,9 @@ _SIGS = {
     "dn_rows_transform_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, P]),
     "dn_relu_bwd_bf16": (ctypes.c_int, [P, P, P, c_i64, P]),
     "dn_rows_chain2_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, P, P, P]),
-    "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P, P, P, P]),
+    "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P, P, P]),
     "dn_fold_tables_workspace_bytes": (c_sz, [c_i64]),
-    "dn_fold_tables_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P, ctypes.POINTER(ctypes.c_int32), P, c_sz, P]),
+    "dn_fold_tables_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, ctypes.POINTER(ctypes.c_int32), P, c_sz, P]),
     "dn_fold_tail_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, P]),
     "dn_rows_pipe_sync_words": (c_sz, [c_i64]),
     "dn_rows_pipe_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, P, P, P, c_i32, c_i32, P, c_i64, P, c_i64, P, P, P, P,

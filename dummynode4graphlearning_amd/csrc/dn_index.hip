@@ -719,11 +719,17 @@ __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t*
     }
 }
 
-// ---- tables of a folded pre-aggregation (dn_rows_selfsum_bf16 with local_of_node) -----------------------------------------
+// ---- tables of a folded pre-aggregation (dn_rows_selfsum_bf16 with fold_info) ---------------------------------------------
 // Segment j = nodes seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (a graph's nodes: the sources of its dummy node).  Valid only if every
 // segment is a non-empty contiguous ascending run and the segments ascend; then the (segment, 32-row tile) pairs that share a
 // row, numbered segment-major, are consecutive within each tile.
 constexpr int kFoldTile = 32;                                    // rows per tile of the closing launch (kSsRows in dn_rel.hip)
+constexpr int kFoldInfo = 12;                                    // int32 words per tile record (kFoldInfo in dn_rel.hip)
+
+__global__ void fold_init_kernel(int64_t tiles, int32_t* __restrict__ info) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < tiles * kFoldInfo) info[i] = (i % kFoldInfo) < 8 ? -1 : 0;       // ids 255 ("no segment"), {first, count, 0, 0} = 0
+}
 
 __device__ __forceinline__ void fold_seg_span(const int32_t* ptr, const int32_t* nodes, int64_t j, int32_t& first, int32_t& last) {
     first = nodes[ptr[j]];
@@ -760,7 +766,8 @@ __global__ void fold_check_kernel(int64_t n, const int32_t* __restrict__ ptr, co
 
 __global__ void fold_fill_kernel(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nodes,
                                  const int32_t* __restrict__ pptr, const int32_t* __restrict__ ok,
-                                 uint8_t* __restrict__ local_of_node, int32_t* __restrict__ tile_part) {
+                                 int32_t* __restrict__ info) {
+    uint8_t* ids = reinterpret_cast<uint8_t*>(info);
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= n || *ok == 0) return;
     int32_t first, last;
@@ -775,7 +782,8 @@ __global__ void fold_fill_kernel(int64_t n, const int32_t* __restrict__ ptr, con
         lo0 = pptr[k] + (t0 - f / kFoldTile);
         if (f / kFoldTile != t0) break;                          // started in an earlier tile: nothing before it is in t0
     }
-    for (int32_t v = first; v <= last; ++v) local_of_node[v] = (uint8_t)(v / kFoldTile == t0 ? p - lo0 : 0);
+    for (int32_t v = first; v <= last; ++v)
+        ids[(size_t)(v / kFoldTile) * (kFoldInfo * 4) + v % kFoldTile] = (uint8_t)(v / kFoldTile == t0 ? p - lo0 : 0);
     // {first partial row, count} of a tile is written by the LAST segment with a row in it
     for (int32_t t = t0; t <= t1; ++t) {
         bool is_last = t < t1;
@@ -785,8 +793,8 @@ __global__ void fold_fill_kernel(int64_t n, const int32_t* __restrict__ ptr, con
         }
         if (is_last) {
             const int32_t mine = p + (t - t0), lo = t == t0 ? lo0 : mine;
-            tile_part[2 * t] = lo;
-            tile_part[2 * t + 1] = mine - lo + 1;
+            info[(size_t)t * kFoldInfo + 8] = lo;
+            info[(size_t)t * kFoldInfo + 9] = mine - lo + 1;
         }
     }
 }
@@ -1245,13 +1253,13 @@ size_t dn_fold_tables_workspace_bytes(int64_t num_segments) {
 }
 
 int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                             uint8_t* local_of_node, int32_t* tile_part, int32_t* part_ptr, int32_t* host_ok, void* workspace,
-                             size_t workspace_bytes, dn_stream_t stream) {
+                             int32_t* fold_info, int32_t* part_ptr, int32_t* host_ok, void* workspace, size_t workspace_bytes,
+                             dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_tables_build: bad sizes");
     DN_REQUIRE(host_ok, "dn_fold_tables_build: NULL pointer");
     *host_ok = 0;
     if (N == 0 || num_segments == 0) return DN_OK;
-    DN_REQUIRE(seg_ptr && seg_nodes && local_of_node && tile_part && part_ptr && workspace, "dn_fold_tables_build: NULL pointer");
+    DN_REQUIRE(seg_ptr && seg_nodes && fold_info && part_ptr && workspace, "dn_fold_tables_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Arena a(workspace, workspace_bytes);
     int32_t* ntile = a.take<int32_t>(num_segments + 1);
@@ -1262,8 +1270,8 @@ int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg
     if (!a.ok()) { dn_set_error("dn_fold_tables_build: workspace too small"); return DN_ERR_WORKSPACE; }
     const int64_t tiles = dn_cdiv(N, kFoldTile);
     DN_CHECK_HIP(hipMemsetAsync(ok, 0x01, sizeof(int32_t), st));                 // any non-zero value: "still valid"
-    DN_CHECK_HIP(hipMemsetAsync(local_of_node, 0xff, (size_t)N, st));
-    DN_CHECK_HIP(hipMemsetAsync(tile_part, 0, (size_t)tiles * 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(fold_init_kernel, dim3(grid_for(tiles * kFoldInfo)), dim3(kBlock), 0, st, tiles, fold_info);
+    DN_CHECK_LAUNCH();
     hipLaunchKernelGGL(fold_count_kernel, dim3(grid_for(num_segments + 1)), dim3(kBlock), 0, st, num_segments, N, seg_ptr, seg_nodes,
                        ntile, ok);
     DN_CHECK_LAUNCH();
@@ -1271,7 +1279,7 @@ int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(excl_scan(temp, tb, ntile, part_ptr, num_segments + 1, st));
     hipLaunchKernelGGL(fold_fill_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, part_ptr,
-                       ok, local_of_node, tile_part);
+                       ok, fold_info);
     DN_CHECK_LAUNCH();
     int32_t h = 0;
     DN_CHECK_HIP(hipMemcpyAsync(&h, ok, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -687,6 +687,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
 // -------------------------------------------------------------------------------------------------
 constexpr int kSsRows = 32;
 constexpr int kSsSlots = 6;
+constexpr int kFoldInfo = 12;   // int32 words per tile of the fold table (dn_fold_tables_build_i32)
 
 // DN_STRIDE (default 1): dense-row launches deal tiles round-robin over the workgroups instead of contiguous ranges
 static bool stride_tiles() {
@@ -701,8 +702,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
                                                              const int32_t* __restrict__ slots, int32_t N,
                                                              int32_t num_tiles, int32_t tiles_per_wg,
                                                              bf16_t* __restrict__ out, int32_t nt,
-                                                             const uint8_t* __restrict__ local_of_node,
-                                                             const int32_t* __restrict__ tile_part,
+                                                             const int32_t* __restrict__ fold_info,
                                                              float* __restrict__ seg_part) {
     constexpr int T = H * 4, K = kSsSlots;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -711,7 +711,11 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
     constexpr int LPR = H / 8;                                   // 16-byte pieces per row
     static_assert(kSsRows * LPR == T, "one piece per thread");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kSsRows * SX + kSsRows * SY];
-    __shared__ __attribute__((aligned(8))) uint8_t segB[2][kSsRows];        // FOLD: partial row of each tile row, minus p0 (255: none)
+    __shared__ __attribute__((aligned(16))) float biasL[H];
+    __shared__ int2 slotL[3][T];                                             // the next tile's slot ids, parked between their
+                                                                             // arrival and the top of the next iteration
+    __shared__ __attribute__((aligned(16))) int32_t segI[2][kFoldInfo];      // FOLD: the tile's record (see dn_hip.h): 32 local
+                                                                             // partial-row ids (bytes), first partial row, count
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kSsRows * SX); };
     bf16_t* bufY = lds + 2 * kSsRows * SX;
 
@@ -731,11 +735,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};                          // bias of my 4 accumulator columns
-    if (bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = (float)bias[n0 + 4 * (lane >> 4) + i];
-    }
+    if (tid < H) biasL[tid] = bias ? (float)bias[tid] : 0.f;     // read back per tile: 4 fewer registers across the loop
 
     auto load_x = [&](int t) -> uint4 {
         const int p = rowbase(t) + pr;
@@ -752,19 +752,17 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         return v;
     };
 
-    auto load_seg = [&](int t) -> int32_t {                       // thread r < 32: the partial row of row r of tile t relative to
-        const int p = rowbase(t) + tid;                           // the tile's first one (255: none)
-        return (FOLD && tid < kSsRows && t < t_end && p < N) ? (int32_t)local_of_node[p] : 255;
-    };
-    auto load_tp = [&](int t) -> int2 {                           // the tile's {first partial row, count}: wave-uniform (scalar loads)
-        return (FOLD && t < t_end) ? *reinterpret_cast<const int2*>(tile_part + 2 * (first + t * step)) : make_int2(0, 0);
+    auto load_seg = [&](int t) -> int32_t {                       // thread i < kFoldInfo: word i of tile t's fold record
+        return (FOLD && tid < kFoldInfo && t < t_end) ? fold_info[(size_t)(first + t * step) * kFoldInfo + tid] : 0;
     };
     auto store_seg = [&](int b, int32_t v) {
-        if (tid < kSsRows) segB[b][tid] = (uint8_t)v;
+        if (tid < kFoldInfo) segI[b][tid] = v;
     };
-    int2 tp = load_tp(t_beg);
     uint4 rx = load_x(t_beg);
-    Slots sl = load_slots(t_beg);
+    {
+        const Slots s0 = load_slots(t_beg);
+        slotL[0][tid] = s0.a; slotL[1][tid] = s0.b; slotL[2][tid] = s0.c;
+    }
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
     if (FOLD) store_seg(0, load_seg(t_beg));
     rx = load_x(t_beg + 1);
@@ -773,10 +771,10 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
 
     for (int t = t_beg; t < t_end; ++t) {
         const int b = (t - t_beg) & 1;
-        const int2 tp_next = load_tp(t + 1);
         // (1) the slot rows of my piece
         uint4 g[K];
-        const int sid[K] = {sl.a.x, sl.a.y, sl.b.x, sl.b.y, sl.c.x, sl.c.y};
+        const int2 sa = slotL[0][tid], sb_ = slotL[1][tid], sc = slotL[2][tid];     // (my own entries: no barrier needed)
+        const int sid[K] = {sa.x, sa.y, sb_.x, sb_.y, sc.x, sc.y};
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             g[k] = make_uint4(0, 0, 0, 0);
@@ -790,7 +788,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         // (3) MFMAs: D = Wn_slice x rows^T, lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
         f32x4 acc[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bv[0], bv[1], bv[2], bv[3]};
+        for (int m = 0; m < MT; ++m) acc[m] = *reinterpret_cast<const f32x4*>(biasL + n0 + 4 * (lane >> 4));
         const bf16_t* xt = bufX(b);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -810,6 +808,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
             *reinterpret_cast<bf16x4*>(bufY + (m * 16 + (lane & 15)) * SY + n0 + 4 * (lane >> 4)) = o;
         }
         *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = rx;          // (zeros past the last tile)
+        slotL[0][tid] = sl_next.a; slotL[1][tid] = sl_next.b; slotL[2][tid] = sl_next.c;
         if (FOLD) store_seg(b ^ 1, sg_next);
         // (3b) column sums of this tile's X rows per SEGMENT (the rows a collapsed relation pre-aggregates: all nodes of a graph
         //      feeding its dummy node) -- the rows are in LDS anyway, so the separate pre-aggregation pass over X (0.5 GB per
@@ -818,9 +817,9 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
         //      partial row per (segment, tile); the partial rows of a tile's segments are consecutive (segments are contiguous
         //      ascending node ranges).  A tail launch adds a segment's partials in tile order.
         if (FOLD) {
-            const int p0 = tp.x, cnt = tp.y;
+            const int p0 = segI[b][8], cnt = __builtin_amdgcn_readfirstlane(segI[b][9]);
             if (cnt > 0) {
-                const uint2 sb = *reinterpret_cast<const uint2*>(&segB[b][8 * (lane >> 4)]);    // my 8 rows' local ids
+                const uint2 sb = *reinterpret_cast<const uint2*>(&segI[b][2 * (lane >> 4)]);    // my 8 rows' local ids
                 const bf16x8 xf = tr_frag(bufX(b), SX, n0, lane);  // element j: X[8*(lane>>4) + j][n0 + (lane & 15)]
                 for (int m0 = 0; m0 < cnt; m0 += 16) {             // (more than 16 segments in 32 rows: graphs of 1-2 nodes)
                     const uint32_t me = (uint32_t)(m0 + (lane & 15));
@@ -835,7 +834,6 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
                 }
             }
         }
-        tp = tp_next;
         rx = load_x(t + 2);
         sg_next = load_seg(t + 2);
         __syncthreads();
@@ -865,26 +863,25 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
             if (nt & 1) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(out + (size_t)p * H + pc * 8));
             else *reinterpret_cast<bf16x8*>(out + (size_t)p * H + pc * 8) = o;
         }
-        sl = sl_next;
         __syncthreads();                                         // bufY is rewritten by the next tile's MFMA phase
     }
 }
 
 template <int H>
 int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const bf16_t* S, const bf16_t* S2, int32_t n1,
-                   const int32_t* slots, int64_t N, bf16_t* out, const uint8_t* local_of_node, const int32_t* tile_part,
-                   float* seg_part, hipStream_t st) {
+                   const int32_t* slots, int64_t N, bf16_t* out, const int32_t* fold_info, float* seg_part,
+                   hipStream_t st) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     static const int nt = dn_knob("DN_NT", 3);
     const int32_t tpw = (int32_t)(stride_tiles() ? 0 : tiles_per_wg);
-    if (local_of_node)
+    if (fold_info)
         hipLaunchKernelGGL((rows_selfsum_kernel<H, true>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, local_of_node, tile_part, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, fold_info, seg_part);
     else
         hipLaunchKernelGGL((rows_selfsum_kernel<H, false>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, local_of_node, tile_part, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, fold_info, seg_part);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1181,7 +1178,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__
 }
 
 
-// ---- tail of a folded pre-aggregation (dn_rows_selfsum_bf16 with local_of_node): per tile of 32 segments
+// ---- tail of a folded pre-aggregation (dn_rows_selfsum_bf16 with fold_info): per tile of 32 segments
 //        aux[j]       = bf16( sum of segment j's partial rows, tile order )          (kept: the weight gradient's operand)
 //        out[idx[j]] += aux[j] @ Wn^T                                               (fp32 product added to the bf16 row, one rounding)
 //      One workgroup per tile, H*4 threads: thread (pr, pc) sums its 8 columns of segment pr, the waves multiply like
@@ -1365,9 +1362,9 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
 }
 
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
-                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, const uint8_t* local_of_node,
-                         const int32_t* tile_part, float* seg_part, dn_stream_t stream) {
-    DN_REQUIRE(local_of_node == nullptr || (tile_part != nullptr && seg_part != nullptr), "dn_rows_selfsum: local_of_node needs tile_part and seg_part");
+                         int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, const int32_t* fold_info,
+                         float* seg_part, dn_stream_t stream) {
+    DN_REQUIRE(fold_info == nullptr || seg_part != nullptr, "dn_rows_selfsum: fold_info needs seg_part");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_selfsum: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_selfsum: unsupported width %d (64/128/256 only)", H);
     DN_REQUIRE(num_slots == kSsSlots, "dn_rows_selfsum: the slot table must have %d columns", kSsSlots);
@@ -1380,9 +1377,9 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,
                  *s2 = (const bf16_t*)S2;
-    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
-    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
-    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, local_of_node, tile_part, seg_part, st);
+    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
+    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
+    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
 }
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,

@@ -325,14 +325,13 @@ SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
-    seg = (local_of_node uint8 [N], tile_part [ceil(N/32), 2], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column
-    sums of x (the folded pre-aggregation, see the header)."""
+    seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
+    folded pre-aggregation, see the header)."""
     require_gpu(x, Wn, bias, S, S2, slots)
     if seg is not None:
         require_gpu(*seg)
-        assert seg[0].dtype == torch.uint8 and seg[0].numel() == x.shape[0] and seg[1].dtype == I32
-        assert seg[1].shape == ((x.shape[0] + 31) // 32, 2) and seg[1].is_contiguous()
-        assert seg[2].dtype == torch.float32 and seg[2].shape[1] == x.shape[1] and seg[2].is_contiguous()
+        assert seg[0].dtype == I32 and seg[0].shape == ((x.shape[0] + 31) // 32, 12) and seg[0].is_contiguous()
+        assert seg[1].dtype == torch.float32 and seg[1].shape[1] == x.shape[1] and seg[1].is_contiguous()
     N, H = x.shape
     assert x.dtype == torch.bfloat16 and Wn.shape == (H, H) and slots.shape == (N, SELFSUM_SLOTS) and slots.dtype == I32
     x, Wn, slots = x.contiguous(), Wn.contiguous(), slots.contiguous()
@@ -343,8 +342,8 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None):
     def _launch():
         check(lib().dn_rows_selfsum_bf16(ptr(x), H, ptr(Wn), ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                          ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out),
-                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None,
-                                         ptr(seg[2]) if seg else None, stream_ptr()), "dn_rows_selfsum_bf16")
+                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, stream_ptr()),
+              "dn_rows_selfsum_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_selfsum", _launch)
     else:
@@ -898,7 +897,7 @@ FOLD_ENABLED = _os.environ.get("DN_FOLD", "1") != "0"
 
 class _Fold:
     """Tables of one folded relation: rows [beg, end) of the row set, one per segment (graph)."""
-    __slots__ = ("rel", "beg", "end", "n", "local_of_node", "tile_part", "part_ptr", "num_parts", "main_tiles", "add_idx")
+    __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "add_idx")
 
 
 def _row_index_fold(ix, direction):
@@ -917,17 +916,16 @@ def _row_index_fold(ix, direction):
         r = rels[0]
         beg, end = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
         N, dev = ix.num_nodes, aux_idx.device
-        lon = torch.empty(N, dtype=torch.uint8, device=dev)
-        tile_part = torch.empty(((N + 31) // 32, 2), dtype=I32, device=dev)
+        fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
         part_ptr = torch.empty(n_aux + 1, dtype=I32, device=dev)
         ws = _ws(lib().dn_fold_tables_workspace_bytes(n_aux), dev)
         ok = ctypes.c_int32(0)
-        check(lib().dn_fold_tables_build_i32(N, n_aux, ptr(aux_ptr), ptr(aux_idx), ptr(lon), ptr(tile_part), ptr(part_ptr),
+        check(lib().dn_fold_tables_build_i32(N, n_aux, ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
                                              ctypes.byref(ok), ptr(ws), ws.numel(), stream_ptr()), "dn_fold_tables_build_i32")
         if ok.value == 1 and end - beg == n_aux:
             info = _Fold()
             info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-            info.local_of_node, info.tile_part, info.part_ptr = lon, tile_part, part_ptr
+            info.fold_info, info.part_ptr = fold_info, part_ptr
             info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
             #                                                    starts one partial row, every tile boundary inside one another
             rel_ptr_d = torch.tensor(ix.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
@@ -1278,7 +1276,7 @@ def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
     slots, optr, oidx, novf = ix.slots(direction)
     ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
-    rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out, seg=(fold.local_of_node, fold.tile_part, part))
+    rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out, seg=(fold.fold_info, part))
     return fold_tail(part, fold.part_ptr, fold.n, Wmat[fold.rel], fold.add_idx, out)
 
 

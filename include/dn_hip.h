@@ -290,30 +290,30 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  Nodes with
  * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 6.
  * H in {64, 128, 256}.
- * Folded pre-aggregation (local_of_node != NULL): the launch also sums the X rows it reads per SEGMENT -- the input row of a
+ * Folded pre-aggregation (fold_info != NULL): the launch also sums the X rows it reads per SEGMENT -- the input row of a
  * collapsed relation (all nodes of a graph -> its dummy node: one row per graph whose input is the sum of the graph's rows,
  * the reference's per-edge messages of the dummy edge type, rgin.py:102-120 on dataset.py:1563-1603's dummy edges) -- so the
  * separate pass over X that dn_gather_segsum_bf16 would make disappears.  Segments must be CONTIGUOUS ascending row ranges;
  * the caller numbers the (segment, 32-row tile) pairs that share a row ("partial rows"), segment-major, so that a tile's pairs
- * are consecutive: tile_part [ceil(N/32)][2] = {first partial row, number of partial rows} of each tile, local_of_node [N]
- * (uint8) = a row's partial row minus its tile's first one (255: the row belongs to no segment).  The launch writes the fp32
- * column sums of every pair to seg_part[pair * H ...] (one extra MFMA per wave with a 0/1 indicator operand);
- * dn_fold_tail_bf16 adds a segment's partial rows in tile order: deterministic. */
+ * are consecutive.  fold_info (dn_fold_tables_build_i32) holds one 12-word record per tile: 32 bytes = each row's partial row
+ * minus the tile's first one (255: the row belongs to no segment), then {first partial row, number of partial rows, 0, 0}.
+ * The launch writes the fp32 column sums of every pair to seg_part[pair * H ...] (one extra MFMA per wave with a 0/1 indicator
+ * operand); dn_fold_tail_bf16 adds a segment's partial rows in tile order: deterministic. */
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out,
-                         const uint8_t* local_of_node, const int32_t* tile_part, float* seg_part, dn_stream_t stream);
+                         const int32_t* fold_info, float* seg_part, dn_stream_t stream);
 
 /* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph
  * that feed / are fed by its dummy node, subgraph_isomorphism/dataset.py:1563-1603).  host_ok = 1 when every segment is a
  * non-empty contiguous ascending run of rows and the segments ascend -- otherwise the outputs are undefined and the caller keeps
- * the separate dn_gather_segsum pass.  Outputs: local_of_node [N] uint8, tile_part [ceil(N/32)][2] as dn_rows_selfsum_bf16 reads
- * them, part_ptr [num_segments + 1] = the partial-row range of each segment (dn_fold_tail_bf16).  The number of partial rows
- * is at most 2 * num_segments + N / 32 + 1.  The call synchronises the stream. */
+ * the separate dn_gather_segsum pass.  Outputs: fold_info [ceil(N/32)][12] int32 as dn_rows_selfsum_bf16 reads it, part_ptr
+ * [num_segments + 1] = the partial-row range of each segment (dn_fold_tail_bf16).  The number of partial rows is at most
+ * 2 * num_segments + N / 32 + 1.  The call synchronises the stream. */
 size_t dn_fold_tables_workspace_bytes(int64_t num_segments);
 int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                             uint8_t* local_of_node, int32_t* tile_part, int32_t* part_ptr, int32_t* host_ok, void* workspace,
-                             size_t workspace_bytes, dn_stream_t stream);
+                             int32_t* fold_info, int32_t* part_ptr, int32_t* host_ok, void* workspace, size_t workspace_bytes,
+                             dn_stream_t stream);
 
 /* Tail of a folded pre-aggregation, one launch:  aux[j, :] = bf16( sum_{k in [part_ptr[j], part_ptr[j+1])} part[k, :] ) in k
  * order (kept by the caller: the collapsed relation's operand of dn_rows_wgrad_bf16), then the relation's transform of those

@@ -4,7 +4,7 @@ for kv in "$@"; do export "$kv"; done
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $out.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 $BENCH_ARGS > $out.log 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then head -14 "$f" | python3 -c "
 import sys,csv
