@@ -491,28 +491,53 @@ int rel_layout(Arena& a, RelWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 // ----- row factorisation index (bf16 fused RGIN/RGCN path; see dn_hip.h dn_row_index_build_i32) -----------------
 constexpr int kModeEdge = 0, kModeAgg = 1, kModeTf = 2;
 
-__global__ void ri_key_kernel(int64_t E, int64_t N, const int32_t* __restrict__ node, const int32_t* __restrict__ etype,
-                              int32_t* key) {
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= E) return;
-    key[e] = (int32_t)((int64_t)etype[e] * N + node[e]);
+// per relation: #edges, #distinct destinations, #distinct sources -- what decides EDGE / AGG / TF.
+// No sorting: one bit per (relation, node) pair, set with atomicOr -- the lane that flips a bit
+// counts it.  Counts are order-independent, so the result is deterministic; per-block LDS histograms keep the R hot counters
+// off the global atomic path.
+constexpr int kStatsMaxR = 1024;
+__global__ void ri_stats_bitmap_kernel(int64_t E, int64_t N, int32_t R, const int32_t* __restrict__ src,
+                                       const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
+                                       unsigned int* __restrict__ bitsD, unsigned int* __restrict__ bitsS,
+                                       int32_t* __restrict__ Er, int32_t* __restrict__ Dr, int32_t* __restrict__ Sr) {
+    __shared__ int32_t h[3][kStatsMaxR];
+    const bool use_lds = R <= kStatsMaxR;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < 3 * kStatsMaxR; i += blockDim.x) (&h[0][0])[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = etype[e];
+        const int64_t kd = (int64_t)r * N + dst[e], ks = (int64_t)r * N + src[e];
+        const unsigned int md = 1u << (kd & 31), ms = 1u << (ks & 31);
+        const bool newd = !(atomicOr(&bitsD[kd >> 5], md) & md), news = !(atomicOr(&bitsS[ks >> 5], ms) & ms);
+        if (use_lds) {
+            atomicAdd(&h[0][r], 1);
+            if (newd) atomicAdd(&h[1][r], 1);
+            if (news) atomicAdd(&h[2][r], 1);
+        } else {
+            atomicAdd(&Er[r], 1);
+            if (newd) atomicAdd(&Dr[r], 1);
+            if (news) atomicAdd(&Sr[r], 1);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += blockDim.x) {
+            if (h[0][r]) atomicAdd(&Er[r], h[0][r]);
+            if (h[1][r]) atomicAdd(&Dr[r], h[1][r]);
+            if (h[2][r]) atomicAdd(&Sr[r], h[2][r]);
+        }
+    }
 }
-// per relation: #edges and #distinct (rel, node) pairs, read off the sorted keys + the exclusive scan of their run heads
-// (binary searches for the relation boundaries: no atomics, a 16-address histogram would serialise 4 M of them)
-__global__ void ri_rel_stats_kernel(int64_t R, int64_t N, int64_t E, const int32_t* __restrict__ skey,
-                                    const int32_t* __restrict__ head, const int32_t* __restrict__ head_scan, int32_t* out_E,
-                                    int32_t* out_distinct) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= R) return;
-    auto lower = [&](int64_t k) {
-        int64_t lo = 0, hi = E;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)skey[mid] < k) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    auto heads_before = [&](int64_t p) { return p >= E ? head_scan[E - 1] + head[E - 1] : head_scan[p]; };
-    const int64_t lo = lower(r * N), hi = lower((r + 1) * N);
-    if (out_E) out_E[r] = (int32_t)(hi - lo);
-    out_distinct[r] = heads_before(hi) - heads_before(lo);
+// the ten scan totals the host needs, packed so that ONE copy fetches them: out[k] = scan[k][E-1] + flag[k][E-1]
+__global__ void ri_totals_kernel(int64_t E, const int32_t* a0, const int32_t* a1, const int32_t* b0, const int32_t* b1,
+                                 const int32_t* c0, const int32_t* c1, const int32_t* d0, const int32_t* d1, const int32_t* e0,
+                                 const int32_t* e1, int32_t* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = a0[E - 1] + a1[E - 1]; out[1] = b0[E - 1] + b1[E - 1]; out[2] = c0[E - 1] + c1[E - 1];
+        out[3] = d0[E - 1] + d1[E - 1]; out[4] = e0[E - 1] + e1[E - 1];
+    }
 }
 __global__ void ri_mode_kernel(int64_t R, float edge_frac, const int32_t* __restrict__ Er, const int32_t* __restrict__ Dr,
                                const int32_t* __restrict__ Sr, int32_t* mode) {
@@ -542,8 +567,13 @@ __global__ void ri_flags_kernel(int64_t E, int64_t N, const int32_t* __restrict_
     agg_edge[i] = m == kModeAgg ? 1 : 0;
     tf_edge[i] = m == kModeTf ? 1 : 0;
 }
-// per sorted edge i (row = rows[i] = inclusive head count - 1): fill row tables at heads, aux lists, list entries
-__global__ void ri_fill_kernel(int64_t E, int64_t N, int64_t P_bound, const int32_t* __restrict__ skey,
+// per sorted edge i (row = rows[i] = inclusive head count - 1): fill row tables at heads, aux lists, list entries.
+// List entries are written COMPACT (only the ones that exist, so the two per-node sorts handle ~E + N entries instead of
+// 2E + N), in the order the stable sort must preserve: the per-edge entries in sorted-edge order, then one entry per collapsed
+// row in row order, then (ri_tail_kernel) the self loops.
+//   forward : edge i unless its relation is AGG -> slot i - agge_scan[i];   AGG row a -> nf_e + a      (nf_e = E - #AGG edges)
+//   backward: edge i unless its relation is TF  -> slot i - tfe_scan[i];    TF row a  -> nb_e + a      (nb_e = E - #TF edges)
+__global__ void ri_fill_kernel(int64_t E, int64_t N, int64_t nf_e, int64_t nb_e, const int32_t* __restrict__ skey,
                                const int32_t* __restrict__ order, const int32_t* __restrict__ mode,
                                const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                const int32_t* __restrict__ head, const int32_t* __restrict__ head_scan,
@@ -563,49 +593,39 @@ __global__ void ri_fill_kernel(int64_t E, int64_t N, int64_t P_bound, const int3
             const int a = aggh_scan[i];
             row_in[row] = (int32_t)N + a; row_out[row] = node;
             aux_f_ptr[a] = agge_scan[i];
-            f_key[E + row] = node; f_row[E + row] = row;       // one forward entry per AGG row
-            b_key[E + row] = (int32_t)N;                        // (invalid: key N is the discard segment)
+            f_key[nf_e + a] = node; f_row[nf_e + a] = row;      // one forward entry per AGG row
         } else if (m == kModeTf) {
             const int a = tfh_scan[i];
             row_in[row] = node; row_out[row] = (int32_t)N + a;
             aux_b_ptr[a] = tfe_scan[i];
-            b_key[E + row] = node; b_row[E + row] = row;
-            f_key[E + row] = (int32_t)N;
+            b_key[nb_e + a] = node; b_row[nb_e + a] = row;
         } else {
             row_in[row] = src[e]; row_out[row] = dst[e];
-            f_key[E + row] = (int32_t)N; b_key[E + row] = (int32_t)N;
         }
     }
     // per-edge entries
+    const int64_t pf = i - agge_scan[i], pb = i - tfe_scan[i];
     if (m == kModeAgg) {
-        aux_f_idx[agge_scan[i]] = src[e];
-        f_key[i] = (int32_t)N;                                  // covered by the row entry
-        b_key[i] = src[e]; b_row[i] = row;
+        aux_f_idx[agge_scan[i]] = src[e];                       // (forward: covered by the row entry)
+        b_key[pb] = src[e]; b_row[pb] = row;
     } else if (m == kModeTf) {
         aux_b_idx[tfe_scan[i]] = dst[e];
-        f_key[i] = dst[e]; f_row[i] = row;
-        b_key[i] = (int32_t)N;
+        f_key[pf] = dst[e]; f_row[pf] = row;
     } else {
-        f_key[i] = dst[e]; f_row[i] = row;
-        b_key[i] = src[e]; b_row[i] = row;
+        f_key[pf] = dst[e]; f_row[pf] = row;
+        b_key[pb] = src[e]; b_row[pb] = row;
     }
-    (void)P_bound;
 }
-__global__ void ri_tail_kernel(int64_t E, int64_t N, int64_t P, int64_t n_agg, int64_t n_tf, int64_t n_agg_e, int64_t n_tf_e,
-                               int32_t self_loop, int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_b_ptr,
-                               int32_t* f_key, int32_t* f_row, int32_t* b_key, int32_t* b_row) {
+__global__ void ri_tail_kernel(int64_t N, int64_t P, int64_t n_agg, int64_t n_tf, int64_t n_agg_e, int64_t n_tf_e,
+                               int64_t f_self, int64_t b_self, int32_t self_loop, int32_t* row_in, int32_t* row_out,
+                               int32_t* aux_f_ptr, int32_t* aux_b_ptr, int32_t* f_key, int32_t* f_row, int32_t* b_key,
+                               int32_t* b_row) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v == 0) { aux_f_ptr[n_agg] = (int32_t)n_agg_e; aux_b_ptr[n_tf] = (int32_t)n_tf_e; }
-    // entry slots [E + P, 2E) are unused row slots: discard them
-    if (E + P + v < 2 * E) { f_key[E + P + v] = (int32_t)N; b_key[E + P + v] = (int32_t)N; }
-    if (v >= N) return;
-    if (self_loop) {
-        row_in[P + v] = (int32_t)v; row_out[P + v] = (int32_t)v;
-        f_key[2 * E + v] = (int32_t)v; f_row[2 * E + v] = (int32_t)(P + v);
-        b_key[2 * E + v] = (int32_t)v; b_row[2 * E + v] = (int32_t)(P + v);
-    } else {
-        f_key[2 * E + v] = (int32_t)N; b_key[2 * E + v] = (int32_t)N;
-    }
+    if (v >= N || !self_loop) return;
+    row_in[P + v] = (int32_t)v; row_out[P + v] = (int32_t)v;
+    f_key[f_self + v] = (int32_t)v; f_row[f_self + v] = (int32_t)(P + v);        // self-loop entries close every list
+    b_key[b_self + v] = (int32_t)v; b_row[b_self + v] = (int32_t)(P + v);
 }
 
 // ----- tile / chunk tables of relation-major rows, built on the device (no host loop, no device -> host sync) ----------------
@@ -646,7 +666,8 @@ __global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_pt
 struct RowWs {
     int32_t *key, *skey, *iota, *order, *Er, *Dr, *Sr, *mode;
     int32_t *head, *aggh, *tfh, *agge, *tfe, *head_s, *aggh_s, *tfh_s, *agge_s, *tfe_s, *row_rel;
-    int32_t *f_key, *f_row, *b_key, *b_row, *perm, *rel_ptr;
+    int32_t *f_key, *f_row, *b_key, *b_row, *perm, *rel_ptr, *totals;
+    unsigned int *bitsD, *bitsS; size_t bits_words;
     void* sort_tmp; size_t sort_tmp_bytes;
     void* scan_tmp; size_t scan_tmp_bytes;
     void* csr_ws; size_t csr_ws_bytes;
@@ -662,6 +683,9 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
     w.f_key = a.take<int32_t>(L); w.f_row = a.take<int32_t>(L); w.b_key = a.take<int32_t>(L); w.b_row = a.take<int32_t>(L);
     w.perm = a.take<int32_t>(L);
     w.rel_ptr = a.take<int32_t>(R + 2);
+    w.totals = a.take<int32_t>(8);
+    w.bits_words = (size_t)((N * R + 31) / 32) + 1;
+    w.bitsD = a.take<unsigned int>((int64_t)w.bits_words); w.bitsS = a.take<unsigned int>((int64_t)w.bits_words);
     hipError_t e = hipSuccess;
     if (E > 0) {
         e = sort_pairs<int32_t>(nullptr, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, 32, st);
@@ -1119,19 +1143,13 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
     DN_CHECK_HIP(hipMemsetAsync(w.Sr, 0, sizeof(int32_t) * (size_t)R, st));
     int64_t P = 0, n_agg = 0, n_tf = 0, n_agg_e = 0, n_tf_e = 0;
     if (E > 0) {
-        // (1) per relation: #edges, #distinct destinations, #distinct sources -> EDGE / AGG / TF
+        // (1) per relation: #edges, #distinct destinations, #distinct sources -> EDGE / AGG / TF   (bitmaps, no sort)
+        DN_CHECK_HIP(hipMemsetAsync(w.bitsD, 0, sizeof(unsigned int) * w.bits_words, st));
+        DN_CHECK_HIP(hipMemsetAsync(w.bitsS, 0, sizeof(unsigned int) * w.bits_words, st));
+        const int64_t sb = dn_cdiv(E, kBlock);
+        hipLaunchKernelGGL(ri_stats_bitmap_kernel, dim3((unsigned)(sb < 2048 ? sb : 2048)), dim3(kBlock), 0, st, E, N, (int32_t)R, src,
+                           dst, etype, w.bitsD, w.bitsS, w.Er, w.Dr, w.Sr);
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.iota, E);
-        hipLaunchKernelGGL(ri_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, dst, etype, w.key);
-        DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, kb, st));
-        hipLaunchKernelGGL(head_flag_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.skey, E, w.head);
-        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.head, w.head_s, E, st));
-        hipLaunchKernelGGL(ri_rel_stats_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, N, E, w.skey, w.head, w.head_s, w.Er, w.Dr);
-        hipLaunchKernelGGL(ri_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, src, etype, w.key);
-        DN_CHECK_HIP(sort_pairs<int32_t>(w.sort_tmp, w.sort_tmp_bytes, w.key, w.skey, w.iota, w.order, E, kb, st));
-        hipLaunchKernelGGL(head_flag_i32_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.skey, E, w.head);
-        DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.head, w.head_s, E, st));
-        hipLaunchKernelGGL(ri_rel_stats_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, N, E, w.skey, w.head, w.head_s,
-                           (int32_t*)nullptr, w.Sr);
     }
     hipLaunchKernelGGL(ri_mode_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, edge_frac, w.Er, w.Dr, w.Sr, w.mode);
     if (E > 0) {
@@ -1145,34 +1163,34 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
         DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.tfh, w.tfh_s, E, st));
         DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.agge, w.agge_s, E, st));
         DN_CHECK_HIP(excl_scan(w.scan_tmp, w.scan_tmp_bytes, w.tfe, w.tfe_s, E, st));
-        int32_t last[10];
-        int32_t* srcs[10] = {w.head_s, w.head, w.aggh_s, w.aggh, w.tfh_s, w.tfh, w.agge_s, w.agge, w.tfe_s, w.tfe};
-        for (int k = 0; k < 10; ++k)
-            DN_CHECK_HIP(hipMemcpyAsync(&last[k], srcs[k] + (E - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        int32_t tot[5];
+        hipLaunchKernelGGL(ri_totals_kernel, dim3(1), dim3(64), 0, st, E, w.head_s, w.head, w.aggh_s, w.aggh, w.tfh_s, w.tfh, w.agge_s,
+                           w.agge, w.tfe_s, w.tfe, w.totals);
+        DN_CHECK_HIP(hipMemcpyAsync(tot, w.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
         DN_CHECK_HIP(hipStreamSynchronize(st));
-        P = (int64_t)last[0] + last[1]; n_agg = (int64_t)last[2] + last[3]; n_tf = (int64_t)last[4] + last[5];
-        n_agg_e = (int64_t)last[6] + last[7]; n_tf_e = (int64_t)last[8] + last[9];
-        hipLaunchKernelGGL(ri_fill_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, P, w.skey, w.order, w.mode, src, dst,
-                           w.head, w.head_s, w.aggh_s, w.tfh_s, w.agge_s, w.tfe_s, row_in, row_out, w.row_rel, aux_f_idx,
-                           aux_f_ptr, aux_b_idx, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
+        P = tot[0]; n_agg = tot[1]; n_tf = tot[2]; n_agg_e = tot[3]; n_tf_e = tot[4];
+        hipLaunchKernelGGL(ri_fill_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, E, N, E - n_agg_e, E - n_tf_e, w.skey, w.order,
+                           w.mode, src, dst, w.head, w.head_s, w.aggh_s, w.tfh_s, w.agge_s, w.tfe_s, row_in, row_out, w.row_rel,
+                           aux_f_idx, aux_f_ptr, aux_b_idx, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
     }
-    {
-        const int64_t work = (N > E ? N : E) + 1;
-        hipLaunchKernelGGL(ri_tail_kernel, dim3(grid_for(work)), dim3(kBlock), 0, st, E, N, P, n_agg, n_tf, n_agg_e, n_tf_e,
-                           self_loop, row_in, row_out, aux_f_ptr, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
-    }
-    // (3) per-node lists of contributing rows (key N = discard segment)
-    const int64_t L = 2 * E + N;
-    if (L > 0) {
-        // N + 1 keys (the last one collects the discarded slots), so dst_ptr / src_ptr receive N + 2 entries
-        rc = csr_build(w.f_key, L, N + 1, dst_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+    const int64_t f_self = E - n_agg_e + n_agg, b_self = E - n_tf_e + n_tf;       // list entries before the self loops
+    hipLaunchKernelGGL(ri_tail_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, P, n_agg, n_tf, n_agg_e, n_tf_e, f_self, b_self,
+                       self_loop, row_in, row_out, aux_f_ptr, aux_b_ptr, w.f_key, w.f_row, w.b_key, w.b_row);
+    // (3) per-node lists of contributing rows.  N + 1 keys (the last segment stays empty), so dst_ptr / src_ptr receive N + 2
+    // entries as before
+    const int64_t n_f = f_self + (self_loop ? N : 0), n_b = b_self + (self_loop ? N : 0);
+    if (n_f > 0) {
+        rc = csr_build(w.f_key, n_f, N + 1, dst_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
         if (rc != DN_OK) return rc;
-        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(L)), dim3(kBlock), 0, st, w.f_row, w.perm, L, dst_rows);
-        rc = csr_build(w.b_key, L, N + 1, src_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
-        if (rc != DN_OK) return rc;
-        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(L)), dim3(kBlock), 0, st, w.b_row, w.perm, L, src_rows);
+        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(n_f)), dim3(kBlock), 0, st, w.f_row, w.perm, n_f, dst_rows);
     } else {
         DN_CHECK_HIP(hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (size_t)(N + 2), st));
+    }
+    if (n_b > 0) {
+        rc = csr_build(w.b_key, n_b, N + 1, src_ptr, w.perm, w.csr_ws, w.csr_ws_bytes, st, nullptr);
+        if (rc != DN_OK) return rc;
+        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(n_b)), dim3(kBlock), 0, st, w.b_row, w.perm, n_b, src_rows);
+    } else {
         DN_CHECK_HIP(hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (size_t)(N + 2), st));
     }
     // (4) relation ranges over rows (edge rows are relation-major; the caller appends the self-loop rows as relation R)
