@@ -492,33 +492,58 @@ int rel_layout(Arena& a, RelWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 constexpr int kModeEdge = 0, kModeAgg = 1, kModeTf = 2;
 
 // per relation: #edges, #distinct destinations, #distinct sources -- what decides EDGE / AGG / TF.
-// No sorting: one bit per (relation, node) pair, set with atomicOr -- the lane that flips a bit
-// counts it.  Counts are order-independent, so the result is deterministic; per-block LDS histograms keep the R hot counters
-// off the global atomic path.
+// No sorting: one bit per (relation, node) pair, set with atomicOr -- the lane that flips a bit counts it (counts do not depend
+// on the order, so the result is deterministic).  Batches list their edges graph by graph, so neighbouring lanes mostly hold
+// the same relation and, for the dummy relations, the same (relation, node) pair: a lane equal to its left neighbour skips
+// the atomic, and every run of equal relations adds its three counts once (LDS histogram per block, then R global atomics).
 constexpr int kStatsMaxR = 1024;
-__global__ void ri_stats_bitmap_kernel(int64_t E, int64_t N, int32_t R, const int32_t* __restrict__ src,
-                                       const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
-                                       unsigned int* __restrict__ bitsD, unsigned int* __restrict__ bitsS,
-                                       int32_t* __restrict__ Er, int32_t* __restrict__ Dr, int32_t* __restrict__ Sr) {
+__global__ __launch_bounds__(kBlock) void ri_stats_bitmap_kernel(int64_t E, int64_t N, int32_t R, const int32_t* __restrict__ src,
+                                                                 const int32_t* __restrict__ dst,
+                                                                 const int32_t* __restrict__ etype,
+                                                                 unsigned int* __restrict__ bitsD,
+                                                                 unsigned int* __restrict__ bitsS, int32_t* __restrict__ Er,
+                                                                 int32_t* __restrict__ Dr, int32_t* __restrict__ Sr) {
     __shared__ int32_t h[3][kStatsMaxR];
     const bool use_lds = R <= kStatsMaxR;
     if (use_lds) {
         for (int i = threadIdx.x; i < 3 * kStatsMaxR; i += blockDim.x) (&h[0][0])[i] = 0;
         __syncthreads();
     }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-        const int r = etype[e];
-        const int64_t kd = (int64_t)r * N + dst[e], ks = (int64_t)r * N + src[e];
-        const unsigned int md = 1u << (kd & 31), ms = 1u << (ks & 31);
-        const bool newd = !(atomicOr(&bitsD[kd >> 5], md) & md), news = !(atomicOr(&bitsS[ks >> 5], ms) & ms);
-        if (use_lds) {
-            atomicAdd(&h[0][r], 1);
-            if (newd) atomicAdd(&h[1][r], 1);
-            if (news) atomicAdd(&h[2][r], 1);
-        } else {
-            atomicAdd(&Er[r], 1);
-            if (newd) atomicAdd(&Dr[r], 1);
-            if (news) atomicAdd(&Sr[r], 1);
+    const int lane = threadIdx.x & 63;
+    const int64_t chunks = (E + blockDim.x - 1) / blockDim.x;
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {                    // whole waves stay in the loop together
+        const int64_t e = c * blockDim.x + threadIdx.x;
+        const bool ok = e < E;
+        const int r = ok ? etype[e] : -1;
+        const int64_t kd = ok ? (int64_t)r * N + dst[e] : -1, ks = ok ? (int64_t)r * N + src[e] : -2;
+        const int rp = __shfl_up(r, 1);
+        const long long kdp = __shfl_up((long long)kd, 1), ksp = __shfl_up((long long)ks, 1);
+        const bool head = ok && (lane == 0 || r != rp);
+        bool newd = false, news = false;
+        if (ok && (lane == 0 || kd != kdp)) {
+            const unsigned int m = 1u << (kd & 31);
+            newd = !(atomicOr(&bitsD[kd >> 5], m) & m);
+        }
+        if (ok && (lane == 0 || ks != ksp)) {
+            const unsigned int m = 1u << (ks & 31);
+            news = !(atomicOr(&bitsS[ks >> 5], m) & m);
+        }
+        const unsigned long long Vm = __ballot(ok), Hm = __ballot(head), Dm = __ballot(newd), Sm = __ballot(news);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : (Hm >> (lane + 1)) << (lane + 1);   // heads after me
+            const int next = later ? __ffsll((long long)later) - 1 : 64;
+            const unsigned long long upto = next == 64 ? ~0ull : ((1ull << next) - 1ull);
+            const unsigned long long run = upto & ~((1ull << lane) - 1ull) & Vm;                     // lanes [me, next head)
+            const int ne = __popcll(run), nd = __popcll(run & Dm), ns = __popcll(run & Sm);
+            if (use_lds) {
+                atomicAdd(&h[0][r], ne);
+                if (nd) atomicAdd(&h[1][r], nd);
+                if (ns) atomicAdd(&h[2][r], ns);
+            } else {
+                atomicAdd(&Er[r], ne);
+                if (nd) atomicAdd(&Dr[r], nd);
+                if (ns) atomicAdd(&Sr[r], ns);
+            }
         }
     }
     if (use_lds) {
@@ -529,6 +554,61 @@ __global__ void ri_stats_bitmap_kernel(int64_t E, int64_t N, int32_t R, const in
             if (h[2][r]) atomicAdd(&Sr[r], h[2][r]);
         }
     }
+}
+// The same counts with plain stores when N * R bytes are affordable (<= kByteMapMax): one BYTE per (relation, node) pair is set
+// to 1 (idempotent: no atomic, no return trip -- the scattered atomicOr above manages ~18 G/s), then the bytes are summed per
+// relation.  #edges per relation comes from the same run aggregation.
+constexpr int64_t kByteMapMax = 1ll << 28;
+__global__ __launch_bounds__(kBlock) void ri_stats_mark_kernel(int64_t E, int64_t Np, int32_t R, const int32_t* __restrict__ src,
+                                                               const int32_t* __restrict__ dst,
+                                                               const int32_t* __restrict__ etype, uint8_t* __restrict__ mapD,
+                                                               uint8_t* __restrict__ mapS, int32_t* __restrict__ Er) {
+    __shared__ int32_t h[kStatsMaxR];
+    const bool use_lds = R <= kStatsMaxR;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < kStatsMaxR; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t chunks = (E + blockDim.x - 1) / blockDim.x;
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const int64_t e = c * blockDim.x + threadIdx.x;
+        const bool ok = e < E;
+        const int r = ok ? etype[e] : -1;
+        if (ok) {
+            mapD[(int64_t)r * Np + dst[e]] = 1;                   // Np: node count rounded up to 16 (aligned 16-byte reads below)
+            mapS[(int64_t)r * Np + src[e]] = 1;
+        }
+        const int rp = __shfl_up(r, 1);
+        const bool head = ok && (lane == 0 || r != rp);
+        const unsigned long long Vm = __ballot(ok), Hm = __ballot(head);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : (Hm >> (lane + 1)) << (lane + 1);
+            const int next = later ? __ffsll((long long)later) - 1 : 64;
+            const unsigned long long upto = next == 64 ? ~0ull : ((1ull << next) - 1ull);
+            const int ne = __popcll(upto & ~((1ull << lane) - 1ull) & Vm);
+            if (use_lds) atomicAdd(&h[r], ne);
+            else atomicAdd(&Er[r], ne);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += blockDim.x)
+            if (h[r]) atomicAdd(&Er[r], h[r]);
+    }
+}
+// Dr[r] / Sr[r] = number of set bytes of relation r (grid: x = slices of the node range, y = relation, z = map)
+__global__ __launch_bounds__(kBlock) void ri_stats_count_kernel(int64_t Np, const uint8_t* __restrict__ mapD,
+                                                                const uint8_t* __restrict__ mapS, int32_t* __restrict__ Dr,
+                                                                int32_t* __restrict__ Sr) {
+    const uint4* m = reinterpret_cast<const uint4*>((blockIdx.z == 0 ? mapD : mapS) + (int64_t)blockIdx.y * Np);
+    int32_t cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Np / 16; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = m[i];                                    // bytes are 0 or 1
+        cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&(blockIdx.z == 0 ? Dr : Sr)[blockIdx.y], cnt);
 }
 // the ten scan totals the host needs, packed so that ONE copy fetches them: out[k] = scan[k][E-1] + flag[k][E-1]
 __global__ void ri_totals_kernel(int64_t E, const int32_t* a0, const int32_t* a1, const int32_t* b0, const int32_t* b1,
@@ -684,7 +764,7 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
     w.perm = a.take<int32_t>(L);
     w.rel_ptr = a.take<int32_t>(R + 2);
     w.totals = a.take<int32_t>(8);
-    w.bits_words = (size_t)((N * R + 31) / 32) + 1;
+    w.bits_words = (N * R <= kByteMapMax ? (size_t)(((N + 15) / 16 * 16) * R / 4) : (size_t)((N * R + 31) / 32)) + 4;   // byte map / bitmap
     w.bitsD = a.take<unsigned int>((int64_t)w.bits_words); w.bitsS = a.take<unsigned int>((int64_t)w.bits_words);
     hipError_t e = hipSuccess;
     if (E > 0) {
@@ -1147,8 +1227,17 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
         DN_CHECK_HIP(hipMemsetAsync(w.bitsD, 0, sizeof(unsigned int) * w.bits_words, st));
         DN_CHECK_HIP(hipMemsetAsync(w.bitsS, 0, sizeof(unsigned int) * w.bits_words, st));
         const int64_t sb = dn_cdiv(E, kBlock);
-        hipLaunchKernelGGL(ri_stats_bitmap_kernel, dim3((unsigned)(sb < 2048 ? sb : 2048)), dim3(kBlock), 0, st, E, N, (int32_t)R, src,
-                           dst, etype, w.bitsD, w.bitsS, w.Er, w.Dr, w.Sr);
+        if (N * R <= kByteMapMax && R <= 65535) {
+            const int64_t Np = (N + 15) / 16 * 16;
+            hipLaunchKernelGGL(ri_stats_mark_kernel, dim3((unsigned)(sb < 4096 ? sb : 4096)), dim3(kBlock), 0, st, E, Np, (int32_t)R, src,
+                               dst, etype, (uint8_t*)w.bitsD, (uint8_t*)w.bitsS, w.Er);
+            const int64_t slices = dn_cdiv(Np / 16, 4 * kBlock);
+            hipLaunchKernelGGL(ri_stats_count_kernel, dim3((unsigned)(slices < 64 ? slices : 64), (unsigned)R, 2), dim3(kBlock), 0, st, Np,
+                               (const uint8_t*)w.bitsD, (const uint8_t*)w.bitsS, w.Dr, w.Sr);
+        } else {
+            hipLaunchKernelGGL(ri_stats_bitmap_kernel, dim3((unsigned)(sb < 2048 ? sb : 2048)), dim3(kBlock), 0, st, E, N, (int32_t)R,
+                               src, dst, etype, w.bitsD, w.bitsS, w.Er, w.Dr, w.Sr);
+        }
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, w.iota, E);
     }
     hipLaunchKernelGGL(ri_mode_kernel, dim3(grid_for(R)), dim3(kBlock), 0, st, R, edge_frac, w.Er, w.Dr, w.Sr, w.mode);

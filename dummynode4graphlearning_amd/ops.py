@@ -961,10 +961,13 @@ class RowIndexSet:
                 bounds.append((npt[g0], npt[g1], ept[g0], ept[g1]))
                 g0 = g1
         self.parts = []
-        s64, d64 = src.long(), dst.long()
-        for n0, n1, e0, e1 in bounds:
-            ix = RowIndex(s64[e0:e1] - n0, d64[e0:e1] - n0, etype[e0:e1], n1 - n0, num_rels, self_loop=self_loop)
-            self.parts.append((n0, n1, ix))
+        if len(bounds) == 1:                                     # (the usual case: no shifted copies of the edge arrays)
+            self.parts.append((0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop)))
+        else:
+            s64, d64 = src.long(), dst.long()
+            for n0, n1, e0, e1 in bounds:
+                ix = RowIndex(s64[e0:e1] - n0, d64[e0:e1] - n0, etype[e0:e1], n1 - n0, num_rels, self_loop=self_loop)
+                self.parts.append((n0, n1, ix))
         if (PIPE_ENABLED and node_ptr is not None and len(self.parts) == 1 and self_loop and N > 0
                 and int(node_ptr.numel()) >= 2):
             pipe = PipeIndex(self.parts[0][2], node_ptr)
