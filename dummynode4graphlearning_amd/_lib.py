@@ -23,8 +23,9 @@ _SIGS = {
     "dn_runtime_probe": (ctypes.c_int, [P]),
     "dn_gather_segsum_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
     "dn_gather_segsum_bf16": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
-    "dn_gather_segsum_tiled_f32": (ctypes.c_int, [P, c_i32, P, P, P, c_i64, P, c_f32, P]),
-    "dn_gather_segsum_tiled_bf16": (ctypes.c_int, [P, c_i32, P, P, P, c_i64, P, c_f32, P]),
+    "dn_window_tiles_host": (ctypes.c_int, [P, c_i64, c_i32, P, c_i64, ctypes.POINTER(c_i64)]),
+    "dn_gather_segsum_window_f32": (ctypes.c_int, [P, c_i32, P, P, P, P, P, c_i64, P, c_f32, P]),
+    "dn_gather_segsum_window_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, P, c_i64, P, c_f32, P]),
     "dn_segment_sum_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
     "dn_segment_sum_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
     "dn_segment_mean_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),

@@ -57,3 +57,27 @@ __device__ __forceinline__ int64_t dn_xcd_chunk(int64_t b, int64_t nblocks) {
     const int64_t per = (nblocks + DN_NUM_XCD - 1) / DN_NUM_XCD;
     return (b % DN_NUM_XCD) * per + b / DN_NUM_XCD;
 }
+
+// LDS-DMA issued from inline asm (cdna_hip_programming.md, inline-asm section: M0 written in the statement that reads
+// it): hipcc's s_waitcnt pass treats a builtin LDS-DMA as a pending LDS write and drains vmcnt(0) before EVERY later
+// ds_read, which would empty the ring each tile; an asm DMA is outside its bookkeeping and is counted by hand below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {      // 4 bytes per lane: lane l lands at lds_dst + 4 l
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}

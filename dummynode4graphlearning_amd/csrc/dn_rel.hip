@@ -252,22 +252,6 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 // -------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint4 g_zero_row[64];        // 1 KiB of zeros (device globals are zero-initialised)
 
-// LDS-DMA issued from inline asm (cdna_hip_programming.md, inline-asm section: M0 written in the statement that reads
-// it): hipcc's s_waitcnt pass treats a builtin LDS-DMA as a pending LDS write and drains vmcnt(0) before EVERY later
-// ds_read, which would empty the ring each tile; an asm DMA is outside its bookkeeping and is counted by hand below.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int H, bool MASKED>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t* __restrict__ A,
                                                                     const bf16_t* __restrict__ A2, int32_t na1,

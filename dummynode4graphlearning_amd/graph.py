@@ -111,7 +111,7 @@ class BatchedGraph:
 
     def edge_index(self):
         if self._cache._edge_index is None:
-            self._cache._edge_index = ops.EdgeIndex(self._src, self._dst, self._n)
+            self._cache._edge_index = ops.EdgeIndex(self._src, self._dst, self._n, node_ptr=self.node_ptr())
         return self._cache._edge_index
 
     def rel_index(self, etype, num_rels):
@@ -221,6 +221,13 @@ def graph_ptr_i32(data):
     return p.to(device=data.x.device, dtype=torch.int32)
 
 
+def _node_ptr_or_none(data):
+    """Graph boundaries of a PyG-style batch for the window gather, or None when the batch carries neither .ptr nor .batch."""
+    if getattr(data, "ptr", None) is None and getattr(data, "batch", None) is None:
+        return None
+    return graph_ptr_i32(data)
+
+
 def edge_index_of(data):
     """Cached ops.EdgeIndex of a PyG-style batch (edge_index row 0 = src, row 1 = dst)."""
     cache = getattr(data, "_cache", None)
@@ -231,7 +238,7 @@ def edge_index_of(data):
         except Exception:
             pass
     if cache._edge_index is None or cache._edge_index.num_edges != data.edge_index.shape[1]:
-        cache._edge_index = ops.EdgeIndex(data.edge_index[0], data.edge_index[1], data.x.shape[0])
+        cache._edge_index = ops.EdgeIndex(data.edge_index[0], data.edge_index[1], data.x.shape[0], node_ptr=_node_ptr_or_none(data))
     return cache._edge_index
 
 
@@ -271,7 +278,7 @@ def gcn_edge_index_of(data):
         src, dst = data.edge_index[0], data.edge_index[1]
         keep = src != dst
         ar = torch.arange(data.x.shape[0], device=src.device, dtype=src.dtype)
-        ix = ops.EdgeIndex(torch.cat([src[keep], ar]), torch.cat([dst[keep], ar]), data.x.shape[0])
+        ix = ops.EdgeIndex(torch.cat([src[keep], ar]), torch.cat([dst[keep], ar]), data.x.shape[0], node_ptr=_node_ptr_or_none(data))
         hit = (ix, keep, data.edge_index.shape[1])
         cache._gcn = hit
     return hit[0], hit[1]

@@ -105,36 +105,63 @@ def gather_segsum(x, idx=None, ptr_=None, num_segments=None, scale=None, self_in
     return out
 
 
-# LDS-window variant of the graph-local gather (dn_gather_segsum_tiled_*): bitwise equal to the plain kernel, but measured
-# SLOWER on the PROTEINS-shaped benchmark batch (0.72 vs 0.49 ms fwd+bwd): fixed 64-row windows catch only part of a graph's
-# edges, the 40-64-entry dummy lists serialise inside a workgroup, and three 45 KB workgroups per CU hide less latency than
-# eight small ones.  Opt in with DN_TILED_GATHER=1.
-TILED_GATHER = _os.environ.get("DN_TILED_GATHER", "0") == "1"
+# Streamed LDS-window variant of the graph-local gather (dn_gather_segsum_window_*): bitwise equal to the plain kernel; every row
+# of a tile (a run of whole graphs) reaches the CU once, by LDS-DMA, instead of once per edge through L2.  Measured on the
+# PROTEINS-shaped benchmark batch (tools/gin_gather_bench.py): staging alone streams the rows in 64 us per launch (the HBM
+# floor), but summing a tile out of LDS costs another ~180 us (bounds -> entries -> rows are three dependent LDS round trips per
+# segment, ~60-row tiles leave half of the 12 gathering waves idle, and one barrier per tile serialises the two phases), so
+# the launch takes 246 us against 213 us for the plain kernel.  Kept as an opt-in (DN_WINDOW_GATHER=1) and parity-tested.
+WINDOW_GATHER = _os.environ.get("DN_WINDOW_GATHER", "0") == "1"
+WINDOW_BYTES = 40 * 1024                                # kWinBytes in csrc/dn_segment.hip
 
 
-def gather_segsum_tiled(x, idx, ptr_, scale=None, self_coef=0.0):
-    """out[s] = self_coef*x[s] + sum_i scale[i]*x[idx[i]] with an LDS window of consecutive rows per workgroup
-    (dn_gather_segsum_tiled_*): for graph-local gathers where segment s <-> row s."""
-    require_gpu(x, idx, ptr_, scale)
-    _i32(idx, "idx"), _i32(ptr_, "ptr")
+def window_tiles(node_ptr, num_rows, rows_per_window):
+    """Tile boundaries (int32 [T + 1], device) for dn_gather_segsum_window_*: greedy runs of whole graphs that fit a window
+    (dn_window_tiles_host: the graph boundaries make one small device -> host copy, the packing is a C loop, the table goes
+    back up; once per batch and row width)."""
+    import numpy as np
+    W = max(int(rows_per_window), 1)
+    npt = np.ascontiguousarray(node_ptr.detach().cpu().numpy().astype(np.int32))
+    G = int(npt.shape[0]) - 1
+    assert G >= 0 and (G == 0 or int(npt[-1]) == int(num_rows)), "node_ptr must cover the rows"
+    cap = G + int(num_rows) // W + 2
+    buf = np.empty(cap, dtype=np.int32)
+    n = ctypes.c_int64(0)
+    check(lib().dn_window_tiles_host(npt.ctypes.data_as(ctypes.c_void_p), G, W, buf.ctypes.data_as(ctypes.c_void_p), cap,
+                                     ctypes.byref(n)), "dn_window_tiles_host")
+    T = int(n.value)
+    return torch.from_numpy(buf[:T + 1].copy()).to(node_ptr.device), T
+
+
+def gather_segsum_window(x, idx, ptr_, tiles, scale=None, self_coef=0.0):
+    """out[s] = self_coef*x[s] + sum_i scale[i]*x[idx[i]] with the rows of each tile streamed through an LDS window
+    (dn_gather_segsum_window_*): for graph-local gathers where segment s <-> row s.  tiles = window_tiles(...) or
+    (tile_ptr, ptr_[tile_ptr], T) when the caller caches the tiles' entry bounds."""
+    tile_ptr, ntiles = tiles[0], tiles[-1]
+    tile_eptr = tiles[1] if len(tiles) == 3 else ptr_[tile_ptr.long()].contiguous()
+    require_gpu(x, idx, ptr_, scale, tile_ptr, tile_eptr)
+    _i32(idx, "idx"), _i32(ptr_, "ptr"), _i32(tile_ptr, "tile_ptr"), _i32(tile_eptr, "tile_eptr")
     S, H = x.shape
-    assert ptr_.numel() == S + 1
+    assert ptr_.numel() == S + 1 and tile_ptr.numel() == ntiles + 1 and tile_eptr.numel() == ntiles + 1
     out = torch.empty_like(x)
-    fn = getattr(lib(), "dn_gather_segsum_tiled_" + _suffix(x))
+    fn = getattr(lib(), "dn_gather_segsum_window_" + _suffix(x))
 
     def _launch():
-        check(fn(ptr(x), H, ptr(idx), ptr(scale), ptr(ptr_), S, ptr(out), float(self_coef), stream_ptr()), "dn_gather_segsum_tiled")
+        check(fn(ptr(x), H, ptr(idx), ptr(scale), ptr(ptr_), ptr(tile_ptr), ptr(tile_eptr), int(ntiles), ptr(out),
+                 float(self_coef), stream_ptr()), "dn_gather_segsum_window")
     if kernel_timer is not None:
-        kernel_timer.launch("gather_segsum_tiled", _launch)
+        kernel_timer.launch("gather_segsum_window", _launch)
     else:
         _launch()
     return out
 
 
-def _tiled_ok(x, num_segments, self_in):
+def _window_ok(x, num_segments, self_in):
     vn = 4 if x.dtype == torch.float32 else 8
-    return (TILED_GATHER and x.shape[0] == num_segments and (self_in is None or self_in is x) and x.shape[1] % vn == 0
-            and x.shape[1] * x.element_size() <= 1024 and x.data_ptr() % 16 == 0)
+    rowb = x.shape[1] * x.element_size()
+    return (WINDOW_GATHER and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] == num_segments
+            and (self_in is None or self_in is x) and x.shape[1] % vn == 0 and 128 <= rowb <= 1024 and x.is_contiguous()
+            and x.data_ptr() % 16 == 0)
 
 
 def csr_build(key, num_keys):
@@ -421,6 +448,7 @@ class _SplitCSR:
     def __init__(self, ptr, idx, num_segments):
         self.ptr, self.idx, self.num_segments = ptr, idx, int(num_segments)
         self.hub_ids = None
+        self.tiles_of, self._wt = None, {}                    # set by EdgeIndex: row bytes -> window tiles of the batch
         if idx.numel() == 0:
             return
         deg = (ptr[1:] - ptr[:-1]).long()
@@ -450,17 +478,30 @@ class _SplitCSR:
         self.fold_ptr = first_chunk.to(I32)                                   # chunk ranges per hub
         self.hub_ids = hub_ids
 
+    def _tiles(self, row_bytes):
+        """(tile_ptr, entry bounds of the tiles in the CSR the main pass walks, T), cached per row width."""
+        t = self._wt.get(row_bytes)
+        if t is None:
+            tile_ptr, n = self.tiles_of(row_bytes)
+            p = self.ptr if self.hub_ids is None else self.ptr_main
+            t = (tile_ptr, p[tile_ptr.long()].contiguous(), n)
+            self._wt[row_bytes] = t
+        return t
+
     def segsum(self, x, scale=None, self_in=None, self_coef=0.0):
-        tiled = _tiled_ok(x, self.num_segments, self_in)      # graph-local gather: LDS window per workgroup
+        tiles = None
+        if self.tiles_of is not None and _window_ok(x, self.num_segments, self_in):
+            tiles = self._tiles(x.shape[1] * x.element_size())        # graph-local gather: rows streamed through LDS windows
+        sc = self_coef if self_in is not None else 0.0
         if self.hub_ids is None:
-            if tiled:
-                return gather_segsum_tiled(x, self.idx, self.ptr, scale=scale, self_coef=self_coef if self_in is not None else 0.0)
+            if tiles is not None:
+                return gather_segsum_window(x, self.idx, self.ptr, tiles, scale=scale, self_coef=sc)
             return gather_segsum(x, self.idx, self.ptr, self.num_segments, scale=scale, self_in=self_in, self_coef=self_coef)
         sc_main = sc_hub = None
         if scale is not None:
             sc_main, sc_hub = scale[self.keep].contiguous(), scale[~self.keep].contiguous()
-        if tiled:
-            out = gather_segsum_tiled(x, self.idx_main, self.ptr_main, scale=sc_main, self_coef=self_coef if self_in is not None else 0.0)
+        if tiles is not None:
+            out = gather_segsum_window(x, self.idx_main, self.ptr_main, tiles, scale=sc_main, self_coef=sc)
         else:
             out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
                                 self_coef=self_coef)
@@ -474,9 +515,12 @@ class EdgeIndex:
     """CSR by destination + CSC by source of one batched COO (int32, device resident).
     The one-shot build DGL / torch-scatter hide behind update_all / scatter."""
 
-    def __init__(self, src, dst, num_nodes):
+    def __init__(self, src, dst, num_nodes, node_ptr=None):
+        """node_ptr (optional, [G + 1]): the batch's graph boundaries -- with it, graph-local gathers stream each graph's rows
+        through an LDS window (dn_gather_segsum_window_*) instead of fetching every neighbour row through L2."""
         require_gpu(src, dst)
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
+        self._node_ptr, self._tiles = node_ptr, {}
         src, dst = src.to(I32).contiguous(), dst.to(I32).contiguous()
         self.src, self.dst = src, dst
         self.in_ptr, self.in_perm = csr_build(dst, num_nodes)
@@ -486,7 +530,16 @@ class EdgeIndex:
         self.dst_by_src = gather_rows_i32(dst, self.out_perm)
         self.fwd = _SplitCSR(self.in_ptr, self.src_by_dst, num_nodes)
         self.bwd = _SplitCSR(self.out_ptr, self.dst_by_src, num_nodes)
+        if node_ptr is not None and int(node_ptr.numel()) >= 2:
+            self.fwd.tiles_of = self.bwd.tiles_of = self.window_tiles
         self._max_bwd = None
+
+    def window_tiles(self, row_bytes):
+        t = self._tiles.get(row_bytes)
+        if t is None:
+            t = window_tiles(self._node_ptr, self.num_nodes, WINDOW_BYTES // int(row_bytes))
+            self._tiles[row_bytes] = t
+        return t
 
     def max_backward_index(self):
         """(tptr, tslot, seg_of_slot): CSR slots grouped by the row they gather, and each slot's destination."""

@@ -65,16 +65,28 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                           const float* scale, const int32_t* ptr, int64_t S, int64_t M, void* out,
                           const void* self_in, float self_coef, int32_t mean, dn_stream_t stream);
 
-/* Tiled variant for graph-local gathers: segment s corresponds to input row s (S rows) and most of its neighbours lie a few
- * rows away -- the GIN / GCN / SAGE aggregation over a batch of small graphs (gconv.py:212, PyG propagate).
- *   out[s,:] = self_coef * in[s,:] + sum_{i in [ptr[s], ptr[s+1])} scale[i] * in[idx[i],:]
- * A workgroup stages a window of consecutive input rows in LDS (each row read from HBM once) and serves the gathered rows
- * that fall inside the window from LDS; rows outside come from global memory, so the result never depends on locality
- * (bitwise equal to dn_gather_segsum_* with self_in = in).  idx and ptr are required; H * sizeof(T) <= 1 KiB. */
-int dn_gather_segsum_tiled_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
-                               float* out, float self_coef, dn_stream_t stream);
-int dn_gather_segsum_tiled_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, int64_t S,
-                                void* out, float self_coef, dn_stream_t stream);
+/* Tile table for dn_gather_segsum_window_*, built on the HOST from the batch's graph boundaries (node_ptr_host [num_graphs + 1],
+ * host memory): greedy runs of whole graphs with at most rows_per_window rows; a graph larger than a window is cut every
+ * rows_per_window rows.  tile_ptr_host receives num_tiles + 1 bounds (capacity entries available; num_graphs +
+ * rows / rows_per_window + 2 always suffice).  Pure host code: no stream, no device access. */
+int dn_window_tiles_host(const int32_t* node_ptr_host, int64_t num_graphs, int32_t rows_per_window, int32_t* tile_ptr_host,
+                         int64_t capacity, int64_t* num_tiles);
+
+/* Graph-local gather streamed through LDS windows:  out[s, :] = self_coef * in[s, :] + sum_i scale[i] * in[idx[i], :]  over
+ * segment s = [ptr[s], ptr[s+1]) -- dn_gather_segsum_* for the case "segment s <-> row s of `in`, neighbours inside the same
+ * graph" (the reference's GINConv / GCNConv / SAGEConv propagate over a batch of small graphs, gconv.py:20-215, and DGL's
+ * update_all, rgin.py:137): tile t = rows [tile_ptr[t], tile_ptr[t+1]) is a run of whole graphs, tile_eptr[t] = ptr[tile_ptr[t]]
+ * its first index entry (both [num_tiles + 1], device).  Any partition is CORRECT: rows, neighbours or index entries that do
+ * not fit the 40 KB window / the staged 1024 entries of a tile are read from global memory.  Every row of a tile reaches the
+ * CU once (LDS-DMA, ring of three windows) instead of once per edge through L2.
+ * Same summation order as dn_gather_segsum_*: bitwise equal results.  Rows must be 128 bytes .. 1 KiB, H a multiple of 4
+ * (f32) / 8 (bf16), in/out 16-byte aligned; scale may be NULL. */
+int dn_gather_segsum_window_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
+                                const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, float* out,
+                                float self_coef, dn_stream_t stream);
+int dn_gather_segsum_window_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
+                                 const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, void* out,
+                                 float self_coef, dn_stream_t stream);
 
 /* Per-graph readouts over CONTIGUOUS rows: out[g,:] = reduce_{v in [ptr[g], ptr[g+1])} in[v,:].
  * Replaces: torch_geometric global_add_pool / global_mean_pool / global_max_pool

@@ -441,29 +441,76 @@ def test_index_builds_reject_out_of_range_edge_types():
     ops.RowIndex(src, dst, torch.tensor([0, 2, 1], device=DEV), 3, 3)
 
 
-@pytest.mark.parametrize("dt,H", [(torch.float32, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float32, 256)])
-def test_tiled_gather_is_bitwise_equal_to_the_untiled_kernel(dt, H):
-    """dn_gather_segsum_tiled_* (LDS window of consecutive rows) against dn_gather_segsum_*: graph-local edges, edges that
-    leave the window, empty segments, a per-edge scale, the self term -- identical bits (same summation order)."""
+@pytest.mark.parametrize("dt,H", [(torch.float32, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float32, 256),
+                                  (torch.bfloat16, 64), (torch.float32, 32)])
+def test_window_gather_is_bitwise_equal_to_the_plain_kernel(dt, H):
+    """dn_gather_segsum_window_* (rows of a tile streamed into LDS windows by LDS-DMA) against dn_gather_segsum_*: graph-local
+    edges, edges that leave the tile, empty segments, long lists (more entries than a tile stages), tiles longer than a window,
+    a per-edge scale, the self term, more tiles than workgroups and fewer -- identical bits (same summation order)."""
     ops = _ops()
     rng = np.random.default_rng(H)
-    N = 5000
+    sizes = np.concatenate([rng.integers(1, 70, size=400), [700, 1, 1, 333], rng.integers(20, 50, size=300)])
+    node_ptr = np.concatenate([[0], np.cumsum(sizes)])
+    N = int(node_ptr[-1])
+    gid = np.repeat(np.arange(len(sizes)), sizes)
     deg = rng.integers(0, 9, size=N)
     deg[::97] = 70                                           # a few long lists (more than one index round)
+    deg[node_ptr[400]] = 2500                                # one list longer than the entries a tile stages
     ptr_ = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
     E = int(ptr_[-1])
     seg = np.repeat(np.arange(N), deg)
-    near = np.clip(seg + rng.integers(-40, 41, size=E), 0, N - 1)
+    local = node_ptr[gid[seg]] + (rng.random(E) * sizes[gid[seg]]).astype(np.int64)      # inside the segment's own graph
     far = rng.integers(0, N, size=E)
-    idx = np.where(rng.random(E) < 0.85, near, far).astype(np.int32)
+    idx = np.where(rng.random(E) < 0.9, local, far).astype(np.int32)
     x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dt).to(DEV)
     sc = torch.from_numpy(rng.random(E).astype(np.float32)).to(DEV)
     p_d, i_d = torch.from_numpy(ptr_).to(DEV), torch.from_numpy(idx).to(DEV)
+    rowb = H * x.element_size()
+    tiles = ops.window_tiles(torch.from_numpy(node_ptr).to(DEV), N, ops.WINDOW_BYTES // rowb)
+    tp = tiles[0].cpu().numpy()
+    assert tp[0] == 0 and tp[-1] == N and (np.diff(tp) > 0).all() and len(tp) == tiles[1] + 1
+    assert np.diff(tp).max() <= ops.WINDOW_BYTES // rowb + sizes.max()
+    one_tile = (torch.tensor([0, N], dtype=torch.int32, device=DEV), 1)                  # any partition is correct
     for scale in (None, sc):
         for coef in (0.0, 1.3):
-            a = ops.gather_segsum_tiled(x, i_d, p_d, scale=scale, self_coef=coef)
             b = ops.gather_segsum(x, i_d, p_d, N, scale=scale, self_in=x if coef else None, self_coef=coef)
-            assert torch.equal(a, b)
+            for tl in (tiles, one_tile):
+                a = ops.gather_segsum_window(x, i_d, p_d, tl, scale=scale, self_coef=coef)
+                assert torch.equal(a, b)
+
+
+def test_neighbor_sum_takes_the_window_path_on_a_batch_with_graph_boundaries():
+    """EdgeIndex(node_ptr=...) -> neighbor_sum forward and backward through dn_gather_segsum_window_*; same bits as without."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(5, 60, size=300)
+    node_ptr = np.concatenate([[0], np.cumsum(sizes)])
+    N, H = int(node_ptr[-1]), 128
+    src, dst = [], []
+    for g, n in enumerate(sizes):
+        m = 4 * n
+        src += list(node_ptr[g] + rng.integers(0, n, size=m)); dst += list(node_ptr[g] + rng.integers(0, n, size=m))
+    s, d = torch.tensor(src, device=DEV), torch.tensor(dst, device=DEV)
+    x = torch.randn(N, H, device=DEV)
+    go = torch.randn(N, H, device=DEV)
+    res = []
+    old_flag, ops.WINDOW_GATHER = ops.WINDOW_GATHER, True            # (opt-in path: see ops.WINDOW_GATHER)
+    for npt in (torch.from_numpy(node_ptr).to(DEV), None):
+        ix = ops.EdgeIndex(s, d, N, node_ptr=npt)
+        assert (ix.fwd.tiles_of is not None) == (npt is not None)
+        xd = x.clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            out = ops.neighbor_sum(xd, ix, 1.0)
+            out.backward(go)
+        finally:
+            ops.kernel_timer = None
+        tags = [r[0] for r in timer.records]
+        assert ("gather_segsum_window" in tags) == (npt is not None), tags
+        res.append((out.detach(), xd.grad))
+    ops.WINDOW_GATHER = old_flag
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

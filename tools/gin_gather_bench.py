@@ -8,7 +8,7 @@ r2 = syn.config2(graphs=16384)
 t2 = {k: torch.from_numpy(v).to(dev) for k, v in r2.items()}
 a2 = tr.dummy_augment_gc(t2["node_ptr"], t2["edge_ptr"], t2["src"], t2["dst"], t2["node_label"], t2["edge_label"])
 N2, E2, H2 = int(a2["node_label"].numel()), int(a2["src"].numel()), 128
-ei = ops.EdgeIndex(a2["src"], a2["dst"], N2)
+ei = ops.EdgeIndex(a2["src"], a2["dst"], N2, node_ptr=a2["node_ptr"])
 x2 = torch.randn(N2, H2, device=dev, requires_grad=True); go2 = torch.randn(N2, H2, device=dev)
 def fb():
     x2.grad = None
