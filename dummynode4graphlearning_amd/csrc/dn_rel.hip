@@ -1170,7 +1170,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__
 template <int H>
 __global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restrict__ part, const int32_t* __restrict__ pptr,
                                                           const bf16_t* __restrict__ Wn, const int32_t* __restrict__ idx,
-                                                          int32_t n, bf16_t* __restrict__ aux, bf16_t* __restrict__ out) {
+                                                          int32_t n, int32_t num_tiles, bf16_t* __restrict__ aux,
+                                                          bf16_t* __restrict__ out) {
     constexpr int SX = H + kPad, SYF = H + 4;
     constexpr int KS = H / 32, MT = kSsRows / 16, LPR = H / 8;
     static_assert(kSsRows * LPR == H * 4, "one piece per thread");
@@ -1178,57 +1179,61 @@ __global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float bufY[kSsRows * SYF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = wave * 16, pr = tid / LPR, pc = tid % LPR;
-    const int j = blockIdx.x * kSsRows + pr;
-    // my output row's current value: in flight under the partial sums and the MFMAs
-    int32_t orow = -1;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (j < n) {
-        orow = idx[j];
-        cur = *reinterpret_cast<const uint4*>(out + (size_t)orow * H + pc * 8);
-        for (int k = pptr[j]; k < pptr[j + 1]; ++k) {
-            const float4 u = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8);
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8 + 4);
-            a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w; a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
-        }
-    }
-    bf16x8 xr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xr[i] = (bf16_t)a[i];
-    *reinterpret_cast<bf16x8*>(bufX + pr * SX + pc * 8) = xr;
-    if (j < n) *reinterpret_cast<bf16x8*>(aux + (size_t)j * H + pc * 8) = xr;
-    bf16x8 wf[KS];
+    bf16x8 wf[KS];                                               // the relation's weights: loaded once per workgroup
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
-    __syncthreads();
-    f32x4 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(bufX + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int j = tile * kSsRows + pr;
+        // my output row's current value: in flight under the partial sums and the MFMAs
+        int32_t orow = -1;
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (j < n) {
+            orow = idx[j];
+            cur = *reinterpret_cast<const uint4*>(out + (size_t)orow * H + pc * 8);
+            for (int k = pptr[j]; k < pptr[j + 1]; ++k) {
+                const float4 u = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8);
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * H + pc * 8 + 4);
+                a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w; a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+            }
         }
-    }
+        bf16x8 xr;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)                                   // lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
-        *reinterpret_cast<f32x4*>(bufY + (m * 16 + (lane & 15)) * SYF + n0 + 4 * (lane >> 4)) = acc[m];
-    __syncthreads();
-    if (j < n) {
-        const float4 y0 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8);
-        const float4 y1 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8 + 4);
-        const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-        bf16x8 o;
+        for (int i = 0; i < 8; ++i) xr[i] = (bf16_t)a[i];
+        *reinterpret_cast<bf16x8*>(bufX + pr * SX + pc * 8) = xr;
+        if (j < n) *reinterpret_cast<bf16x8*>(aux + (size_t)j * H + pc * 8) = xr;
+        __syncthreads();
+        f32x4 acc[MT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = (bf16_t)(__uint_as_float(w[i] << 16) + y[2 * i]);
-            o[2 * i + 1] = (bf16_t)(__uint_as_float(w[i] & 0xffff0000u) + y[2 * i + 1]);
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(bufX + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc[m], 0, 0, 0);
+            }
         }
-        *reinterpret_cast<bf16x8*>(out + (size_t)orow * H + pc * 8) = o;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)                               // lane holds row m*16 + (lane&15), columns n0 + 4*(lane>>4) + i
+            *reinterpret_cast<f32x4*>(bufY + (m * 16 + (lane & 15)) * SYF + n0 + 4 * (lane >> 4)) = acc[m];
+        __syncthreads();
+        if (j < n) {
+            const float4 y0 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8);
+            const float4 y1 = *reinterpret_cast<const float4*>(bufY + pr * SYF + pc * 8 + 4);
+            const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = (bf16_t)(__uint_as_float(w[i] << 16) + y[2 * i]);
+                o[2 * i + 1] = (bf16_t)(__uint_as_float(w[i] & 0xffff0000u) + y[2 * i + 1]);
+            }
+            *reinterpret_cast<bf16x8*>(out + (size_t)orow * H + pc * 8) = o;
+        }
+        __syncthreads();                                         // bufY has been read: the next tile may overwrite bufX / bufY
     }
 }
 
@@ -1244,15 +1249,16 @@ int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_se
     DN_REQUIRE(part && part_ptr && Wn && idx && aux && out, "dn_fold_tail: NULL pointer");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(Wn) | reinterpret_cast<uintptr_t>(aux) |
                 reinterpret_cast<uintptr_t>(out)) % 16 == 0, "dn_fold_tail: unaligned pointer");
-    const unsigned grid = (unsigned)dn_cdiv(num_segments, kSsRows);
+    const int32_t num_tiles = (int32_t)dn_cdiv(num_segments, kSsRows);
+    const unsigned grid = (unsigned)(num_tiles < 512 ? num_tiles : 512);      // two workgroups per CU loop over the tiles
     hipStream_t st = (hipStream_t)stream;
     const float* p = part;
     const bf16_t *w = (const bf16_t*)Wn;
     bf16_t *a = (bf16_t*)aux, *o = (bf16_t*)out;
     const int32_t n = (int32_t)num_segments;
-    if (H == 256) hipLaunchKernelGGL((fold_tail_kernel<256>), dim3(grid), dim3(1024), 0, st, p, part_ptr, w, idx, n, a, o);
-    else if (H == 128) hipLaunchKernelGGL((fold_tail_kernel<128>), dim3(grid), dim3(512), 0, st, p, part_ptr, w, idx, n, a, o);
-    else hipLaunchKernelGGL((fold_tail_kernel<64>), dim3(grid), dim3(256), 0, st, p, part_ptr, w, idx, n, a, o);
+    if (H == 256) hipLaunchKernelGGL((fold_tail_kernel<256>), dim3(grid), dim3(1024), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
+    else if (H == 128) hipLaunchKernelGGL((fold_tail_kernel<128>), dim3(grid), dim3(512), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
+    else hipLaunchKernelGGL((fold_tail_kernel<64>), dim3(grid), dim3(256), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
