@@ -925,9 +925,9 @@ class RowIndex:
         self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
         self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
         self._slots, self._fold = {}, {}
-        # ~1.5 workgroups per CU for the split-K weight gradient whatever the batch size
+        # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size
         self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all,
-                                            max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 384 // 64) * 64)), want_ptr=True)
+                                            max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 256 // 64) * 64)), want_ptr=True)
 
 
 def _row_index_slots(ix, direction):
@@ -1453,9 +1453,9 @@ def _dense_table(n_rows, dev):
     key = (int(n_rows), str(dev))
     t = _dense_tables.get(key)
     if t is None:
-        # split-K chunks sized for ~1.5 workgroups per CU whatever the row count (a 20 k-row GC batch with 4096-row chunks
-        # would run its weight gradient on five workgroups)
-        chunk = max(256, min(WGRAD_CHUNK_ROWS, -(-int(n_rows) // 384 // 64) * 64))
+        # split-K chunks sized for ONE round of 256 workgroups whatever the row count (a 20 k-row GC batch with 4096-row chunks
+        # would run its weight gradient on five workgroups; 378 chunks of a 1 M-row batch would run one and a half rounds)
+        chunk = max(256, min(WGRAD_CHUNK_ROWS, -(-int(n_rows) // 256 // 64) * 64))
         t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev, chunk_rows=chunk))
         if len(_dense_tables) > 8:
             _dense_tables.clear()
