@@ -107,11 +107,20 @@ def test_randomised_parity_sweep():
         e_gx = float(gerr.max())
         if e_gx >= 1e-4:
             # a pre-activation within fp32 rounding of 0 may sit on opposite sides of a ReLU kink in the two evaluations: the
-            # forward value (~0) still matches, but that element's whole gradient path switches.  Such an event touches the
-            # rows around ONE node; a wrong kernel touches many.  Tolerate <= 1 % of the rows (at least 3), report it.
-            bad_rows = int((gerr.max(dim=1).values >= 1e-4).sum())
-            print("fuzz: ReLU-kink event?", desc, "grad_x max err %.2e on %d of %d rows" % (e_gx, bad_rows, N))
-            assert bad_rows <= max(3, N // 100) + 12, desc + ("grad_x", e_gx, bad_rows)
+            # forward value (~0) still matches, but that element's whole gradient path switches.  Such an event at node v touches
+            # v and the SOURCES of v's in-edges (all of a graph when v is its dummy node); a wrong kernel touches rows that no
+            # small set of nodes explains.  Require that at most 2 such neighbourhoods cover every bad row, and report it.
+            bad = np.nonzero((gerr.max(dim=1).values >= 1e-4).numpy())[0]
+            print("fuzz: ReLU-kink event?", desc, "grad_x max err %.2e on %d of %d rows" % (e_gx, len(bad), N))
+            left = set(bad.tolist())
+            nb = [set([v]) for v in range(N)]
+            for u, v in zip(rs["src"].tolist(), rs["dst"].tolist()):
+                nb[v].add(u)
+            for _ in range(2):
+                if left:
+                    best = max(range(N), key=lambda v: len(nb[v] & left))
+                    left -= nb[best]
+            assert not left, desc + ("grad_x", e_gx, len(bad), "rows not explained by two ReLU-kink neighbourhoods", sorted(left)[:8])
         if H in (64, 128) and N > 0:
             bl = dl.to(torch.bfloat16)
             xb = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
