@@ -30,7 +30,7 @@ class HipLinear(Linear):
     def forward(self, x):
         # exact fp32 products: at these batch sizes (10-20 k rows) the dense layers are a few microseconds either way, and the
         # BatchNorm / Adam steps behind them amplify the 1e-5 noise of the bf16 split into visible trajectory differences
-        return ops.linear_any(x, self.weight, self.bias, exact=True)
+        return ops.linear_any(x, self.weight, self.bias, exact="fwd")
 
 
 class HipBatchNorm1d(BatchNorm1d):
@@ -40,10 +40,16 @@ class HipBatchNorm1d(BatchNorm1d):
     def forward(self, x):
         if not (self.training and ops.batch_norm_rows_supported(x) and x.shape[0] > 1):     # (one row: torch raises, as it should)
             return super().forward(x)
-        y, mean, var = ops.batch_norm_rows(x, self.weight if self.affine else None, self.bias if self.affine else None, self.eps)
+        w, b = (self.weight, self.bias) if self.affine else (None, None)
         if self.track_running_stats:
             with torch.no_grad():
                 self.num_batches_tracked += 1
+            if self.momentum is not None and self.running_mean.dtype == torch.float32:
+                # the running-statistics update rides in the statistics launch (five tiny elementwise launches otherwise)
+                return ops.batch_norm_rows(x, w, b, self.eps, self.running_mean, self.running_var, self.momentum)[0]
+        y, mean, var = ops.batch_norm_rows(x, w, b, self.eps)
+        if self.track_running_stats:
+            with torch.no_grad():
                 mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
                 n = x.shape[0]
                 self.running_mean.mul_(1.0 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)

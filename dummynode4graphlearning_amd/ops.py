@@ -1471,7 +1471,10 @@ class _LinearActFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu, exact=None):
         x = x.contiguous()
         tiles, _ = _dense_table(x.shape[0], x.device)
+        # exact: None = module default, True / False, or "fwd" = exact products where errors propagate (forward, input
+        # gradient), the 3-term split for the weight gradient (a leaf: its 1e-5 relative error goes nowhere)
         ctx.exact = F32_EXACT if exact is None else bool(exact)
+        ctx.exact_w = False if exact == "fwd" else ctx.exact
         with f32_exact(ctx.exact):
             y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
                                bias=None if bias is None else bias.contiguous().view(1, -1), relu=relu)
@@ -1497,8 +1500,9 @@ class _LinearActFn(torch.autograd.Function):
             # g^T x -> [out, in] and colsum(g); the ReLU mask is applied while the rows are staged and the masked rows are
             # written out for the input-gradient launch (no separate elementwise pass)
             gm = torch.empty_like(g) if ctx.relu else None
-            gw, cs = rows_wgrad(g, x, chunks, 1, out_dtype=weight.dtype, colsum_of=1, mask_a=y if ctx.relu else None,
-                                a_out=gm)
+            with f32_exact(ctx.exact_w):
+                gw, cs = rows_wgrad(g, x, chunks, 1, out_dtype=weight.dtype, colsum_of=1, mask_a=y if ctx.relu else None,
+                                    a_out=gm)
             g = gm if ctx.relu else g
             gw = gw[0]
             if ctx.has_bias:
@@ -1619,16 +1623,20 @@ class _BatchNormRowsFn(torch.autograd.Function):
     """Training-mode BatchNorm over the rows of [N, C] (dn_batchnorm_rows_*): returns (y, mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.0):
         x = x.contiguous()
         N, C = x.shape
+        if running_mean is not None:
+            assert running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
+            assert running_mean.is_contiguous() and running_var.is_contiguous() and running_mean.numel() == C
         w32 = weight.detach().float().contiguous() if weight is not None else None
         b32 = bias.detach().float().contiguous() if bias is not None else None
         y = torch.empty_like(x)
         mean, var, rstd = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
         ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
         check(getattr(lib(), "dn_batchnorm_rows_" + _suffix(x))(ptr(x), N, C, ptr(w32), ptr(b32), float(eps), ptr(y), ptr(mean), ptr(var),
-                                                               ptr(rstd), ptr(ws), ws.numel(), stream_ptr()), "dn_batchnorm_rows")
+                                                               ptr(rstd), ptr(running_mean), ptr(running_var), float(momentum),
+                                                               ptr(ws), ws.numel(), stream_ptr()), "dn_batchnorm_rows")
         ctx.save_for_backward(x, mean, rstd, w32 if w32 is not None else x.new_empty(0))
         ctx.has_w, ctx.has_b = weight is not None, bias is not None
         ctx.wdtype = weight.dtype if weight is not None else None
@@ -1648,7 +1656,7 @@ class _BatchNormRowsFn(torch.autograd.Function):
                                                                    ws.numel(), stream_ptr()), "dn_batchnorm_rows_bwd")
         gw = s2.to(ctx.wdtype) if ctx.has_w else None
         gb = s1.to(ctx.wdtype if ctx.has_w else dy.dtype) if ctx.has_b else None
-        return dx, gw, gb, None
+        return dx, gw, gb, None, None, None, None
 
 
 def batch_norm_rows_supported(x):
@@ -1656,9 +1664,10 @@ def batch_norm_rows_supported(x):
             and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
 
 
-def batch_norm_rows(x, weight, bias, eps=1e-5):
-    """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x."""
-    return _BatchNormRowsFn.apply(x, weight, bias, eps)
+def batch_norm_rows(x, weight, bias, eps=1e-5, running_mean=None, running_var=None, momentum=0.0):
+    """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x.  running_mean / running_var (fp32
+    buffers, optional) are updated in place by the same launch: r = (1 - momentum) r + momentum * new, unbiased variance."""
+    return _BatchNormRowsFn.apply(x, weight, bias, eps, running_mean, running_var, momentum)
 
 
 _single_rel_tables = {}
