@@ -4,5 +4,6 @@ through the reference's nn.Module surface.  GPU only -- importing is cheap, ever
 built library or with CPU tensors."""
 from . import graph, ops, transforms, tu_io  # noqa: F401
 from .graph import BatchedGraph, GraphBatch  # noqa: F401
+from .hipgraph import StepGraph  # noqa: F401
 
 __version__ = "0.1.0"
