@@ -25,8 +25,9 @@ template <typename T> __device__ __forceinline__ T cvt(float v) { return (T)v; }
 
 // Y[tile rows, n0 : n0 + 64] = A[tile rows, :] @ Wr   with Wr[k][n] = transposed ? W[rel][n][k] : W[rel][k][n]
 template <typename T>
-__global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W, int32_t K,
-                                                             int32_t N, int32_t transposed, const Piece* __restrict__ tiles,
+__global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                             const T* __restrict__ bias, int32_t K, int32_t N,
+                                                             int32_t transposed, const Piece* __restrict__ tiles,
                                                              T* __restrict__ Y) {
     __shared__ float As[TK][TM + 1];
     __shared__ float Ws[TK][TN + 1];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tx * 4 + j;
-            if (n < N) Y[(size_t)(tl.beg + r) * N + n] = cvt<T>(acc[i][j]);
+            if (n < N) Y[(size_t)(tl.beg + r) * N + n] = cvt<T>(acc[i][j] + (bias ? ld(bias + (size_t)tl.rel * N + n) : 0.f));
         }
     }
 }
@@ -77,13 +78,15 @@ __global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(kThreads) void rows_wgrad_any_kernel(const T* __restrict__ A, const T* __restrict__ G, int32_t K,
                                                                   int32_t N, const Piece* __restrict__ chunks,
-                                                                  float* __restrict__ partial) {
+                                                                  float* __restrict__ partial, float* __restrict__ cs_partial) {
     __shared__ float As[TK][TM + 1];                                     // [row in step][k]
     __shared__ float Gs[TK][TN + 1];                                     // [row in step][n]
     const Piece ch = chunks[blockIdx.x];
     const int k0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
     const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
     float acc[4][4] = {};
+    float cs[4] = {};                                                    // column sums of A (n-tile 0, threads tx == 0 only)
+    const bool do_cs = cs_partial != nullptr && blockIdx.z == 0 && tx == 0;
     for (int p0 = ch.beg; p0 < ch.end; p0 += TK) {
         for (int i = tid; i < TK * TM; i += kThreads) {
             const int r = i / TM, k = i % TM;
@@ -103,8 +106,17 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_any_kernel(const T* __res
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] += a[i];
+            }
         }
         __syncthreads();
+    }
+    if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k0 + ty * 4 + i < K) cs_partial[(size_t)blockIdx.x * K + k0 + ty * 4 + i] = cs[i];
     }
     float* out = partial + (size_t)blockIdx.x * K * N;
 #pragma unroll
@@ -122,8 +134,18 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_any_kernel(const T* __res
 // out[r] = sum over relation r's chunks of partial[chunk], chunk order (fixed association)
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_any_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ chunk_ptr,
-                                                               int64_t elems, T* __restrict__ out) {
+                                                               int64_t elems, T* __restrict__ out, const float* __restrict__ cs_partial,
+                                                               int32_t K, float* __restrict__ cs_out) {
     const int r = blockIdx.y;
+    const int64_t tile_blocks = (elems + 255) / 256;
+    if ((int64_t)blockIdx.x >= tile_blocks) {                            // blocks past the tile: the column sums, same order
+        const int64_t k = ((int64_t)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
+        if (k >= K) return;
+        float s = 0.f;
+        for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) s += cs_partial[(size_t)c * K + k];
+        cs_out[(size_t)r * K + k] = s;
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
     float s = 0.f;
@@ -132,34 +154,36 @@ __global__ __launch_bounds__(256) void wgrad_any_reduce_kernel(const float* __re
 }
 
 template <typename T>
-int rows_gemm(const T* A, const T* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles, int64_t num_tiles, T* Y,
-              hipStream_t st) {
+int rows_gemm(const T* A, const T* W, const T* bias, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles, int64_t num_tiles,
+              T* Y, hipStream_t st) {
     DN_REQUIRE(K >= 1 && N >= 1 && num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_gemm: bad sizes");
     if (num_tiles == 0) return DN_OK;
     DN_REQUIRE(A && W && tiles && Y, "dn_rows_gemm: NULL pointer");
-    hipLaunchKernelGGL((rows_gemm_kernel<T>), dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st, A, W, K, N,
-                       transposed, reinterpret_cast<const Piece*>(tiles), Y);
+    hipLaunchKernelGGL((rows_gemm_kernel<T>), dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st, A, W, bias, K,
+                       N, transposed, reinterpret_cast<const Piece*>(tiles), Y);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 template <typename T>
 int rows_wgrad_any(const T* A, const T* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                   const int32_t* chunk_ptr, T* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                   const int32_t* chunk_ptr, T* out, float* colsum_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DN_REQUIRE(K >= 1 && N >= 1 && R >= 0 && num_chunks >= 0 && num_chunks < 65536LL * 32768, "dn_rows_wgrad_any: bad sizes");
     if (R == 0) return DN_OK;
     DN_REQUIRE(out && chunk_ptr, "dn_rows_wgrad_any: NULL pointer");
     DN_REQUIRE(num_chunks == 0 || (A && G && chunks && workspace), "dn_rows_wgrad_any: NULL pointer");
-    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * K * N * sizeof(float), "dn_rows_wgrad_any: workspace too small");
+    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * K * (N + 1) * sizeof(float), "dn_rows_wgrad_any: workspace too small");
+    float* cs_partial = colsum_out ? (float*)workspace + (size_t)num_chunks * K * N : nullptr;
     DN_REQUIRE(dn_cdiv(K, TM) <= 65535 && dn_cdiv(N, TN) <= 65535, "dn_rows_wgrad_any: layer too wide");
     if (num_chunks > 0) {
         hipLaunchKernelGGL((rows_wgrad_any_kernel<T>), dim3((unsigned)num_chunks, (unsigned)dn_cdiv(K, TM), (unsigned)dn_cdiv(N, TN)),
-                           dim3(kThreads), 0, st, A, G, K, N, reinterpret_cast<const Piece*>(chunks), (float*)workspace);
+                           dim3(kThreads), 0, st, A, G, K, N, reinterpret_cast<const Piece*>(chunks), (float*)workspace, cs_partial);
         DN_CHECK_LAUNCH();
     }
     const int64_t elems = (int64_t)K * N;
-    hipLaunchKernelGGL((wgrad_any_reduce_kernel<T>), dim3((unsigned)dn_cdiv(elems, 256), (unsigned)R), dim3(256), 0, st,
-                       (const float*)workspace, chunk_ptr, elems, out);
+    const int64_t cs_blocks = colsum_out ? dn_cdiv(K, 256) : 0;
+    hipLaunchKernelGGL((wgrad_any_reduce_kernel<T>), dim3((unsigned)(dn_cdiv(elems, 256) + cs_blocks), (unsigned)R), dim3(256), 0, st,
+                       (const float*)workspace, chunk_ptr, elems, out, (const float*)cs_partial, K, colsum_out);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -168,26 +192,30 @@ int rows_wgrad_any(const T* A, const T* G, int32_t K, int32_t N, int64_t R, cons
 
 extern "C" {
 
-int dn_rows_gemm_f32(const float* A, const float* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+int dn_rows_gemm_f32(const float* A, const float* W, const float* bias, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
                      int64_t num_tiles, float* Y, dn_stream_t stream) {
-    return rows_gemm<float>(A, W, K, N, transposed, tiles, num_tiles, Y, (hipStream_t)stream);
+    return rows_gemm<float>(A, W, bias, K, N, transposed, tiles, num_tiles, Y, (hipStream_t)stream);
 }
-int dn_rows_gemm_bf16(const void* A, const void* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+int dn_rows_gemm_bf16(const void* A, const void* W, const void* bias, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
                       int64_t num_tiles, void* Y, dn_stream_t stream) {
-    return rows_gemm<bf16_t>((const bf16_t*)A, (const bf16_t*)W, K, N, transposed, tiles, num_tiles, (bf16_t*)Y, (hipStream_t)stream);
+    return rows_gemm<bf16_t>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, K, N, transposed, tiles, num_tiles, (bf16_t*)Y,
+                             (hipStream_t)stream);
 }
 size_t dn_rows_wgrad_any_workspace_bytes(int64_t num_chunks, int32_t K, int32_t N) {
     if (num_chunks < 0 || K <= 0 || N <= 0) { dn_set_error("dn_rows_wgrad_any_workspace_bytes: bad sizes"); return 0; }
-    return (size_t)(num_chunks > 0 ? num_chunks : 1) * (size_t)K * N * sizeof(float);
+    return (size_t)(num_chunks > 0 ? num_chunks : 1) * (size_t)K * (N + 1) * sizeof(float);        // products + column sums
 }
 int dn_rows_wgrad_any_f32(const float* A, const float* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                          const int32_t* chunk_ptr, float* out, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
-    return rows_wgrad_any<float>(A, G, K, N, R, chunks, num_chunks, chunk_ptr, out, workspace, workspace_bytes, (hipStream_t)stream);
+                          const int32_t* chunk_ptr, float* out, float* colsum_out, void* workspace, size_t workspace_bytes,
+                          dn_stream_t stream) {
+    return rows_wgrad_any<float>(A, G, K, N, R, chunks, num_chunks, chunk_ptr, out, colsum_out, workspace, workspace_bytes,
+                                 (hipStream_t)stream);
 }
 int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                           const int32_t* chunk_ptr, void* out, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
-    return rows_wgrad_any<bf16_t>((const bf16_t*)A, (const bf16_t*)G, K, N, R, chunks, num_chunks, chunk_ptr, (bf16_t*)out, workspace,
-                                  workspace_bytes, (hipStream_t)stream);
+                           const int32_t* chunk_ptr, void* out, float* colsum_out, void* workspace, size_t workspace_bytes,
+                           dn_stream_t stream) {
+    return rows_wgrad_any<bf16_t>((const bf16_t*)A, (const bf16_t*)G, K, N, R, chunks, num_chunks, chunk_ptr, (bf16_t*)out, colsum_out,
+                                  workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -733,12 +733,15 @@ def neighbor_max(x, index):
     return _NeighborMax.apply(x, index)
 
 
-def rows_gemm(A, W, tile_table, transpose_w=False):
-    """Y[rows of relation r] = A[rows] @ W[r] (or W[r]^T) for ANY widths in one launch (dn_rows_gemm_*; rows relation-major,
-    64-row tiles from build_row_tables).  W: [R, K, N], or [R, N, K] with transpose_w."""
+def rows_gemm(A, W, tile_table, transpose_w=False, bias=None):
+    """Y[rows of relation r] = A[rows] @ W[r] (or W[r]^T) (+ bias[r]) for ANY widths in one launch (dn_rows_gemm_*; rows
+    relation-major, 64-row tiles from build_row_tables).  W: [R, K, N], or [R, N, K] with transpose_w; bias: [R, N]."""
     tiles, ntiles = tile_table
     A, W = A.contiguous(), W.contiguous()
-    require_gpu(A, W, tiles)
+    require_gpu(A, W, tiles, bias)
+    if bias is not None:
+        bias = bias.contiguous()
+        assert bias.dtype == A.dtype and bias.numel() == W.shape[0] * (W.shape[1] if transpose_w else W.shape[2])
     K = A.shape[1]
     N = W.shape[1] if transpose_w else W.shape[2]
     assert A.dtype == W.dtype and (W.shape[2] if transpose_w else W.shape[1]) == K
@@ -747,8 +750,8 @@ def rows_gemm(A, W, tile_table, transpose_w=False):
         return Y
 
     def _launch():
-        check(getattr(lib(), "dn_rows_gemm_" + _suffix(A))(ptr(A), ptr(W), K, N, 1 if transpose_w else 0, ptr(tiles), ntiles,
-                                                          ptr(Y), stream_ptr()), "dn_rows_gemm")
+        check(getattr(lib(), "dn_rows_gemm_" + _suffix(A))(ptr(A), ptr(W), ptr(bias), K, N, 1 if transpose_w else 0, ptr(tiles),
+                                                          ntiles, ptr(Y), stream_ptr()), "dn_rows_gemm")
     if kernel_timer is not None:
         kernel_timer.launch("rows_gemm", _launch)
     else:
@@ -756,17 +759,19 @@ def rows_gemm(A, W, tile_table, transpose_w=False):
     return Y
 
 
-def rows_wgrad_any(A, G, chunk_table, num_rels):
-    """out[r] = sum_{p in relation r} A[p]^T G[p] for ANY widths (dn_rows_wgrad_any_*)."""
+def rows_wgrad_any(A, G, chunk_table, num_rels, want_colsum=False):
+    """out[r] = sum_{p in relation r} A[p]^T G[p] for ANY widths (dn_rows_wgrad_any_*); want_colsum: also the fp32 column sums
+    of A per relation ([R, K]: the bias gradient when A is a Linear layer's output gradient), from the same launches."""
     chunks, chunk_ptr, nchunks = chunk_table
     A, G = A.contiguous(), G.contiguous()
     require_gpu(A, G, chunks, chunk_ptr)
     K, N = A.shape[1], G.shape[1]
     out = torch.empty((num_rels, K, N), dtype=A.dtype, device=A.device)
+    cs = torch.empty((num_rels, K), dtype=torch.float32, device=A.device) if want_colsum else None
     ws = _ws(lib().dn_rows_wgrad_any_workspace_bytes(nchunks, K, N), A.device)
     check(getattr(lib(), "dn_rows_wgrad_any_" + _suffix(A))(ptr(A), ptr(G), K, N, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr),
-                                                           ptr(out), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_any")
-    return out
+                                                           ptr(out), ptr(cs), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_any")
+    return (out, cs) if want_colsum else out
 
 
 class _RelAggTransform(torch.autograd.Function):
@@ -1696,9 +1701,8 @@ class _LinearAnyFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         x = x.contiguous()
         tiles, _ = _single_rel_table(x.shape[0], x.device)
-        y = rows_gemm(x, weight.contiguous().unsqueeze(0), tiles, transpose_w=True)          # W[0] is [N, K] = [out, in]
-        if bias is not None:
-            y = y + bias
+        y = rows_gemm(x, weight.contiguous().unsqueeze(0), tiles, transpose_w=True,          # W[0] is [N, K] = [out, in]
+                      bias=None if bias is None else bias.contiguous().view(1, -1))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight)
         return y
@@ -1711,10 +1715,12 @@ class _LinearAnyFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = rows_gemm(g, weight.contiguous().unsqueeze(0), tiles)                       # g [P, out] @ W [out, in]
-        if ctx.needs_input_grad[1]:
-            gw = rows_wgrad_any(g, x, chunks, 1)[0]                                          # [out, in]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:                                                # g^T x -> [out, in]; colsum(g) -> bias
+            gw, cs = rows_wgrad_any(g, x, chunks, 1, want_colsum=True)
+            gw = gw[0]
+            if need_b:
+                gb = cs[0].to(g.dtype)
         return gx, gw, gb
 
 

@@ -407,19 +407,23 @@ int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, d
 /* Relation-grouped dense products for ANY widths (what PyG's RGCNConv computes with a Python loop over relations,
  * `for i in range(num_relations): out += h @ weight[i]`; call sites graph_classification/graph_neural_networks/models/
  * rgconv.py:17-18,96): rows p relation-major, pieces from dn_row_tables_build_i32 (step 64 for the tiles).
- *   dn_rows_gemm_*       Y[p,:] = A[p,:] @ Wr,  Wr[k][n] = transposed ? W[rel][n][k] : W[rel][k][n]   (A [P,K], Y [P,N])
+ *   dn_rows_gemm_*       Y[p,:] = A[p,:] @ Wr (+ bias[rel]),  Wr[k][n] = transposed ? W[rel][n][k] : W[rel][k][n]   (A [P,K], Y [P,N];
+ *                        bias [R,N] in the storage type, may be NULL)
  *   dn_rows_wgrad_any_*  out[r] = sum_{p in relation r} A[p,:]^T G[p,:]   ([K,N] per relation; split-K chunks, partials added
- *                        in chunk order; workspace from dn_rows_wgrad_any_workspace_bytes)
+ *                        in chunk order; workspace from dn_rows_wgrad_any_workspace_bytes); colsum_out (fp32 [R,K], may be NULL)
+ *                        = sum_{p in relation r} A[p,:], the bias gradient of a Linear layer whose output gradient is A
  * fp32 accumulation, plain FMA tiles (the widths here are the ones the matrix-core kernels do not cover). */
-int dn_rows_gemm_f32(const float* A, const float* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+int dn_rows_gemm_f32(const float* A, const float* W, const float* bias, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
                      int64_t num_tiles, float* Y, dn_stream_t stream);
-int dn_rows_gemm_bf16(const void* A, const void* W, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
+int dn_rows_gemm_bf16(const void* A, const void* W, const void* bias, int32_t K, int32_t N, int32_t transposed, const int32_t* tiles,
                       int64_t num_tiles, void* Y, dn_stream_t stream);
 size_t dn_rows_wgrad_any_workspace_bytes(int64_t num_chunks, int32_t K, int32_t N);
 int dn_rows_wgrad_any_f32(const float* A, const float* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                          const int32_t* chunk_ptr, float* out, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                          const int32_t* chunk_ptr, float* out, float* colsum_out, void* workspace, size_t workspace_bytes,
+                          dn_stream_t stream);
 int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, int64_t R, const int32_t* chunks, int64_t num_chunks,
-                           const int32_t* chunk_ptr, void* out, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                           const int32_t* chunk_ptr, void* out, float* colsum_out, void* workspace, size_t workspace_bytes,
+                           dn_stream_t stream);
 
 /* BatchNorm over the rows of [N, C] node features, training mode (batch statistics) -- the BatchNorm1d inside the MLPs of the GC
  * models (graph_classification/graph_neural_networks/models/gconv.py:187-194, rgconv.py:85-93).
