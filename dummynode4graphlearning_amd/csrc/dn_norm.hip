@@ -42,10 +42,11 @@ template <> struct V4<bf16_t> {
 
 // One workgroup per chunk of kChunkRows rows: partial[chunk][0][c] = sum_r f(r, c), partial[chunk][1][c] = sum_r g(r, c).
 //   MODE 0 (forward statistics):  f = x - shift,  g = (x - shift)^2        (shift[c] = x[0][c])
-//   MODE 1 (backward reduction):  f = dy,         g = dy * (x - mean) * rstd
+//   MODE 1 (backward reduction):  f = dy,         g = dy * (x - mean) * rstd      (dy masked by y > 0 when a ReLU is fused)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void colreduce_kernel(const T* __restrict__ X, const T* __restrict__ DY,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ w, const float* __restrict__ bias, int32_t relu,
                                                            int64_t N, int32_t C, float* __restrict__ partial) {
     extern __shared__ float red[];                     // [groups][2][C]
     const int LPR = C / 4;                             // lanes per row (C % 4 == 0, C <= 1024)
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(kBlock) void colreduce_kernel(const T* __restrict__
     const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
     const int c = lane * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, s[4], m[4], rs[4];
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, s[4], m[4], rs[4], gw[4], gb[4];
     if (grp < GPB) {
         if (MODE == 0) V4<T>::load(X + c, s);
         else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { m[i] = mean[c + i]; rs[i] = rstd[c + i]; }
+            for (int i = 0; i < 4; ++i) { m[i] = mean[c + i]; rs[i] = rstd[c + i]; gw[i] = w ? w[c + i] : 1.f; gb[i] = bias ? bias[c + i] : 0.f; }
         }
         for (int64_t r = r0 + grp; r < r0 + kChunkRows && r < N; r += GPB) {
             float x[4];
@@ -70,7 +71,13 @@ __global__ __launch_bounds__(kBlock) void colreduce_kernel(const T* __restrict__
                 float dy[4];
                 V4<T>::load(DY + (size_t)r * C + c, dy);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] += dy[i]; b[i] = fmaf(dy[i], (x[i] - m[i]) * rs[i], b[i]); }
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (x[i] - m[i]) * rs[i];
+                    const float keep = (relu && !(fmaf(xh, gw[i], gb[i]) > 0.f)) ? 0.f : 1.f;       // fused ReLU: dy where y > 0
+                    const float d = dy[i] * keep;
+                    a[i] += d;
+                    b[i] = fmaf(d, xh, b[i]);
+                }
             }
         }
 #pragma unroll
@@ -140,13 +147,13 @@ __global__ __launch_bounds__(kBlock) void colfinal_kernel(const float* __restric
     }
 }
 
-// MODE 0: y = (x - mean) * rstd * w + b;   MODE 1: dx = w * rstd * (dy - s1 / N - xhat * s2 / N)
+// MODE 0: y = relu?((x - mean) * rstd * w + b);   MODE 1: dx = w * rstd * (dy' - s1 / N - xhat * s2 / N), dy' = dy masked by y > 0
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ X, const T* __restrict__ DY,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ w, const float* __restrict__ b,
-                                                          const float* __restrict__ s1, const float* __restrict__ s2, int64_t N,
-                                                          int32_t C, T* __restrict__ out) {
+                                                          const float* __restrict__ s1, const float* __restrict__ s2, int32_t relu,
+                                                          int64_t N, int32_t C, T* __restrict__ out) {
     const int64_t total = N * (C / 4);
     const float invN = 1.f / (float)N;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
             for (int k = 0; k < 4; ++k) {
                 const float g = w ? w[c + k] : 1.f, bb = b ? b[c + k] : 0.f;
                 o[k] = fmaf((x[k] - mean[c + k]) * rstd[c + k], g, bb);
+                if (relu) o[k] = fmaxf(o[k], 0.f);
             }
         } else {
             float dy[4];
@@ -166,7 +174,10 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
             for (int k = 0; k < 4; ++k) {
                 const float g = w ? w[c + k] : 1.f;
                 const float xh = (x[k] - mean[c + k]) * rstd[c + k];
-                o[k] = g * rstd[c + k] * (dy[k] - s1[c + k] * invN - xh * s2[c + k] * invN);
+                // (as a product: hipcc 7.0 turns `cond ? 0.f : dy[k]` here into "dy[k] = 0; if (!cond) {}" -- the gradient vanished)
+                const float keep = (relu && !(fmaf(xh, g, b ? b[c + k] : 0.f) > 0.f)) ? 0.f : 1.f;
+                const float d = dy[k] * keep;
+                o[k] = g * rstd[c + k] * (d - s1[c + k] * invN - xh * s2[c + k] * invN);
             }
         }
         V4<T>::store(out + i * 4, o);
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
 
 template <typename T>
 int bn_forward(const T* X, int64_t N, int32_t C, const float* w, const float* b, float eps, T* Y, float* mean, float* var, float* rstd,
-               float* run_mean, float* run_var, float momentum, float* ws, size_t ws_bytes, hipStream_t st) {
+               float* run_mean, float* run_var, float momentum, int32_t relu, float* ws, size_t ws_bytes, hipStream_t st) {
     DN_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "dn_batchnorm_rows: running_mean and running_var come together");
     DN_REQUIRE(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dn_batchnorm_rows: need N >= 1 and C a multiple of 4 in [4, 1024] (got %lld x %d)",
                (long long)N, C);
@@ -186,19 +197,19 @@ int bn_forward(const T* X, int64_t N, int32_t C, const float* w, const float* b,
     const int GPB = kBlock / (C / 4);
     DN_REQUIRE(GPB >= 1, "dn_batchnorm_rows: C too large");
     hipLaunchKernelGGL((colreduce_kernel<T, 0>), dim3((unsigned)nchunks), dim3(kBlock), (size_t)GPB * 2 * C * sizeof(float), st, X,
-                       (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, N, C, ws);
+                       (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, C, ws);
     hipLaunchKernelGGL((colfinal_kernel<0, T>), dim3((unsigned)dn_cdiv(C, kBlock / 8)), dim3(kBlock), 0, st, (const float*)ws, nchunks, N, C, X,
                        eps, mean, var, rstd, run_mean, run_var, momentum);
     const int64_t blocks = dn_cdiv(N * (C / 4), kBlock);
     hipLaunchKernelGGL((colapply_kernel<T, 0>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, st, X, (const T*)nullptr,
-                       (const float*)mean, (const float*)rstd, w, b, (const float*)nullptr, (const float*)nullptr, N, C, Y);
+                       (const float*)mean, (const float*)rstd, w, b, (const float*)nullptr, (const float*)nullptr, relu, N, C, Y);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 template <typename T>
-int bn_backward(const T* DY, const T* X, int64_t N, int32_t C, const float* mean, const float* rstd, const float* w, T* DX, float* s1,
-                float* s2, float* ws, size_t ws_bytes, hipStream_t st) {
+int bn_backward(const T* DY, const T* X, int64_t N, int32_t C, const float* mean, const float* rstd, const float* w, const float* b,
+                int32_t relu, T* DX, float* s1, float* s2, float* ws, size_t ws_bytes, hipStream_t st) {
     DN_REQUIRE(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dn_batchnorm_rows_bwd: bad sizes");
     DN_REQUIRE(DY && X && mean && rstd && DX && s1 && s2 && ws, "dn_batchnorm_rows_bwd: NULL pointer");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(DY) | reinterpret_cast<uintptr_t>(DX)) % 16 == 0,
@@ -207,12 +218,12 @@ int bn_backward(const T* DY, const T* X, int64_t N, int32_t C, const float* mean
     DN_REQUIRE(ws_bytes >= (size_t)nchunks * 2 * C * sizeof(float), "dn_batchnorm_rows_bwd: workspace too small");
     const int GPB = kBlock / (C / 4);
     hipLaunchKernelGGL((colreduce_kernel<T, 1>), dim3((unsigned)nchunks), dim3(kBlock), (size_t)GPB * 2 * C * sizeof(float), st, X, DY, mean,
-                       rstd, N, C, ws);
+                       rstd, w, b, relu, N, C, ws);
     hipLaunchKernelGGL((colfinal_kernel<1, T>), dim3((unsigned)dn_cdiv(C, kBlock / 8)), dim3(kBlock), 0, st, (const float*)ws, nchunks, N, C, X,
                        0.f, s1, s2, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
     const int64_t blocks = dn_cdiv(N * (C / 4), kBlock);
     hipLaunchKernelGGL((colapply_kernel<T, 1>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, st, X, DY, mean, rstd, w,
-                       (const float*)nullptr, (const float*)s1, (const float*)s2, N, C, DX);
+                       b, (const float*)s1, (const float*)s2, relu, N, C, DX);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -226,27 +237,28 @@ size_t dn_batchnorm_rows_workspace_bytes(int64_t N, int32_t C) {
     return (size_t)(N > 0 ? dn_cdiv(N, kChunkRows) : 1) * 2 * (size_t)C * sizeof(float);
 }
 int dn_batchnorm_rows_f32(const float* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, float* Y, float* mean,
-                          float* var, float* rstd, float* running_mean, float* running_var, float momentum, void* workspace,
-                          size_t workspace_bytes, dn_stream_t stream) {
-    return bn_forward<float>(X, N, C, weight, bias, eps, Y, mean, var, rstd, running_mean, running_var, momentum, (float*)workspace,
+                          float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
+                          void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    return bn_forward<float>(X, N, C, weight, bias, eps, Y, mean, var, rstd, running_mean, running_var, momentum, relu, (float*)workspace,
                              workspace_bytes, (hipStream_t)stream);
 }
 int dn_batchnorm_rows_bf16(const void* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, void* Y, float* mean,
-                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, void* workspace,
-                           size_t workspace_bytes, dn_stream_t stream) {
+                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     return bn_forward<bf16_t>((const bf16_t*)X, N, C, weight, bias, eps, (bf16_t*)Y, mean, var, rstd, running_mean, running_var, momentum,
-                              (float*)workspace, workspace_bytes, (hipStream_t)stream);
+                              relu, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 int dn_batchnorm_rows_bwd_f32(const float* DY, const float* X, int64_t N, int32_t C, const float* mean, const float* rstd,
-                              const float* weight, float* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
-                              dn_stream_t stream) {
-    return bn_backward<float>(DY, X, N, C, mean, rstd, weight, DX, sum_dy, sum_dy_xhat, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+                              const float* weight, const float* bias, int32_t relu, float* DX, float* sum_dy, float* sum_dy_xhat,
+                              void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    return bn_backward<float>(DY, X, N, C, mean, rstd, weight, bias, relu, DX, sum_dy, sum_dy_xhat, (float*)workspace, workspace_bytes,
+                              (hipStream_t)stream);
 }
 int dn_batchnorm_rows_bwd_bf16(const void* DY, const void* X, int64_t N, int32_t C, const float* mean, const float* rstd,
-                               const float* weight, void* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
-                               dn_stream_t stream) {
-    return bn_backward<bf16_t>((const bf16_t*)DY, (const bf16_t*)X, N, C, mean, rstd, weight, (bf16_t*)DX, sum_dy, sum_dy_xhat,
-                               (float*)workspace, workspace_bytes, (hipStream_t)stream);
+                               const float* weight, const float* bias, int32_t relu, void* DX, float* sum_dy, float* sum_dy_xhat,
+                               void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    return bn_backward<bf16_t>((const bf16_t*)DY, (const bf16_t*)X, N, C, mean, rstd, weight, bias, relu, (bf16_t*)DX, sum_dy,
+                               sum_dy_xhat, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

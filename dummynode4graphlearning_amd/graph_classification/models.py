@@ -8,7 +8,7 @@ rgconv.py:6-126 (RGCN, RGIN; not exported there and reading ``args.nhid`` -- her
 """
 import torch
 import torch.nn.functional as F
-from torch.nn import BatchNorm1d, Linear, ReLU, Sequential
+from torch.nn import BatchNorm1d, Identity, Linear, ReLU, Sequential
 
 from .. import ops
 from .conv import GCNConv, GINConv, RGCNConv, SAGEConv, global_add_pool, global_max_pool, global_mean_pool
@@ -35,19 +35,27 @@ class HipLinear(Linear):
 
 class HipBatchNorm1d(BatchNorm1d):
     """torch.nn.BatchNorm1d (same parameters, buffers, names) whose training-mode statistics, normalisation and backward run
-    as the row-streaming kernels of dn_norm.hip; eval mode and unsupported shapes fall through to torch."""
+    as the row-streaming kernels of dn_norm.hip; eval mode and unsupported shapes fall through to torch.  fuse_relu: the module
+    also applies the ReLU that follows it in the reference's Sequential (the ReLU's slot then holds an Identity, so the
+    state_dict keys and module indices stay those of `Sequential(Linear, BatchNorm1d, ReLU, ...)`)."""
+
+    def __init__(self, *args, fuse_relu=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.fuse_relu = bool(fuse_relu)
 
     def forward(self, x):
         if not (self.training and ops.batch_norm_rows_supported(x) and x.shape[0] > 1):     # (one row: torch raises, as it should)
-            return super().forward(x)
+            y = super().forward(x)
+            return F.relu(y) if self.fuse_relu else y
         w, b = (self.weight, self.bias) if self.affine else (None, None)
         if self.track_running_stats:
             with torch.no_grad():
                 self.num_batches_tracked += 1
             if self.momentum is not None and self.running_mean.dtype == torch.float32:
                 # the running-statistics update rides in the statistics launch (five tiny elementwise launches otherwise)
-                return ops.batch_norm_rows(x, w, b, self.eps, self.running_mean, self.running_var, self.momentum)[0]
-        y, mean, var = ops.batch_norm_rows(x, w, b, self.eps)
+                return ops.batch_norm_rows(x, w, b, self.eps, self.running_mean, self.running_var, self.momentum,
+                                           relu=self.fuse_relu)[0]
+        y, mean, var = ops.batch_norm_rows(x, w, b, self.eps, relu=self.fuse_relu)
         if self.track_running_stats:
             with torch.no_grad():
                 mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
@@ -58,8 +66,10 @@ class HipBatchNorm1d(BatchNorm1d):
 
 
 def _mlp(in_dim, out_dim):
-    return Sequential(HipLinear(in_dim, out_dim), HipBatchNorm1d(out_dim), ReLU(),
-                      HipLinear(out_dim, out_dim), HipBatchNorm1d(out_dim), ReLU())
+    """gconv.py:187-194 / rgconv.py:85-93: Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) -- same indices and
+    parameter names; each ReLU runs inside the BatchNorm launches before it."""
+    return Sequential(HipLinear(in_dim, out_dim), HipBatchNorm1d(out_dim, fuse_relu=True), Identity(),
+                      HipLinear(out_dim, out_dim), HipBatchNorm1d(out_dim, fuse_relu=True), Identity())
 
 
 def _edge_type(data, x):

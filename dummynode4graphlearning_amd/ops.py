@@ -1628,7 +1628,7 @@ class _BatchNormRowsFn(torch.autograd.Function):
     """Training-mode BatchNorm over the rows of [N, C] (dn_batchnorm_rows_*): returns (y, mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.0):
+    def forward(ctx, x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.0, relu=False):
         x = x.contiguous()
         N, C = x.shape
         if running_mean is not None:
@@ -1641,8 +1641,11 @@ class _BatchNormRowsFn(torch.autograd.Function):
         ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
         check(getattr(lib(), "dn_batchnorm_rows_" + _suffix(x))(ptr(x), N, C, ptr(w32), ptr(b32), float(eps), ptr(y), ptr(mean), ptr(var),
                                                                ptr(rstd), ptr(running_mean), ptr(running_var), float(momentum),
-                                                               ptr(ws), ws.numel(), stream_ptr()), "dn_batchnorm_rows")
-        ctx.save_for_backward(x, mean, rstd, w32 if w32 is not None else x.new_empty(0))
+                                                               1 if relu else 0, ptr(ws), ws.numel(), stream_ptr()),
+              "dn_batchnorm_rows")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, mean, rstd, w32 if w32 is not None else x.new_empty(0),
+                              b32 if (relu and b32 is not None) else x.new_empty(0))
         ctx.has_w, ctx.has_b = weight is not None, bias is not None
         ctx.wdtype = weight.dtype if weight is not None else None
         ctx.mark_non_differentiable(mean, var)
@@ -1650,18 +1653,20 @@ class _BatchNormRowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        x, mean, rstd, w32 = ctx.saved_tensors
+        x, mean, rstd, w32, b32 = ctx.saved_tensors
         dy = dy.contiguous()
         N, C = x.shape
         dx = torch.empty_like(x)
         s1, s2 = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(2))
         ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
         check(getattr(lib(), "dn_batchnorm_rows_bwd_" + _suffix(x))(ptr(dy), ptr(x), N, C, ptr(mean), ptr(rstd),
-                                                                   ptr(w32) if ctx.has_w else None, ptr(dx), ptr(s1), ptr(s2), ptr(ws),
+                                                                   ptr(w32) if ctx.has_w else None,
+                                                                   ptr(b32) if (ctx.relu and ctx.has_b) else None,
+                                                                   1 if ctx.relu else 0, ptr(dx), ptr(s1), ptr(s2), ptr(ws),
                                                                    ws.numel(), stream_ptr()), "dn_batchnorm_rows_bwd")
         gw = s2.to(ctx.wdtype) if ctx.has_w else None
         gb = s1.to(ctx.wdtype if ctx.has_w else dy.dtype) if ctx.has_b else None
-        return dx, gw, gb, None, None, None, None
+        return dx, gw, gb, None, None, None, None, None
 
 
 def batch_norm_rows_supported(x):
@@ -1669,10 +1674,11 @@ def batch_norm_rows_supported(x):
             and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
 
 
-def batch_norm_rows(x, weight, bias, eps=1e-5, running_mean=None, running_var=None, momentum=0.0):
-    """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x.  running_mean / running_var (fp32
-    buffers, optional) are updated in place by the same launch: r = (1 - momentum) r + momentum * new, unbiased variance."""
-    return _BatchNormRowsFn.apply(x, weight, bias, eps, running_mean, running_var, momentum)
+def batch_norm_rows(x, weight, bias, eps=1e-5, running_mean=None, running_var=None, momentum=0.0, relu=False):
+    """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x; relu: y = ReLU(BatchNorm(x)) in the
+    same launches, forward and backward.  running_mean / running_var (fp32 buffers, optional) are updated in place by the
+    statistics launch: r = (1 - momentum) r + momentum * new, unbiased variance."""
+    return _BatchNormRowsFn.apply(x, weight, bias, eps, running_mean, running_var, momentum, relu)
 
 
 _single_rel_tables = {}

@@ -200,7 +200,13 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
         super().__init__(*a, **k)
         self.process_group = process_group
 
+    fuse_relu = False                                # set by convert_sync_batchnorm when the module it replaces applied the ReLU too
+
     def forward(self, x):
+        y = self._forward(x)
+        return torch.relu(y) if self.fuse_relu else y
+
+    def _forward(self, x):
         if not (self.training and _dist_on()) or x.dim() != 2:
             return super().forward(x)
         y, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
@@ -226,6 +232,7 @@ def convert_sync_batchnorm(module, process_group=None):
             new.running_mean, new.running_var = module.running_mean, module.running_var
             new.num_batches_tracked = module.num_batches_tracked
         new.training = module.training
+        new.fuse_relu = bool(getattr(module, "fuse_relu", False))     # graph_classification.models.HipBatchNorm1d(fuse_relu=True)
         return new
     for name, child in list(module.named_children()):
         new = convert_sync_batchnorm(child, process_group)

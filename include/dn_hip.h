@@ -425,25 +425,28 @@ int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, i
                            const int32_t* chunk_ptr, void* out, float* colsum_out, void* workspace, size_t workspace_bytes,
                            dn_stream_t stream);
 
-/* BatchNorm over the rows of [N, C] node features, training mode (batch statistics) -- the BatchNorm1d inside the MLPs of the GC
- * models (graph_classification/graph_neural_networks/models/gconv.py:187-194, rgconv.py:85-93).
- *   forward:   mean / var (biased) / rstd [C] over the rows;  Y = (X - mean) * rstd * weight + bias   (weight / bias may be NULL)
- *   backward:  sum_dy [C] (= dbias), sum_dy_xhat [C] (= dweight);  DX = weight * rstd * (DY - sum_dy / N - xhat * sum_dy_xhat / N)
+/* BatchNorm over the rows of [N, C] node features, training mode (batch statistics), optionally with the ReLU that follows it
+ * -- the `BatchNorm1d, ReLU` pairs inside the MLPs of the GC models (graph_classification/graph_neural_networks/models/
+ * gconv.py:187-194, rgconv.py:85-93).
+ *   forward:   mean / var (biased) / rstd [C] over the rows;  Y = act((X - mean) * rstd * weight + bias), act = ReLU when relu != 0
+ *              (weight / bias may be NULL)
+ *   backward:  DY' = DY where Y > 0 (relu; Y is recomputed from X), else DY;  sum_dy [C] (= dbias), sum_dy_xhat [C] (= dweight)
+ *              of DY';  DX = weight * rstd * (DY' - sum_dy / N - xhat * sum_dy_xhat / N)
  * fp32 statistics whatever the storage type; C a multiple of 4, <= 1024; deterministic.  running_mean / running_var (fp32 [C],
  * both or neither; NULL: skipped) receive torch's update r = (1 - momentum) r + momentum * new with the unbiased variance. */
 size_t dn_batchnorm_rows_workspace_bytes(int64_t N, int32_t C);
 int dn_batchnorm_rows_f32(const float* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, float* Y, float* mean,
-                          float* var, float* rstd, float* running_mean, float* running_var, float momentum, void* workspace,
-                          size_t workspace_bytes, dn_stream_t stream);
+                          float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
+                          void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_batchnorm_rows_bf16(const void* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, void* Y, float* mean,
-                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, void* workspace,
-                           size_t workspace_bytes, dn_stream_t stream);
+                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
+                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_batchnorm_rows_bwd_f32(const float* DY, const float* X, int64_t N, int32_t C, const float* mean, const float* rstd,
-                              const float* weight, float* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
-                              dn_stream_t stream);
+                              const float* weight, const float* bias, int32_t relu, float* DX, float* sum_dy, float* sum_dy_xhat,
+                              void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_batchnorm_rows_bwd_bf16(const void* DY, const void* X, int64_t N, int32_t C, const float* mean, const float* rstd,
-                               const float* weight, void* DX, float* sum_dy, float* sum_dy_xhat, void* workspace, size_t workspace_bytes,
-                               dn_stream_t stream);
+                               const float* weight, const float* bias, int32_t relu, void* DX, float* sum_dy, float* sum_dy_xhat,
+                               void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* RGCN degree normalisation.  Replaces RGCNLayer._node_init_func/_edge_init_func
  * (subgraph_isomorphism/models/rgcn.py:132-165): in_norm = 1/(in_deg+1) with self-loop else 1/in_deg

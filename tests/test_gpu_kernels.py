@@ -572,6 +572,46 @@ def test_batch_norm_rows_matches_torch(N, C, dt):
                                    atol=(0.5 if dt == torch.bfloat16 else 1e-3) * max(1.0, N ** 0.5 / 10))
 
 
+@pytest.mark.parametrize("N,C", [(63, 4), (5000, 128), (20181, 256)])
+def test_batch_norm_rows_with_fused_relu_and_running_statistics(N, C):
+    """relu=True: y = ReLU(BatchNorm(x)) forward and backward (the mask is recomputed from x), and the running statistics updated
+    by the statistics launch -- against torch's BatchNorm1d module + ReLU in fp64 over three steps."""
+    ops = _ops()
+    rng = np.random.default_rng(N * 7 + C)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.standard_normal(C)))
+        bn.bias.copy_(torch.from_numpy(rng.standard_normal(C)))
+    wd = bn.weight.detach().float().to(DEV).requires_grad_(True)
+    bd = bn.bias.detach().float().to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    for step in range(3):
+        x = torch.from_numpy((rng.standard_normal((N, C)) * 2.0 + 3.0).astype(np.float32))
+        for _ in range(8):                          # no pre-activation within 1e-3 of the ReLU kink (fp32 / fp64 must agree on its side)
+            xh = (x.double() - x.double().mean(0)) / (x.double().var(0, unbiased=False) + bn.eps).sqrt()
+            near = (xh * bn.weight.detach() + bn.bias.detach()).abs() < 1e-3
+            if not bool(near.any()):
+                break
+            x = torch.where(near, x + 0.05, x)
+        assert not bool(near.any())
+        coef = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32))
+        xd = x.to(DEV).requires_grad_(True)
+        wd.grad = bd.grad = None
+        y, _, _ = ops.batch_norm_rows(xd, wd, bd, bn.eps, rm, rv, 0.1, relu=True)
+        y.backward(coef.to(DEV))
+        xr = x.double().requires_grad_(True)
+        bn.zero_grad()
+        yr = torch.relu(bn(xr))
+        yr.backward(coef.double())
+        torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=2e-4, atol=2e-4)
+        assert float(y.min()) >= 0.0
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(wd.grad.cpu().double(), bn.weight.grad, rtol=1e-3, atol=1e-3 * max(1.0, N ** 0.5 / 10))
+        torch.testing.assert_close(bd.grad.cpu().double(), bn.bias.grad, rtol=1e-3, atol=1e-3 * max(1.0, N ** 0.5 / 10))
+        torch.testing.assert_close(rm.cpu().double(), bn.running_mean, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(rv.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K,N_", [(5, 128), (38, 256), (128, 128), (64, 2), (256, 256)])
 def test_linear_any_matches_torch(K, N_, dt):
