@@ -717,3 +717,35 @@ def test_fold_is_refused_when_a_graph_is_not_a_contiguous_node_range():
         0, torch.tensor(dst), torch.bmm(x.cpu().double()[torch.tensor(src)].unsqueeze(1), W.cpu().double()[torch.tensor(et)]).squeeze(1))
     ref = ref + x.cpu().double() @ W.cpu().double()[R + 1]
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
+def test_fold_inside_sub_batches_matches_the_single_part_index():
+    """RowIndexSet cut into several parts (each part folds its own dummy relation, tiles restart at every part) against the one-part
+    index: same layer output and gradients up to bf16 rounding of the per-part sums."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    sizes = list(rng.integers(3, 50, size=120))
+    R, H = 4, 128
+    src, dst, et, N = _dummy_batch(rng, sizes, R)
+    node_ptr = np.concatenate([[0], np.cumsum(np.array(sizes) + 1)])
+    order = np.argsort(np.searchsorted(node_ptr, src, side="right"), kind="stable")      # edges graph by graph
+    src, dst, et = src[order], dst[order], et[order]
+    edge_ptr = np.concatenate([[0], np.cumsum(np.bincount(np.searchsorted(node_ptr, src, side="right") - 1, minlength=len(sizes)))])
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, coef = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((N, H)))
+    W = bf(rng.standard_normal((R + 3, H, H)) / np.sqrt(H))
+    b = bf(rng.standard_normal(H))
+    s, d, t = (torch.from_numpy(a).to(DEV) for a in (src, dst, et))
+    res = []
+    for target in (1 << 62, 400):
+        iset = ops.RowIndexSet(s, d, t, N, R + 2, True, node_ptr=torch.from_numpy(node_ptr).to(DEV), edge_ptr=torch.from_numpy(edge_ptr).to(DEV),
+                               target_nodes=target)
+        xd, Wd, bd = (v.to(DEV).requires_grad_(True) for v in (x, W, b))
+        out = ops.rel_transform_fused(xd, Wd, bd, iset)
+        out.backward(coef.to(DEV))
+        folded = [ops._row_index_fold(ix, k) is not None for _, _, ix in iset.parts for k in "fb"]
+        res.append((len(iset.parts), folded, [v.detach().float().cpu() for v in (out, xd.grad, Wd.grad, bd.grad)]))
+    # (a small part may see an ordinary relation collapse too -- two AGG relations -- and then keeps the separate pass: legitimate)
+    assert res[0][0] == 1 and all(res[0][1]) and res[1][0] >= 4 and sum(res[1][1]) >= len(res[1][1]) // 2
+    for name, a, c in zip(("out", "gx", "gW", "gb"), res[0][2], res[1][2]):
+        assert float((a - c).abs().max() / a.abs().max()) < 2e-2, name
