@@ -170,10 +170,23 @@ def run_config4(args, rank, world, dev):
     bucket = FlatGradBucket(model.parameters())
     scale = dp_loss_scale(G, per_gpu * world, world)
 
-    def step():
+    def compute():
         bucket.zero()
         loss = F.nll_loss(model(data), data.y) * scale
         loss.backward()
+        return loss
+
+    # one rank: forward + loss + backward replayed from a HIP graph (the step is ~150 launches of 5-30 us); with more ranks the
+    # SyncBatchNorm collectives sit inside forward / backward, so the launches stay eager
+    graphed = None
+    if world == 1 and not args.no_graph:
+        from dummynode4graphlearning_amd import StepGraph
+        graphed = StepGraph(compute, warmup=max(args.warmup, 2))
+        if not graphed.captured:
+            graphed = None
+
+    def step():
+        loss = graphed() if graphed is not None else compute()
         bucket.all_reduce()
         return loss
 
@@ -204,10 +217,10 @@ def run_config4(args, rank, world, dev):
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config4: GIN(hidden=%d, 2 layers) training step (fwd + nll_loss + bwd + all-reduce) on "
-                                   "%d NCI1-shaped dummy graphs per GPU (global N=%d, E=%d), SyncBatchNorm, eager launches"
-                                   % (H, per_gpu, int(gN), int(gE)),
+                                   "%d NCI1-shaped dummy graphs per GPU (global N=%d, E=%d), SyncBatchNorm, %s"
+                                   % (H, per_gpu, int(gN), int(gE), "HIP-graph replay" if graphed is not None else "eager launches"),
                        "global_edges": int(gE), "parallelism": "dp%d" % world, "grad_bucket_bytes": bucket.bytes(),
-                       "shard_graphs": [g0, g1]},
+                       "shard_graphs": [g0, g1], "hip_graph": graphed is not None},
             "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole training step of a 16 k-node batch per GPU: launch-bound, not a kernel roofline"},

@@ -44,25 +44,30 @@ class HipBatchNorm1d(BatchNorm1d):
         self.fuse_relu = bool(fuse_relu)
 
     def forward(self, x):
-        if not (self.training and ops.batch_norm_rows_supported(x) and x.shape[0] > 1):     # (one row: torch raises, as it should)
-            y = super().forward(x)
-            return F.relu(y) if self.fuse_relu else y
-        w, b = (self.weight, self.bias) if self.affine else (None, None)
-        if self.track_running_stats:
-            with torch.no_grad():
-                self.num_batches_tracked += 1
-            if self.momentum is not None and self.running_mean.dtype == torch.float32:
-                # the running-statistics update rides in the statistics launch (five tiny elementwise launches otherwise)
-                return ops.batch_norm_rows(x, w, b, self.eps, self.running_mean, self.running_var, self.momentum,
-                                           relu=self.fuse_relu)[0]
-        y, mean, var = ops.batch_norm_rows(x, w, b, self.eps, relu=self.fuse_relu)
-        if self.track_running_stats:
-            with torch.no_grad():
-                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
-                n = x.shape[0]
-                self.running_mean.mul_(1.0 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
-                self.running_var.mul_(1.0 - mom).add_((var * (n / max(n - 1, 1))).to(self.running_var.dtype), alpha=mom)
-        return y
+        return hip_batch_norm_forward(self, x, self.fuse_relu)
+
+
+def hip_batch_norm_forward(mod, x, relu):
+    """forward of a BatchNorm1d-like module `mod` (torch's parameters / buffers) on the HIP kernels, optionally with the ReLU behind
+    it; shared by HipBatchNorm1d and by parallel.SyncBatchNorm1d when no process group is active."""
+    if not (mod.training and ops.batch_norm_rows_supported(x) and x.shape[0] > 1):          # (one row: torch raises, as it should)
+        y = BatchNorm1d.forward(mod, x)
+        return F.relu(y) if relu else y
+    w, b = (mod.weight, mod.bias) if mod.affine else (None, None)
+    if mod.track_running_stats:
+        with torch.no_grad():
+            mod.num_batches_tracked += 1
+        if mod.momentum is not None and mod.running_mean.dtype == torch.float32:
+            # the running-statistics update rides in the statistics launch (five tiny elementwise launches otherwise)
+            return ops.batch_norm_rows(x, w, b, mod.eps, mod.running_mean, mod.running_var, mod.momentum, relu=relu)[0]
+    y, mean, var = ops.batch_norm_rows(x, w, b, mod.eps, relu=relu)
+    if mod.track_running_stats:
+        with torch.no_grad():
+            mom = mod.momentum if mod.momentum is not None else 1.0 / float(mod.num_batches_tracked)
+            n = x.shape[0]
+            mod.running_mean.mul_(1.0 - mom).add_(mean.to(mod.running_mean.dtype), alpha=mom)
+            mod.running_var.mul_(1.0 - mom).add_((var * (n / max(n - 1, 1))).to(mod.running_var.dtype), alpha=mom)
+    return y
 
 
 def _mlp(in_dim, out_dim):

@@ -203,12 +203,16 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
     fuse_relu = False                                # set by convert_sync_batchnorm when the module it replaces applied the ReLU too
 
     def forward(self, x):
+        if not (self.training and _dist_on()) or x.dim() != 2:
+            if x.is_cuda:                                        # one process: the HIP BatchNorm launches (ReLU included)
+                from .graph_classification.models import hip_batch_norm_forward
+                return hip_batch_norm_forward(self, x, self.fuse_relu)
+            y = super().forward(x)
+            return torch.relu(y) if self.fuse_relu else y
         y = self._forward(x)
         return torch.relu(y) if self.fuse_relu else y
 
     def _forward(self, x):
-        if not (self.training and _dist_on()) or x.dim() != 2:
-            return super().forward(x)
         y, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
         if self.track_running_stats:
             with torch.no_grad():
