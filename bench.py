@@ -361,6 +361,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # fresh-batch leg (rank 0, one GPU): a training loop sees a new batch every step, so it pays the dummy augmentation and the
+    # index build per step.  Sequentially that is `edges_per_s_incl_index_build`; here the NEXT batch's augmentation + index
+    # build run on a side stream while the current step replays (what the reference's DataLoader workers do for dgl.batch on
+    # the CPU): per-step wall time of the overlapped loop.
+    overlapped_ms = None
+    if rank == 0 and world == 1 and graph is not None and fused and dtype == torch.bfloat16:
+        from dummynode4graphlearning_amd import transforms as _tr
+        side2 = torch.cuda.Stream()
+        traw = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
+
+        def next_batch_index():
+            with torch.cuda.stream(side2):
+                aug = _tr.dummy_augment_si(traw["node_ptr"], traw["edge_ptr"], traw["src"], traw["dst"], traw["node_id"],
+                                           traw["node_label"], traw["edge_id"], traw["edge_label"], raw["max_nv"], raw["max_nvl"],
+                                           raw["max_ne"], raw["max_nel"])
+                g._cache.clear()
+                ix = g.row_index(etype, R, True)
+                for _, _, part in ix.parts:
+                    part.slots("f"), part.slots("b")
+                return aug, ix
+
+        for _ in range(2):
+            step()
+            next_batch_index()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()                                      # replay of the captured step (its own index tables are kept alive by the graph)
+            next_batch_index()                          # host-side syncs of the build overlap the replay
+        torch.cuda.synchronize()
+        overlapped_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     # roofline leg: the conv's gather-scatter launches alone (gather/segment-sum + gathered-row transform of the forward
     # and of the input-gradient pass, exactly the launches the step makes), replayed as their own HIP graph and timed with
     # HIP events on the launch stream
@@ -485,6 +517,8 @@ def main():
                        "dummy_augment_first_call_ms": aug_ms[0],
                        # a training loop sees a NEW batch every step: dummy augmentation + index build + step, per fresh batch
                        "edges_per_s_incl_index_build": world * E / ((ms_per_step + index_ms + aug_ms[1]) * 1e-3),
+                       "fresh_batch_overlapped_ms_per_step": overlapped_ms,
+                       "edges_per_s_fresh_batch_overlapped": (E / (overlapped_ms * 1e-3)) if overlapped_ms else None,
                        "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
