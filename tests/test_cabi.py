@@ -58,3 +58,30 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert rc == -1 and b"bad mode" in L.dn_last_error()
     with pytest.raises(lib.DnHipError):
         lib.check(rc, "dn_conjugate_build_i32")
+    # round-2 entry points: the same contract (arguments are checked before anything is launched)
+    rc = L.dn_fold_tail_bf16(None, None, 5, 100, None, None, None, None, None)
+    assert rc == -1 and b"H must be 64, 128 or 256" in L.dn_last_error()
+    rc = L.dn_fold_tail_bf16(None, None, 5, 256, None, None, None, None, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    assert L.dn_fold_tail_bf16(None, None, 0, 256, None, None, None, None, None) == 0           # nothing to do
+    ok = ctypes.c_int32(7)
+    assert L.dn_fold_tables_build_i32(0, 0, None, None, None, None, ctypes.byref(ok), None, 0, None) == 0 and ok.value == 0
+    rc = L.dn_fold_tables_build_i32(10, 2, None, None, None, None, ctypes.byref(ok), None, 0, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, None)
+    assert rc == -1 and b"fold_info needs seg_part" in L.dn_last_error()
+    rc = L.dn_gather_segsum_window_f32(None, 20, None, None, None, None, None, 3, None, 0.0, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    rc = L.dn_gather_segsum_window_f32(ctypes.c_void_p(16), 20, ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                       ctypes.c_void_p(16), 3, ctypes.c_void_p(16), 0.0, None)
+    assert rc == -1 and b"rows must be 128 bytes" in L.dn_last_error()
+    rc = L.dn_batchnorm_rows_f32(ctypes.c_void_p(16), 8, 64, None, None, 1e-5, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                 ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0.1, 0, ctypes.c_void_p(16), 1 << 20, None)
+    assert rc == -1 and b"running_mean and running_var come together" in L.dn_last_error()
+    # host-side tile packing needs no GPU at all
+    npt = (ctypes.c_int32 * 5)(0, 3, 3, 10, 12)
+    out = (ctypes.c_int32 * 16)()
+    n = ctypes.c_int64(0)
+    assert L.dn_window_tiles_host(npt, 4, 4, out, 16, ctypes.byref(n)) == 0
+    assert n.value == 4 and list(out[:5]) == [0, 3, 7, 10, 12]            # {g0, g1}, g2 cut at 4 rows: [3,7) [7,10), {g3}
+    assert L.dn_window_tiles_host(npt, 4, 4, out, 2, ctypes.byref(n)) == -3 and b"tile table too small" in L.dn_last_error()
