@@ -171,9 +171,10 @@ def run_config4(args, rank, world, dev):
     scale = dp_loss_scale(G, per_gpu * world, world)
 
     def compute():
-        bucket.zero()
+        bucket.zero(set_to_none=True)
         loss = F.nll_loss(model(data), data.y) * scale
         loss.backward()
+        bucket.pack()
         return loss
 
     # one rank: forward + loss + backward replayed from a HIP graph (the step is ~150 launches of 5-30 us); with more ranks the
@@ -304,10 +305,11 @@ def main():
     index, index_ms = build_index()             # steady state (what a training loop pays per new batch)
 
     def compute():
-        bucket.zero()
+        bucket.zero(set_to_none=True)           # optimizer.zero_grad()'s default (train.py:836): gradients are written, not added
         x.grad = None
         out, _ = layer(g, x, etype)
         out.backward(gout)
+        bucket.pack()                           # the step's gradients -> the flat bucket (one launch), inside the captured step
 
     def step_eager():
         compute()

@@ -574,6 +574,12 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                     wf[ks][nt] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * HI + ks * 32 +
                                                                   8 * (lane >> 4));
             if (bias && lane < NT * 16) biasL[n0 + lane] = bias[(size_t)cur_rel * HO + n0 + lane];
+            // pin the wait for the new weights INSIDE this (rare) branch: left to the compiler it sits in front of the MFMAs on
+            // the common path as vmcnt(15) ... vmcnt(0), i.e. every tile waits there for the gather issued just above
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(wf[ks][nt]));
         }
         f32x4 acc[MT][NT];
 #pragma unroll

@@ -95,9 +95,11 @@ class FlatGradBucket:
 
     def _bind(self, copy_existing):
         """Point every p.grad at its slice.  copy_existing: gradients that live elsewhere (fresh tensors autograd made after
-        zero_grad(set_to_none=True)) are copied in first; a missing gradient (unused parameter) becomes zeros."""
+        zero_grad(set_to_none=True)) are copied in first -- all of a bucket's strays in ONE multi-tensor launch; a missing
+        gradient (unused parameter) becomes zeros."""
         self._check()
         for flat, entries in self._groups.values():
+            dsts, srcs = [], []
             for p, off in entries:
                 view = flat[off:off + p.numel()].view_as(p)
                 g = p.grad
@@ -109,14 +111,30 @@ class FlatGradBucket:
                     else:
                         if g.dtype != view.dtype or g.device != view.device:
                             raise RuntimeError("FlatGradBucket: gradient dtype / device differs from its parameter's")
-                        view.copy_(g)
+                        dsts.append(view)
+                        srcs.append(g.detach())
                 p.grad = view
+            if len(dsts) == 1:
+                dsts[0].copy_(srcs[0])
+            elif dsts:
+                torch._foreach_copy_(dsts, srcs)
 
-    def zero(self):
-        """Zero all gradients and (re)alias them to the buckets: use INSTEAD of, or right after, optimizer.zero_grad()."""
+    def zero(self, set_to_none=False):
+        """Zero all gradients and (re)alias them to the buckets: use INSTEAD of, or right after, optimizer.zero_grad().
+        set_to_none=True is optimizer.zero_grad()'s own default: every .grad becomes None, autograd then WRITES the step's
+        gradients (no zero fill, no accumulate launch per parameter) and pack() / all_reduce() gathers them into the bucket."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
         for flat, _ in self._groups.values():
             flat.zero_()
         self._bind(copy_existing=False)
+
+    def pack(self):
+        """Gather the step's gradients into the flat buffers (one launch per bucket) and alias .grad to them; all_reduce() does
+        this itself -- call it separately to keep the copy inside a captured step while the collective stays outside."""
+        self._bind(copy_existing=True)
 
     def all_reduce(self, async_op=False):
         """Call after loss.backward().  Returns the list of work handles (async_op) or None."""
