@@ -871,6 +871,10 @@ def segment_reduce(x, graph_ptr, kind="sum"):
 # ----------------------------------------------------------------------------------------------
 # fused relation-wise message pass on the matrix cores (bf16): row factorisation + MFMA kernels
 # ----------------------------------------------------------------------------------------------
+# DN_LOCAL_INDEX=0: always the general (sort-based) row-index builder, also for batches with graph boundaries
+LOCAL_INDEX_ENABLED = _os.environ.get("DN_LOCAL_INDEX", "1") != "0"
+
+
 class RowIndex:
     """Relation-major ROW FACTORISATION of  out[v] = sum_{e: dst(e)=v} x[src(e)] W[etype(e)]  (+ x[v] W_loop).
 
@@ -885,29 +889,54 @@ class RowIndex:
 
     EDGE, AGG, TF = 0, 1, 2
 
-    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75):
-        """One C-ABI call (dn_row_index_build_i32: stable radix sorts + scans on the device) + host-side tile tables."""
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75, node_ptr=None, edge_ptr=None):
+        """One C-ABI call + device-side tile tables.  With the batch's graph boundaries (node_ptr / edge_ptr, [G+1] each) the
+        graph-local builder runs (dn_row_index_build_local_i32: one wavefront rank-sorts one graph in LDS, one scan); without
+        them, or when the batch does not qualify (a graph over 1024 edges, more than 64 relations), the general one
+        (dn_row_index_build_i32: stable radix sorts + scans over the whole batch).  Both produce the same tables bit for bit."""
         require_gpu(src, dst, etype)
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
         self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
-        _check_edge_types(etype, R)
+        if node_ptr is None or edge_ptr is None or R > 64 or not LOCAL_INDEX_ENABLED:
+            _check_edge_types(etype, R)                               # (the local builder validates on the device)
         src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))
         e32 = lambda n: torch.empty(max(int(n), 1), dtype=I32, device=dev)  # noqa: E731
         row_in, row_out = e32(E + N), e32(E + N)
         aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx = e32(E + 1), e32(E), e32(E + 1), e32(E)
         dst_ptr, dst_rows, src_ptr, src_rows = e32(N + 2), e32(2 * E + N), e32(N + 2), e32(2 * E + N)
-        nbytes = lib().dn_row_index_workspace_bytes(N, R, E)
-        if nbytes == 0:
-            check(-2, "dn_row_index_workspace_bytes")
-        ws = _ws(nbytes, dev)
         counts = (ctypes.c_int64 * 5)()
         host_rel = (ctypes.c_int32 * (R + 1))()
         host_modes = (ctypes.c_int32 * R)()
-        check(lib().dn_row_index_build_i32(N, R, E, ptr(src), ptr(dst), ptr(etype), 1 if self_loop else 0, float(edge_frac),
-                                           ptr(row_in), ptr(row_out), ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr),
-                                           ptr(aux_b_idx), ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts,
-                                           host_rel, host_modes, ptr(ws), ws.numel(), stream_ptr()), "dn_row_index_build_i32")
+        self.built_by = "general"
+        if node_ptr is not None and edge_ptr is not None and R <= 64 and LOCAL_INDEX_ENABLED:
+            require_gpu(node_ptr, edge_ptr)
+            node_ptr, edge_ptr = node_ptr.to(I32).contiguous(), edge_ptr.to(I32).contiguous()
+            G = int(node_ptr.numel()) - 1
+            assert G >= 0 and int(edge_ptr.numel()) == G + 1
+            nbytes = lib().dn_row_index_local_workspace_bytes(G, N, R, E)
+            if nbytes:
+                ws = _ws(nbytes, dev)
+                status = ctypes.c_int32(0)
+                check(lib().dn_row_index_build_local_i32(G, N, R, E, ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype),
+                                                         1 if self_loop else 0, float(edge_frac), ptr(row_in), ptr(row_out),
+                                                         ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr), ptr(aux_b_idx),
+                                                         ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts, host_rel,
+                                                         host_modes, ctypes.byref(status), ptr(ws), ws.numel(), stream_ptr()),
+                      "dn_row_index_build_local_i32")
+                if status.value == 0:
+                    self.built_by = "local"
+                else:
+                    _check_edge_types(etype, R)
+        if self.built_by == "general":
+            nbytes = lib().dn_row_index_workspace_bytes(N, R, E)
+            if nbytes == 0:
+                check(-2, "dn_row_index_workspace_bytes")
+            ws = _ws(nbytes, dev)
+            check(lib().dn_row_index_build_i32(N, R, E, ptr(src), ptr(dst), ptr(etype), 1 if self_loop else 0, float(edge_frac),
+                                               ptr(row_in), ptr(row_out), ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr),
+                                               ptr(aux_b_idx), ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts,
+                                               host_rel, host_modes, ptr(ws), ws.numel(), stream_ptr()), "dn_row_index_build_i32")
         P, n_agg, n_tf, n_agg_e, n_tf_e = (int(v) for v in counts)
         self.modes = [int(m) for m in host_modes]
         rel_ptr = [int(v) for v in host_rel]
@@ -1020,7 +1049,8 @@ class RowIndexSet:
                 g0 = g1
         self.parts = []
         if len(bounds) == 1:                                     # (the usual case: no shifted copies of the edge arrays)
-            self.parts.append((0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop)))
+            self.parts.append((0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop, node_ptr=node_ptr,
+                                              edge_ptr=edge_ptr)))
         else:
             s64, d64 = src.long(), dst.long()
             for n0, n1, e0, e1 in bounds:

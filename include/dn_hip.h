@@ -234,6 +234,24 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
                            int32_t* src_rows, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* The same tables as dn_row_index_build_i32, bit for bit, for a batch that is a disjoint union of G graphs: node_ptr [G+1] /
+ * edge_ptr [G+1] (device) give every graph a contiguous node range and a contiguous edge range (node_ptr[G] == N,
+ * edge_ptr[G] == E) -- the layout dgl.batch / the PyG collate produce (subgraph_isomorphism/dataset.py:1605-1611,
+ * graph_classification main.py:245-247).  Every ordering the general builder establishes with device-wide radix sorts is local
+ * to a graph in such a batch, so one wavefront rank-sorts one graph in LDS and the only batch-wide step is one exclusive scan
+ * of the packed counts: 3 kernels + 1 scan instead of ~60 launches.  R <= 64.  *host_status = 1 (outputs undefined) when the
+ * batch does not qualify -- a graph with more than 1024 edges, an endpoint outside its graph's node range, a relation id
+ * outside [0, R), ranges that do not tile [0, N) / [0, E): the caller then runs dn_row_index_build_i32.  Other arguments and
+ * outputs as dn_row_index_build_i32.  Synchronises the stream (one read-back). */
+size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E);
+int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr,
+                                 const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
+                                 int32_t self_loop, float edge_frac, int32_t* row_in, int32_t* row_out,
+                                 int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx,
+                                 int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
+                                 int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
+                                 void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
 /* Tile / chunk tables of relation-major rows for dn_rows_transform_* (step = 32 rows) and dn_rows_wgrad_* (step = the
  * split-K chunk size), built on the device from rel_ptr [num_rels + 1] (device): entry i = {rel, beg, end, 0}.  The caller
  * sizes `table` by the upper bound max_entries >= rows / step + num_rels; unused entries become empty pieces (beg == end) of

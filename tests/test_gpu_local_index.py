@@ -1,0 +1,126 @@
+"""dn_row_index_build_local_i32 (one wavefront rank-sorts one graph in LDS, one scan) must produce the tables of the general
+sort-based builder dn_row_index_build_i32 BIT FOR BIT -- the general builder is itself pinned against the oracle through the
+layer goldens (tests/test_gpu_layers.py) -- on batches of graphs of every shape the modes can take."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("row_in", "row_out", "aux_f_ptr", "aux_f_idx", "aux_b_ptr", "aux_b_idx", "dst_ptr", "dst_rows", "src_ptr", "src_rows")
+
+
+def _build(src, dst, et, N, R, self_loop, nptr, eptr, edge_frac=0.75):
+    from dummynode4graphlearning_amd import ops
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32, device=dev)  # noqa: E731
+    a = ops.RowIndex(t(src), t(dst), t(et), N, R, self_loop=self_loop, edge_frac=edge_frac)
+    b = ops.RowIndex(t(src), t(dst), t(et), N, R, self_loop=self_loop, edge_frac=edge_frac, node_ptr=t(nptr), edge_ptr=t(eptr))
+    return a, b
+
+
+def _same(a, b):
+    assert a.built_by == "general" and b.built_by == "local"
+    assert a.modes == b.modes and a.rel_ptr_host == b.rel_ptr_host
+    assert (a.num_rows, a.num_edge_rows, a.num_aux_f, a.num_aux_b) == (b.num_rows, b.num_edge_rows, b.num_aux_f, b.num_aux_b)
+    for f in FIELDS:
+        x, y = getattr(a, f).cpu().numpy(), getattr(b, f).cpu().numpy()
+        assert x.shape == y.shape, f
+        assert np.array_equal(x, y), (f, np.flatnonzero(x != y)[:8], x[x != y][:8], y[x != y][:8])
+
+
+def _random_batch(rng, G, R, nmin, nmax, dens, dummy=True, multi=True):
+    """graphs with random sizes; real edges with relations < R - 2 (uniform), optional dummy node with relations R-2 / R-1
+    (u -> dummy / dummy -> u: the collapsed AGG / TF relations), optional empty graphs and multi-edges"""
+    src, dst, et, nptr, eptr = [], [], [], [0], [0]
+    for g in range(G):
+        n = int(rng.integers(nmin, nmax + 1))
+        base = nptr[-1]
+        m = int(rng.integers(0, max(1, int(dens * n)) + 1)) if n > 0 else 0
+        if n > 0 and m > 0:
+            s = rng.integers(0, n, size=m)
+            d = rng.integers(0, n, size=m)
+            r = rng.integers(0, max(1, R - 2), size=m)
+            if multi and m > 3:                                       # repeat a few edges exactly (multi-edges)
+                k = rng.integers(0, m, size=2)
+                s[k[0]], d[k[0]], r[k[0]] = s[k[1]], d[k[1]], r[k[1]]
+            src += list(base + s); dst += list(base + d); et += list(r)
+        if dummy and n > 0:
+            dn = base + n
+            for u in range(n):
+                src.append(base + u); dst.append(dn); et.append(R - 2)
+            for u in range(n):
+                src.append(dn); dst.append(base + u); et.append(R - 1)
+            n += 1
+        nptr.append(base + n)
+        eptr.append(len(src))
+    return np.array(src, np.int64), np.array(dst, np.int64), np.array(et, np.int64), np.array(nptr), np.array(eptr)
+
+
+@pytest.mark.parametrize("self_loop", [True, False])
+@pytest.mark.parametrize("seed", range(6))
+def test_local_builder_equals_general_on_random_batches(seed, self_loop):
+    rng = np.random.default_rng(100 + seed)
+    R = int(rng.integers(3, 12))
+    src, dst, et, nptr, eptr = _random_batch(rng, G=int(rng.integers(1, 90)), R=R, nmin=0, nmax=int(rng.integers(2, 40)),
+                                             dens=float(rng.uniform(0.3, 4.0)), dummy=bool(seed % 2 == 0))
+    a, b = _build(src, dst, et, int(nptr[-1]), R, self_loop, nptr, eptr)
+    _same(a, b)
+
+
+@pytest.mark.parametrize("edge_frac", [0.0, 0.5, 2.0])
+def test_local_builder_every_mode_mix(edge_frac):
+    """edge_frac 0 -> every relation EDGE; 2.0 -> every relation collapses to AGG or TF (several collapsed relations per node)"""
+    rng = np.random.default_rng(7)
+    src, dst, et, nptr, eptr = _random_batch(rng, G=60, R=6, nmin=1, nmax=25, dens=3.0, dummy=True)
+    a, b = _build(src, dst, et, int(nptr[-1]), 6, True, nptr, eptr, edge_frac=edge_frac)
+    _same(a, b)
+    if edge_frac == 2.0:
+        assert set(a.modes) <= {1, 2}
+    if edge_frac == 0.0:
+        assert set(a.modes) == {0}
+
+
+def test_local_builder_config3_shape_and_layer():
+    """SI-style dummy augmentation of a config-3 batch through the device pipeline; the layer on the local index equals the
+    layer on the general index bit for bit (same tables -> same launches)."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    dev = torch.device("cuda:0")
+    raw = synthetic.config3(seed=3, graphs=64)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    vocab = (raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(dev) for k in keys), *vocab)
+    N = int(aug["node_label"].numel())
+    a, b = _build(aug["src"].cpu().numpy(), aug["dst"].cpu().numpy(), aug["edge_label"].cpu().numpy(), N, 8, True,
+                  aug["node_ptr"].cpu().numpy(), aug["edge_ptr"].cpu().numpy())
+    _same(a, b)
+    assert sorted(a.modes) == [0] * 6 + [1, 2]
+
+
+def test_local_builder_declines_and_falls_back():
+    """a graph over the LDS limit, an endpoint outside its graph, ranges that do not tile: the general builder runs"""
+    rng = np.random.default_rng(3)
+    # (1) one graph with 1500 edges
+    n = 40
+    s, d = rng.integers(0, n, size=1500), rng.integers(0, n, size=1500)
+    src = np.concatenate([s, n + rng.integers(0, 5, size=10)]); dst = np.concatenate([d, n + rng.integers(0, 5, size=10)])
+    et = rng.integers(0, 4, size=1510)
+    a, b = _build(src, dst, et, n + 5, 4, True, [0, n, n + 5], [0, 1500, 1510])
+    assert b.built_by == "general"
+    for f in FIELDS:
+        assert torch.equal(getattr(a, f), getattr(b, f))
+    # (2) an edge that leaves its graph
+    src2, dst2, et2 = np.array([0, 1, 2, 5]), np.array([1, 2, 0, 1]), np.array([0, 1, 0, 1])
+    a, b = _build(src2, dst2, et2, 8, 2, True, [0, 4, 8], [0, 3, 4])
+    assert b.built_by == "general"
+    # (3) ranges that do not cover every node
+    a, b = _build(src2[:3], dst2[:3], et2[:3], 8, 2, True, [0, 4, 6], [0, 3, 3])
+    assert b.built_by == "general"
+
+
+def test_local_builder_empty_batch_and_edgeless_graphs():
+    a, b = _build(np.zeros(0), np.zeros(0), np.zeros(0), 7, 3, True, [0, 3, 3, 7], [0, 0, 0, 0])
+    _same(a, b)
+    a, b = _build(np.zeros(0), np.zeros(0), np.zeros(0), 0, 3, False, [0], [0])
+    _same(a, b)
