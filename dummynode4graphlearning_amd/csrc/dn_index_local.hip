@@ -14,7 +14,7 @@
 //   (exclusive scan of the packed counts)
 //   ril_fill_kernel    every table, each entry at  scan offset + rank inside the graph
 //
-// Graphs with more than kLocM edges, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
+// Graphs with more than kLocM edges or kLocNodes nodes, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
 // instead (host_status = 1): the caller then runs the general builder.
 #include <cstring>
 #include <cstdlib>
@@ -27,72 +27,136 @@
 namespace {
 
 constexpr int kLocM = 1024;          // edges of one graph held in LDS
+constexpr int kLocNodes = 1 << 14;   // nodes of one graph (local ids are packed into 14 bits)
 constexpr int kLocWaves = 4;         // graphs in flight per workgroup (one wavefront each)
 constexpr int kLocR = 64;            // relations (per-workgroup counters, one lane per relation)
+constexpr int kLocCG = 4;            // 64-edge chunks a lane keeps in registers per pass over the graph
 constexpr int kEdge = 0, kAgg = 1, kTf = 2;
 constexpr int kSeg = 5;              // packed count arrays over (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges
+typedef uint32_t u32;
 
+// One edge of the graph in LDS, two words:
+//   w0 = relation << 26 | key node << 10 | edge          the edge's place in the (relation, key node, edge) order the general
+//                                                         builder's stable sort establishes; key node = source in a TF relation,
+//                                                         destination otherwise (local ids: node - first node of the graph)
+//   w1 = head << 30 | mode << 28 | source << 14 | destination
+// In the statistics pass (modes not known yet) w0 = relation << 14 | destination, w1 = relation << 14 | source.
 struct LocLds {
-    int32_t rel[kLocWaves][kLocM];   // relation | mode << 8 | head << 10
-    int32_t src[kLocWaves][kLocM];
-    int32_t dst[kLocWaves][kLocM];
+    uint2 e[kLocWaves][kLocM + 4];   // + 4 sentinels behind the last edge (the pair loops read two edges at a time, one pair ahead)
 };
+constexpr u32 kSentinel0 = 0xffffffffu, kSentinel1 = 3u << 28;       // never "before" an edge, never equal to a key, mode 3
 
 __device__ __forceinline__ int mode_of(int32_t Er, int32_t Dr, int32_t Sr, float edge_frac) {
     const int mn = Dr < Sr ? Dr : Sr;
     if (Er == 0 || (float)mn > edge_frac * (float)Er) return kEdge;       // (dn_index.hip: ri_mode_kernel)
     return Dr <= Sr ? kAgg : kTf;
 }
+__device__ __forceinline__ u32 sgpr(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
-// edges of graph g -> LDS (this wavefront's slice).  Returns the edge count, or -1 when the graph is not taken.
-__device__ __forceinline__ int load_graph(LocLds& L, int wave, int lane, int64_t g, int32_t R, const int32_t* node_ptr,
+// body(j, w0, w1) for the edges j = 0 .. jend-1 (and possibly one more: a later edge or a sentinel -- every body is written so
+// that such an edge contributes nothing), their two words wave-uniform in SGPRs; two edges per LDS read, the next pair in flight
+template <typename F>
+__device__ __forceinline__ void for_each_edge(const uint2* X, int jend, F&& body) {
+    uint4 q = *reinterpret_cast<const uint4*>(X);
+    for (int j = 0; j < jend; j += 2) {
+        const uint4 qn = *reinterpret_cast<const uint4*>(X + j + 2);
+        body(j, sgpr(q.x), sgpr(q.y));
+        body(j + 1, sgpr(q.z), sgpr(q.w));
+        q = qn;
+    }
+}
+
+// Edges of graph g -> LDS (this wavefront's slice), packed for the statistics pass (s_mode == nullptr) or with the modes.
+// Returns the edge count, or -1 when the graph is not taken (flagged in *bad by the statistics pass).
+__device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t R, const int32_t* node_ptr,
                                           const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
-                                          int& n0, int& n1, int& e0, int32_t* bad) {
-    n0 = node_ptr[g]; n1 = node_ptr[g + 1]; e0 = edge_ptr[g];
-    const int m = edge_ptr[g + 1] - e0;
-    if (m < 0 || m > kLocM || n1 < n0) {
+                                          const int32_t* s_mode, int& n0, int& n1, int32_t* bad) {
+    n0 = node_ptr[g]; n1 = node_ptr[g + 1];
+    const int e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
+    if (m < 0 || m > kLocM || n1 < n0 || n1 - n0 > kLocNodes) {
         if (bad != nullptr && lane == 0) atomicOr(bad, 1);
         return -1;
     }
     bool oob = false;
     for (int i = lane; i < m; i += 64) {
         const int r = etype[e0 + i], s = src[e0 + i], d = dst[e0 + i];
-        L.rel[wave][i] = r; L.src[wave][i] = s; L.dst[wave][i] = d;
-        oob |= (s < n0) | (s >= n1) | (d < n0) | (d >= n1) | (r < 0) | (r >= R);
+        const bool o = (s < n0) | (s >= n1) | (d < n0) | (d >= n1) | (r < 0) | (r >= R);
+        oob |= o;
+        if (!o) {
+            const u32 sl = (u32)(s - n0), dl = (u32)(d - n0);
+            if (s_mode == nullptr) X[i] = make_uint2(((u32)r << 14) | dl, ((u32)r << 14) | sl);
+            else {
+                const u32 md = (u32)s_mode[r];
+                X[i] = make_uint2(((u32)r << 26) | ((md == kTf ? sl : dl) << 10) | (u32)i, (md << 28) | (sl << 14) | dl);
+            }
+        }
     }
+    if (lane < 4) X[m + lane] = make_uint2(kSentinel0, kSentinel1);
     if (__any(oob)) {
         if (bad != nullptr && lane == 0) atomicOr(bad, 1);
         return -1;
     }
+    __builtin_amdgcn_wave_barrier();
     return m;
 }
 
-// relation word of every edge of the graph: relation | mode << 8 | head << 10   (head: first edge, in edge order, of its
-// (relation, key node) pair; key node = source in a TF relation, destination otherwise)
-__device__ __forceinline__ void flag_graph(LocLds& L, int wave, int lane, int m, const int32_t* s_mode) {
-    int32_t w[kLocM / 64];
+// head bit of every edge: first edge, in edge order, of its (relation, key node) pair
+template <int NC>
+__device__ __forceinline__ void flag_heads_pass(uint2* X, int lane, int m, int c0) {
+    u32 kk[NC], dup[NC];
+    int mine[NC];
 #pragma unroll
-    for (int k = 0; k < kLocM / 64; ++k) {
-        const int i = lane + 64 * k;
-        if (i >= m) break;
-        const int r = L.rel[wave][i], md = s_mode[r];
-        const int kn = md == kTf ? L.src[wave][i] : L.dst[wave][i];
-        bool head = true;
-        for (int j = 0; j < i; ++j) {
-            const int rj = L.rel[wave][j];                                   // (still the plain relation id: written below)
-            if (rj == r) head &= (md == kTf ? L.src[wave][j] : L.dst[wave][j]) != kn;
+    for (int c = 0; c < NC; ++c) {
+        mine[c] = (c0 + c) * 64 + lane;
+        kk[c] = mine[c] < m ? X[mine[c]].x >> 10 : 0xffffffffu;
+        dup[c] = 0;
+    }
+    for_each_edge(X, min(m, (c0 + NC) * 64), [&](int j, u32 j0, u32) {   // (only earlier edges matter)
+        const u32 kj = j0 >> 10;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dup[c] |= (u32)(kk[c] == kj) & (u32)(mine[c] > j);
+    });
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (mine[c] < m && dup[c] == 0) X[mine[c]].y |= 1u << 30;
+}
+__device__ __forceinline__ void flag_heads(uint2* X, int lane, int m) {
+    for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
+        const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
+        if (nc == 1) flag_heads_pass<1>(X, lane, m, c0);
+        else if (nc == 2) flag_heads_pass<2>(X, lane, m, c0);
+        else flag_heads_pass<kLocCG>(X, lane, m, c0);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NC>
+__device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int c0, int32_t (*cnt)[kLocR]) {
+    u32 kd[NC], ks[NC], dd[NC], ds[NC];
+    int mine[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        mine[c] = (c0 + c) * 64 + lane;
+        const uint2 x = mine[c] < m ? X[mine[c]] : make_uint2(0xfffffffeu, 0xfffffffeu);
+        kd[c] = x.x; ks[c] = x.y; dd[c] = 0; ds[c] = 0;
+    }
+    for_each_edge(X, min(m, (c0 + NC) * 64), [&](int j, u32 dj, u32 sj) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32 later = (u32)(mine[c] > j);
+            dd[c] |= (u32)(kd[c] == dj) & later;                          // an earlier edge with my (relation, destination)
+            ds[c] |= (u32)(ks[c] == sj) & later;
         }
-        w[k] = r | (md << 8) | ((head ? 1 : 0) << 10);
-    }
-    // every lane has finished READING the plain ids (the loops above run in lockstep inside the wavefront) before any writes
-    __builtin_amdgcn_wave_barrier();
+    });
 #pragma unroll
-    for (int k = 0; k < kLocM / 64; ++k) {
-        const int i = lane + 64 * k;
-        if (i >= m) break;
-        L.rel[wave][i] = w[k];
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < NC; ++c)
+        if (mine[c] < m) {
+            const int r = (int)(kd[c] >> 14);
+            atomicAdd(&cnt[0][r], 1);
+            if (dd[c] == 0) atomicAdd(&cnt[1][r], 1);
+            if (ds[c] == 0) atomicAdd(&cnt[2][r], 1);
+        }
 }
 
 __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, int32_t R, const int32_t* __restrict__ node_ptr,
@@ -100,27 +164,24 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                                    const int32_t* __restrict__ etype, int64_t N, int64_t E,
                                                                    int32_t* Er, int32_t* Dr, int32_t* Sr, int32_t* bad) {
-    __shared__ LocLds L;
+    __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t cnt[3][kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* X = L.e[wave];
     if (threadIdx.x < 3 * kLocR) cnt[threadIdx.x / kLocR][threadIdx.x % kLocR] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 &&                           // the graphs must tile the node and edge ranges
         (node_ptr[0] != 0 || edge_ptr[0] != 0 || node_ptr[G] != N || edge_ptr[G] != E))
         atomicOr(bad, 1);
     __syncthreads();
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1, e0;
-        const int m = load_graph(L, wave, lane, g, R, node_ptr, edge_ptr, src, dst, etype, n0, n1, e0, bad);
+        int n0, n1;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, n0, n1, bad);
         if (m <= 0) continue;
-        for (int i = lane; i < m; i += 64) {
-            const int r = L.rel[wave][i], s = L.src[wave][i], d = L.dst[wave][i];
-            bool fd = true, fs = true;
-            for (int j = 0; j < i; ++j) {
-                if (L.rel[wave][j] == r) { fd &= L.dst[wave][j] != d; fs &= L.src[wave][j] != s; }
-            }
-            atomicAdd(&cnt[0][r], 1);
-            if (fd) atomicAdd(&cnt[1][r], 1);
-            if (fs) atomicAdd(&cnt[2][r], 1);
+        for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
+            const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
+            if (nc == 1) stats_pass<1>(X, lane, m, c0, cnt);
+            else if (nc == 2) stats_pass<2>(X, lane, m, c0, cnt);
+            else stats_pass<kLocCG>(X, lane, m, c0, cnt);
         }
         __builtin_amdgcn_wave_barrier();                                   // the next graph overwrites this wavefront's slice
     }
@@ -141,9 +202,10 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
                                                                    const int32_t* __restrict__ etype, const int32_t* __restrict__ Er,
                                                                    const int32_t* __restrict__ Dr, const int32_t* __restrict__ Sr,
                                                                    int32_t* mode_out, int32_t* __restrict__ C) {
-    __shared__ LocLds L;
+    __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* X = L.e[wave];
     if (threadIdx.x < kLocR) {
         const int md = threadIdx.x < R ? mode_of(Er[threadIdx.x], Dr[threadIdx.x], Sr[threadIdx.x], edge_frac) : kEdge;
         s_mode[threadIdx.x] = md;
@@ -153,37 +215,120 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
     const int64_t RG = (int64_t)R * G;
     int32_t* Cf = C + kSeg * RG;
     int32_t* Cb = Cf + (N + 1);
+    const int my_mode = s_mode[lane];
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1, e0;
-        const int m = load_graph(L, wave, lane, g, R, node_ptr, edge_ptr, src, dst, etype, n0, n1, e0, nullptr);
+        int n0, n1;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, n0, n1, nullptr);
         if (m < 0) continue;                                               // (flagged by the statistics pass: tables are unused)
-        flag_graph(L, wave, lane, m, s_mode);
-        if (lane < R) {                                                    // one lane per relation
-            int rows = 0, heads = 0, edges = 0;
-            for (int j = 0; j < m; ++j) {
-                const int w = L.rel[wave][j];
-                if ((w & 0xff) == lane) { ++edges; heads += (w >> 10) & 1; }
-            }
-            const int md = s_mode[lane];
-            rows = md == kEdge ? edges : heads;
-            const int64_t at = (int64_t)lane * G + g;
-            C[at] = rows;
-            C[RG + at] = md == kAgg ? heads : 0;
-            C[2 * RG + at] = md == kTf ? heads : 0;
-            C[3 * RG + at] = md == kAgg ? edges : 0;
-            C[4 * RG + at] = md == kTf ? edges : 0;
-        }
-        for (int v = n0 + lane; v < n1; v += 64) {                         // list lengths of the graph's nodes
+        flag_heads(X, lane, m);
+        // lane r: edges and heads of relation r (first pass);  lane v (64 nodes per pass): list lengths of node v
+        int edges = 0, heads = 0;
+        const int n = n1 - n0;
+        for (int v0 = 0; v0 < max(n, 1); v0 += 64) {
+            const u32 v = (u32)(v0 + lane);
+            const int first = v0 == 0 ? 1 : 0;
             int f = self_loop ? 1 : 0, b = f;
-            for (int j = 0; j < m; ++j) {
-                const int w = L.rel[wave][j], md = (w >> 8) & 3, hd = (w >> 10) & 1;
-                if (L.dst[wave][j] == v) f += (md != kAgg) ? 1 : hd;       // per-edge entry, or the one entry of an AGG row
-                if (L.src[wave][j] == v) b += (md != kTf) ? 1 : hd;
-            }
-            Cf[v] = f;
-            Cb[v] = b;
+            for_each_edge(X, m, [&](int, u32 w0, u32 w1) {
+                const u32 rj = w0 >> 26, mdj = (w1 >> 28) & 3u, sj = (w1 >> 14) & 0x3fffu, dj = w1 & 0x3fffu;
+                const int hdj = (int)((w1 >> 30) & 1u), real = mdj != 3u ? first : 0;
+                const int wf = mdj == kAgg ? hdj : (mdj != 3u ? 1 : 0);    // a per-edge entry, or the one entry of an AGG row
+                const int wb = mdj == kTf ? hdj : (mdj != 3u ? 1 : 0);
+                const bool mine = (u32)lane == rj;
+                edges += mine ? real : 0;
+                heads += mine ? (real & hdj) : 0;
+                f += (v == dj) ? wf : 0;
+                b += (v == sj) ? wb : 0;
+            });
+            if ((int)v < n) { Cf[n0 + v] = f; Cb[n0 + v] = b; }
+        }
+        if (lane < R) {
+            const int64_t at = (int64_t)lane * G + g;
+            C[at] = my_mode == kEdge ? edges : heads;
+            C[RG + at] = my_mode == kAgg ? heads : 0;
+            C[2 * RG + at] = my_mode == kTf ? heads : 0;
+            C[3 * RG + at] = my_mode == kAgg ? edges : 0;
+            C[4 * RG + at] = my_mode == kTf ? edges : 0;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct FillArgs {
+    int64_t G, N;
+    const int32_t *S0, *S1, *S2, *S3, *S4, *Sf, *Sb;
+    int32_t b1, b2, b3, b4, bf, bb, self_loop;
+    int32_t *row_in, *row_out, *aux_f_ptr, *aux_f_idx, *aux_b_ptr, *aux_b_idx, *dst_rows, *src_rows;
+};
+
+// my edges of this pass (one per chunk) against every edge j of the graph.  j's words are wave-uniform (SGPRs): the common
+// path is a handful of compares and conditional adds per lane with uniform weights (no branch); the two counts only collapsed
+// rows need sit behind a uniform branch that is taken for the few heads of collapsed relations.
+template <int NC>
+__device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c0, int64_t g, int n0, const FillArgs& A) {
+    u32 w0[NC], w1[NC], rc[NC], dc[NC], sc[NC], ck[NC];
+    int rank_rel[NC], heads_before[NC], rank_d[NC], rank_s[NC], later_rows[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c0 + c) * 64 + lane;
+        const uint2 x = i < m ? X[i] : make_uint2(kSentinel0, kSentinel1);
+        w0[c] = x.x; w1[c] = x.y;
+        rc[c] = x.x >> 26; dc[c] = x.y & 0x3fffu; sc[c] = (x.y >> 14) & 0x3fffu;
+        ck[c] = (((x.y >> 28) & 3u) << 16) | ((x.x >> 10) & 0xffffu);     // mode, key node
+        rank_rel[c] = heads_before[c] = rank_d[c] = rank_s[c] = later_rows[c] = 0;
+    }
+    for_each_edge(X, m, [&](int, u32 j0, u32 j1) {
+        const u32 rj = j0 >> 26, mdj = (j1 >> 28) & 3u, sj = (j1 >> 14) & 0x3fffu, dj = j1 & 0x3fffu;
+        const int nf = (mdj == kEdge || mdj == kTf) ? 1 : 0;               // j has a per-edge forward / backward list entry
+        const int nb = (mdj == kEdge || mdj == kAgg) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool lt = j0 < w0[c];                                    // j before me in the (relation, key node, edge) order
+            rank_rel[c] += (lt & (rc[c] == rj)) ? 1 : 0;
+            rank_d[c] += (lt & (dc[c] == dj)) ? nf : 0;                    // per-edge forward entries of my destination before mine
+            rank_s[c] += (lt & (sc[c] == sj)) ? nb : 0;
+        }
+        if (((j1 >> 30) & 1u) != 0 && (mdj == kAgg || mdj == kTf)) {       // j heads a collapsed row (rare)
+            const u32 kkj = j0 >> 10, ckj = (mdj << 16) | (kkj & 0xffffu);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                heads_before[c] += ((rc[c] == rj) & (kkj < (w0[c] >> 10))) ? 1 : 0;
+                later_rows[c] += ((ck[c] == ckj) & (rj > rc[c])) ? 1 : 0;  // collapsed rows of my mode at my key node after mine
+            }
+        }
+    });
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c0 + c) * 64 + lane;
+        if (i >= m) continue;
+        const int r = (int)rc[c], md = (int)((w1[c] >> 28) & 3u), hd = (int)((w1[c] >> 30) & 1u);
+        const int s = n0 + (int)sc[c], d = n0 + (int)dc[c], kn = md == kTf ? s : d;
+        const int64_t at = (int64_t)r * A.G + g;
+        const int32_t row = A.S0[at] + (md == kEdge ? rank_rel[c] : heads_before[c]);
+        if (md == kEdge) {
+            A.row_in[row] = s; A.row_out[row] = d;
+        } else if (md == kAgg) {
+            const int32_t pos = A.S3[at] - A.b3 + rank_rel[c];              // among the AGG edges, (relation, dst, edge) order
+            A.aux_f_idx[pos] = s;
+            if (hd) {
+                const int32_t a = A.S1[at] - A.b1 + heads_before[c];
+                A.row_in[row] = (int32_t)A.N + a; A.row_out[row] = kn;
+                A.aux_f_ptr[a] = pos;
+                // node kn's list: per-edge entries, then its collapsed rows in row order, then the self loop (if any): counted
+                // from the END of the list, which the scan knows
+                A.dst_rows[A.Sf[kn + 1] - A.bf - A.self_loop - 1 - later_rows[c]] = row;
+            }
+        } else {
+            const int32_t pos = A.S4[at] - A.b4 + rank_rel[c];
+            A.aux_b_idx[pos] = d;
+            if (hd) {
+                const int32_t a = A.S2[at] - A.b2 + heads_before[c];
+                A.row_in[row] = kn; A.row_out[row] = (int32_t)A.N + a;
+                A.aux_b_ptr[a] = pos;
+                A.src_rows[A.Sb[kn + 1] - A.bb - A.self_loop - 1 - later_rows[c]] = row;
+            }
+        }
+        if (md != kAgg) A.dst_rows[A.Sf[d] - A.bf + rank_d[c]] = row;
+        if (md != kTf) A.src_rows[A.Sb[s] - A.bb + rank_s[c]] = row;
     }
 }
 
@@ -194,92 +339,51 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
     int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
     int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr */) {
-    __shared__ LocLds L;
+    __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* X = L.e[wave];
     if (threadIdx.x < kLocR) s_mode[threadIdx.x] = threadIdx.x < R ? mode[threadIdx.x] : kEdge;
     __syncthreads();
     const int64_t RG = (int64_t)R * G;
-    const int32_t* S0 = S;
-    const int32_t* S1 = S + RG;
-    const int32_t* S2 = S + 2 * RG;
-    const int32_t* S3 = S + 3 * RG;
-    const int32_t* S4 = S + 4 * RG;
-    const int32_t* Sf = S + kSeg * RG;
-    const int32_t* Sb = Sf + (N + 1);
-    const int32_t b1 = S1[0], b2 = S2[0], b3 = S3[0], b4 = S4[0], bf = Sf[0], bb = Sb[0];      // (S0[0] == 0)
-    const int32_t P = b1, n_agg = b2 - b1, n_tf = b3 - b2, n_agg_e = b4 - b3, n_tf_e = bf - b4;
+    FillArgs A;
+    A.G = G; A.N = N; A.self_loop = self_loop ? 1 : 0;
+    A.S0 = S; A.S1 = S + RG; A.S2 = S + 2 * RG; A.S3 = S + 3 * RG; A.S4 = S + 4 * RG; A.Sf = S + kSeg * RG; A.Sb = A.Sf + (N + 1);
+    A.b1 = A.S1[0]; A.b2 = A.S2[0]; A.b3 = A.S3[0]; A.b4 = A.S4[0]; A.bf = A.Sf[0]; A.bb = A.Sb[0];           // (S0[0] == 0)
+    A.row_in = row_in; A.row_out = row_out; A.aux_f_ptr = aux_f_ptr; A.aux_f_idx = aux_f_idx; A.aux_b_ptr = aux_b_ptr;
+    A.aux_b_idx = aux_b_idx; A.dst_rows = dst_rows; A.src_rows = src_rows;
+    const int32_t P = A.b1, n_agg = A.b2 - A.b1, n_tf = A.b3 - A.b2, n_agg_e = A.b4 - A.b3, n_tf_e = A.bf - A.b4;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             meta[0] = P; meta[1] = n_agg; meta[2] = n_tf; meta[3] = n_agg_e; meta[4] = n_tf_e;
             aux_f_ptr[n_agg] = n_agg_e;
             aux_b_ptr[n_tf] = n_tf_e;
-            const int32_t tf_ = Sb[0] - bf, tb_ = Sb[N + 1] - bb;
+            const int32_t tf_ = A.Sb[0] - A.bf, tb_ = A.Sb[N + 1] - A.bb;
             dst_ptr[N] = tf_; dst_ptr[N + 1] = tf_;
             src_ptr[N] = tb_; src_ptr[N + 1] = tb_;
         }
-        if (threadIdx.x <= R) meta[5 + threadIdx.x] = threadIdx.x < R ? (G > 0 ? S0[(int64_t)threadIdx.x * G] : 0) : P;
+        if (threadIdx.x <= R) meta[5 + threadIdx.x] = threadIdx.x < R ? (G > 0 ? A.S0[(int64_t)threadIdx.x * G] : 0) : P;
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1, e0;
-        const int m = load_graph(L, wave, lane, g, R, node_ptr, edge_ptr, src, dst, etype, n0, n1, e0, nullptr);
+        int n0, n1;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, n0, n1, nullptr);
         if (m < 0) continue;
-        flag_graph(L, wave, lane, m, s_mode);
+        flag_heads(X, lane, m);
         for (int v = n0 + lane; v < n1; v += 64) {
-            const int32_t pf = Sf[v] - bf, pb = Sb[v] - bb;
+            const int32_t pf = A.Sf[v] - A.bf, pb = A.Sb[v] - A.bb;
             dst_ptr[v] = pf;
             src_ptr[v] = pb;
             if (self_loop) {
                 row_in[P + v] = v; row_out[P + v] = v;
-                dst_rows[Sf[v + 1] - bf - 1] = P + v;                      // the self loop closes every list
-                src_rows[Sb[v + 1] - bb - 1] = P + v;
+                dst_rows[A.Sf[v + 1] - A.bf - 1] = P + v;                  // the self loop closes every list
+                src_rows[A.Sb[v + 1] - A.bb - 1] = P + v;
             }
         }
-        for (int i = lane; i < m; i += 64) {
-            const int w = L.rel[wave][i], r = w & 0xff, md = (w >> 8) & 3, hd = (w >> 10) & 1;
-            const int s = L.src[wave][i], d = L.dst[wave][i], kn = md == kTf ? s : d;
-            const bool collapsed_head = hd && md != kEdge;
-            int rank_rel = 0, heads_before = 0, rank_d = 0, rank_s = 0, others = 0, same_before = 0;
-            for (int j = 0; j < m; ++j) {
-                const int wj = L.rel[wave][j], rj = wj & 0xff, mdj = (wj >> 8) & 3, hdj = (wj >> 10) & 1;
-                const int sj = L.src[wave][j], dj = L.dst[wave][j], knj = mdj == kTf ? sj : dj;
-                const bool lt_in_rel = knj < kn || (knj == kn && j < i);
-                const bool lt = rj < r || (rj == r && lt_in_rel);           // position in the (relation, key node, edge) order
-                if (rj == r) { rank_rel += lt_in_rel; heads_before += hdj & (knj < kn ? 1 : 0); }
-                if (dj == d && mdj != kAgg) rank_d += lt;                    // per-edge forward entries of node d before mine
-                if (sj == s && mdj != kTf) rank_s += lt;
-                if (collapsed_head) {
-                    // entries of node kn's list that precede this collapsed row's entry: every per-edge entry, and the
-                    // collapsed rows of lower relations (row order)
-                    if (md == kAgg) { others += (dj == kn && mdj != kAgg); same_before += (hdj && mdj == kAgg && knj == kn && rj < r); }
-                    else            { others += (sj == kn && mdj != kTf);  same_before += (hdj && mdj == kTf && knj == kn && rj < r); }
-                }
-            }
-            const int64_t at = (int64_t)r * G + g;
-            const int32_t row = S0[at] + (md == kEdge ? rank_rel : heads_before);
-            if (md == kEdge) {
-                row_in[row] = s; row_out[row] = d;
-            } else if (md == kAgg) {
-                const int32_t pos = S3[at] - b3 + rank_rel;                 // among the AGG edges, (relation, dst, edge) order
-                aux_f_idx[pos] = s;
-                if (hd) {
-                    const int32_t a = S1[at] - b1 + heads_before;
-                    row_in[row] = (int32_t)N + a; row_out[row] = kn;
-                    aux_f_ptr[a] = pos;
-                    dst_rows[Sf[kn] - bf + others + same_before] = row;
-                }
-            } else {
-                const int32_t pos = S4[at] - b4 + rank_rel;
-                aux_b_idx[pos] = d;
-                if (hd) {
-                    const int32_t a = S2[at] - b2 + heads_before;
-                    row_in[row] = kn; row_out[row] = (int32_t)N + a;
-                    aux_b_ptr[a] = pos;
-                    src_rows[Sb[kn] - bb + others + same_before] = row;
-                }
-            }
-            if (md != kAgg) dst_rows[Sf[d] - bf + rank_d] = row;
-            if (md != kTf) src_rows[Sb[s] - bb + rank_s] = row;
+        for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
+            const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
+            if (nc == 1) fill_pass<1>(X, lane, m, c0, g, n0, A);
+            else if (nc == 2) fill_pass<2>(X, lane, m, c0, g, n0, A);
+            else fill_pass<kLocCG>(X, lane, m, c0, g, n0, A);
         }
         __builtin_amdgcn_wave_barrier();
     }

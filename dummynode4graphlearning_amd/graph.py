@@ -228,6 +228,19 @@ def _node_ptr_or_none(data):
     return graph_ptr_i32(data)
 
 
+def _edge_ptr_or_none(data, node_ptr):
+    """Edge ranges per graph of a PyG-style batch whose edge list is the concatenation of the graphs' edge lists (what the
+    collate of main.py:245-247 produces): graph of an edge = graph of its source, edge_ptr[g] = first edge of graph g.  No check
+    here: the graph-local index builder validates every edge against its graph's node range on the device and declines (the
+    general builder then runs) when the edges are not grouped by graph."""
+    if node_ptr is None or data.edge_index.shape[1] == 0 or node_ptr.numel() < 2:
+        return None
+    src = data.edge_index[0].contiguous()
+    bounds = node_ptr.to(src.dtype)
+    gid = torch.bucketize(src, bounds[1:].contiguous(), right=True)
+    return torch.searchsorted(gid, torch.arange(bounds.numel(), dtype=gid.dtype, device=gid.device)).to(torch.int32)
+
+
 def edge_index_of(data):
     """Cached ops.EdgeIndex of a PyG-style batch (edge_index row 0 = src, row 1 = dst)."""
     cache = getattr(data, "_cache", None)
@@ -256,7 +269,9 @@ def row_index_of(data, etype, num_rels, self_loop):
         if (t is etype or (t.data_ptr() == etype.data_ptr() and t.numel() == etype.numel())) and ver == etype._version \
                 and r == tag:
             return ix
-    ix = ops.RowIndexSet(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels, self_loop)
+    nptr = _node_ptr_or_none(data)
+    ix = ops.RowIndexSet(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels, self_loop,
+                         node_ptr=nptr, edge_ptr=_edge_ptr_or_none(data, nptr), target_nodes=1 << 62)
     cache._rel.append((etype, etype._version, tag, ix))
     if len(cache._rel) > 4:
         cache._rel.pop(0)
