@@ -124,3 +124,44 @@ def test_local_builder_empty_batch_and_edgeless_graphs():
     _same(a, b)
     a, b = _build(np.zeros(0), np.zeros(0), np.zeros(0), 0, 3, False, [0], [0])
     _same(a, b)
+
+
+def test_local_builder_config5_full_size():
+    """BASELINE config 5 at full size (32,768 graphs, N = 1,015,808, E = 3,997,696, R = 16): every table equal to the general
+    builder's, compared on the device."""
+    from dummynode4graphlearning_amd import ops, synthetic, transforms
+    dev = torch.device("cuda:0")
+    raw = synthetic.config5()
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    vocab = (raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(dev) for k in keys), *vocab)
+    N = int(aug["node_label"].numel())
+    assert (N, int(aug["src"].numel())) == (1015808, 3997696)
+    a = ops.RowIndex(aug["src"], aug["dst"], aug["edge_label"], N, 16, self_loop=True)
+    b = ops.RowIndex(aug["src"], aug["dst"], aug["edge_label"], N, 16, self_loop=True, node_ptr=aug["node_ptr"],
+                     edge_ptr=aug["edge_ptr"])
+    assert (a.built_by, b.built_by) == ("general", "local")
+    assert a.modes == b.modes == [0] * 14 + [1, 2] and a.rel_ptr_host == b.rel_ptr_host
+    for f in FIELDS:
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_pyg_style_batches_reach_the_local_builder():
+    """graph.row_index_of derives the edge ranges of a collated PyG-style batch (edges grouped by graph) and the local builder
+    takes it; a batch whose edges are NOT grouped by graph is declined on the device and the general builder runs -- same tables."""
+    from dummynode4graphlearning_amd import graph as G
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    src, dst, et, nptr, eptr = _random_batch(rng, G=40, R=4, nmin=2, nmax=30, dens=2.5, dummy=True)
+    N = int(nptr[-1])
+    batch = torch.from_numpy(np.repeat(np.arange(len(nptr) - 1), np.diff(nptr))).to(dev)
+    mk = lambda s, d: G.GraphBatch(torch.zeros(N, 4, device=dev), torch.stack([torch.from_numpy(s), torch.from_numpy(d)]).to(dev),  # noqa: E731
+                                   batch=batch)
+    etype = torch.from_numpy(et).to(dev)
+    ix = G.row_index_of(mk(src, dst), etype, 4, True).parts[0][2]
+    assert ix.built_by == "local"
+    perm = rng.permutation(len(src))                                     # shuffle the edge list across graphs
+    etype_p = torch.from_numpy(et[perm]).to(dev)
+    ix_p = G.row_index_of(mk(src[perm], dst[perm]), etype_p, 4, True).parts[0][2]
+    assert ix_p.built_by == "general"
+    assert ix.num_rows == ix_p.num_rows and ix.modes == ix_p.modes       # (same multiset of rows; the order follows the edge ids)
