@@ -790,10 +790,11 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 // to the overflow CSR (ovf_ptr over overflowing nodes in node order, ovf_idx) the caller pre-sums.
 __global__ void slot_count_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
                                   const int32_t* __restrict__ lrows, int32_t* __restrict__ over, int32_t* __restrict__ olen,
-                                  int32_t drop_beg, int32_t drop_end) {
+                                  int32_t drop_beg, int32_t drop_end, const int32_t* __restrict__ drop_enable) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v > N) return;
     if (v == N) { over[N] = 0; olen[N] = 0; return; }            // sentinel: the scans yield the totals at [N]
+    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;     // (decided on the device: no host round trip)
     int cnt = 0;
     for (int i = lptr[v]; i < lptr[v + 1]; ++i) cnt += (lrows[i] < P && !(lrows[i] >= drop_beg && lrows[i] < drop_end)) ? 1 : 0;
     over[v] = cnt > K ? 1 : 0;
@@ -802,10 +803,16 @@ __global__ void slot_count_kernel(int64_t N, int32_t P, int32_t K, const int32_t
 __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lrows, const int32_t* __restrict__ over_id,
                                  const int32_t* __restrict__ ostart, int32_t* __restrict__ slots, int32_t* __restrict__ ovf_ptr,
-                                 int32_t* __restrict__ ovf_idx, int32_t drop_beg, int32_t drop_end) {
+                                 int32_t* __restrict__ ovf_idx, int32_t drop_beg, int32_t drop_end,
+                                 const int32_t* __restrict__ drop_enable, int32_t* __restrict__ dev_counts) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v > N) return;
-    if (v == N) { ovf_ptr[over_id[N]] = ostart[N]; return; }     // closing entry of the overflow CSR
+    if (v == N) {                                                // closing entry of the overflow CSR, totals for the caller
+        ovf_ptr[over_id[N]] = ostart[N];
+        if (dev_counts != nullptr) { dev_counts[0] = over_id[N]; dev_counts[1] = ostart[N]; }
+        return;
+    }
+    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
     const bool is_over = ostart[v + 1] > ostart[v];
     const int keep = is_over ? K - 1 : K;
     int k = 0, o = ostart[v];
@@ -1312,17 +1319,18 @@ size_t dn_slot_table_workspace_bytes(int64_t N) {
     size_t tb = 0;
     if (excl_scan(nullptr, tb, nullptr, nullptr, N + 1, nullptr) != hipSuccess) { dn_set_error("rocprim scan size query failed"); return 0; }
     a.take_bytes(tb);
-    return a.off + 256;
+    return a.off + 1024;                                         // (+ the slot of the two totals, dn_slot_table_build_i32)
 }
 
-int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
-                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+int dn_slot_table_build_async_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
+                                  int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, int32_t* ovf_ptr,
+                                  int32_t* ovf_idx, int32_t* dev_counts, void* workspace, size_t workspace_bytes,
+                                  dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
-    if (host_counts) host_counts[0] = host_counts[1] = 0;
-    if (N == 0) return DN_OK;
-    DN_REQUIRE(list_ptr && list_rows && slots && ovf_ptr && ovf_idx && host_counts && workspace, "dn_slot_table_build: NULL pointer");
+    DN_REQUIRE(dev_counts, "dn_slot_table_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (N == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_counts, 0, 2 * sizeof(int32_t), st)); return DN_OK; }
+    DN_REQUIRE(list_ptr && list_rows && slots && ovf_ptr && ovf_idx && workspace, "dn_slot_table_build: NULL pointer");
     Arena a(workspace, workspace_bytes);
     int32_t* over = a.take<int32_t>(N + 1);
     int32_t* olen = a.take<int32_t>(N + 1);
@@ -1333,16 +1341,32 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
     void* temp = a.take_bytes(tb);
     if (!a.ok()) { dn_set_error("dn_slot_table_build: workspace too small"); return DN_ERR_WORKSPACE; }
     hipLaunchKernelGGL(slot_count_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over, olen, drop_beg, drop_end);
+                       over, olen, drop_beg, drop_end, drop_enable);
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(excl_scan(temp, tb, over, over_id, N + 1, st));
     DN_CHECK_HIP(excl_scan(temp, tb, olen, ostart, N + 1, st));
     hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over_id, ostart, slots, ovf_ptr, ovf_idx, drop_beg, drop_end);
+                       over_id, ostart, slots, ovf_ptr, ovf_idx, drop_beg, drop_end, drop_enable, dev_counts);
     DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
+                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
+                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
+    if (host_counts) host_counts[0] = host_counts[1] = 0;
+    if (N == 0) return DN_OK;
+    DN_REQUIRE(list_ptr && list_rows && slots && ovf_ptr && ovf_idx && host_counts && workspace, "dn_slot_table_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    // the last 256 bytes of the workspace carry the two totals (dn_slot_table_workspace_bytes leaves that much slack)
+    DN_REQUIRE(workspace_bytes >= 512, "dn_slot_table_build: workspace too small");
+    int32_t* dev_counts = reinterpret_cast<int32_t*>((char*)workspace + ((workspace_bytes - 8) & ~(size_t)255));
+    int rc = dn_slot_table_build_async_i32(N, num_edge_rows, K, list_ptr, list_rows, drop_beg, drop_end, nullptr, slots, ovf_ptr,
+                                           ovf_idx, dev_counts, workspace, (size_t)((char*)dev_counts - (char*)workspace), stream);
+    if (rc != DN_OK) return rc;
     int32_t h[2] = {0, 0};
-    DN_CHECK_HIP(hipMemcpyAsync(&h[0], over_id + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    DN_CHECK_HIP(hipMemcpyAsync(&h[1], ostart + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipMemcpyAsync(h, dev_counts, sizeof(h), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
     host_counts[0] = h[0];                                       // overflowing nodes
     host_counts[1] = h[1];                                       // rows in the overflow CSR
@@ -1359,6 +1383,37 @@ size_t dn_fold_tables_workspace_bytes(int64_t num_segments) {
     return a.off + 256;
 }
 
+int dn_fold_tables_build_async_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                                   int32_t* fold_info, int32_t* part_ptr, int32_t* dev_ok, void* workspace, size_t workspace_bytes,
+                                   dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_tables_build: bad sizes");
+    DN_REQUIRE(dev_ok, "dn_fold_tables_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0 || num_segments == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0, sizeof(int32_t), st)); return DN_OK; }
+    DN_REQUIRE(seg_ptr && seg_nodes && fold_info && part_ptr && workspace, "dn_fold_tables_build: NULL pointer");
+    Arena a(workspace, workspace_bytes);
+    int32_t* ntile = a.take<int32_t>(num_segments + 1);
+    a.take<int32_t>(1);
+    size_t tb = 0;
+    DN_CHECK_HIP(excl_scan(nullptr, tb, ntile, part_ptr, num_segments + 1, st));
+    void* temp = a.take_bytes(tb);
+    if (!a.ok()) { dn_set_error("dn_fold_tables_build: workspace too small"); return DN_ERR_WORKSPACE; }
+    const int64_t tiles = dn_cdiv(N, kFoldTile);
+    DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
+    hipLaunchKernelGGL(fold_init_kernel, dim3(grid_for(tiles * kFoldInfo)), dim3(kBlock), 0, st, tiles, fold_info);
+    DN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_count_kernel, dim3(grid_for(num_segments + 1)), dim3(kBlock), 0, st, num_segments, N, seg_ptr, seg_nodes,
+                       ntile, dev_ok);
+    DN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_check_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, dev_ok);
+    DN_CHECK_LAUNCH();
+    DN_CHECK_HIP(excl_scan(temp, tb, ntile, part_ptr, num_segments + 1, st));
+    hipLaunchKernelGGL(fold_fill_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, part_ptr,
+                       dev_ok, fold_info);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
                              int32_t* fold_info, int32_t* part_ptr, int32_t* host_ok, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream) {
@@ -1366,28 +1421,14 @@ int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg
     DN_REQUIRE(host_ok, "dn_fold_tables_build: NULL pointer");
     *host_ok = 0;
     if (N == 0 || num_segments == 0) return DN_OK;
-    DN_REQUIRE(seg_ptr && seg_nodes && fold_info && part_ptr && workspace, "dn_fold_tables_build: NULL pointer");
+    DN_REQUIRE(workspace, "dn_fold_tables_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Arena a(workspace, workspace_bytes);
-    int32_t* ntile = a.take<int32_t>(num_segments + 1);
-    int32_t* ok = a.take<int32_t>(1);
-    size_t tb = 0;
-    DN_CHECK_HIP(excl_scan(nullptr, tb, ntile, part_ptr, num_segments + 1, st));
-    void* temp = a.take_bytes(tb);
-    if (!a.ok()) { dn_set_error("dn_fold_tables_build: workspace too small"); return DN_ERR_WORKSPACE; }
-    const int64_t tiles = dn_cdiv(N, kFoldTile);
-    DN_CHECK_HIP(hipMemsetAsync(ok, 0x01, sizeof(int32_t), st));                 // any non-zero value: "still valid"
-    hipLaunchKernelGGL(fold_init_kernel, dim3(grid_for(tiles * kFoldInfo)), dim3(kBlock), 0, st, tiles, fold_info);
-    DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fold_count_kernel, dim3(grid_for(num_segments + 1)), dim3(kBlock), 0, st, num_segments, N, seg_ptr, seg_nodes,
-                       ntile, ok);
-    DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fold_check_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, ok);
-    DN_CHECK_LAUNCH();
-    DN_CHECK_HIP(excl_scan(temp, tb, ntile, part_ptr, num_segments + 1, st));
-    hipLaunchKernelGGL(fold_fill_kernel, dim3(grid_for(num_segments)), dim3(kBlock), 0, st, num_segments, seg_ptr, seg_nodes, part_ptr,
-                       ok, fold_info);
-    DN_CHECK_LAUNCH();
+    a.take<int32_t>(num_segments + 1);
+    int32_t* ok = a.take<int32_t>(1);                                              // (same layout as the async entry point)
+    int rc = dn_fold_tables_build_async_i32(N, num_segments, seg_ptr, seg_nodes, fold_info, part_ptr, ok, workspace, workspace_bytes,
+                                            stream);
+    if (rc != DN_OK) return rc;
     int32_t h = 0;
     DN_CHECK_HIP(hipMemcpyAsync(&h, ok, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));

@@ -898,7 +898,10 @@ class RowIndex:
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
         self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
-        if node_ptr is None or edge_ptr is None or R > 64 or not LOCAL_INDEX_ENABLED:
+        try_local = node_ptr is not None and edge_ptr is not None and R <= 64 and LOCAL_INDEX_ENABLED
+        if try_local:                                                 # (graphs over the LDS limit: do not even try)
+            try_local = E == 0 or E <= 1024 * (int(node_ptr.numel()) - 1)
+        if not try_local:
             _check_edge_types(etype, R)                               # (the local builder validates on the device)
         src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))
         e32 = lambda n: torch.empty(max(int(n), 1), dtype=I32, device=dev)  # noqa: E731
@@ -909,13 +912,12 @@ class RowIndex:
         host_rel = (ctypes.c_int32 * (R + 1))()
         host_modes = (ctypes.c_int32 * R)()
         self.built_by = "general"
-        if node_ptr is not None and edge_ptr is not None and R <= 64 and LOCAL_INDEX_ENABLED:
+        if try_local:
             require_gpu(node_ptr, edge_ptr)
             node_ptr, edge_ptr = node_ptr.to(I32).contiguous(), edge_ptr.to(I32).contiguous()
             G = int(node_ptr.numel()) - 1
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
-            # (more than 1024 edges per graph on average: some graph exceeds the builder's LDS limit, do not even try)
-            nbytes = lib().dn_row_index_local_workspace_bytes(G, N, R, E) if E <= 1024 * G or E == 0 else 0
+            nbytes = lib().dn_row_index_local_workspace_bytes(G, N, R, E)
             if nbytes:
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
@@ -927,8 +929,8 @@ class RowIndex:
                       "dn_row_index_build_local_i32")
                 if status.value == 0:
                     self.built_by = "local"
-                else:
-                    _check_edge_types(etype, R)
+            if self.built_by != "local":
+                _check_edge_types(etype, R)
         if self.built_by == "general":
             nbytes = lib().dn_row_index_workspace_bytes(N, R, E)
             if nbytes == 0:
@@ -965,16 +967,75 @@ class RowIndex:
                                             max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 256 // 64) * 64)), want_ptr=True)
 
 
+def _fold_candidate(ix, direction):
+    """(relation, first row, end row, #aux lists) of the one collapsed relation whose pre-aggregation the closing launch could
+    absorb in this direction (AGG forward / TF backward), or None -- decided from what the host already knows."""
+    mode = RowIndex.AGG if direction == "f" else RowIndex.TF
+    n_aux = ix.num_aux_f if direction == "f" else ix.num_aux_b
+    rels = [r for r, m in enumerate(ix.modes) if m == mode and ix.rel_ptr_host[r + 1] > ix.rel_ptr_host[r]]
+    if not (FOLD_ENABLED and ix.self_loop and len(rels) == 1 and ix.num_rels <= 64 and n_aux > 0
+            and getattr(ix, "pipe", None) is None):
+        return None
+    r = rels[0]
+    beg, end = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
+    return (r, beg, end, n_aux) if end - beg == n_aux else None
+
+
+def _closing_tables(ix):
+    """Slot tables and fold tables of BOTH directions of a RowIndex, queued back to back (dn_fold_tables_build_async_i32 leaves its
+    verdict on the device, dn_slot_table_build_async_i32 reads it there to decide whether the folded relation's rows are left out
+    of the slots) and read back in ONE copy: one host synchronisation per batch instead of four."""
+    if ix._slots:
+        return
+    N, P, dev, K = ix.num_nodes, ix.num_edge_rows, ix.row_in.device, SELFSUM_SLOTS
+    flags = torch.zeros(8, dtype=I32, device=dev)                  # [ok_f, ok_b, novf_f, nrows_f, novf_b, nrows_b, -, -]
+    work = {}
+    for k, direction in enumerate(("f", "b")):
+        cand = _fold_candidate(ix, direction)
+        fold_info = part_ptr = None
+        if cand is not None:
+            aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+            fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
+            part_ptr = torch.empty(cand[3] + 1, dtype=I32, device=dev)
+            ws = _ws(lib().dn_fold_tables_workspace_bytes(cand[3]), dev)
+            check(lib().dn_fold_tables_build_async_i32(N, cand[3], ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
+                                                       ptr(flags[k:]), ptr(ws), ws.numel(), stream_ptr()),
+                  "dn_fold_tables_build_async_i32")
+        ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
+        ptr_, rows = ptr_.to(I32).contiguous(), rows.to(I32).contiguous()
+        slots = torch.empty((N, K), dtype=I32, device=dev)
+        ovf_ptr = torch.empty(N + 1, dtype=I32, device=dev)
+        ovf_idx = torch.empty(max(int(rows.numel()), 1), dtype=I32, device=dev)
+        ws = _ws(lib().dn_slot_table_workspace_bytes(N), dev)
+        check(lib().dn_slot_table_build_async_i32(N, P, K, ptr(ptr_), ptr(rows), cand[1] if cand else 0, cand[2] if cand else 0,
+                                                  ptr(flags[k:]) if cand else None, ptr(slots), ptr(ovf_ptr), ptr(ovf_idx),
+                                                  ptr(flags[2 + 2 * k:]), ptr(ws), ws.numel(), stream_ptr()),
+              "dn_slot_table_build_async_i32")
+        work[direction] = (cand, fold_info, part_ptr, slots, ovf_ptr, ovf_idx)
+    h = flags.cpu().tolist()                                        # the one synchronisation
+    for k, direction in enumerate(("f", "b")):
+        cand, fold_info, part_ptr, slots, ovf_ptr, ovf_idx = work[direction]
+        info = None
+        if cand is not None and h[k] != 0:
+            r, beg, end, n_aux = cand
+            info = _Fold()
+            info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
+            info.fold_info, info.part_ptr = fold_info, part_ptr
+            info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
+            #                                                    starts one partial row, every tile boundary inside one another
+            rel_ptr_d = torch.tensor(ix.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
+            info.main_tiles = build_row_tables(rel_ptr_d, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+            info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+        ix._fold[direction] = info
+        n_ovf, n_rows = h[2 + 2 * k], h[3 + 2 * k]
+        ix._slots[direction] = (slots, None, None, 0) if n_ovf == 0 else (slots, ovf_ptr[:n_ovf + 1], ovf_idx[:n_rows], n_ovf)
+
+
 def _row_index_slots(ix, direction):
     """Slot tables of a RowIndex for the fused closing launch ('f': rows into each destination, 'b': rows out of each source).
     The rows of a FOLDED relation (_row_index_fold) are left out: they are added by the tail launches."""
-    t = ix._slots.get(direction)
-    if t is None:
-        ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
-        fold = _row_index_fold(ix, direction)
-        t = build_slot_table(ptr_, rows, ix.num_nodes, ix.num_edge_rows, drop=(fold.beg, fold.end) if fold else (0, 0))
-        ix._slots[direction] = t
-    return t
+    _closing_tables(ix)
+    return ix._slots[direction]
 
 
 # The collapsed relation of a dummy-augmented batch (u -> dummy forward, dummy -> u backward) needs the SUM of a graph's rows as
@@ -990,37 +1051,10 @@ class _Fold:
 
 def _row_index_fold(ix, direction):
     """The relation whose pre-aggregation the closing launch can absorb, or None: exactly ONE collapsed relation in this
-    direction (AGG forward / TF backward), its aux lists contiguous ascending node ranges (a graph's nodes), bf16 self-loop path.
-    One device -> host read-back (the contiguity check) when the index is built."""
-    if direction in ix._fold:
-        return ix._fold[direction]
-    info = None
-    mode = RowIndex.AGG if direction == "f" else RowIndex.TF
-    aux_ptr, aux_idx, n_aux = ((ix.aux_f_ptr, ix.aux_f_idx, ix.num_aux_f) if direction == "f"
-                               else (ix.aux_b_ptr, ix.aux_b_idx, ix.num_aux_b))
-    rels = [r for r, m in enumerate(ix.modes) if m == mode and ix.rel_ptr_host[r + 1] > ix.rel_ptr_host[r]]
-    if (FOLD_ENABLED and ix.self_loop and len(rels) == 1 and ix.num_rels <= 64 and n_aux > 0
-            and getattr(ix, "pipe", None) is None):
-        r = rels[0]
-        beg, end = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
-        N, dev = ix.num_nodes, aux_idx.device
-        fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
-        part_ptr = torch.empty(n_aux + 1, dtype=I32, device=dev)
-        ws = _ws(lib().dn_fold_tables_workspace_bytes(n_aux), dev)
-        ok = ctypes.c_int32(0)
-        check(lib().dn_fold_tables_build_i32(N, n_aux, ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
-                                             ctypes.byref(ok), ptr(ws), ws.numel(), stream_ptr()), "dn_fold_tables_build_i32")
-        if ok.value == 1 and end - beg == n_aux:
-            info = _Fold()
-            info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-            info.fold_info, info.part_ptr = fold_info, part_ptr
-            info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
-            #                                                    starts one partial row, every tile boundary inside one another
-            rel_ptr_d = torch.tensor(ix.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
-            info.main_tiles = build_row_tables(rel_ptr_d, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
-            info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
-    ix._fold[direction] = info
-    return info
+    direction (AGG forward / TF backward), its aux lists contiguous ascending node ranges (a graph's nodes), bf16 self-loop path
+    (checked on the device by dn_fold_tables_build_async_i32; the verdict comes back with the slot tables' counts)."""
+    _closing_tables(ix)
+    return ix._fold[direction]
 
 
 RowIndex.slots = _row_index_slots

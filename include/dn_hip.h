@@ -274,6 +274,14 @@ size_t dn_slot_table_workspace_bytes(int64_t N);
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
                             int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
                             int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+/* The same build without the read-back (no synchronisation): dev_counts [2] (device) receives {overflowing nodes, rows in the
+ * overflow CSR}; drop_enable (device, may be NULL) switches the drop range off when *drop_enable == 0 -- the flag
+ * dn_fold_tables_build_async_i32 leaves on the device, so the tables of both directions of a batch are queued back to back and
+ * the caller reads every count in ONE copy (the per-batch bookkeeping of subgraph_isomorphism/dataset.py:1605-1611). */
+int dn_slot_table_build_async_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr,
+                                  const int32_t* list_rows, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
+                                  int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx, int32_t* dev_counts, void* workspace,
+                                  size_t workspace_bytes, dn_stream_t stream);
 
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
@@ -344,6 +352,10 @@ size_t dn_fold_tables_workspace_bytes(int64_t num_segments);
 int dn_fold_tables_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
                              int32_t* fold_info, int32_t* part_ptr, int32_t* host_ok, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream);
+/* The same build without the read-back: *dev_ok (device) ends up non-zero when the tables are valid, 0 otherwise. */
+int dn_fold_tables_build_async_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                                   int32_t* fold_info, int32_t* part_ptr, int32_t* dev_ok, void* workspace,
+                                   size_t workspace_bytes, dn_stream_t stream);
 
 /* Tail of a folded pre-aggregation, one launch:  aux[j, :] = bf16( sum_{k in [part_ptr[j], part_ptr[j+1])} part[k, :] ) in k
  * order (kept by the caller: the collapsed relation's operand of dn_rows_wgrad_bf16), then the relation's transform of those
