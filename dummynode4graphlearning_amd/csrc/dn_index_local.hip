@@ -70,10 +70,11 @@ __device__ __forceinline__ void for_each_edge(const uint2* X, int jend, F&& body
 // Returns the edge count, or -1 when the graph is not taken (flagged in *bad by the statistics pass).
 __device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t R, const int32_t* node_ptr,
                                           const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
-                                          const int32_t* s_mode, int& n0, int& n1, int32_t* bad) {
+                                          const int32_t* s_mode, int64_t N, int64_t E, int& n0, int& n1, int32_t* bad) {
     n0 = node_ptr[g]; n1 = node_ptr[g + 1];
     const int e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
-    if (m < 0 || m > kLocM || n1 < n0 || n1 - n0 > kLocNodes) {
+    // (ranges that leave [0, N) / [0, E) would index past the caller's arrays: never touch such a graph)
+    if (m < 0 || m > kLocM || n1 < n0 || n1 - n0 > kLocNodes || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) {
         if (bad != nullptr && lane == 0) atomicOr(bad, 1);
         return -1;
     }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
     __syncthreads();
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, n0, n1, bad);
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, N, E, n0, n1, bad);
         if (m <= 0) continue;
         for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
             const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
 // C layout (int32): [kSeg][R][G] counts over (relation, graph), then N + 1 forward list lengths (the last one 0), then N + 1
 // backward list lengths, then one closing 0 -- one exclusive scan gives every offset (a segment's own offsets = scan - scan at
 // the segment's first element).
-__global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, int64_t N, int32_t R, float edge_frac, int32_t self_loop,
+__global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, int64_t N, int64_t E, int32_t R, float edge_frac, int32_t self_loop,
                                                                    const int32_t* __restrict__ node_ptr,
                                                                    const int32_t* __restrict__ edge_ptr,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
     const int my_mode = s_mode[lane];
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, n0, n1, nullptr);
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, N, E, n0, n1, nullptr);
         if (m < 0) continue;                                               // (flagged by the statistics pass: tables are unused)
         flag_heads(X, lane, m);
         // lane r: edges and heads of relation r (first pass);  lane v (64 nodes per pass): list lengths of node v
@@ -333,7 +334,7 @@ __device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c
 }
 
 __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
-    int64_t G, int64_t N, int32_t R, int32_t self_loop, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
+    int64_t G, int64_t N, int64_t E, int32_t R, int32_t self_loop, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
     const int32_t* __restrict__ mode, const int32_t* __restrict__ S, int32_t* __restrict__ row_in, int32_t* __restrict__ row_out,
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, n0, n1, nullptr);
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, N, E, n0, n1, nullptr);
         if (m < 0) continue;
         flag_heads(X, lane, m);
         for (int v = n0 + lane; v < n1; v += 64) {
@@ -461,11 +462,11 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
     const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
     hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
                        N, E, w.Er, w.Dr, w.Sr, w.bad);
-    hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, (int32_t)R, edge_frac, self_loop, node_ptr,
+    hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, edge_frac, self_loop, node_ptr,
                        edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.mode, w.C);
     DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
                                          rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
+    hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
                        dst, etype, w.mode, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
                        src_ptr, src_rows, w.meta);
     DN_CHECK_LAUNCH();

@@ -117,6 +117,13 @@ def test_local_builder_declines_and_falls_back():
     # (3) ranges that do not cover every node
     a, b = _build(src2[:3], dst2[:3], et2[:3], 8, 2, True, [0, 4, 6], [0, 3, 3])
     assert b.built_by == "general"
+    # (4) ranges that point past the arrays (never dereferenced: the builder checks them against N and E first)
+    a, b = _build(src2[:3], dst2[:3], et2[:3], 8, 2, True, [0, 4, 800], [0, 3, 300])
+    assert b.built_by == "general"
+    a, b = _build(src2[:3], dst2[:3], et2[:3], 8, 2, True, [0, -4, 8], [0, -3, 3])
+    assert b.built_by == "general"
+    for f in FIELDS:
+        assert torch.equal(getattr(a, f), getattr(b, f))
 
 
 def test_local_builder_empty_batch_and_edgeless_graphs():
