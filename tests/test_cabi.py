@@ -85,3 +85,24 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert L.dn_window_tiles_host(npt, 4, 4, out, 16, ctypes.byref(n)) == 0
     assert n.value == 4 and list(out[:5]) == [0, 3, 7, 10, 12]            # {g0, g1}, g2 cut at 4 rows: [3,7) [7,10), {g3}
     assert L.dn_window_tiles_host(npt, 4, 4, out, 2, ctypes.byref(n)) == -3 and b"tile table too small" in L.dn_last_error()
+
+
+def test_local_index_and_async_table_entry_points_check_their_arguments(lib):
+    """dn_row_index_build_local_i32 / the async table builders: sizes and pointers are checked before anything is launched"""
+    L = lib.lib()
+    assert L.dn_row_index_local_workspace_bytes(4, 10, 65, 20) == 0 and b"bad sizes" in L.dn_last_error()     # R > 64
+    assert L.dn_row_index_local_workspace_bytes(-1, 10, 3, 20) == 0
+    counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 3)(), ctypes.c_int32(0)
+    P16 = ctypes.c_void_p(16)
+    rc = L.dn_row_index_build_local_i32(4, 10, 65, 20, P16, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
+                                        ctypes.byref(st), P16, 1 << 20, None)
+    assert rc == -1 and b"more than 64 relations" in L.dn_last_error()
+    rc = L.dn_row_index_build_local_i32(4, 10, 3, 20, None, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
+                                        ctypes.byref(st), P16, 1 << 20, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    rc = L.dn_slot_table_build_async_i32(10, 5, 6, P16, P16, 0, 0, None, P16, P16, P16, None, P16, 1 << 20, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    rc = L.dn_slot_table_build_async_i32(10, 5, 1, P16, P16, 0, 0, None, P16, P16, P16, P16, P16, 1 << 20, None)
+    assert rc == -1 and b"bad sizes" in L.dn_last_error()
+    rc = L.dn_fold_tables_build_async_i32(10, 2, P16, P16, P16, P16, None, P16, 1 << 20, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
