@@ -370,7 +370,7 @@ def main():
     overlapped_ms = None
     if rank == 0 and world == 1 and graph is not None and fused and dtype == torch.bfloat16:
         from dummynode4graphlearning_amd import transforms as _tr
-        side2 = torch.cuda.Stream()
+        side2 = torch.cuda.Stream()                     # (a high-priority side stream changes nothing: 0.88 vs 0.89 G edges/s)
         traw = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
 
         def next_batch_index():
