@@ -1,0 +1,246 @@
+// Graph-local neighbour sum on the matrix cores (gfx950):
+//   out[v, :] = self_coef * x[v, :] + sum_{i in [ptr[v], ptr[v+1])} x[idx[i], :]        for the rows of the listed tiles
+// -- the aggregation of GINConv (graph_classification/graph_neural_networks/models/gconv.py:197, PyG `propagate(aggr="add")` +
+// `(1 + eps) * x_i`) on a batch of small graphs, where a tile is a run of WHOLE graphs (<= 64 rows), so every neighbour row of
+// a tile's rows lies inside the tile.
+//
+// The plain kernel (dn_gather_segsum_*) walks ptr -> idx -> rows per destination: three dependent round trips per segment, the
+// gathered rows re-read through L2 (34 % of the HBM peak on compulsory bytes).  Here a tile's rows arrive
+// ONCE, coalesced; they are cut into three bf16 planes hi / mid / lo in LDS (hi + mid + lo reproduces the fp32 value to its last
+// bit or so), the tile's adjacency COUNTS (how often row s feeds row d; small integers, exact in bf16) are scattered into a
+// 64 x 64 bf16 matrix in LDS, and the sum is the dense product  Adj x (hi + mid + lo)  on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation: exact products, no dependent loads, HBM sees rows in, rows out and the index once.
+#include "dn_common.h"
+#include "../../include/dn_hip.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGtRows = 64;        // rows of a tile
+constexpr int gt_threads(int H) { return H >= 128 ? 512 : 256; }   // 8 waves measured best at H = 128 (4: -10 %, 16: -12 %)
+constexpr int kGtPad = 8;          // bf16 elements of row padding (planes and adjacency)
+
+// element j of lane l = tile[8 * (l >> 4) + j][col0 + (l & 15)]   (hardware transpose read, as in dn_rel.hip)
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int stride, int col0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const bf16_t* a0 = tile + (8 * g + q) * stride + col0 + 4 * p;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * stride));
+    const short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, f);
+}
+
+// One persistent workgroup walks tiles blockIdx.x, + gridDim.x, ...; what the NEXT tile needs from memory (its rows, its list
+// bounds, its index entries) is requested right after this tile's rows have been handed to LDS and lands under this tile's
+// adjacency build, MFMAs and stores: the memory latency of a tile is off its critical path, which is what a two-workgroup-per-CU
+// kernel with five barriers per tile needs.  Measured on the PROTEINS-shaped GIN batch of bench.py (H = 128): 0.44 GB of
+// compulsory traffic in 100-110 us per direction for the 64 % of the rows that sit in graphs of <= 64 rows = 4.0-4.3 TB/s,
+// against 2.9-3.0 TB/s for the plain kernel; phase ablation: rows in / planes / barriers / rows staged alone 70 us, + stores
+// 27 us, + adjacency 18 us, + MFMAs 20 us (the phases of a workgroup do not overlap; a second workgroup per CU is what does).
+template <int H>
+__global__ __launch_bounds__(gt_threads(H)) void graph_tile_sum_kernel(const float* __restrict__ x, const int32_t* __restrict__ ptr,
+                                                                    const int32_t* __restrict__ idx,
+                                                                    const int32_t* __restrict__ seg,
+                                                                    const int32_t* __restrict__ tiles, int32_t num_tiles,
+                                                                    int32_t num_rows, int32_t num_entries, float self_coef,
+                                                                    float* __restrict__ out, int32_t* __restrict__ bad) {
+    constexpr int kGtThreads = gt_threads(H);
+    constexpr int SP = H + kGtPad;                  // plane row stride (bf16)
+    constexpr int SA = kGtRows + kGtPad;            // adjacency row stride (bf16)
+    constexpr int SO = H + 4;                       // output staging row stride (fp32)
+    constexpr int LPR = H / 4;                      // float4 pieces per row
+    constexpr int PP = kGtRows * LPR / kGtThreads;  // pieces per thread
+    constexpr int NW = kGtThreads / 64, NCT = H / 16;
+    constexpr int MS = NW > NCT ? NW / NCT : 1;     // waves that share a column tile split the row tiles
+    constexpr int NT = NW >= NCT ? 1 : NCT / NW;    // 16-column tiles per wave
+    constexpr int MTW = (kGtRows / 16) / MS;        // 16-row tiles per wave
+    constexpr int EP = 1024 / kGtThreads;           // index entries per thread kept in registers (64 rows x 16 entries)
+    static_assert(kGtRows * LPR % kGtThreads == 0 && H % 64 == 0 && NW % (NCT / NT) == 0 && MTW >= 1, "unsupported width");
+    static_assert(kGtRows * SO * 4 <= 3 * kGtRows * SP * 2, "the output staging tile lives in the planes");
+    __shared__ __attribute__((aligned(16))) bf16_t planes[3 * kGtRows * SP];
+    __shared__ __attribute__((aligned(16))) uint32_t adjW[kGtRows * SA / 2];
+    __shared__ int32_t ptrL[kGtRows + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    struct Tile {                                   // one tile's memory image in registers
+        int row_beg, rows, e_beg, e_end;
+        float4 xr[PP];
+        int32_t ent[EP], sg[EP];                    // index entries and (when the caller has them) their destination rows
+        int32_t pv;                                 // ptr[row_beg + tid] (tid <= rows)
+    };
+    // Every load below is UNCONDITIONAL (row / entry numbers clamped into the tile, values masked afterwards): written as
+    // `cond ? load : 0` hipcc put each load in its own branch and a vmcnt(0) behind it -- eight serial round trips per tile.
+    // tile record: {first row, end row, first index entry, end entry} -- read TWO tiles ahead (uniform address), so that the
+    // loads of the next tile start without a dependent chain tiles -> ptr -> idx in front of them
+    auto record = [&](int t) -> int4 {
+        int4 m = make_int4(0, 0, 0, 0);
+        if (t < num_tiles) m = *reinterpret_cast<const int4*>(tiles + 4 * (size_t)t);
+        return m;
+    };
+    auto request = [&](const int4& m, Tile& T) {
+        T.row_beg = m.x; T.rows = m.y - m.x; T.e_beg = m.z; T.e_end = m.w;
+        if (T.rows < 0 || T.rows > kGtRows || T.row_beg < 0 || (int64_t)T.row_beg + T.rows > num_rows || T.e_beg < 0 ||
+            T.e_end < T.e_beg || T.e_end > num_entries) {                  // (never dereferenced)
+            if (tid == 0) atomicOr(bad, 1);
+            T.row_beg = 0; T.rows = 0; T.e_beg = T.e_end = 0;
+        }
+        const int last = T.rows > 0 ? T.rows - 1 : 0;                      // (num_rows >= 1: row 0 exists)
+#pragma unroll
+        for (int k = 0; k < PP; ++k) {
+            const int p = tid + k * kGtThreads, r = min(p / LPR, last), c4 = p % LPR;
+            T.xr[k] = *reinterpret_cast<const float4*>(x + (size_t)(T.row_beg + r) * H + c4 * 4);
+        }
+        const int e_last = T.e_end > T.e_beg ? T.e_end - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < EP; ++k) {
+            const int e = min(T.e_beg + tid + k * kGtThreads, e_last);
+            T.ent[k] = num_entries > 0 ? idx[e] : 0;
+            T.sg[k] = (seg != nullptr && num_entries > 0) ? seg[e] : 0;
+        }
+        T.pv = ptr[T.row_beg + min(tid, T.rows)];
+    };
+
+    Tile cur, nxt;
+    request(record((int)blockIdx.x), cur);
+    int4 rec_next = record((int)blockIdx.x + (int)gridDim.x);
+    for (int t = (int)blockIdx.x; t < num_tiles; t += (int)gridDim.x) {
+        const int row_beg = cur.row_beg, rows = cur.rows, e_beg = cur.e_beg, e_end = cur.e_end;
+        // (1) this tile's rows -> three bf16 planes; list bounds -> LDS; adjacency cleared
+        if (tid <= rows) ptrL[tid] = cur.pv;
+        for (int i = tid; i < kGtRows * SA / 2; i += kGtThreads) adjW[i] = 0;
+#pragma unroll
+        for (int k = 0; k < PP; ++k) {
+            const int p = tid + k * kGtThreads, r = p / LPR, c4 = p % LPR;
+            const float keep = r < rows ? 1.f : 0.f;                       // (clamped loads: rows past the tile are zero planes)
+            const float v[4] = {cur.xr[k].x * keep, cur.xr[k].y * keep, cur.xr[k].z * keep, cur.xr[k].w * keep};
+            bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hi[i] = (bf16_t)v[i];
+                const float r1 = v[i] - (float)hi[i];
+                mid[i] = (bf16_t)r1;
+                lo[i] = (bf16_t)(r1 - (float)mid[i]);
+            }
+            *reinterpret_cast<bf16x4*>(planes + (0 * kGtRows + r) * SP + c4 * 4) = hi;
+            *reinterpret_cast<bf16x4*>(planes + (1 * kGtRows + r) * SP + c4 * 4) = mid;
+            *reinterpret_cast<bf16x4*>(planes + (2 * kGtRows + r) * SP + c4 * 4) = lo;
+        }
+        request(rec_next, nxt);                                            // in flight until the top of the next iteration
+        rec_next = record(t + 2 * (int)gridDim.x);
+        __syncthreads();
+        // (2) adjacency counts: entry e of the tile's index range feeds row dst(e) (found in the tile's bounds) from row idx[e]
+        auto add_entry = [&](int e, int src_row, int dst_row) {
+            const int s = src_row - row_beg;
+            int d = dst_row - row_beg;
+            if (seg == nullptr) {                                          // destination of entry e: found in the tile's bounds
+                int lo = 0, hi = rows;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ptrL[mid] <= e) lo = mid; else hi = mid;
+                }
+                d = lo;
+            }
+            if (s < 0 || s >= rows || d < 0 || d >= rows) { atomicOr(bad, 1); return; }   // not a run of whole graphs
+            atomicAdd(&adjW[(d * SA + s) >> 1], (s & 1) ? 0x10000u : 1u);
+        };
+#pragma unroll
+        for (int k = 0; k < EP; ++k) {
+            const int e = e_beg + tid + k * kGtThreads;
+            if (e < e_end) add_entry(e, cur.ent[k], cur.sg[k]);
+        }
+        for (int e = e_beg + tid + EP * kGtThreads; e < e_end; e += kGtThreads)                 // (denser tiles)
+            add_entry(e, idx[e], seg != nullptr ? seg[e] : 0);
+        __syncthreads();
+        for (int i = tid; i < kGtRows * SA / 2; i += kGtThreads) {          // counts -> bf16 (exact up to 256)
+            const uint32_t w = adjW[i];
+            adjW[i] = (__float_as_uint((float)(w & 0xffffu)) >> 16) | (__float_as_uint((float)(w >> 16)) & 0xffff0000u);
+        }
+        __syncthreads();
+        // (3) out tile (transposed) = planes^T x Adj^T:  D[col][dst] = sum_src X[src][col] * Adj[dst][src].  A operand = the plane,
+        //     K-strided (transpose read); B operand = Adj row-major (element j of lane l = Adj[dst = l & 15][src = 8 (l >> 4) + j]).
+        //     A lane then holds 4 CONSECUTIVE columns of one destination row: the tile is staged with 16-byte LDS writes.  Per
+        //     32-row K-step every fragment is requested before the first MFMA (Adj fragments serve all three planes).
+        const bf16_t* adj = reinterpret_cast<const bf16_t*>(adjW);
+        const int MT = (rows + 15) >> 4, KS = (rows + 31) >> 5;
+        const int wc = wave % (NCT / NT), m0 = (wave / (NCT / NT)) * MTW;  // my column tiles wc * NT + n, my row tiles m0 + m
+        f32x4 acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[MTW], xf[3][NT];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+                af[m] = *reinterpret_cast<const bf16x8*>(adj + ((m0 + m) * 16 + (lane & 15)) * SA + ks * 32 + 8 * (lane >> 4));
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    xf[tt][n] = tr_frag(planes + (tt * kGtRows + ks * 32) * SP, SP, (wc * NT + n) * 16, lane);
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    if (m0 + m >= MT) break;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[tt][n], af[m], acc[m][n], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                                   // the planes are free: stage the tile for whole-row stores
+        float* outL = reinterpret_cast<float*>(planes);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            if (m0 + m >= MT) break;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)                                   // lane holds D[col = 16(..) + 4(l>>4) + i][dst = 16(m0+m) + (l&15)]
+                *reinterpret_cast<f32x4*>(outL + ((m0 + m) * 16 + (lane & 15)) * SO + (wc * NT + n) * 16 + 4 * (lane >> 4)) = acc[m][n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PP; ++k) {
+            const int p = tid + k * kGtThreads, r = p / LPR, c4 = p % LPR;
+            if (r < rows) {
+                const float4 d = *reinterpret_cast<const float4*>(outL + r * SO + c4 * 4);
+                float4 o;
+                o.x = fmaf(self_coef, cur.xr[k].x, d.x); o.y = fmaf(self_coef, cur.xr[k].y, d.y);
+                o.z = fmaf(self_coef, cur.xr[k].z, d.z); o.w = fmaf(self_coef, cur.xr[k].w, d.w);
+                *reinterpret_cast<float4*>(out + (size_t)(row_beg + r) * H + c4 * 4) = o;
+            }
+        }
+        __syncthreads();                                                   // outL (the planes) is rewritten by the next tile
+        cur = nxt;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dn_graph_tile_sum_f32(const float* x, int64_t num_rows, int32_t H, const int32_t* ptr, const int32_t* idx, const int32_t* seg,
+                          int64_t num_entries, const int32_t* tiles, int64_t num_tiles, float self_coef, float* out, int32_t* bad,
+                          dn_stream_t stream) {
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_graph_tile_sum: H must be 64, 128 or 256");
+    DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL && num_rows >= 0 && num_rows < 0x7fffffffLL && num_entries >= 0 &&
+               num_entries < 0x7fffffffLL, "dn_graph_tile_sum: bad sizes");
+    if (num_tiles == 0 || num_rows == 0) return DN_OK;
+    DN_REQUIRE(x && ptr && (idx || num_entries == 0) && tiles && out && bad, "dn_graph_tile_sum: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    // persistent workgroups: two per CU at H <= 128 (61 KB of LDS each), one at H = 256
+    const int64_t slots = 256 * (H == 256 ? 1 : 2);
+    const unsigned grid = (unsigned)(num_tiles < slots ? num_tiles : slots);
+    if (H == 64) hipLaunchKernelGGL((graph_tile_sum_kernel<64>), dim3(grid), dim3(gt_threads(64)), 0, st, x, ptr, idx, seg, tiles, (int32_t)num_tiles, (int32_t)num_rows, (int32_t)num_entries, self_coef, out, bad);
+    else if (H == 128) hipLaunchKernelGGL((graph_tile_sum_kernel<128>), dim3(grid), dim3(gt_threads(128)), 0, st, x, ptr, idx, seg, tiles, (int32_t)num_tiles, (int32_t)num_rows, (int32_t)num_entries, self_coef, out, bad);
+    else hipLaunchKernelGGL((graph_tile_sum_kernel<256>), dim3(grid), dim3(gt_threads(256)), 0, st, x, ptr, idx, seg, tiles, (int32_t)num_tiles, (int32_t)num_rows, (int32_t)num_entries, self_coef, out, bad);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // extern "C"

@@ -115,6 +115,62 @@ WINDOW_GATHER = _os.environ.get("DN_WINDOW_GATHER", "0") == "1"
 WINDOW_BYTES = 40 * 1024                                # kWinBytes in csrc/dn_segment.hip
 
 
+def graph_tiles(node_ptr, max_rows=64):
+    """Greedy runs of whole graphs with at most max_rows rows each: (tiles [T, 2] int32 on the device, covered rows, rest) where
+    rest = the rows of graphs larger than max_rows as a sorted int64 tensor (they keep the plain gather)."""
+    npt = node_ptr.detach().cpu().tolist()
+    tiles, rest, beg = [], [], None
+    for g in range(len(npt) - 1):
+        a, b = npt[g], npt[g + 1]
+        if b - a > max_rows:
+            if beg is not None:
+                tiles.append((beg, a)); beg = None
+            rest.append((a, b))
+            continue
+        if beg is None:
+            beg = a
+        elif b - beg > max_rows:
+            tiles.append((beg, a)); beg = a
+    if beg is not None:
+        tiles.append((beg, npt[-1]))
+    tiles = [(a, b) for a, b in tiles if b > a]
+    t = torch.tensor(tiles, dtype=I32, device=node_ptr.device).reshape(-1, 2)
+    covered = sum(b - a for a, b in tiles)
+    r = (torch.cat([torch.arange(a, b) for a, b in rest]) if rest else torch.zeros(0, dtype=torch.long)).to(node_ptr.device)
+    return t, covered, r
+
+
+def graph_tile_records(tiles, ptr_):
+    """[T, 4] int32 records {first row, end row, ptr[first row], ptr[end row]} of graph_tiles' row ranges for one CSR."""
+    return torch.cat([tiles, ptr_[tiles.long()].to(I32)], 1).contiguous()
+
+
+def graph_tile_sum(x, idx, ptr_, tiles, self_coef=0.0, out=None, seg=None):
+    """out[v] = self_coef * x[v] + sum of x[idx[i]] over v's list, for the rows of `tiles` only (dn_graph_tile_sum_f32: the tile's
+    adjacency as a dense bf16 matrix, the rows as three bf16 planes, matrix cores).  Rows outside the tiles are left untouched.
+    tiles: graph_tiles' [T, 2] row ranges or graph_tile_records' [T, 4]; seg (optional): the row of every index entry."""
+    require_gpu(x, idx, ptr_, tiles)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (64, 128, 256)
+    assert idx.dtype == I32 and ptr_.dtype == I32 and tiles.dtype == I32 and tiles.is_contiguous()
+    if tiles.shape[1] == 2:
+        tiles = graph_tile_records(tiles, ptr_)
+    assert seg is None or (seg.dtype == I32 and seg.numel() == idx.numel())
+    if out is None:
+        out = torch.empty_like(x)
+    bad = torch.zeros(1, dtype=I32, device=x.device)
+
+    def _launch():
+        check(lib().dn_graph_tile_sum_f32(ptr(x), int(x.shape[0]), int(x.shape[1]), ptr(ptr_), ptr(idx),
+                                          ptr(seg) if seg is not None else None, int(idx.numel()), ptr(tiles),
+                                          int(tiles.shape[0]), float(self_coef), ptr(out), ptr(bad), stream_ptr()),
+              "dn_graph_tile_sum_f32")
+    if kernel_timer is not None:
+        kernel_timer.launch("graph_tile_sum", _launch)
+    else:
+        _launch()
+    return out, bad
+
+
 def window_tiles(node_ptr, num_rows, rows_per_window):
     """Tile boundaries (int32 [T + 1], device) for dn_gather_segsum_window_*: greedy runs of whole graphs that fit a window
     (dn_window_tiles_host: the graph boundaries make one small device -> host copy, the packing is a C loop, the table goes

@@ -192,6 +192,20 @@ int dn_conjugate_build_i32(int32_t mode, int64_t G, int64_t N, int64_t E, int64_
                            int32_t* out_shared_node /*[num_raw]*/, int64_t* host_counts /*[2]*/,
                            void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* Graph-local neighbour sum on the matrix cores, for the rows of the listed tiles only:
+ *   out[v, :] = self_coef * x[v, :] + sum_{i in [ptr[v], ptr[v+1])} x[idx[i], :]
+ * -- GINConv's aggregation (graph_classification/graph_neural_networks/models/gconv.py:197: PyG propagate(aggr="add") plus
+ * (1 + eps) x_i) and, on the transposed index, its input gradient.  tiles [num_tiles][4] = {first row, end row, ptr[first row],
+ * ptr[end row]} of runs of WHOLE graphs with at most 64 rows each; seg (may be NULL) = the row every index entry belongs to
+ * (saves a search in the tile's bounds): every idx of a tile's rows must lie inside the tile (else *bad |= 1 and that entry is
+ * skipped; tiles that leave [0, num_rows) or hold more than 64 rows are flagged the same way and not touched; *bad must be
+ * zeroed by the caller).  x / out have num_rows rows, idx num_entries entries.  A tile's rows are read once, split into three bf16 planes (hi + mid + lo = the
+ * fp32 value to rounding), the tile's adjacency counts form a bf16 matrix in LDS and the sum is a dense product with fp32
+ * accumulation: same value as dn_gather_segsum_f32 up to fp32 summation order.  fp32 rows, H in {64, 128, 256}. */
+int dn_graph_tile_sum_f32(const float* x, int64_t num_rows, int32_t H, const int32_t* ptr, const int32_t* idx,
+                          const int32_t* seg, int64_t num_entries, const int32_t* tiles, int64_t num_tiles,
+                          float self_coef, float* out, int32_t* bad, dn_stream_t stream);
+
 /* Relation-aware segment index for the aggregate-then-transform form of the RGCN/RGIN message pass
  *   sum_e x[src_e] W[etype_e]  ==  sum_r ( sum_{e in r, dst=v} x[src_e] ) W_r      
  * which replaces the reference's per-edge weight gather + bmm (subgraph_isomorphism/models/rgin.py:102-120,
