@@ -106,3 +106,13 @@ def test_local_index_and_async_table_entry_points_check_their_arguments(lib):
     assert rc == -1 and b"bad sizes" in L.dn_last_error()
     rc = L.dn_fold_tables_build_async_i32(10, 2, P16, P16, P16, P16, None, P16, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+
+
+def test_graph_tile_sum_checks_its_arguments(lib):
+    L = lib.lib()
+    P16 = ctypes.c_void_p(16)
+    rc = L.dn_graph_tile_sum_f32(P16, 10, 100, P16, P16, None, 5, P16, 1, 1.0, P16, P16, None)
+    assert rc == -1 and b"H must be 64, 128 or 256" in L.dn_last_error()
+    rc = L.dn_graph_tile_sum_f32(None, 10, 128, P16, P16, None, 5, P16, 1, 1.0, P16, P16, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    assert L.dn_graph_tile_sum_f32(None, 10, 128, None, None, None, 0, None, 0, 1.0, None, None, None) == 0      # no tiles
