@@ -41,6 +41,8 @@ _SIGS = {
     "dn_gather_segmax_bwd_f32": (ctypes.c_int, [P, P, P, P, P, c_i64, c_i32, P, P]),
     "dn_gather_segmax_bwd_bf16": (ctypes.c_int, [P, P, P, P, P, c_i64, c_i32, P, P]),
     "dn_graph_tile_sum_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, P, c_i64, c_f32, P, P, P]),
+    "dn_gather_rows_sum_f32": (ctypes.c_int, [P, c_i32, P, P, P, c_i32, c_i64, c_i32, c_f32, P, P]),
+    "dn_graph_tiles_host": (ctypes.c_int, [P, c_i64, c_i32, P, c_i64, ctypes.POINTER(c_i64)]),
     "dn_csr_build_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dn_csr_build_i32": (ctypes.c_int, [P, c_i64, c_i64, P, P, P, c_sz, P]),
     "dn_dummy_augment_gc_i32": (ctypes.c_int, [c_i64, c_i64, c_i64] + [P] * 16 + [P]),

@@ -220,6 +220,76 @@ __global__ __launch_bounds__(gt_threads(H)) void graph_tile_sum_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same sum for a LIST of rows (the rows of graphs too large for a tile), straight from the full CSR -- no compacted copy of
+// the lists or of x: out[s] = self_coef * x[s] + sum_{i in [ptr[s], ptr[s+1])} x[idx[i]]  for s in rows[0 .. n).
+//   COOP = false: one lane group (H / 4 lanes, 16 bytes per lane) per listed row, 8 row loads in flight.
+//   COOP = true : one workgroup per listed row (the hubs: a dummy node of a 600-node graph has 600 entries): its lane groups
+//                 take the entries round-robin, the partial rows are added in group order through LDS (fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int H, bool COOP, bool RECORDS>
+__global__ __launch_bounds__(256) void gather_rows_sum_kernel(const float* __restrict__ x, const int32_t* __restrict__ ptr,
+                                                              const int32_t* __restrict__ idx, const int32_t* __restrict__ rows,
+                                                              int32_t n, float self_coef, float* __restrict__ out) {
+    constexpr int LPR = H / 4, GPB = 256 / LPR, KU = 8;
+    const int lane = threadIdx.x % LPR, group = threadIdx.x / LPR;
+    __shared__ __attribute__((aligned(16))) float part[COOP ? GPB * H : 4];
+    const int first = COOP ? (int)blockIdx.x : (int)blockIdx.x * GPB + group, step = COOP ? (int)gridDim.x : (int)gridDim.x * GPB;
+    for (int i = first; i < n; i += step) {
+        int s, beg, end;
+        if (RECORDS) {                                                     // {row, first entry, end entry, -}: one load, no ptr round trip
+            const int4 rc = *reinterpret_cast<const int4*>(rows + 4 * (size_t)i);
+            s = rc.x; beg = rc.y; end = rc.z;
+        } else {
+            s = rows[i]; beg = ptr[s]; end = ptr[s + 1];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int e0 = COOP ? beg + group : beg, de = COOP ? GPB : 1;
+        for (int e = e0; e < end; e += KU * de) {
+            float4 v[KU];
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int ee = e + k * de;
+                const int r = idx[min(ee, end - 1)];                       // (clamped: the load is unconditional, masked below)
+                v[k] = *reinterpret_cast<const float4*>(x + (size_t)r * H + lane * 4);
+                if (ee >= end) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < KU; ++k) { acc[0] += v[k].x; acc[1] += v[k].y; acc[2] += v[k].z; acc[3] += v[k].w; }
+        }
+        if (COOP) {
+            *reinterpret_cast<float4*>(part + group * H + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (group == 0) {
+#pragma unroll
+                for (int g = 1; g < GPB; ++g) {
+                    const float4 p = *reinterpret_cast<const float4*>(part + g * H + lane * 4);
+                    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+                }
+            }
+            __syncthreads();
+            if (group != 0) continue;
+        }
+        const float4 xs = *reinterpret_cast<const float4*>(x + (size_t)s * H + lane * 4);
+        *reinterpret_cast<float4*>(out + (size_t)s * H + lane * 4) =
+            make_float4(fmaf(self_coef, xs.x, acc[0]), fmaf(self_coef, xs.y, acc[1]), fmaf(self_coef, xs.z, acc[2]), fmaf(self_coef, xs.w, acc[3]));
+    }
+}
+
+template <int H>
+int launch_rows_sum(const float* x, const int32_t* ptr, const int32_t* idx, const int32_t* rows, int64_t n, int32_t coop, int32_t records,
+                    float self_coef, float* out, hipStream_t st) {
+    constexpr int GPB = 256 / (H / 4);
+    const int64_t blocks = coop ? n : dn_cdiv(n, GPB);
+    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+#define DN_GO(C, R) hipLaunchKernelGGL((gather_rows_sum_kernel<H, C, R>), dim3(grid), dim3(256), 0, st, x, ptr, idx, rows, (int32_t)n, self_coef, out)
+    if (coop) { if (records) DN_GO(true, true); else DN_GO(true, false); }
+    else { if (records) DN_GO(false, true); else DN_GO(false, false); }
+#undef DN_GO
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,6 +310,46 @@ int dn_graph_tile_sum_f32(const float* x, int64_t num_rows, int32_t H, const int
     else if (H == 128) hipLaunchKernelGGL((graph_tile_sum_kernel<128>), dim3(grid), dim3(gt_threads(128)), 0, st, x, ptr, idx, seg, tiles, (int32_t)num_tiles, (int32_t)num_rows, (int32_t)num_entries, self_coef, out, bad);
     else hipLaunchKernelGGL((graph_tile_sum_kernel<256>), dim3(grid), dim3(gt_threads(256)), 0, st, x, ptr, idx, seg, tiles, (int32_t)num_tiles, (int32_t)num_rows, (int32_t)num_entries, self_coef, out, bad);
     DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_gather_rows_sum_f32(const float* x, int32_t H, const int32_t* ptr, const int32_t* idx, const int32_t* rows, int32_t rows_are_records,
+                           int64_t num_listed, int32_t workgroup_per_row, float self_coef, float* out, dn_stream_t stream) {
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_gather_rows_sum: H must be 64, 128 or 256");
+    DN_REQUIRE(num_listed >= 0 && num_listed < 0x7fffffffLL, "dn_gather_rows_sum: bad row count");
+    if (num_listed == 0) return DN_OK;
+    DN_REQUIRE(x && (ptr || rows_are_records) && idx && rows && out, "dn_gather_rows_sum: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 64) return launch_rows_sum<64>(x, ptr, idx, rows, num_listed, workgroup_per_row, rows_are_records, self_coef, out, st);
+    if (H == 128) return launch_rows_sum<128>(x, ptr, idx, rows, num_listed, workgroup_per_row, rows_are_records, self_coef, out, st);
+    return launch_rows_sum<256>(x, ptr, idx, rows, num_listed, workgroup_per_row, rows_are_records, self_coef, out, st);
+}
+
+/* host-side packing (no GPU): greedy runs of WHOLE graphs with at most max_rows rows each; larger graphs are left out */
+int dn_graph_tiles_host(const int32_t* node_ptr, int64_t G, int32_t max_rows, int32_t* tiles, int64_t cap, int64_t* num_tiles) {
+    DN_REQUIRE(G >= 0 && max_rows >= 1 && num_tiles, "dn_graph_tiles_host: bad arguments");
+    DN_REQUIRE(G == 0 || (node_ptr && tiles), "dn_graph_tiles_host: NULL pointer");
+    int64_t T = 0;
+    int32_t beg = -1, end = -1;
+    auto close = [&]() -> bool {
+        if (beg >= 0 && end > beg) {
+            if (T >= cap) return false;
+            tiles[2 * T] = beg; tiles[2 * T + 1] = end; ++T;
+        }
+        beg = -1;
+        return true;
+    };
+    for (int64_t g = 0; g < G; ++g) {
+        const int32_t a = node_ptr[g], b = node_ptr[g + 1];
+        DN_REQUIRE(b >= a, "dn_graph_tiles_host: node_ptr must be non-decreasing");
+        if (b == a) continue;
+        if (b - a > max_rows) { if (!close()) break; continue; }
+        if (beg >= 0 && b - beg > max_rows && !close()) break;
+        if (beg < 0) beg = a;
+        end = b;
+    }
+    if (!close()) { dn_set_error("dn_graph_tiles_host: tile table too small"); return DN_ERR_WORKSPACE; }
+    *num_tiles = T;
     return DN_OK;
 }
 

@@ -145,7 +145,25 @@ def graph_tile_records(tiles, ptr_):
     return torch.cat([tiles, ptr_[tiles.long()].to(I32)], 1).contiguous()
 
 
-def graph_tile_sum(x, idx, ptr_, tiles, self_coef=0.0, out=None, seg=None):
+def gather_rows_sum(x, idx, ptr_, rows, workgroup_per_row, self_coef, out):
+    """out[s] = self_coef * x[s] + sum of x[idx[i]] over s's list, for the listed rows only (dn_gather_rows_sum_f32)."""
+    require_gpu(x, idx, ptr_, rows, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous() and rows.dtype == I32 and rows.is_contiguous()
+    records = rows.dim() == 2                                       # [n, 4] records {row, ptr[row], ptr[row + 1], 0}
+    assert not records or rows.shape[1] == 4
+
+    def _launch():
+        check(lib().dn_gather_rows_sum_f32(ptr(x), int(x.shape[1]), ptr(ptr_), ptr(idx), ptr(rows), 1 if records else 0,
+                                           int(rows.shape[0]), 1 if workgroup_per_row else 0, float(self_coef), ptr(out),
+                                           stream_ptr()), "dn_gather_rows_sum_f32")
+    if kernel_timer is not None:
+        kernel_timer.launch("gather_rows_sum", _launch)
+    else:
+        _launch()
+    return out
+
+
+def graph_tile_sum(x, idx, ptr_, tiles, self_coef=0.0, out=None, seg=None, bad=None):
     """out[v] = self_coef * x[v] + sum of x[idx[i]] over v's list, for the rows of `tiles` only (dn_graph_tile_sum_f32: the tile's
     adjacency as a dense bf16 matrix, the rows as three bf16 planes, matrix cores).  Rows outside the tiles are left untouched.
     tiles: graph_tiles' [T, 2] row ranges or graph_tile_records' [T, 4]; seg (optional): the row of every index entry."""
@@ -157,7 +175,8 @@ def graph_tile_sum(x, idx, ptr_, tiles, self_coef=0.0, out=None, seg=None):
     assert seg is None or (seg.dtype == I32 and seg.numel() == idx.numel())
     if out is None:
         out = torch.empty_like(x)
-    bad = torch.zeros(1, dtype=I32, device=x.device)
+    if bad is None:                                                 # (a caller that launches repeatedly keeps ONE flag: the kernel only ORs)
+        bad = torch.zeros(1, dtype=I32, device=x.device)
 
     def _launch():
         check(lib().dn_graph_tile_sum_f32(ptr(x), int(x.shape[0]), int(x.shape[1]), ptr(ptr_), ptr(idx),
@@ -576,7 +595,7 @@ class EdgeIndex:
         through an LDS window (dn_gather_segsum_window_*) instead of fetching every neighbour row through L2."""
         require_gpu(src, dst)
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
-        self._node_ptr, self._tiles = node_ptr, {}
+        self._node_ptr, self._tiles, self._plan = node_ptr, {}, None
         src, dst = src.to(I32).contiguous(), dst.to(I32).contiguous()
         self.src, self.dst = src, dst
         self.in_ptr, self.in_perm = csr_build(dst, num_nodes)
@@ -596,6 +615,15 @@ class EdgeIndex:
             t = window_tiles(self._node_ptr, self.num_nodes, WINDOW_BYTES // int(row_bytes))
             self._tiles[row_bytes] = t
         return t
+
+    def tile_plan(self):
+        """Plan of the matrix-core neighbour sum (dn_graph_tile_sum_f32) for this batch, or None: tiles = greedy runs of whole
+        graphs with at most 64 rows (packed by dn_window_tiles_host from one small copy of the graph boundaries), the rows of larger
+        graphs as two row lists per direction for dn_gather_rows_sum_f32 (lists of up to 64 entries: a lane group per row; hubs: a
+        workgroup per row).  Built once per batch."""
+        if self._plan is None:
+            self._plan = _build_tile_plan(self) or False
+        return self._plan or None
 
     def max_backward_index(self):
         """(tptr, tslot, seg_of_slot): CSR slots grouped by the row they gather, and each slot's destination."""
@@ -666,6 +694,81 @@ class RelIndex:
 # ----------------------------------------------------------------------------------------------
 # autograd operators
 # ----------------------------------------------------------------------------------------------
+# DN_TILE_SUM=0: graph-local neighbour sums always take the plain gather (dn_gather_segsum_*)
+TILE_SUM_ENABLED = _os.environ.get("DN_TILE_SUM", "1") != "0"
+TILE_SUM_ROWS = 64
+
+
+class _TilePlan:
+    __slots__ = ("dirs", "bad", "checked", "covered")
+
+
+def _build_tile_plan(index):
+    import numpy as np
+    node_ptr = index._node_ptr
+    if node_ptr is None or int(node_ptr.numel()) < 2 or index.num_nodes == 0:
+        return None
+    dev = index.src.device
+    npt = np.ascontiguousarray(node_ptr.detach().cpu().numpy().astype(np.int32))
+    G, N = int(npt.shape[0]) - 1, index.num_nodes
+    if int(npt[0]) != 0 or int(npt[-1]) != N or np.any(np.diff(npt) < 0):
+        return None
+    sizes = np.diff(npt)
+    small = sizes <= TILE_SUM_ROWS
+    if not np.any(small & (sizes > 0)):
+        return None
+    buf = np.empty((max(G, 1), 2), dtype=np.int32)
+    n = ctypes.c_int64(0)
+    check(lib().dn_graph_tiles_host(npt.ctypes.data_as(ctypes.c_void_p), G, TILE_SUM_ROWS, buf.ctypes.data_as(ctypes.c_void_p),
+                                    max(G, 1), ctypes.byref(n)), "dn_graph_tiles_host")
+    tl = buf[:int(n.value)]
+    beg, end = tl[:, 0], tl[:, 1]
+    keep = end > beg
+    tiles = torch.from_numpy(tl.copy()).to(dev)
+    rest = torch.from_numpy(np.flatnonzero(np.repeat(~small, sizes)).astype(np.int32)).to(dev)
+    plan = _TilePlan()
+    plan.bad = torch.zeros(1, dtype=I32, device=dev)
+    plan.checked = False
+    plan.covered = int((end[keep] - beg[keep]).sum())
+    assert plan.covered + int(rest.numel()) == N
+    plan.dirs = {}
+    for d, ptr_, idx in (("f", index.in_ptr, index.src_by_dst), ("b", index.out_ptr, index.dst_by_src)):
+        rec = graph_tile_records(tiles, ptr_)
+        if rest.numel():
+            rl = rest.long()
+            deg = ptr_[rl + 1] - ptr_[rl]
+            recs = torch.stack([rest, ptr_[rl], ptr_[rl + 1], torch.zeros_like(rest)], 1)       # {row, first entry, end entry, 0}
+            short, long_ = recs[deg <= 64].contiguous(), recs[deg > 64].contiguous()
+        else:
+            short = long_ = rest.reshape(0, 4)
+        plan.dirs[d] = (rec, short, long_, ptr_, idx)
+    return plan
+
+
+def _tile_sum_ok(x, index, edge_scale):
+    return (TILE_SUM_ENABLED and edge_scale is None and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] in (64, 128, 256)
+            and x.shape[0] == index.num_nodes and index.tile_plan() is not None)
+
+
+def _tile_neighbor_sum(x, index, direction, self_coef):
+    """self_coef * x[v] + sum over v's list of x rows: tiles of small graphs on the matrix cores, the rows of larger graphs from
+    their row lists.  Same sums as the plain gather up to fp32 summation order (2e-6)."""
+    plan = index.tile_plan()
+    rec, short, long_, ptr_, idx = plan.dirs[direction]
+    out = torch.empty_like(x)
+    graph_tile_sum(x, idx, ptr_, rec, self_coef=self_coef, out=out, bad=plan.bad)
+    if short.numel():
+        gather_rows_sum(x, idx, ptr_, short, False, self_coef, out)
+    if long_.numel():
+        gather_rows_sum(x, idx, ptr_, long_, True, self_coef, out)
+    if not plan.checked:                                            # once per batch: an edge that leaves its tile?
+        if int(plan.bad.item()) != 0:
+            index._plan = False
+            return None
+        plan.checked = True
+    return out
+
+
 class _NeighborSum(torch.autograd.Function):
     """agg[v] = self_coef * x[v] + sum_{e: dst(e)=v} w_e x[src(e)]; backward = same kernel on the CSC."""
 
@@ -679,6 +782,10 @@ class _NeighborSum(torch.autograd.Function):
             sc_out = edge_scale.index_select(0, index.out_perm.long())
         ctx.sc_out = sc_out
         ctx.save_for_backward(x if (edge_scale is not None and ctx.needs_input_grad[3]) else x.new_empty(0))
+        if _tile_sum_ok(x, index, edge_scale):
+            out = _tile_neighbor_sum(x, index, "f", float(self_coef))
+            if out is not None:
+                return out
         return index.fwd.segsum(x, scale=sc_in, self_in=x if self_coef != 0.0 else None, self_coef=self_coef)
 
     @staticmethod
@@ -687,7 +794,9 @@ class _NeighborSum(torch.autograd.Function):
         ix = ctx.index
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = ix.bwd.segsum(g, scale=ctx.sc_out, self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
+            gx = _tile_neighbor_sum(g, ix, "b", ctx.self_coef) if _tile_sum_ok(g, ix, ctx.sc_out) else None
+            if gx is None:
+                gx = ix.bwd.segsum(g, scale=ctx.sc_out, self_in=g if ctx.self_coef != 0.0 else None, self_coef=ctx.self_coef)
         gs = None
         if ctx.needs_input_grad[3]:
             (x,) = ctx.saved_tensors

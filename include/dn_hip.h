@@ -206,6 +206,21 @@ int dn_graph_tile_sum_f32(const float* x, int64_t num_rows, int32_t H, const int
                           const int32_t* seg, int64_t num_entries, const int32_t* tiles, int64_t num_tiles,
                           float self_coef, float* out, int32_t* bad, dn_stream_t stream);
 
+/* The same sum for a LIST of rows, straight from the full CSR (no compacted copy of lists or rows): the companion of
+ * dn_graph_tile_sum_f32 for the rows of graphs too large for a tile.  rows [num_listed]: row ids (rows_are_records = 0) or
+ * 16-byte records {row, ptr[row], ptr[row + 1], 0} (rows_are_records = 1: saves the ptr round trip), each row listed once; any
+ * list length (an empty list gives self_coef * x[s]).  workgroup_per_row = 0: one lane group per
+ * listed row; 1: one workgroup per listed row, its lane groups sharing the list (hubs: hundreds of entries), partial rows added
+ * in fixed order.  Rows not listed are left untouched.  Replaces the same PyG aggregation (gconv.py:197). */
+int dn_gather_rows_sum_f32(const float* x, int32_t H, const int32_t* ptr, const int32_t* idx, const int32_t* rows,
+                           int32_t rows_are_records, int64_t num_listed, int32_t workgroup_per_row, float self_coef,
+                           float* out, dn_stream_t stream);
+
+/* Host-side tile packing for dn_graph_tile_sum_f32 (no GPU): greedy runs of whole graphs with at most max_rows rows each
+ * (node_ptr [G+1] on the HOST); graphs with more rows are left out (their rows go to dn_gather_rows_sum_f32).  tiles receives
+ * {first row, end row} pairs, *num_tiles their number; DN_ERR_WORKSPACE when cap pairs do not suffice (G always do). */
+int dn_graph_tiles_host(const int32_t* node_ptr, int64_t G, int32_t max_rows, int32_t* tiles, int64_t cap, int64_t* num_tiles);
+
 /* Relation-aware segment index for the aggregate-then-transform form of the RGCN/RGIN message pass
  *   sum_e x[src_e] W[etype_e]  ==  sum_r ( sum_{e in r, dst=v} x[src_e] ) W_r      
  * which replaces the reference's per-edge weight gather + bmm (subgraph_isomorphism/models/rgin.py:102-120,

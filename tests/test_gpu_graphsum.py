@@ -58,3 +58,39 @@ def test_graph_tile_sum_flags_a_neighbour_outside_its_tile():
     tiles = torch.tensor([[0, 4], [4, 8]], dtype=torch.int32, device=dev)
     _, bad = ops.graph_tile_sum(x, ei.src_by_dst, ei.in_ptr, tiles)
     assert int(bad.item()) == 1
+
+
+def test_neighbor_sum_takes_the_tile_path_and_matches_the_plain_gather():
+    """ops.neighbor_sum on an index that knows its graph boundaries: tiles for graphs of <= 64 rows, row lists (lane group per row,
+    workgroup per hub) for the rest; forward and backward against the plain path (DN_TILE_SUM off) and fp64."""
+    from dummynode4graphlearning_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    src, dst, nptr = _batch(rng, G=120, nmin=0, nmax=200, deg=2.5)                   # small and large graphs, hubs of up to 199 entries
+    N = int(nptr[-1])
+    ei = ops.EdgeIndex(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), N, node_ptr=torch.from_numpy(nptr).to(dev))
+    plan = ei.tile_plan()
+    assert plan is not None and 0 < plan.covered < N
+    assert all(t[1].numel() > 0 and t[2].numel() > 0 for t in plan.dirs.values())       # both row lists are exercised
+    for H in (64, 128):
+        x = torch.randn(N, H, device=dev, requires_grad=True)
+        go = torch.randn(N, H, device=dev)
+        out = ops.neighbor_sum(x, ei, 1.5)
+        out.backward(go)
+        assert plan.checked and int(plan.bad.item()) == 0
+        x2 = x.detach().clone().requires_grad_(True)
+        try:
+            ops.TILE_SUM_ENABLED = False
+            out2 = ops.neighbor_sum(x2, ei, 1.5)
+            out2.backward(go)
+        finally:
+            ops.TILE_SUM_ENABLED = True
+        xd = x.detach().double()
+        ref = 1.5 * xd
+        ref.index_add_(0, torch.from_numpy(dst).to(dev), xd[torch.from_numpy(src).to(dev)])
+        gref = 1.5 * go.double()
+        gref.index_add_(0, torch.from_numpy(src).to(dev), go.double()[torch.from_numpy(dst).to(dev)])
+        for got, plain, want in ((out, out2, ref), (x.grad, x2.grad, gref)):
+            scale = want.abs().max(dim=1, keepdim=True).values.clamp_min(1e-30)
+            assert ((got.detach().double() - want).abs() / scale).max().item() < 2e-6
+            assert ((plain.detach().double() - want).abs() / scale).max().item() < 2e-6

@@ -495,6 +495,7 @@ def test_neighbor_sum_takes_the_window_path_on_a_batch_with_graph_boundaries():
     go = torch.randn(N, H, device=DEV)
     res = []
     old_flag, ops.WINDOW_GATHER = ops.WINDOW_GATHER, True            # (opt-in path: see ops.WINDOW_GATHER)
+    old_tile, ops.TILE_SUM_ENABLED = ops.TILE_SUM_ENABLED, False     # (the matrix-core tile path would take these batches first)
     for npt in (torch.from_numpy(node_ptr).to(DEV), None):
         ix = ops.EdgeIndex(s, d, N, node_ptr=npt)
         assert (ix.fwd.tiles_of is not None) == (npt is not None)
@@ -510,6 +511,7 @@ def test_neighbor_sum_takes_the_window_path_on_a_batch_with_graph_boundaries():
         assert ("gather_segsum_window" in tags) == (npt is not None), tags
         res.append((out.detach(), xd.grad))
     ops.WINDOW_GATHER = old_flag
+    ops.TILE_SUM_ENABLED = old_tile
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
