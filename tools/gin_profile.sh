@@ -17,14 +17,14 @@ print("# bench line of the stats run:", [l for l in open(out + "/stats.log") if 
 f = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
 print("# kernel stats (gather kernels only): name, calls, average ns")
 for r in csv.DictReader(open(f)):
-    if "gather_segsum" in r["Name"] or "indexFunc" in r["Name"]:
+    if "gather_segsum" in r["Name"] or "indexFunc" in r["Name"] or "graph_tile_sum" in r["Name"] or "gather_rows_sum" in r["Name"]:
         print("%s,%s,%.0f" % (r["Name"][:90].replace(",", ";"), r["Calls"], float(r["AverageNs"])))
 tot = {}
 for ctr, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     f = glob.glob(out + "/" + d + "/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == ctr and "gather_segsum" in r["Kernel_Name"]:
+        if r["Counter_Name"] == ctr and any(k in r["Kernel_Name"] for k in ("gather_segsum", "graph_tile_sum", "gather_rows_sum")):
             k = r["Kernel_Name"][:60]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     tot[ctr] = agg
