@@ -234,8 +234,14 @@ __global__ __launch_bounds__(256) void gather_rows_sum_kernel(const float* __res
     constexpr int LPR = H / 4, GPB = 256 / LPR, KU = 8;
     const int lane = threadIdx.x % LPR, group = threadIdx.x / LPR;
     __shared__ __attribute__((aligned(16))) float part[COOP ? GPB * H : 4];
-    const int first = COOP ? (int)blockIdx.x : (int)blockIdx.x * GPB + group, step = COOP ? (int)gridDim.x : (int)gridDim.x * GPB;
-    for (int i = first; i < n; i += step) {
+    // The listed rows are graph-major: a workgroup takes a CONTIGUOUS chunk of the list and the workgroups of one XCD take
+    // neighbouring chunks (dn_xcd_chunk), so the rows of one large graph -- each other's neighbours -- are gathered through ONE
+    // L2 (dealt round-robin over the chip every XCD fetched them for itself: 3.8x the compulsory reads).
+    const int64_t chunk = dn_xcd_chunk(blockIdx.x, gridDim.x);
+    const int per = (int)(((int64_t)n + gridDim.x - 1) / gridDim.x);
+    const int c_beg = (int)min((int64_t)n, chunk * per), c_end = (int)min((int64_t)n, (chunk + 1) * per);
+    const int first = COOP ? c_beg : c_beg + group, step = COOP ? 1 : GPB;
+    for (int i = first; i < c_end; i += step) {
         int s, beg, end;
         if (RECORDS) {                                                     // {row, first entry, end entry, -}: one load, no ptr round trip
             const int4 rc = *reinterpret_cast<const int4*>(rows + 4 * (size_t)i);
@@ -280,8 +286,10 @@ template <int H>
 int launch_rows_sum(const float* x, const int32_t* ptr, const int32_t* idx, const int32_t* rows, int64_t n, int32_t coop, int32_t records,
                     float self_coef, float* out, hipStream_t st) {
     constexpr int GPB = 256 / (H / 4);
-    const int64_t blocks = coop ? n : dn_cdiv(n, GPB);
-    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    // chunks of ~4 rows per lane group (one row per workgroup for the hubs), a multiple of the XCD count of workgroups
+    int64_t blocks = coop ? n : dn_cdiv(n, (int64_t)GPB * 4);
+    blocks = dn_cdiv(blocks < 16384 ? blocks : 16384, DN_NUM_XCD) * DN_NUM_XCD;
+    const unsigned grid = (unsigned)blocks;
 #define DN_GO(C, R) hipLaunchKernelGGL((gather_rows_sum_kernel<H, C, R>), dim3(grid), dim3(256), 0, st, x, ptr, idx, rows, (int32_t)n, self_coef, out)
     if (coop) { if (records) DN_GO(true, true); else DN_GO(true, false); }
     else { if (records) DN_GO(false, true); else DN_GO(false, false); }
