@@ -67,6 +67,7 @@ def test_neighbor_sum_takes_the_tile_path_and_matches_the_plain_gather():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(5)
     src, dst, nptr = _batch(rng, G=120, nmin=0, nmax=200, deg=2.5)                   # small and large graphs, hubs of up to 199 entries
+    assert int(nptr[-1]) >= ops.TILE_SUM_MIN_ROWS                                     # (smaller batches keep the plain kernel)
     N = int(nptr[-1])
     ei = ops.EdgeIndex(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), N, node_ptr=torch.from_numpy(nptr).to(dev))
     plan = ei.tile_plan()
