@@ -9,7 +9,8 @@
 // O(m^2) comparisons are broadcast LDS reads), and the only batch-wide step is ONE exclusive scan over the packed per-(relation,
 // graph) and per-node counts.  Three kernels + one scan + one read-back.
 //
-//   ril_stats_kernel   per relation: #edges, #distinct destinations, #distinct sources      (-> EDGE / AGG / TF, as before)
+//   ril_stats_kernel   per relation: #edges, #distinct destinations, #distinct sources      (-> EDGE / AGG / TF, as before);
+//                      per edge: is it the first of its (relation, destination) / (relation, source) pair (one byte, reused below)
 //   ril_count_kernel   per (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges;  per node: list lengths
 //   (exclusive scan of the packed counts)
 //   ril_fill_kernel    every table, each entry at  scan offset + rank inside the graph
@@ -70,9 +71,11 @@ __device__ __forceinline__ void for_each_edge(const uint2* X, int jend, F&& body
 // Returns the edge count, or -1 when the graph is not taken (flagged in *bad by the statistics pass).
 __device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t R, const int32_t* node_ptr,
                                           const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
-                                          const int32_t* s_mode, int64_t N, int64_t E, int& n0, int& n1, int32_t* bad) {
+                                          const int32_t* s_mode, const uint8_t* hbits, int64_t N, int64_t E, int& n0, int& n1,
+                                          int& e0, int32_t* bad) {
     n0 = node_ptr[g]; n1 = node_ptr[g + 1];
-    const int e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
+    e0 = edge_ptr[g];
+    const int m = edge_ptr[g + 1] - e0;
     // (ranges that leave [0, N) / [0, E) would index past the caller's arrays: never touch such a graph)
     if (m < 0 || m > kLocM || n1 < n0 || n1 - n0 > kLocNodes || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) {
         if (bad != nullptr && lane == 0) atomicOr(bad, 1);
@@ -87,8 +90,11 @@ __device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t
             const u32 sl = (u32)(s - n0), dl = (u32)(d - n0);
             if (s_mode == nullptr) X[i] = make_uint2(((u32)r << 14) | dl, ((u32)r << 14) | sl);
             else {
-                const u32 md = (u32)s_mode[r];
-                X[i] = make_uint2(((u32)r << 26) | ((md == kTf ? sl : dl) << 10) | (u32)i, (md << 28) | (sl << 14) | dl);
+                // head: first edge, in edge order, of its (relation, key node) pair -- the statistics pass left one byte per edge:
+                // bit 0 = an earlier edge has my (relation, destination), bit 1 = ... my (relation, source)
+                const u32 md = (u32)s_mode[r], hb = hbits[e0 + i];
+                const u32 head = ((md == kTf ? hb >> 1 : hb) & 1u) ^ 1u;
+                X[i] = make_uint2(((u32)r << 26) | ((md == kTf ? sl : dl) << 10) | (u32)i, (head << 30) | (md << 28) | (sl << 14) | dl);
             }
         }
     }
@@ -101,39 +107,8 @@ __device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t
     return m;
 }
 
-// head bit of every edge: first edge, in edge order, of its (relation, key node) pair
 template <int NC>
-__device__ __forceinline__ void flag_heads_pass(uint2* X, int lane, int m, int c0) {
-    u32 kk[NC], dup[NC];
-    int mine[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        mine[c] = (c0 + c) * 64 + lane;
-        kk[c] = mine[c] < m ? X[mine[c]].x >> 10 : 0xffffffffu;
-        dup[c] = 0;
-    }
-    for_each_edge(X, min(m, (c0 + NC) * 64), [&](int j, u32 j0, u32) {   // (only earlier edges matter)
-        const u32 kj = j0 >> 10;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) dup[c] |= (u32)(kk[c] == kj) & (u32)(mine[c] > j);
-    });
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if (mine[c] < m && dup[c] == 0) X[mine[c]].y |= 1u << 30;
-}
-__device__ __forceinline__ void flag_heads(uint2* X, int lane, int m) {
-    for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
-        const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
-        if (nc == 1) flag_heads_pass<1>(X, lane, m, c0);
-        else if (nc == 2) flag_heads_pass<2>(X, lane, m, c0);
-        else flag_heads_pass<kLocCG>(X, lane, m, c0);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int NC>
-__device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int c0, int32_t (*cnt)[kLocR]) {
+__device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int c0, int32_t (*cnt)[kLocR], uint8_t* hb) {
     u32 kd[NC], ks[NC], dd[NC], ds[NC];
     int mine[NC];
 #pragma unroll
@@ -154,6 +129,7 @@ __device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int 
     for (int c = 0; c < NC; ++c)
         if (mine[c] < m) {
             const int r = (int)(kd[c] >> 14);
+            hb[mine[c]] = (uint8_t)(dd[c] | (ds[c] << 1));                  // (read back by the two later passes: no second search)
             atomicAdd(&cnt[0][r], 1);
             if (dd[c] == 0) atomicAdd(&cnt[1][r], 1);
             if (ds[c] == 0) atomicAdd(&cnt[2][r], 1);
@@ -164,7 +140,8 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
                                                                    const int32_t* __restrict__ edge_ptr,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                                    const int32_t* __restrict__ etype, int64_t N, int64_t E,
-                                                                   int32_t* Er, int32_t* Dr, int32_t* Sr, int32_t* bad) {
+                                                                   int32_t* Er, int32_t* Dr, int32_t* Sr, int32_t* bad,
+                                                                   uint8_t* __restrict__ hbits) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t cnt[3][kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,14 +152,14 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         atomicOr(bad, 1);
     __syncthreads();
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, N, E, n0, n1, bad);
+        int n0, n1, e0;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, nullptr, N, E, n0, n1, e0, bad);
         if (m <= 0) continue;
         for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
             const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
-            if (nc == 1) stats_pass<1>(X, lane, m, c0, cnt);
-            else if (nc == 2) stats_pass<2>(X, lane, m, c0, cnt);
-            else stats_pass<kLocCG>(X, lane, m, c0, cnt);
+            if (nc == 1) stats_pass<1>(X, lane, m, c0, cnt, hbits + e0);
+            else if (nc == 2) stats_pass<2>(X, lane, m, c0, cnt, hbits + e0);
+            else stats_pass<kLocCG>(X, lane, m, c0, cnt, hbits + e0);
         }
         __builtin_amdgcn_wave_barrier();                                   // the next graph overwrites this wavefront's slice
     }
@@ -202,7 +179,8 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                                    const int32_t* __restrict__ etype, const int32_t* __restrict__ Er,
                                                                    const int32_t* __restrict__ Dr, const int32_t* __restrict__ Sr,
-                                                                   int32_t* mode_out, int32_t* __restrict__ C) {
+                                                                   const uint8_t* __restrict__ hbits, int32_t* mode_out,
+                                                                   int32_t* __restrict__ C) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,10 +196,9 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
     int32_t* Cb = Cf + (N + 1);
     const int my_mode = s_mode[lane];
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, N, E, n0, n1, nullptr);
+        int n0, n1, e0;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, hbits, N, E, n0, n1, e0, nullptr);
         if (m < 0) continue;                                               // (flagged by the statistics pass: tables are unused)
-        flag_heads(X, lane, m);
         // lane r: edges and heads of relation r (first pass);  lane v (64 nodes per pass): list lengths of node v
         int edges = 0, heads = 0;
         const int n = n1 - n0;
@@ -336,7 +313,8 @@ __device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c
 __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int64_t G, int64_t N, int64_t E, int32_t R, int32_t self_loop, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
-    const int32_t* __restrict__ mode, const int32_t* __restrict__ S, int32_t* __restrict__ row_in, int32_t* __restrict__ row_out,
+    const int32_t* __restrict__ mode, const uint8_t* __restrict__ hbits, const int32_t* __restrict__ S, int32_t* __restrict__ row_in,
+    int32_t* __restrict__ row_out,
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
     int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
     int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr */) {
@@ -366,10 +344,9 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
         if (threadIdx.x <= R) meta[5 + threadIdx.x] = threadIdx.x < R ? (G > 0 ? A.S0[(int64_t)threadIdx.x * G] : 0) : P;
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, N, E, n0, n1, nullptr);
+        int n0, n1, e0;
+        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, hbits, N, E, n0, n1, e0, nullptr);
         if (m < 0) continue;
-        flag_heads(X, lane, m);
         for (int v = n0 + lane; v < n1; v += 64) {
             const int32_t pf = A.Sf[v] - A.bf, pb = A.Sb[v] - A.bb;
             dst_ptr[v] = pf;
@@ -392,12 +369,13 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
 
 struct LocWs {
     int32_t *Er, *Dr, *Sr, *mode, *bad, *meta, *C, *S;
+    uint8_t* hbits;
     void* scan_tmp;
     size_t scan_tmp_bytes, zero_bytes;
     int64_t L;
 };
 
-int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_t N, int64_t R) {
+int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_t N, int64_t R, int64_t E) {
     size_t off = 0;
     auto take = [&](size_t bytes) -> char* {
         off = dn_align_up(off, 256);
@@ -413,6 +391,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.zero_bytes = base ? (size_t)((char*)(w.C + w.L) - z0) : 0;
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
+    w.hbits = (uint8_t*)take((size_t)E);
     w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + kLocR + 1));
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
@@ -435,7 +414,7 @@ size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64
     if (kSeg * R * G + 2 * (N + 1) + 1 >= 0x7fffffffLL) { dn_set_error("dn_row_index_local_workspace_bytes: too large"); return 0; }
     LocWs w;
     size_t need = 0;
-    if (loc_layout(nullptr, 0, need, w, G, N, R) != DN_OK) return 0;
+    if (loc_layout(nullptr, 0, need, w, G, N, R, E) != DN_OK) return 0;
     return need;
 }
 
@@ -455,19 +434,19 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
     hipStream_t st = (hipStream_t)stream;
     LocWs w;
     size_t need = 0;
-    int rc = loc_layout((char*)workspace, workspace_bytes, need, w, G, N, R);
+    int rc = loc_layout((char*)workspace, workspace_bytes, need, w, G, N, R, E);
     if (rc != DN_OK) return rc;
     if (need > workspace_bytes) { dn_set_error("dn_row_index_build_local: workspace too small (%zu < %zu)", workspace_bytes, need); return DN_ERR_WORKSPACE; }
     DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, w.zero_bytes, st));
     const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
     hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
-                       N, E, w.Er, w.Dr, w.Sr, w.bad);
+                       N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits);
     hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, edge_frac, self_loop, node_ptr,
-                       edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.mode, w.C);
+                       edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.hbits, w.mode, w.C);
     DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
                                          rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
-                       dst, etype, w.mode, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
+                       dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
                        src_ptr, src_rows, w.meta);
     DN_CHECK_LAUNCH();
     int32_t h_meta[5 + kLocR + 1], h_mode[kLocR], h_bad = 0;
