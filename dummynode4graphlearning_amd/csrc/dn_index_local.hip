@@ -181,10 +181,15 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
                                                                    const int32_t* __restrict__ Dr, const int32_t* __restrict__ Sr,
                                                                    const uint8_t* __restrict__ hbits, int32_t* mode_out,
                                                                    int32_t* __restrict__ C) {
-    __shared__ __attribute__((aligned(16))) LocLds L;
+    // No pair work here: with the head bytes of the statistics pass every count is a sum over the graph's edges, taken with LDS
+    // atomics -- per node one word {forward list entries | backward list entries << 16}, per relation {edges, heads}.  Node
+    // counters cover kLocCnt nodes at a time (a larger graph walks its edges once per window).
+    constexpr int kLocCnt = 1024;
+    __shared__ uint32_t s_cnt[kLocWaves][kLocCnt];
+    __shared__ uint32_t s_rel[kLocWaves][2][kLocR];
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2* X = L.e[wave];
+    uint32_t* cnt = s_cnt[wave];
     if (threadIdx.x < kLocR) {
         const int md = threadIdx.x < R ? mode_of(Er[threadIdx.x], Dr[threadIdx.x], Sr[threadIdx.x], edge_frac) : kEdge;
         s_mode[threadIdx.x] = md;
@@ -196,30 +201,36 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
     int32_t* Cb = Cf + (N + 1);
     const int my_mode = s_mode[lane];
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1, e0;
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, hbits, N, E, n0, n1, e0, nullptr);
-        if (m < 0) continue;                                               // (flagged by the statistics pass: tables are unused)
-        // lane r: edges and heads of relation r (first pass);  lane v (64 nodes per pass): list lengths of node v
-        int edges = 0, heads = 0;
-        const int n = n1 - n0;
-        for (int v0 = 0; v0 < max(n, 1); v0 += 64) {
-            const u32 v = (u32)(v0 + lane);
-            const int first = v0 == 0 ? 1 : 0;
-            int f = self_loop ? 1 : 0, b = f;
-            for_each_edge(X, m, [&](int, u32 w0, u32 w1) {
-                const u32 rj = w0 >> 26, mdj = (w1 >> 28) & 3u, sj = (w1 >> 14) & 0x3fffu, dj = w1 & 0x3fffu;
-                const int hdj = (int)((w1 >> 30) & 1u), real = mdj != 3u ? first : 0;
-                const int wf = mdj == kAgg ? hdj : (mdj != 3u ? 1 : 0);    // a per-edge entry, or the one entry of an AGG row
-                const int wb = mdj == kTf ? hdj : (mdj != 3u ? 1 : 0);
-                const bool mine = (u32)lane == rj;
-                edges += mine ? real : 0;
-                heads += mine ? (real & hdj) : 0;
-                f += (v == dj) ? wf : 0;
-                b += (v == sj) ? wb : 0;
-            });
-            if ((int)v < n) { Cf[n0 + v] = f; Cb[n0 + v] = b; }
+        const int n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0, n = n1 - n0;
+        if (m < 0 || m > kLocM || n < 0 || n > kLocNodes || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) continue;   // (flagged)
+        s_rel[wave][0][lane] = 0; s_rel[wave][1][lane] = 0;
+        for (int v0 = 0; v0 < max(n, 1); v0 += kLocCnt) {
+            for (int i = lane; i < kLocCnt; i += 64) cnt[i] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < m; i += 64) {
+                const int r = etype[e0 + i], sl = src[e0 + i] - n0, dl = dst[e0 + i] - n0;
+                if (r < 0 || r >= R || sl < 0 || sl >= n || dl < 0 || dl >= n) continue;     // (flagged by the statistics pass)
+                const u32 md = (u32)s_mode[r], hb = hbits[e0 + i];
+                const u32 head = ((md == kTf ? hb >> 1 : hb) & 1u) ^ 1u;
+                if (v0 == 0) {
+                    atomicAdd(&s_rel[wave][0][r], 1u);
+                    if (head) atomicAdd(&s_rel[wave][1][r], 1u);
+                }
+                const u32 wf = md == kAgg ? head : 1u, wb = md == kTf ? head : 1u;            // a per-edge entry, or a collapsed row's one
+                if (wf && dl >= v0 && dl < v0 + kLocCnt) atomicAdd(&cnt[dl - v0], 1u);
+                if (wb && sl >= v0 && sl < v0 + kLocCnt) atomicAdd(&cnt[sl - v0], 1u << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int selfs = self_loop ? 1 : 0;
+            for (int v = v0 + lane; v < min(n, v0 + kLocCnt); v += 64) {
+                const u32 c = cnt[v - v0];
+                Cf[n0 + v] = selfs + (int)(c & 0xffffu);
+                Cb[n0 + v] = selfs + (int)(c >> 16);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane < R) {
+            const int edges = (int)s_rel[wave][0][lane], heads = (int)s_rel[wave][1][lane];
             const int64_t at = (int64_t)lane * G + g;
             C[at] = my_mode == kEdge ? edges : heads;
             C[RG + at] = my_mode == kAgg ? heads : 0;
