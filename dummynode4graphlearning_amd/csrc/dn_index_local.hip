@@ -136,6 +136,67 @@ __device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int 
         }
 }
 
+// The statistics of a graph with at most kHashM edges WITHOUT pair work: both keys of every edge -- (relation, destination) and
+// (relation, source) -- go into one open-addressing hash table in this wavefront's LDS slice (LDS compare-and-swap claims a slot
+// for a key, LDS min keeps the lowest edge number per key); an edge is the first of its pair exactly when its own number came out.
+constexpr int kHashM = 256;          // 2 keys x 256 edges in kHashSlots slots: load factor <= 0.5
+constexpr int kHashSlots = 1024;     // key words [0, 1024) and minimum words [1024, 2048): 8 KB of the 8.2 KB slice
+__device__ __forceinline__ void stats_hashed(u32* tab, int lane, int64_t g, int32_t R, const int32_t* node_ptr, const int32_t* edge_ptr,
+                                             const int32_t* src, const int32_t* dst, const int32_t* etype, int64_t N, int64_t E,
+                                             int32_t (*cnt)[kLocR], uint8_t* hbits, int32_t* bad) {
+    const int n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
+    if (m < 0 || n1 < n0 || n1 - n0 > kLocNodes || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) {
+        if (lane == 0) atomicOr(bad, 1);
+        return;
+    }
+    if (m == 0) return;
+    u32* keys = tab;
+    u32* mins = tab + kHashSlots;
+    for (int i = lane; i < kHashSlots; i += 64) { keys[i] = 0xffffffffu; mins[i] = 0xffffffffu; }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int KE = kHashM / 64;
+    int slot_d[KE], slot_s[KE], rel[KE];
+    bool oob = false;
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+        const int i = lane + 64 * k;
+        slot_d[k] = slot_s[k] = -1; rel[k] = 0;
+        if (i >= m) continue;
+        const int r = etype[e0 + i], s = src[e0 + i], d = dst[e0 + i];
+        if ((s < n0) | (s >= n1) | (d < n0) | (d >= n1) | (r < 0) | (r >= R)) { oob = true; continue; }
+        rel[k] = r;
+        const u32 key2[2] = {((u32)r << 14) | (u32)(d - n0), (1u << 31) | ((u32)r << 14) | (u32)(s - n0)};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32 h = (key2[q] * 2654435761u) >> 22;                         // 10 bits
+            for (;;) {
+                const u32 old = atomicCAS(&keys[h], 0xffffffffu, key2[q]);
+                if (old == 0xffffffffu || old == key2[q]) break;
+                h = (h + 1) & (kHashSlots - 1);
+            }
+            atomicMin(&mins[h], (u32)i);
+            if (q == 0) slot_d[k] = (int)h; else slot_s[k] = (int)h;
+        }
+    }
+    if (__any(oob)) {                                                      // (the graph is not taken: the tables stay unused)
+        if (lane == 0) atomicOr(bad, 1);
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+        const int i = lane + 64 * k;
+        if (i >= m) continue;
+        const u32 dd = mins[slot_d[k]] != (u32)i ? 1u : 0u, ds = mins[slot_s[k]] != (u32)i ? 1u : 0u;
+        hbits[e0 + i] = (uint8_t)(dd | (ds << 1));
+        atomicAdd(&cnt[0][rel[k]], 1);
+        if (dd == 0) atomicAdd(&cnt[1][rel[k]], 1);
+        if (ds == 0) atomicAdd(&cnt[2][rel[k]], 1);
+    }
+    __builtin_amdgcn_wave_barrier();                                       // the next graph re-initialises the table
+}
+
 __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, int32_t R, const int32_t* __restrict__ node_ptr,
                                                                    const int32_t* __restrict__ edge_ptr,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
@@ -153,6 +214,10 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
     __syncthreads();
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1, e0;
+        if (edge_ptr[g + 1] - edge_ptr[g] <= kHashM) {                     // up to 256 edges: first occurrences through a hash table
+            stats_hashed(reinterpret_cast<u32*>(X), lane, g, R, node_ptr, edge_ptr, src, dst, etype, N, E, cnt, hbits, bad);
+            continue;
+        }
         const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, nullptr, N, E, n0, n1, e0, bad);
         if (m <= 0) continue;
         for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {

@@ -172,3 +172,20 @@ def test_pyg_style_batches_reach_the_local_builder():
     ix_p = G.row_index_of(mk(src[perm], dst[perm]), etype_p, 4, True).parts[0][2]
     assert ix_p.built_by == "general"
     assert ix.num_rows == ix_p.num_rows and ix.modes == ix_p.modes       # (same multiset of rows; the order follows the edge ids)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_local_builder_graphs_of_several_hundred_edges(seed):
+    """graphs with 257 .. 1024 edges take the pair-loop statistics (the hash table serves up to 256) and several 64-edge chunks per
+    lane in the fill pass; mixed with small graphs in one batch"""
+    rng = np.random.default_rng(40 + seed)
+    parts = [_random_batch(rng, G=6, R=7, nmin=60, nmax=150, dens=float(rng.uniform(2.5, 4.5)), dummy=bool(seed % 2)),
+             _random_batch(rng, G=20, R=7, nmin=0, nmax=20, dens=2.0, dummy=True)]
+    src, dst, et, nptr, eptr = parts[0]
+    s2, d2, e2, n2, p2 = parts[1]
+    src = np.concatenate([src, s2 + nptr[-1]]); dst = np.concatenate([dst, d2 + nptr[-1]]); et = np.concatenate([et, e2])
+    eptr = np.concatenate([eptr, p2[1:] + eptr[-1]]); nptr = np.concatenate([nptr, n2[1:] + nptr[-1]])
+    sizes = np.diff(eptr)
+    assert sizes.max() > 256 and sizes.max() <= 1024, sizes.max()
+    a, b = _build(src, dst, et, int(nptr[-1]), 7, True, nptr, eptr)
+    _same(a, b)
