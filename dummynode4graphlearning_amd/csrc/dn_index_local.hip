@@ -5,15 +5,19 @@
 // The general builder orders the whole batch with three device-wide radix sorts, eleven scans and ~60 launches (1.4 ms for
 // the 4 M edges of BASELINE config 5, a step's worth for small batches where every launch is latency).  In a batch of graphs
 // every ordering it establishes is LOCAL: the stable sort by (relation, node) is graph-major inside a relation, because node
-// ids ascend with the graph.  So here one wavefront takes one graph into LDS and RANK-sorts it (a few hundred edges: the
-// O(m^2) comparisons are broadcast LDS reads), and the only batch-wide step is ONE exclusive scan over the packed per-(relation,
-// graph) and per-node counts.  Three kernels + one scan + one read-back.
+// ids ascend with the graph.  So here one wavefront takes one graph, and the only batch-wide step is ONE exclusive scan over the
+// packed per-(relation, graph) and per-node counts.  Three kernels + one scan + one read-back.
 //
 //   ril_stats_kernel   per relation: #edges, #distinct destinations, #distinct sources      (-> EDGE / AGG / TF, as before);
-//                      per edge: is it the first of its (relation, destination) / (relation, source) pair (one byte, reused below)
-//   ril_count_kernel   per (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges;  per node: list lengths
+//                      per edge: is it the first of its (relation, destination) / (relation, source) pair (one byte, reused below).
+//                      First occurrences come from an open-addressing hash table in LDS (compare-and-swap claims a slot per key,
+//                      min keeps the lowest edge number); graphs over 256 edges compare all pairs instead.
+//   ril_count_kernel   per (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges;  per node: list lengths -- sums over
+//                      the edges, taken with LDS atomics (no comparisons)
 //   (exclusive scan of the packed counts)
-//   ril_fill_kernel    every table, each entry at  scan offset + rank inside the graph
+//   ril_fill_kernel    every table, each entry at  scan offset + rank inside the graph.  The ranks are counts of edges that
+//                      compare lower in the (relation, key node, edge) order, taken by all lanes at once against ONE edge whose
+//                      packed words are wave-uniform (broadcast LDS read -> SGPRs): O(m^2) compares, no branch on the common path
 //
 // Graphs with more than kLocM edges or kLocNodes nodes, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
 // instead (host_status = 1): the caller then runs the general builder.
