@@ -201,7 +201,9 @@ int dn_conjugate_build_i32(int32_t mode, int64_t G, int64_t N, int64_t E, int64_
  * skipped; tiles that leave [0, num_rows) or hold more than 64 rows are flagged the same way and not touched; *bad must be
  * zeroed by the caller).  x / out have num_rows rows, idx num_entries entries.  A tile's rows are read once, split into three bf16 planes (hi + mid + lo = the
  * fp32 value to rounding), the tile's adjacency counts form a bf16 matrix in LDS and the sum is a dense product with fp32
- * accumulation: same value as dn_gather_segsum_f32 up to fp32 summation order.  fp32 rows, H in {64, 128, 256}. */
+ * accumulation: same value as dn_gather_segsum_f32 up to fp32 summation order for FINITE inputs; a non-finite element turns its
+ * column of the whole tile into NaN (0 x Inf in the dense product, Inf - Inf in the split), where the gather would pass it to its
+ * neighbours only.  fp32 rows, H in {64, 128, 256}. */
 int dn_graph_tile_sum_f32(const float* x, int64_t num_rows, int32_t H, const int32_t* ptr, const int32_t* idx,
                           const int32_t* seg, int64_t num_entries, const int32_t* tiles, int64_t num_tiles,
                           float self_coef, float* out, int32_t* bad, dn_stream_t stream);
