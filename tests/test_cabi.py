@@ -116,3 +116,40 @@ def test_graph_tile_sum_checks_its_arguments(lib):
     rc = L.dn_graph_tile_sum_f32(None, 10, 128, P16, P16, None, 5, P16, 1, 1.0, P16, P16, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     assert L.dn_graph_tile_sum_f32(None, 10, 128, None, None, None, 0, None, 0, 1.0, None, None, None) == 0      # no tiles
+
+
+def test_graph_tiles_host_packs_whole_graphs(lib):
+    """dn_graph_tiles_host is host code (no GPU): greedy runs of whole graphs with at most max_rows rows, larger graphs left out"""
+    import numpy as np
+    L = lib.lib()
+
+    def pack(sizes, max_rows):
+        npt = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        G = len(sizes)
+        buf = np.empty((max(G, 1), 2), dtype=np.int32)
+        n = ctypes.c_int64(0)
+        assert L.dn_graph_tiles_host(npt.ctypes.data_as(ctypes.c_void_p), G, max_rows, buf.ctypes.data_as(ctypes.c_void_p), max(G, 1),
+                                     ctypes.byref(n)) == 0
+        return npt, buf[:n.value].copy()
+
+    npt, t = pack([3, 0, 7, 100, 5, 55, 1, 65], 64)
+    assert t.tolist() == [[0, 10], [110, 171]]
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        sizes = rng.integers(0, 150, size=int(rng.integers(0, 60)))
+        mr = int(rng.integers(1, 130))
+        npt, t = pack(sizes, mr)
+        small = (sizes <= mr) & (sizes > 0)
+        covered = np.zeros(int(npt[-1]) + 1, dtype=bool)
+        for a, b in t:
+            assert 0 < b - a <= mr and a in npt and b in npt                 # whole graphs, within the limit
+            assert not covered[a:b].any()
+            covered[a:b] = True
+        want = np.repeat(small, sizes)                                        # exactly the rows of the small graphs
+        assert np.array_equal(covered[:int(npt[-1])], want)
+        assert all(t[i][1] <= t[i + 1][0] for i in range(len(t) - 1))         # ascending, disjoint
+    # greedy: two consecutive tiles cannot be merged unless a large or ... graph sits between them or the sum exceeds the limit
+    npt, t = pack([10, 10, 10, 10], 25)
+    assert t.tolist() == [[0, 20], [20, 40]]
+    rc = L.dn_graph_tiles_host(None, 3, 64, None, 3, ctypes.byref(ctypes.c_int64(0)))
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
