@@ -205,3 +205,31 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=dict(env, RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_bucket_pack_after_set_to_none_gathers_the_steps_gradients():
+    """zero(set_to_none=True) -- optimizer.zero_grad()'s default -- then backward WRITES fresh gradient tensors; pack() gathers them
+    into the flat buffers in one multi-tensor copy and re-aliases .grad (mixed dtypes, an unused parameter); no process group."""
+    from dummynode4graphlearning_amd.parallel import FlatGradBucket
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(4, 3))
+    b = torch.nn.Parameter(torch.randn(5))
+    c = torch.nn.Parameter(torch.randn(2, 2, dtype=torch.float64))
+    unused = torch.nn.Parameter(torch.randn(3))
+    bucket = FlatGradBucket([a, b, c, unused])
+    for step in range(3):
+        bucket.zero(set_to_none=True)
+        assert all(p.grad is None for p in (a, b, c, unused))
+        x = torch.randn(3)
+        loss = (a @ x).sum() * (step + 1) + (b ** 2).sum() + (c.double() ** 3).sum()
+        loss.backward()
+        want = {id(p): p.grad.detach().clone() for p in (a, b, c)}
+        assert a.grad.data_ptr() != bucket.buckets()[0].data_ptr()              # fresh tensors, not views of the bucket
+        bucket.pack()
+        f32, f64 = bucket.buckets()
+        assert torch.equal(f32[:12].view(4, 3), want[id(a)]) and torch.equal(f32[12:17], want[id(b)])
+        assert torch.equal(f32[17:20], torch.zeros(3))                           # the unused parameter contributes zeros
+        assert torch.equal(f64.view(2, 2), want[id(c)])
+        assert a.grad.data_ptr() == f32.data_ptr() and unused.grad is not None  # .grad aliases the bucket again
+        bucket.all_reduce()                                                      # (a world of one: identity)
+        assert torch.equal(f32[:12].view(4, 3), want[id(a)])
