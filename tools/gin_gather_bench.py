@@ -23,4 +23,7 @@ for _ in range(20): g.replay()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 comp = 2.0 * (2 * N2 * H2 * 4 + 8.0 * E2)
-print("GIN gather fwd+bwd %.3f ms  compulsory %.2f GB -> %.0f GB/s = %.3f of 8 TB/s; hubs split: %s" % (ms, comp / 1e9, comp / ms / 1e6, comp / ms / 1e6 / 8000, ei.fwd.hub_ids is not None))
+plan = ei.tile_plan() if ops.TILE_SUM_ENABLED else None
+path = ("matrix-core tiles for %d of %d rows + row lists" % (plan.covered, ei.num_nodes)) if plan is not None else \
+       ("plain gather, hubs split: %s" % (ei.fwd.hub_ids is not None))
+print("GIN gather fwd+bwd %.3f ms  compulsory %.2f GB -> %.0f GB/s = %.3f of 8 TB/s; %s" % (ms, comp / 1e9, comp / ms / 1e6, comp / ms / 1e6 / 8000, path))
