@@ -1127,6 +1127,7 @@ class RowIndex:
         self.rel_ptr_host = rel_ptr
         # tile / chunk tables on the device (the 18 relation offsets go up in one small copy; no host loops)
         rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
+        self.rel_ptr_dev = rel_ptr_d                                # (reused by the fold tables: one upload per batch)
         self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
         self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
         self._slots, self._fold = {}, {}
@@ -1191,8 +1192,7 @@ def _closing_tables(ix):
             info.fold_info, info.part_ptr = fold_info, part_ptr
             info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
             #                                                    starts one partial row, every tile boundary inside one another
-            rel_ptr_d = torch.tensor(ix.rel_ptr_host, dtype=I32).to(dev, non_blocking=True)
-            info.main_tiles = build_row_tables(rel_ptr_d, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+            info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
             info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
         ix._fold[direction] = info
         n_ovf, n_rows = h[2 + 2 * k], h[3 + 2 * k]
