@@ -218,7 +218,8 @@ __global__ __launch_bounds__(gt_threads(H)) void graph_tile_sum_kernel(const flo
                 float4 o;
                 o.x = fmaf(self_coef, cur.xr[k].x, d.x); o.y = fmaf(self_coef, cur.xr[k].y, d.y);
                 o.z = fmaf(self_coef, cur.xr[k].z, d.z); o.w = fmaf(self_coef, cur.xr[k].w, d.w);
-                *reinterpret_cast<float4*>(out + (size_t)(row_beg + r) * H + c4 * 4) = o;
+                typedef float f32x4v __attribute__((ext_vector_type(4)));   // streaming store (the tile's rows are done: -6 % launch time)
+                __builtin_nontemporal_store(f32x4v{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4v*>(out + (size_t)(row_beg + r) * H + c4 * 4));
             }
         }
         __syncthreads();                                                   // outL (the planes) is rewritten by the next tile
@@ -283,8 +284,10 @@ __global__ __launch_bounds__(256) void gather_rows_sum_kernel(const float* __res
             if (group != 0) continue;
         }
         const float4 xs = *reinterpret_cast<const float4*>(x + (size_t)s * H + lane * 4);
-        *reinterpret_cast<float4*>(out + (size_t)s * H + lane * 4) =
-            make_float4(fmaf(self_coef, xs.x, acc[0]), fmaf(self_coef, xs.y, acc[1]), fmaf(self_coef, xs.z, acc[2]), fmaf(self_coef, xs.w, acc[3]));
+        typedef float f32x4v __attribute__((ext_vector_type(4)));           // streaming store: the row is re-read by a later launch only
+        __builtin_nontemporal_store(f32x4v{fmaf(self_coef, xs.x, acc[0]), fmaf(self_coef, xs.y, acc[1]), fmaf(self_coef, xs.z, acc[2]),
+                                           fmaf(self_coef, xs.w, acc[3])},
+                                    reinterpret_cast<f32x4v*>(out + (size_t)s * H + lane * 4));
     }
 }
 
