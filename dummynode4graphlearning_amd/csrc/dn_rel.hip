@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "dn_common.h"
+#include "dn_internal.h"
 #include "../../include/dn_hip.h"
 
 namespace {
@@ -488,6 +489,8 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
     const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const bf16_t* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
     const bool nt_store = (relu & 2) != 0;          // bit 1: streaming (non-temporal) stores of Y
+    const bool sc1_store = (relu & 4) != 0;         // bit 2: sc1 stores (the written line does not stay in the XCD's L2)
+    const bool abl_nostore = (relu & 8) != 0, abl_hit = (relu & 16) != 0;   // tuning build only: ablations
     relu &= 1;
     constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
     constexpr int SY = HO + kPad;                   // ... of the output tile
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
             const int p = tl.beg + r;
             nidx[j] = -1;
             if (piece < NPX && p < tl.end) nidx[j] = idx ? idx[p] : p;
+            if (abl_hit && nidx[j] >= 0) nidx[j] &= 1023;
         }
     };
     auto load_rows = [&](uint4 (&r)[PX]) {
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
         for (int j = 0; j < PY; ++j) {
             const int piece = tid + j * kTfThreads, r = piece / (HO / 8), c = piece % (HO / 8);
             const int p = tl.beg + r;
-            if (piece < NPY && p < tl.end) {
+            if (piece < NPY && p < tl.end && !(abl_nostore && p != 0)) {
                 uint4 v = *reinterpret_cast<const uint4*>(bufY + r * SY + c * 8);
                 if (mask_pos) {                                  // ReLU backward: keep where the saved activation is > 0
                     const uint4 mk = *reinterpret_cast<const uint4*>(mask_pos + (size_t)p * HO + c * 8);
@@ -648,7 +652,12 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
-                if (nt_store) {
+                if (sc1_store) {
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 vv = {v.x, v.y, v.z, v.w};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(Y + (size_t)p * HO + c * 8), "v"(vv) : "memory");
+                }
+                else if (nt_store) {
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 vv = {v.x, v.y, v.z, v.w};
                     __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(Y + (size_t)p * HO + c * 8));
@@ -1062,7 +1071,9 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     // streaming (non-temporal) stores of the output rows: they are re-read only after ~1 GB of other traffic, so keeping
     // them out of L2 / Infinity Cache is worth 1.5-2 % of the step (DN_NT=0 turns it off: bit 0 transform, bit 1 selfsum)
     static const int nt = dn_knob("DN_NT", 3);
-    relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0);
+    relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0) | ((nt & 4) ? 4 : 0);
+    static const int abl = dn_knob("DN_TF_ABL", 0);
+    relu |= (abl & 3) << 3;
     // workgroups per CU: a tile is 32 rows x 2*HI bytes, so narrower rows need more workgroups in flight to keep the same
     // bytes per CU outstanding (H = 128: 64 VGPRs, 26 KB LDS -> 4 fit; measured 2.24 -> 2.07 ms per step at H = 128)
     const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? (HI <= 128 ? 4 : 2) : 1);
@@ -1352,6 +1363,10 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     const bf16_t *x = (const bf16_t*)X, *x2 = (const bf16_t*)X2, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias;
     const bf16_t* mk = (const bf16_t*)mask_pos;
     DN_REQUIRE(reinterpret_cast<uintptr_t>(mk) % 16 == 0, "dn_rows_transform: unaligned mask");
+    static const int ring = dn_knob("DN_TF_RING", 1);
+    static const int nt_knob = dn_knob("DN_NT", 3);
+    if (Hi == 256 && ring)
+        return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, st);
     if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
