@@ -10,10 +10,15 @@
 
 Workload (config.workload): BASELINE.json configs[4] = SURVEY.md 8(d) config 5, the one the metric is quoted on
 (fits one GPU): synthetic SI-style batch of 32 768 graphs x (30+1) nodes, 62 real + 60 dummy edges, R = 16
-=> N = 1 015 808, E = 3 997 696 per GPU; RGINLayer(256, 256, basis, full) in bf16 storage / fp32 accumulate.
-Weak scaling: every rank processes its own batch of that size (seed 5 + rank); the only collective is the flat
-gradient all-reduce (RCCL).  A step = layer forward + backward (dx and all parameter gradients) + all-reduce,
-inputs resident in HBM; the one-shot index build of the batch is outside the timed region and reported separately.
+=> N = 1 015 808, E = 3 997 696; RGINLayer(256, 256, basis, full) in bf16 storage / fp32 accumulate.
+STRONG scaling (default, what SURVEY 8(d)/8(e) define for config 5): the ONE global batch (seed 5, identical on every
+rank) is cut into contiguous graph ranges by parallel.shard_graphs -- 4 096 graphs per GPU at N = 8 -- every rank builds
+its own index and runs its shard with no data-path collective; the only collective is the flat gradient all-reduce (RCCL).
+value = global E / max-over-ranks step time.  `--scaling weak` keeps round 2's form (every rank its own full batch, seed 5 +
+rank).  A step = layer forward + backward (dx and all parameter gradients) + all-reduce, inputs resident in HBM; the
+one-shot index build of the batch is outside the timed region and reported separately.  At N = 1 the line also carries
+config.strong_scaling_proxy: the step and the fresh-batch index build of ONE eighth of the batch on this GPU and the
+efficiency t(batch) / (8 t(eighth)) an 8-GPU run could reach before the all-reduce.
 
 Rank 0 prints ONE JSON line with `roofline` (gather/segment-sum kernel, HIP events on the launch stream) and
 `cpu_baseline` (oracle port timed on the host cores, bounded sample).
@@ -34,9 +39,29 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def build_batch(dev, seed, graphs, workload):
+def shard_of(raw, rank, world):
+    """Rank `rank`'s contiguous graph range of the global batch `raw` (parallel.shard_graphs on the sizes AFTER the dummy
+    augmentation: n + 1 nodes, m + 2 n edges per graph), as a batch of its own (ids relative to the shard)."""
+    from dummynode4graphlearning_amd.parallel import shard_graphs
+    bnn = raw["node_ptr"][1:] - raw["node_ptr"][:-1]
+    bne = raw["edge_ptr"][1:] - raw["edge_ptr"][:-1]
+    g0, g1 = shard_graphs(torch.from_numpy(bnn + 1), torch.from_numpy(bne + 2 * bnn), world)[rank]
+    if (g0, g1) == (0, len(bnn)):
+        return raw, (g0, g1)
+    n0, n1, e0, e1 = (int(raw[k][g]) for k, g in (("node_ptr", g0), ("node_ptr", g1), ("edge_ptr", g0), ("edge_ptr", g1)))
+    sub = dict(raw)
+    sub.update(node_ptr=raw["node_ptr"][g0:g1 + 1] - n0, edge_ptr=raw["edge_ptr"][g0:g1 + 1] - e0,
+               src=raw["src"][e0:e1] - n0, dst=raw["dst"][e0:e1] - n0, edge_label=raw["edge_label"][e0:e1],
+               edge_id=raw["edge_id"][e0:e1], node_id=raw["node_id"][n0:n1], node_label=raw["node_label"][n0:n1])
+    return {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in sub.items()}, (g0, g1)
+
+
+def build_batch(dev, seed, graphs, workload, shard=None):
+    """shard = (rank, world): only that rank's graphs of the global batch go to the device."""
     from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
     raw = synthetic.config5(seed, graphs) if workload == "config5" else synthetic.config3(seed, graphs)
+    if shard is not None:
+        raw, _ = shard_of(raw, *shard)
     t = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
     aug_ms = []
     for _ in range(3):                                   # first call: code-object load + allocator growth; then steady state
@@ -127,9 +152,24 @@ def dry_run(args, rank, world):
     t = torch.tensor([float(rank + 1)])
     if dist.is_initialized():
         dist.all_reduce(t)
+    # the split every rank would take (host-side bookkeeping only: parallel.shard_graphs on the synthetic batch's sizes)
+    shards = None
+    if args.workload in ("config5", "config3") and args.scaling == "strong":
+        from dummynode4graphlearning_amd import synthetic
+        graphs = args.graphs or {"config5": 32768, "config3": 512}[args.workload]
+        raw = synthetic.config5(5, graphs) if args.workload == "config5" else synthetic.config3(3, graphs)
+        _, (g0, g1) = shard_of(raw, rank, world)
+        mine = torch.tensor([g0, g1], dtype=torch.int64)
+        allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        if dist.is_initialized():
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        shards = [[int(a[0]), int(a[1])] for a in allr]
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps,
-                          "warmup": args.warmup, "workload": args.workload}), flush=True)
+                          "warmup": args.warmup, "workload": args.workload, "scaling": args.scaling,
+                          "shard_graphs": shards}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -235,7 +275,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config5", choices=["config5", "config3", "config4"])
     ap.add_argument("--dry-run", action="store_true", help="CPU-only launch check: rendezvous over gloo, no product code")
-    ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (0 = the workload's own size)")
+    ap.add_argument("--graphs", type=int, default=0, help="graphs in the global batch (strong) / per GPU (weak); 0 = the workload's own size")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="config5 / config3: strong = ONE global batch cut by parallel.shard_graphs (default); weak = a full batch per rank")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (an eighth of the batch)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
     ap.add_argument("--hidden", type=int, default=0, help="override the workload's hidden size (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,73 +321,90 @@ def main():
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     s = 2 if dtype == torch.bfloat16 else 4
 
-    g, raw, aug_ms = build_batch(dev, {"config5": 5, "config3": 3}[args.workload] + rank, graphs, args.workload)
+    strong = args.scaling == "strong"
+    seed0 = {"config5": 5, "config3": 3}[args.workload]
+    if strong:                                  # ONE global batch, this rank's contiguous graph range of it
+        g, raw, aug_ms = build_batch(dev, seed0, graphs, args.workload, shard=(rank, world))
+    else:                                       # weak: every rank its own full batch
+        g, raw, aug_ms = build_batch(dev, seed0 + rank, graphs, args.workload)
     N, E = g.number_of_nodes(), g.number_of_edges()
     etype = g.edata["label"]
     torch.manual_seed(1234)
     layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(dev).to(dtype)
-    gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    x = torch.randn(N, H, device=dev, generator=gen).to(dtype).requires_grad_(True)
-    gout = torch.randn(N, H, device=dev, generator=gen).to(dtype)
     bucket = FlatGradBucket(layer.parameters())
 
     fused = H in (64, 128, 256)                 # row-factorised MFMA pipeline (bf16 and exact-f32) vs generic two-pass path
-
-    def build_index():
-        g._cache.clear()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ix = g.row_index(etype, R, True) if fused else g.rel_index(etype, R)
-        if fused and dtype == torch.bfloat16:   # the slot tables of the closing launch are part of the per-batch index cost
-            for _, _, part in ix.parts:
-                part.slots("f"), part.slots("b")
-        torch.cuda.synchronize()
-        return ix, (time.perf_counter() - t0) * 1e3
-
-    index, index_first_ms = build_index()       # first call: allocator growth + code-object load
-    index, index_ms = build_index()             # steady state (what a training loop pays per new batch)
-
-    def compute():
-        bucket.zero(set_to_none=True)           # optimizer.zero_grad()'s default (train.py:836): gradients are written, not added
-        x.grad = None
-        out, _ = layer(g, x, etype)
-        out.backward(gout)
-        bucket.pack()                           # the step's gradients -> the flat bucket (one launch), inside the captured step
-
-    def step_eager():
-        compute()
-        bucket.all_reduce()
-
-    # The step is launch-bound from Python (a few hundred small launches): capture it once into a HIP graph and replay it.
-    # The gradient all-reduce (RCCL) stays outside the graph, on the same stream right after the replay.
     use_graph = not args.no_graph
-    for _ in range(max(args.warmup, 2)):
-        step_eager()
-    torch.cuda.synchronize()
-    graph = None
-    if use_graph:
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            compute()                                   # warm the private pool on the capture stream
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
-        try:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                compute()
-        except Exception as exc:                        # never lose the measurement to a capture problem: run eagerly
-            sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
-            torch.cuda.synchronize()
-            graph = None
 
-    def step():
-        if graph is not None:
-            graph.replay()
+    def prepare(gb, seed):
+        """Index build (timed, twice), inputs and the captured step of one batch on this GPU.
+        -> dict(step=callable, graph=CUDAGraph or None, index=..., index_ms=(first, steady), x=..., gout=...)."""
+        et = gb.edata["label"]
+        n = gb.number_of_nodes()
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        xb = torch.randn(n, H, device=dev, generator=gen).to(dtype).requires_grad_(True)
+        gob = torch.randn(n, H, device=dev, generator=gen).to(dtype)
+
+        def build_index():
+            gb._cache.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix = gb.row_index(et, R, True) if fused else gb.rel_index(et, R)
+            if fused and dtype == torch.bfloat16:   # the slot tables of the closing launch are part of the per-batch index cost
+                for _, _, part in ix.parts:
+                    part.slots("f"), part.slots("b")
+            torch.cuda.synchronize()
+            return ix, (time.perf_counter() - t0) * 1e3
+
+        ix, first_ms = build_index()            # first call: allocator growth + code-object load
+        ix, steady_ms = build_index()           # steady state (what a training loop pays per new batch)
+
+        def compute():
+            bucket.zero(set_to_none=True)       # optimizer.zero_grad()'s default (train.py:836): gradients are written, not added
+            xb.grad = None
+            out, _ = layer(gb, xb, et)
+            out.backward(gob)
+            bucket.pack()                       # the step's gradients -> the flat bucket (one launch), inside the captured step
+
+        def step_eager():
+            compute()
             bucket.all_reduce()
-        else:
+
+        # The step is launch-bound from Python (a few hundred small launches): capture it once into a HIP graph and replay it.
+        # The gradient all-reduce (RCCL) stays outside the graph, on the same stream right after the replay.
+        for _ in range(max(args.warmup, 2)):
             step_eager()
+        torch.cuda.synchronize()
+        gr = None
+        if use_graph:
+            gr = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                compute()                               # warm the private pool on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
+            try:
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                    compute()
+            except Exception as exc:                    # never lose the measurement to a capture problem: run eagerly
+                sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
+                torch.cuda.synchronize()
+                gr = None
+
+        def step():
+            if gr is not None:
+                gr.replay()
+                bucket.all_reduce()
+            else:
+                step_eager()
+
+        return dict(step=step, graph=gr, index=ix, index_ms=(first_ms, steady_ms), x=xb, gout=gob)
+
+    main = prepare(g, 100 + rank)
+    step, graph, index, x, gout = main["step"], main["graph"], main["index"], main["x"], main["gout"]
+    index_first_ms, index_ms = main["index_ms"]
 
     for _ in range(args.warmup):
         step()
@@ -358,10 +418,36 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    e_glob = float(E)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        te = torch.tensor([float(E)], device=dev, dtype=torch.float64)
+        dist.all_reduce(te)
+        e_glob = float(te.item())               # strong: the global batch's edges; weak: world x E
+
+    # strong-scaling proxy (rank 0, one GPU): ONE eighth of the global batch (the shard rank 0 of an 8-GPU run takes) on this
+    # GPU -- step under HIP-graph replay incl. bucket.pack(), fresh-batch index build -- and the efficiency an 8-GPU run could
+    # reach before the gradient all-reduce: t(batch) / (8 t(eighth)).  No multi-GPU curve is measured here.
+    proxy = None
+    if rank == 0 and world == 1 and strong and not args.no_proxy and graphs >= 8:
+        g8, raw8, aug8 = build_batch(dev, seed0, graphs, args.workload, shard=(0, 8))
+        p8 = prepare(g8, 100)
+        for _ in range(args.warmup):
+            p8["step"]()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            p8["step"]()
+        torch.cuda.synchronize()
+        ms8 = (time.perf_counter() - t1) / args.steps * 1e3
+        ms1 = dt / args.steps * 1e3
+        proxy = {"shard_graphs": int(g8.batch_size), "shard_edges": g8.number_of_edges(), "shard_ms_per_step": ms8,
+                 "shard_index_build_ms": p8["index_ms"][1], "shard_dummy_augment_ms": aug8[1],
+                 "batch_ms_per_step": ms1, "efficiency_at_8": ms1 / (8.0 * ms8), "predicted_speedup_at_8": ms1 / ms8,
+                 "note": "one GPU, no collective: t(batch) / (8 t(eighth)); the 2.5 MB gradient all-reduce of an 8-GPU step is not in it"}
+        del p8, g8
 
     # fresh-batch leg (rank 0, one GPU): a training loop sees a new batch every step, so it pays the dummy augmentation and the
     # index build per step.  Sequentially that is `edges_per_s_incl_index_build`; here the NEXT batch's augmentation + index
@@ -507,18 +593,21 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": world * E / (ms_per_step * 1e-3),
+            "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": e_glob / (ms_per_step * 1e-3),
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd on %d graphs/GPU (N=%d, E=%d per GPU), "
-                                   "SI dummy augmentation" % (args.workload, H, H, R, graphs, N, E),
-                       "global_edges": world * E, "parallelism": "dp%d" % world,
+            "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd, %s (rank 0: N=%d, E=%d), SI dummy augmentation"
+                                   % (args.workload, H, H, R,
+                                      ("ONE global batch of %d graphs cut by parallel.shard_graphs over %d GPU(s)" % (graphs, world))
+                                      if strong else ("%d graphs per GPU" % graphs), N, E),
+                       "global_edges": int(e_glob), "parallelism": "dp%d" % world,
+                       "shard_graphs_rank0": int(g.batch_size), "strong_scaling_proxy": proxy,
                        "rows_P": getattr(index, "num_rows", None) or index.num_segments, "index_build_ms": index_ms,
                        "index_build_first_call_ms": index_first_ms, "dummy_augment_ms": aug_ms[1],
                        "dummy_augment_first_call_ms": aug_ms[0],
                        # a training loop sees a NEW batch every step: dummy augmentation + index build + step, per fresh batch
-                       "edges_per_s_incl_index_build": world * E / ((ms_per_step + index_ms + aug_ms[1]) * 1e-3),
+                       "edges_per_s_incl_index_build": e_glob / ((ms_per_step + index_ms + aug_ms[1]) * 1e-3),
                        "fresh_batch_overlapped_ms_per_step": overlapped_ms,
                        "edges_per_s_fresh_batch_overlapped": (E / (overlapped_ms * 1e-3)) if overlapped_ms else None,
                        "grad_bucket_bytes": bucket.bytes(), "hip_graph": graph is not None,

@@ -358,6 +358,21 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     return (out, colsum) if colsum_of else out
 
 
+def wgrad_chunk_rows(rel_ptr_host, workgroups=256):
+    """Rows per split-K chunk of the weight gradient over relation-major rows: the smallest multiple of 64 (>= 256) for which the
+    chunks of all relations -- every relation ends in a partial chunk -- fit ONE round of `workgroups`; batches too large for
+    that keep WGRAD_CHUNK_ROWS (several rounds).  (A 1/8 shard of config 5 cut by rows / 256 alone made 270 chunks: a second
+    round for 14 workgroups, 138 us instead of 80.)"""
+    sizes = [int(b) - int(a) for a, b in zip(rel_ptr_host[:-1], rel_ptr_host[1:]) if int(b) > int(a)]
+    total = sum(sizes)
+    if total == 0:
+        return 256
+    c = max(256, -(-total // workgroups // 64) * 64)
+    while c < WGRAD_CHUNK_ROWS and sum(-(-n // c) for n in sizes) > workgroups:
+        c += 64
+    return min(c, WGRAD_CHUNK_ROWS)
+
+
 def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False, skip_mask=0):
     """Tile (step = 32) / chunk tables of relation-major rows built ON THE DEVICE (dn_row_tables_build_i32): returns
     (table [M, 4] int32, M) or (table, piece_ptr [num_rels + 1], M) with M = the upper bound rows / step + num_rels --
@@ -1131,9 +1146,9 @@ class RowIndex:
         self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
         self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
         self._slots, self._fold = {}, {}
-        # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size
-        self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all,
-                                            max(256, min(WGRAD_CHUNK_ROWS, -(-P_all // 256 // 64) * 64)), want_ptr=True)
+        # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size:
+        # the smallest chunk that keeps ALL relations' chunks (each relation ends in a partial one) within one round of 256
+        self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
 
 
 def _fold_candidate(ix, direction):

@@ -202,9 +202,39 @@ def test_bench_launches_its_own_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rank_sum"] == 3.0 and lines[0]["steps"] == 3
+    # config 5 is ONE global batch cut by parallel.shard_graphs: the two ranks report complementary graph ranges
+    assert lines[0]["scaling"] == "strong" and lines[0]["shard_graphs"] == [[0, 16384], [16384, 32768]]
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=dict(env, RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_bench_shards_of_the_global_batch_are_disjoint_complete_and_balanced():
+    """bench.shard_of: the 8 ranks of the config-5 run take 4,096 graphs each; on graphs of unequal sizes the ranges
+    still tile the batch and carry equal nodes + edges to within one graph; a shard is a self-contained batch (ids relative)."""
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from dummynode4graphlearning_amd import synthetic
+    raw = synthetic.config5(5, 32768)
+    ranges = [bench.shard_of(raw, r, 8)[1] for r in range(8)]
+    assert ranges == [(4096 * r, 4096 * (r + 1)) for r in range(8)]
+    sub, (g0, g1) = bench.shard_of(raw, 3, 8)
+    assert sub["node_ptr"][0] == 0 and sub["edge_ptr"][0] == 0 and len(sub["node_ptr"]) == g1 - g0 + 1
+    assert sub["src"].min() >= 0 and sub["dst"].max() < sub["node_ptr"][-1] and len(sub["src"]) == sub["edge_ptr"][-1]
+    e0 = int(raw["edge_ptr"][g0])
+    assert np.array_equal(sub["src"], raw["src"][e0:e0 + len(sub["src"])] - raw["node_ptr"][g0])
+    # unequal graphs (config 4's NCI1-shaped sizes, relabelled as an SI batch is not needed: only the split is under test)
+    from dummynode4graphlearning_amd.parallel import shard_graphs
+    r4 = synthetic.config4(seed=4, graphs=1000)
+    bnn = r4["node_ptr"][1:] - r4["node_ptr"][:-1]
+    bne = r4["edge_ptr"][1:] - r4["edge_ptr"][:-1]
+    w = (bnn + 1) + (bne + 2 * bnn)
+    sh = shard_graphs(torch.from_numpy(bnn + 1), torch.from_numpy(bne + 2 * bnn), 8)
+    assert sh[0][0] == 0 and sh[-1][1] == 1000 and all(sh[i][1] == sh[i + 1][0] for i in range(7))
+    loads = [int(w[a:b].sum()) for a, b in sh]
+    assert max(loads) - min(loads) <= 2 * int(w.max())
 
 
 def test_bucket_pack_after_set_to_none_gathers_the_steps_gradients():
