@@ -23,9 +23,6 @@ _SIGS = {
     "dn_runtime_probe": (ctypes.c_int, [P]),
     "dn_gather_segsum_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
     "dn_gather_segsum_bf16": (ctypes.c_int, [P, c_i64, c_i32, P, P, P, c_i64, c_i64, P, P, c_f32, c_i32, P]),
-    "dn_window_tiles_host": (ctypes.c_int, [P, c_i64, c_i32, P, c_i64, ctypes.POINTER(c_i64)]),
-    "dn_gather_segsum_window_f32": (ctypes.c_int, [P, c_i32, P, P, P, P, P, c_i64, P, c_f32, P]),
-    "dn_gather_segsum_window_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, P, c_i64, P, c_f32, P]),
     "dn_segment_sum_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
     "dn_segment_sum_bf16": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
     "dn_segment_mean_f32": (ctypes.c_int, [P, c_i32, P, c_i64, P, P]),
@@ -77,9 +74,6 @@ _SIGS = {
     "dn_fold_tables_workspace_bytes": (c_sz, [c_i64]),
     "dn_fold_tables_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, ctypes.POINTER(ctypes.c_int32), P, c_sz, P]),
     "dn_fold_tail_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, P]),
-    "dn_rows_pipe_sync_words": (c_sz, [c_i64]),
-    "dn_rows_pipe_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, P, P, P, c_i32, c_i32, P, c_i64, P, c_i64, P, P, P, P,
-                                         c_i64, P, c_i32, P, P]),
     "dn_rows_transform_f32": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, P]),
     "dn_rows_wgrad_f32": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P,
                                          c_i32, P, c_sz, P]),

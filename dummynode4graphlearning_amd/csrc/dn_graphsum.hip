@@ -166,6 +166,9 @@ __global__ __launch_bounds__(gt_threads(H)) void graph_tile_sum_kernel(const flo
         __syncthreads();
         for (int i = tid; i < kGtRows * SA / 2; i += kGtThreads) {          // counts -> bf16 (exact up to 256)
             const uint32_t w = adjW[i];
+            // more than 256 parallel edges between one pair of nodes would be rounded by the conversion: raise the flag, the
+            // caller's plan then falls back to the plain gather (ops._tile_neighbor_sum reads it once per batch)
+            if ((w & 0xffffu) > 256u || (w >> 16) > 256u) atomicOr(bad, 1);
             adjW[i] = (__float_as_uint((float)(w & 0xffffu)) >> 16) | (__float_as_uint((float)(w >> 16)) & 0xffff0000u);
         }
         __syncthreads();

@@ -246,265 +246,6 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec1_kernel(
         }
     }
 }
-// -------------------------------------------------------------------------------------------------
-// Graph-local gather through an LDS WINDOW, streamed: out[s] = self_coef * in[s] + sum_i scale[i] * in[idx[i]] for the case
-// "segment s <-> row s, and (almost) every idx of a segment lies in the segment's own tile" -- a GNN conv on a batch of small
-// graphs, where a tile is a run of whole graphs (dn_hip.h: dn_gather_segsum_window_*).  The plain kernel above re-reads every
-// neighbour row through L2 (7.6 TB/s of L2 traffic at 34 % of the HBM peak on the PROTEINS-shaped batch: latency-bound on
-// the ptr -> idx -> row chain); here every row of the tile arrives ONCE, by LDS-DMA, into a ring of kWinStages windows while
-// earlier tiles are being summed out of LDS, so HBM sees two streams (rows in, rows out) and nothing else.
-//   * one persistent workgroup per CU, 16 waves: waves 0-3 only STAGE -- per tile they issue a fixed number of LDS-DMAs: the
-//     window (16 bytes per lane), the tile's segment bounds and its first kWinIdxCap index entries / scales (4 bytes per
-//     lane) -- and nothing else enters their vmcnt queue, so a counted s_waitcnt is exact; waves 4-15 only GATHER (768/LPR
-//     lane groups, one segment at a time each, the same summation order as the plain kernel: bitwise equal results).  One
-//     s_barrier per tile hands a stage over; tiles t+1 and t+2 are in flight while tile t is summed.
-//   * a window is a contiguous byte range of `in`, copied verbatim (lane l of DMA j <-> bytes 1024 j + 16 l): no swizzle
-//     needed, a lane group reads whole rows (conflict-free).  Windows hold kWinBytes; rows of a tile beyond that, idx outside
-//     the tile and index entries beyond kWinIdxCap per tile are read from global memory (correct, just slower).
-// -------------------------------------------------------------------------------------------------
-constexpr int kWinThreads = 1024;
-constexpr int kWinDmaWaves = 4;
-constexpr int kWinStages = 3;
-constexpr int kWinBytes = 40 * 1024;                 // window bytes per stage
-constexpr int kWinIdxCap = 1024;                     // index entries of a tile staged in LDS
-constexpr int kWinPtrCap = 512;                      // segment bounds of a tile staged in LDS (rows are >= 128 bytes: <= 321 used)
-constexpr int kWinCh = 8;                            // columns a gathering lane owns
-constexpr int kWinTileCap = 1023;                    // tiles of a workgroup whose bounds are kept in LDS
-constexpr int kWinDmaRows = kWinBytes / 1024 / kWinDmaWaves;        // per DMA wave and tile: 1 KiB window chunks,
-constexpr int kWinDmaIdx = kWinIdxCap / 64 / kWinDmaWaves;          //   256-byte runs of index entries (and of scales),
-constexpr int kWinDmaPtr = kWinPtrCap / 64 / kWinDmaWaves;          //   256-byte runs of segment bounds
-static_assert(kWinStages == 3, "the stagers' wait count assumes exactly one tile of DMAs issued after the one waited for");
-
-// A value that came from a (rare) global load on the gathering side is pinned INSIDE the branch that loaded it: the compiler's
-// s_waitcnt for it then sits in that branch.  Left to the join point, the wait would run on every pass -- and with the output
-// stores of earlier segments still in flight it is a full vmcnt(0), i.e. one store round trip per segment.
-__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
-template <int N>
-__device__ __forceinline__ void pin(float (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) pin(v[i]);
-}
-
-template <typename T, int LPR, bool HAS_SCALE>
-__global__ __launch_bounds__(kWinThreads) void gather_window_kernel(
-    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
-    const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_eptr,
-    int32_t num_tiles, int32_t tiles_per_wg, int32_t H, T* __restrict__ out, float self_coef) {
-    constexpr int VN = Vec<T>::N;
-    constexpr int DPW = kWinDmaRows + kWinDmaIdx * (HAS_SCALE ? 2 : 1) + kWinDmaPtr;       // DMAs per staging wave and tile
-    __shared__ __attribute__((aligned(1024))) char win[kWinStages * kWinBytes];
-    __shared__ __attribute__((aligned(256))) int32_t idxL[kWinStages][kWinIdxCap];
-    __shared__ __attribute__((aligned(256))) float scL[HAS_SCALE ? kWinStages : 1][HAS_SCALE ? kWinIdxCap : 64];
-    __shared__ __attribute__((aligned(256))) int32_t ptrL[kWinStages][kWinPtrCap];
-    typedef __attribute__((address_space(3))) char* lds_cp;
-    const unsigned win_base = (unsigned)(uintptr_t)(lds_cp)win, idx_base = (unsigned)(uintptr_t)(lds_cp)(char*)idxL;
-    const unsigned sc_base = (unsigned)(uintptr_t)(lds_cp)(char*)scL, ptr_base = (unsigned)(uintptr_t)(lds_cp)(char*)ptrL;
-    __shared__ int32_t tbL[2][kWinTileCap + 1];                              // this workgroup's tile bounds: rows, index entries
-    const int tid = threadIdx.x, lane64 = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, num_tiles);
-    if (t_beg >= t_end) return;
-    const int ntiles = t_end - t_beg;
-    const int rowb = H * (int)sizeof(T);
-    const char* inb = reinterpret_cast<const char*>(in);
-    for (int i = tid; i <= min(ntiles, kWinTileCap); i += kWinThreads) {
-        tbL[0][i] = tile_ptr[t_beg + i];
-        tbL[1][i] = tile_eptr[t_beg + i];
-    }
-    __syncthreads();
-    // bounds of tile T_ of this workgroup (i = T_ or T_ + 1): LDS copy, global beyond its capacity
-    auto rows_at = [&](int i) -> int {
-        if (i <= kWinTileCap) return tbL[0][i];
-        int v = tile_ptr[t_beg + i];
-        pin(v);
-        return v;
-    };
-    auto ents_at = [&](int i) -> int {
-        if (i <= kWinTileCap) return tbL[1][i];
-        int v = tile_eptr[t_beg + i];
-        pin(v);
-        return v;
-    };
-
-    if (wave < kWinDmaWaves) {
-        // ================= staging waves =================
-        const int S_rows = tile_ptr[num_tiles];                              // rows = segments: ptr has S_rows + 1 entries
-        auto issue = [&](int T_) {                                           // the DMAs of tile T_ (static count; past the end: harmless)
-            const int tt = min(T_, ntiles - 1);
-            const int a = rows_at(tt), b = rows_at(tt + 1), e0 = ents_at(tt), e1 = ents_at(tt + 1);
-            const int st = T_ % kWinStages;
-            const int64_t a_b = (int64_t)a * rowb, b_b = (int64_t)b * rowb;
-#pragma unroll
-            for (int j = 0; j < kWinDmaRows; ++j) {
-                const int chunk = wave * kWinDmaRows + j;                    // 1 KiB chunk of the window
-                int64_t off = a_b + (int64_t)chunk * 1024 + lane64 * 16;
-                off = off < b_b ? off : a_b;                                 // bytes past the tile are not needed: re-read its first 16
-                glds16(inb + off, win_base + (unsigned)(st * kWinBytes + chunk * 1024));
-            }
-#pragma unroll
-            for (int j = 0; j < kWinDmaIdx; ++j) {
-                const int run = wave * kWinDmaIdx + j;                       // 64 entries
-                int e = e0 + run * 64 + lane64;
-                e = e < e1 ? e : e0;                                         // (e0 < e1 or nobody reads the entries)
-                e = e1 > e0 ? e : 0;
-                glds4(idx + e, idx_base + (unsigned)((st * kWinIdxCap + run * 64) * 4));
-                if (HAS_SCALE) glds4(scale + e, sc_base + (unsigned)((st * kWinIdxCap + run * 64) * 4));
-            }
-#pragma unroll
-            for (int j = 0; j < kWinDmaPtr; ++j) {
-                const int run = wave * kWinDmaPtr + j;
-                int i = a + run * 64 + lane64;
-                i = i <= S_rows ? i : a;
-                glds4(ptr + i, ptr_base + (unsigned)((st * kWinPtrCap + run * 64) * 4));
-            }
-        };
-#pragma unroll 1
-        for (int T_ = 0; T_ < kWinStages - 1; ++T_) issue(T_);
-#pragma unroll 1
-        for (int t = 0; t < ntiles; ++t) {
-            wait_vmcnt<DPW>();                                               // all but tile t+1's DMAs: tile t has landed
-            __builtin_amdgcn_s_barrier();                                    // tile t is complete in LDS; tile t-1's stage is free
-            issue(t + kWinStages - 1);
-        }
-        wait_vmcnt<0>();                                                     // drain before the LDS is released
-        return;
-    }
-
-    // ================= gatherers =================
-    // A lane owns kWinCh = 16 consecutive columns (64 bytes of an f32 row, 32 of a bf16 row), so a row takes only LPR = H / 16
-    // lanes and a wave works on 64 / LPR segments at once: the per-row bookkeeping (index broadcast, address, loop control) is
-    // paid once per 16 columns instead of once per 4 -- the gather is VALU-issue-bound otherwise, not LDS- or HBM-bound.
-    constexpr int CH = kWinCh, NV = CH / VN;                                 // columns per lane, 16-byte loads per lane and row
-    constexpr int NG = (kWinThreads - 64 * kWinDmaWaves) / LPR;              // lane groups of the 12 gathering waves
-    const int gtid = tid - 64 * kWinDmaWaves;
-    const int lane = gtid % LPR, group = gtid / LPR;
-    // my 16 columns are NV interleaved 16-byte pieces (piece q = columns (lane + q * LPR) * VN ...): the lanes of a group read
-    // and write 16 * LPR contiguous bytes per instruction (no LDS bank conflict inside a group, coalesced stores)
-    auto load_row = [&](const T* rowp, float (&v)[CH]) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            float t4[VN];
-            Vec<T>::load(rowp + (lane + q * LPR) * VN, t4);
-#pragma unroll
-            for (int i = 0; i < VN; ++i) v[q * VN + i] = t4[i];
-        }
-    };
-#pragma unroll 1
-    for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // my LDS reads of tile t-1 are done
-        __builtin_amdgcn_s_barrier();
-        const int a = rows_at(t), b = rows_at(t + 1);
-        const int wrows = min(b - a, kWinBytes / rowb);                      // rows of the tile that are in the window
-        const char* wb = win + (t % kWinStages) * kWinBytes;
-        const int32_t* pL = ptrL[t % kWinStages];
-        const int32_t* iL = idxL[t % kWinStages];
-        const float* sL = scL[HAS_SCALE ? (t % kWinStages) : 0];
-        const int e0 = ents_at(t);
-#pragma unroll 1
-        for (int s = a + group; s < b; s += NG) {
-            const int li = s - a;
-            int beg, end;
-            if (li + 1 < kWinPtrCap) { beg = pL[li]; end = pL[li + 1]; }
-            else { beg = ptr[s]; end = ptr[s + 1]; pin(beg); pin(end); }
-            float acc[CH];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) acc[i] = 0.f;
-            // the list, KU entries at a time: every lane reads the entries itself (same address across the group: an LDS
-            // broadcast), so all KU row addresses are known after ONE round trip and all KU rows arrive after the next
-            constexpr int KU = 8;
-            for (int base = beg; base < end; base += KU) {
-                const int n = min(KU, end - base);
-                int r[KU];
-                float w[KU];
-                if (base - e0 + KU <= kWinIdxCap) {
-#pragma unroll
-                    for (int k = 0; k < KU; ++k) {
-                        r[k] = iL[base - e0 + k];                            // (entries past n: staged garbage, never used)
-                        w[k] = HAS_SCALE ? sL[base - e0 + k] : 1.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < KU; ++k) {
-                        r[k] = k < n ? idx[base + k] : a;
-                        w[k] = (HAS_SCALE && k < n) ? scale[base + k] : 1.f;
-                        pin(r[k]);
-                        pin(w[k]);
-                    }
-                }
-                float v[KU][CH];
-#pragma unroll
-                for (int k = 0; k < KU; ++k) {
-                    if (k < n) {
-                        if (r[k] >= a && r[k] < a + wrows) load_row(reinterpret_cast<const T*>(wb + (size_t)(r[k] - a) * rowb), v[k]);
-                        else { load_row(in + (size_t)r[k] * H, v[k]); pin(v[k]); }                   // outside the window
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < KU; ++k) {
-                    if (k < n) {
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) acc[i] = HAS_SCALE ? fmaf(w[k], v[k][i], acc[i]) : acc[i] + v[k][i];
-                    }
-                }
-            }
-            if (self_coef != 0.f) {
-                float sv[CH];
-                if (li < wrows) load_row(reinterpret_cast<const T*>(wb + (size_t)li * rowb), sv);
-                else { load_row(in + (size_t)s * H, sv); pin(sv); }
-#pragma unroll
-                for (int i = 0; i < CH; ++i) acc[i] = fmaf(self_coef, sv[i], acc[i]);
-            }
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                float t4[VN];
-#pragma unroll
-                for (int i = 0; i < VN; ++i) t4[i] = acc[q * VN + i];
-                Vec<T>::store(out + (size_t)s * H + (lane + q * LPR) * VN, t4);
-            }
-        }
-    }
-}
-
-template <typename T, int LPR>
-int launch_window(const T* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr, const int32_t* tile_ptr,
-                  const int32_t* tile_eptr, int64_t num_tiles, T* out, float self_coef, hipStream_t st) {
-    const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256);                    // one persistent workgroup per CU
-    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    if (scale != nullptr)
-        hipLaunchKernelGGL((gather_window_kernel<T, LPR, true>), dim3((unsigned)grid), dim3(kWinThreads), 0, st, in, idx, scale, ptr,
-                           tile_ptr, tile_eptr, (int32_t)num_tiles, (int32_t)tiles_per_wg, H, out, self_coef);
-    else
-        hipLaunchKernelGGL((gather_window_kernel<T, LPR, false>), dim3((unsigned)grid), dim3(kWinThreads), 0, st, in, idx, scale, ptr,
-                           tile_ptr, tile_eptr, (int32_t)num_tiles, (int32_t)tiles_per_wg, H, out, self_coef);
-    DN_CHECK_LAUNCH();
-    return DN_OK;
-}
-
-template <typename T>
-int gather_segsum_window(const T* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
-                         const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, T* out, float self_coef,
-                         hipStream_t st) {
-    constexpr int VN = Vec<T>::N;
-    DN_REQUIRE(H > 0 && H % VN == 0, "dn_gather_segsum_window: H must be a positive multiple of %d", VN);
-    DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_gather_segsum_window: bad tile count");
-    if (num_tiles == 0) return DN_OK;
-    DN_REQUIRE(in && idx && ptr && tile_ptr && tile_eptr && out, "dn_gather_segsum_window: NULL pointer");
-    DN_REQUIRE((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0, "dn_gather_segsum_window: unaligned pointer");
-    DN_REQUIRE(H % kWinCh == 0 && H * (int)sizeof(T) >= 128 && H * (int)sizeof(T) <= 1024,
-               "dn_gather_segsum_window: rows must be 128 bytes .. 1 KiB with H a multiple of 8 (use dn_gather_segsum_*)");
-    switch (H / kWinCh) {
-        case 4: return launch_window<T, 4>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, st);
-        case 8: return launch_window<T, 8>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, st);
-        case 16: return launch_window<T, 16>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, st);
-        case 32: return launch_window<T, 32>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, st);
-        case 64: return launch_window<T, 64>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, st);
-        default: break;
-    }
-    dn_set_error("dn_gather_segsum_window: H / 8 must be 4, 8, 16, 32 or 64");
-    return DN_ERR_UNSUPPORTED;
-}
-
 // Scalar path: any H (one element per lane per pass); used for narrow / unaligned rows
 // (e.g. the [N, num_classes] readout of gconv.py:210).
 template <typename T, int LPR, bool HAS_SCALE>
@@ -779,50 +520,6 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                           int32_t mean, dn_stream_t stream) {
     return gather_segsum<bf16_t>((const bf16_t*)in, in_rows, H, idx, scale, ptr, S, M, (bf16_t*)out,
                                  (const bf16_t*)self_in, self_coef, mean, (hipStream_t)stream);
-}
-
-int dn_window_tiles_host(const int32_t* node_ptr_host, int64_t num_graphs, int32_t rows_per_window, int32_t* tile_ptr_host,
-                         int64_t capacity, int64_t* num_tiles) {
-    DN_REQUIRE(node_ptr_host && tile_ptr_host && num_tiles && num_graphs >= 0 && rows_per_window >= 1, "dn_window_tiles_host: bad argument");
-    const int64_t W = rows_per_window;
-    int64_t n = 0;
-    auto push = [&](int64_t v) -> bool {
-        if (n >= capacity) return false;
-        tile_ptr_host[n++] = (int32_t)v;
-        return true;
-    };
-    int64_t beg = num_graphs > 0 ? node_ptr_host[0] : 0;                     // first row of the open tile
-    for (int64_t g = 0; g < num_graphs; ++g) {
-        const int64_t gs = node_ptr_host[g], ge = node_ptr_host[g + 1];
-        DN_REQUIRE(ge >= gs, "dn_window_tiles_host: node_ptr must not decrease");
-        if (ge - beg <= W) continue;                                         // the graph still fits the open tile
-        if (gs > beg) {                                                      // close the tile before this graph
-            if (!push(beg)) { dn_set_error("dn_window_tiles_host: tile table too small"); return DN_ERR_WORKSPACE; }
-            beg = gs;
-        }
-        while (ge - beg > W) {                                               // a graph larger than a window: cut it every W rows
-            if (!push(beg)) { dn_set_error("dn_window_tiles_host: tile table too small"); return DN_ERR_WORKSPACE; }
-            beg += W;
-        }
-    }
-    const int64_t end = num_graphs > 0 ? node_ptr_host[num_graphs] : 0;
-    if (end > beg && !push(beg)) { dn_set_error("dn_window_tiles_host: tile table too small"); return DN_ERR_WORKSPACE; }
-    if (n >= capacity) { dn_set_error("dn_window_tiles_host: tile table too small"); return DN_ERR_WORKSPACE; }
-    tile_ptr_host[n] = (int32_t)end;                                         // closing bound (n tiles, n + 1 entries)
-    *num_tiles = n;
-    return DN_OK;
-}
-
-int dn_gather_segsum_window_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
-                                const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, float* out,
-                                float self_coef, dn_stream_t stream) {
-    return gather_segsum_window<float>(in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, out, self_coef, (hipStream_t)stream);
-}
-int dn_gather_segsum_window_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
-                                 const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, void* out,
-                                 float self_coef, dn_stream_t stream) {
-    return gather_segsum_window<bf16_t>((const bf16_t*)in, H, idx, scale, ptr, tile_ptr, tile_eptr, num_tiles, (bf16_t*)out,
-                                        self_coef, (hipStream_t)stream);
 }
 
 static int64_t dn_rows_unknown() { return 0x7ffffffeLL; }

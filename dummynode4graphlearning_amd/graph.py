@@ -16,11 +16,6 @@ from . import ops
 
 import os as _os
 
-# nodes per sub-batch of the fused bf16 path (ops.RowIndexSet); 0 = never split.  Measured on MI355X (config 5,
-# HIP-graph replay): 1 / 4 / 8 / 16 / 32 sub-batches -> 5.17 / 5.92 / 6.76 / 8.23 / 11.2 ms per step, i.e. keeping the
-# intermediate rows "cache resident" by shrinking the launches loses more to under-filled launches than the 256 MiB
-# Infinity Cache gives back, so the default is one full-size launch per kernel.
-ROW_SUBBATCH_NODES = int(_os.environ.get("DN_SUBBATCH_NODES", "0"))
 
 
 class _IndexCache:
@@ -129,8 +124,7 @@ class BatchedGraph:
             if t is etype and ver == etype._version and r == ("row", num_rels, self_loop):
                 return ix
         ix = ops.RowIndexSet(self._src, self._dst, etype, self._n, num_rels, self_loop,
-                             node_ptr=self.node_ptr(), edge_ptr=self.edge_ptr(),
-                             target_nodes=ROW_SUBBATCH_NODES if ROW_SUBBATCH_NODES > 0 else 1 << 62)
+                             node_ptr=self.node_ptr(), edge_ptr=self.edge_ptr())
         self._cache._rel.append((etype, etype._version, ("row", num_rels, self_loop), ix))
         if len(self._cache._rel) > 4:
             self._cache._rel.pop(0)
@@ -222,7 +216,7 @@ def graph_ptr_i32(data):
 
 
 def _node_ptr_or_none(data):
-    """Graph boundaries of a PyG-style batch for the window gather, or None when the batch carries neither .ptr nor .batch."""
+    """Graph boundaries of a PyG-style batch (graph-local index builder, matrix-core neighbour sum), or None when the batch carries neither .ptr nor .batch."""
     if getattr(data, "ptr", None) is None and getattr(data, "batch", None) is None:
         return None
     return graph_ptr_i32(data)
@@ -271,7 +265,7 @@ def row_index_of(data, etype, num_rels, self_loop):
             return ix
     nptr = _node_ptr_or_none(data)
     ix = ops.RowIndexSet(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels, self_loop,
-                         node_ptr=nptr, edge_ptr=_edge_ptr_or_none(data, nptr), target_nodes=1 << 62)
+                         node_ptr=nptr, edge_ptr=_edge_ptr_or_none(data, nptr))
     cache._rel.append((etype, etype._version, tag, ix))
     if len(cache._rel) > 4:
         cache._rel.pop(0)

@@ -36,11 +36,21 @@ class StepGraph:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.result = fn()
             self.graph = g
-        except Exception:
+        except RuntimeError as exc:
+            # Only what stream capture itself refuses (a host read-back, a synchronising call, an allocation the capture cannot
+            # serve) falls back to eager launches -- loudly, because the warm-up calls and the aborted capture have side effects
+            # the caller should know about (BatchNorm running statistics advanced `warmup` extra times on the same batch, .grad
+            # tensors re-bound).  Argument errors of the HIP library (DnHipError), shape bugs etc. propagate.
             torch.cuda.synchronize()
-            if not fallback:
+            msg = str(exc)
+            capture_related = any(k in msg for k in ("captur", "Captur", "hipErrorStreamCapture", "cudaErrorStreamCapture",
+                                                     "operation not permitted when stream is capturing", "graph"))
+            from ._lib import DnHipError
+            if not fallback or not capture_related or isinstance(exc, DnHipError):
                 raise
-            self.graph = None                                   # eager from here on (e.g. a host read-back inside fn)
+            import warnings
+            warnings.warn("StepGraph: HIP-graph capture failed (%s); the step runs eagerly from here on" % msg.splitlines()[0])
+            self.graph = None
 
     @property
     def captured(self):

@@ -105,16 +105,6 @@ def gather_segsum(x, idx=None, ptr_=None, num_segments=None, scale=None, self_in
     return out
 
 
-# Streamed LDS-window variant of the graph-local gather (dn_gather_segsum_window_*): bitwise equal to the plain kernel; every row
-# of a tile (a run of whole graphs) reaches the CU once, by LDS-DMA, instead of once per edge through L2.  Measured on the
-# PROTEINS-shaped benchmark batch (tools/gin_gather_bench.py): staging alone streams the rows in 64 us per launch (the HBM
-# floor), but summing a tile out of LDS costs another ~180 us (bounds -> entries -> rows are three dependent LDS round trips per
-# segment, ~60-row tiles leave half of the 12 gathering waves idle, and one barrier per tile serialises the two phases), so
-# the launch takes 246 us against 213 us for the plain kernel.  Kept as an opt-in (DN_WINDOW_GATHER=1) and parity-tested.
-WINDOW_GATHER = _os.environ.get("DN_WINDOW_GATHER", "0") == "1"
-WINDOW_BYTES = 40 * 1024                                # kWinBytes in csrc/dn_segment.hip
-
-
 def graph_tiles(node_ptr, max_rows=64):
     """Greedy runs of whole graphs with at most max_rows rows each: (tiles [T, 2] int32 on the device, covered rows, rest) where
     rest = the rows of graphs larger than max_rows as a sorted int64 tensor (they keep the plain gather)."""
@@ -188,55 +178,6 @@ def graph_tile_sum(x, idx, ptr_, tiles, self_coef=0.0, out=None, seg=None, bad=N
     else:
         _launch()
     return out, bad
-
-
-def window_tiles(node_ptr, num_rows, rows_per_window):
-    """Tile boundaries (int32 [T + 1], device) for dn_gather_segsum_window_*: greedy runs of whole graphs that fit a window
-    (dn_window_tiles_host: the graph boundaries make one small device -> host copy, the packing is a C loop, the table goes
-    back up; once per batch and row width)."""
-    import numpy as np
-    W = max(int(rows_per_window), 1)
-    npt = np.ascontiguousarray(node_ptr.detach().cpu().numpy().astype(np.int32))
-    G = int(npt.shape[0]) - 1
-    assert G >= 0 and (G == 0 or int(npt[-1]) == int(num_rows)), "node_ptr must cover the rows"
-    cap = G + int(num_rows) // W + 2
-    buf = np.empty(cap, dtype=np.int32)
-    n = ctypes.c_int64(0)
-    check(lib().dn_window_tiles_host(npt.ctypes.data_as(ctypes.c_void_p), G, W, buf.ctypes.data_as(ctypes.c_void_p), cap,
-                                     ctypes.byref(n)), "dn_window_tiles_host")
-    T = int(n.value)
-    return torch.from_numpy(buf[:T + 1].copy()).to(node_ptr.device), T
-
-
-def gather_segsum_window(x, idx, ptr_, tiles, scale=None, self_coef=0.0):
-    """out[s] = self_coef*x[s] + sum_i scale[i]*x[idx[i]] with the rows of each tile streamed through an LDS window
-    (dn_gather_segsum_window_*): for graph-local gathers where segment s <-> row s.  tiles = window_tiles(...) or
-    (tile_ptr, ptr_[tile_ptr], T) when the caller caches the tiles' entry bounds."""
-    tile_ptr, ntiles = tiles[0], tiles[-1]
-    tile_eptr = tiles[1] if len(tiles) == 3 else ptr_[tile_ptr.long()].contiguous()
-    require_gpu(x, idx, ptr_, scale, tile_ptr, tile_eptr)
-    _i32(idx, "idx"), _i32(ptr_, "ptr"), _i32(tile_ptr, "tile_ptr"), _i32(tile_eptr, "tile_eptr")
-    S, H = x.shape
-    assert ptr_.numel() == S + 1 and tile_ptr.numel() == ntiles + 1 and tile_eptr.numel() == ntiles + 1
-    out = torch.empty_like(x)
-    fn = getattr(lib(), "dn_gather_segsum_window_" + _suffix(x))
-
-    def _launch():
-        check(fn(ptr(x), H, ptr(idx), ptr(scale), ptr(ptr_), ptr(tile_ptr), ptr(tile_eptr), int(ntiles), ptr(out),
-                 float(self_coef), stream_ptr()), "dn_gather_segsum_window")
-    if kernel_timer is not None:
-        kernel_timer.launch("gather_segsum_window", _launch)
-    else:
-        _launch()
-    return out
-
-
-def _window_ok(x, num_segments, self_in):
-    vn = 4 if x.dtype == torch.float32 else 8
-    rowb = x.shape[1] * x.element_size()
-    return (WINDOW_GATHER and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] == num_segments
-            and (self_in is None or self_in is x) and x.shape[1] % vn == 0 and 128 <= rowb <= 1024 and x.is_contiguous()
-            and x.data_ptr() % 16 == 0)
 
 
 def csr_build(key, num_keys):
@@ -538,7 +479,6 @@ class _SplitCSR:
     def __init__(self, ptr, idx, num_segments):
         self.ptr, self.idx, self.num_segments = ptr, idx, int(num_segments)
         self.hub_ids = None
-        self.tiles_of, self._wt = None, {}                    # set by EdgeIndex: row bytes -> window tiles of the batch
         if idx.numel() == 0:
             return
         deg = (ptr[1:] - ptr[:-1]).long()
@@ -568,33 +508,14 @@ class _SplitCSR:
         self.fold_ptr = first_chunk.to(I32)                                   # chunk ranges per hub
         self.hub_ids = hub_ids
 
-    def _tiles(self, row_bytes):
-        """(tile_ptr, entry bounds of the tiles in the CSR the main pass walks, T), cached per row width."""
-        t = self._wt.get(row_bytes)
-        if t is None:
-            tile_ptr, n = self.tiles_of(row_bytes)
-            p = self.ptr if self.hub_ids is None else self.ptr_main
-            t = (tile_ptr, p[tile_ptr.long()].contiguous(), n)
-            self._wt[row_bytes] = t
-        return t
-
     def segsum(self, x, scale=None, self_in=None, self_coef=0.0):
-        tiles = None
-        if self.tiles_of is not None and _window_ok(x, self.num_segments, self_in):
-            tiles = self._tiles(x.shape[1] * x.element_size())        # graph-local gather: rows streamed through LDS windows
-        sc = self_coef if self_in is not None else 0.0
         if self.hub_ids is None:
-            if tiles is not None:
-                return gather_segsum_window(x, self.idx, self.ptr, tiles, scale=scale, self_coef=sc)
             return gather_segsum(x, self.idx, self.ptr, self.num_segments, scale=scale, self_in=self_in, self_coef=self_coef)
         sc_main = sc_hub = None
         if scale is not None:
             sc_main, sc_hub = scale[self.keep].contiguous(), scale[~self.keep].contiguous()
-        if tiles is not None:
-            out = gather_segsum_window(x, self.idx_main, self.ptr_main, tiles, scale=sc_main, self_coef=sc)
-        else:
-            out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
-                                self_coef=self_coef)
+        out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
+                            self_coef=self_coef)
         part = gather_segsum(x, self.idx_hub, self.chunk_ptr, self.chunk_ptr.numel() - 1, scale=sc_hub)
         hub = gather_segsum(part, None, self.fold_ptr)                        # per-hub sum of its chunk partials
         out.index_add_(0, self.hub_ids, hub)                                  # distinct rows: order-independent
@@ -606,11 +527,11 @@ class EdgeIndex:
     The one-shot build DGL / torch-scatter hide behind update_all / scatter."""
 
     def __init__(self, src, dst, num_nodes, node_ptr=None):
-        """node_ptr (optional, [G + 1]): the batch's graph boundaries -- with it, graph-local gathers stream each graph's rows
-        through an LDS window (dn_gather_segsum_window_*) instead of fetching every neighbour row through L2."""
+        """node_ptr (optional, [G + 1]): the batch's graph boundaries -- with it, fp32 neighbour sums of small graphs run on the
+        matrix cores (tile_plan / dn_graph_tile_sum_f32)."""
         require_gpu(src, dst)
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
-        self._node_ptr, self._tiles, self._plan = node_ptr, {}, None
+        self._node_ptr, self._plan = node_ptr, None
         src, dst = src.to(I32).contiguous(), dst.to(I32).contiguous()
         self.src, self.dst = src, dst
         self.in_ptr, self.in_perm = csr_build(dst, num_nodes)
@@ -620,20 +541,11 @@ class EdgeIndex:
         self.dst_by_src = gather_rows_i32(dst, self.out_perm)
         self.fwd = _SplitCSR(self.in_ptr, self.src_by_dst, num_nodes)
         self.bwd = _SplitCSR(self.out_ptr, self.dst_by_src, num_nodes)
-        if node_ptr is not None and int(node_ptr.numel()) >= 2:
-            self.fwd.tiles_of = self.bwd.tiles_of = self.window_tiles
         self._max_bwd = None
-
-    def window_tiles(self, row_bytes):
-        t = self._tiles.get(row_bytes)
-        if t is None:
-            t = window_tiles(self._node_ptr, self.num_nodes, WINDOW_BYTES // int(row_bytes))
-            self._tiles[row_bytes] = t
-        return t
 
     def tile_plan(self):
         """Plan of the matrix-core neighbour sum (dn_graph_tile_sum_f32) for this batch, or None: tiles = greedy runs of whole
-        graphs with at most 64 rows (packed by dn_window_tiles_host from one small copy of the graph boundaries), the rows of larger
+        graphs with at most 64 rows (packed by dn_graph_tiles_host from one small copy of the graph boundaries), the rows of larger
         graphs as two row lists per direction for dn_gather_rows_sum_f32 (lists of up to 64 entries: a lane group per row; hubs: a
         workgroup per row).  Built once per batch."""
         if self._plan is None:
@@ -1157,8 +1069,7 @@ def _fold_candidate(ix, direction):
     mode = RowIndex.AGG if direction == "f" else RowIndex.TF
     n_aux = ix.num_aux_f if direction == "f" else ix.num_aux_b
     rels = [r for r, m in enumerate(ix.modes) if m == mode and ix.rel_ptr_host[r + 1] > ix.rel_ptr_host[r]]
-    if not (FOLD_ENABLED and ix.self_loop and len(rels) == 1 and ix.num_rels <= 64 and n_aux > 0
-            and getattr(ix, "pipe", None) is None):
+    if not (FOLD_ENABLED and ix.self_loop and len(rels) == 1 and ix.num_rels <= 64 and n_aux > 0):
         return None
     r = rels[0]
     beg, end = ix.rel_ptr_host[r], ix.rel_ptr_host[r + 1]
@@ -1244,41 +1155,14 @@ RowIndex.slots = _row_index_slots
 
 
 class RowIndexSet:
-    """Row factorisations of CONTIGUOUS GRAPH RANGES of one batch ("sub-batches"), each small enough that its x rows,
-    its transformed rows Y and its output rows stay resident in the 256 MiB Infinity Cache / the XCD L2s between the
-    kernels that produce and consume them.  The kernels below are HBM-bound (rocprof: 4.3-5.5 TB/s), so the win comes
-    from not sending the Y round trip (and the repeated x / g gathers) to HBM at all: every sub-batch reuses ONE Y
-    buffer.  A batch is a disjoint union of graphs, so sub-batches are independent."""
+    """Holder of a batch's RowIndex (`parts` = [(first node, end node, RowIndex)], one part) and of the Y buffer its launches
+    share.  (Rounds 1-2 could cut a batch into cache-resident sub-batches here; under-filled launches lost more than the
+    Infinity Cache returned at every split -- DESIGN.md section 4 -- and the splitting was removed in round 3.)"""
 
-    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop, node_ptr=None, edge_ptr=None,
-                 target_nodes=32768):
-        dev = src.device
-        N, E = int(num_nodes), int(src.numel())
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop, node_ptr=None, edge_ptr=None):
+        N = int(num_nodes)
         self.num_nodes, self.num_rels, self.self_loop = N, int(num_rels), bool(self_loop)
-        bounds = [(0, N, 0, E)]
-        if node_ptr is not None and edge_ptr is not None and N > target_nodes:
-            npt, ept = node_ptr.tolist(), edge_ptr.tolist()
-            bounds, g0, G = [], 0, len(npt) - 1
-            while g0 < G:
-                g1 = g0 + 1
-                while g1 < G and npt[g1 + 1] - npt[g0] <= target_nodes:
-                    g1 += 1
-                bounds.append((npt[g0], npt[g1], ept[g0], ept[g1]))
-                g0 = g1
-        self.parts = []
-        if len(bounds) == 1:                                     # (the usual case: no shifted copies of the edge arrays)
-            self.parts.append((0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop, node_ptr=node_ptr,
-                                              edge_ptr=edge_ptr)))
-        else:
-            s64, d64 = src.long(), dst.long()
-            for n0, n1, e0, e1 in bounds:
-                ix = RowIndex(s64[e0:e1] - n0, d64[e0:e1] - n0, etype[e0:e1], n1 - n0, num_rels, self_loop=self_loop)
-                self.parts.append((n0, n1, ix))
-        if (PIPE_ENABLED and node_ptr is not None and len(self.parts) == 1 and self_loop and N > 0
-                and int(node_ptr.numel()) >= 2):
-            pipe = PipeIndex(self.parts[0][2], node_ptr)
-            if pipe.slot_rows <= PIPE_MAX_SLOT_ROWS:             # (a graph too large for a ring slot: two-launch path)
-                self.parts[0][2].pipe = pipe
+        self.parts = [(0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop, node_ptr=node_ptr, edge_ptr=edge_ptr))]
         self.max_rows = max(ix.num_rows for _, _, ix in self.parts)
         self.num_rows = sum(ix.num_rows for _, _, ix in self.parts)
         self.num_all_rels = self.num_rels + (1 if self_loop else 0)
@@ -1291,264 +1175,6 @@ class RowIndexSet:
             b = torch.empty((self.max_rows, H), dtype=dtype, device=dev)
             self._ybuf[key] = b
         return b
-
-
-# The persistent XCD-local launch (csrc/dn_pipe.hip) is correct and parity-tested but SLOWER than the two-launch path on
-# MI355X (config 5: 1.6 ms against 0.9 ms per direction): the L2 serves the ring reads (86 % hit rate,
-# HBM reads 0.65 GB instead of 3.2 GB) but writes through to HBM anyway (WRITE_SIZE 2.07 GB per launch), and one tile in
-# flight per workgroup behind two hand-offs per batch leaves the launch latency-bound.  Opt in with DN_PIPE=1.
-PIPE_ENABLED = _os.environ.get("DN_PIPE", "0") == "1"
-PIPE_BATCH_NODES = int(_os.environ.get("DN_PIPE_BATCH_NODES", "256"))     # nodes per batch (ring slot ~ 3x that many rows)
-PIPE_RING_DEPTH = int(_os.environ.get("DN_PIPE_DEPTH", "5"))              # batches in flight per XCD
-PIPE_ROLES = int(_os.environ.get("DN_PIPE_ROLES", "64"))                  # workgroups per XCD (2 per CU)
-PIPE_C_WEIGHT = float(_os.environ.get("DN_PIPE_CW", "1.0"))               # cost of a sum tile relative to a transform tile
-PIPE_MAX_SLOT_ROWS = int(_os.environ.get("DN_PIPE_MAX_SLOT_ROWS", "4096"))   # a batch's rows must be able to sit in L2
-PIPE_TIMEOUT_MS = 200
-
-
-class PipeIndex:
-    """Work tables of dn_rows_pipe_bf16 for one RowIndex whose batch is a disjoint union of graphs (node_ptr): the graphs
-    are cut into <= 8 contiguous groups (one per XCD) and each group into batches of consecutive graphs; the edge rows are
-    re-ordered (batch, relation)-major so that every (batch, relation) unit is one contiguous row range, the per-node row
-    lists are re-expressed relative to their batch, and every workgroup of the persistent launch gets a fixed role and tile
-    sequence.  Built once per batch (device sorts / scans by torch index ops, role and tile tables with numpy on the host);
-    both directions of the message pass share everything but the input-row table and the per-node lists."""
-
-    def __init__(self, ix, node_ptr, groups=8, roles_per_group=None, depth=None, batch_nodes=None):
-        import numpy as np
-        dev = ix.row_in.device
-        # the self loop is relation R of the launch: one row per node (RowIndex appends those rows after the edge rows)
-        N, P, R = ix.num_nodes, ix.num_rows, ix.num_all_rels
-        roles_per_group = roles_per_group or PIPE_ROLES
-        depth = depth or PIPE_RING_DEPTH
-        batch_nodes = batch_nodes or PIPE_BATCH_NODES
-        self.ix, self.depth, self.roles_per_group = ix, depth, roles_per_group
-        nptr_h = node_ptr.detach().to("cpu", torch.int64).numpy()
-        G = len(nptr_h) - 1
-        assert G >= 1 and int(nptr_h[-1]) == N and ix.self_loop
-        n_g = np.diff(nptr_h)
-        # ---- rows -> graphs (device) ------------------------------------------------------------------------------------
-        nptr_d = node_ptr.to(device=dev, dtype=torch.int64)
-        graph_of_node = torch.bucketize(torch.arange(N, device=dev), nptr_d[1:], right=True)
-        relp = torch.tensor(ix.rel_ptr_host[:R + 1], dtype=torch.int64)
-        row_rel = torch.repeat_interleave(torch.arange(R, dtype=torch.int64), relp[1:] - relp[:-1]).to(dev)
-        row_in, row_out = ix.row_in[:P].long(), ix.row_out[:P].long()
-        node_of_row = torch.where(row_in < N, row_in, row_out)
-        graph_of_row = graph_of_node[node_of_row] if P else torch.zeros(0, dtype=torch.int64, device=dev)
-        r_g = torch.bincount(graph_of_row, minlength=G).cpu().numpy() if P else np.zeros(G, dtype=np.int64)
-        # ---- groups (balanced by rows + nodes) and batches (fixed number of graphs per batch) on the host ---------------------
-        groups = int(max(1, min(groups, G)))
-        csum = np.cumsum(r_g + n_g)
-        gb = [0]
-        for k in range(1, groups):
-            gb.append(int(min(max(np.searchsorted(csum, csum[-1] * k / groups) + 1, gb[-1]), G)))
-        gb.append(G)
-        mean_n = max(float(N) / G, 1.0)
-        gpb = int(max(1, batch_nodes // mean_n))                     # graphs per batch
-        batch_of_graph = np.zeros(G, dtype=np.int64)
-        bfirst, bgroup, blocal = [], [], []                          # first graph, group, local index of every batch
-        nb = 0
-        for g in range(groups):
-            g0, g1 = gb[g], gb[g + 1]
-            cnt = -(-(g1 - g0) // gpb) if g1 > g0 else 0
-            k = np.arange(g1 - g0) // gpb
-            batch_of_graph[g0:g1] = nb + k
-            bfirst.extend((g0 + np.arange(cnt) * gpb).tolist())
-            bgroup.extend([g] * cnt)
-            blocal.extend(range(cnt))
-            nb += cnt
-        B = nb
-        bfirst = np.asarray(bfirst + [G], dtype=np.int64)
-        bgroup, blocal = np.asarray(bgroup, dtype=np.int64), np.asarray(blocal, dtype=np.int64)
-        bnode = nptr_h[bfirst]                                       # node range of every batch [B + 1]
-        self.num_groups, self.num_batches = groups, B
-        # ---- (batch, relation)-major row order (device) ---------------------------------------------------------------------
-        bog_d = torch.from_numpy(batch_of_graph).to(dev)
-        if P:
-            key = bog_d[graph_of_row] * R + row_rel
-            order = torch.argsort(key, stable=True)
-            inv = torch.empty(P, dtype=torch.int64, device=dev)
-            inv[order] = torch.arange(P, device=dev)
-            unit_cnt = torch.bincount(key, minlength=B * R).cpu().numpy()
-            self.row_idx = {"f": ix.row_in[:P][order].contiguous(), "b": ix.row_out[:P][order].contiguous()}
-        else:
-            inv = torch.zeros(0, dtype=torch.int64, device=dev)
-            unit_cnt = np.zeros(B * R, dtype=np.int64)
-            z = torch.zeros(1, dtype=I32, device=dev)
-            self.row_idx = {"f": z, "b": z}
-        unit_ptr = np.concatenate([[0], np.cumsum(unit_cnt)])
-        rowbase = unit_ptr[np.arange(B) * R]
-        rows_b = unit_ptr[(np.arange(B) + 1) * R] - rowbase
-        slot_rows = int(max(int(rows_b.max()) if B else 0, 1))
-        self.slot_rows, self.ring_rows = slot_rows, groups * depth * slot_rows
-        # ---- per-node lists relative to the batch's first row (device) ------------------------------------------------------------
-        rowbase_d = torch.from_numpy(rowbase).to(dev)
-        batch_of_node = bog_d[graph_of_node]
-        self.list_ptr, self.list_local = {}, {}
-        for d, (lp, lr) in (("f", (ix.dst_ptr, ix.dst_rows)), ("b", (ix.src_ptr, ix.src_rows))):
-            lp64 = lp[:N + 1].long()
-            ent = lr[:int(lp64[N])].long() if N else lr[:0].long()
-            node_of_ent = torch.repeat_interleave(torch.arange(N, device=dev), lp64[1:] - lp64[:-1], output_size=int(ent.numel()))
-            self.list_ptr[d] = lp[:N + 1].to(I32).contiguous()
-            loc = inv[ent] - rowbase_d[batch_of_node[node_of_ent]]
-            self.list_local[d] = (loc.to(I32) if loc.numel() else torch.zeros(1, dtype=I32, device=dev)).contiguous()
-        # ---- tiles and roles (host) --------------------------------------------------------------------------------------------
-        TR = 32
-        ub, ur = np.divmod(np.flatnonzero(unit_cnt > 0), R)          # non-empty units in (batch, relation) order
-        ucnt = unit_cnt[ub * R + ur]
-        ubeg = unit_ptr[ub * R + ur]
-        need_t = np.zeros(B, dtype=np.int64)                         # T tiles per batch (every tile signals)
-        cb_tiles = -(-(bnode[1:] - bnode[:-1]) // TR)                # closing tiles per batch
-        roles = np.zeros((groups * roles_per_group, 4), dtype=np.int32)
-        roles[:, 0] = 2                                              # idle unless assigned
-        tile_chunks = []
-        ntile = 0
-        S = roles_per_group
-        for g in range(groups):
-            bsel = np.flatnonzero(bgroup == g)
-            if bsel.size == 0:
-                continue
-            b0, b1 = int(bsel[0]), int(bsel[-1]) + 1
-            um = (ub >= b0) & (ub < b1)
-            gub, gur, gcnt, gbeg = ub[um], ur[um], ucnt[um], ubeg[um]
-            gtiles = -(-gcnt // TR)
-            rels = np.unique(gur)
-            t_work = np.array([gtiles[gur == r].sum() for r in rels], dtype=np.float64)
-            c_work = float(cb_tiles[b0:b1].sum()) * PIPE_C_WEIGHT
-            nq = len(rels) + 1
-            if nq <= S:
-                work = np.concatenate([t_work, [c_work]])
-                m = np.maximum(1, np.floor(work / work.sum() * S)).astype(np.int64)
-                while m.sum() > S:
-                    m[np.argmax(m)] -= 1
-                while m.sum() < S:                                   # hand the rest to whoever carries most work per role
-                    m[np.argmax(work / m)] += 1
-                m_t, m_c = m[:-1], int(m[-1])
-                role_base = np.concatenate([[0], np.cumsum(m_t)])
-                rel_slot = {int(r): (int(role_base[i]), int(m_t[i])) for i, r in enumerate(rels)}
-                c_base = int(role_base[-1])
-            else:                                                    # more relations than roles: several relations per T role
-                m_c = max(1, S // 4)
-                n_t = S - m_c
-                rel_slot = {int(r): (i % n_t, 1) for i, r in enumerate(rels)}
-                c_base = n_t
-            # T tiles of this group: the tiles of a relation are dealt round-robin (batch-major) to that relation's roles, so a
-            # large unit (the self loop: one row per node) is worked on by several roles at once; every tile signals for itself
-            if gub.size:
-                t_unit = np.repeat(np.arange(gub.size), gtiles)
-                t_k = np.arange(t_unit.size) - np.repeat(np.cumsum(gtiles) - gtiles, gtiles)
-                tbeg = gbeg[t_unit] + TR * t_k
-                tend = np.minimum(tbeg + TR, gbeg[t_unit] + gcnt[t_unit])
-                trel, tbatch = gur[t_unit], gub[t_unit]
-                # rank of every tile inside its relation (tiles are (batch, relation)-major here)
-                o_rel = np.argsort(trel, kind="stable")
-                rank = np.empty(t_unit.size, dtype=np.int64)
-                rel_sorted = trel[o_rel]
-                starts_rel = np.concatenate([[0], np.flatnonzero(np.diff(rel_sorted)) + 1])
-                rank[o_rel] = np.arange(t_unit.size) - np.repeat(starts_rel, np.diff(np.concatenate([starts_rel, [t_unit.size]])))
-                base = np.array([rel_slot[int(r)][0] for r in rels])[np.searchsorted(rels, trel)]
-                mm = np.array([rel_slot[int(r)][1] for r in rels])[np.searchsorted(rels, trel)]
-                trole = base + rank % mm
-                o = np.argsort(trole, kind="stable")                 # batch-major inside a role
-                tb_o, tr_o = tbatch[o], trole[o]
-                firstf = np.ones(o.size, dtype=np.int64)
-                same = (tr_o[1:] == tr_o[:-1]) & (tb_o[1:] == tb_o[:-1])
-                firstf[1:][same] = 0
-                flags = trel[o] | (firstf << 16) | (1 << 17)
-                tt = np.stack([tbeg[o], tend[o], tb_o, flags], 1)
-                cnts = np.bincount(trole, minlength=S)
-                starts = ntile + np.concatenate([[0], np.cumsum(cnts)])
-                for rsl in range(S):
-                    if cnts[rsl]:
-                        roles[g * S + rsl] = (0, starts[rsl], starts[rsl + 1], 0)
-                tile_chunks.append(tt)
-                ntile += tt.shape[0]
-                need_t += np.bincount(tbatch, minlength=B)
-            # C tiles: all node tiles of the group, batch-major, dealt round-robin to the C roles
-            cbt = cb_tiles[b0:b1]
-            c_batch = np.repeat(np.arange(b0, b1), cbt)
-            c_k = np.arange(c_batch.size) - np.repeat(np.cumsum(cbt) - cbt, cbt)
-            cbeg = bnode[c_batch] + TR * c_k
-            cend = np.minimum(cbeg + TR, bnode[c_batch + 1])
-            crole = np.arange(c_batch.size) % m_c
-            o = np.argsort(crole, kind="stable")
-            cb_o, crole_o = c_batch[o], crole[o]
-            firstf = np.ones(o.size, dtype=np.int64)
-            same = (crole_o[1:] == crole_o[:-1]) & (cb_o[1:] == cb_o[:-1])
-            firstf[1:][same] = 0
-            ct = np.stack([cbeg[o], cend[o], cb_o, firstf << 16], 1)
-            cnts = np.bincount(crole, minlength=m_c)
-            starts = ntile + np.concatenate([[0], np.cumsum(cnts)])
-            for j in range(m_c):
-                if cnts[j]:
-                    roles[g * S + c_base + j] = (1, starts[j], starts[j + 1], 0)
-            tile_chunks.append(ct)
-            ntile += ct.shape[0]
-        tiles = np.concatenate(tile_chunks, 0) if tile_chunks else np.zeros((0, 4), dtype=np.int64)
-        self.num_tiles = int(tiles.shape[0])
-        self.tiles = torch.from_numpy(np.ascontiguousarray(tiles.astype(np.int32))).to(dev) if self.num_tiles else torch.zeros((1, 4), dtype=I32, device=dev)
-        self.roles = torch.from_numpy(roles).to(dev)
-        bt = np.zeros((max(B, 1), 8), dtype=np.int32)
-        if B:
-            bt[:, 0] = rowbase
-            bt[:, 1] = (bgroup * depth + blocal % depth) * slot_rows
-            bt[:, 2] = cb_tiles
-            bt[:, 3] = np.where(blocal >= depth, np.arange(B) - depth, -1)
-            bt[:, 4] = need_t
-        self.batches = torch.from_numpy(bt).to(dev)
-        self.sync = torch.zeros(int(lib().dn_rows_pipe_sync_words(B)), dtype=I32, device=dev)
-        self._ring = {}
-        self.disabled = False
-        self.stats = None                                # an int64 [8 * roles_per_group, 8] tensor collects launch statistics
-        self.checks_left = {"f": 2, "b": 2}
-
-    def ring(self, H, dtype, dev):
-        key = (H, dtype)
-        r = self._ring.get(key)
-        if r is None:
-            r = torch.empty((max(self.ring_rows, 1), H), dtype=dtype, device=dev)
-            self._ring[key] = r
-        return r
-
-    def aborted(self):
-        """Abort word of the last launch (synchronises)."""
-        return int(self.sync[2 * self.num_batches + 8].item())
-
-
-def rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):
-    """dn_rows_pipe_bf16: the whole direction in one persistent launch.  Returns False when the launch reported an abort."""
-    require_gpu(xs, aux, Wmat, bias, out)
-    N, H = xs.shape
-    ring = pipe.ring(H, xs.dtype, xs.device)
-    n1 = N if aux is not None else INT32_MAX
-
-    def _launch():
-        check(lib().dn_rows_pipe_bf16(ptr(xs), ptr(aux), n1, ptr(pipe.row_idx[direction]), H, ptr(Wmat), ptr(bias),
-                                      ptr(pipe.roles), pipe.num_groups, pipe.roles_per_group,
-                                      ptr(pipe.tiles), pipe.num_tiles, ptr(pipe.batches), pipe.num_batches,
-                                      ptr(pipe.list_ptr[direction]), ptr(pipe.list_local[direction]), ptr(ring), ptr(pipe.sync),
-                                      N, ptr(out), PIPE_TIMEOUT_MS, ptr(pipe.stats), stream_ptr()), "dn_rows_pipe_bf16")
-    if kernel_timer is not None:
-        kernel_timer.launch("rows_pipe", _launch)
-    else:
-        _launch()
-    if pipe.checks_left[direction] > 0 and not torch.cuda.is_current_stream_capturing():
-        pipe.checks_left[direction] -= 1
-        code = pipe.aborted()
-        if code != 0:
-            pipe.disabled = True
-            import sys
-            sys.stderr.write("[dn_hip] dn_rows_pipe_bf16 aborted (code %d: %s); falling back to the two-launch path\n"
-                             % (code, "workgroups of a group on different XCDs" if code == 1 else "hand-off timeout"))
-            return False
-    return True
-
-
-def _pipe_of(ix, xs):
-    p = getattr(ix, "pipe", None)
-    if p is None or p.disabled or not PIPE_ENABLED or xs.dtype != torch.bfloat16 or not ix.self_loop:
-        return None
-    return p
 
 
 def _selfsum_ok(ix, x):
@@ -1604,9 +1230,6 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
     if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction) is not None:
         return _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows)
     aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
-    pipe = _pipe_of(ix, xs)
-    if pipe is not None and rows_pipe(xs, aux, Wmat, bias, pipe, direction, out):
-        return aux
     if _selfsum_ok(ix, xs):
         P = ix.num_edge_rows
         Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
@@ -1625,7 +1248,7 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
 
 class _RowTransformFn(torch.autograd.Function):
     """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop), evaluated
-    sub-batch by sub-batch (RowIndexSet; one part unless DN_SUBBATCH_NODES is set)."""
+    over the parts of a RowIndexSet (one part)."""
 
     @staticmethod
     def forward(ctx, x, W_all, bias, index_set):

@@ -65,29 +65,6 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                           const float* scale, const int32_t* ptr, int64_t S, int64_t M, void* out,
                           const void* self_in, float self_coef, int32_t mean, dn_stream_t stream);
 
-/* Tile table for dn_gather_segsum_window_*, built on the HOST from the batch's graph boundaries (node_ptr_host [num_graphs + 1],
- * host memory): greedy runs of whole graphs with at most rows_per_window rows; a graph larger than a window is cut every
- * rows_per_window rows.  tile_ptr_host receives num_tiles + 1 bounds (capacity entries available; num_graphs +
- * rows / rows_per_window + 2 always suffice).  Pure host code: no stream, no device access. */
-int dn_window_tiles_host(const int32_t* node_ptr_host, int64_t num_graphs, int32_t rows_per_window, int32_t* tile_ptr_host,
-                         int64_t capacity, int64_t* num_tiles);
-
-/* Graph-local gather streamed through LDS windows:  out[s, :] = self_coef * in[s, :] + sum_i scale[i] * in[idx[i], :]  over
- * segment s = [ptr[s], ptr[s+1]) -- dn_gather_segsum_* for the case "segment s <-> row s of `in`, neighbours inside the same
- * graph" (the reference's GINConv / GCNConv / SAGEConv propagate over a batch of small graphs, gconv.py:20-215, and DGL's
- * update_all, rgin.py:137): tile t = rows [tile_ptr[t], tile_ptr[t+1]) is a run of whole graphs, tile_eptr[t] = ptr[tile_ptr[t]]
- * its first index entry (both [num_tiles + 1], device).  Any partition is CORRECT: rows, neighbours or index entries that do
- * not fit the 40 KB window / the staged 1024 entries of a tile are read from global memory.  Every row of a tile reaches the
- * CU once (LDS-DMA, ring of three windows) instead of once per edge through L2.
- * Same summation order as dn_gather_segsum_*: bitwise equal results.  Rows must be 128 bytes .. 1 KiB, H a multiple of 4
- * (f32) / 8 (bf16), in/out 16-byte aligned; scale may be NULL. */
-int dn_gather_segsum_window_f32(const float* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
-                                const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, float* out,
-                                float self_coef, dn_stream_t stream);
-int dn_gather_segsum_window_bf16(const void* in, int32_t H, const int32_t* idx, const float* scale, const int32_t* ptr,
-                                 const int32_t* tile_ptr, const int32_t* tile_eptr, int64_t num_tiles, void* out,
-                                 float self_coef, dn_stream_t stream);
-
 /* Per-graph readouts over CONTIGUOUS rows: out[g,:] = reduce_{v in [ptr[g], ptr[g+1])} in[v,:].
  * Replaces: torch_geometric global_add_pool / global_mean_pool / global_max_pool
  *   (gconv.py:53,95,148,210,213; rgconv.py:42,119,124) and SI SumPredictNet's sum over the padded
@@ -394,37 +371,6 @@ int dn_fold_tables_build_async_i32(int64_t N, int64_t num_segments, const int32_
  * fp32 product is added to the bf16 row and rounded once).  H in {64, 128, 256}. */
 int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_segments, int32_t H, const void* Wn,
                       const int32_t* idx, void* aux, void* out, dn_stream_t stream);
-
-/* One direction of the row-factorised message pass as ONE persistent launch in which the transformed edge rows travel from
- * their producers to their consumers through the XCD's L2 instead of HBM (csrc/dn_pipe.hip has the design note):
- *   out[v] = (bias) + sum_{p in list(v)} ( Xcat[row_idx[p]] @ Wn[rel(p)]^T )      (the self loop is one more relation:
- *   one row per node with row_idx = the node)
- * Replaces, like dn_rows_transform_bf16 + dn_rows_selfsum_bf16 together, the per-edge transform, the fn.sum reduce and the
- * self-loop / bias update of subgraph_isomorphism/models/rgin.py:102-120,137-145 (and their autograd mirror for the input
- * gradient: X = grad rows, Wn = un-transposed weights, lists by source).
- * The caller cuts the batch into `num_groups` (<= 8, one per XCD) contiguous ranges of graphs and each range into batches:
- *   tiles   [num_tiles][4]  {beg, end, batch, rel | first << 16 | last << 17}: a T tile covers edge rows [beg, end) (<= 32) of
- *           one (batch, relation) unit, an S tile covers nodes [beg, end) (<= 64) of one batch; first / last mark the role's
- *           first / last tile of that unit (S tiles: first tile of the batch in the role's sequence).
- *   roles   [num_groups * roles_per_group][4]  {kind (0 T, 1 S, else idle), tile_beg, tile_end, 0}: the tile sequence of each
- *           workgroup, batches in increasing order.  Workgroup b of the grid serves group b % 8, role b / 8.
- *   batches [num_batches][8]  {rowbase, ringoff, need_c, wait_batch, need_t, 0, 0, 0}: first edge row of the batch, first ring
- *           row of its slot, number of S tiles, the batch whose S tiles must have finished before this batch's ring slot
- *           may be written (-1: none), number of T units that signal for it.
- *   list_ptr [N+1] / list_local: per-node CSR of the rows summed into the node, as row ids RELATIVE to the batch's rowbase.
- *   ring: [ring_rows][H] bf16 scratch (sum over groups of slots x rows per slot); sync: dn_rows_pipe_sync_words(num_batches)
- *   int32 words, zeroed by the call; after the launch sync[2*num_batches + 8] != 0 means the launch ABORTED (the workgroups
- *   of a group were not on one XCD, or a hand-off waited longer than timeout_ms): `out` is then undefined and the caller
- *   must recompute it with dn_rows_transform_bf16 + dn_rows_selfsum_bf16.  The launch cannot hang.
- * stats (may be NULL): int64 [8 * roles_per_group][8] per workgroup {ticks in the launch, ticks waiting on a hand-off,
- * tiles, kind, ticks in four sections of the tile loop} at 100 MHz -- a tuning aid.
- * H in {64, 128, 256}; roles_per_group <= 64 (two 512-thread workgroups per CU must be co-resident). */
-size_t dn_rows_pipe_sync_words(int64_t num_batches);
-int dn_rows_pipe_bf16(const void* X, const void* X2, int32_t n1, const int32_t* row_idx, int32_t H, const void* Wn,
-                      const void* bias, const int32_t* roles, int32_t num_groups, int32_t roles_per_group,
-                      const int32_t* tiles, int64_t num_tiles, const int32_t* batches, int64_t num_batches,
-                      const int32_t* list_ptr, const int32_t* list_local, void* ring, int32_t* sync, int64_t N, void* out,
-                      int32_t timeout_ms, int64_t* stats, dn_stream_t stream);
 
 /* Two dense layers in one pass over the rows (bf16 in, fp32 acc, bf16 out):
  *   Y1 = epi1(m0(X) @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)

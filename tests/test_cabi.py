@@ -70,21 +70,9 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, None)
     assert rc == -1 and b"fold_info needs seg_part" in L.dn_last_error()
-    rc = L.dn_gather_segsum_window_f32(None, 20, None, None, None, None, None, 3, None, 0.0, None)
-    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_gather_segsum_window_f32(ctypes.c_void_p(16), 20, ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16),
-                                       ctypes.c_void_p(16), 3, ctypes.c_void_p(16), 0.0, None)
-    assert rc == -1 and b"rows must be 128 bytes" in L.dn_last_error()
     rc = L.dn_batchnorm_rows_f32(ctypes.c_void_p(16), 8, 64, None, None, 1e-5, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
                                  ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0.1, 0, ctypes.c_void_p(16), 1 << 20, None)
     assert rc == -1 and b"running_mean and running_var come together" in L.dn_last_error()
-    # host-side tile packing needs no GPU at all
-    npt = (ctypes.c_int32 * 5)(0, 3, 3, 10, 12)
-    out = (ctypes.c_int32 * 16)()
-    n = ctypes.c_int64(0)
-    assert L.dn_window_tiles_host(npt, 4, 4, out, 16, ctypes.byref(n)) == 0
-    assert n.value == 4 and list(out[:5]) == [0, 3, 7, 10, 12]            # {g0, g1}, g2 cut at 4 rows: [3,7) [7,10), {g3}
-    assert L.dn_window_tiles_host(npt, 4, 4, out, 2, ctypes.byref(n)) == -3 and b"tile table too small" in L.dn_last_error()
 
 
 def test_local_index_and_async_table_entry_points_check_their_arguments(lib):

@@ -441,80 +441,6 @@ def test_index_builds_reject_out_of_range_edge_types():
     ops.RowIndex(src, dst, torch.tensor([0, 2, 1], device=DEV), 3, 3)
 
 
-@pytest.mark.parametrize("dt,H", [(torch.float32, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float32, 256),
-                                  (torch.bfloat16, 64), (torch.float32, 32)])
-def test_window_gather_is_bitwise_equal_to_the_plain_kernel(dt, H):
-    """dn_gather_segsum_window_* (rows of a tile streamed into LDS windows by LDS-DMA) against dn_gather_segsum_*: graph-local
-    edges, edges that leave the tile, empty segments, long lists (more entries than a tile stages), tiles longer than a window,
-    a per-edge scale, the self term, more tiles than workgroups and fewer -- identical bits (same summation order)."""
-    ops = _ops()
-    rng = np.random.default_rng(H)
-    sizes = np.concatenate([rng.integers(1, 70, size=400), [700, 1, 1, 333], rng.integers(20, 50, size=300)])
-    node_ptr = np.concatenate([[0], np.cumsum(sizes)])
-    N = int(node_ptr[-1])
-    gid = np.repeat(np.arange(len(sizes)), sizes)
-    deg = rng.integers(0, 9, size=N)
-    deg[::97] = 70                                           # a few long lists (more than one index round)
-    deg[node_ptr[400]] = 2500                                # one list longer than the entries a tile stages
-    ptr_ = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
-    E = int(ptr_[-1])
-    seg = np.repeat(np.arange(N), deg)
-    local = node_ptr[gid[seg]] + (rng.random(E) * sizes[gid[seg]]).astype(np.int64)      # inside the segment's own graph
-    far = rng.integers(0, N, size=E)
-    idx = np.where(rng.random(E) < 0.9, local, far).astype(np.int32)
-    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dt).to(DEV)
-    sc = torch.from_numpy(rng.random(E).astype(np.float32)).to(DEV)
-    p_d, i_d = torch.from_numpy(ptr_).to(DEV), torch.from_numpy(idx).to(DEV)
-    rowb = H * x.element_size()
-    tiles = ops.window_tiles(torch.from_numpy(node_ptr).to(DEV), N, ops.WINDOW_BYTES // rowb)
-    tp = tiles[0].cpu().numpy()
-    assert tp[0] == 0 and tp[-1] == N and (np.diff(tp) > 0).all() and len(tp) == tiles[1] + 1
-    assert np.diff(tp).max() <= ops.WINDOW_BYTES // rowb + sizes.max()
-    one_tile = (torch.tensor([0, N], dtype=torch.int32, device=DEV), 1)                  # any partition is correct
-    for scale in (None, sc):
-        for coef in (0.0, 1.3):
-            b = ops.gather_segsum(x, i_d, p_d, N, scale=scale, self_in=x if coef else None, self_coef=coef)
-            for tl in (tiles, one_tile):
-                a = ops.gather_segsum_window(x, i_d, p_d, tl, scale=scale, self_coef=coef)
-                assert torch.equal(a, b)
-
-
-def test_neighbor_sum_takes_the_window_path_on_a_batch_with_graph_boundaries():
-    """EdgeIndex(node_ptr=...) -> neighbor_sum forward and backward through dn_gather_segsum_window_*; same bits as without."""
-    ops = _ops()
-    rng = np.random.default_rng(5)
-    sizes = rng.integers(5, 60, size=300)
-    node_ptr = np.concatenate([[0], np.cumsum(sizes)])
-    N, H = int(node_ptr[-1]), 128
-    src, dst = [], []
-    for g, n in enumerate(sizes):
-        m = 4 * n
-        src += list(node_ptr[g] + rng.integers(0, n, size=m)); dst += list(node_ptr[g] + rng.integers(0, n, size=m))
-    s, d = torch.tensor(src, device=DEV), torch.tensor(dst, device=DEV)
-    x = torch.randn(N, H, device=DEV)
-    go = torch.randn(N, H, device=DEV)
-    res = []
-    old_flag, ops.WINDOW_GATHER = ops.WINDOW_GATHER, True            # (opt-in path: see ops.WINDOW_GATHER)
-    old_tile, ops.TILE_SUM_ENABLED = ops.TILE_SUM_ENABLED, False     # (the matrix-core tile path would take these batches first)
-    for npt in (torch.from_numpy(node_ptr).to(DEV), None):
-        ix = ops.EdgeIndex(s, d, N, node_ptr=npt)
-        assert (ix.fwd.tiles_of is not None) == (npt is not None)
-        xd = x.clone().requires_grad_(True)
-        timer = ops.KernelTimer()
-        ops.kernel_timer = timer
-        try:
-            out = ops.neighbor_sum(xd, ix, 1.0)
-            out.backward(go)
-        finally:
-            ops.kernel_timer = None
-        tags = [r[0] for r in timer.records]
-        assert ("gather_segsum_window" in tags) == (npt is not None), tags
-        res.append((out.detach(), xd.grad))
-    ops.WINDOW_GATHER = old_flag
-    ops.TILE_SUM_ENABLED = old_tile
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K,N", [(8, 64), (38, 256), (32, 32), (100, 7), (64, 64)])
 def test_any_width_grouped_products_match_per_relation_matmuls(K, N, dt):
@@ -719,35 +645,3 @@ def test_fold_is_refused_when_a_graph_is_not_a_contiguous_node_range():
         0, torch.tensor(dst), torch.bmm(x.cpu().double()[torch.tensor(src)].unsqueeze(1), W.cpu().double()[torch.tensor(et)]).squeeze(1))
     ref = ref + x.cpu().double() @ W.cpu().double()[R + 1]
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-2
-
-
-def test_fold_inside_sub_batches_matches_the_single_part_index():
-    """RowIndexSet cut into several parts (each part folds its own dummy relation, tiles restart at every part) against the one-part
-    index: same layer output and gradients up to bf16 rounding of the per-part sums."""
-    ops = _ops()
-    rng = np.random.default_rng(11)
-    sizes = list(rng.integers(3, 50, size=120))
-    R, H = 4, 128
-    src, dst, et, N = _dummy_batch(rng, sizes, R)
-    node_ptr = np.concatenate([[0], np.cumsum(np.array(sizes) + 1)])
-    order = np.argsort(np.searchsorted(node_ptr, src, side="right"), kind="stable")      # edges graph by graph
-    src, dst, et = src[order], dst[order], et[order]
-    edge_ptr = np.concatenate([[0], np.cumsum(np.bincount(np.searchsorted(node_ptr, src, side="right") - 1, minlength=len(sizes)))])
-    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
-    x, coef = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((N, H)))
-    W = bf(rng.standard_normal((R + 3, H, H)) / np.sqrt(H))
-    b = bf(rng.standard_normal(H))
-    s, d, t = (torch.from_numpy(a).to(DEV) for a in (src, dst, et))
-    res = []
-    for target in (1 << 62, 400):
-        iset = ops.RowIndexSet(s, d, t, N, R + 2, True, node_ptr=torch.from_numpy(node_ptr).to(DEV), edge_ptr=torch.from_numpy(edge_ptr).to(DEV),
-                               target_nodes=target)
-        xd, Wd, bd = (v.to(DEV).requires_grad_(True) for v in (x, W, b))
-        out = ops.rel_transform_fused(xd, Wd, bd, iset)
-        out.backward(coef.to(DEV))
-        folded = [ops._row_index_fold(ix, k) is not None for _, _, ix in iset.parts for k in "fb"]
-        res.append((len(iset.parts), folded, [v.detach().float().cpu() for v in (out, xd.grad, Wd.grad, bd.grad)]))
-    # (a small part may see an ordinary relation collapse too -- two AGG relations -- and then keeps the separate pass: legitimate)
-    assert res[0][0] == 1 and all(res[0][1]) and res[1][0] >= 4 and sum(res[1][1]) >= len(res[1][1]) // 2
-    for name, a, c in zip(("out", "gx", "gW", "gb"), res[0][2], res[1][2]):
-        assert float((a - c).abs().max() / a.abs().max()) < 2e-2, name

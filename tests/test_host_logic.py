@@ -201,27 +201,3 @@ def test_tu_reader_rejects_multi_column_attribute_files(tmp_path):
         tu_io.read_raw(str(d))
 
 
-def test_window_tiles_pack_whole_graphs_greedily():
-    """ops.window_tiles (dn_window_tiles_host, pure host code): tiles are runs of whole graphs that fit the window, graphs larger
-    than a window are cut every window-full, empty graphs cost nothing, and the bounds cover the rows exactly."""
-    from dummynode4graphlearning_amd import ops
-    rng = np.random.default_rng(0)
-    for W in (1, 7, 80, 320):
-        sizes = np.concatenate([rng.integers(0, 70, size=500), [700, 0, 0, 333]])
-        npt = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-        tile_ptr, T = ops.window_tiles(torch.from_numpy(npt), int(npt[-1]), W)
-        tp = tile_ptr.numpy()
-        assert tp[0] == 0 and tp[-1] == npt[-1] and (np.diff(tp) > 0).all() and len(tp) == T + 1
-        assert np.diff(tp).max() <= W
-        starts = set(npt.tolist())
-        inside_big = set()
-        for g in range(len(sizes)):
-            if sizes[g] > W:
-                inside_big.update(range(npt[g] + 1, npt[g + 1]))
-        assert all(b in starts or b in inside_big for b in tp.tolist())
-        # greedy: no two neighbouring tiles that are both runs of whole graphs could have been merged
-        for i in range(T - 1):
-            if tp[i + 1] in starts and tp[i] in starts and tp[i + 2] in starts:
-                assert tp[i + 2] - tp[i] > W
-    t, n = ops.window_tiles(torch.zeros(1, dtype=torch.int32), 0, 16)
-    assert n == 0 and t.tolist() == [0]
