@@ -77,7 +77,7 @@ def build_batch(dev, seed, graphs, workload, shard=None):
     bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
     bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
     g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, ndata={"id": aug["node_id"], "label": aug["node_label"]},
-                     edata={"id": aug["edge_id"], "label": aug["edge_label"]})
+                     edata={"id": aug["edge_id"], "label": aug["edge_label"]}, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
     return g, raw, aug_ms
 
 

@@ -397,7 +397,8 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int32_t* __restrict__ row_out,
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
     int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
-    int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr */) {
+    int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr, [R] modes, status */,
+    const int32_t* __restrict__ bad) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -422,6 +423,9 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
             src_ptr[N] = tb_; src_ptr[N + 1] = tb_;
         }
         if (threadIdx.x <= R) meta[5 + threadIdx.x] = threadIdx.x < R ? (G > 0 ? A.S0[(int64_t)threadIdx.x * G] : 0) : P;
+        // modes and the verdict ride in the same block: ONE device -> host copy per build (both are final before this launch)
+        if (threadIdx.x < R) meta[5 + R + 1 + threadIdx.x] = mode[threadIdx.x];
+        if (threadIdx.x == 0) meta[5 + 2 * R + 1] = *bad;
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1, e0;
@@ -472,7 +476,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
     w.hbits = (uint8_t*)take((size_t)E);
-    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + kLocR + 1));
+    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 2));
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
                                 rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) {
@@ -527,17 +531,15 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                          rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
                        dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
-                       src_ptr, src_rows, w.meta);
+                       src_ptr, src_rows, w.meta, w.bad);
     DN_CHECK_LAUNCH();
-    int32_t h_meta[5 + kLocR + 1], h_mode[kLocR], h_bad = 0;
-    DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + R + 1), hipMemcpyDeviceToHost, st));
-    DN_CHECK_HIP(hipMemcpyAsync(h_mode, w.mode, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, st));
-    DN_CHECK_HIP(hipMemcpyAsync(&h_bad, w.bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t h_meta[5 + 2 * kLocR + 2];
+    DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 2), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
-    *host_status = h_bad;
+    *host_status = h_meta[5 + 2 * R + 1];
     for (int k = 0; k < 5; ++k) host_counts[k] = h_meta[k];
     for (int64_t r = 0; r <= R; ++r) host_rel_ptr[r] = h_meta[5 + r];
-    for (int64_t r = 0; r < R; ++r) host_modes[r] = h_mode[r];
+    for (int64_t r = 0; r < R; ++r) host_modes[r] = h_meta[5 + R + 1 + r];
     return DN_OK;
 }
 

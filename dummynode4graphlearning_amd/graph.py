@@ -29,7 +29,10 @@ class _IndexCache:
 
 
 class BatchedGraph:
-    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, batch_num_edges=None, ndata=None, edata=None):
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, batch_num_edges=None, ndata=None, edata=None,
+                 node_ptr=None, edge_ptr=None):
+        """node_ptr / edge_ptr (optional, [G + 1] each): the batch's graph boundaries when the caller already has them (e.g.
+        from transforms.dummy_augment_si): kept as they are instead of being rebuilt from the counts (8 small launches)."""
         self._src = torch.as_tensor(src).reshape(-1)
         self._dst = torch.as_tensor(dst).reshape(-1)
         self._n = int(num_nodes)
@@ -40,6 +43,8 @@ class BatchedGraph:
         self.ndata = dict(ndata or {})
         self.edata = dict(edata or {})
         self._cache = _IndexCache()
+        self._node_ptr = None if node_ptr is None else torch.as_tensor(node_ptr).to(dev).to(torch.int32).contiguous()
+        self._edge_ptr = None if edge_ptr is None else torch.as_tensor(edge_ptr).to(dev).to(torch.int32).contiguous()
 
     # ---- DGL-like surface ---------------------------------------------------------------------
     @property
@@ -89,7 +94,8 @@ class BatchedGraph:
         g = BatchedGraph(self._src.to(device, non_blocking=non_blocking), self._dst.to(device, non_blocking=non_blocking),
                          self._n, self._bnn.to(device), self._bne.to(device),
                          {k: v.to(device, non_blocking=non_blocking) for k, v in self.ndata.items()},
-                         {k: v.to(device, non_blocking=non_blocking) for k, v in self.edata.items()})
+                         {k: v.to(device, non_blocking=non_blocking) for k, v in self.edata.items()},
+                         node_ptr=self._node_ptr, edge_ptr=self._edge_ptr)
         return g
 
     def local_var(self):
@@ -97,12 +103,17 @@ class BatchedGraph:
 
     # ---- index structures consumed by the kernels -----------------------------------------------
     def node_ptr(self):
-        z = torch.zeros(1, dtype=torch.long, device=self._bnn.device)
-        return torch.cat([z, torch.cumsum(self._bnn, 0)]).to(torch.int32)
+        """Graph boundaries of the batch (a property of the batch, not of an index: computed once and kept)."""
+        if self._node_ptr is None:
+            z = torch.zeros(1, dtype=torch.long, device=self._bnn.device)
+            self._node_ptr = torch.cat([z, torch.cumsum(self._bnn, 0)]).to(torch.int32)
+        return self._node_ptr
 
     def edge_ptr(self):
-        z = torch.zeros(1, dtype=torch.long, device=self._bne.device)
-        return torch.cat([z, torch.cumsum(self._bne, 0)]).to(torch.int32)
+        if self._edge_ptr is None:
+            z = torch.zeros(1, dtype=torch.long, device=self._bne.device)
+            self._edge_ptr = torch.cat([z, torch.cumsum(self._bne, 0)]).to(torch.int32)
+        return self._edge_ptr
 
     def edge_index(self):
         if self._cache._edge_index is None:

@@ -1055,12 +1055,31 @@ class RowIndex:
         # tile / chunk tables on the device (the 18 relation offsets go up in one small copy; no host loops)
         rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
         self.rel_ptr_dev = rel_ptr_d                                # (reused by the fold tables: one upload per batch)
-        self.tile_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, 32)
-        self.edge_tile_table = build_row_tables(rel_ptr_d, R, P, 32) if self_loop else self.tile_table
+        self._tile_table = self._edge_tile_table = None             # built on first use: the folded bf16 path needs neither
         self._slots, self._fold = {}, {}
         # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size:
         # the smallest chunk that keeps ALL relations' chunks (each relation ends in a partial one) within one round of 256
         self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
+
+
+def _row_index_tile_table(ix):
+    """Tile table of ALL rows (the self loop as relation R): the path without the fused closing launch."""
+    if ix._tile_table is None:
+        ix._tile_table = build_row_tables(ix.rel_ptr_dev, ix.num_all_rels, ix.num_rows, 32)
+    return ix._tile_table
+
+
+def _row_index_edge_tile_table(ix):
+    """Tile table of the edge rows (relations 0 .. R-1): closing launch without a folded relation."""
+    if not ix.self_loop:
+        return _row_index_tile_table(ix)
+    if ix._edge_tile_table is None:
+        ix._edge_tile_table = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32)
+    return ix._edge_tile_table
+
+
+RowIndex.tile_table = property(_row_index_tile_table)
+RowIndex.edge_tile_table = property(_row_index_edge_tile_table)
 
 
 def _fold_candidate(ix, direction):
