@@ -24,6 +24,16 @@ def _reset(module):
             item.reset_parameters()
 
 
+class HipLinear(nn.Linear):
+    """torch.nn.Linear (same parameters, names and initialisation) whose forward / backward run on the HIP path for 2-D GPU
+    inputs: matrix cores for the square hidden layers, the any-width kernels for F -> H and H -> classes."""
+
+    def forward(self, x):
+        # exact fp32 products: at these batch sizes (10-20 k rows) the dense layers are a few microseconds either way, and the
+        # BatchNorm / Adam steps behind them amplify the 1e-5 noise of the bf16 split into visible trajectory differences
+        return ops.linear_any(x, self.weight, self.bias, exact="fwd")
+
+
 class GINConv(nn.Module):
     def __init__(self, nn_module, eps=0.0, train_eps=False):
         super().__init__()
@@ -114,7 +124,7 @@ class GCNConv(nn.Module):
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.lin = HipLinear(in_channels, out_channels, bias=False)
         if bias:
             self.bias = nn.Parameter(torch.empty(out_channels))
         else:
@@ -138,7 +148,9 @@ class GCNConv(nn.Module):
             if not bool(keep.all()):
                 loop_w = loop_w.index_put((data.edge_index[0][~keep],), ew[~keep])
             w = torch.cat([ew[keep], loop_w])
-        deg = torch.zeros(N, dtype=torch.float32, device=x.device).index_add(0, index.dst.long(), w)
+        # weighted in-degree through the CSR gather (ops.edge_sum: fixed summation order per node, no float atomics -- the
+        # trainable dummy-edge weight flows through it, so torch's index_add would make the step non-reproducible)
+        deg = ops.edge_sum(w.view(-1, 1), index).view(-1)
         dis = deg.pow(-0.5)
         dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
         norm = dis[index.src.long()] * w * dis[index.dst.long()]
@@ -153,8 +165,8 @@ class SAGEConv(nn.Module):
     def __init__(self, in_channels, out_channels, aggr="mean"):
         super().__init__()
         self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
-        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
-        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+        self.lin_l = HipLinear(in_channels, out_channels, bias=True)
+        self.lin_r = HipLinear(in_channels, out_channels, bias=False)
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch.nn import BatchNorm1d, Identity, Linear, ReLU, Sequential
 
 from .. import ops
-from .conv import GCNConv, GINConv, RGCNConv, SAGEConv, global_add_pool, global_max_pool, global_mean_pool
+from .conv import GCNConv, GINConv, HipLinear, RGCNConv, SAGEConv, global_add_pool, global_max_pool, global_mean_pool
 
 
 def _pooling(config):
@@ -21,16 +21,6 @@ def _pooling(config):
     if kind == "mean":
         return global_mean_pool
     raise ValueError("aggregation must be 'sum' or 'mean'")
-
-
-class HipLinear(Linear):
-    """torch.nn.Linear (same parameters, names and initialisation) whose forward / backward run on the HIP path for 2-D GPU
-    inputs: matrix cores for the square hidden layers, the any-width kernels for F -> H and H -> classes."""
-
-    def forward(self, x):
-        # exact fp32 products: at these batch sizes (10-20 k rows) the dense layers are a few microseconds either way, and the
-        # BatchNorm / Adam steps behind them amplify the 1e-5 noise of the bf16 split into visible trajectory differences
-        return ops.linear_any(x, self.weight, self.bias, exact="fwd")
 
 
 class HipBatchNorm1d(BatchNorm1d):

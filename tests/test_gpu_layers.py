@@ -465,6 +465,85 @@ def test_full_size_config5_layer_through_batch_properties():
             assert _rel_l2(gw_a[k] + gw_b[k], gw_f[k]) < 2e-2, k
 
 
+def test_default_bf16_pipeline_on_2048_config5_graphs_matches_fp64_with_the_same_storage_points():
+    """The pipeline bench.py times -- graph-local index builder, folded pre-aggregation, ring transform, fused closing launch,
+    two-layer chain with bit masks, LDS-DMA weight gradients -- on 2,048 config-5 graphs (N = 63,488, E = 249,856, R = 16,
+    H = 256, bf16) against the reference formulation (rgin.py:102-160: per-edge x[src] W[etype], sum by destination, self loop,
+    bias, Linear-ReLU-Linear, ReLU) evaluated in fp64 on the same bf16 parameters and inputs and rounded to bf16 at the points
+    where the GPU path stores a bf16 tensor (per-edge product rows, the collapsed relation's per-graph sum, the layer's
+    pre-MLP rows, both MLP activations); the rounding is transparent to autograd, so the fp64 gradients are those of the reference
+    at the forward values the GPU saw.  The two ReLUs use the GPU run's own sign patterns (its h1 / h2 > 0, recomputed with the
+    same deterministic launches): an element whose pre-activation lies within fp32 summation noise of 0 would otherwise switch
+    a whole row's gradient path in one of the two runs (measured without this: 0.13 of the maximum on a handful of rows).
+    Outputs and EVERY gradient: 2e-2 of the tensor's max, 5e-3 relative L2."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    G, H = 2048, 256
+    raw = synthetic.config5(seed=5, graphs=G)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"],
+                                      raw["max_ne"], raw["max_nel"])
+    R = raw["num_rels"]
+    N, E = int(aug["node_label"].numel()), int(aug["src"].numel())
+    assert (N, E) == (G * 31, G * 122)
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+    et = aug["edge_label"].long()
+    torch.manual_seed(23)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16).requires_grad_(True)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    out, _ = layer(g, x, et)
+    out.backward(coef)
+    ix = g.row_index(et, R, True).parts[0][2]
+    assert ix.built_by == "local" and ops._row_index_fold(ix, "f") is not None and ops._row_index_fold(ix, "b") is not None
+    agg_rel = ops._row_index_fold(ix, "f").rel                     # the collapsed relation of the forward pass (u -> dummy)
+
+    def r(t):                                                       # bf16 storage point, transparent to autograd
+        return t + (t.detach().to(torch.bfloat16).double() - t.detach())
+
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in layer.named_parameters()}
+    xr = x.detach().double().cpu().requires_grad_(True)
+    src, dst, etc = aug["src"].long().cpu(), aug["dst"].long().cpu(), et.cpu()
+    acc = r(xr @ p["loop_weight"] + p["bias"])                      # the closing launch stages the self-loop tile in bf16
+    fold_rows = None
+    for rel in range(R):
+        e = (etc == rel).nonzero().reshape(-1)
+        if e.numel() == 0:
+            continue
+        if rel == agg_rel:                                          # one row per destination: its input is the SUM of the sources,
+            d_u, inv = torch.unique(dst[e], return_inverse=True)    # rounded once; the product joins the output row afterwards
+            aux = r(torch.zeros(d_u.numel(), H, dtype=torch.float64).index_add(0, inv, xr[src[e]]))
+            fold_rows = (d_u, aux @ p["weight"][rel])
+        else:
+            acc = acc.index_add(0, dst[e], r(xr[src[e]] @ p["weight"][rel]))
+    pre = r(acc)
+    pre = pre.index_add(0, fold_rows[0], r(pre[fold_rows[0]] + fold_rows[1]) - pre[fold_rows[0]])
+    # the GPU run's pre-MLP rows and activations (bitwise what the layer computed: same launches, no atomics)
+    with torch.no_grad():
+        W_all = torch.cat([layer.weight, layer.loop_weight.unsqueeze(0)], 0)
+        pre_gpu = ops.rel_transform_fused(x.detach(), W_all, layer.bias, g.row_index(et, R, True))
+        h1_gpu, h2_gpu = ops.rows_chain2(pre_gpu, layer.mlp[0].weight, layer.mlp[0].bias, True, layer.mlp[2].weight,
+                                         layer.mlp[2].bias, True)
+        assert torch.equal(h2_gpu, out.detach())
+    close_pre = _rel_l2(pre_gpu, pre)
+    assert close_pre < 5e-3, close_pre
+    m1, m2 = (h1_gpu > 0).double().cpu(), (h2_gpu > 0).double().cpu()
+    h1 = r((pre @ p["mlp.0.weight"].t() + p["mlp.0.bias"]) * m1)
+    ref = r((h1 @ p["mlp.2.weight"].t() + p["mlp.2.bias"]) * m2)
+    ref.backward(coef.double().cpu())
+
+    def close(a, b, what):
+        assert _rel_max(a, b) < 2e-2 and _rel_l2(a, b) < 5e-3, (what, _rel_max(a, b), _rel_l2(a, b))
+
+    close(out, ref, "output")
+    close(x.grad, xr.grad, "input gradient")
+    for k, v in layer.named_parameters():
+        close(v.grad, p[k].grad, k)
+
+
 def test_bf16_step_is_bitwise_reproducible():
     """No atomics anywhere on the path and fixed summation orders: two runs of the same forward + backward (fused closing
     launch, two-layer chains with bit masks, LDS-DMA weight gradients) must agree bit for bit -- which also screens the
