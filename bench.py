@@ -279,11 +279,15 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="config5 / config3: strong = ONE global batch cut by parallel.shard_graphs (default); weak = a full batch per rank")
     ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (an eighth of the batch)")
+    ap.add_argument("--steady", action="store_true",
+                    help="profiling aid: the replayed step and the roofline leg only (no fresh-batch leg, GIN leg, proxy, CPU baseline)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
     ap.add_argument("--hidden", type=int, default=0, help="override the workload's hidden size (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
+    if args.steady:
+        args.no_proxy = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(args))             # nothing in this process has touched the GPU yet
@@ -454,7 +458,7 @@ def main():
     # build run on a side stream while the current step replays (what the reference's DataLoader workers do for dgl.batch on
     # the CPU): per-step wall time of the overlapped loop.
     overlapped_ms = None
-    if rank == 0 and world == 1 and graph is not None and fused and dtype == torch.bfloat16:
+    if rank == 0 and world == 1 and graph is not None and fused and dtype == torch.bfloat16 and not args.steady:
         from dummynode4graphlearning_amd import transforms as _tr
         side2 = torch.cuda.Stream()                     # (a high-priority side stream changes nothing: 0.88 vs 0.89 G edges/s)
         traw = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
@@ -542,11 +546,13 @@ def main():
     # HBM traffic of those launches comes from PMC counters, which cannot be read from inside the process: it is taken
     # from the committed rocprofv3 measurement of this exact workload (profiles/rNN_traffic.json), else null
     traffic = None
-    for tag in ("r02", "r01"):                           # newest committed measurement of this exact workload
+    from dummynode4graphlearning_amd._lib import source_digest
+    for tag in ("r03", "r02", "r01"):                    # newest committed measurement of this exact workload AND code
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
                 tj = json.load(f)
-            if (tj["workload"], tj["N"], tj["E"], tj["H"], tj["dtype"]) == (args.workload, N, E, H, "bf16" if dtype == torch.bfloat16 else "f32"):
+            if ((tj["workload"], tj["N"], tj["E"], tj["H"], tj["dtype"]) == (args.workload, N, E, H, "bf16" if dtype == torch.bfloat16 else "f32")
+                    and tj.get("source_sha16") == source_digest()):
                 traffic = tj["conv_gather_scatter_hbm_bytes_per_step"]
                 break
         except Exception:
@@ -555,7 +561,7 @@ def main():
     # secondary line (rank 0, N = 1): the pure gather -> segment-sum kernel on a GIN conv (no relation transform), forward
     # + backward, on a PROTEINS-shaped dummy-augmented batch (SURVEY 8d config 2 x 32 graphs, fp32 H = 128)
     gin = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.steady:
         from dummynode4graphlearning_amd import synthetic as syn, transforms as tr
         r2 = syn.config2(graphs=16384)
         t2 = {k: torch.from_numpy(v).to(dev) for k, v in r2.items()}

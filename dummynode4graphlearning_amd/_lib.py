@@ -168,3 +168,20 @@ def require_gpu(*tensors):
                 _probed = True
                 break
     return dev
+
+
+def source_digest():
+    """sha256 (first 16 hex digits) over the sources that decide which launches a step makes and what they do: the HIP kernels,
+    the C header and ops.py.  profiles/*_traffic.json records it; bench.py only quotes a committed traffic measurement whose
+    digest equals the running tree's (a stale file must not label a later code change)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")))
+    files += [os.path.join(os.path.dirname(here), "include", "dn_hip.h"), os.path.join(here, "ops.py")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -5,9 +5,10 @@
 
 Runs (each as a child process, the profiled program directly after `--`):
   1. python bench.py                                             -> <tag>_bench_line.json
-  2. rocprofv3 --kernel-trace --stats        -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
-                                                                 -> <tag>_kernel_stats.csv
-  3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph
+  2. rocprofv3 --kernel-trace --stats        -- python3 bench.py --steps 20 --warmup 5 --steady
+                                                                 -> <tag>_kernel_stats.csv   (the replayed step and the roofline
+                                                                    leg only: AverageNs of the conv kernels reproduces the line)
+  3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 3 --warmup 1 --steady --no-graph
   4. rocprofv3 --kernel-trace --pmc WRITE_SIZE  -- (same)       -> <tag>_hbm_traffic_per_launch.csv, <tag>_traffic.json
   5. rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- (same)
                                                                  -> <tag>_lds_bank_conflicts.csv
@@ -24,10 +25,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dummynode4graphlearning_amd._lib import source_digest  # noqa: E402
 
 # launches of ONE eager step of bench.py's config-5 workload, in order (kernel-name fragment, role)
 STEP = [
-    ("rows_transform_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows)"),
+    ("rows_transform_ring_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows)"),
     ("gather_segsum_vec_kernel", "overflow rows of nodes with > 6 incoming rows (fwd)"),
     ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum + per-graph column sums of x"),
     ("fold_tail_kernel", "fold tail fwd: combine the column sums, transform the one row per graph, add it to the dummy node"),
@@ -37,7 +40,7 @@ STEP = [
     ("rows_chain2_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
-    ("rows_transform_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
+    ("rows_transform_ring_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
     ("gather_segsum_vec_kernel", "overflow rows (bwd)"),
     ("rows_selfsum_kernel", "closing launch bwd: self-loop transform + per-src slot sum + per-graph column sums of g"),
     ("fold_tail_kernel", "fold tail bwd"),
@@ -45,7 +48,7 @@ STEP = [
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
 CONV_ROWS = (0, 1, 2, 3, 10, 11, 12, 13)
-OURS = ("gather_segsum_vec_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
+OURS = ("gather_segsum_vec_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
         "rows_wgrad_dma_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
 
 
@@ -102,17 +105,19 @@ def main():
     env_note = "cd /tmp && export TMPDIR=/tmp"
     os.environ["TMPDIR"] = "/tmp"
     bench = os.path.join(ROOT, "bench.py")
-    eager = ["python3", bench, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-graph"]
+    eager = ["python3", bench, "--steps", "3", "--warmup", "1", "--steady", "--no-graph"]
 
     # 2. kernel stats of the default (graph replay) run
     d = os.path.join(tmp, "stats")
     r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "k", "--",
-             "python3", bench, "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], cwd="/tmp")
+             "python3", bench, "--steps", "20", "--warmup", "5", "--steady"], cwd="/tmp")
     stats = one_csv(d, "kernel_stats.csv")
     with open(stats) as f:
         body = f.read()
     with open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# %s -- rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline\n" % a.tag)
+        f.write("# %s -- rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --steady\n" % a.tag)
+        f.write("# (--steady: HIP-graph replay of the step + the roofline leg only -- no fresh-batch leg, no GIN leg, no proxy; the index\n")
+        f.write("#  build of the one batch runs before the timed region under its own kernel names)\n")
         f.write("# (%s first) bench line of that run: %s\n" % (env_note, r.stdout.strip().splitlines()[-1][:400] if r.stdout.strip() else "n/a"))
         f.write(body)
 
@@ -137,7 +142,7 @@ def main():
     alg = 2 * (E * H * 2 + N * H * 2 + 8 * E)
     with open(os.path.join(a.out, a.tag + "_hbm_traffic_per_launch.csv"), "w") as f:
         f.write("# %s -- HBM traffic per launch of one eager step (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)\n" % a.tag)
-        f.write("# command: rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph\n")
+        f.write("# command: rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --steady --no-graph\n")
         f.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE KB (a wide coalesced read is half-counted); WRITE_SIZE exact. durations under PMC collection (us)\n")
         f.write("kernel,role,hbm_read_MB,hbm_write_MB,hbm_total_MB,duration_us,TB_per_s\n")
         f.write("\n".join(lines) + "\n")
@@ -146,6 +151,7 @@ def main():
     with open(os.path.join(a.out, a.tag + "_traffic.json"), "w") as f:
         json.dump({"workload": "config5", "N": N, "E": E, "H": H, "dtype": "bf16",
                    "conv_gather_scatter_hbm_bytes_per_step": conv * 1e6, "step_hbm_bytes": tot * 1e6,
+                   "source_sha16": source_digest(),
                    "source": "profiles/%s_hbm_traffic_per_launch.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md)" % a.tag},
                   f, indent=1)
 
