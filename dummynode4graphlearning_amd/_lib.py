@@ -59,6 +59,7 @@ _SIGS = {
                                      [ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32), P, c_sz, P]),
     "dn_row_tables_build_i32": (ctypes.c_int, [c_i32, P, c_i32, c_i64, P, P, ctypes.c_uint64, P]),
+    "dn_sweep_tables_build_i32": (ctypes.c_int, [c_i32, P, P, P, c_i64, c_i32, c_i32, ctypes.c_uint64, P, P, P]),
     "dn_slot_table_workspace_bytes": (c_sz, [c_i64]),
     "dn_slot_table_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, P, c_i32, c_i32, P, P, P, ctypes.POINTER(c_i64), P, c_sz,
                                                P]),

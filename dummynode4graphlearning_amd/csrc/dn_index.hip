@@ -743,6 +743,159 @@ __global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_pt
     }
 }
 
+// ----- L2-blocked ("sweep") tile order of relation-major rows for the persistent transform launch (dn_hip.h) --------------
+// One launch, closed forms only: every block recomputes the small per-group tables in LDS (9 x R lower bounds, the shares of
+// the W workgroups of each of the 8 groups), then fills its entries (workgroup b = j * 8 + x, slot m).  Mirrors
+// tests/sweep_ref.py (wg_shares + the event ranks) line by line.
+constexpr int kSwGroups = 8, kSwMaxRel = 64, kSwMaxW = 64, kSwTile = 32;
+
+__global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int32_t* __restrict__ rel_ptr,
+                                                            const int32_t* __restrict__ row_in, const int32_t* __restrict__ row_out,
+                                                            int32_t N, int32_t W, int32_t S_cap, unsigned long long skip_mask,
+                                                            int32_t* __restrict__ table, int32_t* __restrict__ info) {
+    __shared__ int32_t lo[kSwGroups + 1][kSwMaxRel];              // first row of relation r in group x
+    __shared__ int32_t T[kSwGroups][kSwMaxRel];                   // tiles of (group, relation)
+    __shared__ int32_t pure0[kSwGroups][kSwMaxRel + 1];           // first pure workgroup of relation r (prefix of the pure counts)
+    __shared__ int32_t crem[kSwGroups][kSwMaxRel + 1];            // prefix of the left-over tiles
+    __shared__ int32_t Sx[kSwGroups], Wh[kSwGroups];
+    __shared__ int32_t pp[kSwMaxRel + 1];                         // plain order: tiles before relation r
+    __shared__ int32_t s_plain;
+    const int tid = threadIdx.x;
+    auto key_of = [&](int32_t p) -> int32_t { const int32_t o = row_out[p]; return o < N ? o : row_in[p]; };
+    for (int i = tid; i < (kSwGroups + 1) * R; i += blockDim.x) {
+        const int x = i / R, r = i % R;
+        const int32_t a = rel_ptr[r], b = rel_ptr[r + 1];
+        int32_t v;
+        if ((skip_mask >> r) & 1ull) v = a;
+        else if (x == 0) v = a;
+        else if (x == kSwGroups) v = b;
+        else {
+            const int32_t kx = (int32_t)(((int64_t)x * N) / kSwGroups);
+            int32_t l = a, h = b;                                 // first row with key >= kx
+            while (l < h) { const int32_t mid = l + ((h - l) >> 1); if (key_of(mid) < kx) l = mid + 1; else h = mid; }
+            v = l;
+        }
+        lo[x][r] = v;
+    }
+    __syncthreads();
+    if (tid < R) {                                                // keys need not be monotone: make the bounds so (any cut is valid)
+        for (int x = 1; x <= kSwGroups; ++x) lo[x][tid] = max(lo[x][tid], lo[x - 1][tid]);
+        if (!((skip_mask >> tid) & 1ull)) lo[kSwGroups][tid] = rel_ptr[tid + 1];
+    }
+    __syncthreads();
+    for (int i = tid; i < kSwGroups * R; i += blockDim.x) {
+        const int x = i / R, r = i % R;
+        T[x][r] = (lo[x + 1][r] - lo[x][r] + kSwTile - 1) / kSwTile;
+    }
+    __syncthreads();
+    if (tid < kSwGroups) {                                        // shares of group x (sweep_ref.wg_shares)
+        const int x = tid;
+        int64_t Tx = 0;
+        for (int r = 0; r < R; ++r) Tx += T[x][r];
+        const int32_t S = (int32_t)((Tx + W - 1) / W);
+        Sx[x] = S;
+        int32_t j = 0, acc = 0;
+        for (int r = 0; r < R; ++r) {
+            pure0[x][r] = j;
+            crem[x][r] = acc;
+            const int32_t k = S > 0 ? T[x][r] / S : 0;
+            j += k;
+            acc += T[x][r] - k * S;
+        }
+        pure0[x][R] = j;
+        crem[x][R] = acc;
+        Wh[x] = W - j;
+    }
+    if (tid == 0) {
+        int32_t acc = 0;
+        for (int r = 0; r < R; ++r) {
+            pp[r] = acc;
+            const int32_t cnt = ((skip_mask >> r) & 1ull) ? 0 : rel_ptr[r + 1] - rel_ptr[r];
+            acc += (cnt + kSwTile - 1) / kSwTile;
+        }
+        pp[R] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t smax = 0;
+        for (int x = 0; x < kSwGroups; ++x) smax = max(smax, Sx[x]);
+        s_plain = smax > S_cap ? 1 : 0;                           // a group does not fit the table: plain order (always valid)
+        if (blockIdx.x == 0 && info) { info[0] = s_plain; info[1] = smax; }
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)kSwGroups * W * S_cap;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + tid; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int32_t rel = 0, beg = 0, end = 0;
+        if (s_plain) {                                            // relation-major tiles, contiguous ranges per workgroup
+            if (e < pp[R]) {
+                int l = 0, h = R;
+                while (h - l > 1) { const int mid = (l + h) >> 1; if (pp[mid] <= (int32_t)e) l = mid; else h = mid; }
+                rel = l;
+                beg = rel_ptr[rel] + ((int32_t)e - pp[rel]) * kSwTile;
+                end = min(beg + kSwTile, rel_ptr[rel + 1]);
+            }
+        } else {
+            const int32_t b = (int32_t)(e / S_cap), m = (int32_t)(e % S_cap);
+            const int x = b % kSwGroups, j = b / kSwGroups;
+            const int32_t S = Sx[x], np = pure0[x][R], RT = crem[x][R], wh = Wh[x];
+            int r = -1;
+            int32_t n = 0, a_me = 0, s_me = 0;
+            if (S > 0 && j < np) {                                // a workgroup of its own relation
+                if (m < S) {
+                    int l = 0, h = R;                             // last r with pure0[r] <= j (relations without pure workgroups share
+                    while (h - l > 1) { const int mid = (l + h) >> 1; if (pure0[x][mid] <= j) l = mid; else h = mid; }   // a value: take the last)
+                    r = l; n = m; a_me = S; s_me = j - pure0[x][r];
+                }
+            } else if (S > 0 && RT > 0 && wh > 0) {               // a helper: a segment of the left-over line
+                const int32_t k = j - np;
+                const int32_t p0 = (int32_t)(((int64_t)k * RT) / wh), p1 = (int32_t)(((int64_t)(k + 1) * RT) / wh);
+                const int32_t pos = p0 + m;
+                if (pos < p1) {
+                    int l = 0, h = R;                             // last r with crem[r] <= pos (empty left-overs share a value)
+                    while (h - l > 1) { const int mid = (l + h) >> 1; if (crem[x][mid] <= pos) l = mid; else h = mid; }
+                    r = l;
+                    const int32_t c0 = crem[x][r], c1 = crem[x][r + 1];
+                    n = pos - max(c0, p0);
+                    a_me = min(c1, p1) - max(c0, p0);
+                    int32_t kf = 0;                               // first helper that overlaps relation r's left-over
+                    while ((int32_t)(((int64_t)(kf + 1) * RT) / wh) <= c0) ++kf;
+                    s_me = (pure0[x][r + 1] - pure0[x][r]) + (k - kf);
+                }
+            }
+            if (r >= 0) {
+                // rank of event (s_me, n) among all events of relation r: time (2 n' + 1) / (2 a_s'), ties by s'
+                const int32_t npr = pure0[x][r + 1] - pure0[x][r];
+                const int64_t two_n1 = 2 * (int64_t)n + 1;
+                int64_t rank = 0;
+                for (int s2 = 0; s2 < npr; ++s2) {
+                    const int64_t num = two_n1 * S;
+                    const int64_t q = s2 < s_me ? num / a_me : (num - 1) / a_me;
+                    rank += (q + 1) / 2;
+                }
+                if (RT > 0 && wh > 0) {
+                    const int32_t c0 = crem[x][r], c1 = crem[x][r + 1];
+                    int32_t kf = 0;
+                    while ((int32_t)(((int64_t)(kf + 1) * RT) / wh) <= c0 && kf < wh) ++kf;
+                    for (int32_t k2 = kf; k2 < wh; ++k2) {
+                        const int32_t q0 = (int32_t)(((int64_t)k2 * RT) / wh), q1 = (int32_t)(((int64_t)(k2 + 1) * RT) / wh);
+                        if (q0 >= c1) break;
+                        const int32_t a2 = min(c1, q1) - max(c0, q0);
+                        if (a2 <= 0) continue;
+                        const int s2 = npr + (k2 - kf);
+                        const int64_t num = two_n1 * a2;
+                        const int64_t q = s2 < s_me ? num / a_me : (num - 1) / a_me;
+                        rank += (q + 1) / 2;
+                    }
+                }
+                rel = r;
+                beg = lo[x][r] + (int32_t)rank * kSwTile;
+                end = min(beg + kSwTile, lo[x + 1][r]);
+            }
+        }
+        table[4 * e] = rel; table[4 * e + 1] = beg; table[4 * e + 2] = end; table[4 * e + 3] = 0;
+    }
+}
+
 struct RowWs {
     int32_t *key, *skey, *iota, *order, *Er, *Dr, *Sr, *mode;
     int32_t *head, *aggh, *tfh, *agge, *tfe, *head_s, *aggh_s, *tfh_s, *agge_s, *tfe_s, *row_rel;
@@ -1297,6 +1450,23 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
     DN_CHECK_HIP(hipMemcpyAsync(host_modes, w.mode, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
     host_counts[0] = P; host_counts[1] = n_agg; host_counts[2] = n_tf; host_counts[3] = n_agg_e; host_counts[4] = n_tf_e;
+    return DN_OK;
+}
+
+int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out,
+                              int64_t num_nodes, int32_t workgroups_per_group, int32_t tiles_per_workgroup, uint64_t skip_mask,
+                              int32_t* table, int32_t* info, dn_stream_t stream) {
+    DN_REQUIRE(num_rels >= 1 && num_rels <= kSwMaxRel, "dn_sweep_tables_build: 1 <= num_rels <= 64");
+    DN_REQUIRE(workgroups_per_group >= 1 && workgroups_per_group <= kSwMaxW, "dn_sweep_tables_build: 1 <= workgroups_per_group <= 64");
+    DN_REQUIRE(tiles_per_workgroup >= 1 && num_nodes >= 0 && num_nodes < 0x7fffffffLL, "dn_sweep_tables_build: bad sizes");
+    DN_REQUIRE(rel_ptr && row_in && row_out && table, "dn_sweep_tables_build: NULL pointer");
+    const int64_t total = (int64_t)kSwGroups * workgroups_per_group * tiles_per_workgroup;
+    DN_REQUIRE(total < 0x7fffffffLL, "dn_sweep_tables_build: table too large");
+    const int64_t blocks = dn_cdiv(total, 256);
+    hipLaunchKernelGGL(sweep_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
+                       num_rels, rel_ptr, row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup,
+                       (unsigned long long)skip_mask, table, info);
+    DN_CHECK_LAUNCH();
     return DN_OK;
 }
 

@@ -67,8 +67,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-#ifdef DN_TUNING_ENV
-// tuning build: cycle counters of the last launch, per workgroup: compute wave 0 {loop, barrier wait, reads + MFMAs, epilogue},
+#ifdef DN_RING_STATS
+// diagnostic build (-DDN_RING_STATS): cycle counters of the last launch, per workgroup: compute wave 0 {loop, barrier wait, reads + MFMAs, epilogue},
 // loader 0 {loop, vm wait, barrier wait, body}, wall ticks (100 MHz) of the compute loop, its start tick
 __device__ unsigned long long g_ring_stats[256][10];
 #define DN_STAMP() __builtin_amdgcn_s_memtime()
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
             DN_STAT(st_vm, a1 - a0); DN_STAT(st_bar, a2 - a1); DN_STAT(st_body, DN_STAMP() - a2);
         }
         wait_vmcnt<0>();                                                   // nothing may land after the LDS is given back
-#ifdef DN_TUNING_ENV
+#ifdef DN_RING_STATS
         if (q == 0 && lane == 0 && blockIdx.x < 256) {
             g_ring_stats[blockIdx.x][4] = DN_STAMP() - l0; g_ring_stats[blockIdx.x][5] = st_vm;
             g_ring_stats[blockIdx.x][6] = st_bar; g_ring_stats[blockIdx.x][7] = st_body;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 
     unsigned long long sc_bar = 0, sc_mfma = 0, sc_epi = 0;
     const unsigned long long c0 = DN_STAMP();
-#ifdef DN_TUNING_ENV
+#ifdef DN_RING_STATS
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll 1
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
         t_pend = __builtin_amdgcn_readfirstlane((int)dn[2]);
     }
     if (late && e_pend > e_pbeg) epilogue(e_pbeg, e_pend);                 // the last tile's
-#ifdef DN_TUNING_ENV
+#ifdef DN_RING_STATS
     if (wave == 0 && lane == 0 && blockIdx.x < 256) {
         g_ring_stats[blockIdx.x][0] = DN_STAMP() - c0; g_ring_stats[blockIdx.x][1] = sc_bar;
         g_ring_stats[blockIdx.x][2] = sc_mfma; g_ring_stats[blockIdx.x][3] = sc_epi;
@@ -374,7 +374,7 @@ int launch_transform_ring256(const void* X, const void* X2, int32_t n1, const in
 
 }  // namespace dn_internal
 
-#ifdef DN_TUNING_ENV
+#ifdef DN_RING_STATS
 extern "C" int dn_debug_ring_stats(unsigned long long* out) {              // tuning build only: 256 x 10 counters of the last launch
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_stats), sizeof(g_ring_stats)) == hipSuccess ? 0 : -2;
 }

@@ -329,6 +329,29 @@ def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False, skip
     return (table, pptr, M) if want_ptr else (table, M)
 
 
+SWEEP_ENABLED = _os.environ.get("DN_SWEEP", "1") != "0"
+SWEEP_WG_PER_GROUP = 32                  # dn_rows_transform_bf16 at H = 256: 256 persistent workgroups = 8 XCDs x 32 CUs
+SWEEP_MIN_TILES_PER_WG = 32              # smaller launches fit the L2s anyway
+
+
+def build_sweep_tables(rel_ptr_dev, num_rels, row_in, row_out, num_nodes, num_rows, skip_mask=0, wg_per_group=SWEEP_WG_PER_GROUP,
+                       want_info=False):
+    """L2-blocked tile order of relation-major rows for the persistent transform launch (dn_sweep_tables_build_i32; see
+    include/dn_hip.h): (table [8 * wg_per_group * S, 4] int32, 8 * wg_per_group * S) -- the pair rows_transform takes.  S is
+    sized from what the host knows (rows / 32 + one partial tile per group and relation, 6 % head-room for uneven groups); when
+    a group needs more the builder writes the plain order into the same table (still valid), no read-back."""
+    require_gpu(rel_ptr_dev, row_in, row_out)
+    _i32(rel_ptr_dev, "rel_ptr"), _i32(row_in, "row_in"), _i32(row_out, "row_out")
+    G = 8 * int(wg_per_group)
+    S = int(1.06 * (int(num_rows) // 32 + 8 * int(num_rels)) / G) + 2
+    table = torch.empty((G * S, 4), dtype=I32, device=rel_ptr_dev.device)
+    info = torch.empty(2, dtype=I32, device=rel_ptr_dev.device) if want_info else None
+    check(lib().dn_sweep_tables_build_i32(int(num_rels), ptr(rel_ptr_dev), ptr(row_in), ptr(row_out), int(num_nodes),
+                                          int(wg_per_group), S, int(skip_mask), ptr(table), ptr(info), stream_ptr()),
+          "dn_sweep_tables_build_i32")
+    return ((table, G * S), info) if want_info else (table, G * S)
+
+
 def make_row_tiles(rel_ptr_host, device, tile_rows=32):
     """Tile table for dn_rows_transform_bf16: [T,4] int32 rows {rel, beg, end, 0}, tiles never cross relations."""
     import numpy as np
@@ -1062,6 +1085,19 @@ class RowIndex:
         self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
 
 
+def _conv_tiles(ix, fold, xs):
+    """Tile table of the edge rows (minus the folded relation) for the conv's transform launch: the L2-blocked sweep order when
+    the persistent H = 256 bf16 launch will walk it and the batch is large enough for the order to matter (built once per
+    index and direction, on first use), else the plain relation-major tiles."""
+    P, R = ix.num_edge_rows, ix.num_rels
+    if not (SWEEP_ENABLED and xs.dtype == torch.bfloat16 and xs.shape[1] == 256 and R <= 64
+            and P // 32 >= 8 * SWEEP_WG_PER_GROUP * SWEEP_MIN_TILES_PER_WG):
+        return fold.main_tiles
+    if fold.sweep_tiles is None:
+        fold.sweep_tiles = build_sweep_tables(ix.rel_ptr_dev, R, ix.row_in, ix.row_out, ix.num_nodes, P, skip_mask=1 << fold.rel)
+    return fold.sweep_tiles
+
+
 def _row_index_tile_table(ix):
     """Tile table of ALL rows (the self loop as relation R): the path without the fused closing launch."""
     if ix._tile_table is None:
@@ -1138,6 +1174,7 @@ def _closing_tables(ix):
             info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
             #                                                    starts one partial row, every tile boundary inside one another
             info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+            info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
             info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
         ix._fold[direction] = info
         n_ovf, n_rows = h[2 + 2 * k], h[3 + 2 * k]
@@ -1159,7 +1196,7 @@ FOLD_ENABLED = _os.environ.get("DN_FOLD", "1") != "0"
 
 class _Fold:
     """Tables of one folded relation: rows [beg, end) of the row set, one per segment (graph)."""
-    __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "add_idx")
+    __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "sweep_tiles", "add_idx")
 
 
 def _row_index_fold(ix, direction):
@@ -1226,7 +1263,7 @@ def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
     add each product to its node).  Same sums as the unfolded path up to bf16 rounding of the collapsed rows."""
     fold = _row_index_fold(ix, direction)
     P, H = ix.num_edge_rows, xs.shape[1]
-    Y = rows_transform(xs, Wmat, fold.main_tiles, P, idx=idx_rows, tag="conv", out=ybuf)
+    Y = rows_transform(xs, Wmat, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf)
     slots, optr, oidx, novf = ix.slots(direction)
     ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)

@@ -270,6 +270,25 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
 int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,
                             int32_t* piece_ptr, uint64_t skip_mask, dn_stream_t stream);
 
+/* L2-blocked ("sweep") tile order of relation-major rows for the persistent launch of dn_rows_transform_bf16 (H = 256: one
+ * workgroup per CU, 256 in all).  The batch is cut into 8 contiguous key ranges (key of row p = the node it belongs to:
+ * row_out[p] when < num_nodes, else row_in[p]; non-decreasing inside a relation for the tables of dn_row_index_build_*); group x
+ * is walked by the workgroups b = j * 8 + x (blocks b, b + 8, ... share an XCD and its L2).  Inside a group most workgroups serve
+ * ONE relation for the whole launch (weights stay in registers) and take every k-th of its tiles, so all of them move through
+ * the group's graphs at the same pace and a source row fetched for one relation is still in that XCD's L2 when the other
+ * relations ask for it; a few helper workgroups take the left-overs of several relations one after the other.
+ * table: [8 * workgroups_per_group][tiles_per_workgroup][4] int32 {rel, beg, end, 0}, unused slots empty -- pass it to
+ * dn_rows_transform_bf16 with num_tiles = 8 * workgroups_per_group * tiles_per_workgroup and workgroups_per_group = 32 (the
+ * launch then gives workgroup b the entries [b * tiles_per_workgroup, (b + 1) * tiles_per_workgroup)).  Every row of every
+ * relation not in skip_mask is covered exactly once whatever the keys are (placement is a speed matter only).  When a group
+ * needs more than tiles_per_workgroup slots the table holds the plain relation-major order instead (always valid provided
+ * 8 * workgroups_per_group * tiles_per_workgroup >= rows / 32 + num_rels); info (may be NULL) receives {plain order taken, slots the
+ * largest group needs}.  One launch, no host synchronisation.  Replaces nothing in the reference (DGL's update_all has no
+ * notion of a traversal order, models/rgin.py:156-160): it is the order in which the replacement reads x. */
+int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out,
+                              int64_t num_nodes, int32_t workgroups_per_group, int32_t tiles_per_workgroup, uint64_t skip_mask,
+                              int32_t* table, int32_t* info, dn_stream_t stream);
+
 /* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build; replaces the reference's
  * per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`, subgraph_isomorphism/models/rgin.py:137).
  * list_ptr [N+1] / list_rows: CSR of row ids per node (dn_row_index_build_i32's dst_ptr/dst_rows or src_ptr/src_rows).

@@ -645,3 +645,63 @@ def test_fold_is_refused_when_a_graph_is_not_a_contiguous_node_range():
         0, torch.tensor(dst), torch.bmm(x.cpu().double()[torch.tensor(src)].unsqueeze(1), W.cpu().double()[torch.tensor(et)]).squeeze(1))
     ref = ref + x.cpu().double() @ W.cpu().double()[R + 1]
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("seed,R,W,skew", [(0, 16, 32, False), (1, 5, 32, True), (2, 40, 16, False), (3, 3, 64, True), (4, 17, 32, False)])
+def test_sweep_tile_tables_match_the_host_restatement(seed, R, W, skew):
+    """dn_sweep_tables_build_i32 (L2-blocked tile order of the persistent transform launch) against tests/sweep_ref.py: the same
+    table bit for bit; every row of every kept relation covered exactly once; keys that are not monotone (any cut is valid);
+    a table too small for a group falls back to the plain order (still a partition)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sweep_ref import check_partition, sweep_tables
+    ops = _ops()
+    rng = np.random.default_rng(100 + seed)
+    G = 3000
+    sizes = rng.integers(1, 40, size=G)
+    node_ptr = np.concatenate([[0], np.cumsum(sizes)])
+    N = int(node_ptr[-1])
+    rel_ptr, keys, rin = [0], [], []
+    skip = 1 << int(rng.integers(0, R))
+    for r in range(R):
+        lam = (8.0 if (skew and r == 0) else 1.0) * rng.uniform(0.2, 2.5)
+        cnt = rng.poisson(lam, G) if r % 7 != 6 else np.where(np.arange(G) % 50 == 0, 3, 0)       # a sparse relation too
+        k = np.repeat(node_ptr[:-1], cnt) + rng.integers(0, np.repeat(sizes, cnt))
+        k = np.sort(k)
+        keys.append(k)
+        rin.append(rng.integers(0, N, size=k.size))
+        rel_ptr.append(rel_ptr[-1] + k.size)
+    key = np.concatenate(keys).astype(np.int64)
+    P = int(rel_ptr[-1])
+    # the kernel's key: row_out when < N, else row_in -- give half the relations their key through row_in (row_out = N + something)
+    row_out, row_in = key.copy(), np.concatenate(rin).astype(np.int64)
+    for r in range(0, R, 2):
+        a, b = rel_ptr[r], rel_ptr[r + 1]
+        row_in[a:b] = key[a:b]
+        row_out[a:b] = N + np.arange(b - a)
+    rp = torch.tensor(rel_ptr, dtype=torch.int32, device=DEV)
+    ri, ro = (torch.from_numpy(v.astype(np.int32)).to(DEV) for v in (row_in, row_out))
+    (table, ntiles), info = ops.build_sweep_tables(rp, R, ri, ro, N, P, skip_mask=skip, wg_per_group=W, want_info=True)
+    S = ntiles // (8 * W)
+    plain, smax = (int(v) for v in info.cpu())
+    assert plain == 0 and smax <= S
+    got = table.cpu().numpy().reshape(8 * W, S, 4)
+    want, _ = sweep_tables(rel_ptr, key, N, W, skip_mask=skip, s_cap=S)
+    assert np.array_equal(got, want)
+    check_partition(got, np.asarray(rel_ptr), skip)
+    # non-monotone keys: still a partition
+    ro2 = ro.clone()
+    a, b = rel_ptr[1], rel_ptr[2]
+    if b - a > 10 and 1 % 2 == 1:
+        ro2[a:b] = ro2[a:b].flip(0)
+    (t2, n2), _ = ops.build_sweep_tables(rp, R, ri, ro2, N, P, skip_mask=skip, wg_per_group=W, want_info=True)
+    check_partition(t2.cpu().numpy().reshape(8 * W, -1, 4), np.asarray(rel_ptr), skip)
+    # a table with too few slots per workgroup for the largest group: the plain order, flagged
+    tiny = torch.empty((8 * W * (smax - 1), 4), dtype=torch.int32, device=DEV)
+    info2 = torch.zeros(2, dtype=torch.int32, device=DEV)
+    from dummynode4graphlearning_amd._lib import check, lib, ptr, stream_ptr
+    if 8 * W * (smax - 1) >= P // 32 + R:
+        check(lib().dn_sweep_tables_build_i32(R, ptr(rp), ptr(ri), ptr(ro), N, W, smax - 1, skip, ptr(tiny), ptr(info2), stream_ptr()), "sweep")
+        assert int(info2[0]) == 1
+        check_partition(tiny.cpu().numpy().reshape(8 * W, -1, 4), np.asarray(rel_ptr), skip)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--xcd-major", action="store_true", help="control: wrong placement (workgroup b -> group b // W)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", choices=["", "baseline", "sweep"])
+    ap.add_argument("--ab", type=int, default=0, help="conv leg A/B only: plain and sweep tile order alternated this many times")
     a = ap.parse_args()
     import bench
     from dummynode4graphlearning_amd import ops
@@ -60,6 +61,24 @@ def main():
     gout = torch.randn(N, H, device=dev).to(torch.bfloat16)
     bias = torch.zeros(H, device=dev, dtype=torch.bfloat16)
     alg = 2.0 * (E * H * 2 + N * H * 2 + 8.0 * E)
+    if a.ab:
+        plain = {d: ops._row_index_fold(ix, d).main_tiles for d in ("f", "b")}
+        swept = {}
+        for d in ("f", "b"):
+            fold = ops._row_index_fold(ix, d)
+            tab, S = sweep_tables(rel_ptr, key, N, a.wgs[0], skip_mask=1 << fold.rel)
+            swept[d] = (torch.from_numpy(tab.reshape(-1, 4)).to(dev), int(tab.shape[0] * tab.shape[1]))
+        res = {"plain": [], "sweep": []}
+        for it in range(a.ab):
+            for name, tabs in (("plain", plain), ("sweep", swept)) if it % 2 == 0 else (("sweep", swept), ("plain", plain)):
+                for d in ("f", "b"):
+                    ops._row_index_fold(ix, d).main_tiles = tabs[d]
+                res[name].append(conv_leg(ops, ix, x, gout, W, bias, dev, reps=30))
+        for name in ("plain", "sweep"):
+            v = res[name]
+            print("conv leg %s tile order: %s  mean %.4f ms (frac %.4f)" % (name, " ".join("%.4f" % t for t in v), sum(v) / len(v),
+                                                                            alg / (sum(v) / len(v) * 1e-3) / 8e12), flush=True)
+        return
     t_conv = conv_leg(ops, ix, x, gout, W, bias, dev)
     print("conv leg, plain tile order: %.4f ms  (roofline frac %.4f)" % (t_conv, alg / (t_conv * 1e-3) / 8e12), flush=True)
     for direction in ("f", "b"):
