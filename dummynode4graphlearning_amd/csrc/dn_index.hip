@@ -941,46 +941,21 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 // Per node v the kept rows of its list are those < num_edge_rows (self-loop rows dropped).  cnt <= K: slots = the rows, -1
 // padded.  cnt > K: the first K-1 rows, slot K-1 = num_edge_rows + j for the j-th overflowing node, and rows K-1 .. cnt-1 go
 // to the overflow CSR (ovf_ptr over overflowing nodes in node order, ovf_idx) the caller pre-sums.
-__global__ void slot_count_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
-                                  const int32_t* __restrict__ lrows, int32_t* __restrict__ over, int32_t* __restrict__ olen,
-                                  int32_t drop_beg, int32_t drop_end, const int32_t* __restrict__ drop_enable) {
-    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (v > N) return;
-    if (v == N) { over[N] = 0; olen[N] = 0; return; }            // sentinel: the scans yield the totals at [N]
-    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;     // (decided on the device: no host round trip)
-    int cnt = 0;
-    for (int i = lptr[v]; i < lptr[v + 1]; ++i) cnt += (lrows[i] < P && !(lrows[i] >= drop_beg && lrows[i] < drop_end)) ? 1 : 0;
-    over[v] = cnt > K ? 1 : 0;
-    olen[v] = cnt > K ? cnt - (K - 1) : 0;
-}
 __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
-                                 const int32_t* __restrict__ lrows, const int32_t* __restrict__ over_id,
-                                 const int32_t* __restrict__ ostart, int32_t* __restrict__ slots, int32_t* __restrict__ ovf_ptr,
-                                 int32_t* __restrict__ ovf_idx, int32_t drop_beg, int32_t drop_end,
-                                 const int32_t* __restrict__ drop_enable, int32_t* __restrict__ dev_counts) {
+                                 const int32_t* __restrict__ lrows, int32_t* __restrict__ slots, int32_t drop_beg, int32_t drop_end,
+                                 const int32_t* __restrict__ drop_enable) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (v > N) return;
-    if (v == N) {                                                // closing entry of the overflow CSR, totals for the caller
-        ovf_ptr[over_id[N]] = ostart[N];
-        if (dev_counts != nullptr) { dev_counts[0] = over_id[N]; dev_counts[1] = ostart[N]; }
-        return;
-    }
-    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
-    const bool is_over = ostart[v + 1] > ostart[v];
-    const int keep = is_over ? K - 1 : K;
-    int k = 0, o = ostart[v];
+    if (v >= N) return;
+    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;     // (decided on the device: no host round trip)
+    int k = 0;
     for (int i = lptr[v]; i < lptr[v + 1]; ++i) {
         const int r = lrows[i];
         if (r >= P || (r >= drop_beg && r < drop_end)) continue;
-        if (k < keep) slots[v * (int64_t)K + k] = r;
-        else ovf_idx[o++] = r;
+        if (k < K) slots[v * (int64_t)K + k] = r;
         ++k;
     }
-    for (int j = min(k, keep); j < K; ++j) slots[v * (int64_t)K + j] = -1;
-    if (is_over) {
-        slots[v * (int64_t)K + K - 1] = P + over_id[v];
-        ovf_ptr[over_id[v]] = ostart[v];
-    }
+    for (int j = min(k, K); j < K; ++j) slots[v * (int64_t)K + j] = -1;
+    if (k > K) slots[v * (int64_t)K + K - 1] = -2;               // more rows than slots: the closing launch walks the list for the rest
 }
 
 // ---- tables of a folded pre-aggregation (dn_rows_selfsum_bf16 with fold_info) ---------------------------------------------
@@ -1482,64 +1457,14 @@ int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t st
     return DN_OK;
 }
 
-size_t dn_slot_table_workspace_bytes(int64_t N) {
-    if (N < 0) { dn_set_error("dn_slot_table_workspace_bytes: negative size"); return 0; }
-    Arena a(nullptr, 0);
-    a.take<int32_t>(N + 1); a.take<int32_t>(N + 1); a.take<int32_t>(N + 1); a.take<int32_t>(N + 1);
-    size_t tb = 0;
-    if (excl_scan(nullptr, tb, nullptr, nullptr, N + 1, nullptr) != hipSuccess) { dn_set_error("rocprim scan size query failed"); return 0; }
-    a.take_bytes(tb);
-    return a.off + 1024;                                         // (+ the slot of the two totals, dn_slot_table_build_i32)
-}
-
-int dn_slot_table_build_async_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                                  int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, int32_t* ovf_ptr,
-                                  int32_t* ovf_idx, int32_t* dev_counts, void* workspace, size_t workspace_bytes,
-                                  dn_stream_t stream) {
-    DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
-    DN_REQUIRE(dev_counts, "dn_slot_table_build: NULL pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (N == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_counts, 0, 2 * sizeof(int32_t), st)); return DN_OK; }
-    DN_REQUIRE(list_ptr && list_rows && slots && ovf_ptr && ovf_idx && workspace, "dn_slot_table_build: NULL pointer");
-    Arena a(workspace, workspace_bytes);
-    int32_t* over = a.take<int32_t>(N + 1);
-    int32_t* olen = a.take<int32_t>(N + 1);
-    int32_t* over_id = a.take<int32_t>(N + 1);
-    int32_t* ostart = a.take<int32_t>(N + 1);
-    size_t tb = 0;
-    DN_CHECK_HIP(excl_scan(nullptr, tb, over, over_id, N + 1, st));
-    void* temp = a.take_bytes(tb);
-    if (!a.ok()) { dn_set_error("dn_slot_table_build: workspace too small"); return DN_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(slot_count_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over, olen, drop_beg, drop_end, drop_enable);
-    DN_CHECK_LAUNCH();
-    DN_CHECK_HIP(excl_scan(temp, tb, over, over_id, N + 1, st));
-    DN_CHECK_HIP(excl_scan(temp, tb, olen, ostart, N + 1, st));
-    hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(N + 1)), dim3(kBlock), 0, st, N, num_edge_rows, K, list_ptr, list_rows,
-                       over_id, ostart, slots, ovf_ptr, ovf_idx, drop_beg, drop_end, drop_enable, dev_counts);
-    DN_CHECK_LAUNCH();
-    return DN_OK;
-}
-
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
-                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
-    if (host_counts) host_counts[0] = host_counts[1] = 0;
     if (N == 0) return DN_OK;
-    DN_REQUIRE(list_ptr && list_rows && slots && ovf_ptr && ovf_idx && host_counts && workspace, "dn_slot_table_build: NULL pointer");
-    hipStream_t st = (hipStream_t)stream;
-    // the last 256 bytes of the workspace carry the two totals (dn_slot_table_workspace_bytes leaves that much slack)
-    DN_REQUIRE(workspace_bytes >= 512, "dn_slot_table_build: workspace too small");
-    int32_t* dev_counts = reinterpret_cast<int32_t*>((char*)workspace + ((workspace_bytes - 8) & ~(size_t)255));
-    int rc = dn_slot_table_build_async_i32(N, num_edge_rows, K, list_ptr, list_rows, drop_beg, drop_end, nullptr, slots, ovf_ptr,
-                                           ovf_idx, dev_counts, workspace, (size_t)((char*)dev_counts - (char*)workspace), stream);
-    if (rc != DN_OK) return rc;
-    int32_t h[2] = {0, 0};
-    DN_CHECK_HIP(hipMemcpyAsync(h, dev_counts, sizeof(h), hipMemcpyDeviceToHost, st));
-    DN_CHECK_HIP(hipStreamSynchronize(st));
-    host_counts[0] = h[0];                                       // overflowing nodes
-    host_counts[1] = h[1];                                       // rows in the overflow CSR
+    DN_REQUIRE(list_ptr && list_rows && slots, "dn_slot_table_build: NULL pointer");
+    hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, N, num_edge_rows, K, list_ptr,
+                       list_rows, slots, drop_beg, drop_end, drop_enable);
+    DN_CHECK_LAUNCH();
     return DN_OK;
 }
 

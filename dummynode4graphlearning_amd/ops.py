@@ -404,10 +404,12 @@ SELFSUM_SLOTS = 6
 SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 
-def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None):
+def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
     seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
-    folded pre-aggregation, see the header)."""
+    folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end): the per-node row
+    lists the slot table was built from -- nodes with more rows than slots (-2 in their last slot) are finished from them by a
+    second small launch (dn_overflow_rows_add_bf16)."""
     require_gpu(x, Wn, bias, S, S2, slots)
     if seg is not None:
         require_gpu(*seg)
@@ -429,6 +431,20 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None):
         kernel_timer.launch("rows_selfsum", _launch)
     else:
         _launch()
+    if lists is not None:
+        lp, lr, ner, db, de = lists
+        require_gpu(lp, lr)
+        _i32(lp, "list_ptr"), _i32(lr, "list_rows")
+        assert lp.numel() >= N + 1 and S2 is None
+
+        def _launch2():
+            check(lib().dn_overflow_rows_add_bf16(ptr(S) if S is not None and S.numel() else None, H, ptr(slots), SELFSUM_SLOTS, N,
+                                                  ptr(lp), ptr(lr), int(ner), int(db), int(de), ptr(out), stream_ptr()),
+                  "dn_overflow_rows_add_bf16")
+        if kernel_timer is not None:
+            kernel_timer.launch("overflow_rows_add", _launch2)
+        else:
+            _launch2()
     return out
 
 
@@ -460,27 +476,19 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     return (Y1, Y2, bits1, bits2) if want_bits else (Y1, Y2)
 
 
-def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0)):
-    """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16 (dn_slot_table_build_i32, one C-ABI call):
-    (slots [N, K] int32, ovf_ptr, ovf_idx, n_ovf).  Rows >= num_edge_rows (the self-loop rows) are dropped; a node with more
-    than K rows keeps its first K-1 and gets the id num_edge_rows + j of overflow row j in its last slot (ovf_ptr/ovf_idx:
-    CSR of the rows to pre-sum into it).  drop = (beg, end): rows of that range are left out too."""
+def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0), drop_enable=None):
+    """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16 (dn_slot_table_build_i32: one launch, no read-back):
+    slots [N, K] int32.  Rows >= num_edge_rows (the self-loop rows) and rows in drop = (beg, end) are left out (drop_enable: a
+    device flag that switches the range off when 0); a node with more than K rows keeps its first K-1 and gets -2 in its last
+    slot -- the closing launch finishes it from the list itself (pass the same lists to rows_selfsum)."""
     require_gpu(list_ptr, list_rows)
     dev = list_rows.device
     N, P = int(num_nodes), int(num_edge_rows)
     list_ptr, list_rows = list_ptr.to(I32).contiguous(), list_rows.to(I32).contiguous()
     slots = torch.empty((N, K), dtype=I32, device=dev)
-    ovf_ptr = torch.empty(N + 1, dtype=I32, device=dev)
-    ovf_idx = torch.empty(max(int(list_rows.numel()), 1), dtype=I32, device=dev)
-    ws = _ws(lib().dn_slot_table_workspace_bytes(N), dev)
-    counts = (ctypes.c_int64 * 2)()
-    check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), int(drop[0]), int(drop[1]), ptr(slots),
-                                        ptr(ovf_ptr), ptr(ovf_idx), counts, ptr(ws), ws.numel(), stream_ptr()),
-          "dn_slot_table_build_i32")
-    n_ovf, n_rows = int(counts[0]), int(counts[1])
-    if n_ovf == 0:
-        return slots, None, None, 0
-    return slots, ovf_ptr[:n_ovf + 1], ovf_idx[:n_rows], n_ovf
+    check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), int(drop[0]), int(drop[1]), ptr(drop_enable),
+                                        ptr(slots), stream_ptr()), "dn_slot_table_build_i32")
+    return slots
 
 
 def wgrad_supported(A, G):
@@ -1133,12 +1141,12 @@ def _fold_candidate(ix, direction):
 
 def _closing_tables(ix):
     """Slot tables and fold tables of BOTH directions of a RowIndex, queued back to back (dn_fold_tables_build_async_i32 leaves its
-    verdict on the device, dn_slot_table_build_async_i32 reads it there to decide whether the folded relation's rows are left out
-    of the slots) and read back in ONE copy: one host synchronisation per batch instead of four."""
+    verdict on the device, dn_slot_table_build_i32 reads it there to decide whether the folded relation's rows are left out of
+    the slots); the host reads the two verdicts in ONE copy (it picks the launch sequence by them)."""
     if ix._slots:
         return
     N, P, dev, K = ix.num_nodes, ix.num_edge_rows, ix.row_in.device, SELFSUM_SLOTS
-    flags = torch.zeros(8, dtype=I32, device=dev)                  # [ok_f, ok_b, novf_f, nrows_f, novf_b, nrows_b, -, -]
+    flags = torch.zeros(2, dtype=I32, device=dev)                  # [ok_f, ok_b]: verdicts of the two fold-table builds
     work = {}
     for k, direction in enumerate(("f", "b")):
         cand = _fold_candidate(ix, direction)
@@ -1153,18 +1161,12 @@ def _closing_tables(ix):
                   "dn_fold_tables_build_async_i32")
         ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
         ptr_, rows = ptr_.to(I32).contiguous(), rows.to(I32).contiguous()
-        slots = torch.empty((N, K), dtype=I32, device=dev)
-        ovf_ptr = torch.empty(N + 1, dtype=I32, device=dev)
-        ovf_idx = torch.empty(max(int(rows.numel()), 1), dtype=I32, device=dev)
-        ws = _ws(lib().dn_slot_table_workspace_bytes(N), dev)
-        check(lib().dn_slot_table_build_async_i32(N, P, K, ptr(ptr_), ptr(rows), cand[1] if cand else 0, cand[2] if cand else 0,
-                                                  ptr(flags[k:]) if cand else None, ptr(slots), ptr(ovf_ptr), ptr(ovf_idx),
-                                                  ptr(flags[2 + 2 * k:]), ptr(ws), ws.numel(), stream_ptr()),
-              "dn_slot_table_build_async_i32")
-        work[direction] = (cand, fold_info, part_ptr, slots, ovf_ptr, ovf_idx)
-    h = flags.cpu().tolist()                                        # the one synchronisation
+        slots = build_slot_table(ptr_, rows, N, P, K, drop=(cand[1], cand[2]) if cand else (0, 0),
+                                 drop_enable=flags[k:] if cand else None)
+        work[direction] = (cand, fold_info, part_ptr, slots, ptr_, rows)
+    h = flags.cpu().tolist()                                        # the one synchronisation: the two fold verdicts
     for k, direction in enumerate(("f", "b")):
-        cand, fold_info, part_ptr, slots, ovf_ptr, ovf_idx = work[direction]
+        cand, fold_info, part_ptr, slots, ptr_, rows = work[direction]
         info = None
         if cand is not None and h[k] != 0:
             r, beg, end, n_aux = cand
@@ -1177,8 +1179,8 @@ def _closing_tables(ix):
             info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
             info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
         ix._fold[direction] = info
-        n_ovf, n_rows = h[2 + 2 * k], h[3 + 2 * k]
-        ix._slots[direction] = (slots, None, None, 0) if n_ovf == 0 else (slots, ovf_ptr[:n_ovf + 1], ovf_idx[:n_rows], n_ovf)
+        drop = (info.beg, info.end) if info is not None else (0, 0)
+        ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1]))
 
 
 def _row_index_slots(ix, direction):
@@ -1264,10 +1266,9 @@ def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
     fold = _row_index_fold(ix, direction)
     P, H = ix.num_edge_rows, xs.shape[1]
     Y = rows_transform(xs, Wmat, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf)
-    slots, optr, oidx, novf = ix.slots(direction)
-    ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
+    slots, lists = ix.slots(direction)
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
-    rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out, seg=(fold.fold_info, part))
+    rows_selfsum(xs, Wmat[-1], bias, Y[:P], None, slots, out=out, seg=(fold.fold_info, part), lists=lists)
     return fold_tail(part, fold.part_ptr, fold.n, Wmat[fold.rel], fold.add_idx, out)
 
 
@@ -1289,9 +1290,8 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
     if _selfsum_ok(ix, xs):
         P = ix.num_edge_rows
         Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
-        slots, optr, oidx, novf = ix.slots(direction)
-        ovf = gather_segsum(Y, oidx, optr, novf) if novf else None
-        rows_selfsum(xs, Wmat[-1], bias, Y[:P], ovf, slots, out=out)
+        slots, lists = ix.slots(direction)
+        rows_selfsum(xs, Wmat[-1], bias, Y[:P], None, slots, out=out, lists=lists)
         return aux
     bias_all = None
     if bias is not None:

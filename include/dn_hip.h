@@ -289,26 +289,19 @@ int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const in
                               int64_t num_nodes, int32_t workgroups_per_group, int32_t tiles_per_workgroup, uint64_t skip_mask,
                               int32_t* table, int32_t* info, dn_stream_t stream);
 
-/* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build; replaces the reference's
- * per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`, subgraph_isomorphism/models/rgin.py:137).
+/* Fixed-width slot table of per-node row lists for dn_rows_selfsum_bf16 (one-shot index build, ONE launch, no workspace, no
+ * host synchronisation; replaces the reference's per-node reduce bookkeeping inside `g.update_all(..., fn.sum(...))`,
+ * subgraph_isomorphism/models/rgin.py:137).
  * list_ptr [N+1] / list_rows: CSR of row ids per node (dn_row_index_build_i32's dst_ptr/dst_rows or src_ptr/src_rows).
  * Rows >= num_edge_rows (the self-loop rows) and rows in [drop_beg, drop_end) (a relation the caller adds in a launch of its
- * own; drop_beg == drop_end for none) are dropped.  slots [N, K]: the kept rows, -1 padded; a node with more than K
- * kept rows keeps its first K-1 and gets num_edge_rows + j in slot K-1, j = its rank among such nodes, whose remaining rows
- * form the CSR (ovf_ptr [<= N+1], ovf_idx [<= len(list_rows)]) the caller pre-sums into overflow row j.
- * host_counts[0] = number of overflowing nodes, [1] = rows in the overflow CSR (the call synchronises the stream). */
-size_t dn_slot_table_workspace_bytes(int64_t N);
+ * own; drop_beg == drop_end for none) are dropped; drop_enable (device, may be NULL) switches the drop range off when
+ * *drop_enable == 0 -- the verdict dn_fold_tables_build_async_i32 leaves on the device, so the tables of both directions of a
+ * batch are queued back to back (the per-batch bookkeeping of subgraph_isomorphism/dataset.py:1605-1611).
+ * slots [N, K]: the kept rows in list order, -1 padded; a node with MORE than K kept rows keeps its first K-1 and gets -2 in
+ * slot K-1: dn_overflow_rows_add_bf16 adds the rest straight from the node's list after the closing launch (pass it the same
+ * list and drop range). */
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t drop_beg, int32_t drop_end, int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx,
-                            int64_t* host_counts, void* workspace, size_t workspace_bytes, dn_stream_t stream);
-/* The same build without the read-back (no synchronisation): dev_counts [2] (device) receives {overflowing nodes, rows in the
- * overflow CSR}; drop_enable (device, may be NULL) switches the drop range off when *drop_enable == 0 -- the flag
- * dn_fold_tables_build_async_i32 leaves on the device, so the tables of both directions of a batch are queued back to back and
- * the caller reads every count in ONE copy (the per-batch bookkeeping of subgraph_isomorphism/dataset.py:1605-1611). */
-int dn_slot_table_build_async_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr,
-                                  const int32_t* list_rows, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
-                                  int32_t* slots, int32_t* ovf_ptr, int32_t* ovf_idx, int32_t* dev_counts, void* workspace,
-                                  size_t workspace_bytes, dn_stream_t stream);
+                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, dn_stream_t stream);
 
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
@@ -352,9 +345,9 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * 140-145, rgcn.py:168-182) fused with the per-node sum of the transformed rows (the reference's `fn.sum(msg, out)`
  * reduce, rgin.py:137 / rgcn.py:166) -- and, in the backward direction, the same for the input gradient.
  * Wn is [H][H] with k contiguous.  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
- * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  Nodes with
- * more than num_slots rows must have had their excess pre-summed into one S2 row by the caller.  num_slots must be 6.
- * H in {64, 128, 256}.
+ * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  A node with
+ * more than num_slots rows carries -2 in its last slot (dn_slot_table_build_i32) and is finished by dn_overflow_rows_add_bf16
+ * right after this launch.  num_slots must be 6.  H in {64, 128, 256}.
  * Folded pre-aggregation (fold_info != NULL): the launch also sums the X rows it reads per SEGMENT -- the input row of a
  * collapsed relation (all nodes of a graph -> its dummy node: one row per graph whose input is the sum of the graph's rows,
  * the reference's per-edge messages of the dummy edge type, rgin.py:102-120 on dataset.py:1563-1603's dummy edges) -- so the
@@ -367,6 +360,17 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out,
                          const int32_t* fold_info, float* seg_part, dn_stream_t stream);
+
+/* Nodes with more rows than slots: out[v, :] += sum of the rows of v's list beyond the first num_slots - 1 kept ones, for every
+ * node whose last slot holds -2 (dn_slot_table_build_i32).  The walk applies the table builder's filter (rows >= num_edge_rows
+ * and rows in [drop_beg, drop_end) are not edge rows of this launch) in list order; fp32 sum added to the bf16 row, one rounding.
+ * Runs after dn_rows_selfsum_bf16 on the same `out` (the remainder of the reference's fn.sum reduce for high in-degree nodes,
+ * subgraph_isomorphism/models/rgin.py:137).  In the closing launch itself the walk -- dependent loads of a few nodes -- stalled
+ * every other tile (measured: + 130 us per config-5 launch); as a launch of its own it is a screen of N ints and a few thousand
+ * short lists.  H in {64, 128, 256}. */
+int dn_overflow_rows_add_bf16(const void* S, int32_t H, const int32_t* slots, int32_t num_slots, int64_t N, const int32_t* list_ptr,
+                              const int32_t* list_rows, int32_t num_edge_rows, int32_t drop_beg, int32_t drop_end, void* out,
+                              dn_stream_t stream);
 
 /* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph

@@ -70,6 +70,10 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, None)
     assert rc == -1 and b"fold_info needs seg_part" in L.dn_last_error()
+    rc = L.dn_overflow_rows_add_bf16(None, 100, None, 6, 8, None, None, 5, 0, 0, None, None)
+    assert rc == -1 and b"unsupported width" in L.dn_last_error()
+    rc = L.dn_overflow_rows_add_bf16(None, 256, None, 6, 8, None, None, 5, 0, 0, None, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_batchnorm_rows_f32(ctypes.c_void_p(16), 8, 64, None, None, 1e-5, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
                                  ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0.1, 0, ctypes.c_void_p(16), 1 << 20, None)
     assert rc == -1 and b"running_mean and running_var come together" in L.dn_last_error()
@@ -88,9 +92,13 @@ def test_local_index_and_async_table_entry_points_check_their_arguments(lib):
     rc = L.dn_row_index_build_local_i32(4, 10, 3, 20, None, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
                                         ctypes.byref(st), P16, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_slot_table_build_async_i32(10, 5, 6, P16, P16, 0, 0, None, P16, P16, P16, None, P16, 1 << 20, None)
+    rc = L.dn_slot_table_build_i32(10, 5, 6, P16, P16, 0, 0, None, None, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_slot_table_build_async_i32(10, 5, 1, P16, P16, 0, 0, None, P16, P16, P16, P16, P16, 1 << 20, None)
+    rc = L.dn_slot_table_build_i32(10, 5, 1, P16, P16, 0, 0, None, P16, None)
+    assert rc == -1 and b"bad sizes" in L.dn_last_error()
+    rc = L.dn_sweep_tables_build_i32(100, P16, P16, P16, 10, 32, 8, 0, P16, None, None)
+    assert rc == -1 and b"num_rels <= 64" in L.dn_last_error()
+    rc = L.dn_sweep_tables_build_i32(4, P16, P16, P16, 10, 32, 0, 0, P16, None, None)
     assert rc == -1 and b"bad sizes" in L.dn_last_error()
     rc = L.dn_fold_tables_build_async_i32(10, 2, P16, P16, P16, P16, None, P16, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()

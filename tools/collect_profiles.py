@@ -31,8 +31,8 @@ from dummynode4graphlearning_amd._lib import source_digest  # noqa: E402
 # launches of ONE eager step of bench.py's config-5 workload, in order (kernel-name fragment, role)
 STEP = [
     ("rows_transform_ring_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows)"),
-    ("gather_segsum_vec_kernel", "overflow rows of nodes with > 6 incoming rows (fwd)"),
     ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum + per-graph column sums of x"),
+    ("overflow_rows_add_kernel", "nodes with > 6 incoming rows finished from their lists (fwd)"),
     ("fold_tail_kernel", "fold tail fwd: combine the column sums, transform the one row per graph, add it to the dummy node"),
     ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors)"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
@@ -41,14 +41,14 @@ STEP = [
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_ring_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
-    ("gather_segsum_vec_kernel", "overflow rows (bwd)"),
     ("rows_selfsum_kernel", "closing launch bwd: self-loop transform + per-src slot sum + per-graph column sums of g"),
+    ("overflow_rows_add_kernel", "nodes with > 6 outgoing rows finished from their lists (bwd)"),
     ("fold_tail_kernel", "fold tail bwd"),
     ("rows_wgrad_dma_kernel", "conv wgrad (LDS-DMA ring; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
 CONV_ROWS = (0, 1, 2, 3, 10, 11, 12, 13)
-OURS = ("gather_segsum_vec_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
+OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
         "rows_wgrad_dma_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
 
 

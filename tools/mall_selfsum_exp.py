@@ -15,21 +15,21 @@ dev = torch.device("cuda:0")
 g, raw, _ = bench.build_batch(dev, 5, 32768, "config5")
 N, H, R = g.number_of_nodes(), 256, 16
 ix = g.row_index(g.edata["label"], R, True).parts[0][2]
-slots, optr, oidx, novf = ix.slots("f")
+slots, lists = ix.slots("f")
 P = ix.num_edge_rows
 x = torch.randn(N, H, device=dev).to(torch.bfloat16)
 W = (torch.randn(H, H, device=dev) * 0.05).to(torch.bfloat16)
-Y = torch.randn(P + max(novf, 1), H, device=dev).to(torch.bfloat16)
+Y = torch.randn(P, H, device=dev).to(torch.bfloat16)
 out = torch.empty_like(x)
 
 
 def timed(sl, reps=20):
     for _ in range(3):
-        ops.rows_selfsum(x, W, None, Y, None, sl, out=out)
+        ops.rows_selfsum(x, W, None, Y, None, sl, out=out, lists=lists)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.rows_selfsum(x, W, None, Y, None, sl, out=out)
+        ops.rows_selfsum(x, W, None, Y, None, sl, out=out, lists=lists)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
