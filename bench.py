@@ -620,7 +620,7 @@ def main():
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rows_transform_kernel + gather_segsum_vec_kernel (overflow rows) + rows_selfsum_kernel + fold_tail_kernel (conv launches, both directions)",
+                         "kernel": "rows_transform_ring_kernel + rows_selfsum_kernel + overflow_rows_add_kernel + fold_tail_kernel (the conv's launches, both directions)",
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step},
         }

@@ -60,7 +60,7 @@ _SIGS = {
                                       ctypes.POINTER(c_i32), P, c_sz, P]),
     "dn_row_tables_build_i32": (ctypes.c_int, [c_i32, P, c_i32, c_i64, P, P, ctypes.c_uint64, P]),
     "dn_sweep_tables_build_i32": (ctypes.c_int, [c_i32, P, P, P, c_i64, c_i32, c_i32, ctypes.c_uint64, P, P, P]),
-    "dn_slot_table_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, P, c_i32, c_i32, P, P, P]),
+    "dn_slot_table_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, P, c_i32, c_i32, P, P, P, P]),
     "dn_fold_tables_build_async_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P, P, c_sz, P]),
     "dn_rows_wgrad_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "dn_rows_wgrad_bf16": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32,

@@ -943,7 +943,7 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 // to the overflow CSR (ovf_ptr over overflowing nodes in node order, ovf_idx) the caller pre-sums.
 __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lrows, int32_t* __restrict__ slots, int32_t drop_beg, int32_t drop_end,
-                                 const int32_t* __restrict__ drop_enable) {
+                                 const int32_t* __restrict__ drop_enable, uint8_t* __restrict__ over) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v >= N) return;
     if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;     // (decided on the device: no host round trip)
@@ -955,7 +955,8 @@ __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t*
         ++k;
     }
     for (int j = min(k, K); j < K; ++j) slots[v * (int64_t)K + j] = -1;
-    if (k > K) slots[v * (int64_t)K + K - 1] = -2;               // more rows than slots: the closing launch walks the list for the rest
+    if (k > K) slots[v * (int64_t)K + K - 1] = -2;               // more rows than slots: dn_overflow_rows_add_bf16 adds the rest
+    if (over) over[v] = k > K ? 1 : 0;                           // ... and screens this byte per node instead of the 24-byte slot line
 }
 
 // ---- tables of a folded pre-aggregation (dn_rows_selfsum_bf16 with fold_info) ---------------------------------------------
@@ -1458,12 +1459,13 @@ int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t st
 }
 
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, dn_stream_t stream) {
+                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, uint8_t* overflow,
+                            dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && K >= 2 && num_edge_rows >= 0, "dn_slot_table_build: bad sizes");
     if (N == 0) return DN_OK;
     DN_REQUIRE(list_ptr && list_rows && slots, "dn_slot_table_build: NULL pointer");
     hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, N, num_edge_rows, K, list_ptr,
-                       list_rows, slots, drop_beg, drop_end, drop_enable);
+                       list_rows, slots, drop_beg, drop_end, drop_enable, overflow);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -509,51 +509,86 @@ int gather_segmax_bwd(const T* gout, const int32_t* argmax, const int32_t* tptr,
 
 // ---------------------------------------------------------------------------------------------
 // dn_overflow_rows_add_bf16: out[v] += sum of the rows of node v's list that did not fit its slots (dn_slot_table_build_i32
-// leaves -2 in the last slot of such a node).  Runs after dn_rows_selfsum_bf16; a block screens 256 nodes (one int each),
+// leaves -2 in the last slot of such a node and 1 in its byte of `overflow`).  Runs after dn_rows_selfsum_bf16; a block screens 256 bytes,
 // collects the few flagged ones in LDS and finishes each with a lane group (16 bytes per lane), fp32 sum, one rounding.
 // ---------------------------------------------------------------------------------------------
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void overflow_rows_add_kernel(const bf16_t* __restrict__ S, const int32_t* __restrict__ slots,
+__global__ __launch_bounds__(kBlock) void overflow_rows_add_kernel(const bf16_t* __restrict__ S, const uint8_t* __restrict__ over,
                                                                    int32_t K, int64_t N, const int32_t* __restrict__ lptr,
                                                                    const int32_t* __restrict__ lrows, int32_t num_edge_rows,
                                                                    int32_t drop_beg, int32_t drop_end, bf16_t* __restrict__ out) {
     constexpr int H = LPR * 8;
+    constexpr int kMaxList = 64;                                  // list entries a lane group takes in one sweep (longer lists: loop)
     __shared__ int32_t found[kBlock];
+    __shared__ int32_t ent[kBlock / LPR][kMaxList];               // per lane group: the EXTRA rows of the node it is finishing
     __shared__ int32_t nfound;
     if (threadIdx.x == 0) nfound = 0;
     __syncthreads();
     const int64_t v0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (v0 < N && slots[v0 * K + K - 1] == -2) found[atomicAdd(&nfound, 1)] = (int32_t)v0;
+    if (v0 < N && over[v0] != 0) found[atomicAdd(&nfound, 1)] = (int32_t)v0;
     __syncthreads();
     const int cnt = nfound;
-    const int grp = threadIdx.x / LPR, pc = threadIdx.x % LPR;
-    for (int q = grp; q < cnt; q += kBlock / LPR) {
+    if (cnt == 0) return;
+    // one WAVE per flagged node: its 64 lanes read 64 list entries at once (one round trip), a ballot ranks the kept ones, the
+    // extras go to LDS; then the wave's lane groups (LPR lanes = one row) take the extras round-robin, all row loads in flight
+    // together, and the groups' fp32 sums meet in LDS -- four dependent round trips per node instead of two per list entry
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int GPW = 64 / LPR;                                 // lane groups per wave
+    const int grp = lane / LPR, pc = lane % LPR;
+    __shared__ float part[kBlock / 64][GPW][H];
+    for (int q = wave; q < cnt; q += kBlock / 64) {
         const int32_t v = found[q];
+        const int beg = lptr[v], end = lptr[v + 1];
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int kept = 0;
-        for (int i = lptr[v], ie = lptr[v + 1]; i < ie; ++i) {
-            const int r = lrows[i];
-            if (r >= num_edge_rows || (r >= drop_beg && r < drop_end)) continue;     // the table builder's filter
-            if (kept++ < K - 1) continue;                                            // those sit in the slots
-            const uint4 e = *reinterpret_cast<const uint4*>(S + (size_t)r * H + pc * 8);
-            const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+        int kept_before = 0;
+        for (int base = beg; base < end; base += 64) {
+            const int i = base + lane;
+            const int r = i < end ? lrows[i] : -1;
+            const bool keep = i < end && r < num_edge_rows && !(r >= drop_beg && r < drop_end);     // the table builder's filter
+            const unsigned long long m = __ballot(keep);
+            const int rank = kept_before + __popcll(m & ((1ull << lane) - 1ull));
+            const int first_extra = K - 1;                         // ranks below sit in the slots
+            const int n_extra_before = max(kept_before - first_extra, 0);
+            if (keep && rank >= first_extra) ent[wave][rank - first_extra - n_extra_before] = r;
+            const int kept_here = __popcll(m);
+            const int n_extra = max(kept_before + kept_here - first_extra, 0) - n_extra_before;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = grp; e < n_extra; e += GPW) {
+                const int rr = ent[wave][e];
+                const uint4 x4 = *reinterpret_cast<const uint4*>(S + (size_t)rr * H + pc * 8);
+                const uint32_t w[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[2 * j] += __uint_as_float(w[j] << 16);
+                    a[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                }
+            }
+            kept_before += kept_here;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave][grp][pc * 8 + j] = a[j];
+        __builtin_amdgcn_wave_barrier();
+        if (grp == 0) {                                           // fixed order over the groups: deterministic
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t[j] = 0.f;
+                for (int g2 = 0; g2 < GPW; ++g2) t[j] += part[wave][g2][pc * 8 + j];
+            }
+            uint4* po = reinterpret_cast<uint4*>(out + (size_t)v * H + pc * 8);
+            const uint4 o = *po;
+            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+            uint32_t res[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[2 * j] += __uint_as_float(w[j] << 16);
-                a[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                const bf16_t lo = (bf16_t)(t[2 * j] + __uint_as_float(w[j] << 16));
+                const bf16_t hi = (bf16_t)(t[2 * j + 1] + __uint_as_float(w[j] & 0xffff0000u));
+                res[j] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
             }
+            *po = make_uint4(res[0], res[1], res[2], res[3]);
         }
-        uint4* po = reinterpret_cast<uint4*>(out + (size_t)v * H + pc * 8);
-        const uint4 o = *po;
-        const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-        uint32_t res[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16_t lo = (bf16_t)(a[2 * j] + __uint_as_float(w[j] << 16));
-            const bf16_t hi = (bf16_t)(a[2 * j + 1] + __uint_as_float(w[j] & 0xffff0000u));
-            res[j] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
-        }
-        *po = make_uint4(res[0], res[1], res[2], res[3]);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -573,21 +608,21 @@ int dn_gather_segsum_bf16(const void* in, int64_t in_rows, int32_t H, const int3
                                  (const bf16_t*)self_in, self_coef, mean, (hipStream_t)stream);
 }
 
-int dn_overflow_rows_add_bf16(const void* S, int32_t H, const int32_t* slots, int32_t num_slots, int64_t N, const int32_t* list_ptr,
+int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow, int32_t num_slots, int64_t N, const int32_t* list_ptr,
                               const int32_t* list_rows, int32_t num_edge_rows, int32_t drop_beg, int32_t drop_end, void* out,
                               dn_stream_t stream) {
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_overflow_rows_add: unsupported width %d (64/128/256 only)", H);
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_slots >= 2 && num_edge_rows >= 0, "dn_overflow_rows_add: bad sizes");
     if (N == 0) return DN_OK;
-    DN_REQUIRE(slots && list_ptr && list_rows && out && (S || num_edge_rows == 0), "dn_overflow_rows_add: NULL pointer");
+    DN_REQUIRE(overflow && list_ptr && list_rows && out && (S || num_edge_rows == 0), "dn_overflow_rows_add: NULL pointer");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(out)) % 16 == 0, "dn_overflow_rows_add: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)dn_cdiv(N, kBlock)), block(kBlock);
     const bf16_t* s = (const bf16_t*)S;
     bf16_t* o = (bf16_t*)out;
-    if (H == 256) hipLaunchKernelGGL((overflow_rows_add_kernel<32>), grid, block, 0, st, s, slots, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
-    else if (H == 128) hipLaunchKernelGGL((overflow_rows_add_kernel<16>), grid, block, 0, st, s, slots, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
-    else hipLaunchKernelGGL((overflow_rows_add_kernel<8>), grid, block, 0, st, s, slots, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
+    if (H == 256) hipLaunchKernelGGL((overflow_rows_add_kernel<32>), grid, block, 0, st, s, overflow, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
+    else if (H == 128) hipLaunchKernelGGL((overflow_rows_add_kernel<16>), grid, block, 0, st, s, overflow, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
+    else hipLaunchKernelGGL((overflow_rows_add_kernel<8>), grid, block, 0, st, s, overflow, num_slots, N, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, o);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

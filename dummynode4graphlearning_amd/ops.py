@@ -407,7 +407,7 @@ SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
     seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
-    folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end): the per-node row
+    folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, overflow): the per-node row
     lists the slot table was built from -- nodes with more rows than slots (-2 in their last slot) are finished from them by a
     second small launch (dn_overflow_rows_add_bf16)."""
     require_gpu(x, Wn, bias, S, S2, slots)
@@ -432,13 +432,13 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
     else:
         _launch()
     if lists is not None:
-        lp, lr, ner, db, de = lists
-        require_gpu(lp, lr)
+        lp, lr, ner, db, de, over = lists
+        require_gpu(lp, lr, over)
         _i32(lp, "list_ptr"), _i32(lr, "list_rows")
-        assert lp.numel() >= N + 1 and S2 is None
+        assert lp.numel() >= N + 1 and S2 is None and over.dtype == torch.uint8 and over.numel() >= N
 
         def _launch2():
-            check(lib().dn_overflow_rows_add_bf16(ptr(S) if S is not None and S.numel() else None, H, ptr(slots), SELFSUM_SLOTS, N,
+            check(lib().dn_overflow_rows_add_bf16(ptr(S) if S is not None and S.numel() else None, H, ptr(over), SELFSUM_SLOTS, N,
                                                   ptr(lp), ptr(lr), int(ner), int(db), int(de), ptr(out), stream_ptr()),
                   "dn_overflow_rows_add_bf16")
         if kernel_timer is not None:
@@ -478,17 +478,18 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
 
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0), drop_enable=None):
     """Fixed-width view of per-node row lists for dn_rows_selfsum_bf16 (dn_slot_table_build_i32: one launch, no read-back):
-    slots [N, K] int32.  Rows >= num_edge_rows (the self-loop rows) and rows in drop = (beg, end) are left out (drop_enable: a
+    (slots [N, K] int32, overflow [N] uint8).  Rows >= num_edge_rows (the self-loop rows) and rows in drop = (beg, end) are left out (drop_enable: a
     device flag that switches the range off when 0); a node with more than K rows keeps its first K-1 and gets -2 in its last
-    slot -- the closing launch finishes it from the list itself (pass the same lists to rows_selfsum)."""
+    slot and 1 in its overflow byte -- a small launch after the closing launch finishes it from the list (pass lists to rows_selfsum)."""
     require_gpu(list_ptr, list_rows)
     dev = list_rows.device
     N, P = int(num_nodes), int(num_edge_rows)
     list_ptr, list_rows = list_ptr.to(I32).contiguous(), list_rows.to(I32).contiguous()
     slots = torch.empty((N, K), dtype=I32, device=dev)
+    over = torch.empty(max(N, 1), dtype=torch.uint8, device=dev)
     check(lib().dn_slot_table_build_i32(N, P, K, ptr(list_ptr), ptr(list_rows), int(drop[0]), int(drop[1]), ptr(drop_enable),
-                                        ptr(slots), stream_ptr()), "dn_slot_table_build_i32")
-    return slots
+                                        ptr(slots), ptr(over), stream_ptr()), "dn_slot_table_build_i32")
+    return slots, over
 
 
 def wgrad_supported(A, G):
@@ -1161,12 +1162,12 @@ def _closing_tables(ix):
                   "dn_fold_tables_build_async_i32")
         ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
         ptr_, rows = ptr_.to(I32).contiguous(), rows.to(I32).contiguous()
-        slots = build_slot_table(ptr_, rows, N, P, K, drop=(cand[1], cand[2]) if cand else (0, 0),
-                                 drop_enable=flags[k:] if cand else None)
-        work[direction] = (cand, fold_info, part_ptr, slots, ptr_, rows)
+        slots, over = build_slot_table(ptr_, rows, N, P, K, drop=(cand[1], cand[2]) if cand else (0, 0),
+                                       drop_enable=flags[k:] if cand else None)
+        work[direction] = (cand, fold_info, part_ptr, slots, ptr_, rows, over)
     h = flags.cpu().tolist()                                        # the one synchronisation: the two fold verdicts
     for k, direction in enumerate(("f", "b")):
-        cand, fold_info, part_ptr, slots, ptr_, rows = work[direction]
+        cand, fold_info, part_ptr, slots, ptr_, rows, over = work[direction]
         info = None
         if cand is not None and h[k] != 0:
             r, beg, end, n_aux = cand
@@ -1180,7 +1181,7 @@ def _closing_tables(ix):
             info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
         ix._fold[direction] = info
         drop = (info.beg, info.end) if info is not None else (0, 0)
-        ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1]))
+        ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1], over))
 
 
 def _row_index_slots(ix, direction):

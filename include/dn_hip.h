@@ -298,10 +298,11 @@ int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const in
  * *drop_enable == 0 -- the verdict dn_fold_tables_build_async_i32 leaves on the device, so the tables of both directions of a
  * batch are queued back to back (the per-batch bookkeeping of subgraph_isomorphism/dataset.py:1605-1611).
  * slots [N, K]: the kept rows in list order, -1 padded; a node with MORE than K kept rows keeps its first K-1 and gets -2 in
- * slot K-1: dn_overflow_rows_add_bf16 adds the rest straight from the node's list after the closing launch (pass it the same
- * list and drop range). */
+ * slot K-1 and 1 in overflow[v] (uint8 [N], may be NULL; 0 for every other node): dn_overflow_rows_add_bf16 adds the rest
+ * straight from the node's list after the closing launch (pass it `overflow`, the same list and the drop range). */
 int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const int32_t* list_ptr, const int32_t* list_rows,
-                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, dn_stream_t stream);
+                            int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* slots, uint8_t* overflow,
+                            dn_stream_t stream);
 
 /* Weight gradient of the relation-wise transform Y[p] = A[p] W[rel(p)] on the matrix cores (bf16 in, fp32 acc):
  *   out[r] = sum_{p in relation r} A[idx_a[p], :]^T G[idx_g[p], :]            ([Hi x Ho] per relation)
@@ -362,13 +363,13 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
                          const int32_t* fold_info, float* seg_part, dn_stream_t stream);
 
 /* Nodes with more rows than slots: out[v, :] += sum of the rows of v's list beyond the first num_slots - 1 kept ones, for every
- * node whose last slot holds -2 (dn_slot_table_build_i32).  The walk applies the table builder's filter (rows >= num_edge_rows
+ * node with overflow[v] != 0 (dn_slot_table_build_i32's byte per node).  The walk applies the table builder's filter (rows >= num_edge_rows
  * and rows in [drop_beg, drop_end) are not edge rows of this launch) in list order; fp32 sum added to the bf16 row, one rounding.
  * Runs after dn_rows_selfsum_bf16 on the same `out` (the remainder of the reference's fn.sum reduce for high in-degree nodes,
  * subgraph_isomorphism/models/rgin.py:137).  In the closing launch itself the walk -- dependent loads of a few nodes -- stalled
  * every other tile (measured: + 130 us per config-5 launch); as a launch of its own it is a screen of N ints and a few thousand
  * short lists.  H in {64, 128, 256}. */
-int dn_overflow_rows_add_bf16(const void* S, int32_t H, const int32_t* slots, int32_t num_slots, int64_t N, const int32_t* list_ptr,
+int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow, int32_t num_slots, int64_t N, const int32_t* list_ptr,
                               const int32_t* list_rows, int32_t num_edge_rows, int32_t drop_beg, int32_t drop_end, void* out,
                               dn_stream_t stream);
 

@@ -92,9 +92,9 @@ def test_local_index_and_async_table_entry_points_check_their_arguments(lib):
     rc = L.dn_row_index_build_local_i32(4, 10, 3, 20, None, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
                                         ctypes.byref(st), P16, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_slot_table_build_i32(10, 5, 6, P16, P16, 0, 0, None, None, None)
+    rc = L.dn_slot_table_build_i32(10, 5, 6, P16, P16, 0, 0, None, None, None, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_slot_table_build_i32(10, 5, 1, P16, P16, 0, 0, None, P16, None)
+    rc = L.dn_slot_table_build_i32(10, 5, 1, P16, P16, 0, 0, None, P16, None, None)
     assert rc == -1 and b"bad sizes" in L.dn_last_error()
     rc = L.dn_sweep_tables_build_i32(100, P16, P16, P16, 10, 32, 8, 0, P16, None, None)
     assert rc == -1 and b"num_rels <= 64" in L.dn_last_error()

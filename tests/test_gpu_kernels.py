@@ -377,15 +377,16 @@ def test_rows_selfsum_matches_reference(H):
     ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
     rows = np.concatenate(lists)
     lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
-    slots = ops.build_slot_table(lp, lr, N, P)
+    slots, over = ops.build_slot_table(lp, lr, N, P)
     sl = slots.cpu().numpy()
     assert slots.shape == (N, K) and int((sl[:, K - 1] == -2).sum()) == int((cnt > K).sum())
+    assert np.array_equal(over.cpu().numpy()[:N] != 0, cnt > K)
     for v in (0, 1, int(np.argmax(cnt))):                       # kept rows in list order, -1 padded, -2 marks "walk the list"
         want = list(lists[v][:-1][:K - 1 if cnt[v] > K else K])
         assert list(sl[v][:len(want)]) == want and set(sl[v][len(want):]) <= {-1, -2}
     Yd = Y.to(DEV)
     for bias in (b.to(DEV), None):
-        out = ops.rows_selfsum(x.to(DEV), W.to(DEV), bias, Yd, None, slots, lists=(lp, lr, P, 0, 0))
+        out = ops.rows_selfsum(x.to(DEV), W.to(DEV), bias, Yd, None, slots, lists=(lp, lr, P, 0, 0, over))
         ref = x.double() @ W.double().t() + (b.double() if bias is not None else 0.0)
         for v in range(N):
             ref[v] += Y[lists[v][:-1]].double().sum(0)
@@ -393,8 +394,8 @@ def test_rows_selfsum_matches_reference(H):
         assert float(err) < 1.2e-2, float(err)        # bf16 roundings: the self-loop tile, the output row, the overflow add
     # a dropped row range (the relation a fold handles elsewhere) is left out by the table AND by the list walk
     d0, d1 = 700, 1100
-    slots_d = ops.build_slot_table(lp, lr, N, P, drop=(d0, d1))
-    out = ops.rows_selfsum(x.to(DEV), W.to(DEV), None, Yd, None, slots_d, lists=(lp, lr, P, d0, d1))
+    slots_d, over_d = ops.build_slot_table(lp, lr, N, P, drop=(d0, d1))
+    out = ops.rows_selfsum(x.to(DEV), W.to(DEV), None, Yd, None, slots_d, lists=(lp, lr, P, d0, d1, over_d))
     ref = x.double() @ W.double().t()
     for v in range(N):
         keep = [r for r in lists[v][:-1] if not (d0 <= r < d1)]
