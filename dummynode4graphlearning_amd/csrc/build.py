@@ -43,6 +43,9 @@ def build(force=False, verbose=True, tuning=False):
     global FLAGS
     if (tuning or os.environ.get("DN_BUILD_TUNING") == "1") and "-DDN_TUNING_ENV" not in FLAGS:
         FLAGS = FLAGS + ["-DDN_TUNING_ENV"]
+    for extra in os.environ.get("DN_BUILD_EXTRA", "").split():         # e.g. -DDN_RING_STATS (diagnostic builds only)
+        if extra not in FLAGS:
+            FLAGS = FLAGS + [extra]
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     os.makedirs(OBJDIR, exist_ok=True)

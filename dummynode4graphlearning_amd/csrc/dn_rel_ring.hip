@@ -4,26 +4,29 @@
 //
 // One workgroup per CU, 12 waves (3 per SIMD: two compute waves and a loader):
 //   * waves 8..11 ("loaders") issue nothing but LDS-DMAs (global_load_lds): the 32 gathered rows of a tile go global -> LDS
-//     without staging VGPRs into a ring of NS 16-KiB stages, NS-1 tiles (112 KiB per CU) in flight.  Tile records and row
-//     indices travel AHEAD of the rows through two small per-wave LDS rings, also by LDS-DMA and in batches of 8 tiles (one
-//     wave-instruction fetches the 64 indices a loader needs for 8 tiles): a scalar or vector load per tile instead (record ->
-//     index -> row address) is a dependent chain through HBM that one tile of look-ahead cannot hide -- the index stream is
-//     read once, every tile misses.  vmcnt counts every vector-memory operation of a wave in issue order, so the wait for
-//     "the rows of tile t have landed" is a counted s_waitcnt vmcnt(4 (NS-2)) (a batch's two extra DMAs only make it stricter).
+//     without staging VGPRs into a ring of NS 16-KiB stages.  Tile records and row indices travel AHEAD of the rows through two
+//     small per-wave LDS rings, also by LDS-DMA and in batches of 8 tiles (one wave-instruction fetches the 64 indices a loader
+//     needs for 8 tiles): a scalar or vector load per tile instead (record -> index -> row address) is a dependent chain
+//     through HBM that one tile of look-ahead cannot hide -- the index stream is read once, every tile misses.  The source
+//     addresses of a pair of tiles are worked out BEFORE the barrier that frees their stages, so the eight row DMAs leave
+//     right behind it.  vmcnt counts every vector-memory operation of a wave in issue order, so "the rows up to tile t + 2 have
+//     landed" is a counted s_waitcnt vmcnt(4 (NS-5)) (a batch's two extra DMAs only make it stricter).
 //   * waves 0..7 ("compute") own 32 output columns each, their slice of Wn[rel] in 64 VGPRs (reloaded when the relation
-//     changes).  Per tile: 16 ds_read_b128 fragment reads, all in flight before the first MFMA needs one (inline asm with
-//     hand-counted s_waitcnt lgkmcnt(n) per k-step: hipcc either serialises them -- one read, lgkmcnt(0), two MFMAs -- or,
-//     behind a sched_barrier, waits for all sixteen; a pending scalar load would force lgkmcnt(0) too, so the loop has no
-//     SMEM: the next tile's record arrives as a 17th LDS read), 32 v_mfma_f32_16x16x32_bf16 on the TRANSPOSED tile (A = weights, B =
-//     rows), and the finished rows leave straight from the accumulators: the weight rows of the two 16-column MFMA tiles are
-//     interleaved (A row i of tile n <-> output column 8 (i >> 2) + 4 n + (i & 3)), so a lane ends up with 8 CONSECUTIVE columns
-//     of one row = one 16-byte streaming store, no second trip through LDS and no second barrier.
-//   * the two compute waves of a SIMD are STAGGERED: waves 4..7 keep a tile's sums in registers across the barrier and run its
-//     epilogue (convert, bias, ReLU, store) at the start of the next interval, under their partner's MFMAs; the partner's own
-//     epilogue then runs under theirs.  In lock step both waves' MFMAs and both epilogues would queue on one SIMD.
-//   * ONE raw s_barrier per tile joins all twelve waves: after barrier t the stage of tile t is visible to the compute waves
-//     (each loader waited for its own DMAs of tile t) and the stage of tile t-1 is free (every compute wave drained its
-//     LDS reads before arriving), so the loaders refill it with tile t + NS - 1.
+//     changes).  Per tile: 16 ds_read_b128 fragment reads (inline asm with hand-counted s_waitcnt lgkmcnt(n) per k-step: hipcc
+//     either serialises them -- one read, lgkmcnt(0), two MFMAs -- or, behind a sched_barrier, waits for all sixteen; a pending
+//     scalar load would force lgkmcnt(0) too, so the loop has no SMEM: the next tile's record arrives as a 17th LDS read), 32
+//     v_mfma_f32_16x16x32_bf16 on the TRANSPOSED tile (A = weights, B = rows), and the finished rows leave straight from the
+//     accumulators: the weight rows of the two 16-column MFMA tiles are interleaved (A row i of tile n <-> output column
+//     8 (i >> 2) + 4 n + (i & 3)), so a lane ends up with 8 CONSECUTIVE columns of one row = one 16-byte streaming store, no
+//     second trip through LDS and no second barrier.
+//   * the compute loop is software-pipelined over tiles: the fragments of the first two k-steps of tile t + 1 are fetched during
+//     tile t (into the registers those k-steps just consumed), so a tile's MFMAs start right behind the previous tile's and the
+//     other six k-steps' reads land behind them.  (All eight a tile ahead, or the two waves of a SIMD staggered by half a tile
+//     with the sums kept across the barrier, do not fit the 168 registers a wave has at 3 waves per SIMD: hipcc spills.)
+//   * ONE raw s_barrier per PAIR of tiles joins all twelve waves (every rendezvous makes eleven waves wait for the slowest):
+//     behind the barrier of tiles 2 p, 2 p + 1 the stages up to tile 2 p + 2 are visible to the compute waves (each loader
+//     waited for its own DMAs) and the stages of tiles 2 p - 2, 2 p - 1 are free (every compute wave drained its LDS reads
+//     before arriving), so the loaders refill them with tiles 2 p + 6, 2 p + 7.
 //   * an LDS-DMA wave-instruction writes 1 KiB lane-linearly (2 rows): the image is unpadded and the bank spread of the fragment
 //     reads comes from an XOR swizzle of the 16-byte pieces applied to the per-lane SOURCE address: LDS (row r, position q)
 //     holds global piece q ^ (r & 15).  ds_read_b128 serves a wave in 4 groups of 16 lanes ({0-3,12-15,20-27}, ...); with
@@ -32,7 +35,8 @@
 // Why: the register-staged kernel (dn_rel.hip) needs ~2,300 shader cycles per tile and CU whatever the memory system does
 // (hipcc serialises its fragment reads, one tile in flight per workgroup, two barriers and a trip through LDS for the
 // output), and under this traffic the chip holds ~1.45 GHz: the launch was bound by its own instruction stream, which is why
-// neither fewer HBM bytes (L2-blocked tile order) nor cache residency made it faster.
+// neither fewer HBM bytes (L2-blocked tile order) nor cache residency made it faster.  This
+// kernel needs ~1,450 (MFMA floor: 1,024); measurements: DESIGN.md section 4.
 #include "dn_common.h"
 #include "dn_internal.h"
 
@@ -82,7 +86,7 @@ __device__ int32_t g_zero_idx[64];     // row 0 (device globals are zero-initial
 
 #define DN_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 
-template <bool MASK, bool IDX>
+template <bool MASK, bool IDX, bool EPI, bool HASX2>
 __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t flags, const bf16_t* __restrict__ mask_pos,
@@ -103,13 +107,16 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 
     if (wave >= kCompute) {
         // ------------------------------------------------------------------------------------------------ loaders
-        // Batch b = tiles [8 b, 8 b + 8).  When the rows of tile u = 8 b are issued (body(u)), the indices of batch b + 1 and
+        // Batch b = tiles [8 b, 8 b + 8).  At tile u = 8 b (batch(u)) the indices of batch b + 1 and
         // the records of batch b + 2 are requested; both are consumed 8 tiles later, by which time the counted wait at the top
-        // of an iteration (at most 6 iterations' DMAs outstanding) has covered them.
+        // of an iteration (at most 3 tiles' DMAs outstanding) has covered them.
         static_assert(kBatch == 8 && kNS - 1 <= kBatch && 3 * kBatch <= kRecRing && 2 * kBatch <= kIdxRing &&
-                      3 * kBatch <= kDescRing && kDmaPerTile * (kNS - 2) < 64, "ring sizes");
+                      3 * kBatch <= kDescRing && kDmaPerTile * (kNS - 2) < 64 && kNS >= 6 && (kBatch & 1) == 0, "ring sizes");
         const int q = wave - kCompute;
         const int rin = lane >> 5, pos = lane & 31;
+#ifdef DN_TUNING_ENV
+        if (flags & 256) __builtin_amdgcn_s_setprio(3);                    // (experiment: the loaders win the issue arbitration)
+#endif
         int swoff[kDmaPerTile];
 #pragma unroll
         for (int j = 0; j < kDmaPerTile; ++j) {
@@ -143,21 +150,37 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
                 idxR[q][T % kIdxRing][lane & 7] = pc;
             }
         };
-        auto body = [&](int u) {
-            if ((u & (kBatch - 1)) == 0) {                                 // wave-uniform
-                stage_idx(u + kBatch);
-                dma_recs(u + 2 * kBatch);
-            }
+        // The rows of tile u are requested right behind the barrier that frees their stage, from addresses worked out BEFORE it
+        // (prep(u): the index read and the address arithmetic of the next tile run while the loader would otherwise wait).
+        const char* srcA[kDmaPerTile];
+        const char* srcB[kDmaPerTile];
+        auto prep = [&](int u, const char* (&src)[kDmaPerTile]) {
             typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
             const i32x4 iv = *reinterpret_cast<const i32x4*>(&idxR[q][u % kIdxRing][4 * rin]);   // rows rin, 2 + rin, 4 + rin, 6 + rin
-            const unsigned st = lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB;
 #pragma unroll
             for (int j = 0; j < kDmaPerTile; ++j) {
                 int32_t r = iv[j];
-                if (flags & 16) r &= 1023;                                 // (tuning build: ablation, every gather hits L2)
-                const char* base = r < n1 ? reinterpret_cast<const char*>(X) + (size_t)r * kRowB
-                                          : reinterpret_cast<const char*>(X2) + (size_t)(r - n1) * kRowB;
-                glds16(base + swoff[j], st + (unsigned)(2 * j) * kRowB);   // lane l lands at + 16 l
+#ifdef DN_TUNING_ENV
+                if (flags & 16) r &= 1023;                                 // (ablation: every gather hits L2)
+#endif
+                const char* base = reinterpret_cast<const char*>(X) + (size_t)r * kRowB;
+                if constexpr (HASX2)
+                    if (r >= n1) base = reinterpret_cast<const char*>(X2) + (size_t)(r - n1) * kRowB;
+                src[j] = base + swoff[j];
+            }
+        };
+        auto rows = [&](int u, const char* (&src)[kDmaPerTile]) {
+            const unsigned st = lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB;
+#ifdef DN_TUNING_ENV
+            if (flags & 128) return;                                       // (ablation: no row DMAs)
+#endif
+#pragma unroll
+            for (int j = 0; j < kDmaPerTile; ++j) glds16(src[j], st + (unsigned)(2 * j) * kRowB);   // lane l lands at + 16 l
+        };
+        auto batch = [&](int u) {                                          // u = 8 b: indices of batch b + 1, records of batch b + 2
+            if ((u & (kBatch - 1)) == 0) {                                 // wave-uniform
+                stage_idx(u + kBatch);
+                dma_recs(u + 2 * kBatch);
             }
         };
         dma_recs(0);
@@ -165,19 +188,40 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
         wait_vmcnt<0>();
         stage_idx(0);
         wait_vmcnt<0>();
+        // One rendezvous per PAIR of tiles (every barrier makes twelve waves wait for the slowest of them): at the barrier
+        // of tiles 2 p, 2 p + 1 the tiles up to 2 p + 2 have landed (the compute waves fetch one tile's first fragments during
+        // the tile before it) and the stages of tiles 2 p - 2, 2 p - 1 are free; the rows of tiles 2 p + 6, 2 p + 7 go there.
 #pragma unroll 1
-        for (int u = 0; u < kNS - 1; ++u) body(u);
+        for (int u = 0; u < kNS - 2; ++u) {
+            batch(u);
+            prep(u, srcA);
+            rows(u, srcA);
+        }
+        batch(kNS - 2);
+        prep(kNS - 2, srcA);
+        batch(kNS - 1);
+        prep(kNS - 1, srcB);
+        wait_vmcnt<kDmaPerTile*(kNS - 3)>();                               // tile 0 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // (the compute waves fetch tile 0's fragments)
         unsigned long long st_vm = 0, st_bar = 0, st_body = 0;
         const unsigned long long l0 = DN_STAMP();
 #pragma unroll 1
-        for (int t = 0; t < nt; ++t) {
+        for (int t = 0; t < nt; t += 2) {
             const unsigned long long a0 = DN_STAMP();
-            wait_vmcnt<kDmaPerTile*(kNS - 2)>();                           // everything up to the rows of tile t has landed
+#ifdef DN_TUNING_ENV
+            if (flags & 128) wait_vmcnt<0>();                              // (ablation without row DMAs: the count no longer bounds)
+#endif
+            wait_vmcnt<kDmaPerTile*(kNS - 5)>();                           // issued: up to tile t + 5; landed: up to tile t + 2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the records I copied for the compute waves
             const unsigned long long a1 = DN_STAMP();
-            __builtin_amdgcn_s_barrier();                                  // everyone's have; stage of tile t-1 is free
+            __builtin_amdgcn_s_barrier();                                  // everyone's have; stages of tiles t-2, t-1 are free
             const unsigned long long a2 = DN_STAMP();
-            body(t + kNS - 1);
+            rows(t + kNS - 2, srcA);
+            rows(t + kNS - 1, srcB);
+            batch(t + kNS);
+            prep(t + kNS, srcA);
+            prep(t + kNS + 1, srcB);
             DN_STAT(st_vm, a1 - a0); DN_STAT(st_bar, a2 - a1); DN_STAT(st_body, DN_STAMP() - a2);
         }
         wait_vmcnt<0>();                                                   // nothing may land after the LDS is given back
@@ -192,20 +236,22 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 
     // ---------------------------------------------------------------------------------------------------- compute
     const bool relu = (flags & 1) != 0, nt_store = (flags & 2) != 0;
-    const bool late = wave >= kCompute / 2;                                // second compute wave of its SIMD: epilogue one tile late
+#ifdef DN_TUNING_ENV
+    if ((flags & 512) && wave >= kCompute / 2) __builtin_amdgcn_s_setprio(1);   // (experiment: the younger compute half)
+    if ((flags & 1024)) __builtin_amdgcn_s_setprio(2);                          // (experiment: compute over loaders)
+#endif
     const int n0 = 32 * wave;
     const int j = lane & 15, g = lane >> 4;
     // byte address of my fragment of k-step ks inside stage 0: row j (+ 16 m), piece (4 ks + g) ^ j
-    unsigned off[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) off[ks] = lds_base + (unsigned)(j * kRowB + (((4 * ks + g) ^ j) << 4));
+    // piece (4 ks + g) ^ j = (g ^ j) ^ (4 ks): with the stage bases multiples of 1 KiB, k-step ks is at (stage + off0) ^ (64 (ks & 3))
+    // + 256 (ks >> 2) -- one register, an XOR with a constant and an immediate offset
+    const unsigned off0 = lds_base + (unsigned)(j * kRowB + ((g ^ j) << 4));
     const int colA0 = 8 * (j >> 2) + (j & 3);                              // output column (minus n0) of A row j, MFMA tile 0
     const size_t ocol = (size_t)(n0 + 8 * g);
     bf16x8 wf[8][2];
     u32x4 bv = {0u, 0u, 0u, 0u};                                           // bias of my 8 columns (bf16 x 8)
     int cur_rel = -1;
     int32_t t_rel = 0, t_pbeg = 0, t_pend = 0;                             // record of the current tile
-    int32_t e_pbeg = 0, e_pend = 0;                                        // ... of the tile whose sums wait in acc (late waves)
     f32x4 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -228,16 +274,18 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[4 * n + i] = acc[m][n][i];
-            if (bias) {
+            if constexpr (EPI) {                                           // (the conv's launches carry neither bias nor ReLU)
+                if (bias) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[2 * i] += __uint_as_float(bv[i] << 16);
-                    v[2 * i + 1] += __uint_as_float(bv[i] & 0xffff0000u);
+                    for (int i = 0; i < 4; ++i) {
+                        v[2 * i] += __uint_as_float(bv[i] << 16);
+                        v[2 * i + 1] += __uint_as_float(bv[i] & 0xffff0000u);
+                    }
                 }
-            }
-            if (relu) {
+                if (relu) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
             }
             u32x4 o;
 #pragma unroll
@@ -250,13 +298,56 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
                     o[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
                 }
             }
-            if (p < pend && !((flags & 8) && p != 0)) {                    // (flags & 8: tuning build ablation, no stores)
+#ifdef DN_TUNING_ENV
+            if (p < pend && !((flags & 8) && p != 0)) {                    // (flags & 8: ablation, no stores)
+#else
+            if (p < pend) {
+#endif
                 u32x4* dst = reinterpret_cast<u32x4*>(Y + (size_t)p * kH + ocol);
                 if (nt_store) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
             }
         }
     };
+
+    // Software pipeline over tiles: the first two k-steps' fragments of tile t + 1 are fetched during tile t, each into the
+    // registers its k-step just consumed (an MFMA reads its A/B operands when it issues; the LDS answer comes >= 64 cycles
+    // later), and have arrived before the loop's back edge (lgkmcnt(0) behind the epilogue: no value the compiler may copy there
+    // is still in flight).  A wave therefore starts a tile's MFMAs at once; the other six k-steps' reads are issued at the top of
+    // the tile and land behind those MFMAs (counted waits).  Four or eight k-steps ahead made hipcc spill weights to scratch
+    // (168 registers a wave: weights 64 + fragments 64 + sums 16 + the values carried over the back edge).
+#define DN_FETCH(KS, SB)                                                                                              \
+    {                                                                                                                 \
+        const unsigned a_ = ((SB) + off0) ^ (unsigned)(((KS) & 3) << 6);                                              \
+        if ((KS) < 4) {                                                                                               \
+            DN_DS_READ128(xf[KS][0], a_, 0);                                                                          \
+            DN_DS_READ128(xf[KS][1], a_, 8192); /* rows 16..31 of the stage */                                        \
+        } else {                                                                                                      \
+            DN_DS_READ128(xf[KS][0], a_, 256);                                                                        \
+            DN_DS_READ128(xf[KS][1], a_, 8448);                                                                       \
+        }                                                                                                             \
+    }
+#ifdef DN_TUNING_ENV
+#define DN_SB(SBV) ((flags & 64) ? ((desc_base - off0) & ~1023u) : (SBV))             // (flags & 64: ablation, every lane reads one word)
+#else
+#define DN_SB(SBV) (SBV)
+#endif
+    bf16x8 xf[8][2];
+    u32x4 dn;                                                              // record of the next tile
+    __builtin_amdgcn_s_barrier();                                          // tile 0 has landed
+    {
+        const unsigned a0 = desc_base;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(a0));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) DN_FETCH(ks, 0u)
+    }
+#define DN_ARRIVED()                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                 : "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[1][0]), "+v"(xf[1][1]), "+v"(dn))
+    DN_ARRIVED();
+    t_rel = __builtin_amdgcn_readfirstlane((int)dn[0]);
+    t_pbeg = __builtin_amdgcn_readfirstlane((int)dn[1]);
+    t_pend = __builtin_amdgcn_readfirstlane((int)dn[2]);
 
     unsigned long long sc_bar = 0, sc_mfma = 0, sc_epi = 0;
     const unsigned long long c0 = DN_STAMP();
@@ -265,23 +356,18 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 #endif
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my fragment reads of tile t-1 are done
         const unsigned long long b0 = DN_STAMP();
-        __builtin_amdgcn_s_barrier();
+        if ((t & 1) == 0) __builtin_amdgcn_s_barrier();                    // one per pair of tiles: tiles up to t + 2 have landed
         const unsigned long long b1 = DN_STAMP();
         DN_STAT(sc_bar, b1 - b0);
-        if (t == 0) {                                                      // (later records arrive one tile ahead, below)
-            u32x4 d0;
-            const unsigned a0 = desc_base;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d0) : "v"(a0));
-            t_rel = __builtin_amdgcn_readfirstlane((int)d0[0]);
-            t_pbeg = __builtin_amdgcn_readfirstlane((int)d0[1]);
-            t_pend = __builtin_amdgcn_readfirstlane((int)d0[2]);
-        }
-        if (late && e_pend > e_pbeg) epilogue(e_pbeg, e_pend);             // tile t-1, while the partner wave multiplies tile t
         const unsigned long long b2 = DN_STAMP();
-        u32x4 dn;                                                          // record of tile t + 1
         const unsigned an = desc_base + (unsigned)((t + 1) % kDescRing) * 16u;
+        const unsigned sb = DN_SB((unsigned)(t % kNS) * kStageB);
+        const unsigned nsb = DN_SB((unsigned)((t + 1) % kNS) * kStageB);
+        if (t_pend > t_pbeg) {
+            DN_FETCH(2, sb) DN_FETCH(3, sb) DN_FETCH(4, sb) DN_FETCH(5, sb) DN_FETCH(6, sb) DN_FETCH(7, sb)
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (t_pend > t_pbeg) {
             if (t_rel != cur_rel) {                                        // wave-uniform, rare
                 cur_rel = t_rel;
@@ -291,50 +377,60 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         wf[ks][n] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
-                if (bias) bv = *reinterpret_cast<const u32x4*>(bias + (size_t)cur_rel * kH + n0 + 8 * g);
+                if constexpr (EPI)
+                    if (bias) bv = *reinterpret_cast<const u32x4*>(bias + (size_t)cur_rel * kH + n0 + 8 * g);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(wf[ks][n]));   // the wait for them stays in this branch
-                asm volatile("" : "+v"(bv));
+                if constexpr (EPI) asm volatile("" : "+v"(bv));
             }
-            const unsigned sb = (unsigned)(t % kNS) * kStageB;
-            bf16x8 xf[8][2];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const unsigned a = sb + off[ks];
-                DN_DS_READ128(xf[ks][0], a, 0);
-                DN_DS_READ128(xf[ks][1], a, 8192);                         // rows 16..31 of the stage
-            }
-            asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));      // the 17th: next tile's record
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define DN_KSTEP(KS, CNT)                                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(xf[KS][0]), "+v"(xf[KS][1]));                            \
+#define DN_MFMA4(KS)                                                                                                  \
             _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                              \
             _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                              \
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[KS][n], xf[KS][m], acc[m][n], 0, 0, 0);      \
             __builtin_amdgcn_sched_barrier(0);
-            DN_KSTEP(0, 15) DN_KSTEP(1, 13) DN_KSTEP(2, 11) DN_KSTEP(3, 9)
-            DN_KSTEP(4, 7) DN_KSTEP(5, 5) DN_KSTEP(6, 3) DN_KSTEP(7, 1)
-#undef DN_KSTEP
+#define DN_KSTEP_A(KS)  /* fragments fetched a tile ahead; refill them for tile t + 1 */                              \
+            DN_MFMA4(KS)                                                                                               \
+            DN_FETCH(KS, nsb)                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);
+#define DN_KSTEP_B(KS, CNT)  /* fragments fetched behind the barrier: behind them in the queue 2 (7 - KS) + 4 reads */  \
+            asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(xf[KS][0]), "+v"(xf[KS][1]));                            \
+            DN_MFMA4(KS)
+#ifdef DN_TUNING_ENV
+            if (flags & 32) {                                              // (ablation: no MFMAs)
+                DN_FETCH(0, nsb) DN_FETCH(1, nsb)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+            } else
+#endif
+            {
+            DN_KSTEP_A(0) DN_KSTEP_A(1)
+            DN_KSTEP_B(2, 14) DN_KSTEP_B(3, 12) DN_KSTEP_B(4, 10) DN_KSTEP_B(5, 8) DN_KSTEP_B(6, 6) DN_KSTEP_B(7, 4)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));    // (behind the last k-step: its registers are free)
+            }
+#undef DN_KSTEP_A
+#undef DN_KSTEP_B
+#undef DN_MFMA4
             const unsigned long long b3 = DN_STAMP();
             DN_STAT(sc_mfma, b3 - b2);
-            if (!late) epilogue(t_pbeg, t_pend);
+            epilogue(t_pbeg, t_pend);
             DN_STAT(sc_epi, DN_STAMP() - b3);
         } else {
+            DN_FETCH(0, nsb) DN_FETCH(1, nsb)
             asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
         }
-        e_pbeg = t_pbeg;
-        e_pend = t_pend;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn));
+        DN_ARRIVED();
         t_rel = __builtin_amdgcn_readfirstlane((int)dn[0]);
         t_pbeg = __builtin_amdgcn_readfirstlane((int)dn[1]);
         t_pend = __builtin_amdgcn_readfirstlane((int)dn[2]);
     }
-    if (late && e_pend > e_pbeg) epilogue(e_pbeg, e_pend);                 // the last tile's
+#undef DN_FETCH
+#undef DN_SB
+#undef DN_ARRIVED
 #ifdef DN_RING_STATS
     if (wave == 0 && lane == 0 && blockIdx.x < 256) {
         g_ring_stats[blockIdx.x][0] = DN_STAMP() - c0; g_ring_stats[blockIdx.x][1] = sc_bar;
@@ -349,23 +445,31 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 
 namespace dn_internal {
 
-int launch_transform_ring256(const void* X, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
+int launch_transform_ring256(const void* X_, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
                              int64_t tiles_per_wg, void* Y, hipStream_t st) {
     if (tiles_per_wg <= 0) tiles_per_wg = dn_cdiv(num_tiles, 256);       // one persistent workgroup per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    static const int abl = dn_knob("DN_TF_ABL", 0);                       // tuning build only: 1 no stores, 2 gathers hit L2
-    const int32_t flags = (relu ? 1 : 0) | (nt_store ? 2 : 0) | ((abl & 3) << 3);
-#define DN_RING_LAUNCH(M, I)                                                                                           \
-    hipLaunchKernelGGL((rows_transform_ring_kernel<M, I>), dim3((unsigned)grid), dim3(kThreads), 0, st, (const bf16_t*)X,   \
-                       (const bf16_t*)X2, n1, idx, (const bf16_t*)Wn, (const bf16_t*)bias, flags, (const bf16_t*)mask_pos,  \
+    static const int abl = dn_knob("DN_TF_ABL", 0);   // tuning build only: 1 no stores, 2 gathers hit L2, 4 no MFMAs, 8 trivial LDS reads, 16 no row DMAs
+    const int32_t flags = (relu ? 1 : 0) | (nt_store ? 2 : 0) | ((abl & 255) << 3);
+#define DN_RING_LAUNCH(M, I, E, X)                                                                                      \
+    hipLaunchKernelGGL((rows_transform_ring_kernel<M, I, E, X>), dim3((unsigned)grid), dim3(kThreads), 0, st, (const bf16_t*)X_, \
+                       (const bf16_t*)X2, n1, idx, (const bf16_t*)Wn, (const bf16_t*)bias, flags, (const bf16_t*)mask_pos,      \
                        reinterpret_cast<const Tile*>(tiles), (int32_t)num_tiles, (int32_t)tiles_per_wg, (bf16_t*)Y)
+    // the conv's launches (gathered rows, no epilogue, one source) get the leanest instruction stream: the loop is bound by
+    // vector-instruction issue, not by the matrix pipe (~180 VALU instructions per SIMD and tile before this split)
+    const bool epi = bias != nullptr || relu != 0;
+    const bool x2 = X2 != nullptr;
     if (mask_pos) {
-        if (idx) DN_RING_LAUNCH(true, true);
-        else DN_RING_LAUNCH(true, false);
+        if (idx) DN_RING_LAUNCH(true, true, true, true);
+        else DN_RING_LAUNCH(true, false, true, false);
+    } else if (idx) {
+        if (!epi && !x2) DN_RING_LAUNCH(false, true, false, false);
+        else if (!epi) DN_RING_LAUNCH(false, true, false, true);
+        else DN_RING_LAUNCH(false, true, true, true);
     } else {
-        if (idx) DN_RING_LAUNCH(false, true);
-        else DN_RING_LAUNCH(false, false);
+        if (!epi) DN_RING_LAUNCH(false, false, false, false);
+        else DN_RING_LAUNCH(false, false, true, false);
     }
 #undef DN_RING_LAUNCH
     DN_CHECK_LAUNCH();
