@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/fork.txt; : > $o
-timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -8 >> $o
+o=gpurun_out/ring_ns9.txt; : > $o
+for abl in 0 3 0; do echo "== ring DN_TF_ABL=$abl" >> $o; DN_TF_ABL=$abl timeout -k 10 300 python tools/sweep_exp.py --wgs 32 --only baseline --reps 40 2>&1 | grep "^dir\|fault\|rror" >> $o; done
 grep -q "Memory access fault" $o && { cat $o; exit 1; }
-for f in 1 0 1 0; do echo "== DN_TAIL_FORK=$f" >> $o; DN_TAIL_FORK=$f timeout -k 10 400 python tools/sweep_exp.py --wgs 32 --ab 2 2>&1 | grep "conv leg" >> $o; done
+timeout -k 10 400 python tools/sweep_exp.py --wgs 32 --ab 4 >> $o 2>&1
+grep -q "Memory access fault" $o && { cat $o; exit 1; }
 cat $o
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "transform or sweep or ring" 2>&1 | tail -3
