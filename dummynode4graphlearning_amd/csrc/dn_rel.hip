@@ -465,6 +465,197 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
 }
 
 // -------------------------------------------------------------------------------------------------
+// rows_wgrad_ix_kernel: the LDS-DMA ring above for GATHERED operands (both index arrays given; H = 256; the conv's weight
+// gradient), with the per-tile bookkeeping moved off the scalar unit.  In the kernel above every wave fetches its 8 row indices
+// with scalar loads right before the fragment reads, and the `s_waitcnt lgkmcnt(0)` in front of the first MFMA (SMEM shares the
+// counter with LDS) waits for them: ~2,400-2,900 cycles per 32-row tile against 1,024 of MFMA, from L2 as from HBM.  Here a
+// wave's 8 indices of a tile arrive as ONE 8-lane LDS-DMA two tiles ahead of their use (into a small per-wave LDS ring), the
+// row addresses are picked with selects instead of exec-masked branches, and nothing in the loop touches SMEM.
+// vmcnt arithmetic: a wave issues per tile [index DMA] [4 row DMAs], in this order.  (Walking the rows in the L2-blocked sweep order
+// with one partial product per run of tiles was built on top of this kernel and measured: 1.1 GB fewer HBM reads per launch, the same
+// time -- docs/LAB_NOTES.md, round 3.)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
+                                                                   int32_t na1, const int32_t* __restrict__ ia,
+                                                                   const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
+                                                                   int32_t ng1, const int32_t* __restrict__ ig,
+                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                   int32_t colsum_of, float* __restrict__ colsum_partial) {
+    constexpr int H = 256, TR = 32, NST = 4, ROWB = 2 * H, MATB = TR * ROWB, STB = 2 * MATB;
+    constexpr int LPRW = H / 8, RW = TR / 8;       // 32 lanes per row; 4 rows of each operand per wave and tile
+    constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
+    constexpr int kSlots = 8;                      // per-wave ring of index octets
+    constexpr int kOps = 5;                        // vector-memory operations a wave issues per tile
+    __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+    __shared__ __attribute__((aligned(32))) int32_t idxL[8][kSlots][8];       // {ia[p0..p0+3], ig[p0..p0+3]} of a wave's rows
+    typedef __attribute__((address_space(3))) char* lds_wp;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const Chunk ch = chunks[blockIdx.x];
+    const int ntiles = (ch.end - ch.beg + TR - 1) / TR;
+    const int32_t ch_beg = ch.beg, ch_end = ch.end;
+    const char* zero = reinterpret_cast<const char*>(g_zero_row);
+    const unsigned idx_base = (unsigned)(uintptr_t)(lds_wp)&idxL[wave][0][0];
+
+    // {first row of my 4, last row of the tile, live} of tile T (wave-uniform values; tiles past the end repeat the last one)
+    auto tile_rows = [&](int T, int& p0, int& pe, bool& live) {
+        live = T < ntiles;
+        const int Tc = min(T, ntiles - 1);
+        p0 = ch_beg + Tc * TR + RW * wave;
+        pe = min(ch_beg + Tc * TR + TR, ch_end) - 1;
+    };
+    auto dma_idx = [&](int T) {                    // lanes 0..7: {ia, ig}[min(p0 + (lane & 3), pe)] -> ring (lane l lands at + 4 l)
+        int p0, pe;
+        bool live;
+        tile_rows(T, p0, pe, live);
+        const int pc = max(min(p0 + (lane & 3), pe), 0);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T % kSlots) * 32u));
+        if (lane < 8) glds4((lane < 4 ? ia : ig) + pc, dst);
+    };
+    const int rin = lane / LPRW, cpos = lane % LPRW;
+    auto issue = [&](int T) {                      // the 4 row DMAs of tile T (indices of tile T have landed)
+        int p0, pe;
+        bool live;
+        tile_rows(T, p0, pe, live);
+        const int32_t* iv = &idxL[wave][T % kSlots][0];
+        const unsigned st = lds_base + (unsigned)(T % NST) * STB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * j + rin;                                     // my row of the wave's 4
+            const int rl = RW * wave + k;                                  // row of the stage this lane fills
+            const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
+            const int gch = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;   // source byte offset inside the row
+            const bool ok = live && p0 + k <= pe;
+            const int32_t ra = iv[k], rg = iv[4 + k];
+            const bool a2 = ra >= na1, g2 = rg >= ng1;
+            const uint64_t ba = a2 ? (uint64_t)(uintptr_t)A2 : (uint64_t)(uintptr_t)A;
+            const uint64_t bg = g2 ? (uint64_t)(uintptr_t)G2 : (uint64_t)(uintptr_t)G;
+            const uint64_t oa = (uint64_t)(uint32_t)(a2 ? ra - na1 : ra) * ROWB, og = (uint64_t)(uint32_t)(g2 ? rg - ng1 : rg) * ROWB;
+            const uint64_t pa = (ok ? ba + oa : (uint64_t)(uintptr_t)zero) + (uint64_t)gch;
+            const uint64_t pg = (ok ? bg + og : (uint64_t)(uintptr_t)zero) + (uint64_t)gch;
+            const unsigned da = st + (unsigned)(RW * wave + 2 * j) * ROWB;  // wave-uniform; lane l lands at + 16 l
+            glds16(reinterpret_cast<const char*>(pa), da);
+            glds16(reinterpret_cast<const char*>(pg), da + MATB);
+        }
+    };
+
+    // ---- MFMA side (as in rows_wgrad_dma_kernel) ----------------------------------------------------------------
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int fsw = fq | ((fg & 1) << 2);
+    const int frow = (8 * fg + fq) * ROWB + 8 * fp;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    auto frag = [&](const char* mat, int slot) -> bf16x8 {
+        const char* a0 = mat + frow + ((slot ^ fsw) << 5);
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * ROWB));
+        const short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int CPT = TR * LPRW / kWgThreads;                            // column-sum pieces per thread and tile (2)
+    const int cchunk = tid % LPRW, crow = tid / LPRW;
+    auto flush = [&](int slab) {                   // one partial product (+ its column sums) out to workspace slab `slab`; sums restart
+        float* out = partial + (size_t)slab * H * H;
+        const int k0 = wm * (H / 2), n0 = wn * (H / 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
+                    out[(size_t)k * H + c] = acc[m][n][i];
+                }
+                acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    // ---- prologue --------------------------------------------------------------------------------------------------
+    if (ntiles <= 0) {
+        for (int i = tid; i < H * H; i += kWgThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
+        if (colsum_of != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
+        return;
+    }
+#pragma unroll 1
+    for (int T = 0; T < 5; ++T) dma_idx(T);
+    wait_vmcnt<0>();
+#pragma unroll 1
+    for (int T = 0; T < NST - 1; ++T) issue(T);
+    wait_vmcnt<8>();                                                       // tile 0 has landed (the loop's count starts at tile 1)
+    const bool dma_first = wave < 4;
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        // issued after the index octet of tile t+3 (two tiles ago): its tile's 4 row DMAs and last tile's kOps operations
+        wait_vmcnt<kOps + 4>();                                            // rows of tile t, indices of tile t+3
+        __builtin_amdgcn_s_barrier();                                      // everyone's have; stage of tile t-1 is free
+        // the two waves of a SIMD (w and w + 4) take turns: one issues its DMAs while the other multiplies (issuing a DMA costs a
+        // wave 100-185 cycles; in lock step the SIMD's matrix pipe would idle through both waves' issue phases)
+        if (dma_first) {
+            dma_idx(t + 5);
+            issue(t + NST - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        char* sA = lds + (t % NST) * STB;
+        const char* sG = sA + MATB;
+        {
+            bf16x8 fb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) fb[n] = frag(sG, wn * NT + n);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 fa = frag(sA, wm * MT + m);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (colsum_of != 0) {
+            const char* M = colsum_of == 1 ? sA : sG;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int r = crow + j * (kWgThreads / LPRW);
+                const int f = (r & 3) | (((r >> 3) & 1) << 2);
+                const int pos = (((cchunk >> 1) ^ f) << 1) | (cchunk & 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(M + r * ROWB + pos * 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cs[2 * i] += __uint_as_float(w[i] << 16);
+                    cs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!dma_first) {
+            dma_idx(t + 5);
+            issue(t + NST - 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my LDS reads of tile t are done before the next barrier
+    }
+    wait_vmcnt<0>();                                                       // drain what is still in flight
+    __builtin_amdgcn_s_barrier();
+    flush((int)blockIdx.x);
+    if (colsum_of != 0) {
+        constexpr int TPC = kWgThreads / LPRW;
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[crow * H + cchunk * 8 + i] = cs[i];
+        __syncthreads();
+        if (tid < H) {
+            float sum = 0.f;
+            for (int sl = 0; sl < TPC; ++sl) sum += red[sl * H + tid];
+            colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // dn_rows_transform_bf16:   Y[p, :] = epi( X[idx[p], :] @ Wn[rel(p)]^T )          (rows p relation-major)
 //   Wn[r] is [HO][HI] (k contiguous), i.e. Y[p][n] = sum_k X[idx[p]][k] * Wn[r][n][k].
 //   One workgroup (4 waves) walks a contiguous range of 32-row tiles (tile table: {rel, beg, end}); each wave
@@ -1099,7 +1290,7 @@ template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
-                                                           int32_t H, float* __restrict__ out_colsum) {
+                                                           int32_t H, float* __restrict__ out_colsum, int32_t cs_mult) {
     constexpr int SL = 8, EL = 256 / SL;
     __shared__ float red[SL][EL];
     const int r = blockIdx.y;
@@ -1140,12 +1331,25 @@ int wgrad_dma_mode() {
     return mode;
 }
 
+int wgrad_ix_mode() {                              // tuning build: DN_WGRAD_IX=0 keeps the scalar-index ring for gathered operands
+    static const int mode = dn_knob("DN_WGRAD_IX", 1);
+    return mode;
+}
+
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
                  float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, hipStream_t st) {
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
         if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
+            if constexpr (HI == 256) {
+                if (maskBits == nullptr && ia != nullptr && ig != nullptr && wgrad_ix_mode()) {   // gathered operands: index ring
+                    hipLaunchKernelGGL(rows_wgrad_ix_kernel, dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
+                                       na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial);
+                    DN_CHECK_LAUNCH();
+                    return DN_OK;
+                }
+            }
             if (maskBits)
                 hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, true>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
                                    na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits);

@@ -194,6 +194,10 @@ def test_rows_wgrad_matches_reference(H, arith):
     _, cs_a = ops.rows_wgrad(A.to(DEV), G.to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV), colsum_of=1)
     cs_ref = torch.stack([A[ia[rel_ptr[r]:rel_ptr[r + 1]].long()].double().sum(0) for r in range(R)])
     torch.testing.assert_close(cs_a.cpu().double(), cs_ref, rtol=1e-4, atol=1e-3)
+    # operands as virtual concatenations [A1; A2], [G1; G2] (the conv's rows + its pre-aggregated rows): the same bits
+    got4 = ops.rows_wgrad(A[:2000].contiguous().to(DEV), G[:1700].contiguous().to(DEV), table, R, idx_a=ia.to(DEV), idx_g=ig.to(DEV),
+                          out_dtype=torch.float32, A2=A[2000:].contiguous().to(DEV), G2=G[1700:].contiguous().to(DEV))
+    assert torch.equal(got, got4)
     # contiguous rows (no index) + bf16 output
     P2 = min(P, NA, NG)
     t2 = ops.make_row_chunks([0, P2], DEV, chunk_rows=1024)
