@@ -1290,7 +1290,7 @@ template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
-                                                           int32_t H, float* __restrict__ out_colsum, int32_t cs_mult) {
+                                                           int32_t H, float* __restrict__ out_colsum) {
     constexpr int SL = 8, EL = 256 / SL;
     __shared__ float red[SL][EL];
     const int r = blockIdx.y;
