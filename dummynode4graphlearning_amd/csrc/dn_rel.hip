@@ -329,13 +329,16 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                 ra = (rin == k) ? nxa[RPI * j + k] : ra;
                 rg = (rin == k) ? nxg[RPI * j + k] : rg;
             }
-            const char* pa = ra < 0 ? zero : (ra < na1 ? reinterpret_cast<const char*>(A) + (size_t)ra * ROWB
-                                                       : reinterpret_cast<const char*>(A2) + (size_t)(ra - na1) * ROWB);
-            const char* pg = rg < 0 ? zero : (rg < ng1 ? reinterpret_cast<const char*>(G) + (size_t)rg * ROWB
-                                                       : reinterpret_cast<const char*>(G2) + (size_t)(rg - ng1) * ROWB);
+            // (selects, not branches: written as nested ?: on pointers hipcc emits two exec-masked regions per DMA)
+            const bool a2 = ra >= na1, g2 = rg >= ng1;
+            const uint64_t ba = a2 ? (uint64_t)(uintptr_t)A2 : (uint64_t)(uintptr_t)A;
+            const uint64_t bg = g2 ? (uint64_t)(uintptr_t)G2 : (uint64_t)(uintptr_t)G;
+            const uint64_t oa = (uint64_t)(uint32_t)(a2 ? ra - na1 : ra) * ROWB, og = (uint64_t)(uint32_t)(g2 ? rg - ng1 : rg) * ROWB;
+            const uint64_t pa = (ra < 0 ? (uint64_t)(uintptr_t)zero : ba + oa) + (uint64_t)gch;
+            const uint64_t pg = (rg < 0 ? (uint64_t)(uintptr_t)zero : bg + og) + (uint64_t)gch;
             const unsigned da = st + (unsigned)(RW * wave + RPI * j) * ROWB; // wave-uniform; lane l lands at + 16 l
-            glds16(pa + gch, da);
-            glds16(pg + gch, da + MATB);
+            glds16(reinterpret_cast<const char*>(pa), da);
+            glds16(reinterpret_cast<const char*>(pg), da + MATB);
         }
         if constexpr (MASKED) {
             // the mask bits of my RW rows: H/8 bytes per row = (H/128) 16-byte pieces; 8 active lanes, 128 bytes per wave
