@@ -1,16 +1,14 @@
 #!/usr/bin/env python3
-"""Timing of the conv weight gradient alone (config 5 or a shard of it): python tools/wgrad_exp.py [--graphs 32768] [--sweep W]
-(--sweep: additionally the L2-blocked order with a HOST-built table, tests/sweep_ref.py; the tuning build's DN_WGRAD_IX=0 selects the scalar-index kernel)."""
+"""Timing of the conv weight gradient alone (config 5 or a shard of it): python tools/wgrad_exp.py [--graphs 32768]
+(the tuning build's DN_WGRAD_IX=0 selects the scalar-index kernel)."""
 import argparse
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def timed(fn, reps=20):
@@ -29,7 +27,6 @@ def timed(fn, reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=32768)
-    ap.add_argument("--sweep", type=int, default=0)
     a = ap.parse_args()
     import bench
     from dummynode4graphlearning_amd import ops
@@ -62,19 +59,6 @@ def main():
             ref = xa[ix.row_in[a_:b_].long()].t() @ ga[ix.row_out[a_:b_].long()]
             worst = max(worst, float((gw0[r].double() - ref).abs().max() / ref.abs().max()))
     print("plain chunks (%d): %.1f us incl. reduce   max-norm error vs fp64 on 3 relations %.2e" % (ix.chunk_table[2], t0, worst), flush=True)
-    if a.sweep:
-        from sweep_ref import sweep_tables
-        rel_ptr = np.asarray(rp[:Rt + 1], dtype=np.int64)
-        row_in, row_out = ix.row_in.cpu().numpy().astype(np.int64), ix.row_out.cpu().numpy().astype(np.int64)
-        key = np.where(row_out < N, row_out, row_in)
-        tab, S, slot_ptr = sweep_tables(rel_ptr, key, N, a.sweep, with_slots=True)
-        st = (torch.from_numpy(tab.reshape(-1, 4)).to(dev), torch.from_numpy(slot_ptr).to(dev), tab.shape[0], S, int(slot_ptr[-1]))
-        t1, (gw1, cs1) = timed(lambda: ops.rows_wgrad_sweep(x, gout, st, Rt, **kw))
-        print("sweep order (%d x %d tiles, %d slots): %.1f us   difference gW %.2e, colsum %.2e" % (
-            tab.shape[0], S, int(slot_ptr[-1]), t1, float((gw1 - gw0).abs().max() / gw0.abs().max()),
-            float((cs1[-1] - cs0[-1]).abs().max() / cs0[-1].abs().max())), flush=True)
-        _, (gw2, cs2) = timed(lambda: ops.rows_wgrad_sweep(x, gout, st, Rt, **kw), reps=2)
-        print("bitwise reproducible:", bool(torch.equal(gw1, gw2) and torch.equal(cs1, cs2)), flush=True)
 
 
 if __name__ == "__main__":
