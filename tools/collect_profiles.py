@@ -44,12 +44,12 @@ STEP = [
     ("rows_selfsum_kernel", "closing launch bwd: self-loop transform + per-src slot sum + per-graph column sums of g"),
     ("overflow_rows_add_kernel", "nodes with > 6 outgoing rows finished from their lists (bwd)"),
     ("fold_tail_kernel", "fold tail bwd"),
-    ("rows_wgrad_dma_kernel", "conv wgrad (LDS-DMA ring; gathers x and g rows, + bias colsum)"),
+    ("rows_wgrad_ix_kernel", "conv wgrad (LDS-DMA ring, row indices by LDS-DMA; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
 CONV_ROWS = (0, 1, 2, 3, 10, 11, 12, 13)
 OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
-        "rows_wgrad_dma_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
+        "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
 
 
 def short(name):
