@@ -93,3 +93,51 @@ def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
     for (k, u), (_, v) in zip(ref.state_dict().items(), syn.state_dict().items()):
         if "running_" in k:
             torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5, msg=k)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shards_of_a_global_batch_reproduce_the_full_batch_step(world):
+    """What `bench.py --gpus N` relies on (no data-path collective): the config-5 layer run on each rank's shard of ONE
+    global batch (bench.shard_of = parallel.shard_graphs on the augmented sizes) gives the full-batch outputs row for row, and the
+    shards' parameter gradients add up to the full batch's -- here with all shards on the one GPU, bf16 pipeline, 1,024 graphs."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    dev = torch.device(DEV)
+    H, R, graphs = 256, 16, 1024
+    torch.manual_seed(3)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(dev).to(torch.bfloat16)
+    params = [p for p in layer.parameters()]
+
+    def run(gb, x, go):
+        for p in params:
+            p.grad = None
+        xs = x.clone().requires_grad_(True)
+        out, _ = layer(gb, xs, gb.edata["label"])
+        out.backward(go)
+        return out.detach().float(), xs.grad.float(), [p.grad.float().clone() for p in params]
+
+    full, raw, _ = bench.build_batch(dev, 5, graphs, "config5")
+    N = full.number_of_nodes()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(N, H, device=dev, generator=gen).to(torch.bfloat16)
+    go = torch.randn(N, H, device=dev, generator=gen).to(torch.bfloat16)
+    out_f, gx_f, gp_f = run(full, x, go)
+    outs, gxs, gps, covered = [], [], None, 0
+    for r in range(world):
+        shard, _, _ = bench.build_batch(dev, 5, graphs, "config5", shard=(r, world))
+        n = shard.number_of_nodes()
+        o, gx, gp = run(shard, x[covered:covered + n], go[covered:covered + n])      # shards are contiguous graph (= node) ranges
+        outs.append(o); gxs.append(gx)
+        gps = gp if gps is None else [a + b for a, b in zip(gps, gp)]
+        covered += n
+    assert covered == N
+    out_s, gx_s = torch.cat(outs), torch.cat(gxs)
+    # the same rows go through the same arithmetic; only tile boundaries (bf16 rounding points of the per-graph fold sums) move
+    assert float((out_s - out_f).abs().max() / out_f.abs().max()) < 2e-2
+    assert float((out_s - out_f).norm() / out_f.norm()) < 2e-3
+    assert float((gx_s - gx_f).norm() / gx_f.norm()) < 2e-3
+    for a, b, p in zip(gps, gp_f, params):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-6)) < 1e-2, tuple(p.shape)      # sums of bf16-rounded per-shard gradients
