@@ -361,6 +361,37 @@ def test_edge_dot_and_neighbor_max(dtype, H):
         torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tiles_per_wg", [1, 2, 3, 4, 7, 8, 9, 17])
+def test_ring_transform_at_every_short_pipeline_length(tiles_per_wg):
+    """The persistent H = 256 transform (dn_rel_ring.hip) meets all twelve waves once per PAIR of tiles and runs eight stages
+    ahead: tables that give a workgroup 1, 2, 3, ... tiles (shorter than the ring, odd counts, the last workgroup shorter than
+    the others), with EMPTY tiles in the middle and at the end of a workgroup's range and a relation change at every tile."""
+    ops = _ops()
+    H = 256
+    rng = np.random.default_rng(40 + tiles_per_wg)
+    ntile = 256 * tiles_per_wg - (tiles_per_wg > 1) * 3           # dn_cdiv(ntile, 256) == tiles_per_wg, last workgroups short
+    R, N1 = 7, 900
+    recs, rows = [], 0
+    for t in range(ntile):
+        if t % 11 == 5 or t >= ntile - 2:
+            recs.append((int(rng.integers(0, R)), rows, rows, 0))   # an empty tile: skipped, its relation not loaded
+            continue
+        n = 32 if t % 5 else int(rng.integers(1, 32))               # some partial tiles
+        recs.append((t % R, rows, rows + n, 0))
+        rows += n
+    P = rows
+    tiles = (torch.tensor(recs, dtype=torch.int32, device=DEV), ntile)
+    rel_of_row = torch.cat([torch.full((e - b,), r) for r, b, e, _ in recs if e > b])
+    X = torch.from_numpy(rng.standard_normal((N1, H)).astype(np.float32)).to(torch.bfloat16)
+    Wn = torch.from_numpy((rng.standard_normal((R, H, H)) / np.sqrt(H)).astype(np.float32)).to(torch.bfloat16)
+    idx = torch.from_numpy(rng.integers(0, N1, size=P)).to(torch.int32)
+    got = ops.rows_transform(X.to(DEV), Wn.to(DEV), tiles, P, idx=idx.to(DEV))
+    ref = torch.einsum("pk,pnk->pn", X.double()[idx.long()], Wn.double()[rel_of_row])
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-2, atol=2e-2)
+    again = ops.rows_transform(X.to(DEV), Wn.to(DEV), tiles, P, idx=idx.to(DEV))
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("H", [64, 128, 256])
 def test_rows_selfsum_matches_reference(H):
     """dn_rows_selfsum_bf16: self-loop transform + bias + fixed-slot row sum (nodes with more rows than slots finished from
