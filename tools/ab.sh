@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/ab.sh VAR v1 v2 ... -- [bench args]   : runs bench.py once per value of the env var VAR, prints ms/step etc.
-# The knobs of the Python layer (DN_SELFSUM, DN_CHAIN2, DN_PIPE*, DN_WGRAD_CHUNK, DN_F32_EXACT ...) work with the shipped
+# The knobs of the Python layer (DN_SELFSUM, DN_CHAIN2, DN_WGRAD_CHUNK, DN_F32_EXACT ...) work with the shipped
 # library; the knobs INSIDE libdn_hip.so (DN_STRIDE, DN_NT, DN_TF_DEPTH, DN_TF_WGS, DN_WGRAD_DMA) need a tuning build first:
 #   python -m dummynode4graphlearning_amd.csrc.build --tuning --force      (the default build has no environment access)
 VAR=$1; shift
