@@ -354,9 +354,9 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             ix = gb.row_index(et, R, True) if fused else gb.rel_index(et, R)
-            if fused and dtype == torch.bfloat16:   # the slot tables of the closing launch are part of the per-batch index cost
+            if fused and dtype == torch.bfloat16:   # the closing tables and tile orders are part of the per-batch index cost
                 for _, _, part in ix.parts:
-                    part.slots("f"), part.slots("b")
+                    ops.prepare_closing(part, H, dtype)
             torch.cuda.synchronize()
             return ix, (time.perf_counter() - t0) * 1e3
 
@@ -471,7 +471,7 @@ def main():
                 g._cache.clear()
                 ix = g.row_index(etype, R, True)
                 for _, _, part in ix.parts:
-                    part.slots("f"), part.slots("b")
+                    ops.prepare_closing(part, H, dtype)
                 return aug, ix
 
         for _ in range(2):

@@ -1,0 +1,623 @@
+// Closing launch of the row-factorised message pass, H = 256 bf16, as a stream of 32-row UNITS through an LDS-DMA ring
+// (the structure of dn_rel_ring.hip; replaces rows_selfsum_kernel + overflow_rows_add_kernel at this width).
+//
+//   out[v, :] = x[v, :] @ W_loop (+ bias)  +  sum_{rows p of v's list} S[p, :]          (rgin.py:137-146 after the fn.sum reduce)
+//
+// A tile = 32 consecutive nodes.  Its work is cut into units of 32 rows x 512 bytes that all travel the same way, global -> LDS by
+// LDS-DMA into a ring of eight 16-KiB stages, issued by four loader waves that do nothing else:
+//   * ONE X unit: the tile's 32 rows of x.  The eight compute waves (32 output columns each, their slice of W_loop in 64 VGPRs for
+//     the whole launch) multiply it exactly like the ring transform: 16 ds_read_b128 fragment reads, 32 v_mfma_f32_16x16x32_bf16 on
+//     the transposed tile (A = weights, B = rows), weight rows interleaved so that a lane ends with 8 consecutive columns of a row.
+//   * ceil(c / 32) ENTRY units: the c DISTINCT rows of S that the tile's nodes sum (dn_close_units_build_i32 lists them per tile,
+//     each with a 32-bit membership mask: bit i = node i of the tile adds this row; a row shared by many nodes of the tile -- the
+//     product of a collapsed "dummy -> u" relation -- is fetched once).  The sum is one more MFMA k-step per unit INTO THE SAME
+//     ACCUMULATORS:  acc[column][node] += sum_e S[e][column] * mask[e][node]  with A = the unit's rows read TRANSPOSED from the
+//     row-major LDS image (ds_read_b64_tr_b16; the chunk addresses a lane supplies reproduce the interleaved column order) and
+//     B = the 0/1 selection matrix built from the masks.  So there is no per-slot vector add, no fixed slot count and no overflow
+//     launch (a node with 500 rows is 16 more units), no staging of the products through LDS, one rounding at the end, and the
+//     finished rows leave as 16-byte streaming stores straight from the accumulators.
+//   * FOLD (the pre-aggregation of a collapsed relation absorbed here, as in rows_selfsum_kernel): the per-(graph, tile) column sums
+//     of x are the same transposed read of the X unit against a 0/1 segment indicator.
+// LDS image: unpadded rows, 16-byte pieces XOR-swizzled by (row & 15) on the per-lane SOURCE address of the DMA.  The
+// ds_read_b128 fragment reads (lane = row & 15 + 16 k-group) are conflict-free as in the ring transform; a transposed read takes
+// its four rows 4 apart (rows g + 4 q + 16 jh for lane group g), so the 16 lanes of a group hit 16 distinct 16-byte slots, and the
+// two groups that share a 32-lane bank cycle read the two different 8-byte halves (the registers are swapped back with selects).
+//
+// Numerics: everything that reaches an output element is summed in the fp32 accumulators in a fixed order and rounded once.
+// A non-finite element of S makes its column of the whole TILE NaN (0 x Inf inside the selection product), where the slot
+// kernel handed it to the nodes that sum that row only: DN_CLOSE_RING=0 restores the slot path for tracing overflows.
+#include "dn_common.h"
+#include "dn_internal.h"
+#include "../../include/dn_hip.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Unit {
+    int32_t flags, beg, end, aux;      // X unit: nodes [beg, end), aux = tile;  ENTRY unit: entries [beg, end), aux = the tile's first node
+};
+constexpr int kUnitEntry = 1, kUnitLast = 2;
+
+// ---------------------------------------------------------------------------------------------------------------- tables
+constexpr int kCbWaves = 4;            // tiles per workgroup of the builder (one wavefront each)
+constexpr int kCbCap = 512;            // list entries of a tile that are de-duplicated (LDS hash table); larger tiles are listed as is
+constexpr int kCbSlots = 1024;
+constexpr uint32_t kEmpty = 0xffffffffu;
+
+__device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total) {
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(s, d, 64);
+        if (lane >= d) s += o;
+    }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
+// One wavefront per tile, lane v < 32 = node p0 + v walks its own list (entries in list order = the order they are emitted in).
+// kept = rows < P (the self-loop rows are not list material here) outside the dropped range.  Entries of DIFFERENT nodes with the
+// same row merge into one (mask = OR of the node bits); a row that one node lists twice (parallel edges into a fanned-out row)
+// stays a second entry of its own.
+__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t P, int32_t T, const int32_t* __restrict__ lptr,
+                                                                      const int32_t* __restrict__ lrows, int32_t drop_beg,
+                                                                      int32_t drop_end, const int32_t* __restrict__ drop_enable,
+                                                                      int32_t* __restrict__ ent_row, uint32_t* __restrict__ ent_mask,
+                                                                      int32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t s_key[kCbWaves][kCbSlots], s_first[kCbWaves][kCbSlots], s_mask[kCbWaves][kCbSlots];
+    __shared__ int32_t s_plain[kCbWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = (int)blockIdx.x * kCbWaves + wave;
+    if (t >= T) return;                                                    // (no workgroup barrier below)
+    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
+    const int p0 = t * 32, pend = min(p0 + 32, N);
+    const int lb = lptr[p0], raw = lptr[pend] - lb;
+    const bool node = lane < pend - p0;
+    const int my_b = node ? lptr[p0 + lane] : 0, my_e = node ? lptr[p0 + lane + 1] : 0;
+    auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
+    uint32_t* key = s_key[wave];
+    uint32_t* first = s_first[wave];
+    uint32_t* msk = s_mask[wave];
+    bool plain = raw > kCbCap;
+    if (!plain) {
+        for (int i = lane; i < kCbSlots; i += 64) { key[i] = kEmpty; first[i] = kEmpty; msk[i] = 0u; }
+        if (lane == 0) s_plain[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int prev = -1;
+        for (int i = my_b; i < my_e; ++i) {
+            const int r = lrows[i];
+            if (!kept(r)) continue;
+            uint32_t h = ((uint32_t)r * 2654435761u) >> 22;
+            for (;;) {
+                const uint32_t old = atomicCAS(&key[h], kEmpty, (uint32_t)r);
+                if (old == kEmpty || old == (uint32_t)r) break;
+                h = (h + 1) & (kCbSlots - 1);
+            }
+            const uint32_t was = atomicOr(&msk[h], 1u << lane);
+            if (was & (1u << lane)) {                                      // my own earlier entry: stays separate
+                if (r != prev) s_plain[wave] = 1;                          // (lists are row-ordered; if not, list the tile as is)
+            } else {
+                atomicMin(&first[h], (uint32_t)(i - lb));
+            }
+            prev = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        plain = s_plain[wave] != 0;
+    }
+    // emitted entries of my list: count, prefix over the nodes, write
+    auto lookup = [&](int r) {
+        uint32_t h = ((uint32_t)r * 2654435761u) >> 22;
+        while (key[h] != (uint32_t)r) h = (h + 1) & (kCbSlots - 1);
+        return h;
+    };
+    int mine = 0;
+    {
+        int prev = -1;
+        for (int i = my_b; i < my_e; ++i) {
+            const int r = lrows[i];
+            if (!kept(r)) continue;
+            if (plain || r == prev) ++mine;
+            else if (first[lookup(r)] == (uint32_t)(i - lb)) ++mine;
+            prev = r;
+        }
+    }
+    int total;
+    int at = lb + wave_excl_sum(mine, lane, total);
+    {
+        int prev = -1;
+        for (int i = my_b; i < my_e; ++i) {
+            const int r = lrows[i];
+            if (!kept(r)) continue;
+            if (plain || r == prev) {
+                ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
+            } else {
+                const uint32_t h = lookup(r);
+                if (first[h] == (uint32_t)(i - lb)) {
+                    uint32_t m = msk[h];
+                    // a node that lists the row twice contributes its FIRST occurrence to the merged entry only: its bit is set once
+                    ent_row[at] = r; ent_mask[at] = m; ++at;
+                }
+            }
+            prev = r;
+        }
+    }
+    if (lane == 0) tile_cnt[t] = total;
+}
+
+// Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
+// as one stream); position k' = w * Tper + n holds tile n * G + w.  One workgroup scans the G * Tper unit counts.
+__global__ __launch_bounds__(1024) void close_scan_kernel(int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_cnt,
+                                                          int32_t* __restrict__ uoff, int32_t* __restrict__ unit_ptr) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t M = (int64_t)G * Tper;
+    const int64_t per = (M + 1023) / 1024;
+    const int64_t k0 = min((int64_t)tid * per, M), k1 = min(k0 + per, M);
+    auto units_at = [&](int64_t k) -> int32_t {
+        const int64_t tl = (k % Tper) * G + k / Tper;
+        return tl < T ? 1 + (tile_cnt[tl] + 31) / 32 : 0;
+    };
+    int32_t s = 0;
+    for (int64_t k = k0; k < k1; ++k) s += units_at(k);
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                                   // Hillis-Steele over the 1024 partial sums
+        const int32_t o = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += o;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - s;
+    for (int64_t k = k0; k < k1; ++k) {
+        uoff[k] = run;
+        if (k % Tper == 0) unit_ptr[k / Tper] = run;
+        run += units_at(k);
+    }
+    if (tid == 1023) { uoff[M] = part[1023]; unit_ptr[G] = part[1023]; }
+}
+
+__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ lptr,
+                                  const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ uoff, Unit* __restrict__ units) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k = (t % G) * Tper + t / G;
+    const int32_t p0 = (int32_t)t * 32, pend = min(p0 + 32, N), c = tile_cnt[t], e0 = lptr[p0];
+    Unit* u = units + uoff[k];
+    const int ne = (c + 31) / 32;
+    u[0] = Unit{ne == 0 ? kUnitLast : 0, p0, pend, (int32_t)t};
+    for (int i = 0; i < ne; ++i)
+        u[1 + i] = Unit{kUnitEntry | (i == ne - 1 ? kUnitLast : 0), e0 + 32 * i, e0 + min(32 * (i + 1), c), p0};
+}
+
+// ---------------------------------------------------------------------------------------------------------------- kernel
+constexpr int kH = 256;
+constexpr int kRowB = 2 * kH;          // bytes per row
+constexpr int kTR = 32;                // rows per unit
+constexpr int kStageB = kTR * kRowB;   // 16 KiB
+constexpr int kNS = 8;                 // ring stages (128 KiB)
+constexpr int kCompute = 8, kLoaders = 4;
+constexpr int kThreads = 64 * (kCompute + kLoaders);
+constexpr int kRowsPerLoader = kTR / kLoaders;      // 8
+constexpr int kDmaPerTile = kRowsPerLoader / 2;     // 4 DMA wave-instructions per loader and unit (2 rows each)
+constexpr int kBatch = 8;                           // units per batch of records / indices / masks
+constexpr int kRecRing = 32, kIdxRing = 16, kDescRing = 32, kMaskRing = 32, kFoldRing = 32;
+constexpr int kFoldInfo = 12;                       // int32 words per tile of the fold table (dn_fold_tables_build_i32)
+
+__device__ int32_t g_close_zero[64];                // zeros (device globals are zero-initialised): the mask of a row past a unit's end
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (bf16_t)a;
+    v[1] = (bf16_t)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+#define DN_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+
+template <bool FOLD>
+__global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int32_t w_kn, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ S, const Unit* __restrict__ units, const int32_t* __restrict__ unit_ptr,
+    const int32_t* __restrict__ ent_row, const uint32_t* __restrict__ ent_mask, int32_t N, int32_t flags, bf16_t* __restrict__ out,
+    const int32_t* __restrict__ fold_info, float* __restrict__ seg_part) {
+    __shared__ __attribute__((aligned(1024))) char lds[kNS * kStageB];
+    __shared__ __attribute__((aligned(1024))) int32_t foldR[kFoldRing][16];                   // fold records of the X units (12 words used)
+    __shared__ __attribute__((aligned(256))) uint32_t maskR[kMaskRing][32];                   // membership masks of the entry units, k order
+    __shared__ __attribute__((aligned(16))) int32_t descL[kDescRing][4];                      // unit records for the compute waves
+    __shared__ __attribute__((aligned(128))) int32_t recR[kLoaders][kRecRing][4];             // loader-private rings: unit records
+    __shared__ __attribute__((aligned(256))) int32_t idxR[kLoaders][kIdxRing][kRowsPerLoader]; // ... and source rows
+    typedef __attribute__((address_space(3))) char* lds_wp;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
+    const unsigned desc_base = (unsigned)(uintptr_t)(lds_wp)&descL[0][0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u_beg = unit_ptr[blockIdx.x];
+    const int nt = unit_ptr[blockIdx.x + 1] - u_beg;
+    if (nt <= 0) return;
+    units += u_beg;
+
+    if (wave >= kCompute) {
+        // ------------------------------------------------------------------------------------------------ loaders
+        // (the protocol of dn_rel_ring.hip: records two batches ahead, source rows and masks one batch ahead, rows kNS - 2 units
+        // ahead; one rendezvous per pair of units; the counted wait only ever gets stricter by the extra DMAs of a batch)
+        static_assert(kBatch == 8 && kNS - 1 <= kBatch && 3 * kBatch <= kRecRing && 2 * kBatch <= kIdxRing &&
+                      3 * kBatch <= kDescRing && 3 * kBatch <= kMaskRing && 3 * kBatch <= kFoldRing &&
+                      kDmaPerTile * (kNS - 2) < 64 && kNS >= 6 && (kBatch & 1) == 0, "ring sizes");
+        const int q = wave - kCompute;
+        const int rin = lane >> 5, pos = lane & 31;
+        int swoff[kDmaPerTile];
+#pragma unroll
+        for (int j = 0; j < kDmaPerTile; ++j) {
+            const int rl = kRowsPerLoader * q + 2 * j + rin;               // row of the stage this lane fills
+            swoff[j] = (pos ^ (rl & 15)) * 16;                             // source byte offset inside the row
+        }
+        const unsigned rec_base = (unsigned)(uintptr_t)(lds_wp)&recR[q][0][0];
+        const unsigned idx_base = (unsigned)(uintptr_t)(lds_wp)&idxR[q][0][0];
+        const unsigned mask_base = (unsigned)(uintptr_t)(lds_wp)&maskR[0][0];
+        const unsigned fold_base = (unsigned)(uintptr_t)(lds_wp)&foldR[0][0];
+        const int myrow = 2 * (lane & 3) + ((lane >> 2) & 1);              // the index ring holds a unit's 8 rows as {0,2,4,6,1,3,5,7}
+        auto dma_recs = [&](int T0) {                                      // records of units T0 .. T0 + 7 (clamped: valid memory)
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(rec_base + (unsigned)(T0 % kRecRing) * 16u));
+            if (lane < kBatch) glds16(units + min(T0 + lane, nt - 1), dst);
+        };
+        auto stage_idx = [&](int T0) {                                     // source rows of my 8 rows of units T0 .. T0 + 7; records -> descL
+            const int T = T0 + (lane >> 3);
+            const int32_t* rp = &recR[q][T % kRecRing][0];
+            const int fl = rp[0], beg = rp[1], end = rp[2];
+            const int pc = end > beg ? min(beg + kRowsPerLoader * q + myrow, end - 1) : 0;   // past the end: the last row again
+            if (q == 0 && lane < 4 * kBatch)
+                descL[(T0 + (lane >> 2)) % kDescRing][lane & 3] = recR[0][(T0 + (lane >> 2)) % kRecRing][lane & 3];
+            const unsigned dst =
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T0 % kIdxRing) * (4u * kRowsPerLoader)));
+            if (fl & kUnitEntry) glds4(ent_row + pc, dst);                 // lane l lands at + 4 l: [unit][8 rows]
+            else idxR[q][T % kIdxRing][lane & 7] = pc;                     // an X unit's rows are its nodes
+            // membership masks of units T0 + 2 q, T0 + 2 q + 1, in the k order of the transposed reads:
+            // position k = 8 g + 4 jh + qq  <->  row g + 16 jh + 4 qq of the unit
+            {
+                const int Tm = T0 + 2 * q + (lane >> 5), kk = lane & 31;
+                const int r = (kk >> 3) + 16 * ((kk >> 2) & 1) + 4 * (kk & 3);
+                const int32_t* mp = &recR[q][Tm % kRecRing][0];
+                const int e = mp[1] + r;
+                const bool ok = (mp[0] & kUnitEntry) && e < mp[2];
+                const unsigned mdst =
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(mask_base + (unsigned)((T0 + 2 * q) % kMaskRing) * 128u));
+                glds4(ok ? (const void*)(ent_mask + e) : (const void*)(g_close_zero + kk), mdst);
+            }
+            if constexpr (FOLD) {
+                if (q == 1) {                                              // fold records of the batch's X units: lane 4 k + c = 16-byte chunk c
+                    const int Tf = T0 + (lane >> 2), c = lane & 3;
+                    const int32_t* fp = &recR[1][Tf % kRecRing][0];
+                    const unsigned fdst =
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)(fold_base + (unsigned)(T0 % kFoldRing) * 64u));
+                    if (lane < 4 * kBatch && c < 3 && !(fp[0] & kUnitEntry))
+                        glds16(fold_info + (size_t)fp[3] * kFoldInfo + 4 * c, fdst);
+                }
+            }
+        };
+        const char* srcA[kDmaPerTile];
+        const char* srcB[kDmaPerTile];
+        auto prep = [&](int u, const char* (&src)[kDmaPerTile]) {
+            typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 iv = *reinterpret_cast<const i32x4*>(&idxR[q][u % kIdxRing][4 * rin]);   // rows rin, 2 + rin, 4 + rin, 6 + rin
+            const bool ent = (recR[q][u % kRecRing][0] & kUnitEntry) != 0;
+            const char* base0 = reinterpret_cast<const char*>(ent ? S : X);
+#pragma unroll
+            for (int j = 0; j < kDmaPerTile; ++j) src[j] = base0 + (size_t)(uint32_t)iv[j] * kRowB + swoff[j];
+        };
+        auto rows = [&](int u, const char* (&src)[kDmaPerTile]) {
+            const unsigned st = lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB;
+#pragma unroll
+            for (int j = 0; j < kDmaPerTile; ++j) glds16(src[j], st + (unsigned)(2 * j) * kRowB);   // lane l lands at + 16 l
+        };
+        auto batch = [&](int u) {                                          // u = 8 b: rows / masks of batch b + 1, records of batch b + 2
+            if ((u & (kBatch - 1)) == 0) {                                 // wave-uniform
+                stage_idx(u + kBatch);
+                dma_recs(u + 2 * kBatch);
+            }
+        };
+        dma_recs(0);
+        dma_recs(kBatch);
+        wait_vmcnt<0>();
+        stage_idx(0);
+        wait_vmcnt<0>();
+#pragma unroll 1
+        for (int u = 0; u < kNS - 2; ++u) {
+            batch(u);
+            prep(u, srcA);
+            rows(u, srcA);
+        }
+        batch(kNS - 2);
+        prep(kNS - 2, srcA);
+        batch(kNS - 1);
+        prep(kNS - 1, srcB);
+        wait_vmcnt<kDmaPerTile*(kNS - 3)>();                               // unit 0 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = 0; t < nt; t += 2) {
+            wait_vmcnt<kDmaPerTile*(kNS - 5)>();                           // issued: up to unit t + 5; landed: up to unit t + 2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the records I copied for the compute waves
+            __builtin_amdgcn_s_barrier();                                  // everyone's have; stages of units t-2, t-1 are free
+            rows(t + kNS - 2, srcA);
+            rows(t + kNS - 1, srcB);
+            batch(t + kNS);
+            prep(t + kNS, srcA);
+            prep(t + kNS + 1, srcB);
+        }
+        wait_vmcnt<0>();                                                   // nothing may land after the LDS is given back
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- compute
+    const bool nt_store = (flags & 2) != 0;
+    const int n0 = 32 * wave;
+    const int j = lane & 15, g = lane >> 4;
+    // fragment of k-step ks inside stage 0: row j (+ 16 m), piece (4 ks + g) ^ j  (dn_rel_ring.hip)
+    const unsigned off0 = lds_base + (unsigned)(j * kRowB + ((g ^ j) << 4));
+    const int colA0 = 8 * (j >> 2) + (j & 3);                              // output column (minus n0) of A row j, MFMA tile 0
+    const size_t ocol = (size_t)(n0 + 8 * g);
+    // transposed reads: lane (group g, q4 = j >> 2, p4 = j & 3) supplies row g + 4 q4 (+ 16 jh), logical piece 4 wave + p4, 8-byte half
+    // nn; read t = 2 jh + s takes half s ^ (g & 1)
+    const int q4 = j >> 2, p4 = j & 3, rt = g + 4 * q4;
+    const unsigned tr0 = (unsigned)(rt * kRowB + (((4 * wave + p4) ^ rt) << 4) + 8 * (g & 1));     // (relative to the stage)
+    const bool odd = (g & 1) != 0;
+    bf16x8 wf[8][2];
+    if (w_kn == 0) {                                                       // W given as [out][in] (the caller's transposed copy)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                wf[ks][n] = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
+    } else {                                                               // W as the parameter stores it, [in][out]: once per launch
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[ks][n][e] = W[(size_t)(ks * 32 + 8 * g + e) * kH + n0 + colA0 + 4 * n];
+    }
+    u32x4 bv = {0u, 0u, 0u, 0u};                                           // bias of my 8 columns (bf16 x 8)
+    if (bias) bv = *reinterpret_cast<const u32x4*>(bias + n0 + 8 * g);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef short4v __attribute__((address_space(3))) * lds_tr;
+    // A operand of a transposed product over the 32 rows of a stage: element jj of a[n] = row g + 16 (jj >> 2) + 4 (jj & 3),
+    // column n0 + 8 (j >> 2) + 4 n + (j & 3)
+    auto tr_frags = [&](unsigned sb, bf16x8 (&a)[2]) {
+        const unsigned b0 = sb + tr0;
+        const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)b0);
+        const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)(b0 ^ 8u));
+        const short4v r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)(b0 + 16u * kRowB));
+        const short4v r3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)((b0 ^ 8u) + 16u * kRowB));
+        const short4v lo0 = odd ? r1 : r0, hi0 = odd ? r3 : r2;           // half 0 of the pieces: columns + 0..3
+        const short4v lo1 = odd ? r0 : r1, hi1 = odd ? r2 : r3;           // half 1: columns + 4..7
+        const short8v f0 = {lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]};
+        const short8v f1 = {lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]};
+        a[0] = __builtin_bit_cast(bf16x8, f0);
+        a[1] = __builtin_bit_cast(bf16x8, f1);
+    };
+
+    // rows p0 + j and p0 + 16 + j of the tile, my 8 columns: bias, bf16, one 16-byte store each
+    auto epilogue = [&](int32_t p0, int32_t pend) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int p = p0 + j + 16 * m;
+            float v[8];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * n + i] = acc[m][n][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] += __uint_as_float(bv[i] << 16);
+                v[2 * i + 1] += __uint_as_float(bv[i] & 0xffff0000u);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+            if (p < pend) {
+                u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)p * kH + ocol);
+                if (nt_store) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
+            }
+        }
+    };
+
+#define DN_FETCH(KS, SB)                                                                                              \
+    {                                                                                                                 \
+        const unsigned a_ = ((SB) + off0) ^ (unsigned)(((KS) & 3) << 6);                                              \
+        if ((KS) < 4) {                                                                                               \
+            DN_DS_READ128(xf[KS][0], a_, 0);                                                                          \
+            DN_DS_READ128(xf[KS][1], a_, 8192); /* rows 16..31 of the stage */                                        \
+        } else {                                                                                                      \
+            DN_DS_READ128(xf[KS][0], a_, 256);                                                                        \
+            DN_DS_READ128(xf[KS][1], a_, 8448);                                                                       \
+        }                                                                                                             \
+    }
+#define DN_KSTEP(KS, CNT) /* behind this k-step's two reads in the queue: 2 (7 - KS) reads + the next record */       \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(xf[KS][0]), "+v"(xf[KS][1]));                                    \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                      \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                      \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[KS][n], xf[KS][m], acc[m][n], 0, 0, 0);              \
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 dn;                                                              // record of the next unit
+    __builtin_amdgcn_s_barrier();                                          // unit 0 has landed
+    {
+        const unsigned a0 = desc_base;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(a0));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");
+    int32_t u_fl = __builtin_amdgcn_readfirstlane((int)dn[0]);
+    int32_t u_beg2 = __builtin_amdgcn_readfirstlane((int)dn[1]);
+    int32_t u_aux = __builtin_amdgcn_readfirstlane((int)dn[3]);
+
+#pragma unroll 1
+    for (int u = 0; u < nt; ++u) {
+        if ((u & 1) == 0) __builtin_amdgcn_s_barrier();                    // one per pair of units: units up to u + 2 have landed
+        const unsigned an = desc_base + (unsigned)((u + 1) % kDescRing) * 16u;
+        const unsigned sb = (unsigned)(u % kNS) * kStageB;
+        int32_t p0;
+        if (!(u_fl & kUnitEntry)) {
+            // ---- X unit: acc = W_loop^T-slice x rows^T
+            p0 = u_beg2;
+            bf16x8 xf[8][2];
+            DN_FETCH(0, sb) DN_FETCH(1, sb) DN_FETCH(2, sb) DN_FETCH(3, sb) DN_FETCH(4, sb) DN_FETCH(5, sb) DN_FETCH(6, sb) DN_FETCH(7, sb)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            DN_KSTEP(0, 15) DN_KSTEP(1, 13) DN_KSTEP(2, 11) DN_KSTEP(3, 9) DN_KSTEP(4, 7) DN_KSTEP(5, 5) DN_KSTEP(6, 3) DN_KSTEP(7, 1)
+            if constexpr (FOLD) {
+                // column sums of the tile's x rows per segment (graph): D[column][s] = sum_r x[r][column] [row r in segment s]
+                const int32_t* fr = &foldR[u % kFoldRing][0];
+                const int cnt = __builtin_amdgcn_readfirstlane(fr[9]);
+                if (cnt > 0) {
+                    const int first = fr[8];
+                    const u32x4 w0 = *reinterpret_cast<const u32x4*>(fr), w1 = *reinterpret_cast<const u32x4*>(fr + 4);
+                    uint32_t id[8];                                        // local segment id of my row jj: byte g of word jj
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        id[i] = (w0[i] >> (8 * g)) & 0xffu;
+                        id[4 + i] = (w1[i] >> (8 * g)) & 0xffu;
+                    }
+                    bf16x8 a[2];
+                    tr_frags(lds_base + sb, a);
+                    for (int m0 = 0; m0 < cnt; m0 += 16) {                 // (more than 16 segments in 32 rows: graphs of 1-2 nodes)
+                        const uint32_t me = (uint32_t)(m0 + j);
+                        u32x4 iw;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            iw[i] = (id[2 * i] == me ? 0x3f80u : 0u) | (id[2 * i + 1] == me ? 0x3f800000u : 0u);
+                        const bf16x8 ind = __builtin_bit_cast(bf16x8, iw);
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            if ((int)me < cnt)
+                                *reinterpret_cast<f32x4*>(seg_part + (size_t)(first + (int)me) * kH + ocol + 4 * n) = d;
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- entry unit: acc[column][node] += sum_e S[e][column] * mask[e][node]
+            p0 = u_aux;
+            const u32x4 mA = *reinterpret_cast<const u32x4*>(&maskR[u % kMaskRing][8 * g]);
+            const u32x4 mB = *reinterpret_cast<const u32x4*>(&maskR[u % kMaskRing][8 * g + 4]);
+            bf16x8 a[2];
+            tr_frags(lds_base + sb, a);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+            bf16x8 sel[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const uint32_t rb = (uint32_t)(j + 16 * m);
+                u32x4 sw;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    sw[i] = (((mA[2 * i] >> rb) & 1u) | (((mA[2 * i + 1] >> rb) & 1u) << 16)) * 0x3f80u;
+                    sw[2 + i] = (((mB[2 * i] >> rb) & 1u) | (((mB[2 * i + 1] >> rb) & 1u) << 16)) * 0x3f80u;
+                }
+                sel[m] = __builtin_bit_cast(bf16x8, sw);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], sel[m], acc[m][n], 0, 0, 0);
+        }
+        if (u_fl & kUnitLast) epilogue(p0, min(p0 + kTR, N));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");     // my LDS reads are done before I arrive at a barrier
+        u_fl = __builtin_amdgcn_readfirstlane((int)dn[0]);
+        u_beg2 = __builtin_amdgcn_readfirstlane((int)dn[1]);
+        u_aux = __builtin_amdgcn_readfirstlane((int)dn[3]);
+    }
+#undef DN_FETCH
+#undef DN_KSTEP
+}
+#undef DN_DS_READ128
+
+}  // namespace
+
+extern "C" {
+
+int64_t dn_close_units_capacity(int64_t N, int64_t num_list_entries) {
+    const int64_t T = dn_cdiv(N, 32);
+    return 2 * T + num_list_entries / 32 + 1;
+}
+
+size_t dn_close_units_workspace_bytes(int64_t N, int32_t num_wg) {
+    if (N < 0 || num_wg <= 0) { dn_set_error("dn_close_units_workspace_bytes: bad sizes"); return 0; }
+    const int64_t T = dn_cdiv(N, 32), Tper = dn_cdiv(T, num_wg);
+    return (size_t)(T + 1) * 4 + (size_t)((int64_t)num_wg * Tper + 1) * 4 + 512;
+}
+
+int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* list_ptr, const int32_t* list_rows,
+                             int64_t num_list_entries, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
+                             int32_t* unit_ptr, int32_t* units, int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask,
+                             void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_edge_rows >= 0 && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0,
+               "dn_close_units_build: bad sizes");
+    DN_REQUIRE(unit_ptr, "dn_close_units_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) { DN_CHECK_HIP(hipMemsetAsync(unit_ptr, 0, sizeof(int32_t) * ((size_t)num_wg + 1), st)); return DN_OK; }
+    DN_REQUIRE(list_ptr && list_rows && units && ent_row && ent_mask && workspace, "dn_close_units_build: NULL pointer");
+    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(N, num_list_entries), "dn_close_units_build: unit table too small");
+    DN_REQUIRE(workspace_bytes >= dn_close_units_workspace_bytes(N, num_wg), "dn_close_units_build: workspace too small");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(units) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 4 == 0,
+               "dn_close_units_build: unaligned pointer");
+    const int32_t T = (int32_t)dn_cdiv(N, 32), Tper = (int32_t)dn_cdiv(T, num_wg);
+    int32_t* tile_cnt = reinterpret_cast<int32_t*>(workspace);
+    int32_t* uoff = tile_cnt + T + 1;
+    hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,
+                       T, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt);
+    DN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(close_scan_kernel, dim3(1), dim3(1024), 0, st, T, num_wg, Tper, tile_cnt, uoff, unit_ptr);
+    DN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(T, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, list_ptr, tile_cnt,
+                       uoff, reinterpret_cast<Unit*>(units));
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
+                       const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
+                       const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
+                       dn_stream_t stream) {
+    DN_REQUIRE(H == 256, "dn_rows_close: unsupported width %d (256 only; dn_rows_selfsum_bf16 serves 64 / 128)", H);
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096, "dn_rows_close: bad sizes");
+    DN_REQUIRE(fold_info == nullptr || seg_part != nullptr, "dn_rows_close: fold_info needs seg_part");
+    if (N == 0) return DN_OK;
+    DN_REQUIRE(X && W && unit_ptr && units && ent_row && ent_mask && out, "dn_rows_close: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(S) |
+                reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(units) | reinterpret_cast<uintptr_t>(bias) |
+                reinterpret_cast<uintptr_t>(fold_info) | reinterpret_cast<uintptr_t>(seg_part)) % 16 == 0,
+               "dn_rows_close: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    static const int nt = dn_knob("DN_NT", 3);
+    const int32_t flags = (nt & 2) ? 2 : 0;
+    const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
+    if (fold_info)
+        hipLaunchKernelGGL((rows_close_ring_kernel<true>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X,
+                           (const bf16_t*)W, w_kn, (const bf16_t*)bias, s, reinterpret_cast<const Unit*>(units), unit_ptr, ent_row,
+                           ent_mask, (int32_t)N, flags, (bf16_t*)out, fold_info, seg_part);
+    else
+        hipLaunchKernelGGL((rows_close_ring_kernel<false>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X,
+                           (const bf16_t*)W, w_kn, (const bf16_t*)bias, s, reinterpret_cast<const Unit*>(units), unit_ptr, ent_row,
+                           ent_mask, (int32_t)N, flags, (bf16_t*)out, fold_info, seg_part);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // extern "C"

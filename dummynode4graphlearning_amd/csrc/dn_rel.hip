@@ -1572,7 +1572,9 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     DN_REQUIRE(reinterpret_cast<uintptr_t>(mk) % 16 == 0, "dn_rows_transform: unaligned mask");
     static const int ring = dn_knob("DN_TF_RING", 1);
     static const int nt_knob = dn_knob("DN_NT", 3);
-    if (Hi == 256 && ring)
+    // (identity rows over the concatenation [X; X2] -- idx == NULL with a second source -- stay on the register-staged kernel:
+    //  the ring kernel's loaders only tell the two sources apart through the row index)
+    if (Hi == 256 && ring && (idx != nullptr || X2 == nullptr))
         return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, st);
     if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);

@@ -44,7 +44,7 @@ class StepGraph:
             torch.cuda.synchronize()
             msg = str(exc)
             capture_related = any(k in msg for k in ("captur", "Captur", "hipErrorStreamCapture", "cudaErrorStreamCapture",
-                                                     "operation not permitted when stream is capturing", "graph"))
+                                                     "operation not permitted when stream is capturing"))
             from ._lib import DnHipError
             if not fallback or not capture_related or isinstance(exc, DnHipError):
                 raise

@@ -492,6 +492,70 @@ def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SL
     return slots, over
 
 
+# The closing launch at H = 256 as a stream of 32-row units (csrc/dn_close.hip): no slot limit, no overflow launch.
+# DN_CLOSE_RING=0 keeps dn_rows_selfsum_bf16 + dn_overflow_rows_add_bf16 at every width (e.g. to trace a non-finite row: the
+# unit kernel turns a NaN / Inf of one product row into NaN for that column of the whole 32-node tile).
+CLOSE_RING_ENABLED = _os.environ.get("DN_CLOSE_RING", "1") != "0"
+
+
+class CloseUnits:
+    """Tables of dn_rows_close_bf16 for one direction of a RowIndex (dn_close_units_build_i32)."""
+    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes")
+
+
+def _num_cus(dev):
+    return int(torch.cuda.get_device_properties(dev).multi_processor_count)
+
+
+def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None):
+    """Per 32-node tile the distinct kept rows of its nodes' lists + membership masks, and the per-workgroup unit records the
+    closing launch streams (three launches, no read-back).  Same filter as build_slot_table."""
+    require_gpu(list_ptr, list_rows)
+    dev = list_rows.device
+    N, P, L = int(num_nodes), int(num_edge_rows), int(list_rows.numel())
+    list_ptr, list_rows = list_ptr.to(I32).contiguous(), list_rows.to(I32).contiguous()
+    cu = CloseUnits()
+    cu.num_wg = int(num_wg) if num_wg else _num_cus(dev)
+    cu.num_nodes = N
+    cap = int(lib().dn_close_units_capacity(N, L))
+    cu.unit_ptr = torch.empty(cu.num_wg + 1, dtype=I32, device=dev)
+    cu.units = torch.empty((cap, 4), dtype=I32, device=dev)
+    cu.ent_row = torch.empty(max(L, 1), dtype=I32, device=dev)
+    cu.ent_mask = torch.empty(max(L, 1), dtype=I32, device=dev)
+    ws = _ws(lib().dn_close_units_workspace_bytes(N, cu.num_wg), dev)
+    check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(list_ptr), ptr(list_rows), L, int(drop[0]), int(drop[1]),
+                                         ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap, ptr(cu.ent_row), ptr(cu.ent_mask),
+                                         ptr(ws), ws.numel(), stream_ptr()), "dn_close_units_build_i32")
+    return cu
+
+
+def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False):
+    """out[v] = x[v] @ W_loop (+ bias) + sum of the rows of S that cu lists for v  (dn_rows_close_bf16, H = 256).
+    W: [out, in] (w_kn False, the transposed copy) or [in, out] as the parameter stores it (w_kn True).  seg as in rows_selfsum."""
+    require_gpu(x, W, bias, S, cu.unit_ptr, cu.units, cu.ent_row, cu.ent_mask)
+    N, H = x.shape
+    assert H == 256 and x.dtype == torch.bfloat16 and W.shape == (H, H) and W.dtype == x.dtype and N == cu.num_nodes
+    assert S is None or (S.dtype == x.dtype and S.shape[1] == H and S.is_contiguous())
+    x, W = x.contiguous(), W.contiguous()
+    if seg is not None:
+        require_gpu(*seg)
+        assert seg[0].dtype == I32 and seg[0].shape == ((N + 31) // 32, 12) and seg[0].is_contiguous()
+        assert seg[1].dtype == torch.float32 and seg[1].shape[1] == H and seg[1].is_contiguous()
+    if out is None:
+        out = torch.empty((N, H), dtype=x.dtype, device=x.device)
+
+    def _launch():
+        check(lib().dn_rows_close_bf16(ptr(x), H, ptr(W), 1 if w_kn else 0, ptr(bias), ptr(S) if S is not None and S.numel() else None,
+                                       ptr(cu.unit_ptr), ptr(cu.units), cu.num_wg, ptr(cu.ent_row), ptr(cu.ent_mask), N, ptr(out),
+                                       ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, stream_ptr()),
+              "dn_rows_close_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_close", _launch)
+    else:
+        _launch()
+    return out
+
+
 def wgrad_supported(A, G):
     return A.dtype == G.dtype and A.dtype in MFMA_DTYPES and A.shape[1] == G.shape[1] and A.shape[1] in (64, 128, 256)
 
@@ -1088,7 +1152,7 @@ class RowIndex:
         rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
         self.rel_ptr_dev = rel_ptr_d                                # (reused by the fold tables: one upload per batch)
         self._tile_table = self._edge_tile_table = None             # built on first use: the folded bf16 path needs neither
-        self._slots, self._fold = {}, {}
+        self._slots, self._units, self._fold = {}, {}, {}
         # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size:
         # the smallest chunk that keeps ALL relations' chunks (each relation ends in a partial one) within one round of 256
         self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
@@ -1098,13 +1162,28 @@ def _conv_tiles(ix, fold, xs):
     """Tile table of the edge rows (minus the folded relation) for the conv's transform launch: the L2-blocked sweep order when
     the persistent H = 256 bf16 launch will walk it and the batch is large enough for the order to matter (built once per
     index and direction, on first use), else the plain relation-major tiles."""
+    return _conv_tiles_for(ix, fold, xs.shape[1], xs.dtype)
+
+
+def _conv_tiles_for(ix, fold, H, dtype):
     P, R = ix.num_edge_rows, ix.num_rels
-    if not (SWEEP_ENABLED and xs.dtype == torch.bfloat16 and xs.shape[1] == 256 and R <= 64
+    if not (SWEEP_ENABLED and dtype == torch.bfloat16 and H == 256 and R <= 64
             and P // 32 >= 8 * SWEEP_WG_PER_GROUP * SWEEP_MIN_TILES_PER_WG):
         return fold.main_tiles
     if fold.sweep_tiles is None:
         fold.sweep_tiles = build_sweep_tables(ix.rel_ptr_dev, R, ix.row_in, ix.row_out, ix.num_nodes, P, skip_mask=1 << fold.rel)
     return fold.sweep_tiles
+
+
+def prepare_closing(ix, H, dtype):
+    """Every table message_pass would build lazily on a batch's first step -- the closing tables of both directions (slot tables
+    or unit streams, fold tables) and the sweep tile orders -- so that a loop can account the per-batch index cost outside the
+    step (bench.py's index_build_ms, the overlapped fresh-batch leg)."""
+    kind = "units" if (CLOSE_RING_ENABLED and H == 256 and dtype == torch.bfloat16) else "slots"
+    _closing_tables(ix, kind)
+    for d in ("f", "b"):
+        if ix._fold[d] is not None:
+            _conv_tiles_for(ix, ix._fold[d], H, dtype)
 
 
 def _row_index_tile_table(ix):
@@ -1140,55 +1219,83 @@ def _fold_candidate(ix, direction):
     return (r, beg, end, n_aux) if end - beg == n_aux else None
 
 
-def _closing_tables(ix):
-    """Slot tables and fold tables of BOTH directions of a RowIndex, queued back to back (dn_fold_tables_build_async_i32 leaves its
-    verdict on the device, dn_slot_table_build_i32 reads it there to decide whether the folded relation's rows are left out of
-    the slots); the host reads the two verdicts in ONE copy (it picks the launch sequence by them)."""
-    if ix._slots:
+def _closing_tables(ix, kind="slots"):
+    """Tables of the closing launches of BOTH directions of a RowIndex, queued back to back: the fold tables
+    (dn_fold_tables_build_async_i32 leaves its verdict on the device) and, per direction, either the slot table
+    (kind "slots": dn_rows_selfsum_bf16) or the unit stream (kind "units": dn_rows_close_bf16, H = 256) -- both builders read the
+    verdict on the device to decide whether the folded relation's rows are left out.  The host reads the two verdicts in ONE copy
+    (it picks the launch sequence by them).  A second kind on the same index reuses the verdicts."""
+    have = ix._slots if kind == "slots" else ix._units
+    if have:
         return
     N, P, dev, K = ix.num_nodes, ix.num_edge_rows, ix.row_in.device, SELFSUM_SLOTS
-    flags = torch.zeros(2, dtype=I32, device=dev)                  # [ok_f, ok_b]: verdicts of the two fold-table builds
+    first = not ix._fold
+    flags = torch.zeros(2, dtype=I32, device=dev) if first else None   # [ok_f, ok_b]: verdicts of the two fold-table builds
     work = {}
     for k, direction in enumerate(("f", "b")):
-        cand = _fold_candidate(ix, direction)
-        fold_info = part_ptr = None
-        if cand is not None:
-            aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
-            fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
-            part_ptr = torch.empty(cand[3] + 1, dtype=I32, device=dev)
-            ws = _ws(lib().dn_fold_tables_workspace_bytes(cand[3]), dev)
-            check(lib().dn_fold_tables_build_async_i32(N, cand[3], ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
-                                                       ptr(flags[k:]), ptr(ws), ws.numel(), stream_ptr()),
-                  "dn_fold_tables_build_async_i32")
+        cand = fold_info = part_ptr = drop_enable = None
+        drop = (0, 0)
+        if first:
+            cand = _fold_candidate(ix, direction)
+            if cand is not None:
+                aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+                fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
+                part_ptr = torch.empty(cand[3] + 1, dtype=I32, device=dev)
+                ws = _ws(lib().dn_fold_tables_workspace_bytes(cand[3]), dev)
+                check(lib().dn_fold_tables_build_async_i32(N, cand[3], ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
+                                                           ptr(flags[k:]), ptr(ws), ws.numel(), stream_ptr()),
+                      "dn_fold_tables_build_async_i32")
+                drop, drop_enable = (cand[1], cand[2]), flags[k:]
+        elif ix._fold[direction] is not None:
+            drop = (ix._fold[direction].beg, ix._fold[direction].end)
         ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
         ptr_, rows = ptr_.to(I32).contiguous(), rows.to(I32).contiguous()
-        slots, over = build_slot_table(ptr_, rows, N, P, K, drop=(cand[1], cand[2]) if cand else (0, 0),
-                                       drop_enable=flags[k:] if cand else None)
-        work[direction] = (cand, fold_info, part_ptr, slots, ptr_, rows, over)
-    h = flags.cpu().tolist()                                        # the one synchronisation: the two fold verdicts
+        if kind == "slots":
+            tab = build_slot_table(ptr_, rows, N, P, K, drop=drop, drop_enable=drop_enable)
+        else:
+            tab = build_close_units(ptr_, rows, N, P, drop=drop, drop_enable=drop_enable)
+        work[direction] = (cand, fold_info, part_ptr, tab, ptr_, rows)
+    h = flags.cpu().tolist() if first else None                     # the one synchronisation: the two fold verdicts
     for k, direction in enumerate(("f", "b")):
-        cand, fold_info, part_ptr, slots, ptr_, rows, over = work[direction]
-        info = None
-        if cand is not None and h[k] != 0:
-            r, beg, end, n_aux = cand
-            info = _Fold()
-            info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-            info.fold_info, info.part_ptr = fold_info, part_ptr
-            info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
-            #                                                    starts one partial row, every tile boundary inside one another
-            info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
-            info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
-            info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
-        ix._fold[direction] = info
+        cand, fold_info, part_ptr, tab, ptr_, rows = work[direction]
+        if first:
+            info = None
+            if cand is not None and h[k] != 0:
+                r, beg, end, n_aux = cand
+                info = _Fold()
+                info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
+                info.fold_info, info.part_ptr = fold_info, part_ptr
+                info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
+                #                                                    starts one partial row, every tile boundary inside one another
+                info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+                info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
+                info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+            ix._fold[direction] = info
+        info = ix._fold[direction]
         drop = (info.beg, info.end) if info is not None else (0, 0)
-        ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1], over))
+        if kind == "slots":
+            slots, over = tab
+            ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1], over))
+        else:
+            ix._units[direction] = tab
 
 
 def _row_index_slots(ix, direction):
     """Slot tables of a RowIndex for the fused closing launch ('f': rows into each destination, 'b': rows out of each source).
     The rows of a FOLDED relation (_row_index_fold) are left out: they are added by the tail launches."""
-    _closing_tables(ix)
+    _closing_tables(ix, "slots")
     return ix._slots[direction]
+
+
+def _row_index_close_units(ix, direction):
+    """The same lists as the unit stream of dn_rows_close_bf16 (H = 256)."""
+    _closing_tables(ix, "units")
+    return ix._units[direction]
+
+
+def _close_kind(x):
+    """Which closing launch serves rows of this width: the unit stream (H = 256) or the slot kernel."""
+    return "units" if (CLOSE_RING_ENABLED and x.shape[1] == 256 and x.dtype == torch.bfloat16) else "slots"
 
 
 # The collapsed relation of a dummy-augmented batch (u -> dummy forward, dummy -> u backward) needs the SUM of a graph's rows as
@@ -1202,15 +1309,16 @@ class _Fold:
     __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "sweep_tiles", "add_idx")
 
 
-def _row_index_fold(ix, direction):
+def _row_index_fold(ix, direction, kind="slots"):
     """The relation whose pre-aggregation the closing launch can absorb, or None: exactly ONE collapsed relation in this
     direction (AGG forward / TF backward), its aux lists contiguous ascending node ranges (a graph's nodes), bf16 self-loop path
-    (checked on the device by dn_fold_tables_build_async_i32; the verdict comes back with the slot tables' counts)."""
-    _closing_tables(ix)
+    (checked on the device by dn_fold_tables_build_async_i32; the verdict comes back with the closing tables of `kind`)."""
+    _closing_tables(ix, kind)
     return ix._fold[direction]
 
 
 RowIndex.slots = _row_index_slots
+RowIndex.close_units = _row_index_close_units
 
 
 class RowIndexSet:
@@ -1260,16 +1368,24 @@ def fold_tail(part, part_ptr, num_segments, Wn, idx, out):
     return aux
 
 
+def _closing_launch(xs, W_loop, bias, Y, ix, direction, out, seg=None):
+    """The closing launch over one RowIndex: the unit stream at H = 256 (dn_rows_close_bf16), else the slot kernel + its
+    overflow launch (dn_rows_selfsum_bf16, dn_overflow_rows_add_bf16)."""
+    if _close_kind(xs) == "units":
+        return rows_close(xs, W_loop, bias, Y, ix.close_units(direction), out=out, seg=seg)
+    slots, lists = ix.slots(direction)
+    return rows_selfsum(xs, W_loop, bias, Y, None, slots, out=out, seg=seg, lists=lists)
+
+
 def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
     """message_pass with the collapsed relation's pre-aggregation absorbed by the closing launch: transform of every other
     relation -> closing launch (+ per-graph column sums of xs) -> tail launch (combine the sums, transform the one row per graph,
     add each product to its node).  Same sums as the unfolded path up to bf16 rounding of the collapsed rows."""
-    fold = _row_index_fold(ix, direction)
+    fold = _row_index_fold(ix, direction, _close_kind(xs))
     P, H = ix.num_edge_rows, xs.shape[1]
     Y = rows_transform(xs, Wmat, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf)
-    slots, lists = ix.slots(direction)
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
-    rows_selfsum(xs, Wmat[-1], bias, Y[:P], None, slots, out=out, seg=(fold.fold_info, part), lists=lists)
+    _closing_launch(xs, Wmat[-1], bias, Y[:P], ix, direction, out, seg=(fold.fold_info, part))
     return fold_tail(part, fold.part_ptr, fold.n, Wmat[fold.rel], fold.add_idx, out)
 
 
@@ -1285,14 +1401,13 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
-    if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction) is not None:
+    if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction, _close_kind(xs)) is not None:
         return _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows)
     aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
     if _selfsum_ok(ix, xs):
         P = ix.num_edge_rows
         Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
-        slots, lists = ix.slots(direction)
-        rows_selfsum(xs, Wmat[-1], bias, Y[:P], None, slots, out=out, lists=lists)
+        _closing_launch(xs, Wmat[-1], bias, Y[:P], ix, direction, out)
         return aux
     bias_all = None
     if bias is not None:

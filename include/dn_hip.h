@@ -373,6 +373,38 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
                               const int32_t* list_rows, int32_t num_edge_rows, int32_t drop_beg, int32_t drop_end, void* out,
                               dn_stream_t stream);
 
+/* The closing launch at H = 256 as a stream of 32-row units (csrc/dn_close.hip; same result as dn_rows_selfsum_bf16 +
+ * dn_overflow_rows_add_bf16, with no slot limit and no second launch):
+ *   out[v, :] = X[v, :] @ W_loop (+ bias)  +  sum over the kept rows p of v's list of S[p, :]
+ * (the reference's `fn.sum(msg, out)` reduce + `th.matmul(node_feat, self.loop_weight)` + bias,
+ * subgraph_isomorphism/models/rgin.py:137-146 / rgcn.py:166-182; backward direction: the same for the input gradient).
+ *
+ * dn_close_units_build_i32 (one-shot index build per batch and direction, three launches, no host synchronisation; the
+ * bookkeeping dgl.batch + update_all do per step, subgraph_isomorphism/dataset.py:1605-1611): nodes are cut into tiles of 32;
+ * for every tile the DISTINCT kept rows of its nodes' lists (list_ptr [N+1] / list_rows as in dn_slot_table_build_i32, same
+ * num_edge_rows / drop range / drop_enable filter) are written to ent_row with a 32-bit membership mask in ent_mask (bit i: node
+ * 32 t + i adds the row; a row that ONE node lists twice stays a second entry), at the offset list_ptr[32 t] onwards -- so
+ * ent_row / ent_mask need num_list_entries elements.  units [unit_capacity][4] int32 records {flags, beg, end, aux} in
+ * WORKGROUP-MAJOR order (workgroup w of num_wg takes tiles w, w + num_wg, ...; its records are units[unit_ptr[w] .. unit_ptr[w+1])):
+ * per tile one X record {0 | 2 if no entries, first node, end node, tile} followed by one record per 32 entries
+ * {1 | 2 on the last, first entry, end entry, first node}.  unit_capacity >= dn_close_units_capacity(N, num_list_entries).
+ *
+ * dn_rows_close_bf16: one persistent workgroup per entry of unit_ptr (launch num_wg = the builder's).  W: the self-loop weight,
+ * w_kn = 0: [H][H] with k contiguous (W_loop transposed, as dn_rows_selfsum_bf16 takes it), w_kn = 1: [k][n] as the
+ * parameter stores it (`loop_weight`, rgin.py:61) -- no transposed copy needed.  bias may be NULL.  fold_info / seg_part: the
+ * folded pre-aggregation exactly as in dn_rows_selfsum_bf16.  A non-finite element of S turns its column of the whole 32-node
+ * tile into NaN (0 x Inf inside the selection product).  H must be 256. */
+int64_t dn_close_units_capacity(int64_t N, int64_t num_list_entries);
+size_t dn_close_units_workspace_bytes(int64_t N, int32_t num_wg);
+int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* list_ptr, const int32_t* list_rows,
+                             int64_t num_list_entries, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
+                             int32_t* unit_ptr, int32_t* units, int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask,
+                             void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
+                       const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
+                       const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
+                       dn_stream_t stream);
+
 /* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph
  * that feed / are fed by its dummy node, subgraph_isomorphism/dataset.py:1563-1603).  host_ok = 1 when every segment is a

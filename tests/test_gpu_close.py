@@ -1,0 +1,132 @@
+"""The H = 256 closing launch as a unit stream (csrc/dn_close.hip): dn_close_units_build_i32 bit-exact against its host
+restatement (tests/close_ref.py), dn_rows_close_bf16 against fp64 math on the same bf16 operands and against the slot kernel it
+replaces (dn_rows_selfsum_bf16 + dn_overflow_rows_add_bf16).  Reference semantics: the fn.sum reduce + self loop + bias of
+subgraph_isomorphism/models/rgin.py:137-146."""
+import numpy as np
+import pytest
+import torch
+
+from close_ref import close_units_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lists(rng, N, P, kind):
+    """Per-node row lists (row-ordered, each ending with the node's self row P + v as the row index builders emit them)."""
+    lists = []
+    shared = np.sort(rng.choice(P, size=max(N // 20, 2), replace=False))        # rows fanned out to runs of consecutive nodes
+    for v in range(N):
+        c = int(rng.poisson(2.0))
+        rows = list(rng.integers(0, P, size=c))
+        if kind != "plain":
+            rows.append(int(shared[(v // 29) % len(shared)]))                    # one row shared by ~29 consecutive nodes
+        if kind == "repeat" and v % 7 == 0 and rows:
+            rows.append(rows[0])                                                 # the same row twice in ONE list (parallel edges)
+        if kind == "hub" and v in (3, 40, N - 1):
+            rows += list(rng.integers(0, P, size=700 if v == 40 else 90))        # a tile over the de-duplication capacity / long lists
+        lists.append(np.append(np.sort(np.array(rows, dtype=np.int64)), P + v))
+    if kind == "unsorted":
+        lists[5] = np.array([7, 9, 7, P + 5])                                    # a repeat that is not adjacent: the tile is listed as is
+    ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    return lists, ptr, np.concatenate(lists)
+
+
+@pytest.mark.parametrize("kind", ["plain", "shared", "repeat", "hub", "unsorted"])
+@pytest.mark.parametrize("N,G", [(1000, 256), (33, 4), (64, 1), (2500, 7)])
+def test_close_unit_tables_match_the_host_restatement(kind, N, G):
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(N + G)
+    P = 3 * N
+    lists, ptr, rows = _lists(rng, N, P, kind)
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    for drop in ((0, 0), (P // 3, P // 2)):
+        cu = ops.build_close_units(lp, lr, N, P, drop=drop, num_wg=G)
+        up, un, tiles = close_units_ref(ptr, rows, N, P, G, drop)
+        got_up = cu.unit_ptr.cpu().numpy()
+        assert np.array_equal(got_up, up), (got_up[:8], up[:8])
+        assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
+        er, em = cu.ent_row.cpu().numpy(), cu.ent_mask.cpu().numpy().view(np.uint32)
+        for t, (e0, r, m) in tiles.items():
+            assert list(er[e0:e0 + len(r)]) == r, t
+            assert list(em[e0:e0 + len(r)]) == m, t
+        # the lists are reproduced exactly: node v's kept rows (with multiplicity) = the entries of its tile that carry its bit
+        for v in rng.integers(0, N, size=50):
+            e0, r, m = tiles[v // 32]
+            mine = sorted(rr for rr, mm in zip(r, m) if (mm >> (v % 32)) & 1)
+            want = sorted(int(x) for x in lists[v] if x < P and not (drop[0] <= x < drop[1]))
+            assert mine == want
+
+
+def _close_case(rng, N, P, kind):
+    H = 256
+    lists, ptr, rows = _lists(rng, N, P, kind)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, Y = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((P, H)))
+    W = bf(rng.standard_normal((H, H)) / np.sqrt(H))                           # [in][out], as the parameter stores it
+    b = bf(rng.standard_normal(H))
+    return lists, ptr, rows, x, Y, W, b
+
+
+def _ref_close(x, W, b, Y, lists, P, drop=(0, 0)):
+    ref = x.double() @ W.double() + (b.double() if b is not None else 0.0)
+    for v, l in enumerate(lists):
+        keep = [int(r) for r in l if r < P and not (drop[0] <= r < drop[1])]
+        if keep:
+            ref[v] += Y[keep].double().sum(0)
+    return ref
+
+
+@pytest.mark.parametrize("kind", ["shared", "repeat", "hub"])
+@pytest.mark.parametrize("N,G", [(1003, 256), (1003, 3), (37, 256), (32, 1), (4100, 256)])
+def test_rows_close_matches_reference(kind, N, G):
+    """Every pipeline length (workgroups with 0, 1, 2, ... units up to hundreds), both weight layouts, with / without bias, a
+    dropped row range; against fp64 on the same bf16 operands (one rounding of the fp32 sums: 2^-8 relative to the row)."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(N * 7 + G)
+    P = 3 * N
+    lists, ptr, rows, x, Y, W, b = _close_case(rng, N, P, kind)
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    xd, Yd, Wd, bd = x.to(DEV), Y.to(DEV), W.to(DEV), b.to(DEV)
+    Wn = Wd.t().contiguous()
+    cu = ops.build_close_units(lp, lr, N, P, num_wg=G)
+    outs = []
+    for bias, w_kn in ((bd, True), (bd, False), (None, True)):
+        out = ops.rows_close(xd, Wd if w_kn else Wn, bias, Yd, cu, w_kn=w_kn)
+        ref = _ref_close(x, W, b if bias is not None else None, Y, lists, P)
+        err = (out.cpu().double() - ref).abs() / (ref.abs() + 1.0)
+        assert float(err.max()) < 6e-3, (w_kn, float(err.max()), int(err.max(1).values.argmax()))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])                                       # the two weight layouts: same arithmetic
+    assert torch.equal(outs[0], ops.rows_close(xd, Wd, bd, Yd, cu, w_kn=True))  # run to run
+    d0, d1 = P // 4, P // 2
+    cud = ops.build_close_units(lp, lr, N, P, drop=(d0, d1), num_wg=G)
+    out = ops.rows_close(xd, Wd, None, Yd, cud, w_kn=True)
+    ref = _ref_close(x, W, None, Y, lists, P, (d0, d1))
+    assert float(((out.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max()) < 6e-3
+
+
+def test_rows_close_against_the_slot_kernel_and_without_any_rows():
+    """Same inputs through dn_rows_selfsum_bf16 + dn_overflow_rows_add_bf16: the two closing launches agree to the slot kernel's
+    extra roundings; a batch without a single list row is x W + b."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(11)
+    N, P = 2000, 5000
+    lists, ptr, rows, x, Y, W, b = _close_case(rng, N, P, "hub")
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    xd, Yd, Wd, bd = x.to(DEV), Y.to(DEV), W.to(DEV), b.to(DEV)
+    cu = ops.build_close_units(lp, lr, N, P)
+    new = ops.rows_close(xd, Wd, bd, Yd, cu, w_kn=True)
+    slots, over = ops.build_slot_table(lp, lr, N, P)
+    old = ops.rows_selfsum(xd, Wd.t().contiguous(), bd, Yd, None, slots, lists=(lp, lr, P, 0, 0, over))
+    ref = _ref_close(x, W, b, Y, lists, P)
+    e_new = float(((new.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max())
+    e_old = float(((old.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max())
+    assert e_new < 6e-3 and e_new <= e_old + 1e-6, (e_new, e_old)
+    only_self = [np.array([P + v]) for v in range(N)]
+    p2 = torch.arange(N + 1, device=DEV, dtype=torch.int32)
+    r2 = torch.arange(P, P + N, device=DEV, dtype=torch.int32)
+    cu0 = ops.build_close_units(p2, r2, N, P)
+    out = ops.rows_close(xd, Wd, bd, None, cu0, w_kn=True)
+    ref = _ref_close(x, W, b, Y, only_self, P)
+    assert float(((out.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max()) < 6e-3
