@@ -492,12 +492,16 @@ def main():
         with torch.no_grad():
             W = layer.weight
             if fused:
-                W_all = torch.cat([W, layer.loop_weight.unsqueeze(0)], 0)
-                Wn = W_all.transpose(1, 2).contiguous()
+                # exactly what _RowTransformFn issues: the forward pass on the parameters as they are stored ([k][n]: no cat /
+                # transpose launches at H = 256 bf16), the input-gradient pass on W itself
+                fw = ops.PassWeights(W, layer.loop_weight, kn=True)
+                if not ops._kn_ok(x):
+                    fw = fw.nk()
+                bw = ops.PassWeights(W, layer.loop_weight, kn=False)
                 ybuf = index.ybuf(H, dtype, dev)
                 for n0, n1, ix in index.parts:
-                    ops.message_pass(x[n0:n1], Wn, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
-                    ops.message_pass(gout[n0:n1], W_all, None, ix, "b", ybuf, cg_out[n0:n1])
+                    ops.message_pass(x[n0:n1], fw, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
+                    ops.message_pass(gout[n0:n1], bw, None, ix, "b", ybuf, cg_out[n0:n1])
             else:
                 A = ops.gather_segsum(x, index.src1, index.seg_ptr, index.num_segments)
                 ops.gather_segsum(A, index.sperm, index.dptr, N)
@@ -620,7 +624,7 @@ def main():
                        "sub_batches": len(index.parts) if hasattr(index, "parts") else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rows_transform_ring_kernel + rows_selfsum_kernel + overflow_rows_add_kernel + fold_tail_kernel (the conv's launches, both directions)",
+                         "kernel": "rows_transform_ring_kernel + rows_close_ring_kernel + fold_tail_kernel (the conv's launches, both directions)",
                          "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step},
         }

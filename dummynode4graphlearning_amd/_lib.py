@@ -65,7 +65,7 @@ _SIGS = {
     "dn_rows_wgrad_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "dn_rows_wgrad_bf16": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32,
                                           c_i32, P, P, P, P, P, c_sz, P]),
-    "dn_rows_transform_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, P]),
+    "dn_rows_transform_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, P]),
     "dn_relu_bwd_bf16": (ctypes.c_int, [P, P, P, c_i64, P]),
     "dn_rows_chain2_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, P, P, P]),
     "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P, P, P]),
@@ -74,9 +74,11 @@ _SIGS = {
     "dn_close_units_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "dn_close_units_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, P, c_i64, c_i32, c_i32, P, P, P, c_i64, P, P, P, c_sz, P]),
     "dn_rows_close_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, P, P, c_i32, P, P, c_i64, P, P, P, P]),
+    "dn_bdd_compose": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),
+    "dn_bdd_extract": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),
     "dn_fold_tables_workspace_bytes": (c_sz, [c_i64]),
     "dn_fold_tables_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, ctypes.POINTER(ctypes.c_int32), P, c_sz, P]),
-    "dn_fold_tail_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, P]),
+    "dn_fold_tail_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, c_i32, P]),
     "dn_rows_transform_f32": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, P]),
     "dn_rows_wgrad_f32": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P,
                                          c_i32, P, c_sz, P]),

@@ -46,8 +46,9 @@ constexpr int kUnitEntry = 1, kUnitLast = 2;
 
 // ---------------------------------------------------------------------------------------------------------------- tables
 constexpr int kCbWaves = 4;            // tiles per workgroup of the builder (one wavefront each)
-constexpr int kCbCap = 512;            // list entries of a tile that are de-duplicated (LDS hash table); larger tiles are listed as is
-constexpr int kCbSlots = 1024;
+constexpr int kCbCap = 256;            // list entries of a tile that are de-duplicated (LDS hash table); larger tiles are listed as is
+constexpr int kCbSlots = 512;          // (9 KB of LDS per wavefront: four workgroups of four tiles per CU)
+constexpr int kCbHashShift = 23;       // 32 - log2(kCbSlots)
 constexpr uint32_t kEmpty = 0xffffffffu;
 
 __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total) {
@@ -61,91 +62,129 @@ __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total) {
     return s - v;
 }
 
-// One wavefront per tile, lane v < 32 = node p0 + v walks its own list (entries in list order = the order they are emitted in).
-// kept = rows < P (the self-loop rows are not list material here) outside the dropped range.  Entries of DIFFERENT nodes with the
-// same row merge into one (mask = OR of the node bits); a row that one node lists twice (parallel edges into a fanned-out row)
-// stays a second entry of its own.
+// One wavefront per tile.  kept = rows < P (the self-loop rows are not list material here) outside the dropped range.  Entries of
+// DIFFERENT nodes with the same row merge into one (mask = OR of the node bits); a row that one node lists twice (parallel edges
+// into a fanned-out row; adjacent, the lists are row-ordered) stays a second entry of its own.  A tile's entries are emitted
+// SORTED BY ROW: the rows of one (relation, graph) are neighbours in S, so consecutive entries -- the two rows of one LDS-DMA, the
+// rows of consecutive DMAs -- are consecutive in memory (runs of ~2 KB instead of single 512-byte rows).
+// Common path (<= kCbCap raw list entries): the tile's slice of the lists goes to LDS in one coalesced sweep, every later step is
+// lane-per-entry out of LDS: hash-table merge, ballot ranks into a staging list, rank sort.  Larger tiles (or a node that repeats
+// a row NOT next to itself) are listed as they are, lane-per-node, in list order.
+struct CbLds {
+    uint32_t key[kCbSlots], first[kCbSlots], mask[kCbSlots];
+    int32_t raw[kCbCap];
+    uint32_t srow[kCbCap + 4], smask[kCbCap];
+    uint8_t node[kCbCap];              // the node (0 .. 31) whose list holds raw entry i
+    int32_t ptr[36];
+    int32_t plain;
+};
+
 __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t P, int32_t T, const int32_t* __restrict__ lptr,
                                                                       const int32_t* __restrict__ lrows, int32_t drop_beg,
                                                                       int32_t drop_end, const int32_t* __restrict__ drop_enable,
                                                                       int32_t* __restrict__ ent_row, uint32_t* __restrict__ ent_mask,
                                                                       int32_t* __restrict__ tile_cnt) {
-    __shared__ uint32_t s_key[kCbWaves][kCbSlots], s_first[kCbWaves][kCbSlots], s_mask[kCbWaves][kCbSlots];
-    __shared__ int32_t s_plain[kCbWaves];
+    __shared__ __attribute__((aligned(16))) CbLds Ls[kCbWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (int)blockIdx.x * kCbWaves + wave;
     if (t >= T) return;                                                    // (no workgroup barrier below)
     if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
-    const int p0 = t * 32, pend = min(p0 + 32, N);
+    CbLds& L = Ls[wave];
+    const int p0 = t * 32, pend = min(p0 + 32, N), nn = pend - p0;
     const int lb = lptr[p0], raw = lptr[pend] - lb;
-    const bool node = lane < pend - p0;
-    const int my_b = node ? lptr[p0 + lane] : 0, my_e = node ? lptr[p0 + lane + 1] : 0;
     auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
-    uint32_t* key = s_key[wave];
-    uint32_t* first = s_first[wave];
-    uint32_t* msk = s_mask[wave];
     bool plain = raw > kCbCap;
     if (!plain) {
-        for (int i = lane; i < kCbSlots; i += 64) { key[i] = kEmpty; first[i] = kEmpty; msk[i] = 0u; }
-        if (lane == 0) s_plain[wave] = 0;
+        const int my0 = lane <= nn ? lptr[p0 + lane] - lb : raw;
+        if (lane <= nn) L.ptr[lane] = my0;
+        for (int i = lane; i < raw; i += 64) L.raw[i] = lrows[lb + i];
+        {
+            const int my1 = __shfl_down(my0, 1, 64);                       // lane v < nn: its list is [my0, my1)
+            if (lane < nn)
+                for (int i = my0; i < my1; ++i) L.node[i] = (uint8_t)lane;
+        }
+        for (int i = lane; i < kCbSlots; i += 64) { L.key[i] = kEmpty; L.first[i] = kEmpty; L.mask[i] = 0u; }
+        if (lane == 0) L.plain = 0;
         __builtin_amdgcn_wave_barrier();
-        int prev = -1;
-        for (int i = my_b; i < my_e; ++i) {
-            const int r = lrows[i];
+        auto node_of = [&](int i) { return (int)L.node[i]; };
+        auto slot_of = [&](int r) {
+            uint32_t h = ((uint32_t)r * 2654435761u) >> kCbHashShift;
+            while (L.key[h] != (uint32_t)r) h = (h + 1) & (kCbSlots - 1);
+            return h;
+        };
+        for (int base = 0; base < raw; base += 64) {
+            const int i = base + lane;
+            if (i >= raw) continue;
+            const int r = L.raw[i];
             if (!kept(r)) continue;
-            uint32_t h = ((uint32_t)r * 2654435761u) >> 22;
+            const int v = node_of(i);
+            if (i > L.ptr[v] && L.raw[i - 1] == r) continue;               // my node's own repeat: a separate entry, not merged
+            uint32_t h = ((uint32_t)r * 2654435761u) >> kCbHashShift;
             for (;;) {
-                const uint32_t old = atomicCAS(&key[h], kEmpty, (uint32_t)r);
+                const uint32_t old = atomicCAS(&L.key[h], kEmpty, (uint32_t)r);
                 if (old == kEmpty || old == (uint32_t)r) break;
                 h = (h + 1) & (kCbSlots - 1);
             }
-            const uint32_t was = atomicOr(&msk[h], 1u << lane);
-            if (was & (1u << lane)) {                                      // my own earlier entry: stays separate
-                if (r != prev) s_plain[wave] = 1;                          // (lists are row-ordered; if not, list the tile as is)
-            } else {
-                atomicMin(&first[h], (uint32_t)(i - lb));
-            }
-            prev = r;
+            const uint32_t was = atomicOr(&L.mask[h], 1u << v);
+            if (was & (1u << v)) L.plain = 1;                              // a repeat that is not adjacent: list the tile as it is
+            else atomicMin(&L.first[h], (uint32_t)i);
         }
         __builtin_amdgcn_wave_barrier();
-        plain = s_plain[wave] != 0;
-    }
-    // emitted entries of my list: count, prefix over the nodes, write
-    auto lookup = [&](int r) {
-        uint32_t h = ((uint32_t)r * 2654435761u) >> 22;
-        while (key[h] != (uint32_t)r) h = (h + 1) & (kCbSlots - 1);
-        return h;
-    };
-    int mine = 0;
-    {
-        int prev = -1;
-        for (int i = my_b; i < my_e; ++i) {
-            const int r = lrows[i];
-            if (!kept(r)) continue;
-            if (plain || r == prev) ++mine;
-            else if (first[lookup(r)] == (uint32_t)(i - lb)) ++mine;
-            prev = r;
+        plain = L.plain != 0;
+        if (!plain) {
+            int n = 0;                                                     // emitted entries so far (wave-uniform)
+            for (int base = 0; base < raw; base += 64) {
+                const int i = base + lane;
+                bool emit = false;
+                int r = 0;
+                uint32_t m = 0;
+                if (i < raw) {
+                    r = L.raw[i];
+                    if (kept(r)) {
+                        const int v = node_of(i);
+                        if (i > L.ptr[v] && L.raw[i - 1] == r) { emit = true; m = 1u << v; }
+                        else {
+                            const uint32_t h = slot_of(r);
+                            if (L.first[h] == (uint32_t)i) { emit = true; m = L.mask[h]; }
+                        }
+                    }
+                }
+                const unsigned long long b = __ballot(emit);
+                if (emit) {
+                    const int at = n + __popcll(b & ((1ull << lane) - 1ull));
+                    L.srow[at] = (uint32_t)r;
+                    L.smask[at] = m;
+                }
+                n += __popcll(b);
+            }
+            if (lane < 4) L.srow[n + lane] = 0xffffffffu;                  // sentinels: the rank loop reads four rows at a time
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t ri = L.srow[i];
+                int rank = 0;
+                for (int j = 0; j < n; j += 4) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(&L.srow[j]);
+                    rank += (q.x < ri || (q.x == ri && j < i)) + (q.y < ri || (q.y == ri && j + 1 < i)) +
+                            (q.z < ri || (q.z == ri && j + 2 < i)) + (q.w < ri || (q.w == ri && j + 3 < i));
+                }
+                ent_row[lb + rank] = (int32_t)ri;
+                ent_mask[lb + rank] = L.smask[i];
+            }
+            if (lane == 0) tile_cnt[t] = n;
+            return;
         }
     }
+    // listed as it is: lane v = node p0 + v walks its own list, every kept row an entry of its own
+    const bool node = lane < nn;
+    const int my_b = node ? lptr[p0 + lane] : 0, my_e = node ? lptr[p0 + lane + 1] : 0;
+    int mine = 0;
+    for (int i = my_b; i < my_e; ++i) mine += kept(lrows[i]) ? 1 : 0;
     int total;
     int at = lb + wave_excl_sum(mine, lane, total);
-    {
-        int prev = -1;
-        for (int i = my_b; i < my_e; ++i) {
-            const int r = lrows[i];
-            if (!kept(r)) continue;
-            if (plain || r == prev) {
-                ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
-            } else {
-                const uint32_t h = lookup(r);
-                if (first[h] == (uint32_t)(i - lb)) {
-                    uint32_t m = msk[h];
-                    // a node that lists the row twice contributes its FIRST occurrence to the merged entry only: its bit is set once
-                    ent_row[at] = r; ent_mask[at] = m; ++at;
-                }
-            }
-            prev = r;
-        }
+    for (int i = my_b; i < my_e; ++i) {
+        const int r = lrows[i];
+        if (!kept(r)) continue;
+        ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
     }
     if (lane == 0) tile_cnt[t] = total;
 }
@@ -233,6 +272,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     __shared__ __attribute__((aligned(16))) int32_t descL[kDescRing][4];                      // unit records for the compute waves
     __shared__ __attribute__((aligned(128))) int32_t recR[kLoaders][kRecRing][4];             // loader-private rings: unit records
     __shared__ __attribute__((aligned(256))) int32_t idxR[kLoaders][kIdxRing][kRowsPerLoader]; // ... and source rows
+    __shared__ __attribute__((aligned(16))) char wscr[kCompute][2048];                         // transposition scratch of a [k][n] W
     typedef __attribute__((address_space(3))) char* lds_wp;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
     const unsigned desc_base = (unsigned)(uintptr_t)(lds_wp)&descL[0][0];
@@ -308,8 +348,13 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             const i32x4 iv = *reinterpret_cast<const i32x4*>(&idxR[q][u % kIdxRing][4 * rin]);   // rows rin, 2 + rin, 4 + rin, 6 + rin
             const bool ent = (recR[q][u % kRecRing][0] & kUnitEntry) != 0;
             const char* base0 = reinterpret_cast<const char*>(ent ? S : X);
+#ifdef DN_TUNING_ENV
+            const uint32_t rmask = (flags & (ent ? 4 : 8)) ? 1023u : 0xffffffffu;   // (ablation: the rows come from L2)
+#else
+            constexpr uint32_t rmask = 0xffffffffu;
+#endif
 #pragma unroll
-            for (int j = 0; j < kDmaPerTile; ++j) src[j] = base0 + (size_t)(uint32_t)iv[j] * kRowB + swoff[j];
+            for (int j = 0; j < kDmaPerTile; ++j) src[j] = base0 + (size_t)((uint32_t)iv[j] & rmask) * kRowB + swoff[j];
         };
         auto rows = [&](int u, const char* (&src)[kDmaPerTile]) {
             const unsigned st = lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB;
@@ -342,6 +387,10 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
         __builtin_amdgcn_s_barrier();
 #pragma unroll 1
         for (int t = 0; t < nt; t += 2) {
+#ifdef DN_TUNING_ENV
+            if (flags & 64) wait_vmcnt<kDmaPerTile*(kNS - 4)>();           // (experiment: landed up to unit t + 1 only)
+            else
+#endif
             wait_vmcnt<kDmaPerTile*(kNS - 5)>();                           // issued: up to unit t + 5; landed: up to unit t + 2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the records I copied for the compute waves
             __builtin_amdgcn_s_barrier();                                  // everyone's have; stages of units t-2, t-1 are free
@@ -376,12 +425,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             for (int n = 0; n < 2; ++n)
                 wf[ks][n] = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
     } else {                                                               // W as the parameter stores it, [in][out]: once per launch
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) wf[ks][n][e] = W[(size_t)(ks * 32 + 8 * g + e) * kH + n0 + colA0 + 4 * n];
+        dn_load_w_kn32<8>(W, kH, n0, lane, wscr[wave], wf);
     }
     u32x4 bv = {0u, 0u, 0u, 0u};                                           // bias of my 8 columns (bf16 x 8)
     if (bias) bv = *reinterpret_cast<const u32x4*>(bias + n0 + 8 * g);
@@ -426,7 +470,11 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             u32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+#ifdef DN_TUNING_ENV
+            if (p < pend && !((flags & 16) && p != 0)) {                   // (flags & 16: ablation, no stores)
+#else
             if (p < pend) {
+#endif
                 u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)p * kH + ocol);
                 if (nt_store) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
@@ -515,6 +563,12 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
         } else {
             // ---- entry unit: acc[column][node] += sum_e S[e][column] * mask[e][node]
             p0 = u_aux;
+#ifdef DN_TUNING_ENV
+            if (flags & 32) {                                              // (ablation: entry units are fetched but not summed)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+            } else
+#endif
+            {
             const u32x4 mA = *reinterpret_cast<const u32x4*>(&maskR[u % kMaskRing][8 * g]);
             const u32x4 mB = *reinterpret_cast<const u32x4*>(&maskR[u % kMaskRing][8 * g + 4]);
             bf16x8 a[2];
@@ -536,6 +590,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], sel[m], acc[m][n], 0, 0, 0);
+            }
         }
         if (u_fl & kUnitLast) epilogue(p0, min(p0 + kTR, N));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");     // my LDS reads are done before I arrive at a barrier
@@ -606,7 +661,8 @@ int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, co
                "dn_rows_close: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     static const int nt = dn_knob("DN_NT", 3);
-    const int32_t flags = (nt & 2) ? 2 : 0;
+    const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
+    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 31) << 2);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
     if (fold_info)
         hipLaunchKernelGGL((rows_close_ring_kernel<true>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X,

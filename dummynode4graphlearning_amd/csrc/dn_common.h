@@ -81,3 +81,66 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+// A wave's slice of a weight matrix stored [k][n] (the layout of the reference's parameters) as MFMA A-operand fragments, which
+// want 8 consecutive k per lane: one 32-k-row slab at a time goes global -> registers (coalesced 16-byte pieces, all slabs
+// requested up front) -> a wave-private LDS scratch -> ds_read_b64_tr_b16 (the hardware transpose).  2-byte gathers instead
+// cost ~30 us per call: hipcc serialises the 128 partial-register loads of a wave behind vmcnt(0) waits.
+//   NC = 32: the wave owns columns n0 .. n0+31, fragment [ks][n] row i <-> column n0 + 8 (i >> 2) + 4 n + (i & 3)  (ring kernels)
+//   NC = 16: columns n0 .. n0+15, fragment [ks] row i <-> column n0 + i
+// scratch: 32 x 2 NC bytes, 16-byte aligned, private to the wave.  KS = K / 32.
+typedef short dn_short4v __attribute__((ext_vector_type(4)));
+typedef short dn_short8v __attribute__((ext_vector_type(8)));
+typedef __bf16 dn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int dn_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS>
+__device__ __forceinline__ void dn_load_w_kn32(const __bf16* __restrict__ w, int ldw, int n0, int lane, char* scratch,
+                                               dn_bf16x8 (&wf)[KS][2]) {
+    typedef dn_short4v __attribute__((address_space(3))) * lds_tr;
+    const int r16 = lane >> 2, pc4 = lane & 3;
+    dn_u32x4 raw[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            raw[ks][h] = *reinterpret_cast<const dn_u32x4*>(w + (size_t)(32 * ks + 16 * h + r16) * ldw + n0 + 8 * pc4);
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        *reinterpret_cast<dn_u32x4*>(scratch + r16 * 64 + 16 * pc4) = raw[ks][0];
+        *reinterpret_cast<dn_u32x4*>(scratch + (16 + r16) * 64 + 16 * pc4) = raw[ks][1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const char* a0 = scratch + (8 * g + q4) * 64 + 16 * p4 + 8 * n;
+            const dn_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+            const dn_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * 64));
+            const dn_short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            wf[ks][n] = __builtin_bit_cast(dn_bf16x8, f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void dn_load_w_kn16(const __bf16* __restrict__ w, int ldw, int n0, int lane, char* scratch,
+                                               dn_bf16x8 (&wf)[KS]) {
+    typedef dn_short4v __attribute__((address_space(3))) * lds_tr;
+    const int r32 = lane >> 1, pc2 = lane & 1;
+    dn_u32x4 raw[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) raw[ks] = *reinterpret_cast<const dn_u32x4*>(w + (size_t)(32 * ks + r32) * ldw + n0 + 8 * pc2);
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        *reinterpret_cast<dn_u32x4*>(scratch + r32 * 32 + 16 * pc2) = raw[ks];
+        __builtin_amdgcn_wave_barrier();
+        const char* a0 = scratch + (8 * g + q4) * 32 + 8 * p4;
+        const dn_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+        const dn_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * 32));
+        const dn_short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        wf[ks] = __builtin_bit_cast(dn_bf16x8, f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}

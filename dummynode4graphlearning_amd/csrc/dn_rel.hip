@@ -1395,7 +1395,7 @@ template <int H>
 __global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restrict__ part, const int32_t* __restrict__ pptr,
                                                           const bf16_t* __restrict__ Wn, const int32_t* __restrict__ idx,
                                                           int32_t n, int32_t num_tiles, bf16_t* __restrict__ aux,
-                                                          bf16_t* __restrict__ out) {
+                                                          bf16_t* __restrict__ out, int32_t w_kn) {
     constexpr int SX = H + kPad, SYF = H + 4;
     constexpr int KS = H / 32, MT = kSsRows / 16, LPR = H / 8;
     static_assert(kSsRows * LPR == H * 4, "one piece per thread");
@@ -1404,9 +1404,14 @@ __global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = wave * 16, pr = tid / LPR, pc = tid % LPR;
     bf16x8 wf[KS];                                               // the relation's weights: loaded once per workgroup
+    if (w_kn) {                                                  // stored [k][n] (the parameter's own layout): transposed through LDS
+        dn_load_w_kn16<KS>(Wn, H, n0, lane, reinterpret_cast<char*>(bufY) + wave * 1024, wf);
+        __syncthreads();                                         // (bufY is the tiles' staging buffer from here on)
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+        for (int ks = 0; ks < KS; ++ks)
+            wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    }
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const int j = tile * kSsRows + pr;
@@ -1466,7 +1471,7 @@ __global__ __launch_bounds__(H * 4) void fold_tail_kernel(const float* __restric
 extern "C" {
 
 int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_segments, int32_t H, const void* Wn,
-                      const int32_t* idx, void* aux, void* out, dn_stream_t stream) {
+                      const int32_t* idx, void* aux, void* out, int32_t w_kn, dn_stream_t stream) {
     DN_REQUIRE(num_segments >= 0 && num_segments < INT32_MAX, "dn_fold_tail: bad sizes");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_fold_tail: H must be 64, 128 or 256");
     if (num_segments == 0) return DN_OK;
@@ -1480,9 +1485,9 @@ int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_se
     const bf16_t *w = (const bf16_t*)Wn;
     bf16_t *a = (bf16_t*)aux, *o = (bf16_t*)out;
     const int32_t n = (int32_t)num_segments;
-    if (H == 256) hipLaunchKernelGGL((fold_tail_kernel<256>), dim3(grid), dim3(1024), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
-    else if (H == 128) hipLaunchKernelGGL((fold_tail_kernel<128>), dim3(grid), dim3(512), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
-    else hipLaunchKernelGGL((fold_tail_kernel<64>), dim3(grid), dim3(256), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o);
+    if (H == 256) hipLaunchKernelGGL((fold_tail_kernel<256>), dim3(grid), dim3(1024), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o, w_kn);
+    else if (H == 128) hipLaunchKernelGGL((fold_tail_kernel<128>), dim3(grid), dim3(512), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o, w_kn);
+    else hipLaunchKernelGGL((fold_tail_kernel<64>), dim3(grid), dim3(256), 0, st, p, part_ptr, w, idx, n, num_tiles, a, o, w_kn);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1556,7 +1561,7 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
 
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos, const int32_t* tiles,
-                           int64_t num_tiles, void* Y, dn_stream_t stream) {
+                           int64_t num_tiles, void* Y, int32_t w_kn, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform: bad tile count");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
@@ -1575,7 +1580,8 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     // (identity rows over the concatenation [X; X2] -- idx == NULL with a second source -- stay on the register-staged kernel:
     //  the ring kernel's loaders only tell the two sources apart through the row index)
     if (Hi == 256 && ring && (idx != nullptr || X2 == nullptr))
-        return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, st);
+        return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, w_kn, st);
+    if (w_kn) { dn_set_error("dn_rows_transform: w_kn = 1 is served by the H = 256 ring kernel only"); return DN_ERR_UNSUPPORTED; }
     if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
     return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
     __shared__ __attribute__((aligned(16))) int32_t descL[kDescRing][4]; // tile records for the compute waves (copied by loader 0)
     __shared__ __attribute__((aligned(128))) int32_t recR[kLoaders][kRecRing][4];            // loader-private rings: tile records
     __shared__ __attribute__((aligned(256))) int32_t idxR[kLoaders][kIdxRing][kRowsPerLoader];  // ... and row indices, by LDS-DMA
+    __shared__ __attribute__((aligned(16))) char wscr[kCompute][2048];     // per compute wave: transposition scratch of [k][n] weights
     typedef __attribute__((address_space(3))) char* lds_wp;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
     const unsigned desc_base = (unsigned)(uintptr_t)(lds_wp)&descL[0][0];
@@ -372,11 +373,15 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
             if (t_rel != cur_rel) {                                        // wave-uniform, rare
                 cur_rel = t_rel;
                 const bf16_t* w = Wn + (size_t)cur_rel * kH * kH;
+                if (flags & 4) {                                           // the relation's weights as the parameter stores them,
+                    dn_load_w_kn32<8>(w, kH, n0, lane, wscr[wave], wf);    // [k][n]: transposed through a wave-private LDS scratch
+                } else {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
+                    for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        wf[ks][n] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
+                        for (int n = 0; n < 2; ++n)
+                            wf[ks][n] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
+                }
                 if constexpr (EPI)
                     if (bias) bv = *reinterpret_cast<const u32x4*>(bias + (size_t)cur_rel * kH + n0 + 8 * g);
 #pragma unroll
@@ -447,11 +452,11 @@ namespace dn_internal {
 
 int launch_transform_ring256(const void* X_, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
-                             int64_t tiles_per_wg, void* Y, hipStream_t st) {
+                             int64_t tiles_per_wg, void* Y, int32_t w_kn, hipStream_t st) {
     if (tiles_per_wg <= 0) tiles_per_wg = dn_cdiv(num_tiles, 256);       // one persistent workgroup per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     static const int abl = dn_knob("DN_TF_ABL", 0);   // tuning build only: 1 no stores, 2 gathers hit L2, 4 no MFMAs, 8 trivial LDS reads, 16 no row DMAs
-    const int32_t flags = (relu ? 1 : 0) | (nt_store ? 2 : 0) | ((abl & 255) << 3);
+    const int32_t flags = (relu ? 1 : 0) | (nt_store ? 2 : 0) | (w_kn ? 4 : 0) | ((abl & 255) << 3);
 #define DN_RING_LAUNCH(M, I, E, X)                                                                                      \
     hipLaunchKernelGGL((rows_transform_ring_kernel<M, I, E, X>), dim3((unsigned)grid), dim3(kThreads), 0, st, (const bf16_t*)X_, \
                        (const bf16_t*)X2, n1, idx, (const bf16_t*)Wn, (const bf16_t*)bias, flags, (const bf16_t*)mask_pos,      \

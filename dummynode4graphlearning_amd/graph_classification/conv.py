@@ -97,8 +97,7 @@ class RGCNConv(nn.Module):
         if self.aggr == "add" and self.root is not None and ops.fused_path_supported(x, self.weight):
             # bf16: relation transform + root weight + bias in the row-factorised MFMA pipeline (as SI RGINLayer)
             index = row_index_of(data, edge_type, self.num_relations, True)
-            W_all = torch.cat([self.weight, self.root.unsqueeze(0)], 0)
-            return ops.rel_transform_fused(x, W_all, self.bias, index)
+            return ops.rel_transform_fused(x, self.weight, self.bias, index, W_loop=self.root)
         index = rel_index_of(data, edge_type, self.num_relations)
         scale = None
         if self.aggr == "mean":

@@ -366,12 +366,14 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
 
 
 def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense",
-                   out=None):
-    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16)."""
+                   out=None, w_kn=False):
+    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16).
+    w_kn: Wn[r] is given [in][out] (the parameter's own layout; bf16 H = 256 ring kernel only) instead of [out][in]."""
     tiles, ntiles = tile_table
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
     assert X.dtype == Wn.dtype and X.dtype in (torch.bfloat16, torch.float32) and Wn.dim() == 3
     assert bias is None or bias.dtype == X.dtype
+    assert not w_kn or (X.dtype == torch.bfloat16 and Wn.shape[1] == Wn.shape[2] == 256)
     Ho, Hi = Wn.shape[1], Wn.shape[2]
     assert X.shape[1] == Hi
     if out is None:
@@ -388,7 +390,8 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
                   "dn_rows_transform_f32")
         else:
             check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
-                                               ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), stream_ptr()), "dn_rows_transform_bf16")
+                                               ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if w_kn else 0, stream_ptr()),
+                  "dn_rows_transform_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_transform:" + tag, _launch)
@@ -1348,9 +1351,9 @@ def _selfsum_ok(ix, x):
     return SELFSUM_ENABLED and ix.self_loop and x.dtype == torch.bfloat16
 
 
-def fold_tail(part, part_ptr, num_segments, Wn, idx, out):
-    """aux[j] = sum of partial rows part_ptr[j] .. part_ptr[j+1] in order;  out[idx[j]] += aux[j] @ Wn^T  (dn_fold_tail_bf16).
-    Returns aux (bf16)."""
+def fold_tail(part, part_ptr, num_segments, Wn, idx, out, w_kn=False):
+    """aux[j] = sum of partial rows part_ptr[j] .. part_ptr[j+1] in order;  out[idx[j]] += aux[j] @ Wn^T  (dn_fold_tail_bf16;
+    w_kn: Wn given [in][out] instead).  Returns aux (bf16)."""
     require_gpu(part, part_ptr, Wn, idx, out)
     H = part.shape[1]
     assert part.dtype == torch.float32 and part_ptr.dtype == I32 and idx.dtype == I32 and idx.numel() == num_segments
@@ -1360,7 +1363,7 @@ def fold_tail(part, part_ptr, num_segments, Wn, idx, out):
 
     def _launch():
         check(lib().dn_fold_tail_bf16(ptr(part), ptr(part_ptr), int(num_segments), H, ptr(Wn), ptr(idx), ptr(aux), ptr(out),
-                                      stream_ptr()), "dn_fold_tail_bf16")
+                                      1 if w_kn else 0, stream_ptr()), "dn_fold_tail_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("fold_tail", _launch)
     else:
@@ -1368,47 +1371,83 @@ def fold_tail(part, part_ptr, num_segments, Wn, idx, out):
     return aux
 
 
-def _closing_launch(xs, W_loop, bias, Y, ix, direction, out, seg=None):
+class PassWeights:
+    """Weights of ONE direction of a message pass: rel [R, H, H] for the edge relations, loop [H, H] for the self loop (or None).
+    kn = False: every matrix is [n][k] (rows = output columns, the form the MFMA kernels read contiguously: W^T for the forward
+    pass, W itself for the input-gradient pass); kn = True: [k][n] -- the forward pass straight on the parameters `weight` /
+    `loop_weight` as the reference stores them (rgin.py:61-67), which the H = 256 bf16 kernels gather themselves, so the step
+    has no `cat` / `transpose().contiguous()` launches."""
+    __slots__ = ("rel", "loop", "kn", "_all")
+
+    def __init__(self, rel, loop, kn=False):
+        self.rel, self.loop, self.kn, self._all = rel.contiguous(), (loop.contiguous() if loop is not None else None), bool(kn), None
+
+    def all_nk(self):
+        """[R (+1), n, k] in one contiguous tensor (loop last): the kernels without a kn mode (fp32, H != 256, no closing launch)."""
+        if self._all is None:
+            w = self.rel if self.loop is None else torch.cat([self.rel, self.loop.unsqueeze(0)], 0)
+            self._all = w.transpose(1, 2).contiguous() if self.kn else w.contiguous()
+        return self._all
+
+    def nk(self):
+        """The same weights with kn = False."""
+        if not self.kn:
+            return self
+        a = self.all_nk()
+        return PassWeights(a if self.loop is None else a[:-1], None if self.loop is None else a[-1], False)
+
+
+def _kn_ok(xs):
+    """The launches that take [k][n] weights: bf16 H = 256 (ring transform, unit-stream closing launch, fold tail)."""
+    return xs.dtype == torch.bfloat16 and xs.shape[1] == 256 and CLOSE_RING_ENABLED
+
+
+def _closing_launch(xs, W_loop, bias, Y, ix, direction, out, seg=None, w_kn=False):
     """The closing launch over one RowIndex: the unit stream at H = 256 (dn_rows_close_bf16), else the slot kernel + its
     overflow launch (dn_rows_selfsum_bf16, dn_overflow_rows_add_bf16)."""
     if _close_kind(xs) == "units":
-        return rows_close(xs, W_loop, bias, Y, ix.close_units(direction), out=out, seg=seg)
+        return rows_close(xs, W_loop, bias, Y, ix.close_units(direction), out=out, seg=seg, w_kn=w_kn)
+    assert not w_kn
     slots, lists = ix.slots(direction)
     return rows_selfsum(xs, W_loop, bias, Y, None, slots, out=out, seg=seg, lists=lists)
 
 
-def _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows):
+def _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows):
     """message_pass with the collapsed relation's pre-aggregation absorbed by the closing launch: transform of every other
     relation -> closing launch (+ per-graph column sums of xs) -> tail launch (combine the sums, transform the one row per graph,
     add each product to its node).  Same sums as the unfolded path up to bf16 rounding of the collapsed rows."""
     fold = _row_index_fold(ix, direction, _close_kind(xs))
     P, H = ix.num_edge_rows, xs.shape[1]
-    Y = rows_transform(xs, Wmat, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf)
+    Y = rows_transform(xs, pw.rel, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf, w_kn=pw.kn)
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
-    _closing_launch(xs, Wmat[-1], bias, Y[:P], ix, direction, out, seg=(fold.fold_info, part))
-    return fold_tail(part, fold.part_ptr, fold.n, Wmat[fold.rel], fold.add_idx, out)
+    _closing_launch(xs, pw.loop, bias, Y[:P], ix, direction, out, seg=(fold.fold_info, part), w_kn=pw.kn)
+    return fold_tail(part, fold.part_ptr, fold.n, pw.rel[fold.rel], fold.add_idx, out, w_kn=pw.kn)
 
 
-def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
+def message_pass(xs, pw, bias, ix, direction, ybuf, out):
     """One direction of the row-factorised pass over one RowIndex -- the launches that ARE the layer's gather-scatter:
-         'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          Wmat = W^T per relation ([R', out, in])
-         'b':  out[u] = sum_{rows p <- u} (g_row(p)  @ W[rel p]^T)        Wmat = W       per relation ([R', in, out])
+         'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          pw = the weights (PassWeights), [k][n] or W^T
+         'b':  out[u] = sum_{rows p <- u} (g_row(p)  @ W[rel p]^T)        pw = W per relation as it is ([n = in][k = out])
        = pre-aggregation of the collapsed relations (gather_segsum) -> gathered-row transform on the matrix cores ->
-       closing launch.  With a self loop in bf16 the closing launch is dn_rows_selfsum_bf16 (self-loop transform + bias +
-       per-node sum of the edge rows in one pass); otherwise the self-loop rows go through the transform like any relation
-       and a per-node gather_segsum closes.  Returns the pre-aggregated rows (kept for the weight gradient)."""
+       closing launch.  With a self loop in bf16 the closing launch is dn_rows_close_bf16 / dn_rows_selfsum_bf16 (self-loop
+       transform + bias + per-node sum of the edge rows in one pass); otherwise the self-loop rows go through the transform like
+       any relation and a per-node gather_segsum closes.  Returns the pre-aggregated rows (kept for the weight gradient)."""
     if direction == "f":
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
+    if pw.kn and not (_kn_ok(xs) and _selfsum_ok(ix, xs)):
+        pw = pw.nk()
     if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction, _close_kind(xs)) is not None:
-        return _message_pass_folded(xs, Wmat, bias, ix, direction, ybuf, out, idx_rows)
+        return _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows)
     aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux) if n_aux else None
     if _selfsum_ok(ix, xs):
         P = ix.num_edge_rows
-        Y = rows_transform(xs, Wmat, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf) if P else ybuf[:0]
-        _closing_launch(xs, Wmat[-1], bias, Y[:P], ix, direction, out)
+        Y = (rows_transform(xs, pw.rel, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf, w_kn=pw.kn)
+             if P else ybuf[:0])
+        _closing_launch(xs, pw.loop, bias, Y[:P], ix, direction, out, w_kn=pw.kn)
         return aux
+    Wmat = pw.all_nk()
     bias_all = None
     if bias is not None:
         bias_all = torch.zeros((Wmat.shape[0], Wmat.shape[1]), dtype=xs.dtype, device=xs.device)
@@ -1419,54 +1458,91 @@ def message_pass(xs, Wmat, bias, ix, direction, ybuf, out):
 
 
 class _RowTransformFn(torch.autograd.Function):
-    """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W[R] + bias when the index has the self loop), evaluated
-    over the parts of a RowIndexSet (one part)."""
+    """out = sum over in-edges of x[src] @ W[etype]  (+ x @ W_loop + bias when the index has the self loop), evaluated
+    over the parts of a RowIndexSet (one part).  W [R, in, out] and W_loop [in, out] are the layer's own tensors: nothing is
+    concatenated or transposed on the bf16 H = 256 path."""
 
     @staticmethod
-    def forward(ctx, x, W_all, bias, index_set):
+    def forward(ctx, x, W, W_loop, bias, index_set):
         x = x.contiguous()
-        Wn = W_all.transpose(1, 2).contiguous()                              # [R', out, in]
-        out = torch.empty((x.shape[0], W_all.shape[2]), dtype=x.dtype, device=x.device)
-        ybuf = index_set.ybuf(W_all.shape[2], x.dtype, x.device)
+        H_out = W.shape[2]
+        pw = PassWeights(W, W_loop, kn=True)
+        if not _kn_ok(x):
+            pw = pw.nk()                                                     # [R', out, in], one cat + transposed copy
+        out = torch.empty((x.shape[0], H_out), dtype=x.dtype, device=x.device)
+        ybuf = index_set.ybuf(H_out, x.dtype, x.device)
         auxs = []
         for n0, n1, ix in index_set.parts:
-            aux = message_pass(x[n0:n1], Wn, bias, ix, "f", ybuf, out[n0:n1])
+            aux = message_pass(x[n0:n1], pw, bias, ix, "f", ybuf, out[n0:n1])
             auxs.append(aux if aux is not None else x.new_empty(0))      # a few MB: kept for the weight gradient
-        ctx.index_set, ctx.has_bias = index_set, bias is not None
-        ctx.save_for_backward(x, W_all, *auxs)
+        ctx.index_set, ctx.has_bias, ctx.has_loop = index_set, bias is not None, W_loop is not None
+        ctx.save_for_backward(x, W, W_loop if W_loop is not None else x.new_empty(0), *auxs)
         return out
 
     @staticmethod
     def backward(ctx, g):
         iset = ctx.index_set
         g = g.contiguous()
-        x, W_all = ctx.saved_tensors[:2]
-        auxs = ctx.saved_tensors[2:]
-        Wc = W_all.contiguous()
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        x, W, W_loop = ctx.saved_tensors[:3]
+        auxs = ctx.saved_tensors[3:]
+        R_all = W.shape[0] + (1 if ctx.has_loop else 0)
+        pw = PassWeights(W, W_loop if ctx.has_loop else None, kn=False)     # the input-gradient pass reads W as it is
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])
         gx = torch.empty_like(x) if need_x else None
         gW32 = cs32 = None
-        ybuf = iset.ybuf(W_all.shape[1], g.dtype, g.device)
+        ybuf = iset.ybuf(W.shape[1], g.dtype, g.device)
         single = len(iset.parts) == 1
         for part, (n0, n1, ix) in enumerate(iset.parts):
             gs, xs = g[n0:n1], x[n0:n1]
             if need_x:
-                aux_b = message_pass(gs, Wc, None, ix, "b", ybuf, gx[n0:n1])
+                aux_b = message_pass(gs, pw, None, ix, "b", ybuf, gx[n0:n1])
             else:
                 aux_b = gather_segsum(gs, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b) if ix.num_aux_b else None
             if need_w:
                 aux = auxs[part] if ix.num_aux_f else None
                 # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
-                gw, cs = rows_wgrad(xs, gs, ix.chunk_table, W_all.shape[0], idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
-                                    G2=aux_b, out_dtype=W_all.dtype if single else torch.float32, colsum_of=2)
+                gw, cs = rows_wgrad(xs, gs, ix.chunk_table, R_all, idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
+                                    G2=aux_b, out_dtype=W.dtype if single else torch.float32, colsum_of=2)
                 gW32 = gw if gW32 is None else gW32.add_(gw)
                 cs32 = cs if cs32 is None else cs32.add_(cs)
-        gW = gb = None
+        gW = gL = gb = None
         if need_w:
-            gW = gW32.to(W_all.dtype)
+            gAll = gW32.to(W.dtype)                                          # [R (+1), in, out]: the two gradients are views of it
+            gW = gAll[:W.shape[0]]
+            if ctx.has_loop:
+                gL = gAll[W.shape[0]]
             if ctx.has_bias:
                 gb = cs32[-1].to(g.dtype)
-        return gx, gW, gb, None
+        return gx, gW, gL, gb, None
+
+
+class _BddDenseFn(torch.autograd.Function):
+    """Block-diagonal relation weights [R, B * si * so] -> dense [R, B * si, B * so] (dn_bdd_compose), gradient = the diagonal
+    blocks of the dense gradient (dn_bdd_extract): one launch each way (rgin.py:114-120's per-block products as dense ones)."""
+
+    @staticmethod
+    def forward(ctx, weight, R, B, si, so):
+        w = weight.contiguous()
+        require_gpu(w)
+        assert w.numel() == R * B * si * so and w.dtype in (torch.bfloat16, torch.float32)
+        dense = torch.empty((R, B * si, B * so), dtype=w.dtype, device=w.device)
+        check(lib().dn_bdd_compose(ptr(w), R, B, si, so, w.element_size(), ptr(dense), stream_ptr()), "dn_bdd_compose")
+        ctx.dims, ctx.shape = (R, B, si, so), weight.shape
+        return dense
+
+    @staticmethod
+    def backward(ctx, g):
+        R, B, si, so = ctx.dims
+        g = g.contiguous()
+        gb = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        check(lib().dn_bdd_extract(ptr(g), R, B, si, so, g.element_size(), ptr(gb), stream_ptr()), "dn_bdd_extract")
+        return gb, None, None, None, None
+
+
+def bdd_dense(weight, num_rels, num_bases, submat_in, submat_out):
+    """Dense [R, B * si, B * so] view of block-diagonal relation weights, differentiable (GPU, bf16 / fp32)."""
+    return _BddDenseFn.apply(weight, int(num_rels), int(num_bases), int(submat_in), int(submat_out))
 
 
 def fused_path_supported(x, W):
@@ -1476,9 +1552,10 @@ def fused_path_supported(x, W):
             and W.shape[1] == W.shape[2] and W.shape[1] in (64, 128, 256) and x.shape[1] == W.shape[1])
 
 
-def rel_transform_fused(x, W_all, bias, index_set):
-    """Fused bf16 path.  W_all: [R(+1), in, out] with the self-loop weight last when index_set.self_loop; bias is added on
-    the self-loop rows (requires the self loop).  index_set: RowIndexSet (or a single RowIndex)."""
+def rel_transform_fused(x, W, bias, index_set, W_loop=None):
+    """Fused row-factorised path.  Either W = [R, in, out] with the self-loop weight given separately (W_loop [in, out] -- the
+    layer's own parameters, nothing concatenated), or, without W_loop, W = [R (+1), in, out] with the self-loop weight LAST when
+    index_set.self_loop.  bias is added on the self-loop rows (requires the self loop).  index_set: RowIndexSet (or a RowIndex)."""
     if isinstance(index_set, RowIndex):
         one = index_set
         index_set = RowIndexSet.__new__(RowIndexSet)
@@ -1486,8 +1563,11 @@ def rel_transform_fused(x, W_all, bias, index_set):
         index_set.parts, index_set.max_rows, index_set.num_rows = [(0, one.num_nodes, one)], one.num_rows, one.num_rows
         index_set.num_all_rels, index_set._ybuf = one.num_all_rels, {}
     assert bias is None or index_set.self_loop
-    assert W_all.shape[0] == index_set.num_all_rels
-    return _RowTransformFn.apply(x, W_all, bias, index_set)
+    if W_loop is None and index_set.self_loop:
+        assert W.shape[0] == index_set.num_all_rels
+        W, W_loop = W[:-1], W[-1]                                            # views: their gradients flow back into W's
+    assert W.shape[0] == index_set.num_rels and (W_loop is not None) == index_set.self_loop
+    return _RowTransformFn.apply(x, W, W_loop, bias, index_set)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@ def dense_relation_weights(layer):
             return th.matmul(layer.w_comp, w).view(layer.num_rels, layer.input_dim, layer.hidden_dim)
         return layer.weight
     si, so = layer.input_dim // layer.num_bases, layer.hidden_dim // layer.num_bases
+    if layer.weight.is_cuda and layer.weight.dtype in (th.bfloat16, th.float32):
+        return ops.bdd_dense(layer.weight, layer.num_rels, layer.num_bases, si, so)      # one launch (dn_bdd_compose)
     blocks = layer.weight.view(layer.num_rels, layer.num_bases, si, so)
     # block_diag per relation, differentiable: [R, B, si, B, so] with zeros off the diagonal
     eye = th.eye(layer.num_bases, dtype=blocks.dtype, device=blocks.device)
@@ -110,8 +112,8 @@ class RGINLayer(nn.Module):
         if ops.fused_path_supported(node_feat, W):
             # bf16: message pass, self loop (rgin.py:140-142) and bias in ONE row-factorised MFMA pipeline
             index = g.row_index(edge_type, self.num_rels, self.self_loop)
-            W_all = th.cat([W, self.loop_weight.unsqueeze(0)], 0) if self.self_loop else W
-            out = ops.rel_transform_fused(node_feat, W_all, self.bias if self.self_loop else None, index)
+            out = ops.rel_transform_fused(node_feat, W, self.bias if self.self_loop else None, index,
+                                          W_loop=self.loop_weight if self.self_loop else None)
             if self.bias is not None and not self.self_loop:
                 out = out + self.bias
         else:

@@ -335,10 +335,12 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
  * Replaces the reference's per-edge `weight.index_select(0, etype)` + `th.bmm` message function
  * (subgraph_isomorphism/models/rgin.py:102-120, rgcn.py:100-122), its self-loop matmul (rgin.py:141) and, in the
  * backward direction (X = grad rows, Wn = W_r), autograd's transposed product.  Ho == Hi in {64, 128, 256}.
- * mask_pos (may be NULL): after epi, elements where mask_pos[p, n] <= 0 are zeroed. */
+ * mask_pos (may be NULL): after epi, elements where mask_pos[p, n] <= 0 are zeroed.
+ * w_kn != 0 (Hi == 256 with idx != NULL or X2 == NULL only, DN_ERR_UNSUPPORTED otherwise): Wn[r] is stored [k][n] -- the layout
+ * of the reference's `weight` parameter (rgin.py:61-67), so the forward pass needs no transposed copy of the weights. */
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos,
-                           const int32_t* tiles, int64_t num_tiles, void* Y, dn_stream_t stream);
+                           const int32_t* tiles, int64_t num_tiles, void* Y, int32_t w_kn, dn_stream_t stream);
 
 /* Closing launch of the row-factorised message pass (bf16 in, fp32 acc, bf16 out):
  *   out[v, :] = X[v, :] @ Wn^T (+ bias)  +  sum_{k < num_slots} Scat[slots[v * num_slots + k], :]
@@ -424,9 +426,19 @@ int dn_fold_tables_build_async_i32(int64_t N, int64_t num_segments, const int32_
 /* Tail of a folded pre-aggregation, one launch:  aux[j, :] = bf16( sum_{k in [part_ptr[j], part_ptr[j+1])} part[k, :] ) in k
  * order (kept by the caller: the collapsed relation's operand of dn_rows_wgrad_bf16), then the relation's transform of those
  * rows added to their one output row each:  out[idx[j], :] += aux[j, :] @ Wn^T   (Wn [H][H], k contiguous; idx distinct; the
- * fp32 product is added to the bf16 row and rounded once).  H in {64, 128, 256}. */
+ * fp32 product is added to the bf16 row and rounded once).  H in {64, 128, 256}.  w_kn != 0: Wn is stored [k][n]. */
 int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_segments, int32_t H, const void* Wn,
-                      const int32_t* idx, void* aux, void* out, dn_stream_t stream);
+                      const int32_t* idx, void* aux, void* out, int32_t w_kn, dn_stream_t stream);
+
+/* Block-diagonal relation weights (regularizer "bdd", the reference CLI's default: subgraph_isomorphism/config.py:145-158):
+ * blocks [R, B, si, so] (the layer's `weight` parameter viewed per relation, rgin.py:68-78) -> dense [R, B*si, B*so] with the B
+ * blocks of a relation on its diagonal and zeros elsewhere, so that `bdd` runs on the same relation-transform kernels as `basis`
+ * (the reference multiplies per block, rgin.py:114-120; the zeros add nothing).  dn_bdd_extract is the gradient: the diagonal
+ * blocks of a dense [R, B*si, B*so] gradient.  elem_bytes = 2 (bf16) or 4 (f32).  One launch each. */
+int dn_bdd_compose(const void* blocks, int64_t R, int32_t B, int32_t si, int32_t so, int32_t elem_bytes, void* dense,
+                   dn_stream_t stream);
+int dn_bdd_extract(const void* dense, int64_t R, int32_t B, int32_t si, int32_t so, int32_t elem_bytes, void* blocks,
+                   dn_stream_t stream);
 
 /* Two dense layers in one pass over the rows (bf16 in, fp32 acc, bf16 out):
  *   Y1 = epi1(m0(X) @ W1n^T),  Y2 = epi2(Y1 @ W2n^T)

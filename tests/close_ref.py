@@ -2,7 +2,7 @@
 masks and the workgroup-major unit records of the H = 256 closing launch.  Test infrastructure only."""
 import numpy as np
 
-DEDUP_CAP = 512          # kCbCap in csrc/dn_close.hip: tiles with more raw list entries are listed without merging
+DEDUP_CAP = 256          # kCbCap in csrc/dn_close.hip: tiles with more raw list entries are listed without merging
 
 
 def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0)):
@@ -35,6 +35,9 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0)):
                     where[r] = len(ent_r)
                     ent_r.append(r); ent_m.append(1 << i)
                 prev = r
+        if not plain:                                  # common path: a tile's entries leave sorted by row (stable)
+            order = sorted(range(len(ent_r)), key=lambda k: (ent_r[k], k))
+            ent_r, ent_m = [ent_r[k] for k in order], [ent_m[k] for k in order]
         tiles[t] = (int(lp[p0]), ent_r, ent_m)
     Tper = (T + G - 1) // G if T else 0
     unit_ptr, units = [0], []

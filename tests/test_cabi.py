@@ -52,21 +52,31 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert L.dn_version() >= 100
     rc = L.dn_gather_segsum_f32(None, 0, 0, None, None, None, 0, 0, None, None, 0.0, 0, None)   # H == 0
     assert rc == -1 and b"H must be > 0" in L.dn_last_error()
-    rc = L.dn_rows_transform_bf16(None, None, 0x7fffffff, None, 100, 100, None, None, 0, None, None, 1, None, None)
+    rc = L.dn_rows_transform_bf16(None, None, 0x7fffffff, None, 100, 100, None, None, 0, None, None, 1, None, 0, None)
     assert rc == -1 and b"unsupported widths" in L.dn_last_error()
     rc = L.dn_conjugate_build_i32(7, 0, 0, 0, 0, *([None] * 13), (ctypes.c_int64 * 2)(), None, 0, None)
     assert rc == -1 and b"bad mode" in L.dn_last_error()
     with pytest.raises(lib.DnHipError):
         lib.check(rc, "dn_conjugate_build_i32")
     # round-2 entry points: the same contract (arguments are checked before anything is launched)
-    rc = L.dn_fold_tail_bf16(None, None, 5, 100, None, None, None, None, None)
+    rc = L.dn_fold_tail_bf16(None, None, 5, 100, None, None, None, None, 0, None)
     assert rc == -1 and b"H must be 64, 128 or 256" in L.dn_last_error()
-    rc = L.dn_fold_tail_bf16(None, None, 5, 256, None, None, None, None, None)
+    rc = L.dn_fold_tail_bf16(None, None, 5, 256, None, None, None, None, 0, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    assert L.dn_fold_tail_bf16(None, None, 0, 256, None, None, None, None, None) == 0           # nothing to do
+    assert L.dn_fold_tail_bf16(None, None, 0, 256, None, None, None, None, 0, None) == 0           # nothing to do
     ok = ctypes.c_int32(7)
     assert L.dn_fold_tables_build_i32(0, 0, None, None, None, None, ctypes.byref(ok), None, 0, None) == 0 and ok.value == 0
     rc = L.dn_fold_tables_build_i32(10, 2, None, None, None, None, ctypes.byref(ok), None, 0, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    # round-4 entry points
+    rc = L.dn_rows_close_bf16(None, 128, None, 0, None, None, None, None, 256, None, None, 8, None, None, None, None)
+    assert rc == -1 and b"unsupported width" in L.dn_last_error()
+    rc = L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 8, None, None, None, None)
+    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
+    assert L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 0, None, None, None, None) == 0
+    assert L.dn_close_units_capacity(64, 320) == 2 * 2 + 10 + 1
+    assert L.dn_close_units_workspace_bytes(64, 4) > 0
+    rc = L.dn_close_units_build_i32(10, 5, 4, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, None)
     assert rc == -1 and b"fold_info needs seg_part" in L.dn_last_error()

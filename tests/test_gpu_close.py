@@ -24,7 +24,7 @@ def _lists(rng, N, P, kind):
         if kind == "repeat" and v % 7 == 0 and rows:
             rows.append(rows[0])                                                 # the same row twice in ONE list (parallel edges)
         if kind == "hub" and v in (3, 40, N - 1):
-            rows += list(rng.integers(0, P, size=700 if v == 40 else 90))        # a tile over the de-duplication capacity / long lists
+            rows += list(rng.integers(0, P, size=400 if v == 40 else 90))        # a tile over the de-duplication capacity / long lists
         lists.append(np.append(np.sort(np.array(rows, dtype=np.int64)), P + v))
     if kind == "unsorted":
         lists[5] = np.array([7, 9, 7, P + 5])                                    # a repeat that is not adjacent: the tile is listed as is
@@ -130,3 +130,39 @@ def test_rows_close_against_the_slot_kernel_and_without_any_rows():
     out = ops.rows_close(xd, Wd, bd, None, cu0, w_kn=True)
     ref = _ref_close(x, W, b, Y, only_self, P)
     assert float(((out.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max()) < 6e-3
+
+
+def test_parameter_layout_weights_give_the_same_bits_as_the_transposed_copy():
+    """w_kn = 1 (weights read as the reference stores them, [in][out]) against w_kn = 0 on an explicit transposed copy: the ring
+    transform (several relation switches per workgroup) and the fold tail, bit for bit; other widths refuse w_kn."""
+    from dummynode4graphlearning_amd import ops
+    from dummynode4graphlearning_amd._lib import DnHipError
+    rng = np.random.default_rng(5)
+    H, R, N = 256, 7, 3000
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16).to(DEV)  # noqa: E731
+    X = bf(rng.standard_normal((N, H)))
+    W = bf(rng.standard_normal((R, H, H)) / np.sqrt(H))                        # [R][in][out]
+    Wn = W.transpose(1, 2).contiguous()
+    cnt = rng.integers(0, 900, size=R)
+    cnt[3] = 0                                                                 # an empty relation
+    rel_ptr = np.concatenate([[0], np.cumsum(cnt)])
+    P = int(rel_ptr[-1])
+    idx = torch.from_numpy(rng.integers(0, N, size=P)).to(DEV).int()
+    tiles = ops.make_row_tiles([int(v) for v in rel_ptr], torch.device(DEV))
+    a = ops.rows_transform(X, W, tiles, P, idx=idx, w_kn=True)
+    b = ops.rows_transform(X, Wn, tiles, P, idx=idx)
+    assert torch.equal(a, b)
+    ref = torch.cat([X[idx[rel_ptr[r]:rel_ptr[r + 1]].long()].double() @ W[r].double() for r in range(R)])
+    assert float((a.double() - ref).abs().max() / ref.abs().max()) < 8e-3
+    # fold tail
+    nseg = 70
+    part_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(rng.integers(1, 4, size=nseg))])).to(DEV).int()
+    part = torch.from_numpy(rng.standard_normal((int(part_ptr[-1]), H)).astype(np.float32)).to(DEV)
+    tgt = torch.from_numpy(rng.permutation(N)[:nseg]).to(DEV).int()
+    o1, o2 = X.clone(), X.clone()
+    x1 = ops.fold_tail(part, part_ptr, nseg, W[2], tgt, o1, w_kn=True)
+    x2 = ops.fold_tail(part, part_ptr, nseg, Wn[2].contiguous(), tgt, o2)
+    assert torch.equal(o1, o2) and torch.equal(x1, x2)
+    W64 = bf(rng.standard_normal((1, 64, 64)))
+    with pytest.raises((DnHipError, AssertionError)):
+        ops.rows_transform(X[:, :64].contiguous(), W64, ops.make_row_tiles([0, 100], torch.device(DEV)), 100, w_kn=True)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Experiment (tuning build: python -m dummynode4graphlearning_amd.csrc.build --tuning --force): where does the H = 256 closing
+launch spend its time?  dn_rows_close_bf16 on the config-5 index with DN_CLOSE_ABL ablations, interleaved in one process.
+bits: 1 entry rows from L2 (row & 1023), 2 x rows from L2, 4 no stores, 8 entry units fetched but not summed.
+usage (GPU box): python tools/close_exp.py [rounds]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from dummynode4graphlearning_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+graphs = int(os.environ.get("GRAPHS", "32768"))
+g, raw, _ = bench.build_batch(dev, 5, graphs, "config5")
+N, H, R = g.number_of_nodes(), 256, 16
+ix = g.row_index(g.edata["label"], R, True).parts[0][2]
+P = ix.num_edge_rows
+x = torch.randn(N, H, device=dev).to(torch.bfloat16)
+W = (torch.randn(H, H, device=dev) * 0.05).to(torch.bfloat16)
+Y = torch.randn(P, H, device=dev).to(torch.bfloat16)
+out = torch.empty_like(x)
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for d in ("f", "b"):
+    cu = ix.close_units(d)
+    fold = ops._row_index_fold(ix, d, "units")
+    part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=dev) if fold is not None else None
+    seg = (fold.fold_info, part) if fold is not None else None
+    nu = int(cu.unit_ptr[-1])
+    print("direction %s: %d units for %d tiles (%.2f per tile), fold %s" % (d, nu, (N + 31) // 32, nu / ((N + 31) // 32), fold is not None))
+
+    def timed(abl, reps=20):
+        os.environ["DN_CLOSE_ABL"] = str(abl)
+        for _ in range(3):
+            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    res = {}
+    for _ in range(rounds):
+        for abl in (0, 16, 0, 16):
+            res.setdefault(abl, []).append(timed(abl))
+    for abl, v in res.items():
+        print("  DN_CLOSE_ABL=%2d: %s us (min %.1f)" % (abl, " ".join("%.1f" % t for t in v), min(v)))

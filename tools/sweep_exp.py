@@ -119,8 +119,8 @@ def conv_leg(ops, ix, x, gout, W_all, bias, dev, reps=20):
 
     def leg():
         with torch.no_grad():
-            ops.message_pass(x, Wn, bias, ix, "f", ybuf, out)
-            ops.message_pass(gout, W_all, None, ix, "b", ybuf, out)
+            ops.message_pass(x, ops.PassWeights(Wn[:-1], Wn[-1]), bias, ix, "f", ybuf, out)
+            ops.message_pass(gout, ops.PassWeights(W_all[:-1], W_all[-1]), None, ix, "b", ybuf, out)
     leg()
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()

@@ -43,8 +43,8 @@ def main():
     ybuf = torch.empty((ix.num_rows, H), dtype=x.dtype, device=dev)
     out = torch.empty_like(x)
     with torch.no_grad():
-        aux = ops.message_pass(x, Wn, None, ix, "f", ybuf, out)
-        aux_b = ops.message_pass(gout, W, None, ix, "b", ybuf, out)
+        aux = ops.message_pass(x, ops.PassWeights(Wn[:-1], Wn[-1]), None, ix, "f", ybuf, out)
+        aux_b = ops.message_pass(gout, ops.PassWeights(W[:-1], W[-1]), None, ix, "b", ybuf, out)
     Rt = ix.num_all_rels
     kw = dict(idx_a=ix.row_in, idx_g=ix.row_out, A2=aux, G2=aux_b, out_dtype=torch.float32, colsum_of=2)
     t0, (gw0, cs0) = timed(lambda: ops.rows_wgrad(x, gout, ix.chunk_table, Rt, **kw))
