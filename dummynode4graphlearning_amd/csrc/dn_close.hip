@@ -41,8 +41,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Unit {
     int32_t flags, beg, end, aux;      // X unit: nodes [beg, end), aux = tile;  ENTRY unit: entries [beg, end), aux = the tile's first node
-};
-constexpr int kUnitEntry = 1, kUnitLast = 2;
+};                                     // AGG unit: the workgroup's tiles number [beg, end) (their segments' aux rows); NOP: nothing
+// flags: bit 0 entry unit, bit 1 last unit of its tile (epilogue), bit 2 AGG unit, bit 3 NOP unit, bits 8-15 rows of the tile
+constexpr int kUnitEntry = 1, kUnitLast = 2, kUnitAgg = 4, kUnitNop = 8;
+constexpr int kAggGap = 8;             // NOP units between a workgroup's last tile and its first AGG unit (>= the loaders' run-ahead)
 
 // ---------------------------------------------------------------------------------------------------------------- tables
 constexpr int kCbWaves = 4;            // tiles per workgroup of the builder (one wavefront each)
@@ -50,6 +52,7 @@ constexpr int kCbCap = 256;            // list entries of a tile that are de-dup
 constexpr int kCbSlots = 512;          // (9 KB of LDS per wavefront: four workgroups of four tiles per CU)
 constexpr int kCbHashShift = 23;       // 32 - log2(kCbSlots)
 constexpr uint32_t kEmpty = 0xffffffffu;
+constexpr int kFoldInfoWords = 12;       // int32 words per tile of a fold table
 
 __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total) {
     int s = v;
@@ -79,7 +82,8 @@ struct CbLds {
     int32_t plain;
 };
 
-__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t P, int32_t T, const int32_t* __restrict__ lptr,
+__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t P, int32_t T, const int32_t* __restrict__ tile_ptr,
+                                                                      const int32_t* __restrict__ lptr,
                                                                       const int32_t* __restrict__ lrows, int32_t drop_beg,
                                                                       int32_t drop_end, const int32_t* __restrict__ drop_enable,
                                                                       int32_t* __restrict__ ent_row, uint32_t* __restrict__ ent_mask,
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     if (t >= T) return;                                                    // (no workgroup barrier below)
     if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
     CbLds& L = Ls[wave];
-    const int p0 = t * 32, pend = min(p0 + 32, N), nn = pend - p0;
+    const int p0 = tile_ptr ? tile_ptr[t] : t * 32;
+    const int pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N), nn = pend - p0;   // (a tile never has more than 32 nodes)
     const int lb = lptr[p0], raw = lptr[pend] - lb;
     auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
     bool plain = raw > kCbCap;
@@ -192,15 +197,22 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
 // as one stream); position k' = w * Tper + n holds tile n * G + w.  One workgroup scans the G * Tper unit counts.
 __global__ __launch_bounds__(1024) void close_scan_kernel(int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_cnt,
-                                                          int32_t* __restrict__ uoff, int32_t* __restrict__ unit_ptr) {
+                                                          int32_t agg, int32_t* __restrict__ uoff, int32_t* __restrict__ unit_ptr) {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
     const int64_t M = (int64_t)G * Tper;
     const int64_t per = (M + 1023) / 1024;
     const int64_t k0 = min((int64_t)tid * per, M), k1 = min(k0 + per, M);
+    // with agg: workgroup w's tiles are followed by kAggGap NOP units and one AGG unit per 32 of its tiles; they are counted at
+    // the workgroup's LAST position (k % Tper == Tper - 1)
     auto units_at = [&](int64_t k) -> int32_t {
-        const int64_t tl = (k % Tper) * G + k / Tper;
-        return tl < T ? 1 + (tile_cnt[tl] + 31) / 32 : 0;
+        const int64_t w = k / Tper, n = k % Tper, tl = n * G + w;
+        int32_t u = tl < T ? 1 + (tile_cnt[tl] + 31) / 32 : 0;
+        if (agg && n == Tper - 1) {
+            const int64_t nw = w < T ? (T - w + G - 1) / G : 0;           // tiles of workgroup w
+            if (nw > 0) u += kAggGap + (int32_t)((nw + 31) / 32);
+        }
+        return u;
     };
     int32_t s = 0;
     for (int64_t k = k0; k < k1; ++k) s += units_at(k);
@@ -221,17 +233,62 @@ __global__ __launch_bounds__(1024) void close_scan_kernel(int32_t T, int32_t G, 
     if (tid == 1023) { uoff[M] = part[1023]; unit_ptr[G] = part[1023]; }
 }
 
-__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ lptr,
-                                  const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ uoff, Unit* __restrict__ units) {
+__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_ptr,
+                                  const int32_t* __restrict__ lptr, const int32_t* __restrict__ tile_cnt,
+                                  const int32_t* __restrict__ uoff, int32_t agg, Unit* __restrict__ units) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const int64_t k = (t % G) * Tper + t / G;
-    const int32_t p0 = (int32_t)t * 32, pend = min(p0 + 32, N), c = tile_cnt[t], e0 = lptr[p0];
+    const int64_t w = t % G, n = t / G, k = w * Tper + n;
+    const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
+    const int32_t pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N);
+    const int32_t c = tile_cnt[t], e0 = lptr[p0], rows = (pend - p0) << 8;
     Unit* u = units + uoff[k];
     const int ne = (c + 31) / 32;
-    u[0] = Unit{ne == 0 ? kUnitLast : 0, p0, pend, (int32_t)t};
+    u[0] = Unit{(ne == 0 ? kUnitLast : 0) | rows, p0, pend, (int32_t)t};
     for (int i = 0; i < ne; ++i)
-        u[1 + i] = Unit{kUnitEntry | (i == ne - 1 ? kUnitLast : 0), e0 + 32 * i, e0 + min(32 * (i + 1), c), p0};
+        u[1 + i] = Unit{kUnitEntry | (i == ne - 1 ? kUnitLast : 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), c), p0};
+    if (agg && t + G >= T) {                                               // the workgroup's last tile: its NOP gap and AGG units
+        const int32_t nw = (int32_t)n + 1;
+        Unit* a = u + 1 + ne;
+        for (int i = 0; i < kAggGap; ++i) a[i] = Unit{kUnitNop, 0, 1, 0};
+        a += kAggGap;
+        for (int i = 0; 32 * i < nw; ++i) a[i] = Unit{kUnitAgg | kUnitLast, 32 * i, min(32 * (i + 1), nw), 0};
+    }
+}
+
+// Tiles = the graphs of a batch (segment-complete tiles for the absorbed fold): segment j = the nodes seg_nodes[seg_ptr[j] ..
+// seg_ptr[j+1]) (a graph's nodes that feed its dummy node).  Block j = [first node of segment j (0 for j = 0), first node of
+// segment j + 1 (N for the last)).  Valid when every segment is a non-empty contiguous ascending run, the segments ascend and
+// every block has at most 32 nodes; then tile j = block j, fold record j = {local ids: 0 inside the segment, 255 outside;
+// first aux row = j; count = 1}.
+__global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
+                                        int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, int32_t* __restrict__ ok) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > S) return;
+    if (j == S) { tile_ptr[S] = N; return; }
+    const int32_t cnt = sptr[j + 1] - sptr[j];
+    bool good = cnt > 0;
+    int32_t first = 0, last = 0, nxt = N;
+    if (good) {
+        first = snodes[sptr[j]];
+        last = snodes[sptr[j + 1] - 1];
+        good = first >= 0 && last < N && last - first == cnt - 1;
+        for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
+        if (good && j + 1 < S) {
+            good = sptr[j + 2] > sptr[j + 1];
+            if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
+        }
+    }
+    const int32_t b0 = j == 0 ? 0 : first;
+    if (good) good = nxt - b0 <= 32 && nxt - b0 >= 1;
+    if (!good) { *ok = 0; return; }
+    tile_ptr[j] = b0;
+    uint8_t ids[32];
+    for (int i = 0; i < 32; ++i) ids[i] = (b0 + i >= first && b0 + i <= last) ? 0 : 255;
+    int32_t* rec = info + (size_t)j * kFoldInfoWords;
+    for (int i = 0; i < 8; ++i)
+        rec[i] = (int32_t)((uint32_t)ids[4 * i] | ((uint32_t)ids[4 * i + 1] << 8) | ((uint32_t)ids[4 * i + 2] << 16) | ((uint32_t)ids[4 * i + 3] << 24));
+    rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 0; rec[11] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernel
@@ -260,12 +317,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 
 #define DN_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 
-template <bool FOLD>
+// FOLD: 0 none; 1 the per-(segment, tile) column sums of x leave as fp32 partial rows (seg_part; dn_fold_tail_bf16 finishes);
+// 2 every segment lies inside one tile: its column sum leaves as the bf16 aux row, and the workgroup's AGG units at the end of
+// its stream multiply those rows by W_agg and add each product to its output row (agg_idx) -- no partial rows, no tail launch.
+template <int FOLD>
 __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int32_t w_kn, const bf16_t* __restrict__ bias,
     const bf16_t* __restrict__ S, const Unit* __restrict__ units, const int32_t* __restrict__ unit_ptr,
     const int32_t* __restrict__ ent_row, const uint32_t* __restrict__ ent_mask, int32_t N, int32_t flags, bf16_t* __restrict__ out,
-    const int32_t* __restrict__ fold_info, float* __restrict__ seg_part) {
+    const int32_t* __restrict__ fold_info, float* __restrict__ seg_part, const bf16_t* __restrict__ W_agg,
+    bf16_t* __restrict__ aux, const int32_t* __restrict__ agg_idx) {
     __shared__ __attribute__((aligned(1024))) char lds[kNS * kStageB];
     __shared__ __attribute__((aligned(1024))) int32_t foldR[kFoldRing][16];                   // fold records of the X units (12 words used)
     __shared__ __attribute__((aligned(256))) uint32_t maskR[kMaskRing][32];                   // membership masks of the entry units, k order
@@ -278,8 +339,9 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     const unsigned desc_base = (unsigned)(uintptr_t)(lds_wp)&descL[0][0];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int u_beg = unit_ptr[blockIdx.x];
-    const int nt = unit_ptr[blockIdx.x + 1] - u_beg;
+    const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
+    const int u_beg = unit_ptr[wg];
+    const int nt = unit_ptr[wg + 1] - u_beg;
     if (nt <= 0) return;
     units += u_beg;
 
@@ -303,11 +365,13 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
         const unsigned mask_base = (unsigned)(uintptr_t)(lds_wp)&maskR[0][0];
         const unsigned fold_base = (unsigned)(uintptr_t)(lds_wp)&foldR[0][0];
         const int myrow = 2 * (lane & 3) + ((lane >> 2) & 1);              // the index ring holds a unit's 8 rows as {0,2,4,6,1,3,5,7}
-        auto dma_recs = [&](int T0) {                                      // records of units T0 .. T0 + 7 (clamped: valid memory)
+        // source bases as one base + differences: a three-way select of captured variables makes hipcc keep the closure on the stack
+        const uint64_t baseX = (uint64_t)(uintptr_t)X, dS = (uint64_t)(uintptr_t)S - baseX, dA = (uint64_t)(uintptr_t)aux - baseX;
+        auto dma_recs = [&](int T0) __attribute__((always_inline)) {                                      // records of units T0 .. T0 + 7 (clamped: valid memory)
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(rec_base + (unsigned)(T0 % kRecRing) * 16u));
             if (lane < kBatch) glds16(units + min(T0 + lane, nt - 1), dst);
         };
-        auto stage_idx = [&](int T0) {                                     // source rows of my 8 rows of units T0 .. T0 + 7; records -> descL
+        auto stage_idx = [&](int T0) __attribute__((always_inline)) {                                     // source rows of my 8 rows of units T0 .. T0 + 7; records -> descL
             const int T = T0 + (lane >> 3);
             const int32_t* rp = &recR[q][T % kRecRing][0];
             const int fl = rp[0], beg = rp[1], end = rp[2];
@@ -317,7 +381,9 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             const unsigned dst =
                 (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T0 % kIdxRing) * (4u * kRowsPerLoader)));
             if (fl & kUnitEntry) glds4(ent_row + pc, dst);                 // lane l lands at + 4 l: [unit][8 rows]
-            else idxR[q][T % kIdxRing][lane & 7] = pc;                     // an X unit's rows are its nodes
+            else if (FOLD == 2 && (fl & kUnitAgg))                         // the aux row of my pc-th tile (= its segment)
+                idxR[q][T % kIdxRing][lane & 7] = wg + nwg * pc;
+            else idxR[q][T % kIdxRing][lane & 7] = (fl & kUnitNop) ? 0 : pc;   // an X unit's rows are its nodes
             // membership masks of units T0 + 2 q, T0 + 2 q + 1, in the k order of the transposed reads:
             // position k = 8 g + 4 jh + qq  <->  row g + 16 jh + 4 qq of the unit
             {
@@ -326,42 +392,51 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 const int32_t* mp = &recR[q][Tm % kRecRing][0];
                 const int e = mp[1] + r;
                 const bool ok = (mp[0] & kUnitEntry) && e < mp[2];
+                const void* msrc = ok ? (const void*)(ent_mask + e) : (const void*)(g_close_zero + kk);
+                if constexpr (FOLD == 2) {                                 // an AGG unit's "masks" are the output rows of its 32 products
+                    const int ord = mp[1] + kk;
+                    if ((mp[0] & kUnitAgg) && ord < mp[2]) msrc = agg_idx + (wg + nwg * ord);
+                }
                 const unsigned mdst =
                     (unsigned)__builtin_amdgcn_readfirstlane((int)(mask_base + (unsigned)((T0 + 2 * q) % kMaskRing) * 128u));
-                glds4(ok ? (const void*)(ent_mask + e) : (const void*)(g_close_zero + kk), mdst);
+                glds4(msrc, mdst);
             }
-            if constexpr (FOLD) {
+            if constexpr (FOLD != 0) {
                 if (q == 1) {                                              // fold records of the batch's X units: lane 4 k + c = 16-byte chunk c
                     const int Tf = T0 + (lane >> 2), c = lane & 3;
                     const int32_t* fp = &recR[1][Tf % kRecRing][0];
                     const unsigned fdst =
                         (unsigned)__builtin_amdgcn_readfirstlane((int)(fold_base + (unsigned)(T0 % kFoldRing) * 64u));
-                    if (lane < 4 * kBatch && c < 3 && !(fp[0] & kUnitEntry))
+                    if (lane < 4 * kBatch && c < 3 && !(fp[0] & (kUnitEntry | kUnitAgg | kUnitNop)))
                         glds16(fold_info + (size_t)fp[3] * kFoldInfo + 4 * c, fdst);
                 }
             }
         };
         const char* srcA[kDmaPerTile];
         const char* srcB[kDmaPerTile];
-        auto prep = [&](int u, const char* (&src)[kDmaPerTile]) {
+        auto prep = [&](int u, const char* (&src)[kDmaPerTile]) __attribute__((always_inline)) {
             typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
             const i32x4 iv = *reinterpret_cast<const i32x4*>(&idxR[q][u % kIdxRing][4 * rin]);   // rows rin, 2 + rin, 4 + rin, 6 + rin
-            const bool ent = (recR[q][u % kRecRing][0] & kUnitEntry) != 0;
-            const char* base0 = reinterpret_cast<const char*>(ent ? S : X);
+            const int kind = recR[q][u % kRecRing][0];
+            const bool ent = (kind & kUnitEntry) != 0, agg = FOLD == 2 && (kind & kUnitAgg) != 0;
+            // (selects, not branches: a branch here keeps hipcc from holding the source addresses in registers)
+            const uint64_t base0 = baseX + (ent ? dS : 0ull) + (agg ? dA : 0ull);      // (X, S or aux)
 #ifdef DN_TUNING_ENV
             const uint32_t rmask = (flags & (ent ? 4 : 8)) ? 1023u : 0xffffffffu;   // (ablation: the rows come from L2)
 #else
             constexpr uint32_t rmask = 0xffffffffu;
 #endif
 #pragma unroll
-            for (int j = 0; j < kDmaPerTile; ++j) src[j] = base0 + (size_t)((uint32_t)iv[j] & rmask) * kRowB + swoff[j];
+            for (int j = 0; j < kDmaPerTile; ++j)
+                src[j] = reinterpret_cast<const char*>(base0 + (uint64_t)((uint32_t)iv[j] & rmask) * kRowB + (uint64_t)swoff[j]);
         };
-        auto rows = [&](int u, const char* (&src)[kDmaPerTile]) {
-            const unsigned st = lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB;
+        auto rows = [&](int u, const char* (&src)[kDmaPerTile]) __attribute__((always_inline)) {
+            const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(lds_base + (unsigned)(u % kNS) * kStageB + (unsigned)(kRowsPerLoader * q) * kRowB));
 #pragma unroll
             for (int j = 0; j < kDmaPerTile; ++j) glds16(src[j], st + (unsigned)(2 * j) * kRowB);   // lane l lands at + 16 l
         };
-        auto batch = [&](int u) {                                          // u = 8 b: rows / masks of batch b + 1, records of batch b + 2
+        auto batch = [&](int u) __attribute__((always_inline)) {                                          // u = 8 b: rows / masks of batch b + 1, records of batch b + 2
             if ((u & (kBatch - 1)) == 0) {                                 // wave-uniform
                 stage_idx(u + kBatch);
                 dma_recs(u + 2 * kBatch);
@@ -438,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     typedef short4v __attribute__((address_space(3))) * lds_tr;
     // A operand of a transposed product over the 32 rows of a stage: element jj of a[n] = row g + 16 (jj >> 2) + 4 (jj & 3),
     // column n0 + 8 (j >> 2) + 4 n + (j & 3)
-    auto tr_frags = [&](unsigned sb, bf16x8 (&a)[2]) {
+    auto tr_frags = [&](unsigned sb, bf16x8 (&a)[2]) __attribute__((always_inline)) {
         const unsigned b0 = sb + tr0;
         const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)b0);
         const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(uintptr_t)(b0 ^ 8u));
@@ -453,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     };
 
     // rows p0 + j and p0 + 16 + j of the tile, my 8 columns: bias, bf16, one 16-byte store each
-    auto epilogue = [&](int32_t p0, int32_t pend) {
+    auto epilogue = [&](int32_t p0, int32_t pend) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int p = p0 + j + 16 * m;
@@ -478,6 +553,36 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)p * kH + ocol);
                 if (nt_store) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
+            }
+        }
+    };
+
+    // AGG unit: row r of the unit is the product of one segment's aux row with W_agg; it is ADDED to output row tgt[r] (this
+    // workgroup stored that row itself, units ago, and drained its stores at the NOP gap in between).  The rows' current values
+    // are requested before the unit's MFMAs (agg_fetch) and added behind them (epilogue_agg).
+    u32x4 agg_old[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    u32x4* agg_dst[2] = {nullptr, nullptr};
+    auto agg_fetch = [&](const uint32_t* tgt, int32_t cnt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int r = j + 16 * m;
+            agg_dst[m] = reinterpret_cast<u32x4*>(out + (size_t)tgt[r < cnt ? r : 0] * kH + ocol);
+            if (r < cnt) agg_old[m] = *agg_dst[m];
+        }
+    };
+    auto epilogue_agg = [&](int32_t cnt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int r = j + 16 * m;
+            if (r < cnt) {
+                const u32x4 old = agg_old[m];
+                u32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = i >> 1, e = 2 * (i & 1);
+                    o[i] = pack_bf16x2(acc[m][n][e] + __uint_as_float(old[i] << 16), acc[m][n][e + 1] + __uint_as_float(old[i] & 0xffff0000u));
+                }
+                *agg_dst[m] = o;
             }
         }
     };
@@ -509,16 +614,20 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");
     int32_t u_fl = __builtin_amdgcn_readfirstlane((int)dn[0]);
     int32_t u_beg2 = __builtin_amdgcn_readfirstlane((int)dn[1]);
+    int32_t u_end = __builtin_amdgcn_readfirstlane((int)dn[2]);
     int32_t u_aux = __builtin_amdgcn_readfirstlane((int)dn[3]);
 
-#pragma unroll 1
-    for (int u = 0; u < nt; ++u) {
+    auto unit = [&](int u) __attribute__((always_inline)) {
         if ((u & 1) == 0) __builtin_amdgcn_s_barrier();                    // one per pair of units: units up to u + 2 have landed
         const unsigned an = desc_base + (unsigned)((u + 1) % kDescRing) * 16u;
         const unsigned sb = (unsigned)(u % kNS) * kStageB;
-        int32_t p0;
-        if (!(u_fl & kUnitEntry)) {
-            // ---- X unit: acc = W_loop^T-slice x rows^T
+        int32_t p0 = 0;
+        if (u_fl & kUnitNop) {
+            // ---- gap between the workgroup's tiles and its AGG units: my stores of aux rows and output rows have left
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+        } else if (!(u_fl & kUnitEntry)) {
+            // ---- X unit: acc = W_loop^T-slice x rows^T      (AGG unit: the same product on 32 aux rows with W_agg)
             p0 = u_beg2;
             bf16x8 xf[8][2];
             DN_FETCH(0, sb) DN_FETCH(1, sb) DN_FETCH(2, sb) DN_FETCH(3, sb) DN_FETCH(4, sb) DN_FETCH(5, sb) DN_FETCH(6, sb) DN_FETCH(7, sb)
@@ -529,7 +638,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             DN_KSTEP(0, 15) DN_KSTEP(1, 13) DN_KSTEP(2, 11) DN_KSTEP(3, 9) DN_KSTEP(4, 7) DN_KSTEP(5, 5) DN_KSTEP(6, 3) DN_KSTEP(7, 1)
-            if constexpr (FOLD) {
+            if constexpr (FOLD != 0) {
                 // column sums of the tile's x rows per segment (graph): D[column][s] = sum_r x[r][column] [row r in segment s]
                 const int32_t* fr = &foldR[u % kFoldRing][0];
                 const int cnt = __builtin_amdgcn_readfirstlane(fr[9]);
@@ -551,11 +660,21 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                         for (int i = 0; i < 4; ++i)
                             iw[i] = (id[2 * i] == me ? 0x3f80u : 0u) | (id[2 * i + 1] == me ? 0x3f800000u : 0u);
                         const bf16x8 ind = __builtin_bit_cast(bf16x8, iw);
+                        if constexpr (FOLD == 1) {
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            if ((int)me < cnt)
-                                *reinterpret_cast<f32x4*>(seg_part + (size_t)(first + (int)me) * kH + ocol + 4 * n) = d;
+                            for (int n = 0; n < 2; ++n) {
+                                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                if ((int)me < cnt)
+                                    *reinterpret_cast<f32x4*>(seg_part + (size_t)(first + (int)me) * kH + ocol + 4 * n) = d;
+                            }
+                        } else {                                           // the segment is complete: its sum IS the aux row
+                            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            if ((int)me < cnt) {
+                                const u32x4 o = {pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
+                                                 pack_bf16x2(d1[2], d1[3])};
+                                *reinterpret_cast<u32x4*>(aux + (size_t)(first + (int)me) * kH + ocol) = o;
+                            }
                         }
                     }
                 }
@@ -592,11 +711,55 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], sel[m], acc[m][n], 0, 0, 0);
             }
         }
-        if (u_fl & kUnitLast) epilogue(p0, min(p0 + kTR, N));
+        if (u_fl & kUnitLast) epilogue(p0, p0 + ((u_fl >> 8) & 0xff));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");     // my LDS reads are done before I arrive at a barrier
         u_fl = __builtin_amdgcn_readfirstlane((int)dn[0]);
         u_beg2 = __builtin_amdgcn_readfirstlane((int)dn[1]);
+        u_end = __builtin_amdgcn_readfirstlane((int)dn[2]);
         u_aux = __builtin_amdgcn_readfirstlane((int)dn[3]);
+    };
+    int u = 0;
+#pragma unroll 1
+    for (; u < nt; ++u) {
+        if (FOLD == 2 && (u_fl & kUnitAgg)) break;
+        unit(u);
+    }
+    if constexpr (FOLD == 2) {
+        if (u < nt) {                                                      // the workgroup's AGG units: W_agg replaces W_loop in wf
+            if (w_kn == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        wf[ks][n] = *reinterpret_cast<const bf16x8*>(W_agg + (size_t)(n0 + colA0 + 4 * n) * kH + ks * 32 + 8 * g);
+            } else {
+                dn_load_w_kn32<8>(W_agg, kH, n0, lane, wscr[wave], wf);
+            }
+            // phase B: nothing but AGG units from here on -- the same product on 32 aux rows, added to their output rows
+            auto agg_unit = [&](int u) __attribute__((always_inline)) {
+                if ((u & 1) == 0) __builtin_amdgcn_s_barrier();
+                const unsigned an = desc_base + (unsigned)((u + 1) % kDescRing) * 16u;
+                const unsigned sb = (unsigned)(u % kNS) * kStageB;
+                const int32_t cnt = (u_fl & kUnitAgg) ? u_end - u_beg2 : 0;
+                agg_fetch(&maskR[u % kMaskRing][0], cnt);
+                bf16x8 xf[8][2];
+                DN_FETCH(0, sb) DN_FETCH(1, sb) DN_FETCH(2, sb) DN_FETCH(3, sb) DN_FETCH(4, sb) DN_FETCH(5, sb) DN_FETCH(6, sb) DN_FETCH(7, sb)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dn) : "v"(an));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                DN_KSTEP(0, 15) DN_KSTEP(1, 13) DN_KSTEP(2, 11) DN_KSTEP(3, 9) DN_KSTEP(4, 7) DN_KSTEP(5, 5) DN_KSTEP(6, 3) DN_KSTEP(7, 1)
+                epilogue_agg(cnt);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");
+                u_fl = __builtin_amdgcn_readfirstlane((int)dn[0]);
+                u_beg2 = __builtin_amdgcn_readfirstlane((int)dn[1]);
+                u_end = __builtin_amdgcn_readfirstlane((int)dn[2]);
+            };
+#pragma unroll 1
+            for (; u < nt; ++u) agg_unit(u);
+        }
     }
 #undef DN_FETCH
 #undef DN_KSTEP
@@ -607,41 +770,58 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
 
 extern "C" {
 
-int64_t dn_close_units_capacity(int64_t N, int64_t num_list_entries) {
-    const int64_t T = dn_cdiv(N, 32);
-    return 2 * T + num_list_entries / 32 + 1;
+int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {
+    return 2 * num_tiles + num_list_entries / 32 + 1 + (int64_t)num_wg * (kAggGap + 1) + num_tiles / 32;
 }
 
-size_t dn_close_units_workspace_bytes(int64_t N, int32_t num_wg) {
-    if (N < 0 || num_wg <= 0) { dn_set_error("dn_close_units_workspace_bytes: bad sizes"); return 0; }
-    const int64_t T = dn_cdiv(N, 32), Tper = dn_cdiv(T, num_wg);
-    return (size_t)(T + 1) * 4 + (size_t)((int64_t)num_wg * Tper + 1) * 4 + 512;
+size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
+    if (num_tiles < 0 || num_wg <= 0) { dn_set_error("dn_close_units_workspace_bytes: bad sizes"); return 0; }
+    const int64_t Tper = dn_cdiv(num_tiles, num_wg);
+    return (size_t)(num_tiles + 1) * 4 + (size_t)((int64_t)num_wg * Tper + 1) * 4 + 512;
 }
 
-int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* list_ptr, const int32_t* list_rows,
-                             int64_t num_list_entries, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
-                             int32_t* unit_ptr, int32_t* units, int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask,
-                             void* workspace, size_t workspace_bytes, dn_stream_t stream) {
-    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_edge_rows >= 0 && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0,
-               "dn_close_units_build: bad sizes");
+int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
+                             int32_t agg_units, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
+                             int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
+                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
+                             dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_edge_rows >= 0 && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 &&
+               num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_close_units_build: bad sizes");
+    DN_REQUIRE(tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the %lld "
+               "32-node windows", (long long)dn_cdiv(N, 32));
     DN_REQUIRE(unit_ptr, "dn_close_units_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (N == 0) { DN_CHECK_HIP(hipMemsetAsync(unit_ptr, 0, sizeof(int32_t) * ((size_t)num_wg + 1), st)); return DN_OK; }
+    if (N == 0 || num_tiles == 0) { DN_CHECK_HIP(hipMemsetAsync(unit_ptr, 0, sizeof(int32_t) * ((size_t)num_wg + 1), st)); return DN_OK; }
     DN_REQUIRE(list_ptr && list_rows && units && ent_row && ent_mask && workspace, "dn_close_units_build: NULL pointer");
-    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(N, num_list_entries), "dn_close_units_build: unit table too small");
-    DN_REQUIRE(workspace_bytes >= dn_close_units_workspace_bytes(N, num_wg), "dn_close_units_build: workspace too small");
+    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
+    DN_REQUIRE(workspace_bytes >= dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(units) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 4 == 0,
                "dn_close_units_build: unaligned pointer");
-    const int32_t T = (int32_t)dn_cdiv(N, 32), Tper = (int32_t)dn_cdiv(T, num_wg);
+    const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
     int32_t* tile_cnt = reinterpret_cast<int32_t*>(workspace);
     int32_t* uoff = tile_cnt + T + 1;
     hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,
-                       T, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt);
+                       T, tile_ptr, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt);
     DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(close_scan_kernel, dim3(1), dim3(1024), 0, st, T, num_wg, Tper, tile_cnt, uoff, unit_ptr);
+    hipLaunchKernelGGL(close_scan_kernel, dim3(1), dim3(1024), 0, st, T, num_wg, Tper, tile_cnt, agg_units ? 1 : 0, uoff, unit_ptr);
     DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(T, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, list_ptr, tile_cnt,
-                       uoff, reinterpret_cast<Unit*>(units));
+    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(T, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, tile_ptr,
+                       list_ptr, tile_cnt, uoff, agg_units ? 1 : 0, reinterpret_cast<Unit*>(units));
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                                  int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_graph_tiles_build: bad sizes");
+    DN_REQUIRE(dev_ok, "dn_fold_graph_tiles_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0 || num_segments == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0, sizeof(int32_t), st)); return DN_OK; }
+    DN_REQUIRE(seg_ptr && seg_nodes && tile_ptr && fold_info, "dn_fold_graph_tiles_build: NULL pointer");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0, "dn_fold_graph_tiles_build: unaligned pointer");
+    DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
+    hipLaunchKernelGGL(fold_graph_tiles_kernel, dim3((unsigned)dn_cdiv(num_segments + 1, 256)), dim3(256), 0, st, (int32_t)N,
+                       (int32_t)num_segments, seg_ptr, seg_nodes, tile_ptr, fold_info, dev_ok);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -649,29 +829,32 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
-                       dn_stream_t stream) {
+                       const void* W_agg, void* aux, const int32_t* agg_idx, dn_stream_t stream) {
     DN_REQUIRE(H == 256, "dn_rows_close: unsupported width %d (256 only; dn_rows_selfsum_bf16 serves 64 / 128)", H);
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096, "dn_rows_close: bad sizes");
-    DN_REQUIRE(fold_info == nullptr || seg_part != nullptr, "dn_rows_close: fold_info needs seg_part");
+    const bool agg = W_agg != nullptr || aux != nullptr || agg_idx != nullptr;
+    DN_REQUIRE(fold_info == nullptr || seg_part != nullptr || agg, "dn_rows_close: fold_info needs seg_part (or W_agg / aux / agg_idx)");
+    DN_REQUIRE(!agg || (fold_info && W_agg && aux && agg_idx && !seg_part),
+               "dn_rows_close: the absorbed fold takes fold_info, W_agg, aux and agg_idx together, without seg_part");
     if (N == 0) return DN_OK;
     DN_REQUIRE(X && W && unit_ptr && units && ent_row && ent_mask && out, "dn_rows_close: NULL pointer");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(S) |
                 reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(units) | reinterpret_cast<uintptr_t>(bias) |
-                reinterpret_cast<uintptr_t>(fold_info) | reinterpret_cast<uintptr_t>(seg_part)) % 16 == 0,
-               "dn_rows_close: unaligned pointer");
+                reinterpret_cast<uintptr_t>(fold_info) | reinterpret_cast<uintptr_t>(seg_part) | reinterpret_cast<uintptr_t>(W_agg) |
+                reinterpret_cast<uintptr_t>(aux)) % 16 == 0, "dn_rows_close: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     static const int nt = dn_knob("DN_NT", 3);
     const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
     const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 31) << 2);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
-    if (fold_info)
-        hipLaunchKernelGGL((rows_close_ring_kernel<true>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X,
-                           (const bf16_t*)W, w_kn, (const bf16_t*)bias, s, reinterpret_cast<const Unit*>(units), unit_ptr, ent_row,
-                           ent_mask, (int32_t)N, flags, (bf16_t*)out, fold_info, seg_part);
-    else
-        hipLaunchKernelGGL((rows_close_ring_kernel<false>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X,
-                           (const bf16_t*)W, w_kn, (const bf16_t*)bias, s, reinterpret_cast<const Unit*>(units), unit_ptr, ent_row,
-                           ent_mask, (int32_t)N, flags, (bf16_t*)out, fold_info, seg_part);
+#define DN_CLOSE_LAUNCH(F)                                                                                                         \
+    hipLaunchKernelGGL((rows_close_ring_kernel<F>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X, (const bf16_t*)W, \
+                       w_kn, (const bf16_t*)bias, s, reinterpret_cast<const Unit*>(units), unit_ptr, ent_row, ent_mask, (int32_t)N, \
+                       flags, (bf16_t*)out, fold_info, seg_part, (const bf16_t*)W_agg, (bf16_t*)aux, agg_idx)
+    if (agg) DN_CLOSE_LAUNCH(2);
+    else if (fold_info) DN_CLOSE_LAUNCH(1);
+    else DN_CLOSE_LAUNCH(0);
+#undef DN_CLOSE_LAUNCH
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -503,55 +503,88 @@ CLOSE_RING_ENABLED = _os.environ.get("DN_CLOSE_RING", "1") != "0"
 
 class CloseUnits:
     """Tables of dn_rows_close_bf16 for one direction of a RowIndex (dn_close_units_build_i32)."""
-    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes")
+    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes", "num_tiles", "agg")
 
 
 def _num_cus(dev):
     return int(torch.cuda.get_device_properties(dev).multi_processor_count)
 
 
-def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None):
-    """Per 32-node tile the distinct kept rows of its nodes' lists + membership masks, and the per-workgroup unit records the
-    closing launch streams (three launches, no read-back).  Same filter as build_slot_table."""
-    require_gpu(list_ptr, list_rows)
+def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None):
+    """Tiles = the graphs of a batch, for the absorbed fold (dn_fold_graph_tiles_build_i32, one launch, no read-back):
+    -> (tile_ptr [S + 1], fold_info [S, 12], ok [1] device flag: non-zero when every graph has at most 32 nodes and the
+    segments are contiguous ascending runs)."""
+    require_gpu(seg_ptr, seg_nodes)
+    dev = seg_ptr.device
+    S = int(seg_ptr.numel()) - 1
+    tile_ptr = torch.empty(S + 1, dtype=I32, device=dev)
+    info = torch.empty((max(S, 1), 12), dtype=I32, device=dev)
+    if ok is None:
+        ok = torch.zeros(1, dtype=I32, device=dev)
+    check(lib().dn_fold_graph_tiles_build_i32(int(num_nodes), S, ptr(seg_ptr), ptr(seg_nodes), ptr(tile_ptr), ptr(info), ptr(ok),
+                                              stream_ptr()), "dn_fold_graph_tiles_build_i32")
+    return tile_ptr, info[:S], ok
+
+
+def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None, tile_ptr=None,
+                      agg=False):
+    """Per tile (32-node windows, or the node ranges tile_ptr gives) the distinct kept rows of its nodes' lists + membership
+    masks, and the per-workgroup unit records the closing launch streams (three launches, no read-back).  Same filter as
+    build_slot_table.  agg: append every workgroup's AGG units (the absorbed fold, tile_ptr from build_graph_tiles)."""
+    require_gpu(list_ptr, list_rows, tile_ptr)
     dev = list_rows.device
     N, P, L = int(num_nodes), int(num_edge_rows), int(list_rows.numel())
     list_ptr, list_rows = list_ptr.to(I32).contiguous(), list_rows.to(I32).contiguous()
     cu = CloseUnits()
     cu.num_wg = int(num_wg) if num_wg else _num_cus(dev)
-    cu.num_nodes = N
-    cap = int(lib().dn_close_units_capacity(N, L))
+    cu.num_nodes, cu.agg = N, bool(agg)
+    cu.num_tiles = T = (int(tile_ptr.numel()) - 1) if tile_ptr is not None else (N + 31) // 32
+    assert not agg or tile_ptr is not None
+    cap = int(lib().dn_close_units_capacity(T, L, cu.num_wg))
     cu.unit_ptr = torch.empty(cu.num_wg + 1, dtype=I32, device=dev)
     cu.units = torch.empty((cap, 4), dtype=I32, device=dev)
     cu.ent_row = torch.empty(max(L, 1), dtype=I32, device=dev)
     cu.ent_mask = torch.empty(max(L, 1), dtype=I32, device=dev)
-    ws = _ws(lib().dn_close_units_workspace_bytes(N, cu.num_wg), dev)
-    check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(list_ptr), ptr(list_rows), L, int(drop[0]), int(drop[1]),
-                                         ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap, ptr(cu.ent_row), ptr(cu.ent_mask),
-                                         ptr(ws), ws.numel(), stream_ptr()), "dn_close_units_build_i32")
+    ws = _ws(lib().dn_close_units_workspace_bytes(T, cu.num_wg), dev)
+    check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(tile_ptr), T, 1 if agg else 0, ptr(list_ptr), ptr(list_rows), L,
+                                         int(drop[0]), int(drop[1]), ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap,
+                                         ptr(cu.ent_row), ptr(cu.ent_mask), ptr(ws), ws.numel(), stream_ptr()),
+          "dn_close_units_build_i32")
     return cu
 
 
-def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False):
+def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
     """out[v] = x[v] @ W_loop (+ bias) + sum of the rows of S that cu lists for v  (dn_rows_close_bf16, H = 256).
-    W: [out, in] (w_kn False, the transposed copy) or [in, out] as the parameter stores it (w_kn True).  seg as in rows_selfsum."""
+    W: [out, in] (w_kn False, the transposed copy) or [in, out] as the parameter stores it (w_kn True).  seg as in rows_selfsum
+    (fp32 partial rows for dn_fold_tail_bf16).  agg = (fold_info [T, 12], W_agg [H, H] in W's layout, aux [S, H] out, agg_idx [S]):
+    the absorbed fold -- cu built with build_graph_tiles' tiles and agg=True; aux[j] = the column sum of segment j (bf16),
+    out[agg_idx[j]] += aux[j] @ W_agg inside the same launch."""
     require_gpu(x, W, bias, S, cu.unit_ptr, cu.units, cu.ent_row, cu.ent_mask)
     N, H = x.shape
     assert H == 256 and x.dtype == torch.bfloat16 and W.shape == (H, H) and W.dtype == x.dtype and N == cu.num_nodes
     assert S is None or (S.dtype == x.dtype and S.shape[1] == H and S.is_contiguous())
+    assert (agg is not None) == cu.agg and not (agg is not None and seg is not None)
     x, W = x.contiguous(), W.contiguous()
+    fi = sp = wa = ax = ai = None
     if seg is not None:
         require_gpu(*seg)
-        assert seg[0].dtype == I32 and seg[0].shape == ((N + 31) // 32, 12) and seg[0].is_contiguous()
-        assert seg[1].dtype == torch.float32 and seg[1].shape[1] == H and seg[1].is_contiguous()
+        fi, sp = seg
+        assert fi.dtype == I32 and fi.shape == (cu.num_tiles, 12) and fi.is_contiguous()
+        assert sp.dtype == torch.float32 and sp.shape[1] == H and sp.is_contiguous()
+    if agg is not None:
+        require_gpu(*agg)
+        fi, wa, ax, ai = agg
+        assert fi.dtype == I32 and fi.shape == (cu.num_tiles, 12) and fi.is_contiguous()
+        assert wa.dtype == x.dtype and wa.shape == (H, H) and wa.is_contiguous()
+        assert ax.dtype == x.dtype and ax.shape == (cu.num_tiles, H) and ax.is_contiguous()
+        assert ai.dtype == I32 and ai.numel() == cu.num_tiles and ai.is_contiguous()
     if out is None:
         out = torch.empty((N, H), dtype=x.dtype, device=x.device)
 
     def _launch():
         check(lib().dn_rows_close_bf16(ptr(x), H, ptr(W), 1 if w_kn else 0, ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                        ptr(cu.unit_ptr), ptr(cu.units), cu.num_wg, ptr(cu.ent_row), ptr(cu.ent_mask), N, ptr(out),
-                                       ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, stream_ptr()),
-              "dn_rows_close_bf16")
+                                       ptr(fi), ptr(sp), ptr(wa), ptr(ax), ptr(ai), stream_ptr()), "dn_rows_close_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_close", _launch)
     else:
@@ -1222,24 +1255,30 @@ def _fold_candidate(ix, direction):
     return (r, beg, end, n_aux) if end - beg == n_aux else None
 
 
+# DN_CLOSE_AGG=0: keep the fp32 partial rows + dn_fold_tail_bf16 even where every graph fits one tile of the unit stream
+CLOSE_AGG_ENABLED = _os.environ.get("DN_CLOSE_AGG", "1") != "0"
+
+
 def _closing_tables(ix, kind="slots"):
-    """Tables of the closing launches of BOTH directions of a RowIndex, queued back to back: the fold tables
-    (dn_fold_tables_build_async_i32 leaves its verdict on the device) and, per direction, either the slot table
-    (kind "slots": dn_rows_selfsum_bf16) or the unit stream (kind "units": dn_rows_close_bf16, H = 256) -- both builders read the
-    verdict on the device to decide whether the folded relation's rows are left out.  The host reads the two verdicts in ONE copy
-    (it picks the launch sequence by them).  A second kind on the same index reuses the verdicts."""
+    """Tables of the closing launches of BOTH directions of a RowIndex.  First call: the fold tables of both directions are queued
+    (dn_fold_tables_build_async_i32; for the unit stream also dn_fold_graph_tiles_build_i32: are the graphs small enough for the
+    ABSORBED fold?), every builder leaves its verdict on the device and the host reads them all in ONE copy (it picks the launch
+    sequence by them).  kind "slots" (dn_rows_selfsum_bf16): the slot tables are queued in front of that copy, reading the verdict
+    on the device; kind "units" (dn_rows_close_bf16, H = 256): the unit streams are built behind it (their tiles depend on the
+    verdicts).  A second kind on the same index reuses the verdicts."""
     have = ix._slots if kind == "slots" else ix._units
     if have:
         return
     N, P, dev, K = ix.num_nodes, ix.num_edge_rows, ix.row_in.device, SELFSUM_SLOTS
     first = not ix._fold
-    flags = torch.zeros(2, dtype=I32, device=dev) if first else None   # [ok_f, ok_b]: verdicts of the two fold-table builds
-    work = {}
-    for k, direction in enumerate(("f", "b")):
-        cand = fold_info = part_ptr = drop_enable = None
-        drop = (0, 0)
-        if first:
+    lists = {d: tuple(t.to(I32).contiguous() for t in ((ix.dst_ptr, ix.dst_rows) if d == "f" else (ix.src_ptr, ix.src_rows)))
+             for d in ("f", "b")}
+    work, flags = {}, None
+    if first:
+        flags = torch.zeros(4, dtype=I32, device=dev)                # [ok_f, ok_b, graph_tiles_f, graph_tiles_b]
+        for k, direction in enumerate(("f", "b")):
             cand = _fold_candidate(ix, direction)
+            fold_info = part_ptr = gt = None
             if cand is not None:
                 aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
                 fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
@@ -1248,20 +1287,23 @@ def _closing_tables(ix, kind="slots"):
                 check(lib().dn_fold_tables_build_async_i32(N, cand[3], ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
                                                            ptr(flags[k:]), ptr(ws), ws.numel(), stream_ptr()),
                       "dn_fold_tables_build_async_i32")
-                drop, drop_enable = (cand[1], cand[2]), flags[k:]
-        elif ix._fold[direction] is not None:
-            drop = (ix._fold[direction].beg, ix._fold[direction].end)
-        ptr_, rows = (ix.dst_ptr, ix.dst_rows) if direction == "f" else (ix.src_ptr, ix.src_rows)
-        ptr_, rows = ptr_.to(I32).contiguous(), rows.to(I32).contiguous()
-        if kind == "slots":
-            tab = build_slot_table(ptr_, rows, N, P, K, drop=drop, drop_enable=drop_enable)
-        else:
-            tab = build_close_units(ptr_, rows, N, P, drop=drop, drop_enable=drop_enable)
-        work[direction] = (cand, fold_info, part_ptr, tab, ptr_, rows)
-    h = flags.cpu().tolist() if first else None                     # the one synchronisation: the two fold verdicts
-    for k, direction in enumerate(("f", "b")):
-        cand, fold_info, part_ptr, tab, ptr_, rows = work[direction]
-        if first:
+                if kind == "units" and CLOSE_AGG_ENABLED:
+                    gt = build_graph_tiles(aux_ptr[:cand[3] + 1].contiguous(), aux_idx, N, ok=flags[2 + k:])
+            work[direction] = (cand, fold_info, part_ptr, gt)
+    if kind == "slots":
+        tabs = {}
+        for k, direction in enumerate(("f", "b")):
+            if first:
+                cand = work[direction][0]
+                drop, enable = ((cand[1], cand[2]), flags[k:]) if cand is not None else ((0, 0), None)
+            else:
+                info = ix._fold[direction]
+                drop, enable = ((info.beg, info.end) if info is not None else (0, 0)), None
+            tabs[direction] = build_slot_table(*lists[direction], N, P, K, drop=drop, drop_enable=enable)
+    if first:
+        h = flags.cpu().tolist()                                     # the one synchronisation: the verdicts
+        for k, direction in enumerate(("f", "b")):
+            cand, fold_info, part_ptr, gt = work[direction]
             info = None
             if cand is not None and h[k] != 0:
                 r, beg, end, n_aux = cand
@@ -1273,14 +1315,18 @@ def _closing_tables(ix, kind="slots"):
                 info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
                 info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
                 info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+                info.graph_tiles = (gt[0], gt[1]) if (gt is not None and h[2 + k] != 0) else None
             ix._fold[direction] = info
+    for direction in ("f", "b"):
         info = ix._fold[direction]
         drop = (info.beg, info.end) if info is not None else (0, 0)
         if kind == "slots":
-            slots, over = tab
-            ix._slots[direction] = (slots, (ptr_, rows, P, drop[0], drop[1], over))
+            slots, over = tabs[direction]
+            ix._slots[direction] = (slots, (*lists[direction], P, drop[0], drop[1], over))
+        elif info is not None and info.graph_tiles is not None:     # every graph inside one tile: the fold is absorbed
+            ix._units[direction] = build_close_units(*lists[direction], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
         else:
-            ix._units[direction] = tab
+            ix._units[direction] = build_close_units(*lists[direction], N, P, drop=drop)
 
 
 def _row_index_slots(ix, direction):
@@ -1309,7 +1355,8 @@ FOLD_ENABLED = _os.environ.get("DN_FOLD", "1") != "0"
 
 class _Fold:
     """Tables of one folded relation: rows [beg, end) of the row set, one per segment (graph)."""
-    __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "sweep_tiles", "add_idx")
+    __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "sweep_tiles", "add_idx",
+                 "graph_tiles")
 
 
 def _row_index_fold(ix, direction, kind="slots"):
@@ -1415,10 +1462,18 @@ def _closing_launch(xs, W_loop, bias, Y, ix, direction, out, seg=None, w_kn=Fals
 def _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows):
     """message_pass with the collapsed relation's pre-aggregation absorbed by the closing launch: transform of every other
     relation -> closing launch (+ per-graph column sums of xs) -> tail launch (combine the sums, transform the one row per graph,
-    add each product to its node).  Same sums as the unfolded path up to bf16 rounding of the collapsed rows."""
-    fold = _row_index_fold(ix, direction, _close_kind(xs))
+    add each product to its node).  Where every graph fits one tile of the unit stream (H = 256) the closing launch does the
+    tail's work itself (its AGG units): two launches per direction.  Same sums as the unfolded path up to bf16 rounding of the
+    collapsed rows."""
+    kind = _close_kind(xs)
+    fold = _row_index_fold(ix, direction, kind)
     P, H = ix.num_edge_rows, xs.shape[1]
     Y = rows_transform(xs, pw.rel, _conv_tiles(ix, fold, xs), P, idx=idx_rows, tag="conv", out=ybuf, w_kn=pw.kn)
+    if kind == "units" and ix.close_units(direction).agg:
+        aux = torch.empty((fold.n, H), dtype=xs.dtype, device=xs.device)
+        rows_close(xs, pw.loop, bias, Y[:P], ix.close_units(direction), out=out, w_kn=pw.kn,
+                   agg=(fold.graph_tiles[1], pw.rel[fold.rel], aux, fold.add_idx))
+        return aux
     part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=xs.device)
     _closing_launch(xs, pw.loop, bias, Y[:P], ix, direction, out, seg=(fold.fold_info, part), w_kn=pw.kn)
     return fold_tail(part, fold.part_ptr, fold.n, pw.rel[fold.rel], fold.add_idx, out, w_kn=pw.kn)

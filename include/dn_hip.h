@@ -382,30 +382,48 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * subgraph_isomorphism/models/rgin.py:137-146 / rgcn.py:166-182; backward direction: the same for the input gradient).
  *
  * dn_close_units_build_i32 (one-shot index build per batch and direction, three launches, no host synchronisation; the
- * bookkeeping dgl.batch + update_all do per step, subgraph_isomorphism/dataset.py:1605-1611): nodes are cut into tiles of 32;
- * for every tile the DISTINCT kept rows of its nodes' lists (list_ptr [N+1] / list_rows as in dn_slot_table_build_i32, same
- * num_edge_rows / drop range / drop_enable filter) are written to ent_row with a 32-bit membership mask in ent_mask (bit i: node
- * 32 t + i adds the row; a row that ONE node lists twice stays a second entry), at the offset list_ptr[32 t] onwards -- so
- * ent_row / ent_mask need num_list_entries elements.  units [unit_capacity][4] int32 records {flags, beg, end, aux} in
- * WORKGROUP-MAJOR order (workgroup w of num_wg takes tiles w, w + num_wg, ...; its records are units[unit_ptr[w] .. unit_ptr[w+1])):
- * per tile one X record {0 | 2 if no entries, first node, end node, tile} followed by one record per 32 entries
- * {1 | 2 on the last, first entry, end entry, first node}.  unit_capacity >= dn_close_units_capacity(N, num_list_entries).
+ * bookkeeping dgl.batch + update_all do per step, subgraph_isomorphism/dataset.py:1605-1611): nodes are cut into num_tiles
+ * tiles of at most 32 -- tile t = nodes [tile_ptr[t], tile_ptr[t+1]) (device, [num_tiles + 1]), or the 32-node windows when
+ * tile_ptr == NULL (num_tiles = ceil(N / 32)).  For every tile the DISTINCT kept rows of its nodes' lists (list_ptr [N+1] /
+ * list_rows as in dn_slot_table_build_i32, same num_edge_rows / drop range / drop_enable filter), sorted by row, are written to
+ * ent_row with a 32-bit membership mask in ent_mask (bit i: node tile_ptr[t] + i adds the row; a row that ONE node lists twice
+ * stays a second entry), from the offset list_ptr[tile_ptr[t]] onwards -- so ent_row / ent_mask need num_list_entries elements.
+ * units [unit_capacity][4] int32 records {flags, beg, end, aux} in WORKGROUP-MAJOR order (workgroup w of num_wg takes tiles w,
+ * w + num_wg, ...; its records are units[unit_ptr[w] .. unit_ptr[w+1])): per tile one X record {rows << 8 | 2 if no entries,
+ * first node, end node, tile} followed by one record per 32 entries {rows << 8 | 1 | 2 on the last, first entry, end entry, first
+ * node}; with agg_units != 0 a workgroup's tiles are followed by 8 records {8, 0, 1, 0} (a gap) and one record {4 | 2, n, n', 0}
+ * per 32 of its tiles (the n-th .. n'-th of them): the AGG units of the absorbed fold below.
+ * unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg).
+ *
+ * dn_fold_graph_tiles_build_i32 (one launch): the tiles of a batch of GRAPHS for the absorbed fold.  Segment j = the nodes
+ * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) as in dn_fold_tables_build_i32; block j = [first node of segment j (0 for j = 0), first
+ * node of segment j + 1 (N for the last)).  *dev_ok (device) stays non-zero when every segment is a non-empty contiguous
+ * ascending run, the segments ascend and every block has at most 32 nodes; then tile_ptr [num_segments + 1] = the block starts
+ * (tile j = block j) and fold_info [num_segments][12] = per tile {32 bytes: 0 for a node of the segment, 255 otherwise; j; 1; 0; 0}.
  *
  * dn_rows_close_bf16: one persistent workgroup per entry of unit_ptr (launch num_wg = the builder's).  W: the self-loop weight,
  * w_kn = 0: [H][H] with k contiguous (W_loop transposed, as dn_rows_selfsum_bf16 takes it), w_kn = 1: [k][n] as the
- * parameter stores it (`loop_weight`, rgin.py:61) -- no transposed copy needed.  bias may be NULL.  fold_info / seg_part: the
- * folded pre-aggregation exactly as in dn_rows_selfsum_bf16.  A non-finite element of S turns its column of the whole 32-node
- * tile into NaN (0 x Inf inside the selection product).  H must be 256. */
-int64_t dn_close_units_capacity(int64_t N, int64_t num_list_entries);
-size_t dn_close_units_workspace_bytes(int64_t N, int32_t num_wg);
-int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* list_ptr, const int32_t* list_rows,
-                             int64_t num_list_entries, int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable,
-                             int32_t* unit_ptr, int32_t* units, int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask,
-                             void* workspace, size_t workspace_bytes, dn_stream_t stream);
+ * parameter stores it (`loop_weight`, rgin.py:61) -- no transposed copy needed.  bias may be NULL.  fold_info + seg_part: the
+ * folded pre-aggregation exactly as in dn_rows_selfsum_bf16 (fp32 partial rows, finished by dn_fold_tail_bf16).
+ * fold_info + W_agg + aux + agg_idx (seg_part NULL; tables built with tile_ptr / agg_units from dn_fold_graph_tiles_build_i32):
+ * the ABSORBED fold -- every segment lies inside one tile, so its column sum leaves as the bf16 row aux[segment] (kept by the
+ * caller: the collapsed relation's operand of dn_rows_wgrad_bf16), and the workgroup's AGG units multiply its segments' aux rows
+ * by W_agg (same layout flag as W) and add each product to out[agg_idx[segment]] -- what dn_fold_tail_bf16 does, inside this
+ * launch.  A non-finite element of S turns its column of the whole tile into NaN (0 x Inf inside the selection product).
+ * H must be 256. */
+int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg);
+size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg);
+int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
+                             int32_t agg_units, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
+                             int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
+                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
+                             dn_stream_t stream);
+int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                                  int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok, dn_stream_t stream);
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
-                       dn_stream_t stream);
+                       const void* W_agg, void* aux, const int32_t* agg_idx, dn_stream_t stream);
 
 /* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph

@@ -5,13 +5,44 @@ import numpy as np
 DEDUP_CAP = 256          # kCbCap in csrc/dn_close.hip: tiles with more raw list entries are listed without merging
 
 
-def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0)):
+AGG_GAP = 8              # kAggGap: NOP units between a workgroup's tiles and its AGG units
+
+
+def graph_tiles_ref(seg_ptr, seg_nodes, N):
+    """dn_fold_graph_tiles_build_i32: -> (ok, tile_ptr [S+1], fold_info [S,12] int32)."""
+    sp, sn = np.asarray(seg_ptr, dtype=np.int64), np.asarray(seg_nodes, dtype=np.int64)
+    S = len(sp) - 1
+    firsts, lasts = [], []
+    for j in range(S):
+        nodes = sn[sp[j]:sp[j + 1]]
+        if len(nodes) == 0 or np.any(np.diff(nodes) != 1) or nodes[0] < 0 or nodes[-1] >= N:
+            return False, None, None
+        firsts.append(int(nodes[0])); lasts.append(int(nodes[-1]))
+    tile_ptr = np.zeros(S + 1, dtype=np.int64)
+    info = np.zeros((S, 12), dtype=np.int32)
+    for j in range(S):
+        b0 = 0 if j == 0 else firsts[j]
+        nxt = firsts[j + 1] if j + 1 < S else N
+        if j + 1 < S and nxt <= lasts[j]:
+            return False, None, None
+        if not (1 <= nxt - b0 <= 32):
+            return False, None, None
+        tile_ptr[j] = b0
+        ids = np.array([0 if firsts[j] <= b0 + i <= lasts[j] else 255 for i in range(32)], dtype=np.uint8)
+        info[j, :8] = ids.view(np.int32)
+        info[j, 8], info[j, 9] = j, 1
+    tile_ptr[S] = N
+    return True, tile_ptr, info
+
+
+def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False):
     """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])})."""
     lp, lr = np.asarray(list_ptr, dtype=np.int64), np.asarray(list_rows, dtype=np.int64)
-    T = (N + 31) // 32
+    T = (N + 31) // 32 if tile_ptr is None else len(tile_ptr) - 1
+    tp = np.minimum(np.arange(T + 1) * 32, N) if tile_ptr is None else np.asarray(tile_ptr, dtype=np.int64)
     tiles = {}
     for t in range(T):
-        p0, pend = 32 * t, min(32 * t + 32, N)
+        p0, pend = int(tp[t]), int(min(tp[t + 1], tp[t] + 32))
         kept = []
         for v in range(p0, pend):
             kept.append([int(r) for r in lr[lp[v]:lp[v + 1]] if r < P and not (drop[0] <= r < drop[1])])
@@ -42,15 +73,20 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0)):
     Tper = (T + G - 1) // G if T else 0
     unit_ptr, units = [0], []
     for w in range(G):
+        nw = 0
         for n in range(Tper):
             t = n * G + w
             if t >= T:
                 continue
+            nw += 1
             e0, ent_r, _ = tiles[t]
-            c, p0, pend = len(ent_r), 32 * t, min(32 * t + 32, N)
-            ne = (c + 31) // 32
-            units.append([2 if ne == 0 else 0, p0, pend, t])
+            c, p0, pend = len(ent_r), int(tp[t]), int(min(tp[t + 1], tp[t] + 32))
+            ne, rows = (c + 31) // 32, (pend - p0) << 8
+            units.append([(2 if ne == 0 else 0) | rows, p0, pend, t])
             for i in range(ne):
-                units.append([1 | (2 if i == ne - 1 else 0), e0 + 32 * i, e0 + min(32 * (i + 1), c), p0])
+                units.append([1 | (2 if i == ne - 1 else 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), c), p0])
+        if agg and nw:
+            units += [[8, 0, 1, 0]] * AGG_GAP
+            units += [[4 | 2, 32 * i, min(32 * (i + 1), nw), 0] for i in range((nw + 31) // 32)]
         unit_ptr.append(len(units))
     return np.array(unit_ptr, dtype=np.int64), np.array(units, dtype=np.int64).reshape(-1, 4), tiles

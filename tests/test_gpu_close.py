@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from close_ref import close_units_ref
+from close_ref import close_units_ref, graph_tiles_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -166,3 +166,69 @@ def test_parameter_layout_weights_give_the_same_bits_as_the_transposed_copy():
     W64 = bf(rng.standard_normal((1, 64, 64)))
     with pytest.raises((DnHipError, AssertionError)):
         ops.rows_transform(X[:, :64].contiguous(), W64, ops.make_row_tiles([0, 100], torch.device(DEV)), 100, w_kn=True)
+
+
+def _graph_batch(rng, sizes, P):
+    """Graphs of `size` real nodes + one dummy node each; lists as the row index emits them; the segment of a graph = its real nodes."""
+    lists, seg_ptr, seg_nodes, dummies, base = [], [0], [], [], 0
+    for n in sizes:
+        for v in range(n + 1):
+            c = int(rng.poisson(2.0)) if v < n else 1
+            lists.append(np.append(np.sort(rng.integers(0, P, size=c)), P + base + v))
+        seg_nodes += list(range(base, base + n))
+        seg_ptr.append(len(seg_nodes))
+        dummies.append(base + n)
+        base += n + 1
+    ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    return lists, ptr, np.concatenate(lists), np.array(seg_ptr), np.array(seg_nodes), np.array(dummies), base
+
+
+@pytest.mark.parametrize("G", [256, 5, 1])
+@pytest.mark.parametrize("sizes_kind", ["config5", "mixed"])
+def test_absorbed_fold_tables_and_launch(sizes_kind, G):
+    """Every graph inside one tile: dn_fold_graph_tiles_build_i32 + the unit tables with AGG units against the host restatement,
+    and the launch -- out = x W_loop + b + list rows, aux[j] = bf16 column sum of graph j's real nodes, out[dummy_j] += aux[j] W_agg
+    -- against fp64 (what dn_rows_close_bf16 + dn_fold_tail_bf16 compute in two launches)."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(G + len(sizes_kind))
+    sizes = [30] * 300 if sizes_kind == "config5" else list(rng.integers(1, 32, size=260)) + [31, 31, 1, 1]
+    H, P = 256, 4000
+    lists, ptr, rows, seg_ptr, seg_nodes, dummies, N = _graph_batch(rng, sizes, P)
+    S = len(sizes)
+    sp, sn = torch.from_numpy(seg_ptr).to(DEV).int(), torch.from_numpy(seg_nodes).to(DEV).int()
+    tile_ptr, info, ok = ops.build_graph_tiles(sp, sn, N)
+    okr, tpr, infor = graph_tiles_ref(seg_ptr, seg_nodes, N)
+    assert okr and int(ok.item()) != 0
+    assert np.array_equal(tile_ptr.cpu().numpy(), tpr) and np.array_equal(info.cpu().numpy(), infor)
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True)
+    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True)
+    assert np.array_equal(cu.unit_ptr.cpu().numpy(), up)
+    assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
+    er, em = cu.ent_row.cpu().numpy(), cu.ent_mask.cpu().numpy().view(np.uint32)
+    for t, (e0, r, m) in tiles.items():
+        assert list(er[e0:e0 + len(r)]) == r and list(em[e0:e0 + len(r)]) == m, t
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, Y = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((P, H)))
+    W, Wa = bf(rng.standard_normal((H, H)) / np.sqrt(H)), bf(rng.standard_normal((H, H)) / np.sqrt(H))
+    b = bf(rng.standard_normal(H))
+    tgt = torch.from_numpy(dummies).to(DEV).int()
+    for w_kn in (True, False):
+        aux = torch.empty((S, H), dtype=torch.bfloat16, device=DEV)
+        Wd, Wad = (W.to(DEV), Wa.to(DEV)) if w_kn else (W.t().contiguous().to(DEV), Wa.t().contiguous().to(DEV))
+        out = ops.rows_close(x.to(DEV), Wd, b.to(DEV), Y.to(DEV), cu, w_kn=w_kn, agg=(info, Wad, aux, tgt))
+        aux_ref = torch.stack([x[seg_nodes[seg_ptr[j]:seg_ptr[j + 1]]].double().sum(0) for j in range(S)])
+        assert float((aux.cpu().double() - aux_ref).abs().max() / aux_ref.abs().max()) < 5e-3
+        ref = _ref_close(x, W, b, Y, lists, P)
+        ref[dummies] += aux.cpu().double() @ Wa.double()                         # (the launch multiplies its own rounded aux rows)
+        err = (out.cpu().double() - ref).abs() / (ref.abs() + 1.0)
+        real = np.setdiff1d(np.arange(N), dummies)
+        assert float(err[real].max()) < 8e-3, (w_kn, float(err[real].max()))
+        # a dummy node's row is rounded to bf16 twice (stored, then re-read by its AGG unit: as dn_fold_tail_bf16 does): the error
+        # is relative to the two terms, not to their (possibly cancelling) sum
+        prod = (aux.cpu().double() @ Wa.double()).abs()
+        errd = (out.cpu().double() - ref)[dummies].abs() / (ref[dummies].abs() + prod + 1.0)
+        assert float(errd.max()) < 8e-3, (w_kn, float(errd.max()))
+    # a graph over 32 nodes: the verdict is "no" and the caller keeps the partial rows + tail
+    big_ptr, big_nodes = torch.tensor([0, 40], device=DEV, dtype=torch.int32), torch.arange(40, device=DEV, dtype=torch.int32)
+    assert int(ops.build_graph_tiles(big_ptr, big_nodes, 41)[2].item()) == 0
