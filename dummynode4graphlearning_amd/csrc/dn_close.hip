@@ -30,6 +30,11 @@
 #include "dn_internal.h"
 #include "../../include/dn_hip.h"
 
+#include <cstring>
+#include <cstdlib>
+
+#include <rocprim/rocprim.hpp>
+
 namespace {
 
 typedef __bf16 bf16_t;
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
                                                                       const int32_t* __restrict__ lrows, int32_t drop_beg,
                                                                       int32_t drop_end, const int32_t* __restrict__ drop_enable,
                                                                       int32_t* __restrict__ ent_row, uint32_t* __restrict__ ent_mask,
-                                                                      int32_t* __restrict__ tile_cnt) {
+                                                                      int32_t* __restrict__ tile_cnt, int32_t G, int32_t Tper,
+                                                                      int32_t agg, int32_t* __restrict__ ucnt) {
     __shared__ __attribute__((aligned(16))) CbLds Ls[kCbWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (int)blockIdx.x * kCbWaves + wave;
@@ -98,6 +104,9 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     const int pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N), nn = pend - p0;   // (a tile never has more than 32 nodes)
     const int lb = lptr[p0], raw = lptr[pend] - lb;
     auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
+    // units of this tile in the workgroup-major table: one X unit + one per 32 entries; a workgroup's LAST tile (t + G >= T) also
+    // carries the workgroup's NOP gap and AGG units (one per 32 of its t / G + 1 tiles)
+    auto units_of = [&](int c) { return 1 + (c + 31) / 32 + ((agg && t + G >= T) ? kAggGap + (t / G + 1 + 31) / 32 : 0); };
     bool plain = raw > kCbCap;
     if (!plain) {
         const int my0 = lane <= nn ? lptr[p0 + lane] - lb : raw;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
                 ent_row[lb + rank] = (int32_t)ri;
                 ent_mask[lb + rank] = L.smask[i];
             }
-            if (lane == 0) tile_cnt[t] = n;
+            if (lane == 0) { tile_cnt[t] = n; ucnt[(int64_t)(t % G) * Tper + t / G] = units_of(n); }
             return;
         }
     }
@@ -191,52 +200,18 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
         if (!kept(r)) continue;
         ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
     }
-    if (lane == 0) tile_cnt[t] = total;
+    if (lane == 0) { tile_cnt[t] = total; ucnt[(int64_t)(t % G) * Tper + t / G] = units_of(total); }
 }
 
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
-// as one stream); position k' = w * Tper + n holds tile n * G + w.  One workgroup scans the G * Tper unit counts.
-__global__ __launch_bounds__(1024) void close_scan_kernel(int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_cnt,
-                                                          int32_t agg, int32_t* __restrict__ uoff, int32_t* __restrict__ unit_ptr) {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t M = (int64_t)G * Tper;
-    const int64_t per = (M + 1023) / 1024;
-    const int64_t k0 = min((int64_t)tid * per, M), k1 = min(k0 + per, M);
-    // with agg: workgroup w's tiles are followed by kAggGap NOP units and one AGG unit per 32 of its tiles; they are counted at
-    // the workgroup's LAST position (k % Tper == Tper - 1)
-    auto units_at = [&](int64_t k) -> int32_t {
-        const int64_t w = k / Tper, n = k % Tper, tl = n * G + w;
-        int32_t u = tl < T ? 1 + (tile_cnt[tl] + 31) / 32 : 0;
-        if (agg && n == Tper - 1) {
-            const int64_t nw = w < T ? (T - w + G - 1) / G : 0;           // tiles of workgroup w
-            if (nw > 0) u += kAggGap + (int32_t)((nw + 31) / 32);
-        }
-        return u;
-    };
-    int32_t s = 0;
-    for (int64_t k = k0; k < k1; ++k) s += units_at(k);
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                                   // Hillis-Steele over the 1024 partial sums
-        const int32_t o = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += o;
-        __syncthreads();
-    }
-    int32_t run = part[tid] - s;
-    for (int64_t k = k0; k < k1; ++k) {
-        uoff[k] = run;
-        if (k % Tper == 0) unit_ptr[k / Tper] = run;
-        run += units_at(k);
-    }
-    if (tid == 1023) { uoff[M] = part[1023]; unit_ptr[G] = part[1023]; }
-}
-
+// as one stream); position k' = w * Tper + n holds tile n * G + w.  The entries kernel leaves each tile's unit count there, one
+// exclusive scan (rocPRIM) gives the offsets.
 __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_ptr,
                                   const int32_t* __restrict__ lptr, const int32_t* __restrict__ tile_cnt,
-                                  const int32_t* __restrict__ uoff, int32_t agg, Unit* __restrict__ units) {
+                                  const int32_t* __restrict__ uoff, int32_t agg, Unit* __restrict__ units,
+                                  int32_t* __restrict__ unit_ptr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= G) unit_ptr[t] = uoff[t * Tper];                             // (position G * Tper holds the total)
     if (t >= T) return;
     const int64_t w = t % G, n = t / G, k = w * Tper + n;
     const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
@@ -776,8 +751,11 @@ int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int
 
 size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
     if (num_tiles < 0 || num_wg <= 0) { dn_set_error("dn_close_units_workspace_bytes: bad sizes"); return 0; }
-    const int64_t Tper = dn_cdiv(num_tiles, num_wg);
-    return (size_t)(num_tiles + 1) * 4 + (size_t)((int64_t)num_wg * Tper + 1) * 4 + 512;
+    const int64_t M = (int64_t)num_wg * dn_cdiv(num_tiles, num_wg);
+    size_t tb = 0;
+    if (rocprim::exclusive_scan(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(),
+                                (hipStream_t)nullptr) != hipSuccess) { dn_set_error("rocprim scan size query failed"); return 0; }
+    return dn_align_up((size_t)(num_tiles + 1) * 4, 256) + 2 * dn_align_up((size_t)(M + 1) * 4, 256) + dn_align_up(tb, 256) + 512;
 }
 
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
@@ -795,18 +773,29 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
     DN_REQUIRE(list_ptr && list_rows && units && ent_row && ent_mask && workspace, "dn_close_units_build: NULL pointer");
     DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
     DN_REQUIRE(workspace_bytes >= dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
-    DN_REQUIRE(reinterpret_cast<uintptr_t>(units) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 4 == 0,
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(units) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
                "dn_close_units_build: unaligned pointer");
     const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
-    int32_t* tile_cnt = reinterpret_cast<int32_t*>(workspace);
-    int32_t* uoff = tile_cnt + T + 1;
+    const int64_t M = (int64_t)num_wg * Tper;
+    char* wsp = reinterpret_cast<char*>(workspace);
+    int32_t* tile_cnt = reinterpret_cast<int32_t*>(wsp);
+    wsp += dn_align_up((size_t)(T + 1) * 4, 256);
+    int32_t* ucnt = reinterpret_cast<int32_t*>(wsp);
+    wsp += dn_align_up((size_t)(M + 1) * 4, 256);
+    int32_t* uoff = reinterpret_cast<int32_t*>(wsp);
+    wsp += dn_align_up((size_t)(M + 1) * 4, 256);
+    size_t tb = 0;
+    DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
+    if (M + 1 != T)                                                        // positions without a tile (T not a multiple of num_wg) and the total's slot
+        DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, (size_t)(M + 1) * 4, st));
     hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,
-                       T, tile_ptr, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt);
+                       T, tile_ptr, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt, num_wg, Tper,
+                       agg_units ? 1 : 0, ucnt);
     DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(close_scan_kernel, dim3(1), dim3(1024), 0, st, T, num_wg, Tper, tile_cnt, agg_units ? 1 : 0, uoff, unit_ptr);
-    DN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(T, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, tile_ptr,
-                       list_ptr, tile_cnt, uoff, agg_units ? 1 : 0, reinterpret_cast<Unit*>(units));
+    DN_CHECK_HIP(rocprim::exclusive_scan(wsp, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
+    const int64_t nthreads = T > num_wg + 1 ? T : num_wg + 1;
+    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(nthreads, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, tile_ptr,
+                       list_ptr, tile_cnt, uoff, agg_units ? 1 : 0, reinterpret_cast<Unit*>(units), unit_ptr);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

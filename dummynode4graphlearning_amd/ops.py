@@ -1259,13 +1259,27 @@ def _fold_candidate(ix, direction):
 CLOSE_AGG_ENABLED = _os.environ.get("DN_CLOSE_AGG", "1") != "0"
 
 
+def _queue_fold_tables(ix, direction, n_aux, flag):
+    """dn_fold_tables_build_async_i32 for one direction (32-node tiles, fp32 partial rows): -> (fold_info, part_ptr); verdict in flag."""
+    N, dev = ix.num_nodes, ix.row_in.device
+    aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+    fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
+    part_ptr = torch.empty(n_aux + 1, dtype=I32, device=dev)
+    ws = _ws(lib().dn_fold_tables_workspace_bytes(n_aux), dev)
+    check(lib().dn_fold_tables_build_async_i32(N, n_aux, ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr), ptr(flag),
+                                               ptr(ws), ws.numel(), stream_ptr()), "dn_fold_tables_build_async_i32")
+    return fold_info, part_ptr
+
+
 def _closing_tables(ix, kind="slots"):
-    """Tables of the closing launches of BOTH directions of a RowIndex.  First call: the fold tables of both directions are queued
-    (dn_fold_tables_build_async_i32; for the unit stream also dn_fold_graph_tiles_build_i32: are the graphs small enough for the
-    ABSORBED fold?), every builder leaves its verdict on the device and the host reads them all in ONE copy (it picks the launch
-    sequence by them).  kind "slots" (dn_rows_selfsum_bf16): the slot tables are queued in front of that copy, reading the verdict
-    on the device; kind "units" (dn_rows_close_bf16, H = 256): the unit streams are built behind it (their tiles depend on the
-    verdicts).  A second kind on the same index reuses the verdicts."""
+    """Tables of the closing launches of BOTH directions of a RowIndex.  Every builder leaves its verdict on the device; the host
+    reads the verdicts of both directions in ONE copy (it picks the launch sequence by them).
+      kind "units" (dn_rows_close_bf16, H = 256): first dn_fold_graph_tiles_build_i32 -- are the graphs small enough for the
+        ABSORBED fold? -- one copy; only a direction that fails gets the 32-node-tile fold tables (dn_fold_tables_build_async_i32)
+        and a second copy.  The unit streams are built behind the verdicts (their tiles depend on them).
+      kind "slots" (dn_rows_selfsum_bf16): the fold tables and the slot tables (which read the verdict on the device) are queued
+        in front of the one copy.
+    A second kind on the same index reuses the verdicts and builds only what it misses."""
     have = ix._slots if kind == "slots" else ix._units
     if have:
         return
@@ -1273,60 +1287,72 @@ def _closing_tables(ix, kind="slots"):
     first = not ix._fold
     lists = {d: tuple(t.to(I32).contiguous() for t in ((ix.dst_ptr, ix.dst_rows) if d == "f" else (ix.src_ptr, ix.src_rows)))
              for d in ("f", "b")}
-    work, flags = {}, None
+    dirs = ("f", "b")
+
+    def make_info(direction, cand):
+        r, beg, end, n_aux = cand
+        info = _Fold()
+        info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
+        info.fold_info = info.part_ptr = info.graph_tiles = None
+        info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment starts
+        #                                                    one partial row, every tile boundary inside one another
+        info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+        info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
+        info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+        return info
+
+    tabs = {}
     if first:
-        flags = torch.zeros(4, dtype=I32, device=dev)                # [ok_f, ok_b, graph_tiles_f, graph_tiles_b]
-        for k, direction in enumerate(("f", "b")):
-            cand = _fold_candidate(ix, direction)
-            fold_info = part_ptr = gt = None
-            if cand is not None:
-                aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
-                fold_info = torch.empty(((N + 31) // 32, 12), dtype=I32, device=dev)
-                part_ptr = torch.empty(cand[3] + 1, dtype=I32, device=dev)
-                ws = _ws(lib().dn_fold_tables_workspace_bytes(cand[3]), dev)
-                check(lib().dn_fold_tables_build_async_i32(N, cand[3], ptr(aux_ptr), ptr(aux_idx), ptr(fold_info), ptr(part_ptr),
-                                                           ptr(flags[k:]), ptr(ws), ws.numel(), stream_ptr()),
-                      "dn_fold_tables_build_async_i32")
-                if kind == "units" and CLOSE_AGG_ENABLED:
-                    gt = build_graph_tiles(aux_ptr[:cand[3] + 1].contiguous(), aux_idx, N, ok=flags[2 + k:])
-            work[direction] = (cand, fold_info, part_ptr, gt)
-    if kind == "slots":
-        tabs = {}
-        for k, direction in enumerate(("f", "b")):
-            if first:
-                cand = work[direction][0]
-                drop, enable = ((cand[1], cand[2]), flags[k:]) if cand is not None else ((0, 0), None)
-            else:
-                info = ix._fold[direction]
-                drop, enable = ((info.beg, info.end) if info is not None else (0, 0)), None
-            tabs[direction] = build_slot_table(*lists[direction], N, P, K, drop=drop, drop_enable=enable)
-    if first:
-        h = flags.cpu().tolist()                                     # the one synchronisation: the verdicts
-        for k, direction in enumerate(("f", "b")):
-            cand, fold_info, part_ptr, gt = work[direction]
+        cands = {d: _fold_candidate(ix, d) for d in dirs}
+        flags = torch.zeros(4, dtype=I32, device=dev)                # [parts_f, parts_b, graph_tiles_f, graph_tiles_b]
+        gts, parts = {}, {}
+        h = hp = [0, 0, 0, 0]
+        if kind == "units" and CLOSE_AGG_ENABLED:
+            for k, d in enumerate(dirs):
+                if cands[d] is not None:
+                    aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if d == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+                    gts[d] = build_graph_tiles(aux_ptr[:cands[d][3] + 1].contiguous(), aux_idx, N, ok=flags[2 + k:])
+            if gts:
+                h = flags.cpu().tolist()                             # synchronisation 1: can the fold be absorbed?
+        need_parts = [d for k, d in enumerate(dirs) if cands[d] is not None and h[2 + k] == 0]
+        for d in need_parts:
+            parts[d] = _queue_fold_tables(ix, d, cands[d][3], flags[dirs.index(d):])
+        if kind == "slots":
+            for k, d in enumerate(dirs):
+                drop, enable = ((cands[d][1], cands[d][2]), flags[k:]) if cands[d] is not None else ((0, 0), None)
+                tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop, drop_enable=enable)
+        if need_parts:
+            hp = flags.cpu().tolist()                                # synchronisation 2 (the only one for kind "slots")
+        for k, d in enumerate(dirs):
             info = None
-            if cand is not None and h[k] != 0:
-                r, beg, end, n_aux = cand
-                info = _Fold()
-                info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-                info.fold_info, info.part_ptr = fold_info, part_ptr
-                info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment
-                #                                                    starts one partial row, every tile boundary inside one another
-                info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
-                info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
-                info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
-                info.graph_tiles = (gt[0], gt[1]) if (gt is not None and h[2 + k] != 0) else None
-            ix._fold[direction] = info
-    for direction in ("f", "b"):
-        info = ix._fold[direction]
+            if cands[d] is not None and h[2 + k] != 0:
+                info = make_info(d, cands[d])
+                info.graph_tiles = (gts[d][0], gts[d][1])
+            elif cands[d] is not None and hp[k] != 0:
+                info = make_info(d, cands[d])
+                info.fold_info, info.part_ptr = parts[d]
+            ix._fold[d] = info
+    elif kind == "slots":
+        for d in dirs:
+            info = ix._fold[d]
+            if info is not None and info.fold_info is None:          # absorbed so far: the slot kernel needs the partial-row tables
+                flag = torch.zeros(1, dtype=I32, device=dev)         # (valid whenever the graph tiles were: same contiguity test)
+                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, flag)
+            drop = (info.beg, info.end) if info is not None else (0, 0)
+            tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop)
+    for d in dirs:
+        info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
         if kind == "slots":
-            slots, over = tabs[direction]
-            ix._slots[direction] = (slots, (*lists[direction], P, drop[0], drop[1], over))
+            slots, over = tabs[d]
+            ix._slots[d] = (slots, (*lists[d], P, drop[0], drop[1], over))
         elif info is not None and info.graph_tiles is not None:     # every graph inside one tile: the fold is absorbed
-            ix._units[direction] = build_close_units(*lists[direction], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
+            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
         else:
-            ix._units[direction] = build_close_units(*lists[direction], N, P, drop=drop)
+            if info is not None and info.fold_info is None:
+                flag = torch.zeros(1, dtype=I32, device=dev)
+                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, flag)
+            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop)
 
 
 def _row_index_slots(ix, direction):

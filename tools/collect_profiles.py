@@ -30,10 +30,8 @@ from dummynode4graphlearning_amd._lib import source_digest  # noqa: E402
 
 # launches of ONE eager step of bench.py's config-5 workload, in order (kernel-name fragment, role)
 STEP = [
-    ("rows_transform_ring_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows)"),
-    ("rows_selfsum_kernel", "closing launch fwd: self-loop transform + bias + per-dst slot sum + per-graph column sums of x"),
-    ("overflow_rows_add_kernel", "nodes with > 6 incoming rows finished from their lists (fwd)"),
-    ("fold_tail_kernel", "fold tail fwd: combine the column sums, transform the one row per graph, add it to the dummy node"),
+    ("rows_transform_ring_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows; weights read [k][n])"),
+    ("rows_close_ring_kernel", "closing launch fwd (unit stream): self-loop transform + bias + per-dst row sums (selection MFMA) + per-graph column sums -> aux rows + AGG units (aux x W_agg added to the dummy nodes)"),
     ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors)"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
@@ -41,15 +39,14 @@ STEP = [
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_ring_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
-    ("rows_selfsum_kernel", "closing launch bwd: self-loop transform + per-src slot sum + per-graph column sums of g"),
-    ("overflow_rows_add_kernel", "nodes with > 6 outgoing rows finished from their lists (bwd)"),
-    ("fold_tail_kernel", "fold tail bwd"),
+    ("rows_close_ring_kernel", "closing launch bwd (unit stream): self-loop transform + per-src row sums + per-graph column sums of g -> aux rows + AGG units"),
     ("rows_wgrad_ix_kernel", "conv wgrad (LDS-DMA ring, row indices by LDS-DMA; gathers x and g rows, + bias colsum)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
-CONV_ROWS = (0, 1, 2, 3, 10, 11, 12, 13)
-OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel",
-        "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel", "wgrad_reduce_kernel")
+CONV_ROWS = (0, 1, 8, 9)
+OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_close_ring_kernel",
+        "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_kernel", "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
+        "wgrad_reduce_kernel")
 
 
 def short(name):
@@ -93,6 +90,57 @@ def last_step(rows):
     raise SystemExit("step pattern not found in the trace")
 
 
+def trace_rows(path):
+    """kernel trace -> [(kernel name, start ns, end ns)] in start order."""
+    out = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    out.sort(key=lambda t: t[1])
+    return out
+
+
+def write_window_stats(path, header, rows):
+    """per-kernel Calls / TotalDurationNs / AverageNs of the launches in `rows` (the layout of rocprofv3's kernel_stats.csv)."""
+    agg = {}
+    for name, t0, t1 in rows:
+        e = agg.setdefault(name, [0, 0])
+        e[0] += 1
+        e[1] += t1 - t0
+    tot = sum(v[1] for v in agg.values()) or 1
+    with open(path, "w") as f:
+        for h in header:
+            f.write("# " + h + "\n")
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n')
+        for name, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write('"%s",%d,%d,%.1f,%.2f\n' % (name, c, d, d / c, 100.0 * d / tot))
+    return tot
+
+
+def split_step_and_leg(trace, steps, reps):
+    """The timed regions of `bench.py --steady`: the last `steps` replays of the captured step (every launch between the first
+    kernel of a STEP pattern and the pattern's last reduce, torch glue included) and, behind them, the roofline leg = the last
+    reps x 4 conv launches (graph replays of ring, close, ring, close)."""
+    conv = ("rows_transform_ring_kernel", "rows_close_ring_kernel")
+    n_leg = reps * len(CONV_ROWS)
+    tail = trace[-n_leg:]
+    assert all(any(c in t[0] for c in conv) for t in tail), "the trace does not end with the roofline leg"
+    body = trace[:-n_leg]
+    want = [n for n, _ in STEP]
+    ours = [(i, short(t[0])) for i, t in enumerate(body) if short(t[0])]
+    names = [n for _, n in ours]
+    found, s = [], len(names) - len(want)
+    while s >= 0 and len(found) < steps:
+        if names[s:s + len(want)] == want:
+            found.append((ours[s][0], ours[s + len(want) - 1][0]))
+            s -= len(want)
+        else:
+            s -= 1
+    assert len(found) == steps, "found %d of %d step replays in the trace" % (len(found), steps)
+    lo, hi = found[-1][0], found[0][1]
+    return body[lo:hi + 1], tail
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r01")
@@ -120,6 +168,18 @@ def main():
         f.write("#  build of the one batch runs before the timed region under its own kernel names)\n")
         f.write("# (%s first) bench line of that run: %s\n" % (env_note, r.stdout.strip().splitlines()[-1][:400] if r.stdout.strip() else "n/a"))
         f.write(body)
+    # the same run cut into its two timed regions (from the kernel trace): AverageNs x Calls / 20 of the first file reproduces
+    # ms_per_step, of the second kernel_ms_per_step
+    step_rows, leg_rows = split_step_and_leg(trace_rows(one_csv(d, "kernel_trace.csv")), 20, 20)
+    t_step = write_window_stats(os.path.join(a.out, a.tag + "_kernel_stats_step.csv"),
+                                ["%s -- the 20 timed replays of the captured step of the run above (kernel trace, all launches incl. torch glue)" % a.tag], step_rows)
+    t_leg = write_window_stats(os.path.join(a.out, a.tag + "_kernel_stats_leg.csv"),
+                               ["%s -- the 20 timed replays of the roofline leg of the run above (the conv's 4 launches: ring, close, ring, close)" % a.tag], leg_rows)
+    span = lambda rows: (rows[-1][2] - rows[0][1]) / 1e6  # noqa: E731
+    with open(os.path.join(a.out, a.tag + "_kernel_stats_step.csv"), "a") as f:
+        f.write("# sum of kernel durations / 20 = %.4f ms per step; first start to last end / 20 = %.4f ms\n" % (t_step / 20e6, span(step_rows) / 20))
+    with open(os.path.join(a.out, a.tag + "_kernel_stats_leg.csv"), "a") as f:
+        f.write("# sum of kernel durations / 20 = %.4f ms per leg; first start to last end / 20 = %.4f ms\n" % (t_leg / 20e6, span(leg_rows) / 20))
 
     # 3./4. HBM traffic per launch
     vals = {}
@@ -146,7 +206,7 @@ def main():
         f.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE KB (a wide coalesced read is half-counted); WRITE_SIZE exact. durations under PMC collection (us)\n")
         f.write("kernel,role,hbm_read_MB,hbm_write_MB,hbm_total_MB,duration_us,TB_per_s\n")
         f.write("\n".join(lines) + "\n")
-        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-4 and 11-14): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
+        f.write("# step total %.1f MB; conv gather-scatter launches (rows 1-2 and 9-10): %.1f MB vs %.1f MB algorithmic (SURVEY 8d) = %.2fx\n"
                 % (tot, conv, alg / 1e6, conv * 1e6 / alg))
     with open(os.path.join(a.out, a.tag + "_traffic.json"), "w") as f:
         json.dump({"workload": "config5", "N": N, "E": E, "H": H, "dtype": "bf16",
