@@ -752,10 +752,10 @@ int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int
 size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
     if (num_tiles < 0 || num_wg <= 0) { dn_set_error("dn_close_units_workspace_bytes: bad sizes"); return 0; }
     const int64_t M = (int64_t)num_wg * dn_cdiv(num_tiles, num_wg);
-    size_t tb = 0;
-    if (rocprim::exclusive_scan(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(),
-                                (hipStream_t)nullptr) != hipSuccess) { dn_set_error("rocprim scan size query failed"); return 0; }
-    return dn_align_up((size_t)(num_tiles + 1) * 4, 256) + 2 * dn_align_up((size_t)(M + 1) * 4, 256) + dn_align_up(tb, 256) + 512;
+    // (the scan's temporary storage -- a look-back state per few thousand elements -- is bounded here without asking rocPRIM, so
+    //  that the size query needs no device; dn_close_units_build_i32 checks the real requirement against it)
+    const size_t scan_tmp = 8192 + (size_t)(M + 1);
+    return dn_align_up((size_t)(num_tiles + 1) * 4, 256) + 2 * dn_align_up((size_t)(M + 1) * 4, 256) + dn_align_up(scan_tmp, 256) + 512;
 }
 
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
@@ -786,6 +786,7 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
     wsp += dn_align_up((size_t)(M + 1) * 4, 256);
     size_t tb = 0;
     DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
+    DN_REQUIRE(tb <= 8192 + (size_t)(M + 1), "dn_close_units_build: scan storage %zu exceeds the reserved bound", tb);
     if (M + 1 != T)                                                        // positions without a tile (T not a multiple of num_wg) and the total's slot
         DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, (size_t)(M + 1) * 4, st));
     hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,

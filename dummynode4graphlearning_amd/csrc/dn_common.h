@@ -123,6 +123,36 @@ __device__ __forceinline__ void dn_load_w_kn32(const __bf16* __restrict__ w, int
     }
 }
 
+// (the same with the PLAIN column order of the dense-row kernels: fragment [ks][n] row i <-> column n0 + 16 n + i)
+template <int KS>
+__device__ __forceinline__ void dn_load_w_kn32p(const __bf16* __restrict__ w, int ldw, int n0, int lane, char* scratch,
+                                                dn_bf16x8 (&wf)[KS][2]) {
+    typedef dn_short4v __attribute__((address_space(3))) * lds_tr;
+    const int r16 = lane >> 2, pc4 = lane & 3;
+    dn_u32x4 raw[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            raw[ks][h] = *reinterpret_cast<const dn_u32x4*>(w + (size_t)(32 * ks + 16 * h + r16) * ldw + n0 + 8 * pc4);
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        *reinterpret_cast<dn_u32x4*>(scratch + r16 * 64 + 16 * pc4) = raw[ks][0];
+        *reinterpret_cast<dn_u32x4*>(scratch + (16 + r16) * 64 + 16 * pc4) = raw[ks][1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const char* a0 = scratch + (8 * g + q4) * 64 + 32 * n + 8 * p4;
+            const dn_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+            const dn_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * 64));
+            const dn_short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            wf[ks][n] = __builtin_bit_cast(dn_bf16x8, f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int KS>
 __device__ __forceinline__ void dn_load_w_kn16(const __bf16* __restrict__ w, int ldw, int n0, int lane, char* scratch,
                                                dn_bf16x8 (&wf)[KS]) {

@@ -1136,11 +1136,16 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     const bf16_t* Wn = role ? W2n : W1n;
     const bool relu = role ? (flags & 2) : (flags & 1);
     bf16x8 wf[KS][NT];
+    if (flags & (role ? 16 : 8)) {                               // this layer's weights are stored [k][n] (a Linear's own weight seen
+        // from the input-gradient side): transposed through a wave-private scratch in buf1 / buf2 (idle until the first barrier)
+        dn_load_w_kn32p<KS>(Wn, H, n0, lane, reinterpret_cast<char*>(buf1(0)) + wave * 2048, wf);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-            wf[ks][n] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + n * 16 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+            for (int n = 0; n < NT; ++n)
+                wf[ks][n] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + n * 16 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    }
     for (int i = threadIdx.x; i < 2 * H; i += T) {
         const bf16_t* bb = i < H ? b1 : b2;
         biasL[i] = bb ? (float)bb[i % H] : 0.f;
@@ -1293,7 +1298,7 @@ template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
-                                                           int32_t H, float* __restrict__ out_colsum) {
+                                                           int32_t H, float* __restrict__ out_colsum, TO* __restrict__ out_colsum_lp) {
     constexpr int SL = 8, EL = 256 / SL;
     __shared__ float red[SL][EL];
     const int r = blockIdx.y;
@@ -1321,8 +1326,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         float t = red[0][elem];
 #pragma unroll
         for (int k = 1; k < SL; ++k) t += red[k][elem];
-        if (is_cs) out_colsum[(size_t)r * H + i] = t;
-        else out[(size_t)r * tile_elems + i] = (TO)t;
+        if (is_cs) {
+            out_colsum[(size_t)r * H + i] = t;
+            if (out_colsum_lp) out_colsum_lp[(size_t)r * H + i] = (TO)t;    // (the bias gradient in the parameter's dtype: no cast launch)
+        } else out[(size_t)r * tile_elems + i] = (TO)t;
     }
 }
 
@@ -1514,9 +1521,10 @@ size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho)
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G, const void* G2,
                        int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                        int64_t num_chunks, const int32_t* chunk_ptr, void* out, int32_t out_is_f32, int32_t colsum_of,
-                       float* out_colsum, const void* mask_a, void* a_out, const void* mask_a_bits, void* workspace,
-                       size_t workspace_bytes, dn_stream_t stream) {
+                       float* out_colsum, const void* mask_a, void* a_out, const void* mask_a_bits, void* out_colsum_lp,
+                       void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad: mask_a needs a single A source");
+    DN_REQUIRE(out_colsum_lp == nullptr || colsum_of != 0, "dn_rows_wgrad: out_colsum_lp needs colsum_of");
     DN_REQUIRE(mask_a_bits == nullptr || (mask_a == nullptr && A2 == nullptr), "dn_rows_wgrad: mask_a_bits excludes mask_a / A2");
     DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad: a_out needs mask_a and idx_a == NULL");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0, "dn_rows_wgrad: unaligned mask");
@@ -1551,10 +1559,10 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
     dim3 grid((unsigned)(dn_cdiv(tile, 32) + (csp ? dn_cdiv(Hi, 32) : 0)), (unsigned)R);
     if (out_is_f32)
         hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
-                           (float*)out, csp, Hi, out_colsum);
+                           (float*)out, csp, Hi, out_colsum, (float*)out_colsum_lp);
     else
         hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
-                           (bf16_t*)out, csp, Hi, out_colsum);
+                           (bf16_t*)out, csp, Hi, out_colsum, (bf16_t*)out_colsum_lp);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1610,7 +1618,7 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
                         const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
-                        void* bits1, void* bits2, dn_stream_t stream) {
+                        void* bits1, void* bits2, int32_t w_kn, dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_chain2: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_chain2: unsupported width %d (64/128/256 only)", H);
     if (N == 0) return DN_OK;
@@ -1619,7 +1627,7 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
                 reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
                "dn_rows_chain2: unaligned pointer");
     static const int nt = dn_knob("DN_NT", 3);
-    const int32_t flags = (relu1 ? 1 : 0) | (relu2 ? 2 : 0) | ((nt & 1) ? 4 : 0);
+    const int32_t flags = (relu1 ? 1 : 0) | (relu2 ? 2 : 0) | ((nt & 1) ? 4 : 0) | ((w_kn & 1) ? 8 : 0) | ((w_kn & 2) ? 16 : 0);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w1 = (const bf16_t*)W1n, *w2 = (const bf16_t*)W2n, *bb1 = (const bf16_t*)b1,
                  *bb2 = (const bf16_t*)b2;

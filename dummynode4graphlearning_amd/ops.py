@@ -260,10 +260,11 @@ INT32_MAX = 0x7fffffff
 
 
 def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0,
-               mask_a=None, a_out=None, mask_a_bits=None):
+               mask_a=None, a_out=None, mask_a_bits=None, colsum_lp=False):
     """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
     Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
-    column sums [R, H] of operand A|G (the bias gradient)."""
+    column sums [R, H] of operand A|G (the bias gradient); colsum_lp: return them in out's dtype instead (bf16 output: written
+    by the reduce launch itself, so the bias gradient needs no cast launch)."""
     chunks, chunk_ptr, nchunks = chunk_table
     require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out, mask_a_bits)
     assert A.dtype == G.dtype and A.dtype in (torch.bfloat16, torch.float32)
@@ -277,6 +278,9 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     out = torch.empty((num_rels, Hi, Ho), dtype=out_dtype, device=A.device)
     ws = _ws(lib().dn_rows_wgrad_workspace_bytes(nchunks, Hi, Ho), A.device)
     colsum = torch.empty((num_rels, Hi), dtype=torch.float32, device=A.device) if colsum_of else None
+    # the column sums again in the output dtype (the bias gradient as the parameter wants it): written by the reduce launch
+    colsum_lp = (torch.empty((num_rels, Hi), dtype=out_dtype, device=A.device)
+                 if (colsum_lp and colsum_of and not is_f32 and out_dtype != torch.float32) else None)
 
     def _launch():
         na1 = A.shape[0] if A2 is not None else INT32_MAX
@@ -290,13 +294,16 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                            ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
                                            1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
-                                           ptr(a_out), ptr(mask_a_bits), ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_bf16")
+                                           ptr(a_out), ptr(mask_a_bits), ptr(colsum_lp), ptr(ws), ws.numel(), stream_ptr()),
+                  "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
         kernel_timer.launch("rows_wgrad", _launch)
     else:
         _launch()
-    return (out, colsum) if colsum_of else out
+    if colsum_of:
+        return out, (colsum_lp if colsum_lp is not None else colsum)
+    return out
 
 
 def wgrad_chunk_rows(rel_ptr_host, workgroups=256):
@@ -454,10 +461,11 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
 CHAIN2_ENABLED = _os.environ.get("DN_CHAIN2", "1") != "0"
 
 
-def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=None, want_bits=False):
+def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=None, want_bits=False, w_kn=(False, False)):
     """(Y1, Y2[, bits1, bits2]) with Y1 = epi1(m0(x) @ W1n^T), Y2 = epi2(Y1 @ W2n^T) in one pass over the rows
     (dn_rows_chain2_bf16).  mask*_bits: uint8 [N, H/8] keep-masks (input / stage-1 output); want_bits: also return the
-    "> 0" bit tensors of Y1 and Y2 (the ReLU masks the backward needs, 1/16 of the activations)."""
+    "> 0" bit tensors of Y1 and Y2 (the ReLU masks the backward needs, 1/16 of the activations).  w_kn[i]: weight i is given
+    [in][out] instead of [out][in] (the backward chain on the Linear weights as they are: no transposed copies)."""
     x, W1n, W2n = x.contiguous(), W1n.contiguous(), W2n.contiguous()
     require_gpu(x, W1n, b1, W2n, b2, mask0_bits, mask1_bits)
     N, H = x.shape
@@ -471,7 +479,7 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     def _launch():
         check(lib().dn_rows_chain2_bf16(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask0_bits), ptr(mask1_bits),
                                         ptr(W2n), ptr(b2), 1 if relu2 else 0, N, ptr(Y1), ptr(Y2), ptr(bits1), ptr(bits2),
-                                        stream_ptr()), "dn_rows_chain2_bf16")
+                                        (1 if w_kn[0] else 0) | (2 if w_kn[1] else 0), stream_ptr()), "dn_rows_chain2_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_chain2", _launch)
     else:
@@ -1584,7 +1592,7 @@ class _RowTransformFn(torch.autograd.Function):
                 aux = auxs[part] if ix.num_aux_f else None
                 # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
                 gw, cs = rows_wgrad(xs, gs, ix.chunk_table, R_all, idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
-                                    G2=aux_b, out_dtype=W.dtype if single else torch.float32, colsum_of=2)
+                                    G2=aux_b, out_dtype=W.dtype if single else torch.float32, colsum_of=2, colsum_lp=single)
                 gW32 = gw if gW32 is None else gW32.add_(gw)
                 cs32 = cs if cs32 is None else cs32.add_(cs)
         gW = gL = gb = None
@@ -1769,9 +1777,9 @@ class _ReluMlpFn(torch.autograd.Function):
         if ctx.chain:
             x0, h1, bits1, bits2, w1, w2 = saved
             _, chunks = _dense_table(x0.shape[0], x0.device)
-            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a_bits=bits2)
-            g1, g0 = rows_chain2(g, w2.t(), None, False, w1.t(), None, False, mask0_bits=bits2, mask1_bits=bits1)
-            gw1, cs1 = rows_wgrad(g1, x0, chunks, 1, out_dtype=w1.dtype, colsum_of=1)
+            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a_bits=bits2, colsum_lp=True)
+            g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True))
+            gw1, cs1 = rows_wgrad(g1, x0, chunks, 1, out_dtype=w1.dtype, colsum_of=1, colsum_lp=True)
             grads[1], grads[3] = gw1[0], gw2[0]
             if ctx.has_bias[0]:
                 grads[2] = cs1[0].to(g.dtype)

@@ -318,13 +318,15 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
  * mask_a (may be NULL; needs A2 == NULL): A rows are first zeroed where mask_a[row, k] <= 0 (ReLU backward folded into the
  * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears.
  * mask_a_bits (may be NULL; excludes mask_a and A2): the same mask as a bit tensor, uint8 [rows of A, Hi/8], bit i of byte
- * (row, c) = keep element (row, 8c + i) -- the bits1 / bits2 outputs of dn_rows_chain2_bf16. */
+ * (row, c) = keep element (row, 8c + i) -- the bits1 / bits2 outputs of dn_rows_chain2_bf16.
+ * out_colsum_lp (may be NULL; needs colsum_of): a second copy of the column sums in out's element type ([R, H]): the bias
+ * gradient in the parameter's dtype without a cast launch. */
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
 int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t* idx_a, const void* G,
                        const void* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                        const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
                        int32_t out_is_f32, int32_t colsum_of, float* out_colsum, const void* mask_a, void* a_out,
-                       const void* mask_a_bits, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                       const void* mask_a_bits, void* out_colsum_lp, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
@@ -468,11 +470,12 @@ int dn_bdd_extract(const void* dense, int64_t R, int32_t B, int32_t si, int32_t 
  * Forward of the reference's two-layer MLP after the aggregate (subgraph_isomorphism/models/rgin.py:50-57 followed by the
  * layer activation, :147-151: Linear-ReLU-Linear-ReLU), emitting the ReLU masks as bits, and -- with mask0 = bits of the
  * output activation, mask1 = bits of the hidden one -- the input-gradient chain of its backward.  W1n / W2n are [H][H]
- * with k contiguous (nn.Linear.weight for the forward, its transpose for the backward); b1 / b2 may be NULL.  Y1 is
- * written but never re-read.  H in {64, 128, 256}. */
+ * with k contiguous (nn.Linear.weight for the forward); b1 / b2 may be NULL.  w_kn: bit 0 / bit 1 = W1n / W2n is stored
+ * [k][n] instead -- the backward chain takes the Linear weights as they are (its first product is g @ W2, k = W2's rows), so no
+ * transposed copies are made.  Y1 is written but never re-read.  H in {64, 128, 256}. */
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
                         const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
-                        void* bits1, void* bits2, dn_stream_t stream);
+                        void* bits1, void* bits2, int32_t w_kn, dn_stream_t stream);
 
 /* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
  * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the
