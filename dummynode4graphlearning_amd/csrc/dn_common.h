@@ -174,3 +174,35 @@ __device__ __forceinline__ void dn_load_w_kn16(const __bf16* __restrict__ w, int
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// ---- ReLU / leaky ReLU.  slope = 0: ReLU (max(v, 0): the negative side is an exact 0 whatever v is); slope > 0: leaky ReLU, the
+// reference's default activation (`leaky_relu`, slope 1 / 5.5: subgraph_isomorphism/utils/act.py:466, constants.py:10).  The backward
+// multiplies a gradient by 1 where the saved activation (or its sign bit) is > 0 and by `slope` elsewhere.
+__device__ __forceinline__ float dn_neg(float v, float slope) { return slope != 0.f ? v * slope : 0.f; }
+__device__ __forceinline__ float dn_act(float v, float slope) { return v > 0.f ? v : dn_neg(v, slope); }
+__device__ __forceinline__ uint32_t dn_bf16_bits(float v) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v);
+}
+// one packed pair of bf16 values: element kept where its flag is set, scaled by slope (0: zeroed) otherwise
+__device__ __forceinline__ uint32_t dn_pair_keep_or_scale(uint32_t w, bool keep_lo, bool keep_hi, float slope) {
+    if (slope == 0.f) return w & ((keep_lo ? 0x0000ffffu : 0u) | (keep_hi ? 0xffff0000u : 0u));
+    const uint32_t lo = keep_lo ? (w & 0xffffu) : dn_bf16_bits(__uint_as_float(w << 16) * slope);
+    const uint32_t hi = keep_hi ? (w >> 16) : dn_bf16_bits(__uint_as_float(w & 0xffff0000u) * slope);
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ bool dn_bf16_pos(uint32_t h) { return h != 0u && h < 0x8000u; }       // bf16 bits > 0
+// 8 bf16 values (16 bytes), bit i of `bits` <-> element i
+__device__ __forceinline__ uint4 dn_keep_or_scale_bits(const uint4& v, uint32_t bits, float slope) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = dn_pair_keep_or_scale(w[i], (bits >> (2 * i)) & 1u, (bits >> (2 * i + 1)) & 1u, slope);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// ... kept where the bf16 mask element (a saved activation) is > 0
+__device__ __forceinline__ uint4 dn_keep_or_scale_mask(const uint4& v, const uint4& mk, float slope) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t m[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = dn_pair_keep_or_scale(w[i], dn_bf16_pos(m[i] & 0xffffu), dn_bf16_pos(m[i] >> 16), slope);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}

@@ -819,8 +819,12 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
     if (tid == 0) {
         int32_t smax = 0;
         for (int x = 0; x < kSwGroups; ++x) smax = max(smax, Sx[x]);
-        s_plain = smax > S_cap ? 1 : 0;                           // a group does not fit the table: plain order (always valid)
-        if (blockIdx.x == 0 && info) { info[0] = s_plain; info[1] = smax; }
+        s_plain = smax > S_cap ? 1 : 0;                           // a group does not fit the table: plain order (valid as long as
+        // the table holds all pp[R] tiles; info[0] = 2 reports a table that cannot even hold those -- rows would go untransformed)
+        if (blockIdx.x == 0 && info) {
+            info[0] = s_plain ? ((int64_t)pp[R] > (int64_t)kSwGroups * W * S_cap ? 2 : 1) : 0;
+            info[1] = smax;
+        }
     }
     __syncthreads();
     const int64_t total = (int64_t)kSwGroups * W * S_cap;
@@ -938,9 +942,9 @@ int row_layout(Arena& a, RowWs& w, int64_t N, int64_t R, int64_t E, hipStream_t 
 }  // namespace
 
 // ----- fixed-width slot tables for dn_rows_selfsum_bf16 ----------------------------------------------------------------------
-// Per node v the kept rows of its list are those < num_edge_rows (self-loop rows dropped).  cnt <= K: slots = the rows, -1
-// padded.  cnt > K: the first K-1 rows, slot K-1 = num_edge_rows + j for the j-th overflowing node, and rows K-1 .. cnt-1 go
-// to the overflow CSR (ovf_ptr over overflowing nodes in node order, ovf_idx) the caller pre-sums.
+// Per node v the kept rows of its list are those < num_edge_rows (self-loop rows dropped) outside the dropped range.  cnt <= K:
+// slots = the rows, -1 padded.  cnt > K: the first K-1 rows, slot K-1 = -2 and over[v] = 1: dn_overflow_rows_add_bf16 walks
+// such a node's list itself after the closing launch (rows K-1 .. cnt-1), screening the byte per node.
 __global__ void slot_fill_kernel(int64_t N, int32_t P, int32_t K, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lrows, int32_t* __restrict__ slots, int32_t drop_beg, int32_t drop_end,
                                  const int32_t* __restrict__ drop_enable, uint8_t* __restrict__ over) {

@@ -7,9 +7,9 @@ namespace dn_internal {
 
 // dn_rel_ring.hip: dn_rows_transform_bf16 at Hi == Ho == 256 (persistent workgroups, LDS-DMA ring, wave-specialised).
 // tiles_per_wg <= 0: contiguous tile ranges, one workgroup per CU; > 0: the table is laid out [workgroup][tiles_per_wg].
-// w_kn != 0: Wn[r] is stored [k][n] (the parameter's own layout) instead of [n][k].
+// w_kn != 0: Wn[r] is stored [k][n] (the parameter's own layout) instead of [n][k].  slope: leaky-ReLU slope of the epilogue / mask (0: ReLU).
 int launch_transform_ring256(const void* X, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
-                             int64_t tiles_per_wg, void* Y, int32_t w_kn, hipStream_t st);
+                             int64_t tiles_per_wg, void* Y, int32_t w_kn, float slope, hipStream_t st);
 
 }  // namespace dn_internal

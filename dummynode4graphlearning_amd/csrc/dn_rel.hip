@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                                                                 float* __restrict__ colsum_partial,
                                                                 const bf16_t* __restrict__ maskA,
                                                                 bf16_t* __restrict__ A_out,
-                                                                const uint8_t* __restrict__ maskBits) {
+                                                                const uint8_t* __restrict__ maskBits, float slope) {
     constexpr int SA = HI + kPad, SG = HO + kPad;
     constexpr int MT = HI / 2 / 16, NT = HO / 4 / 16;           // 16x16 tiles per wave
     constexpr int NPA = kTileRows * HI / 8, NPG = kTileRows * HO / 8;   // 16-byte pieces per tile
@@ -148,18 +148,11 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int piece = tid + j * kWgThreads, r = piece / (HI / 8), c = piece % (HI / 8);
-            if (maskA && sa_cur[j] >= 0) {                       // A <- A where mask > 0 (ReLU backward), optionally saved
-                const uint32_t mw[4] = {rm[j].x, rm[j].y, rm[j].z, rm[j].w};
-                uint32_t vw[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
-                    vw[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
-                }
-                ra[j] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+            if (maskA && sa_cur[j] >= 0) {                       // A <- A where mask > 0, slope * A elsewhere (activation backward)
+                ra[j] = dn_keep_or_scale_mask(ra[j], rm[j], slope);
                 if (A_out) *reinterpret_cast<uint4*>(A_out + (size_t)sa_cur[j] * HI + c * 8) = ra[j];
             }
-            if (maskBits && sa_cur[j] >= 0) ra[j] = keep_bits(ra[j], rm[j].x);
+            if (maskBits && sa_cur[j] >= 0) ra[j] = dn_keep_or_scale_bits(ra[j], rm[j].x, slope);
             if (piece < NPA) *reinterpret_cast<uint4*>(bufA(b) + r * SA + c * 8) = ra[j];
             if (colsum_of == 1 && piece < NPA) add_cs(ra[j]);
         }
@@ -263,7 +256,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                                                                     const Chunk* __restrict__ chunks,
                                                                     float* __restrict__ partial, int32_t colsum_of,
                                                                     float* __restrict__ colsum_partial,
-                                                                    const uint8_t* __restrict__ maskBits) {
+                                                                    const uint8_t* __restrict__ maskBits, float slope) {
     static_assert(H == 256 || H == 128, "unsupported width");
     constexpr int TR = (H == 256) ? 32 : 64;       // rows per stage: 32 KiB per stage at either width (1 or 2 MFMA K-steps)
     constexpr int NST = 4;                         // ring stages (128 KiB)
@@ -404,7 +397,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                 const int f = (r & 3) | (((r >> 3) & 1) << 2);
                 const int gchunk = (((q >> 1) ^ f) << 1) | (q & 1);
                 uint4* pp = reinterpret_cast<uint4*>(sA + r * ROWB + q * 16);
-                *pp = keep_bits(*pp, sB[r * (H / 8) + gchunk]);
+                *pp = dn_keep_or_scale_bits(*pp, sB[r * (H / 8) + gchunk], slope);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -680,11 +673,15 @@ constexpr int kTfRows = 32;
 template <int HI, int HO, int D>
 __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
-    const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, const bf16_t* __restrict__ mask_pos,
+    const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t relu, float slope, const bf16_t* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
     const bool nt_store = (relu & 2) != 0;          // bit 1: streaming (non-temporal) stores of Y
     const bool sc1_store = (relu & 4) != 0;         // bit 2: sc1 stores (the written line does not stay in the XCD's L2)
+#ifdef DN_TUNING_ENV
     const bool abl_nostore = (relu & 8) != 0, abl_hit = (relu & 16) != 0;   // tuning build only: ablations
+#else
+    constexpr bool abl_nostore = false, abl_hit = false;
+#endif
     relu &= 1;
     constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
     constexpr int SY = HO + kPad;                   // ... of the output tile
@@ -813,7 +810,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
                 }
                 if (relu) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < 4; ++i) v[i] = dn_act(v[i], slope);
                 }
                 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                 bf16x4 o;
@@ -832,20 +829,8 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
             const int p = tl.beg + r;
             if (piece < NPY && p < tl.end && !(abl_nostore && p != 0)) {
                 uint4 v = *reinterpret_cast<const uint4*>(bufY + r * SY + c * 8);
-                if (mask_pos) {                                  // ReLU backward: keep where the saved activation is > 0
-                    const uint4 mk = *reinterpret_cast<const uint4*>(mask_pos + (size_t)p * HO + c * 8);
-                    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-                    uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        // bf16 > 0  <=>  sign clear and magnitude non-zero (NaN counts as "not > 0" only if signed)
-                        const uint32_t lo = mw[i] & 0xffffu, hi = mw[i] >> 16;
-                        const uint32_t keep_lo = (lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u;
-                        const uint32_t keep_hi = (hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u;
-                        vw[i] &= (keep_lo | keep_hi);
-                    }
-                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-                }
+                if (mask_pos)                                    // activation backward: keep where the saved activation is > 0
+                    v = dn_keep_or_scale_mask(v, *reinterpret_cast<const uint4*>(mask_pos + (size_t)p * HO + c * 8), slope);
                 if (sc1_store) {
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 vv = {v.x, v.y, v.z, v.w};
@@ -1097,7 +1082,7 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
                                                             const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                                             int32_t N, int32_t num_tiles, int32_t tiles_per_wg,
                                                             bf16_t* __restrict__ Y1, bf16_t* __restrict__ Y2,
-                                                            uint8_t* __restrict__ bits1, uint8_t* __restrict__ bits2) {
+                                                            uint8_t* __restrict__ bits1, uint8_t* __restrict__ bits2, float slope) {
     // Wave-specialised two-stage pipeline: the first half of the waves owns layer 1 (32 output columns each, their slice of
     // W1n in 64 VGPRs), the second half layer 2; in one iteration layer 1 works on tile t while layer 2 works on tile t-1, so
     // the two products overlap and every wave re-reads the 32-row LDS tile for 32 columns instead of 16 (LDS fragment reads
@@ -1187,8 +1172,8 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
                 bf16x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = relu ? fmaxf(acc[m][n][i], 0.f) : acc[m][n][i];
-                    o[i] = (bf16_t)(((nib >> i) & 1u) ? v : 0.f);
+                    const float v = relu ? dn_act(acc[m][n][i], slope) : acc[m][n][i];
+                    o[i] = (bf16_t)(((nib >> i) & 1u) ? v : dn_neg(v, slope));
                 }
                 *reinterpret_cast<bf16x4*>(dst + row * SX + col) = o;
             }
@@ -1201,7 +1186,7 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
     };
 
     // X pieces (and their mask bits) and the stage-1 mask bits one tile ahead (in flight across the whole iteration)
-    uint4 rx = keep_bits(load_x(t_beg), load_bits(mask0, t_beg));
+    uint4 rx = dn_keep_or_scale_bits(load_x(t_beg), load_bits(mask0, t_beg), slope);
     *reinterpret_cast<uint4*>(bufX(0) + pr * SX + pc * 8) = rx;
     bitsL[pr * LPR + pc] = (uint8_t)load_bits(mask1, t_beg);
     rx = load_x(t_beg + 1);
@@ -1230,7 +1215,7 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
             if (t > t_beg && t - 1 < t_end) stage(buf1(b ^ 1), buf2(b ^ 1), nullptr);
         }
         if (t + 1 < t_end) {
-            *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? keep_bits(rx, m0) : rx;
+            *reinterpret_cast<uint4*>(bufX(b ^ 1) + pr * SX + pc * 8) = mask0 ? dn_keep_or_scale_bits(rx, m0, slope) : rx;
             bitsL[(b ^ 1) * (kSsRows * LPR) + pr * LPR + pc] = (uint8_t)mk1;
         }
         rx = load_x(t + 2);
@@ -1243,12 +1228,12 @@ __global__ __launch_bounds__(H * 4) void rows_chain2_kernel(const bf16_t* __rest
 template <int H>
 int launch_chain2(const bf16_t* X, const bf16_t* W1n, const bf16_t* b1, const bf16_t* W2n, const bf16_t* b2, int32_t flags,
                   const uint8_t* mask0, const uint8_t* mask1, int64_t N, bf16_t* Y1, bf16_t* Y2, uint8_t* bits1,
-                  uint8_t* bits2, hipStream_t st) {
+                  uint8_t* bits2, float slope, hipStream_t st) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     hipLaunchKernelGGL((rows_chain2_kernel<H>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, W1n, b1, W2n, b2, flags, mask0,
-                       mask1, (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), Y1, Y2, bits1, bits2);
+                       mask1, (int32_t)N, (int32_t)num_tiles, (int32_t)(stride_tiles() ? 0 : tiles_per_wg), Y1, Y2, bits1, bits2, slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1264,7 +1249,7 @@ static int tf_wg_per_cu() {
 
 template <int HI, int HO>
 int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_t* idx, const bf16_t* Wn, const bf16_t* bias,
-                     int32_t relu, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
+                     int32_t relu, float slope, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
     // contiguous tile ranges keep a workgroup inside one relation most of the time
     const int depth = tf_depth();
     // streaming (non-temporal) stores of the output rows: they are re-read only after ~1 GB of other traffic, so keeping
@@ -1281,7 +1266,7 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
 #define DN_TF_LAUNCH(DEPTH)                                                                                                  \
     hipLaunchKernelGGL((rows_transform_kernel<HI, HO, DEPTH>), dim3((unsigned)grid), dim3(kTfThreads), 0, st, X, X2, n1, idx, \
-                       Wn, bias, relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y)
+                       Wn, bias, relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y)
     if (depth == 1) DN_TF_LAUNCH(1);
     else if (depth == 2) DN_TF_LAUNCH(2);
     else if (depth == 3) DN_TF_LAUNCH(3);
@@ -1349,7 +1334,7 @@ int wgrad_ix_mode() {                              // tuning build: DN_WGRAD_IX=
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
-                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, hipStream_t st) {
+                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, float slope, hipStream_t st) {
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
         if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
             if constexpr (HI == 256) {
@@ -1362,34 +1347,25 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
             }
             if (maskBits)
                 hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, true>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
-                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits);
+                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope);
             else
                 hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, false>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
-                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits);
+                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope);
             DN_CHECK_LAUNCH();
             return DN_OK;
         }
     }
     hipLaunchKernelGGL((rows_wgrad_kernel<HI, HO>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, na1, ia, G, G2,
-                       ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out, maskBits);
+                       ng1, ig, chunks, partial, colsum_of, cs_partial, maskA, A_out, maskBits, slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 // out = (y > 0) ? g : 0, 8 bf16 per lane
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y,
-                                                       uint4* __restrict__ out, int64_t n16) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
-        const uint4 gv = g[i], yv = y[i];
-        const uint32_t mw[4] = {yv.x, yv.y, yv.z, yv.w};
-        uint32_t vw[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = mw[k] & 0xffffu, hi = mw[k] >> 16;
-            vw[k] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
-        }
-        out[i] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-    }
+                                                       uint4* __restrict__ out, int64_t n16, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+        out[i] = dn_keep_or_scale_mask(g[i], y[i], slope);
 }
 
 
@@ -1499,7 +1475,7 @@ int dn_fold_tail_bf16(const float* part, const int32_t* part_ptr, int64_t num_se
     return DN_OK;
 }
 
-int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream) {
+int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, float act_slope, dn_stream_t stream) {
     DN_REQUIRE(numel >= 0 && numel % 8 == 0, "dn_relu_bwd: numel must be a non-negative multiple of 8");
     if (numel == 0) return DN_OK;
     DN_REQUIRE(g && y && out, "dn_relu_bwd: NULL pointer");
@@ -1508,7 +1484,7 @@ int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_
     const int64_t n16 = numel / 8;
     const int64_t grid = dn_cdiv(n16, 256) < 256 * 16 ? dn_cdiv(n16, 256) : 256 * 16;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (const uint4*)y,
-                       (uint4*)out, n16);
+                       (uint4*)out, n16, act_slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1522,7 +1498,7 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
                        int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                        int64_t num_chunks, const int32_t* chunk_ptr, void* out, int32_t out_is_f32, int32_t colsum_of,
                        float* out_colsum, const void* mask_a, void* a_out, const void* mask_a_bits, void* out_colsum_lp,
-                       void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                       float act_slope, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad: mask_a needs a single A source");
     DN_REQUIRE(out_colsum_lp == nullptr || colsum_of != 0, "dn_rows_wgrad: out_colsum_lp needs colsum_of");
     DN_REQUIRE(mask_a_bits == nullptr || (mask_a == nullptr && A2 == nullptr), "dn_rows_wgrad: mask_a_bits excludes mask_a / A2");
@@ -1549,9 +1525,9 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
         const bf16_t* mk = (const bf16_t*)mask_a;
         bf16_t* ao = (bf16_t*)a_out;
         const uint8_t* mb = (const uint8_t*)mask_a_bits;
-        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
-        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
-        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, st);
+        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
+        else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
+        else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
@@ -1569,7 +1545,7 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
 
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos, const int32_t* tiles,
-                           int64_t num_tiles, void* Y, int32_t w_kn, dn_stream_t stream) {
+                           int64_t num_tiles, void* Y, int32_t w_kn, float act_slope, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform: bad tile count");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
@@ -1588,11 +1564,11 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     // (identity rows over the concatenation [X; X2] -- idx == NULL with a second source -- stay on the register-staged kernel:
     //  the ring kernel's loaders only tell the two sources apart through the row index)
     if (Hi == 256 && ring && (idx != nullptr || X2 == nullptr))
-        return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, w_kn, st);
+        return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, w_kn, act_slope, st);
     if (w_kn) { dn_set_error("dn_rows_transform: w_kn = 1 is served by the H = 256 ring kernel only"); return DN_ERR_UNSUPPORTED; }
-    if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
-    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
-    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, mk, tl, num_tiles, (bf16_t*)Y, st);
+    if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
+    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
+    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
 }
 
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
@@ -1618,7 +1594,7 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
                         const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
-                        void* bits1, void* bits2, int32_t w_kn, dn_stream_t stream) {
+                        void* bits1, void* bits2, int32_t w_kn, float act_slope, dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_chain2: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_chain2: unsupported width %d (64/128/256 only)", H);
     if (N == 0) return DN_OK;
@@ -1633,9 +1609,9 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
                  *bb2 = (const bf16_t*)b2;
     const uint8_t *m0 = (const uint8_t*)mask0_bits, *m1 = (const uint8_t*)mask1_bits;
     uint8_t *o1 = (uint8_t*)bits1, *o2 = (uint8_t*)bits2;
-    if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
-    if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
-    return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, st);
+    if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
+    if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
+    return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
 }
 
 }  // extern "C"

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32_kernel(const float* _
                                                                   int32_t ng1, const int32_t* __restrict__ ig,
                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
                                                                   int32_t colsum_of, float* __restrict__ colsum_partial,
-                                                                  const float* __restrict__ maskA, float* __restrict__ A_out) {
+                                                                  const float* __restrict__ maskA, float* __restrict__ A_out, float slope) {
     constexpr int S = H + 16;                                   // LDS row stride in floats: rows p, p+1 land 16 banks apart
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     constexpr int NP = kRows * H / 4;                           // 16-byte pieces per operand tile
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32_kernel(const float* _
         for (int j = 0; j < P; ++j) {
             const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
             if (maskA && sa_cur[j] >= 0) {
-                ra[j].x = rm[j].x > 0.f ? ra[j].x : 0.f; ra[j].y = rm[j].y > 0.f ? ra[j].y : 0.f;
-                ra[j].z = rm[j].z > 0.f ? ra[j].z : 0.f; ra[j].w = rm[j].w > 0.f ? ra[j].w : 0.f;
+                ra[j].x = rm[j].x > 0.f ? ra[j].x : dn_neg(ra[j].x, slope); ra[j].y = rm[j].y > 0.f ? ra[j].y : dn_neg(ra[j].y, slope);
+                ra[j].z = rm[j].z > 0.f ? ra[j].z : dn_neg(ra[j].z, slope); ra[j].w = rm[j].w > 0.f ? ra[j].w : dn_neg(ra[j].w, slope);
                 if (A_out) *reinterpret_cast<float4*>(A_out + (size_t)sa_cur[j] * H + c * 4) = ra[j];
             }
             if (piece < NP) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* 
                                                                    int32_t ng1, const int32_t* __restrict__ ig,
                                                                    const Chunk* __restrict__ chunks, float* __restrict__ partial,
                                                                    int32_t colsum_of, float* __restrict__ colsum_partial,
-                                                                   const float* __restrict__ maskA, float* __restrict__ A_out) {
+                                                                   const float* __restrict__ maskA, float* __restrict__ A_out, float slope) {
     constexpr int S = H + 8;                                    // bf16 elements per LDS row
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     constexpr int NP = kRows * H / 4;                           // 4-float pieces per operand tile
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* 
         for (int j = 0; j < P; ++j) {
             const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
             if (maskA && sa_cur[j] >= 0) {
-                ra[j].x = rm[j].x > 0.f ? ra[j].x : 0.f; ra[j].y = rm[j].y > 0.f ? ra[j].y : 0.f;
-                ra[j].z = rm[j].z > 0.f ? ra[j].z : 0.f; ra[j].w = rm[j].w > 0.f ? ra[j].w : 0.f;
+                ra[j].x = rm[j].x > 0.f ? ra[j].x : dn_neg(ra[j].x, slope); ra[j].y = rm[j].y > 0.f ? ra[j].y : dn_neg(ra[j].y, slope);
+                ra[j].z = rm[j].z > 0.f ? ra[j].z : dn_neg(ra[j].z, slope); ra[j].w = rm[j].w > 0.f ? ra[j].w : dn_neg(ra[j].w, slope);
                 if (A_out) *reinterpret_cast<float4*>(A_out + (size_t)sa_cur[j] * H + c * 4) = ra[j];
             }
             if (piece < NP) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __re
 template <int H>
 __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
-    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, const float* __restrict__ mask_pos,
+    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, float slope, const float* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
     constexpr int S = H + 4;                                    // 16-byte row pad: conflict-free ds_read_b128 fragments
     constexpr int KB = H / 16;                                  // 16-wide k blocks (4 MFMA steps each)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
                         const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (relu) { v.x = dn_act(v.x, slope); v.y = dn_act(v.y, slope); v.z = dn_act(v.z, slope); v.w = dn_act(v.w, slope); }
                     *reinterpret_cast<float4*>(bufY + (m * 16 + (lane & 15)) * S + col) = v;
                 }
         }
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
                 float4 v = *reinterpret_cast<const float4*>(bufY + r * S + c * 4);
                 if (mask_pos) {
                     const float4 mk = *reinterpret_cast<const float4*>(mask_pos + (size_t)p * H + c * 4);
-                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    v.x = mk.x > 0.f ? v.x : dn_neg(v.x, slope); v.y = mk.y > 0.f ? v.y : dn_neg(v.y, slope);
+                    v.z = mk.z > 0.f ? v.z : dn_neg(v.z, slope); v.w = mk.w > 0.f ? v.w : dn_neg(v.w, slope);
                 }
                 *reinterpret_cast<float4*>(Y + (size_t)p * H + c * 4) = v;
             }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
 template <int H>
 __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
-    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, const float* __restrict__ mask_pos,
+    const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, float slope, const float* __restrict__ mask_pos,
     const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
     constexpr int SX = H + 8;                                   // bf16 elements per LDS row of an input tile
     constexpr int SY = H + 4;                                   // floats per LDS row of the output tile
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
                         const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (relu) { v.x = dn_act(v.x, slope); v.y = dn_act(v.y, slope); v.z = dn_act(v.z, slope); v.w = dn_act(v.w, slope); }
                     *reinterpret_cast<float4*>(ldy + (m * 16 + (lane & 15)) * SY + col) = v;
                 }
         }
@@ -639,8 +639,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
                 float4 v = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
                 if (mask_pos) {
                     const float4 mk = *reinterpret_cast<const float4*>(mask_pos + (size_t)p * H + c * 4);
-                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    v.x = mk.x > 0.f ? v.x : dn_neg(v.x, slope); v.y = mk.y > 0.f ? v.y : dn_neg(v.y, slope);
+                    v.z = mk.z > 0.f ? v.z : dn_neg(v.z, slope); v.w = mk.w > 0.f ? v.w : dn_neg(v.w, slope);
                 }
                 *reinterpret_cast<float4*>(Y + (size_t)p * H + c * 4) = v;
             }
@@ -650,40 +650,41 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
 }
 
 __global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
-                                                           float4* __restrict__ out, int64_t n4) {
+                                                           float4* __restrict__ out, int64_t n4, float slope) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 gv = g[i], yv = y[i];
-        out[i] = make_float4(yv.x > 0.f ? gv.x : 0.f, yv.y > 0.f ? gv.y : 0.f, yv.z > 0.f ? gv.z : 0.f, yv.w > 0.f ? gv.w : 0.f);
+        out[i] = make_float4(yv.x > 0.f ? gv.x : dn_neg(gv.x, slope), yv.y > 0.f ? gv.y : dn_neg(gv.y, slope),
+                             yv.z > 0.f ? gv.z : dn_neg(gv.z, slope), yv.w > 0.f ? gv.w : dn_neg(gv.w, slope));
     }
 }
 
 template <int H>
 int launch_wgrad(const float* A, const float* A2, int32_t na1, const int32_t* ia, const float* G, const float* G2, int32_t ng1,
                  const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of, float* csp,
-                 const float* maskA, float* A_out, int32_t exact, hipStream_t st) {
+                 const float* maskA, float* A_out, float slope, int32_t exact, hipStream_t st) {
     if (exact)
         hipLaunchKernelGGL((rows_wgrad_f32_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2,
-                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out);
+                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out, slope);
     else
         hipLaunchKernelGGL((rows_wgrad_f32s_kernel<H>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, A, A2, na1, ia, G, G2,
-                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out);
+                           ng1, ig, chunks, partial, colsum_of, csp, maskA, A_out, slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 template <int H>
 int launch_transform(const float* X, const float* X2, int32_t n1, const int32_t* idx, const float* Wn, const float* bias,
-                     int32_t relu, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, int32_t exact,
+                     int32_t relu, float slope, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, int32_t exact,
                      hipStream_t st) {
     const int64_t max_wg = 256 * (H == 256 ? 1 : 2);             // LDS: one 100 KB workgroup per CU at H = 256
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     if (exact)
         hipLaunchKernelGGL((rows_transform_f32_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                           relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
     else
         hipLaunchKernelGGL((rows_transform_f32s_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                           relu, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -692,7 +693,7 @@ int launch_transform(const float* X, const float* X2, int32_t n1, const int32_t*
 
 extern "C" {
 
-int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, dn_stream_t stream) {
+int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, float act_slope, dn_stream_t stream) {
     DN_REQUIRE(numel >= 0 && numel % 4 == 0, "dn_relu_bwd_f32: numel must be a non-negative multiple of 4");
     if (numel == 0) return DN_OK;
     DN_REQUIRE(g && y && out, "dn_relu_bwd_f32: NULL pointer");
@@ -701,7 +702,7 @@ int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, d
     const int64_t n4 = numel / 4;
     const int64_t grid = dn_cdiv(n4, 256) < 256 * 16 ? dn_cdiv(n4, 256) : 256 * 16;
     hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4*)g,
-                       (const float4*)y, (float4*)out, n4);
+                       (const float4*)y, (float4*)out, n4, act_slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -709,7 +710,7 @@ int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, d
 int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G, const float* G2,
                       int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R, const int32_t* chunks,
                       int64_t num_chunks, const int32_t* chunk_ptr, float* out, int32_t colsum_of, float* out_colsum,
-                      const float* mask_a, float* a_out, int32_t precision, void* workspace, size_t workspace_bytes,
+                      const float* mask_a, float* a_out, int32_t precision, float act_slope, void* workspace, size_t workspace_bytes,
                       dn_stream_t stream) {
     DN_REQUIRE(R >= 0 && num_chunks >= 0, "dn_rows_wgrad_f32: negative size");
     DN_REQUIRE(precision == 0 || precision == 1, "dn_rows_wgrad_f32: precision must be 0 (bf16 split) or 1 (exact f32)");
@@ -733,9 +734,9 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
     float* csp = ws + (size_t)num_chunks * Hi * Ho;
     int rc = DN_OK;
     if (num_chunks > 0) {
-        if (Hi == 256) rc = launch_wgrad<256>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
-        else if (Hi == 128) rc = launch_wgrad<128>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
-        else rc = launch_wgrad<64>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, precision, st);
+        if (Hi == 256) rc = launch_wgrad<256>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, act_slope, precision, st);
+        else if (Hi == 128) rc = launch_wgrad<128>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, act_slope, precision, st);
+        else rc = launch_wgrad<64>(A, A2, na1, idx_a, G, G2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mask_a, a_out, act_slope, precision, st);
         if (rc != DN_OK) return rc;
     }
     const int64_t tile = (int64_t)Hi * Ho;
@@ -748,7 +749,7 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
 
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos, const int32_t* tiles,
-                          int64_t num_tiles, float* Y, int32_t precision, dn_stream_t stream) {
+                          int64_t num_tiles, float* Y, int32_t precision, float act_slope, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform_f32: bad tile count");
     DN_REQUIRE(precision == 0 || precision == 1, "dn_rows_transform_f32: precision must be 0 (bf16 split) or 1 (exact f32)");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform_f32: unsupported widths %d x %d "
@@ -761,9 +762,9 @@ int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int
                "dn_rows_transform_f32: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
-    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
-    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
-    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, mask_pos, tl, num_tiles, Y, precision, st);
+    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
+    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
+    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
 }
 
 }  // extern "C"

@@ -90,7 +90,7 @@ template <bool MASK, bool IDX, bool EPI, bool HASX2>
 __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const bf16_t* __restrict__ Wn, const bf16_t* __restrict__ bias, int32_t flags, const bf16_t* __restrict__ mask_pos,
-    const Tile* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y) {
+    const Tile* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, bf16_t* __restrict__ Y, float slope) {
     __shared__ __attribute__((aligned(1024))) char lds[kNS * kStageB];
     __shared__ __attribute__((aligned(16))) int32_t descL[kDescRing][4]; // tile records for the compute waves (copied by loader 0)
     __shared__ __attribute__((aligned(128))) int32_t recR[kLoaders][kRecRing][4];            // loader-private rings: tile records
@@ -285,19 +285,16 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
                 }
                 if (relu) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < 8; ++i) v[i] = dn_act(v[i], slope);
                 }
             }
             u32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-            if constexpr (MASK) {                                          // keep where the saved activation is > 0
+            if constexpr (MASK) {                                          // keep where the saved activation is > 0, x slope elsewhere
                 const u32x4 mk = m ? mk1 : mk0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = mk[i] & 0xffffu, hi = mk[i] >> 16;
-                    o[i] &= ((lo != 0u && lo < 0x8000u) ? 0x0000ffffu : 0u) | ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
-                }
+                const uint4 r4 = dn_keep_or_scale_mask(make_uint4(o[0], o[1], o[2], o[3]), make_uint4(mk[0], mk[1], mk[2], mk[3]), slope);
+                o = u32x4{r4.x, r4.y, r4.z, r4.w};
             }
 #ifdef DN_TUNING_ENV
             if (p < pend && !((flags & 8) && p != 0)) {                    // (flags & 8: ablation, no stores)
@@ -452,7 +449,7 @@ namespace dn_internal {
 
 int launch_transform_ring256(const void* X_, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
-                             int64_t tiles_per_wg, void* Y, int32_t w_kn, hipStream_t st) {
+                             int64_t tiles_per_wg, void* Y, int32_t w_kn, float slope, hipStream_t st) {
     if (tiles_per_wg <= 0) tiles_per_wg = dn_cdiv(num_tiles, 256);       // one persistent workgroup per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     static const int abl = dn_knob("DN_TF_ABL", 0);   // tuning build only: 1 no stores, 2 gathers hit L2, 4 no MFMAs, 8 trivial LDS reads, 16 no row DMAs
@@ -460,7 +457,7 @@ int launch_transform_ring256(const void* X_, const void* X2, int32_t n1, const i
 #define DN_RING_LAUNCH(M, I, E, X)                                                                                      \
     hipLaunchKernelGGL((rows_transform_ring_kernel<M, I, E, X>), dim3((unsigned)grid), dim3(kThreads), 0, st, (const bf16_t*)X_, \
                        (const bf16_t*)X2, n1, idx, (const bf16_t*)Wn, (const bf16_t*)bias, flags, (const bf16_t*)mask_pos,      \
-                       reinterpret_cast<const Tile*>(tiles), (int32_t)num_tiles, (int32_t)tiles_per_wg, (bf16_t*)Y)
+                       reinterpret_cast<const Tile*>(tiles), (int32_t)num_tiles, (int32_t)tiles_per_wg, (bf16_t*)Y, slope)
     // the conv's launches (gathered rows, no epilogue, one source) get the leanest instruction stream: the loop is bound by
     // vector-instruction issue, not by the matrix pipe (~180 VALU instructions per SIMD and tile before this split)
     const bool epi = bias != nullptr || relu != 0;

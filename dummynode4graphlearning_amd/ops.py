@@ -260,7 +260,7 @@ INT32_MAX = 0x7fffffff
 
 
 def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0,
-               mask_a=None, a_out=None, mask_a_bits=None, colsum_lp=False):
+               mask_a=None, a_out=None, mask_a_bits=None, colsum_lp=False, slope=0.0):
     """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
     Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
     column sums [R, H] of operand A|G (the bias gradient); colsum_lp: return them in out's dtype instead (bf16 output: written
@@ -288,13 +288,13 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
         if is_f32:
             check(lib().dn_rows_wgrad_f32(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                           ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out), int(colsum_of), ptr(colsum),
-                                          ptr(mask_a), ptr(a_out), 1 if F32_EXACT else 0, ptr(ws), ws.numel(), stream_ptr()),
+                                          ptr(mask_a), ptr(a_out), 1 if F32_EXACT else 0, float(slope), ptr(ws), ws.numel(), stream_ptr()),
                   "dn_rows_wgrad_f32")
         else:
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                            ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
                                            1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
-                                           ptr(a_out), ptr(mask_a_bits), ptr(colsum_lp), ptr(ws), ws.numel(), stream_ptr()),
+                                           ptr(a_out), ptr(mask_a_bits), ptr(colsum_lp), float(slope), ptr(ws), ws.numel(), stream_ptr()),
                   "dn_rows_wgrad_bf16")
 
     if kernel_timer is not None:
@@ -373,9 +373,11 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
 
 
 def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense",
-                   out=None, w_kn=False):
+                   out=None, w_kn=False, slope=0.0):
     """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16).
-    w_kn: Wn[r] is given [in][out] (the parameter's own layout; bf16 H = 256 ring kernel only) instead of [out][in]."""
+    w_kn: Wn[r] is given [in][out] (the parameter's own layout; bf16 H = 256 ring kernel only) instead of [out][in].
+    slope: `relu` / `mask_pos` as leaky ReLU (0 = ReLU): relu gives max(v, 0) + slope * min(v, 0), mask_pos multiplies by slope
+    instead of zeroing."""
     tiles, ntiles = tile_table
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
     assert X.dtype == Wn.dtype and X.dtype in (torch.bfloat16, torch.float32) and Wn.dim() == 3
@@ -393,11 +395,11 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
         n1 = X.shape[0] if X2 is not None else INT32_MAX
         if X.dtype == torch.float32:
             check(lib().dn_rows_transform_f32(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
-                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, stream_ptr()),
+                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, float(slope), stream_ptr()),
                   "dn_rows_transform_f32")
         else:
             check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
-                                               ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if w_kn else 0, stream_ptr()),
+                                               ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if w_kn else 0, float(slope), stream_ptr()),
                   "dn_rows_transform_bf16")
 
     if kernel_timer is not None:
@@ -461,7 +463,8 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
 CHAIN2_ENABLED = _os.environ.get("DN_CHAIN2", "1") != "0"
 
 
-def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=None, want_bits=False, w_kn=(False, False)):
+def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=None, want_bits=False, w_kn=(False, False),
+                slope=0.0):
     """(Y1, Y2[, bits1, bits2]) with Y1 = epi1(m0(x) @ W1n^T), Y2 = epi2(Y1 @ W2n^T) in one pass over the rows
     (dn_rows_chain2_bf16).  mask*_bits: uint8 [N, H/8] keep-masks (input / stage-1 output); want_bits: also return the
     "> 0" bit tensors of Y1 and Y2 (the ReLU masks the backward needs, 1/16 of the activations).  w_kn[i]: weight i is given
@@ -479,7 +482,8 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     def _launch():
         check(lib().dn_rows_chain2_bf16(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask0_bits), ptr(mask1_bits),
                                         ptr(W2n), ptr(b2), 1 if relu2 else 0, N, ptr(Y1), ptr(Y2), ptr(bits1), ptr(bits2),
-                                        (1 if w_kn[0] else 0) | (2 if w_kn[1] else 0), stream_ptr()), "dn_rows_chain2_bf16")
+                                        (1 if w_kn[0] else 0) | (2 if w_kn[1] else 0), float(slope), stream_ptr()),
+              "dn_rows_chain2_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_chain2", _launch)
     else:
@@ -1729,30 +1733,33 @@ class _LinearActFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-def relu_bwd(g, y):
-    """(y > 0) ? g : 0  (dn_relu_bwd_bf16)."""
+def relu_bwd(g, y, slope=0.0):
+    """(y > 0) ? g : slope * g  (dn_relu_bwd_bf16 / _f32; slope 0 = ReLU)."""
     require_gpu(g, y)
     out = torch.empty_like(g)
     fn = lib().dn_relu_bwd_f32 if g.dtype == torch.float32 else lib().dn_relu_bwd_bf16
-    check(fn(ptr(g), ptr(y), ptr(out), g.numel(), stream_ptr()), "dn_relu_bwd")
+    check(fn(ptr(g), ptr(y), ptr(out), g.numel(), float(slope), stream_ptr()), "dn_relu_bwd")
     return out
 
 
 class _ReluMlpFn(torch.autograd.Function):
-    """y_L = relu(lin_L(... relu(lin_1(x)))) with every Linear followed by ReLU (the reference MLP + final activation
-    when act_func == "relu", rgin.py:50-57,147-151).
-    Two layers in bf16 (the reference default): ONE forward launch (dn_rows_chain2_bf16) that also emits both ReLU masks
-    as bit tensors, and three backward launches: weight gradient of layer 2 (outer mask applied from its bits while the
-    rows are staged), the whole input-gradient chain (mask, dgrad 2, mask, dgrad 1), weight gradient of layer 1.
-    Otherwise: one fused Linear+bias+ReLU launch per layer forward; per layer backward a weight/bias-gradient launch and
-    an input-gradient launch whose epilogue applies the ReLU mask of the layer below."""
+    """y_L = act(lin_L(... act(lin_1(x)))) with every Linear followed by the activation -- ReLU (slope 0) or leaky ReLU (the
+    reference MLP + final activation, rgin.py:50-57,147-151, for act_func "relu" and for its CLI default "leaky_relu", slope
+    1 / 5.5: config.py:329-335, utils/act.py:466).
+    Two layers in bf16 (the reference default): ONE forward launch (dn_rows_chain2_bf16) that also emits both activation masks
+    as bit tensors (sign of the output = sign of the pre-activation for either activation), and three backward launches: weight
+    gradient of layer 2 (outer mask applied from its bits while the rows are staged), the whole input-gradient chain (mask,
+    dgrad 2, mask, dgrad 1), weight gradient of layer 1.
+    Otherwise: one fused Linear+bias+activation launch per layer forward; per layer backward a weight/bias-gradient launch and
+    an input-gradient launch whose epilogue applies the activation mask of the layer below."""
 
     @staticmethod
-    def forward(ctx, x, *wb):
+    def forward(ctx, x, slope, *wb):
         n = len(wb) // 2
         x = x.contiguous()
+        ctx.slope = slope = float(slope)
         if n == 2 and CHAIN2_ENABLED and x.dtype == torch.bfloat16:
-            h1, h2, bits1, bits2 = rows_chain2(x, wb[0], wb[1], True, wb[2], wb[3], True, want_bits=True)
+            h1, h2, bits1, bits2 = rows_chain2(x, wb[0], wb[1], True, wb[2], wb[3], True, want_bits=True, slope=slope)
             ctx.n, ctx.chain = n, True
             ctx.has_bias = [wb[1] is not None, wb[3] is not None]
             ctx.save_for_backward(x, h1, bits1, bits2, wb[0], wb[2])      # the output itself is not kept: only its sign bits
@@ -1762,7 +1769,7 @@ class _ReluMlpFn(torch.autograd.Function):
         for i in range(n):
             w, b = wb[2 * i], wb[2 * i + 1]
             acts.append(rows_transform(acts[-1], w.contiguous().unsqueeze(0), tiles, x.shape[0],
-                                       bias=None if b is None else b.contiguous().view(1, -1), relu=True))
+                                       bias=None if b is None else b.contiguous().view(1, -1), relu=True, slope=slope))
         ctx.n, ctx.chain = n, False
         ctx.has_bias = [wb[2 * i + 1] is not None for i in range(n)]
         ctx.save_for_backward(*acts, *[wb[2 * i] for i in range(n)])
@@ -1770,21 +1777,22 @@ class _ReluMlpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        n = ctx.n
+        n, slope = ctx.n, ctx.slope
         saved = ctx.saved_tensors
         g = gout.contiguous()
-        grads = [None] * (1 + 2 * n)
+        grads = [None] * (2 + 2 * n)
         if ctx.chain:
             x0, h1, bits1, bits2, w1, w2 = saved
             _, chunks = _dense_table(x0.shape[0], x0.device)
-            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a_bits=bits2, colsum_lp=True)
-            g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True))
+            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a_bits=bits2, colsum_lp=True, slope=slope)
+            g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True),
+                                 slope=slope)
             gw1, cs1 = rows_wgrad(g1, x0, chunks, 1, out_dtype=w1.dtype, colsum_of=1, colsum_lp=True)
-            grads[1], grads[3] = gw1[0], gw2[0]
+            grads[2], grads[4] = gw1[0], gw2[0]
             if ctx.has_bias[0]:
-                grads[2] = cs1[0].to(g.dtype)
+                grads[3] = cs1[0].to(g.dtype)
             if ctx.has_bias[1]:
-                grads[4] = cs2[0].to(g.dtype)
+                grads[5] = cs2[0].to(g.dtype)
             grads[0] = g0 if ctx.needs_input_grad[0] else None
             return tuple(grads)
         acts, ws = saved[:n + 1], saved[n + 1:]
@@ -1792,19 +1800,19 @@ class _ReluMlpFn(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             w = ws[i]
             if i == n - 1:
-                # outermost ReLU: masked while the rows are staged for the weight gradient, masked rows saved for the
+                # outermost activation: masked while the rows are staged for the weight gradient, masked rows saved for the
                 # input-gradient launch -- no separate elementwise pass
                 gm = torch.empty_like(g)
-                gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1, mask_a=acts[n], a_out=gm)
+                gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1, mask_a=acts[n], a_out=gm, slope=slope)
                 g = gm
             else:
                 gw, cs = rows_wgrad(g, acts[i], chunks, 1, out_dtype=w.dtype, colsum_of=1)   # g^T a_{i} ; colsum(g)
-            grads[1 + 2 * i] = gw[0]
+            grads[2 + 2 * i] = gw[0]
             if ctx.has_bias[i]:
-                grads[2 + 2 * i] = cs[0].to(g.dtype)
+                grads[3 + 2 * i] = cs[0].to(g.dtype)
             if i > 0 or ctx.needs_input_grad[0]:
                 g = rows_transform(g, w.t().contiguous().unsqueeze(0), tiles, g.shape[0],
-                                   mask_pos=acts[i] if i > 0 else None)                # masked for the ReLU below
+                                   mask_pos=acts[i] if i > 0 else None, slope=slope)   # masked for the activation below
         grads[0] = g if ctx.needs_input_grad[0] else None
         return tuple(grads)
 
@@ -1815,11 +1823,12 @@ def relu_mlp_supported(x, linears):
                     and x.shape[1] in (64, 128, 256) for l in linears))
 
 
-def relu_mlp(x, linears):
-    args = []
+def relu_mlp(x, linears, slope=0.0):
+    """act(lin_L(... act(lin_1(x)))) through _ReluMlpFn; slope 0 = ReLU, > 0 = leaky ReLU."""
+    wb = []
     for l in linears:
-        args += [l.weight, l.bias]
-    return _ReluMlpFn.apply(x, *args)
+        wb += [l.weight, l.bias]
+    return _ReluMlpFn.apply(x, float(slope), *wb)
 
 
 def linear_act(x, weight, bias=None, relu=False, exact=None):

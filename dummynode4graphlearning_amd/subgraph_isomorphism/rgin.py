@@ -14,6 +14,15 @@ from .init import init_weight
 NODEFEAT, EDGETYPE, NODEOUTPUT = "node_feat", "edge_type", "node_out"  # constants.py:26-35
 
 
+def _fused_slope(act):
+    """Negative-side slope of an activation the fused kernels implement (0 for ReLU), else None."""
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    return None
+
+
 def dense_relation_weights(layer):
     """[R, in, out] weights from the basis / block-diagonal parameterisation (rgin.py:103-108, 114-117)."""
     if layer.regularizer in ("none", "basis"):
@@ -133,13 +142,15 @@ class RGINLayer(nn.Module):
         return out, edge_type
 
     def _run_mlp(self, out):
-        """self.mlp(out), with every Linear (and a ReLU that follows it -- including the layer's final activation) sent
-        through the fused MFMA Linear+bias+ReLU kernel when the dtype/width allow it.  Returns (out, final_act_applied)."""
+        """self.mlp(out), with every Linear (and the ReLU / leaky ReLU that follows it -- including the layer's final activation)
+        sent through the fused MFMA Linear + bias + activation kernels when the dtype / width allow it: `relu` and the reference
+        CLI's default `leaky_relu` (slope 1 / 5.5, config.py:329-335) take the same launches.  Returns (out, final_act_applied)."""
         mods = list(self.mlp)
         linears = [m for m in mods if isinstance(m, nn.Linear)]
-        if (isinstance(self.act, nn.ReLU) and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in mods)
+        slope = _fused_slope(self.act)
+        if (slope is not None and all(isinstance(m, nn.Linear) or _fused_slope(m) == slope for m in mods)
                 and ops.relu_mlp_supported(out, linears)):
-            return ops.relu_mlp(out, linears), True                 # Linear-ReLU chain + final ReLU, fused end to end
+            return ops.relu_mlp(out, linears, slope), True          # Linear-act chain + final activation, fused end to end
         i, act_done = 0, False
         while i < len(mods):
             m = mods[i]

@@ -282,8 +282,9 @@ int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t st
  * launch then gives workgroup b the entries [b * tiles_per_workgroup, (b + 1) * tiles_per_workgroup)).  Every row of every
  * relation not in skip_mask is covered exactly once whatever the keys are (placement is a speed matter only).  When a group
  * needs more than tiles_per_workgroup slots the table holds the plain relation-major order instead (always valid provided
- * 8 * workgroups_per_group * tiles_per_workgroup >= rows / 32 + num_rels); info (may be NULL) receives {plain order taken, slots the
- * largest group needs}.  One launch, no host synchronisation.  Replaces nothing in the reference (DGL's update_all has no
+ * 8 * workgroups_per_group * tiles_per_workgroup >= rows / 32 + num_rels); info (may be NULL) receives {0: sweep order, 1: plain order taken, 2: plain
+ * order taken AND the table cannot hold all its tiles (8 * workgroups_per_group * tiles_per_workgroup < sum over relations of
+ * ceil(rows / 32)): rows would go untransformed, size the table as stated; slots the largest group needs}.  One launch, no host synchronisation.  Replaces nothing in the reference (DGL's update_all has no
  * notion of a traversal order, models/rgin.py:156-160): it is the order in which the replacement reads x. */
 int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out,
                               int64_t num_nodes, int32_t workgroups_per_group, int32_t tiles_per_workgroup, uint64_t skip_mask,
@@ -326,7 +327,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
                        const void* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                        const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, void* out,
                        int32_t out_is_f32, int32_t colsum_of, float* out_colsum, const void* mask_a, void* a_out,
-                       const void* mask_a_bits, void* out_colsum_lp, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                       const void* mask_a_bits, void* out_colsum_lp, float act_slope, void* workspace, size_t workspace_bytes,
+                       dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
@@ -338,11 +340,15 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
  * (subgraph_isomorphism/models/rgin.py:102-120, rgcn.py:100-122), its self-loop matmul (rgin.py:141) and, in the
  * backward direction (X = grad rows, Wn = W_r), autograd's transposed product.  Ho == Hi in {64, 128, 256}.
  * mask_pos (may be NULL): after epi, elements where mask_pos[p, n] <= 0 are zeroed.
+ * act_slope: the activation of `relu` / `mask_pos` generalised to leaky ReLU -- relu: max(v, 0) + act_slope * min(v, 0); mask_pos:
+ * elements whose saved activation is <= 0 are multiplied by act_slope instead of zeroed.  0 = ReLU; 1 / 5.5 = the reference's
+ * default `leaky_relu` (subgraph_isomorphism/utils/act.py:466, constants.py:10).  The same argument, with the same meaning for
+ * their ReLU flags / masks / mask bits, is taken by dn_rows_wgrad_*, dn_rows_chain2_bf16 and dn_relu_bwd_*.
  * w_kn != 0 (Hi == 256 with idx != NULL or X2 == NULL only, DN_ERR_UNSUPPORTED otherwise): Wn[r] is stored [k][n] -- the layout
  * of the reference's `weight` parameter (rgin.py:61-67), so the forward pass needs no transposed copy of the weights. */
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos,
-                           const int32_t* tiles, int64_t num_tiles, void* Y, int32_t w_kn, dn_stream_t stream);
+                           const int32_t* tiles, int64_t num_tiles, void* Y, int32_t w_kn, float act_slope, dn_stream_t stream);
 
 /* Closing launch of the row-factorised message pass (bf16 in, fp32 acc, bf16 out):
  *   out[v, :] = X[v, :] @ Wn^T (+ bias)  +  sum_{k < num_slots} Scat[slots[v * num_slots + k], :]
@@ -475,13 +481,13 @@ int dn_bdd_extract(const void* dense, int64_t R, int32_t B, int32_t si, int32_t 
  * transposed copies are made.  Y1 is written but never re-read.  H in {64, 128, 256}. */
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,
                         const void* mask1_bits, const void* W2n, const void* b2, int32_t relu2, int64_t N, void* Y1, void* Y2,
-                        void* bits1, void* bits2, int32_t w_kn, dn_stream_t stream);
+                        void* bits1, void* bits2, int32_t w_kn, float act_slope, dn_stream_t stream);
 
 /* ReLU backward of the post-aggregate MLP (act_func "relu": utils/act.py:463; applied at rgin.py:56,147-151):
  * out = (y > 0) ? g : 0 on bf16 tensors of `numel` elements (multiple of 8).  The same mask is available as the
  * `mask_pos` epilogue of dn_rows_transform_bf16 ([rows, Ho] saved activations), so a Linear's input gradient comes
  * out already masked for the ReLU in front of it. */
-int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_stream_t stream);
+int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, float act_slope, dn_stream_t stream);
 
 /* fp32 twins of the three entry points above: same semantics and argument meaning, float tensors, float partials /
  * outputs -- the path that keeps the reference's fp32 numerics (outputs within 1e-4) while still avoiding its [E,H,H]
@@ -492,13 +498,13 @@ int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, dn_
  *   1  exact f32 (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain): the checker. */
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos,
-                          const int32_t* tiles, int64_t num_tiles, float* Y, int32_t precision, dn_stream_t stream);
+                          const int32_t* tiles, int64_t num_tiles, float* Y, int32_t precision, float act_slope, dn_stream_t stream);
 int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G,
                       const float* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                       const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, float* out,
                       int32_t colsum_of, float* out_colsum, const float* mask_a, float* a_out, int32_t precision,
-                      void* workspace, size_t workspace_bytes, dn_stream_t stream);
-int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, dn_stream_t stream);
+                      float act_slope, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_relu_bwd_f32(const float* g, const float* y, float* out, int64_t numel, float act_slope, dn_stream_t stream);
 
 /* Relation-grouped dense products for ANY widths (what PyG's RGCNConv computes with a Python loop over relations,
  * `for i in range(num_relations): out += h @ weight[i]`; call sites graph_classification/graph_neural_networks/models/

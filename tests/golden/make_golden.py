@@ -754,6 +754,16 @@ def make_si_layers():
         meta.append(dict(tag=tag, kind=kind, input_dim=256, seed=1000 + cid, N=160, E=640, **kw))
         run(tag, cls, dict(kw), 160, 640, 256, 1000 + cid)
         cid += 1
+    # round 4: the reference CLI's DEFAULT configuration -- regulariser bdd with 4 bases, activation leaky_relu, hidden 64
+    # (subgraph_isomorphism/config.py:145-158, 329-335) -- plus the same activation with basis weights and at the benchmark width;
+    # appended behind every earlier case, so those regenerate bit for bit
+    for H_, R_, reg, nb, N_, E_ in ((64, 8, "bdd", 4, 500, 2000), (64, 8, "basis", -1, 500, 2000), (256, 4, "bdd", 4, 160, 640)):
+        tag = "rgin%02d" % cid
+        kw = dict(hidden_dim=H_, num_rels=R_, regularizer=reg, num_bases=nb, num_mlp_layers=2, self_loop=True,
+                  act_func="leaky_relu")
+        meta.append(dict(tag=tag, kind="rgin", input_dim=H_, seed=1000 + cid, N=N_, E=E_, **kw))
+        run(tag, rgin.RGINLayer, dict(kw), N_, E_, H_, 1000 + cid)
+        cid += 1
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "si_layers.npz"), **out)
     print("si_layers.npz: %d cases" % len(meta))

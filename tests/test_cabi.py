@@ -52,7 +52,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert L.dn_version() >= 100
     rc = L.dn_gather_segsum_f32(None, 0, 0, None, None, None, 0, 0, None, None, 0.0, 0, None)   # H == 0
     assert rc == -1 and b"H must be > 0" in L.dn_last_error()
-    rc = L.dn_rows_transform_bf16(None, None, 0x7fffffff, None, 100, 100, None, None, 0, None, None, 1, None, 0, None)
+    rc = L.dn_rows_transform_bf16(None, None, 0x7fffffff, None, 100, 100, None, None, 0, None, None, 1, None, 0, 0.0, None)
     assert rc == -1 and b"unsupported widths" in L.dn_last_error()
     rc = L.dn_conjugate_build_i32(7, 0, 0, 0, 0, *([None] * 13), (ctypes.c_int64 * 2)(), None, 0, None)
     assert rc == -1 and b"bad mode" in L.dn_last_error()
