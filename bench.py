@@ -283,6 +283,10 @@ def main():
                     help="profiling aid: the replayed step and the roofline leg only (no fresh-batch leg, GIN leg, proxy, CPU baseline)")
     ap.add_argument("--dtype", default="", choices=["", "bf16", "f32"])
     ap.add_argument("--hidden", type=int, default=0, help="override the workload's hidden size (experiments only)")
+    ap.add_argument("--act", default="relu", choices=["relu", "leaky_relu"],
+                    help="activation of the layer's MLP (the reference CLI's default is leaky_relu, config.py:329-335)")
+    ap.add_argument("--regularizer", default="basis", choices=["basis", "bdd"],
+                    help="relation-weight parameterisation (the reference CLI's default is bdd with 4 bases, config.py:145-158)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
@@ -334,7 +338,8 @@ def main():
     N, E = g.number_of_nodes(), g.number_of_edges()
     etype = g.edata["label"]
     torch.manual_seed(1234)
-    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(dev).to(dtype)
+    layer = RGINLayer(H, H, num_rels=R, regularizer=args.regularizer, num_bases=4 if args.regularizer == "bdd" else -1,
+                      num_mlp_layers=2, act_func=args.act).to(dev).to(dtype)
     bucket = FlatGradBucket(layer.parameters())
 
     fused = H in (64, 128, 256)                 # row-factorised MFMA pipeline (bf16 and exact-f32) vs generic two-pass path
@@ -490,7 +495,8 @@ def main():
     # HIP events on the launch stream
     def conv_gather_scatter():
         with torch.no_grad():
-            W = layer.weight
+            from dummynode4graphlearning_amd.subgraph_isomorphism.rgin import dense_relation_weights
+            W = dense_relation_weights(layer)                       # (basis with num_bases == R: the parameter itself)
             if fused:
                 # exactly what _RowTransformFn issues: the forward pass on the parameters as they are stored ([k][n]: no cat /
                 # transpose launches at H = 256 bf16), the input-gradient pass on W itself
@@ -607,8 +613,8 @@ def main():
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,basis) fwd+bwd, %s (rank 0: N=%d, E=%d), SI dummy augmentation"
-                                   % (args.workload, H, H, R,
+            "config": {"workload": "%s: RGINLayer(%d,%d,R=%d,%s,%s) fwd+bwd, %s (rank 0: N=%d, E=%d), SI dummy augmentation"
+                                   % (args.workload, H, H, R, args.regularizer, args.act,
                                       ("ONE global batch of %d graphs cut by parallel.shard_graphs over %d GPU(s)" % (graphs, world))
                                       if strong else ("%d graphs per GPU" % graphs), N, E),
                        "global_edges": int(e_glob), "parallelism": "dp%d" % world,

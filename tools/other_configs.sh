@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for args in "--workload config3" "--workload config3 --dtype bf16" "--workload config4" "--dtype f32 --no-proxy"; do
+for args in "--workload config3" "--workload config3 --act leaky_relu --regularizer bdd" "--workload config3 --dtype bf16" "--workload config3 --dtype bf16 --act leaky_relu --regularizer bdd" "--act leaky_relu --regularizer bdd --no-proxy" "--workload config4" "--dtype f32 --no-proxy"; do
   echo "== bench.py $args"
   timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $args 2>gpurun_out/oc.err | python -c "
 import sys, json
