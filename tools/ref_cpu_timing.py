@@ -37,7 +37,7 @@ def best(fn, n=3):
     return min(ts)
 
 
-def si_rgin(cfg, H, regularizer, num_bases):
+def si_rgin(cfg, H, regularizer, num_bases, act="relu"):
     SI = os.path.join(REF, "subgraph_isomorphism")
     sys.path.insert(0, SI)
     if "models" not in sys.modules:
@@ -50,7 +50,7 @@ def si_rgin(cfg, H, regularizer, num_bases):
                               raw["max_nv"], raw["max_nvl"], raw["max_ne"], raw["max_nel"])
     N, E, R = len(aug["node_label"]), len(aug["src"]), raw["num_rels"]
     th.manual_seed(0)
-    layer = rgin.RGINLayer(H, H, num_rels=R, regularizer=regularizer, num_bases=num_bases, num_mlp_layers=2, act_func="relu")
+    layer = rgin.RGINLayer(H, H, num_rels=R, regularizer=regularizer, num_bases=num_bases, num_mlp_layers=2, act_func=act)
     g = S.FakeDGLGraph(aug["src"], aug["dst"], N)
     x = th.randn(N, H, requires_grad=True)
     et = th.from_numpy(aug["edge_label"])
@@ -95,6 +95,6 @@ if __name__ == "__main__":
     print("config 1  GIN 3-layer H=64 model step (32 MUTAG-shaped dummy graphs, N=%d, E=%d): %.2f ms -> %.2f M edges/s" % (N, E, t * 1e3, E / t / 1e6))
     N, E, t = gc_gin(synthetic.config2, 5, 128, 3, 2)
     print("config 2  GIN 2-layer H=128 model step (512 PROTEINS-shaped dummy graphs, N=%d, E=%d): %.1f ms -> %.2f M edges/s" % (N, E, t * 1e3, E / t / 1e6))
-    for reg, nb in (("basis", -1), ("bdd", 4)):
-        N, E, t = si_rgin(synthetic.config3, 64, reg, nb)
-        print("config 3  RGINLayer H=64 R=8 %s fwd+bwd (N=%d, E=%d): %.0f ms -> %.3f M edges/s" % (reg, N, E, t * 1e3, E / t / 1e6))
+    for reg, nb, act in (("basis", -1, "relu"), ("bdd", 4, "relu"), ("bdd", 4, "leaky_relu")):
+        N, E, t = si_rgin(synthetic.config3, 64, reg, nb, act)
+        print("config 3  RGINLayer H=64 R=8 %s %s fwd+bwd (N=%d, E=%d): %.0f ms -> %.3f M edges/s" % (reg, act, N, E, t * 1e3, E / t / 1e6))
