@@ -27,19 +27,23 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for d in ("f", "b"):
     cu = ix.close_units(d)
     fold = ops._row_index_fold(ix, d, "units")
-    part = torch.empty((fold.num_parts, H), dtype=torch.float32, device=dev) if fold is not None else None
-    seg = (fold.fold_info, part) if fold is not None else None
+    seg = agg = None
+    if fold is not None and cu.agg:          # absorbed fold: AGG units at the end of every workgroup's stream
+        aux = torch.empty((fold.n, H), dtype=x.dtype, device=dev)
+        agg = (fold.graph_tiles[1], W, aux, fold.add_idx)
+    elif fold is not None:
+        seg = (fold.fold_info, torch.empty((fold.num_parts, H), dtype=torch.float32, device=dev))
     nu = int(cu.unit_ptr[-1])
-    print("direction %s: %d units for %d tiles (%.2f per tile), fold %s" % (d, nu, (N + 31) // 32, nu / ((N + 31) // 32), fold is not None))
+    print("direction %s: %d units for %d tiles (%.2f per tile), fold %s" % (d, nu, cu.num_tiles, nu / cu.num_tiles, "absorbed" if agg else ("partial rows" if seg else "none")))
 
     def timed(abl, reps=20):
         os.environ["DN_CLOSE_ABL"] = str(abl)
         for _ in range(3):
-            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True)
+            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True, agg=agg)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True)
+            ops.rows_close(x, W, None, Y, cu, out=out, seg=seg, w_kn=True, agg=agg)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
