@@ -81,7 +81,7 @@ _SIGS = {
     "dn_fold_tables_workspace_bytes": (c_sz, [c_i64]),
     "dn_fold_tables_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, ctypes.POINTER(ctypes.c_int32), P, c_sz, P]),
     "dn_fold_tail_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, c_i32, P]),
-    "dn_rows_transform_f32": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, c_f32, P]),
+    "dn_rows_transform_f32": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, c_f32, P, c_i32, c_i32, c_i32, P]),
     "dn_rows_wgrad_f32": (ctypes.c_int, [P, P, c_i32, P, P, P, c_i32, P, c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P,
                                          c_i32, c_f32, P, c_sz, P]),
     "dn_relu_bwd_f32": (ctypes.c_int, [P, P, P, c_i64, c_f32, P]),

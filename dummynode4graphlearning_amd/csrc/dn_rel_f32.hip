@@ -58,6 +58,22 @@ __device__ __forceinline__ bf16x8 tr_frag16(const bf16_t* tile, int stride, int 
 constexpr int kThreads = 512;
 constexpr int kRows = 32;
 
+// Where a tile's weight matrix and bias row live (dn_rows_transform_f32): relation `loop_rel` reads W_loop instead of Wn[rel]
+// (the layer's self-loop parameter, rgin.py:66-67, no concatenated copy); kn = the matrices are [k][n] (parameter layout);
+// bias_rel >= 0: `bias` is ONE row [H] that only tiles of that relation add (rgin.py:146), < 0: one row per relation.
+struct WeightForm {
+    const float* W_loop;
+    int32_t loop_rel, bias_rel, kn;
+    __device__ __forceinline__ const float* matrix(const float* Wn, int rel, int H) const {
+        return rel == loop_rel ? W_loop : Wn + (size_t)rel * H * H;
+    }
+    __device__ __forceinline__ const float* bias_row(const float* bias, int rel, int H) const {
+        if (bias == nullptr) return nullptr;
+        if (bias_rel < 0) return bias + (size_t)rel * H;
+        return rel == bias_rel ? bias : nullptr;
+    }
+};
+
 struct Chunk {
     int32_t rel, beg, end, pad;
 };
@@ -381,7 +397,7 @@ template <int H>
 __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, float slope, const float* __restrict__ mask_pos,
-    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
+    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y, WeightForm wform) {
     constexpr int S = H + 4;                                    // 16-byte row pad: conflict-free ds_read_b128 fragments
     constexpr int KB = H / 16;                                  // 16-wide k blocks (4 MFMA steps each)
     constexpr int NT = (H / 8 + 15) / 16;
@@ -443,13 +459,18 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
         if (t + 1 < t_end) load_rows();
         if (tl.rel != cur_rel && wave_active) {
             cur_rel = tl.rel;
-            const float* w = Wn + (size_t)cur_rel * H * H;
+            const float* w = wform.matrix(Wn, cur_rel, H);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wf[kb][nt] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * H + kb * 16 +
-                                                                  4 * (lane >> 4));
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + nt * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4);
+                    if (wform.kn)                               // [k][n] as the parameter is stored: 16 lanes share a 64-byte run
+                        wf[kb][nt] = make_float4(w[(size_t)k * H + n], w[(size_t)(k + 1) * H + n], w[(size_t)(k + 2) * H + n],
+                                                 w[(size_t)(k + 3) * H + n]);
+                    else
+                        wf[kb][nt] = *reinterpret_cast<const float4*>(w + (size_t)n * H + k);
+                }
         }
         if (wave_active) {
             f32x4 acc[MT][NT];
@@ -479,8 +500,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32_kernel(
                 for (int n = 0; n < NT; ++n) {
                     const int col = n0 + n * 16 + 4 * (lane >> 4);
                     float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-                    if (bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
+                    if (const float* brow = wform.bias_row(bias, cur_rel, H)) {
+                        const float4 bv = *reinterpret_cast<const float4*>(brow + col);
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
                     if (relu) { v.x = dn_act(v.x, slope); v.y = dn_act(v.y, slope); v.z = dn_act(v.z, slope); v.w = dn_act(v.w, slope); }
@@ -514,7 +535,7 @@ template <int H>
 __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, int32_t n1, const int32_t* __restrict__ idx,
     const float* __restrict__ Wn, const float* __restrict__ bias, int32_t relu, float slope, const float* __restrict__ mask_pos,
-    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y) {
+    const Chunk* __restrict__ tiles, int32_t num_tiles, int32_t tiles_per_wg, float* __restrict__ Y, WeightForm wform) {
     constexpr int SX = H + 8;                                   // bf16 elements per LDS row of an input tile
     constexpr int SY = H + 4;                                   // floats per LDS row of the output tile
     constexpr int KS = H / 32;
@@ -580,13 +601,20 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
         if (t + 1 < t_end) load_rows();
         if (tl.rel != cur_rel && wave_active) {
             cur_rel = tl.rel;
-            const float* w = Wn + (size_t)cur_rel * H * H;
+            const float* w = wform.matrix(Wn, cur_rel, H);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float* wp = w + (size_t)(n0 + nt * 16 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4);
-                    split8(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wh[ks][nt], wl[ks][nt]);
+                    const int n = n0 + nt * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4);
+                    if (wform.kn) {                             // [k][n] as the parameter is stored: 16 lanes share a 64-byte run
+                        const float* wp = w + (size_t)k * H + n;
+                        split8(make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]),
+                               make_float4(wp[4 * H], wp[5 * H], wp[6 * H], wp[7 * H]), wh[ks][nt], wl[ks][nt]);
+                    } else {
+                        const float* wp = w + (size_t)n * H + k;
+                        split8(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wh[ks][nt], wl[ks][nt]);
+                    }
                 }
         }
         if (wave_active) {
@@ -620,8 +648,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
                 for (int n = 0; n < NT; ++n) {
                     const int col = n0 + n * 16 + 4 * (lane >> 4);
                     float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-                    if (bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias + (size_t)cur_rel * H + col);
+                    if (const float* brow = wform.bias_row(bias, cur_rel, H)) {
+                        const float4 bv = *reinterpret_cast<const float4*>(brow + col);
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
                     if (relu) { v.x = dn_act(v.x, slope); v.y = dn_act(v.y, slope); v.z = dn_act(v.z, slope); v.w = dn_act(v.w, slope); }
@@ -675,16 +703,16 @@ int launch_wgrad(const float* A, const float* A2, int32_t na1, const int32_t* ia
 template <int H>
 int launch_transform(const float* X, const float* X2, int32_t n1, const int32_t* idx, const float* Wn, const float* bias,
                      int32_t relu, float slope, const float* mask_pos, const Chunk* tiles, int64_t num_tiles, float* Y, int32_t exact,
-                     hipStream_t st) {
+                     WeightForm wform, hipStream_t st) {
     const int64_t max_wg = 256 * (H == 256 ? 1 : 2);             // LDS: one 100 KB workgroup per CU at H = 256
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, max_wg);
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
     if (exact)
         hipLaunchKernelGGL((rows_transform_f32_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y, wform);
     else
         hipLaunchKernelGGL((rows_transform_f32s_kernel<H>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, X2, n1, idx, Wn, bias,
-                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y);
+                           relu, slope, mask_pos, tiles, (int32_t)num_tiles, (int32_t)tiles_per_wg, Y, wform);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -749,22 +777,26 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
 
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos, const int32_t* tiles,
-                          int64_t num_tiles, float* Y, int32_t precision, float act_slope, dn_stream_t stream) {
+                          int64_t num_tiles, float* Y, int32_t precision, float act_slope, const float* W_loop, int32_t loop_rel,
+                          int32_t bias_rel, int32_t w_kn, dn_stream_t stream) {
     DN_REQUIRE(num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_transform_f32: bad tile count");
     DN_REQUIRE(precision == 0 || precision == 1, "dn_rows_transform_f32: precision must be 0 (bf16 split) or 1 (exact f32)");
     DN_REQUIRE(Hi == Ho && (Hi == 64 || Hi == 128 || Hi == 256), "dn_rows_transform_f32: unsupported widths %d x %d "
                "(square 64/128/256 only)", Hi, Ho);
     if (num_tiles == 0) return DN_OK;
     DN_REQUIRE(X && Wn && tiles && Y, "dn_rows_transform_f32: NULL pointer");
+    DN_REQUIRE(W_loop != nullptr || loop_rel < 0, "dn_rows_transform_f32: loop_rel >= 0 needs W_loop");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(W_loop) % 16 == 0, "dn_rows_transform_f32: unaligned pointer");
+    const WeightForm wform{W_loop, W_loop ? loop_rel : -1, bias_rel, w_kn ? 1 : 0};
     DN_REQUIRE(X2 != nullptr || n1 == 0x7fffffff, "dn_rows_transform_f32: X2 == NULL requires n1 == INT32_MAX");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Wn) |
                 reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(mask_pos)) % 16 == 0,
                "dn_rows_transform_f32: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const Chunk* tl = reinterpret_cast<const Chunk*>(tiles);
-    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
-    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
-    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, st);
+    if (Hi == 256) return launch_transform<256>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, wform, st);
+    if (Hi == 128) return launch_transform<128>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, wform, st);
+    return launch_transform<64>(X, X2, n1, idx, Wn, bias, relu, act_slope, mask_pos, tl, num_tiles, Y, precision, wform, st);
 }
 
 }  // extern "C"

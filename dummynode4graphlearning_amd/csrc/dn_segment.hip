@@ -246,6 +246,84 @@ __global__ __launch_bounds__(kBlock) void gather_segsum_vec1_kernel(
         }
     }
 }
+// Few, long segments (the pre-aggregation of a collapsed dummy relation on a small batch: ~500 lists of ~50 rows): one
+// WORKGROUP per segment.  Its GPB lane groups take the entries beg + group, beg + group + GPB, ... -- all rows of a ~50-row
+// list are in flight after two dependent round trips (bounds -> indices -> rows) instead of a dozen -- and group 0 adds the GPB
+// partial sums in a fixed order (bit-reproducible).
+template <typename T, int LPR, bool HAS_SCALE>
+__global__ __launch_bounds__(kBlock) void gather_segsum_block_kernel(
+    const T* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+    const int32_t* __restrict__ ptr, int64_t S, int32_t H, T* __restrict__ out, const T* __restrict__ self_in,
+    float self_coef, int32_t mean) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int GPB = kBlock / LPR;
+    constexpr int KU = 4;
+    __shared__ float part[GPB][LPR * VN + 1];
+    const int lane = threadIdx.x % LPR;
+    const int group = threadIdx.x / LPR;
+    const int64_t s = blockIdx.x;
+    if (s >= S) return;
+    const int beg = ptr[s], end = ptr[s + 1];
+    for (int col0 = 0; col0 < H; col0 += LPR * VN) {
+        const int col = col0 + lane * VN;
+        const bool colok = col < H;
+        float acc[VN];
+#pragma unroll
+        for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+        for (int e0 = beg + group; e0 < end; e0 += GPB * KU) {
+            int r[KU];
+            float w[KU];
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int e = e0 + k * GPB;
+                r[k] = e < end ? (idx != nullptr ? idx[e] : e) : -1;
+                w[k] = (HAS_SCALE && e < end) ? scale[e] : 1.f;
+            }
+            float v[KU][VN];
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                if (r[k] >= 0 && colok) {
+                    Vec<T>::load(in + (size_t)r[k] * H + col, v[k]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) v[k][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+#pragma unroll
+                for (int i = 0; i < VN; ++i) {
+                    if (HAS_SCALE) acc[i] = fmaf(w[k], v[k][i], acc[i]);
+                    else acc[i] += v[k][i];
+                }
+            }
+        }
+        if (col0 > 0) __syncthreads();                        // the previous pass's partials have been read
+#pragma unroll
+        for (int i = 0; i < VN; ++i) part[group][lane * VN + i] = acc[i];
+        __syncthreads();
+        if (group == 0 && colok) {
+#pragma unroll 4
+            for (int g = 1; g < GPB; ++g) {
+#pragma unroll
+                for (int i = 0; i < VN; ++i) acc[i] += part[g][lane * VN + i];
+            }
+            if (mean) {
+                const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+#pragma unroll
+                for (int i = 0; i < VN; ++i) acc[i] *= inv;
+            }
+            if (self_in != nullptr) {
+                float sv[VN];
+                Vec<T>::load(self_in + (size_t)s * H + col, sv);
+#pragma unroll
+                for (int i = 0; i < VN; ++i) acc[i] = fmaf(self_coef, sv[i], acc[i]);
+            }
+            Vec<T>::store(out + (size_t)s * H + col, acc);
+        }
+    }
+}
+
 // Scalar path: any H (one element per lane per pass); used for narrow / unaligned rows
 // (e.g. the [N, num_classes] readout of gconv.py:210).
 template <typename T, int LPR, bool HAS_SCALE>
@@ -287,6 +365,18 @@ int launch_lpr(const T* in, const int32_t* idx, const float* scale, const int32_
     // graph) keep the simple kernel; short graph-local lists take the form that is pipelined across segments
     static const int force = dn_knob("DN_GATHER_V1", -1);
     const bool use_v1 = force >= 0 ? force != 0 : (ptr != nullptr && S > 0 && M / S >= 16);
+    // few long lists: a workgroup per segment (the chip is empty otherwise: S / (GPB * kSegsPerGroup) workgroups)
+    static const int block_max = dn_knob("DN_GATHER_BLOCK", 8192);
+    if constexpr (VECP) if (ptr != nullptr && S > 0 && S <= block_max && M / S >= 24) {
+        if (scale != nullptr)
+            hipLaunchKernelGGL((gather_segsum_block_kernel<T, LPR, true>), dim3((unsigned)S), dim3(kBlock), 0, st, in, idx, scale, ptr,
+                               S, H, out, self_in, self_coef, mean);
+        else
+            hipLaunchKernelGGL((gather_segsum_block_kernel<T, LPR, false>), dim3((unsigned)S), dim3(kBlock), 0, st, in, idx, scale, ptr,
+                               S, H, out, self_in, self_coef, mean);
+        DN_CHECK_LAUNCH();
+        return DN_OK;
+    }
     const int64_t nchunks = dn_cdiv(S, (int64_t)GPB * kSegsPerGroup);
     const int64_t grid = dn_cdiv(nchunks, DN_NUM_XCD) * DN_NUM_XCD;
     if (grid > 0x7fffffffLL) { dn_set_error("dn_gather_segsum: grid too large"); return DN_ERR_ARG; }

@@ -373,16 +373,20 @@ def make_row_tiles(rel_ptr_host, device, tile_rows=32):
 
 
 def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, relu=False, mask_pos=None, tag="dense",
-                   out=None, w_kn=False, slope=0.0):
-    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16).
-    w_kn: Wn[r] is given [in][out] (the parameter's own layout; bf16 H = 256 ring kernel only) instead of [out][in].
-    slope: `relu` / `mask_pos` as leaky ReLU (0 = ReLU): relu gives max(v, 0) + slope * min(v, 0), mask_pos multiplies by slope
-    instead of zeroing."""
+                   out=None, w_kn=False, slope=0.0, W_loop=None, loop_rel=-1, bias_rel=-1):
+    """Y[p] = epi(Xcat[idx[p]] @ Wn[rel(p)]^T), zeroed where mask_pos[p] <= 0  (dn_rows_transform_bf16 / _f32).
+    w_kn: Wn[r] is given [in][out] (the parameter's own layout; the bf16 H = 256 ring kernel and the fp32 kernels) instead of
+    [out][in].  slope: `relu` / `mask_pos` as leaky ReLU (0 = ReLU): relu gives max(v, 0) + slope * min(v, 0), mask_pos
+    multiplies by slope instead of zeroing.  fp32 only: W_loop [H, H] serves the tiles of relation `loop_rel` (the self-loop
+    parameter, not concatenated behind Wn); bias_rel >= 0: `bias` is one row [H] added to that relation's tiles only."""
     tiles, ntiles = tile_table
-    require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos)
+    require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos, W_loop)
     assert X.dtype == Wn.dtype and X.dtype in (torch.bfloat16, torch.float32) and Wn.dim() == 3
     assert bias is None or bias.dtype == X.dtype
-    assert not w_kn or (X.dtype == torch.bfloat16 and Wn.shape[1] == Wn.shape[2] == 256)
+    assert not w_kn or X.dtype == torch.float32 or Wn.shape[1] == Wn.shape[2] == 256
+    assert (W_loop is None and bias_rel < 0) or X.dtype == torch.float32
+    assert W_loop is None or (W_loop.dtype == X.dtype and W_loop.shape == Wn.shape[1:] and W_loop.is_contiguous() and loop_rel >= 0)
+    assert Wn.is_contiguous() and (bias is None or bias.is_contiguous())
     Ho, Hi = Wn.shape[1], Wn.shape[2]
     assert X.shape[1] == Hi
     if out is None:
@@ -395,7 +399,9 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
         n1 = X.shape[0] if X2 is not None else INT32_MAX
         if X.dtype == torch.float32:
             check(lib().dn_rows_transform_f32(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
-                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, float(slope), stream_ptr()),
+                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, float(slope),
+                                              ptr(W_loop), int(loop_rel) if W_loop is not None else -1, int(bias_rel),
+                                              1 if w_kn else 0, stream_ptr()),
                   "dn_rows_transform_f32")
         else:
             check(lib().dn_rows_transform_bf16(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
@@ -1483,7 +1489,10 @@ class PassWeights:
 
 
 def _kn_ok(xs):
-    """The launches that take [k][n] weights: bf16 H = 256 (ring transform, unit-stream closing launch, fold tail)."""
+    """The launches that take [k][n] weights: bf16 H = 256 (ring transform, unit-stream closing launch, fold tail) and the
+    fp32 transform (any of its widths; it also takes the self-loop matrix and the bias where the parameters lie)."""
+    if xs.dtype == torch.float32:
+        return xs.shape[1] in (64, 128, 256)
     return xs.dtype == torch.bfloat16 and xs.shape[1] == 256 and CLOSE_RING_ENABLED
 
 
@@ -1529,7 +1538,8 @@ def message_pass(xs, pw, bias, ix, direction, ybuf, out):
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
-    if pw.kn and not (_kn_ok(xs) and _selfsum_ok(ix, xs)):
+    f32_direct = xs.dtype == torch.float32 and _kn_ok(xs) and pw.rel.shape[1] == pw.rel.shape[2]
+    if pw.kn and not (f32_direct or (_kn_ok(xs) and _selfsum_ok(ix, xs))):
         pw = pw.nk()
     if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction, _close_kind(xs)) is not None:
         return _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows)
@@ -1539,6 +1549,14 @@ def message_pass(xs, pw, bias, ix, direction, ybuf, out):
         Y = (rows_transform(xs, pw.rel, ix.edge_tile_table, P, idx=idx_rows, X2=aux, tag="conv", out=ybuf, w_kn=pw.kn)
              if P else ybuf[:0])
         _closing_launch(xs, pw.loop, bias, Y[:P], ix, direction, out, w_kn=pw.kn)
+        return aux
+    if f32_direct:
+        # fp32: the transform reads weight / loop_weight / h_bias where the parameters lie (no cat, no transposed copy, no padded
+        # bias matrix); the self-loop rows are relation R of the tile table
+        R = pw.rel.shape[0]
+        Y = rows_transform(xs, pw.rel, ix.tile_table, ix.num_rows, idx=idx_rows, X2=aux, bias=bias, tag="conv", out=ybuf,
+                           w_kn=pw.kn, W_loop=pw.loop, loop_rel=R, bias_rel=R if bias is not None else -1)
+        gather_segsum(Y, lst, lptr, ix.num_nodes, out=out)
         return aux
     Wmat = pw.all_nk()
     bias_all = None
@@ -1729,7 +1747,8 @@ class _LinearActFn(torch.autograd.Function):
             if ctx.has_bias:
                 gb = cs[0].to(g.dtype)
         if ctx.needs_input_grad[0]:
-            gx = rows_transform(g, weight.t().contiguous().unsqueeze(0), tiles, x.shape[0])  # g @ weight
+            kn = g.dtype == torch.float32                       # the fp32 kernels read Linear.weight [out = k][in = n] as it is
+            gx = rows_transform(g, (weight if kn else weight.t()).contiguous().unsqueeze(0), tiles, x.shape[0], w_kn=kn)  # g @ weight
         return gx, gw, gb, None
 
 
@@ -1811,8 +1830,9 @@ class _ReluMlpFn(torch.autograd.Function):
             if ctx.has_bias[i]:
                 grads[3 + 2 * i] = cs[0].to(g.dtype)
             if i > 0 or ctx.needs_input_grad[0]:
-                g = rows_transform(g, w.t().contiguous().unsqueeze(0), tiles, g.shape[0],
-                                   mask_pos=acts[i] if i > 0 else None, slope=slope)   # masked for the activation below
+                kn = g.dtype == torch.float32                   # fp32 kernels read Linear.weight [out = k][in = n] as it is
+                g = rows_transform(g, (w if kn else w.t()).contiguous().unsqueeze(0), tiles, g.shape[0],
+                                   mask_pos=acts[i] if i > 0 else None, slope=slope, w_kn=kn)   # masked for the activation below
         grads[0] = g if ctx.needs_input_grad[0] else None
         return tuple(grads)
 

@@ -495,10 +495,18 @@ int dn_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t numel, flo
  *   0  3-term bf16 split on the fast matrix path: operands cut into hi = bf16(x), lo = bf16(x - hi) as they are staged,
  *      products evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with f32 accumulation (O(2^-16) relative
  *      per product, 1e-5-level agreement with the reference; 3/16 of the exact path's matrix time);
- *   1  exact f32 (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain): the checker. */
+ *   1  exact f32 (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain): the checker.
+ * dn_rows_transform_f32 reads the layer's parameters where they lie (rgin.py:61-67: weight [R, in, out], loop_weight
+ * [in, out], h_bias [out]), so a step needs no concatenated / transposed weight copy and no padded bias matrix:
+ *   W_loop / loop_rel  tiles of relation `loop_rel` use the matrix W_loop instead of Wn[loop_rel] (loop_rel < 0 or W_loop
+ *                      NULL: every relation indexes Wn);
+ *   bias_rel           >= 0: `bias` is ONE row [Ho] that only tiles of that relation add (the self-loop rows, rgin.py:146);
+ *                      < 0: `bias` is [R, Ho], one row per relation (as dn_rows_transform_bf16);
+ *   w_kn               1: every matrix is [k = in][n = out] (parameter layout), 0: [n][k]. */
 int dn_rows_transform_f32(const float* X, const float* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                           const float* Wn, const float* bias, int32_t relu, const float* mask_pos,
-                          const int32_t* tiles, int64_t num_tiles, float* Y, int32_t precision, float act_slope, dn_stream_t stream);
+                          const int32_t* tiles, int64_t num_tiles, float* Y, int32_t precision, float act_slope,
+                          const float* W_loop, int32_t loop_rel, int32_t bias_rel, int32_t w_kn, dn_stream_t stream);
 int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_t* idx_a, const float* G,
                       const float* G2, int32_t ng1, const int32_t* idx_g, int32_t Hi, int32_t Ho, int64_t R,
                       const int32_t* chunks, int64_t num_chunks, const int32_t* chunk_ptr, float* out,

@@ -257,6 +257,75 @@ def test_rows_transform_matches_reference(H, arith):
             torch.testing.assert_close(got[sel.to(DEV)].cpu().double(), ref_r, **tol)
 
 
+@pytest.mark.parametrize("H", [64, 128, 256])
+@pytest.mark.parametrize("exact", [False, True])
+def test_fp32_transform_on_the_parameters_where_they_lie(H, exact):
+    """dn_rows_transform_f32 with weight [R, in, out] / loop_weight [in, out] / h_bias [out] read in place (w_kn, W_loop /
+    loop_rel, bias_rel) gives the SAME BITS as the concatenated + transposed weight copy and the padded bias matrix it replaces."""
+    ops = _ops()
+    rng = np.random.default_rng(77 + H)
+    sizes = [129, 0, 65, 700, 31, 260]                          # the last relation is the self loop
+    rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
+    R, P, N1 = len(sizes) - 1, rel_ptr[-1], 500
+    X = torch.from_numpy(rng.standard_normal((N1, H)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.standard_normal((R, H, H)) / np.sqrt(H)).astype(np.float32)).to(DEV)          # [R, in, out]
+    W_loop = torch.from_numpy((rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)).to(DEV)       # [in, out]
+    bias = torch.from_numpy(rng.standard_normal(H).astype(np.float32)).to(DEV)
+    idx = torch.from_numpy(rng.integers(0, N1, size=P)).to(torch.int32).to(DEV)
+    tiles = ops.make_row_tiles(rel_ptr, DEV)
+    W_all = torch.cat([W, W_loop.unsqueeze(0)], 0).transpose(1, 2).contiguous()                           # [R + 1, out, in]
+    bias_all = torch.zeros((R + 1, H), device=DEV)
+    bias_all[-1] = bias
+    with ops.f32_exact(exact):
+        want = ops.rows_transform(X, W_all, tiles, P, idx=idx, bias=bias_all, relu=True, slope=0.25)
+        got = ops.rows_transform(X, W, tiles, P, idx=idx, bias=bias, relu=True, slope=0.25, w_kn=True, W_loop=W_loop, loop_rel=R,
+                                 bias_rel=R)
+        assert torch.equal(got, want)
+        # [n][k] matrices with a separate loop matrix (the input-gradient pass), no bias
+        want = ops.rows_transform(X, torch.cat([W, W_loop.unsqueeze(0)], 0), tiles, P, idx=idx)
+        got = ops.rows_transform(X, W, tiles, P, idx=idx, W_loop=W_loop, loop_rel=R)
+        assert torch.equal(got, want)
+    ref = torch.einsum("pk,pkn->pn", X[idx.long()].double().cpu(),
+                       torch.cat([W, W_loop.unsqueeze(0)], 0).double().cpu()[torch.repeat_interleave(torch.arange(R + 1), torch.tensor(sizes))])
+    with ops.f32_exact(exact):
+        got = ops.rows_transform(X, W, tiles, P, idx=idx, w_kn=True, W_loop=W_loop, loop_rel=R)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("H", [8, 64, 128, 256, 520])
+def test_gather_segsum_over_few_long_lists(dtype, tol, H):
+    """The workgroup-per-segment form (few segments of >= 24 rows on average: the pre-aggregation of a collapsed dummy relation on
+    a small batch), incl. empty and very long lists, scale / mean / self term, and bitwise reproducibility."""
+    ops = _ops()
+    rng = np.random.default_rng(900 + H)
+    rows, S = 4000, 301
+    deg = rng.integers(20, 80, size=S)
+    deg[[0, 17, S - 1]] = 0
+    deg[5] = 1500
+    deg[6] = 1
+    ptr = np.zeros(S + 1, dtype=np.int64)
+    np.cumsum(deg, out=ptr[1:])
+    idx = rng.integers(0, rows, size=int(ptr[-1]))
+    x = torch.from_numpy(rng.standard_normal((rows, H)).astype(np.float32)).to(dtype)
+    scale = torch.from_numpy(rng.uniform(0.2, 1.5, size=len(idx)).astype(np.float32))
+    self_in = torch.from_numpy(rng.standard_normal((S, H)).astype(np.float32)).to(dtype)
+    xd, idxd, ptrd = x.to(DEV), torch.from_numpy(idx).to(DEV, torch.int32), torch.from_numpy(ptr).to(DEV, torch.int32)
+    for use_scale, use_self, mean in [(False, False, False), (True, True, True), (False, True, False), (True, False, False)]:
+        kw = dict(scale=scale.to(DEV) if use_scale else None, self_in=self_in.to(DEV) if use_self else None,
+                  self_coef=1.25 if use_self else 0.0, mean=mean)
+        got = ops.gather_segsum(xd, idxd, ptrd, **kw)
+        ref = _ref_gather_segsum(x.float(), idx, ptr, scale if use_scale else None, self_in.float() if use_self else None, 1.25, mean)
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())) * 0.5)
+        assert torch.equal(got, ops.gather_segsum(xd, idxd, ptrd, **kw))
+    # contiguous lists (idx == None)
+    n = int(ptr[-1])
+    xc = torch.from_numpy(rng.standard_normal((n, H)).astype(np.float32)).to(dtype)
+    got = ops.gather_segsum(xc.to(DEV), None, ptrd)
+    ref = _ref_gather_segsum(xc.float(), None, ptr)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())) * 0.5)
+
+
 @pytest.mark.parametrize("self_loop", [True, False])
 def test_fused_row_factorisation_forward_backward(self_loop, arith):
     """Fused path (EDGE / AGG / TF relations + self loop), bf16 / fp32 split / exact-f32 MFMA, against the fp64 per-edge
