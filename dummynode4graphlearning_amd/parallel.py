@@ -146,14 +146,90 @@ class FlatGradBucket:
         if not _dist_on():
             return None
         works = []
+        # RCCL averages inside the collective (one launch less per bucket and step); gloo has no AVG: scale first
+        avg_op = self.average and dist.get_backend() == "nccl"
         for flat, _ in self._groups.values():
-            if self.average:
+            if self.average and not avg_op:
                 flat.div_(dist.get_world_size())
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op))
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM, async_op=async_op))
         return works if async_op else None
 
     def bytes(self):
         return sum(g[0].numel() * g[0].element_size() for g in self._groups.values())
+
+
+class OverlappedGradReducer:
+    """Gradient all-reduce that runs UNDER the backward pass: one FlatGradBucket per parameter group (normally one per layer, in
+    forward order), each reduced asynchronously the moment its last gradient has been accumulated -- while autograd is still
+    working on the layers below it.  The communication stream (RCCL's own, or gloo's worker thread) waits only for the work
+    queued so far, so the collective of layer L overlaps the backward launches of layers L-1, L-2, ...
+
+        reducer = OverlappedGradReducer([layer.parameters() for layer in model.layers])
+        for batch in loader:
+            optimizer.zero_grad()              # set_to_none=True (the default) is fine: see FlatGradBucket
+            loss(model(batch)).backward()      # hooks: pack + async all-reduce per group, as the groups complete
+            reducer.finish()                   # wait for the collectives (and reduce groups that never completed)
+            optimizer.step()
+
+    Within ONE RGIN layer nothing can be overlapped: the conv's weight gradient needs the per-graph gradient sums that the
+    input-gradient pass produces as a by-product (the absorbed fold), so it is the last launch of the layer's backward; the
+    overlap is between layers (the reference stacks 3, config.py `rgin_num_layers`).  `launched` logs, per step, (group index,
+    number of parameters of LATER-completing groups that had no gradient yet) -- what the tests use to show the collective left
+    before backward ended."""
+
+    def __init__(self, param_groups, average=True):
+        self.buckets = [FlatGradBucket(list(g), average=average) for g in param_groups]
+        if not self.buckets:
+            raise ValueError("no parameter groups")
+        self._pending = [set() for _ in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self._done = [False] * len(self.buckets)
+        self.launched = []
+        self._handles = []
+        for gi, b in enumerate(self.buckets):
+            for p in b.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(gi)))
+        self._arm()
+
+    def _arm(self):
+        for gi, b in enumerate(self.buckets):
+            self._pending[gi] = {id(p) for p in b.params}
+            self._works[gi], self._done[gi] = None, False
+        self.launched = []
+
+    def _make_hook(self, gi):
+        def hook(param):
+            pend = self._pending[gi]
+            pend.discard(id(param))
+            if not pend and not self._done[gi]:
+                self._launch(gi)
+        return hook
+
+    def _launch(self, gi):
+        waiting = sum(1 for gj, b in enumerate(self.buckets) if not self._done[gj] and gj != gi
+                      for p in b.params if id(p) in self._pending[gj])
+        self.launched.append((gi, waiting))
+        self._done[gi] = True
+        self._works[gi] = self.buckets[gi].all_reduce(async_op=True)
+
+    def finish(self):
+        """Call after backward(): reduces the groups whose hooks never all fired (unused parameters), waits for every collective
+        and re-arms the hooks for the next step."""
+        for gi in range(len(self.buckets)):
+            if not self._done[gi]:
+                self._launch(gi)
+        for works in self._works:
+            for w in works or ():
+                w.wait()
+        self._arm()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def bytes(self):
+        return sum(b.bytes() for b in self.buckets)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

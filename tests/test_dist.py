@@ -140,6 +140,56 @@ def test_bucket_survives_zero_grad_and_replicas_stay_identical():
         assert unused_grad == 0.0
 
 
+def _overlap_worker(rank, world, port, q):
+    """OverlappedGradReducer: one bucket per layer, each all-reduced from INSIDE backward the moment its last gradient lands."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dummynode4graphlearning_amd.parallel import OverlappedGradReducer
+
+        def make():
+            torch.manual_seed(0)
+            return torch.nn.Sequential(torch.nn.Linear(6, 7), torch.nn.ReLU(), torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        model, ref = make(), make()
+        unused = torch.nn.Parameter(torch.ones(4))                     # a group whose hooks never fire
+        layers = [model[0], model[2], model[4]]
+        reducer = OverlappedGradReducer([l.parameters() for l in layers] + [[unused]])
+        opt = torch.optim.SGD(list(model.parameters()) + [unused], lr=0.1)
+        ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+        torch.manual_seed(1)
+        data = torch.randn(8, 6)
+        half = slice(0, 4) if rank == 0 else slice(4, 8)
+        logs = []
+        for step in range(3):
+            opt.zero_grad()                                           # set_to_none=True
+            model(data[half]).square().mean().backward()
+            logs.append(list(reducer.launched))                       # what left during backward, before finish()
+            reducer.finish()
+            opt.step()
+            ropt.zero_grad()
+            ref(data).square().mean().backward()
+            ropt.step()
+        err = max(float((p - r).abs().max()) for p, r in zip(model.parameters(), ref.parameters()))
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        q.put((rank, err, float((gathered[0] - gathered[1]).abs().max()), logs, float(unused.grad.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_launches_each_layers_collective_inside_backward():
+    for rank, err, spread, logs, unused_grad in _run_world(_overlap_worker):
+        assert err < 1e-6, (rank, err)                  # 3 SGD steps == the single-process run on the whole batch
+        assert spread == 0.0
+        assert unused_grad == 0.0
+        for log in logs:
+            # the three layer groups left in reverse layer order, from inside backward(); when the last layer's bucket left, the 4
+            # parameters of the two layers below had no gradient yet (their backward had not run), then 2, then 0
+            assert [g for g, _ in log] == [2, 1, 0], log
+            assert [w - 1 for _, w in log] == [4, 2, 0], log           # (-1: the never-used parameter stays pending)
+
+
 def _syncbn_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -95,6 +95,54 @@ def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
             torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5, msg=k)
 
 
+def test_overlapped_reducer_over_rccl_on_a_three_layer_stack(nccl_world_of_one):
+    """parallel.OverlappedGradReducer on a 3-layer RGIN stack (the reference's depth, config.py rgin_num_layers): every layer's
+    bucket leaves for RCCL from INSIDE backward, in reverse layer order, and the step equals the plain one."""
+    from dummynode4graphlearning_amd import BatchedGraph, parallel, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config3(seed=6, graphs=24)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"],
+                                      raw["max_ne"], raw["max_nel"])
+    N, R = int(aug["node_label"].numel()), raw["num_rels"]
+    g = BatchedGraph(aug["src"], aug["dst"], N)
+    et = aug["edge_label"].long()
+
+    def stack():
+        torch.manual_seed(0)
+        return torch.nn.ModuleList([RGINLayer(64, 64, num_rels=R, regularizer="bdd", num_bases=4, act_func="leaky_relu") for _ in range(3)]).to(DEV)
+
+    def run(layers, x):
+        h = x
+        for l in layers:
+            h = l(g, h, et)[0]
+        return h.square().mean()
+    a, b = stack(), stack()
+    reducer = parallel.OverlappedGradReducer([l.parameters() for l in a])
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a_, **k_: (calls.append("all_reduce"), orig(*a_, **k_))[1]
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.05), torch.optim.SGD(b.parameters(), lr=0.05)
+    x = torch.randn(N, 64, device=DEV)
+    try:
+        for _ in range(2):
+            oa.zero_grad()
+            run(a, x).backward()
+            assert [gi for gi, _ in reducer.launched] == [2, 1, 0]          # all three left before backward() returned
+            assert [w for _, w in reducer.launched][0] > 0 and reducer.launched[-1][1] == 0
+            reducer.finish()
+            oa.step()
+            ob.zero_grad()
+            run(b, x).backward()
+            ob.step()
+    finally:
+        dist.all_reduce = orig
+        reducer.remove()
+    assert len(calls) == 6
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_shards_of_a_global_batch_reproduce_the_full_batch_step(world):
     """What `bench.py --gpus N` relies on (no data-path collective): the config-5 layer run on each rank's shard of ONE
