@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdn_hip.so")
+# DN_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box, tools/ab_lib.sh); no fallback either way
+LIB_PATH = os.environ.get("DN_HIP_LIB") or os.path.join(_HERE, "libdn_hip.so")
 
 c_i32, c_i64, c_f32, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 P = ctypes.c_void_p

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
 // -------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint4 g_zero_row[64];        // 1 KiB of zeros (device globals are zero-initialised)
 
+#ifndef DN_WGM_ABL
+#define DN_WGM_ABL 0        // diagnostic builds (DN_BUILD_EXTRA=-DDN_WGM_ABL=n): 1 no mask pass, 2 mask bits from the zero row
+#endif
 template <int H, bool MASKED>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t* __restrict__ A,
                                                                     const bf16_t* __restrict__ A2, int32_t na1,
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     constexpr int RPI = 64 / LPRW;                 // rows per DMA wave-instruction (2 or 4)
     constexpr int RW = TR / 8;                     // rows of each operand a wave stages per tile (4 or 8)
     constexpr int PPW = RW / RPI;                  // DMA instructions per wave, operand and tile
-    constexpr int GL = 2 * PPW + (MASKED ? 1 : 0); // DMA instructions per wave and tile
+    constexpr int GL = 2 * PPW;                    // DMA instructions per wave and tile (+ 1 on the wave that fetches a tile's mask bits)
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     };
     auto issue = [&](int T) {
         const unsigned st = lds_base + (unsigned)(T % NST) * STB;
+        uint64_t pgs[PPW];
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int rl = RW * wave + RPI * j + rin;                      // row of the stage this lane fills
@@ -331,18 +335,23 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
             const uint64_t pg = (rg < 0 ? (uint64_t)(uintptr_t)zero : bg + og) + (uint64_t)gch;
             const unsigned da = st + (unsigned)(RW * wave + RPI * j) * ROWB; // wave-uniform; lane l lands at + 16 l
             glds16(reinterpret_cast<const char*>(pa), da);
-            glds16(reinterpret_cast<const char*>(pg), da + MATB);
+            if constexpr (MASKED) pgs[j] = pg;                              // (masked: every A piece and the bits go first, see the loop)
+            else glds16(reinterpret_cast<const char*>(pg), da + MATB);
         }
         if constexpr (MASKED) {
-            // the mask bits of my RW rows: H/8 bytes per row = (H/128) 16-byte pieces; 8 active lanes, 128 bytes per wave
+            // the tile's mask bits (TR rows x H/8 bytes = 1 KiB, contiguous: the masked operand is never gathered) go as ONE
+            // full-width DMA by wave T % 8 -- eight 128-byte requests per tile (every wave its own rows) measured 16 us per
+            // launch at 127 k rows, as much as the mask pass itself
             constexpr int LPB = H / 128;                                   // lanes per row of bits
-            if (lane < RW * LPB) {
-                int32_t ra = nxa[0];
-#pragma unroll
-                for (int k = 1; k < RW; ++k) ra = (lane / LPB == k) ? nxa[k] : ra;
-                const char* pb = ra < 0 ? zero : reinterpret_cast<const char*>(maskBits) + (size_t)ra * (H / 8) + (lane % LPB) * 16;
-                glds16(pb, st + 2 * MATB + (unsigned)wave * (RW * (H / 8)));
+            if (wave == (T & 7)) {
+                const int p = ch.beg + T * TR + lane / LPB;
+                const char* pb = (p >= ch.end || (DN_WGM_ABL & 2)) ? zero + lane * 16
+                                                                   : reinterpret_cast<const char*>(maskBits) + (size_t)p * (H / 8) + (lane % LPB) * 16;
+                glds16(pb, st + 2 * MATB);
             }
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+                glds16(reinterpret_cast<const char*>(pgs[j]), st + (unsigned)(RW * wave + RPI * j) * ROWB + MATB);
         }
     };
 
@@ -379,29 +388,51 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
         issue(T);
         load_idx(T + 1);
     }
+    // Masked variant: the activation mask is applied to a landed A tile IN PLACE, one tile AHEAD of the products: tile t+1 is
+    // masked (and its column sums taken, from the registers the masked piece passes through) in the same barrier interval in
+    // which tile t is multiplied, so a tile costs ONE barrier and the read-modify-write is off the path between a tile's arrival
+    // and its MFMAs.  A wave issues per tile [A pieces][bits][G pieces]; masking tile t+1 needs its A pieces and bits only, so
+    // the counted wait leaves the G pieces of t+1 and all of t+2 in flight (half a stage less than the unmasked ring).
+    constexpr int MPT = TR * LPRW / kWgThreads;                            // pieces a thread masks per tile (2), rows mrow + j * MRS
+    constexpr int MRS = kWgThreads / LPRW;                                 // (a multiple of 16: the swizzle f(r) is the same for both)
+    const int mrow = tid / LPRW, mq = tid % LPRW;
+    const int mf = (mrow & 3) | (((mrow >> 3) & 1) << 2);
+    const int mchunk = (((mq >> 1) ^ mf) << 1) | (mq & 1);                  // the 8 columns this thread's pieces hold
+    static_assert(MRS % 16 == 0, "both pieces of a thread must share their column chunk");
+    auto mask_tile = [&](int T) {
+        char* sT = lds + (T % NST) * STB;
+        const uint8_t* sB = reinterpret_cast<const uint8_t*>(sT + 2 * MATB);
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            const int r = mrow + j * MRS;
+            uint4* pp = reinterpret_cast<uint4*>(sT + r * ROWB + mq * 16);
+            const uint4 v = dn_keep_or_scale_bits(*pp, sB[r * (H / 8) + mchunk], slope);
+            *pp = v;
+            if (colsum_of == 1) {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cs[2 * i] += __uint_as_float(w[i] << 16);
+                    cs[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if constexpr (MASKED) {
+        wait_vmcnt<PPW + GL*(NST - 2)>();                                  // my A pieces and bits of tile 0 have landed
+        __builtin_amdgcn_s_barrier();
+        mask_tile(0);
+    }
 #pragma unroll 1
     for (int t = 0; t < ntiles; ++t) {
-        wait_vmcnt<GL*(NST - 2)>();                                        // my pieces of tile t have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my fragment reads of tile t-1 are done
+        if constexpr (MASKED) wait_vmcnt<PPW + GL*(NST - 3)>();            // all of tile t, A pieces + bits of tile t+1
+        else wait_vmcnt<GL*(NST - 2)>();                                   // my pieces of tile t have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my fragment reads of tile t-1 (and mask writes of tile t) are done
         __builtin_amdgcn_s_barrier();                                      // everyone's have / are
         issue(t + NST - 1);                                                // refill the stage tile t-1 used
         load_idx(t + NST);
         char* sA = lds + (t % NST) * STB;
         const char* sG = sA + MATB;
-        if constexpr (MASKED) {
-            // ReLU backward on the landed A tile, in place: piece (row r, position q) holds global chunk ((q>>1)^f(r))<<1 | (q&1)
-            const uint8_t* sB = reinterpret_cast<const uint8_t*>(sA + 2 * MATB);
-#pragma unroll
-            for (int j = 0; j < TR * LPRW / kWgThreads; ++j) {
-                const int piece = tid + j * kWgThreads, r = piece / LPRW, q = piece % LPRW;
-                const int f = (r & 3) | (((r >> 3) & 1) << 2);
-                const int gchunk = (((q >> 1) ^ f) << 1) | (q & 1);
-                uint4* pp = reinterpret_cast<uint4*>(sA + r * ROWB + q * 16);
-                *pp = dn_keep_or_scale_bits(*pp, sB[r * (H / 8) + gchunk], slope);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
 #pragma unroll
         for (int kk = 0; kk < TR / 32; ++kk) {
             bf16x8 fb[NT];
@@ -414,7 +445,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
             }
         }
-        if (colsum_of != 0) {
+        if constexpr (MASKED) { if (!(DN_WGM_ABL & 1)) mask_tile(t + 1); } // behind the MFMAs in program order (a zero tile past the end stays zero)
+        if (colsum_of != 0 && !(MASKED && colsum_of == 1)) {
             const char* M = colsum_of == 1 ? sA : sG;
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
@@ -449,8 +481,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     if (colsum_of != 0) {
         constexpr int TPC = kWgThreads / LPRW;                             // threads per column chunk
         float* red = reinterpret_cast<float*>(lds);
+        const int ochunk = (MASKED && colsum_of == 1) ? mchunk : cchunk;    // (masked: summed where the piece was masked)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[crow * H + cchunk * 8 + i] = cs[i];
+        for (int i = 0; i < 8; ++i) red[crow * H + ochunk * 8 + i] = cs[i];
         __syncthreads();
         if (tid < H) {
             float sum = 0.f;
@@ -1277,44 +1310,57 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
 }
 
 // out[r] = sum of the partials of relation r's chunks.  The sum is latency-bound (a few hundred 256 KB slabs, each element
-// read once), so 8 threads share an output element: thread `slice` adds chunks slice, slice+8, ... with 4 loads in flight,
-// the 8 slice sums are then folded through LDS in slice order.  Fixed association -> bitwise reproducible.
+// read once, most of them still in the memory-side cache the weight-gradient launch wrote them through), so what counts is bytes
+// in flight: a thread owns FOUR consecutive elements (one 16-byte load per slab), 8 threads share them -- thread `slice` adds
+// chunks slice, slice+8, ... with 8 loads in flight -- and the 8 slice sums are folded through LDS in slice order.
+// Fixed association -> bitwise reproducible.  (Round 3's form -- one float per thread, 4 in flight -- ran at 3.9 TB/s.)
 template <typename TO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ chunk_ptr, int64_t tile_elems,
                                                            TO* __restrict__ out, const float* __restrict__ cs_partial,
                                                            int32_t H, float* __restrict__ out_colsum, TO* __restrict__ out_colsum_lp) {
-    constexpr int SL = 8, EL = 256 / SL;
-    __shared__ float red[SL][EL];
+    constexpr int SL = 8, TL = 256 / SL, EL = 4 * TL;                       // 32 threads x 4 elements per slice
+    __shared__ float4 red[SL][TL];
     const int r = blockIdx.y;
-    const int elem = threadIdx.x % EL, slice = threadIdx.x / EL;
+    const int quad = threadIdx.x % TL, slice = threadIdx.x / TL;
     const int cb = chunk_ptr[r], ce = chunk_ptr[r + 1];
     // blocks past the tile handle the column sums (bias gradient) the same way
     const int64_t tile_blocks = (tile_elems + EL - 1) / EL;
     const bool is_cs = (int64_t)blockIdx.x >= tile_blocks;
     const float* src = is_cs ? cs_partial : partial;
-    const int64_t stride = is_cs ? (int64_t)H : tile_elems;
-    const int64_t i = (is_cs ? (int64_t)blockIdx.x - tile_blocks : (int64_t)blockIdx.x) * EL + elem;
-    float s = 0.f;
+    const int64_t stride = is_cs ? (int64_t)H : tile_elems;                 // (both multiples of 4: H in {64, 128, 256})
+    const int64_t i = (is_cs ? (int64_t)blockIdx.x - tile_blocks : (int64_t)blockIdx.x) * EL + 4 * quad;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
     if (i < stride) {
+        const float* base = src + i;
         int c = cb + slice;
-        for (; c + 3 * SL < ce; c += 4 * SL) {
-            const float v0 = src[(size_t)c * stride + i], v1 = src[(size_t)(c + SL) * stride + i];
-            const float v2 = src[(size_t)(c + 2 * SL) * stride + i], v3 = src[(size_t)(c + 3 * SL) * stride + i];
-            s += v0; s += v1; s += v2; s += v3;
+        for (; c + 7 * SL < ce; c += 8 * SL) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(c + k * SL) * stride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) add(v[k]);
         }
-        for (; c < ce; c += SL) s += src[(size_t)c * stride + i];
+        for (; c < ce; c += SL) add(*reinterpret_cast<const float4*>(base + (size_t)c * stride));
     }
-    red[slice][elem] = s;
+    red[slice][quad] = s;
     __syncthreads();
     if (slice == 0 && i < stride) {
-        float t = red[0][elem];
+        float4 t = red[0][quad];
 #pragma unroll
-        for (int k = 1; k < SL; ++k) t += red[k][elem];
+        for (int k = 1; k < SL; ++k) { const float4 u = red[k][quad]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float tv[4] = {t.x, t.y, t.z, t.w};
         if (is_cs) {
-            out_colsum[(size_t)r * H + i] = t;
-            if (out_colsum_lp) out_colsum_lp[(size_t)r * H + i] = (TO)t;    // (the bias gradient in the parameter's dtype: no cast launch)
-        } else out[(size_t)r * tile_elems + i] = (TO)t;
+            *reinterpret_cast<float4*>(out_colsum + (size_t)r * H + i) = t;
+            if (out_colsum_lp) {                                               // (the bias gradient in the parameter's dtype: no cast launch)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out_colsum_lp[(size_t)r * H + i + k] = (TO)tv[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[(size_t)r * tile_elems + i + k] = (TO)tv[k];
+        }
     }
 }
 
@@ -1501,7 +1547,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
                        float act_slope, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(mask_a == nullptr || A2 == nullptr, "dn_rows_wgrad: mask_a needs a single A source");
     DN_REQUIRE(out_colsum_lp == nullptr || colsum_of != 0, "dn_rows_wgrad: out_colsum_lp needs colsum_of");
-    DN_REQUIRE(mask_a_bits == nullptr || (mask_a == nullptr && A2 == nullptr), "dn_rows_wgrad: mask_a_bits excludes mask_a / A2");
+    DN_REQUIRE(mask_a_bits == nullptr || (mask_a == nullptr && A2 == nullptr && idx_a == nullptr),
+               "dn_rows_wgrad: mask_a_bits excludes mask_a / A2 / idx_a (the bit-masked operand is read in row order)");
     DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad: a_out needs mask_a and idx_a == NULL");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0, "dn_rows_wgrad: unaligned mask");
     DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
@@ -1514,6 +1561,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
     DN_REQUIRE(out && chunk_ptr, "dn_rows_wgrad: NULL pointer");
     DN_REQUIRE(num_chunks == 0 || (A && G && chunks && workspace), "dn_rows_wgrad: NULL pointer");
     DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * ((size_t)Hi * Ho + Hi) * sizeof(float), "dn_rows_wgrad: workspace too small");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out_colsum)) % 16 == 0,
+               "dn_rows_wgrad: workspace / out_colsum must be 16-byte aligned");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G)) % 16 == 0, "dn_rows_wgrad: unaligned input");
     hipStream_t st = (hipStream_t)stream;
     const Chunk* ch = reinterpret_cast<const Chunk*>(chunks);
@@ -1532,7 +1581,7 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
     }
     const int64_t tile = (int64_t)Hi * Ho;
     const float* csp = colsum_of ? (const float*)workspace + (size_t)num_chunks * tile : nullptr;
-    dim3 grid((unsigned)(dn_cdiv(tile, 32) + (csp ? dn_cdiv(Hi, 32) : 0)), (unsigned)R);
+    dim3 grid((unsigned)(dn_cdiv(tile, 128) + (csp ? dn_cdiv(Hi, 128) : 0)), (unsigned)R);
     if (out_is_f32)
         hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
                            (float*)out, csp, Hi, out_colsum, (float*)out_colsum_lp);

@@ -318,8 +318,9 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
  * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL).
  * mask_a (may be NULL; needs A2 == NULL): A rows are first zeroed where mask_a[row, k] <= 0 (ReLU backward folded into the
  * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears.
- * mask_a_bits (may be NULL; excludes mask_a and A2): the same mask as a bit tensor, uint8 [rows of A, Hi/8], bit i of byte
- * (row, c) = keep element (row, 8c + i) -- the bits1 / bits2 outputs of dn_rows_chain2_bf16.
+ * mask_a_bits (may be NULL; excludes mask_a, A2 and idx_a: the bit-masked operand is read in row order): the same mask as
+ * a bit tensor, uint8 [rows of A, Hi/8], bit i of byte (row, c) = keep element (row, 8c + i) -- the bits1 / bits2 outputs of
+ * dn_rows_chain2_bf16.
  * out_colsum_lp (may be NULL; needs colsum_of): a second copy of the column sums in out's element type ([R, H]): the bias
  * gradient in the parameter's dtype without a cast launch. */
 size_t dn_rows_wgrad_workspace_bytes(int64_t num_chunks, int32_t Hi, int32_t Ho);
