@@ -546,6 +546,52 @@ def test_rows_wgrad_with_bit_mask_and_chain2(H):
     assert float((g0.cpu().double() - rg0).abs().max() / rg0.abs().max()) < 6e-3
 
 
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 257, 8191, 8224, 300001])
+@pytest.mark.parametrize("slope", [0.0, 1.0 / 5.5])
+def test_chain2_ring_kernel_at_every_pipeline_length(N, slope):
+    """dn_rows_chain2_bf16 at H = 256 (csrc/dn_chain2.hip: LDS-DMA ring, counted waits over loads AND stores, results from the
+    accumulators): forward with and without the sign-bit outputs, the backward chain with both masks on the weights as stored,
+    from one row (one workgroup, one tile, every look-ahead tile past the end) to many tiles per workgroup with a ragged last
+    tile -- against fp64 math on the same bf16 operands and storage points; bits bit-exact; run-to-run bitwise equal."""
+    from dummynode4graphlearning_amd import ops
+    H = 256
+    rng = np.random.default_rng(N)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, g = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((N, H)))
+    W1, W2 = bf(rng.standard_normal((H, H)) / np.sqrt(H)), bf(rng.standard_normal((H, H)) / np.sqrt(H))
+    b1, b2 = bf(rng.standard_normal(H) * 0.1), bf(rng.standard_normal(H) * 0.1)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    act = lambda v: torch.where(v > 0, v, v * slope)  # noqa: E731
+    rel = lambda a, r: float((a.cpu().double() - r).abs().max() / r.abs().max().clamp(min=1e-3))  # noqa: E731
+    h1, h2, bits1, bits2 = ops.rows_chain2(d(x), d(W1), d(b1), True, d(W2), d(b2), True, want_bits=True, slope=slope)
+    r1 = act(x.double() @ W1.double().t() + b1.double())
+    assert rel(h1, r1) < 6e-3
+    r2 = act(h1.cpu().double() @ W2.double().t() + b2.double())            # from the stored (bf16) hidden rows
+    assert rel(h2, r2) < 6e-3
+    unpack = lambda b: ((b.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(N, H).bool()  # noqa: E731
+    assert torch.equal(unpack(bits1), h1.cpu() > 0) and torch.equal(unpack(bits2), h2.cpu() > 0)
+    # without the bit outputs, without bias, second layer linear: the same rows
+    p1, p2 = ops.rows_chain2(d(x), d(W1), d(b1), True, d(W2), d(b2), True, slope=slope)
+    assert torch.equal(p1, h1) and torch.equal(p2, h2)
+    q1, q2 = ops.rows_chain2(d(x), d(W1), None, True, d(W2), None, False, slope=slope)
+    s1 = act(x.double() @ W1.double().t())
+    assert rel(q1, s1) < 6e-3 and rel(q2, q1.cpu().double() @ W2.double().t()) < 6e-3
+    # the backward chain: outer mask, dgrad 2, inner mask, dgrad 1 -- weights [k][n] as the Linear stores them, and transposed copies
+    keep2, keep1 = (h2.cpu() > 0), (h1.cpu() > 0)
+    gm = torch.where(keep2, g.double(), g.double() * slope)
+    rg1 = gm @ W2.double()
+    rg1 = torch.where(keep1, rg1, rg1 * slope)
+    g1, g0 = ops.rows_chain2(d(g), d(W2), None, False, d(W1), None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True),
+                             slope=slope)
+    assert rel(g1, rg1) < 6e-3
+    assert rel(g0, g1.cpu().double() @ W1.double()) < 6e-3
+    t1, t0 = ops.rows_chain2(d(g), d(W2).t().contiguous(), None, False, d(W1).t().contiguous(), None, False, mask0_bits=bits2,
+                             mask1_bits=bits1, slope=slope)
+    assert torch.equal(t1, g1) and torch.equal(t0, g0)
+    again = ops.rows_chain2(d(g), d(W2), None, False, d(W1), None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True), slope=slope)
+    assert torch.equal(again[0], g1) and torch.equal(again[1], g0)
+
+
 def test_index_builds_reject_out_of_range_edge_types():
     """an edge type >= num_rels (easy to hit in the SI flow: the dummy labels extend the relation set) must raise,
     not be silently grouped into another relation."""
