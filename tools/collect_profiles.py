@@ -32,7 +32,7 @@ from dummynode4graphlearning_amd._lib import source_digest  # noqa: E402
 STEP = [
     ("rows_transform_ring_kernel", "conv transform fwd, edge rows except the collapsed dummy relation (gathers x rows; weights read [k][n])"),
     ("rows_close_ring_kernel", "closing launch fwd (unit stream): self-loop transform + bias + per-dst row sums (selection MFMA) + per-graph column sums -> aux rows + AGG units (aux x W_agg added to the dummy nodes)"),
-    ("rows_chain2_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors)"),
+    ("rows_chain2_ring_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors); LDS-DMA ring kernel"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_chain2_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass"),
