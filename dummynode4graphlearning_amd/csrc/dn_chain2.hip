@@ -20,11 +20,11 @@
 //     up with 8 consecutive columns of a row = one 16-byte store (bias, activation, masks and sign bits applied in registers);
 //     layer 1 writes the same 16-byte piece into the hand-off tile in the swizzled image, so layer 2 reads it like an X tile;
 //   * the sign-bit outputs are collected in 1 KiB LDS tiles and leave as one 16-byte-per-lane store a tile later.
-// This kernel serves the FORWARD form (bias, activation, optional sign-bit outputs).  The backward form (mask0 on the input,
-// mask1 on layer 1's result) was built on the same skeleton too -- mask bits as one 1 KiB DMA per tile, mask0 applied to a landed
-// tile in place one tile ahead -- and measured SLOWER than the register-staged kernel (419 vs 397 us standalone at config 5: the
-// in-place mask pass is 32 KB of extra LDS traffic and ~40 VALU instructions per thread and tile, and the wait for the tile
-// ahead costs a stage of look-ahead), so the masked calls stay on rows_chain2_kernel (docs/LAB_NOTES.md, round 4).
+//   * the backward form (KEEP): the activation-mask bit tensors (mask0 on the input, mask1 on layer 1's result) travel as one
+//     1 KiB DMA per tile and mask next to the rows; mask0 is applied to a landed tile in place one tile AHEAD of its use (no
+//     second barrier; the counted wait then asks for tile t + 1), mask1 in layer 1's epilogue from the tile's bits in LDS.
+//     (Built before the epilogue diet below it measured 419 us against the register-staged kernel's 397 and was shelved; with the
+//     diet the forward form runs 305 us in the step against ~370, and this form followed: docs/LAB_NOTES.md, round 4.)
 // vmcnt counts loads, stores and LDS-DMAs of a wave together, in issue order.  So that "tile t has landed" stays a COUNTED wait
 // with kD tiles in flight, every wave issues the same vector-memory operations per tile -- 2 row DMAs, then 4 result stores
 // (rows past the end and the idle role of the first / last iterations store into a dump area instead of being predicated
@@ -44,9 +44,9 @@ constexpr int kRowB = 2 * kH;                 // bytes per row
 constexpr int kTR = 32;                       // rows per tile
 constexpr int kTileB = kTR * kRowB;           // 16 KiB
 constexpr int kBitsB = kTR * (kH / 8);        // 1 KiB: one tile of mask / sign bits
-constexpr int kStageB = kTileB;                // an X stage
+constexpr int kStageB = kTileB + 2 * kBitsB;   // an X stage: the rows, the tile's mask0 bits, its mask1 bits (backward form)
 constexpr int kD = 4;                         // tiles requested ahead of the one being multiplied
-constexpr int kNS = kD + 1;                   // X ring stages (80 KiB)
+constexpr int kNS = kD + 1;                   // X ring stages (90 KiB)
 constexpr int kThreads = 512;
 constexpr int kDma = 2, kStores = 4;          // vector-memory operations every wave issues per tile, in this order (+ 1 store with sign bits)
 
@@ -73,23 +73,25 @@ __device__ __forceinline__ uint32_t pos_bits(const u32x4& v) {     // bit i: bf1
 
 // "the rows of tile t have landed" at the top of iteration t: all but the operations issued after them may be outstanding.  Issue
 // order of a wave: rows of tiles 0 .. kD-1 (prologue), then per iteration [rows of tile t + kD][ST stores].  A tile still from
-// the prologue has (kD - 1 - t) later prologue tiles and t full iterations behind it.
-template <int ST>                                                         // ST: result stores a wave issues per tile (4, + 1 with the sign bits)
-__device__ __forceinline__ void c2_wait(int t) {
-    if (t == 0) { wait_vmcnt<kDma * (kD - 1)>(); return; }
-    if (t == 1) { wait_vmcnt<kDma * (kD - 2) + (kDma + ST)>(); return; }
-    if (t == 2) { wait_vmcnt<kDma * (kD - 3) + 2 * (kDma + ST)>(); return; }
-    if (t == 3) { wait_vmcnt<kDma * (kD - 4) + 3 * (kDma + ST)>(); return; }
-    wait_vmcnt<ST + (kDma + ST) * (kD - 1)>();
+// the prologue has (kD - 1 - t) later prologue tiles and t full iterations behind it.  (The mask-bit DMAs of the backward form --
+// one wave per tile and mask -- are extra operations behind the rows they belong to: they only make that wave's wait stricter.)
+template <int ST, bool AHEAD>                                             // ST: result stores a wave issues per tile (4, + 1 with the sign bits);
+__device__ __forceinline__ void c2_wait(int t) {                          // AHEAD: tile t + 1 must have landed (the mask pass works a tile ahead)
+    constexpr int A = AHEAD ? 1 : 0, IT = kDma + ST;
+    if constexpr (0 + A < kD) if (t == 0) { wait_vmcnt<kDma * (kD - 1 - A)>(); return; }
+    if constexpr (1 + A < kD) if (t == 1) { wait_vmcnt<kDma * (kD - 2 - A) + IT>(); return; }
+    if constexpr (2 + A < kD) if (t == 2) { wait_vmcnt<kDma * (kD - 3 - A) + 2 * IT>(); return; }
+    if constexpr (3 + A < kD) if (t == 3) { wait_vmcnt<kDma * (kD - 4 - A) + 3 * IT>(); return; }
+    wait_vmcnt<ST + IT * (kD - 1 - A)>();
 }
 static_assert(kD == 4, "c2_wait spells out the first kD iterations");
 
 #define DN_C2_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 
-template <bool SBITS>
+template <bool KEEP, bool SBITS>
 __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1n, const bf16_t* __restrict__ b1, const bf16_t* __restrict__ W2n,
-    const bf16_t* __restrict__ b2, int32_t flags, int32_t N,
+    const bf16_t* __restrict__ b2, int32_t flags, const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, int32_t N,
     int32_t num_tiles, bf16_t* __restrict__ Y1, bf16_t* __restrict__ Y2, uint8_t* __restrict__ bits1, uint8_t* __restrict__ bits2,
     float slope) {
     __shared__ __attribute__((aligned(1024))) char lds[kNS * kStageB + 2 * kTileB + 4 * kBitsB];
@@ -167,6 +169,34 @@ __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
             const char* src = (p < N ? reinterpret_cast<const char*>(X) + p * kRowB : zero) + ((pos ^ (rl & 15)) << 4);
             glds16(src, st + (unsigned)(4 * wave + 2 * jj) * kRowB);      // lane l lands at + 16 l
         }
+        if constexpr (KEEP) {                                             // the tile's 1 KiB of mask0 / mask1 bits: one full-width DMA each
+            const int64_t p = rb + (lane >> 1);
+            const size_t boff = (size_t)p * (kH / 8) + (lane & 1) * 16;
+            if (wave == (T & 7)) glds16(p < N ? reinterpret_cast<const char*>(mask0) + boff : zero + lane * 16, st + kTileB);
+            if (wave == ((T + 4) & 7)) glds16(p < N ? reinterpret_cast<const char*>(mask1) + boff : zero + lane * 16, st + kTileB + kBitsB);
+        }
+    };
+    // mask0 on a landed tile, in place: a thread's two pieces (row r, position q) hold source piece q ^ (r & 15).  Keep where the
+    // bit is set, x slope (0: zero) elsewhere; the word masks come from signed 1-bit field extracts (0 / ~0) and one bit-select.
+    auto mask_tile = [&](int T) __attribute__((always_inline)) {
+        char* sT = lds + (T % kNS) * kStageB;
+        const uint8_t* sB = reinterpret_cast<const uint8_t*>(sT + kTileB);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int piece = tid + kThreads * jj, r = piece >> 5, q = piece & 31;
+            u32x4* pp = reinterpret_cast<u32x4*>(sT + r * kRowB + q * 16);
+            const int32_t kb = (int32_t)sB[r * (kH / 8) + (q ^ (r & 15))];
+            u32x4 v = *pp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe(kb, 2 * i, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe(kb, 2 * i + 1, 1);
+                const uint32_t mk = (m0 & 0xffffu) | (m1 & 0xffff0000u);
+                uint32_t alt = 0u;
+                if (slope != 0.f) alt = pack2(__uint_as_float(v[i] << 16) * slope, __uint_as_float(v[i] & 0xffff0000u) * slope);
+                v[i] = (v[i] & mk) | (alt & ~mk);
+            }
+            *pp = v;
+        }
     };
     // ---- compute side
     const unsigned off0 = (unsigned)(j * kRowB + ((g ^ j) << 4));         // my fragment of k-step 0, rows j and 16 + j (+ 8192)
@@ -236,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
         char* ybase = reinterpret_cast<char*>(Yout) + rb * kRowB + yoff0;
         char* h1w = lds + kH1Off + par * kTileB + hoff0;
         uint8_t* obL = reinterpret_cast<uint8_t*>(lds + kObOff + (2 * role + par) * kBitsB + boff0);
+        const uint8_t* keepL = reinterpret_cast<const uint8_t*>(lds + ((Te + kNS) % kNS) * kStageB + kTileB + kBitsB + boff0);   // mask1 bits of tile Te (layer 1)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const bool ok = rb + 16 * m + j < N;
@@ -261,6 +292,17 @@ __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
                 } else if (act_mode == 3) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = dn_act(v[i], slope);
+                }
+                if constexpr (KEEP) {
+                    if (role == 0) {                                       // mask1: keep where the bit is set, x slope (0: zero) elsewhere
+                        const int32_t kb = (int32_t)keepL[512 * m + 4 * h];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe(kb, i, 1);
+                            const uint32_t alt = slope != 0.f ? __float_as_uint(v[i] * slope) : 0u;
+                            v[i] = __uint_as_float((__float_as_uint(v[i]) & mk) | (alt & ~mk));
+                        }
+                    }
                 }
                 u32x4 o;
 #pragma unroll
@@ -292,13 +334,19 @@ __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
 
 #pragma unroll 1
     for (int T = 0; T < kD; ++T) issue(T);
+    if constexpr (KEEP) {
+        wait_vmcnt<kDma*(kD - 1)>();                                      // tile 0 (and its bits) have landed
+        __builtin_amdgcn_s_barrier();
+        mask_tile(0);
+    }
 
 #pragma unroll 1
     for (int t = 0; t <= nt + 1; ++t) {
-        c2_wait<kStores + (SBITS ? 1 : 0)>(t);
+        c2_wait<kStores + (SBITS ? 1 : 0), KEEP>(t);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my LDS reads / writes of the previous iteration are done
         __builtin_amdgcn_s_barrier();
         issue(t + kD);                                                     // into the stage tile t - 1 used
+        if constexpr (KEEP) mask_tile(t + 1);                              // (a tile past the end is zeros and stays zeros)
         // Sign bits collected during the previous iteration (layer 1's of tile t - 1, layer 2's of tile t - 3): every wave of the
         // layer takes a quarter of the 1 KiB tile (16 lanes x 16 bytes), behind its MFMA block (the other wave of the SIMD is busy
         // meanwhile), so that no fifth store on ONE wave's vmcnt queue (which would make that wave wait for a tile
@@ -348,23 +396,29 @@ __global__ __launch_bounds__(kThreads) void rows_chain2_ring_kernel(
 namespace dn_internal {
 
 bool chain2_ring_supported(bool has_mask0, bool has_mask1, bool has_bits1, bool has_bits2) {
-    return !has_mask0 && !has_mask1 && has_bits1 == has_bits2;              // the forward form (header comment)
+    if (has_mask0 != has_mask1 || has_bits1 != has_bits2) return false;
+    return !(has_mask0 && has_bits1);                                       // forward: no masks; backward: both masks, no sign bits
 }
 
 int launch_chain2_ring256(const void* X, const void* W1n, const void* b1, const void* W2n, const void* b2, int32_t flags,
-                          int64_t N, void* Y1, void* Y2, void* bits1, void* bits2, float slope, hipStream_t st) {
+                          const void* mask0, const void* mask1, int64_t N, void* Y1, void* Y2, void* bits1, void* bits2,
+                          float slope, hipStream_t st) {
     const int64_t num_tiles = dn_cdiv(N, (int64_t)kTR);
-    const unsigned grid = (unsigned)(num_tiles < 256 ? num_tiles : 256);  // one workgroup per CU (116 KiB of LDS)
+    const unsigned grid = (unsigned)(num_tiles < 256 ? num_tiles : 256);  // one workgroup per CU (126 KiB of LDS)
     const bf16_t *x = (const bf16_t*)X, *w1 = (const bf16_t*)W1n, *w2 = (const bf16_t*)W2n, *bb1 = (const bf16_t*)b1,
                  *bb2 = (const bf16_t*)b2;
+    const uint8_t *m0 = (const uint8_t*)mask0, *m1 = (const uint8_t*)mask1;
     bf16_t *y1 = (bf16_t*)Y1, *y2 = (bf16_t*)Y2;
     uint8_t *o1 = (uint8_t*)bits1, *o2 = (uint8_t*)bits2;
-    if (o1 != nullptr)
-        hipLaunchKernelGGL((rows_chain2_ring_kernel<true>), dim3(grid), dim3(kThreads), 0, st, x, w1, bb1, w2, bb2, flags,
-                           (int32_t)N, (int32_t)num_tiles, y1, y2, o1, o2, slope);
+    if (m0 != nullptr)
+        hipLaunchKernelGGL((rows_chain2_ring_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, x, w1, bb1, w2, bb2, flags,
+                           m0, m1, (int32_t)N, (int32_t)num_tiles, y1, y2, o1, o2, slope);
+    else if (o1 != nullptr)
+        hipLaunchKernelGGL((rows_chain2_ring_kernel<false, true>), dim3(grid), dim3(kThreads), 0, st, x, w1, bb1, w2, bb2, flags,
+                           m0, m1, (int32_t)N, (int32_t)num_tiles, y1, y2, o1, o2, slope);
     else
-        hipLaunchKernelGGL((rows_chain2_ring_kernel<false>), dim3(grid), dim3(kThreads), 0, st, x, w1, bb1, w2, bb2, flags,
-                           (int32_t)N, (int32_t)num_tiles, y1, y2, o1, o2, slope);
+        hipLaunchKernelGGL((rows_chain2_ring_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, x, w1, bb1, w2, bb2, flags,
+                           m0, m1, (int32_t)N, (int32_t)num_tiles, y1, y2, o1, o2, slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -12,10 +12,11 @@ int launch_transform_ring256(const void* X, const void* X2, int32_t n1, const in
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
                              int64_t tiles_per_wg, void* Y, int32_t w_kn, float slope, hipStream_t st);
 
-// dn_chain2.hip: dn_rows_chain2_bf16 at H == 256, forward form (no masks; both sign-bit outputs or neither): LDS-DMA ring, 8 waves,
-// results straight from the accumulators.  The masked (backward) form stays on dn_rel.hip's register-staged kernel.
+// dn_chain2.hip: dn_rows_chain2_bf16 at H == 256 (LDS-DMA ring, 8 waves, results straight from the accumulators).  Serves the
+// forward (no masks; both sign-bit outputs or neither) and the backward (both masks, no sign-bit outputs) forms.
 bool chain2_ring_supported(bool has_mask0, bool has_mask1, bool has_bits1, bool has_bits2);
 int launch_chain2_ring256(const void* X, const void* W1n, const void* b1, const void* W2n, const void* b2, int32_t flags,
-                          int64_t N, void* Y1, void* Y2, void* bits1, void* bits2, float slope, hipStream_t st);
+                          const void* mask0, const void* mask1, int64_t N, void* Y1, void* Y2, void* bits1, void* bits2,
+                          float slope, hipStream_t st);
 
 }  // namespace dn_internal

@@ -1660,9 +1660,9 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
     uint8_t *o1 = (uint8_t*)bits1, *o2 = (uint8_t*)bits2;
     static const int c2ring = dn_knob("DN_C2_RING", 1);                // tuning build: 0 keeps the register-staged kernel at H = 256
     if (H == 256 && c2ring && dn_internal::chain2_ring_supported(m0 != nullptr, m1 != nullptr, o1 != nullptr, o2 != nullptr) &&
-        ((reinterpret_cast<uintptr_t>(o1) | reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(b1) |
-          reinterpret_cast<uintptr_t>(b2)) % 16 == 0))
-        return dn_internal::launch_chain2_ring256(X, W1n, b1, W2n, b2, flags, N, Y1, Y2, o1, o2, act_slope, st);
+        ((reinterpret_cast<uintptr_t>(m0) | reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(o1) |
+          reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2)) % 16 == 0))
+        return dn_internal::launch_chain2_ring256(X, W1n, b1, W2n, b2, flags, m0, m1, N, Y1, Y2, o1, o2, act_slope, st);
     if (H == 256) return launch_chain2<256>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
     if (H == 128) return launch_chain2<128>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
     return launch_chain2<64>(x, w1, bb1, w2, bb2, flags, m0, m1, N, (bf16_t*)Y1, (bf16_t*)Y2, o1, o2, act_slope, st);
