@@ -35,7 +35,7 @@ STEP = [
     ("rows_chain2_ring_kernel", "MLP forward: Linear+ReLU, Linear+ReLU in one pass (+ ReLU masks as bit tensors); LDS-DMA ring kernel"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
-    ("rows_chain2_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass"),
+    ("rows_chain2_ring_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass (masks from bits, by DMA)"),
     ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_ring_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
