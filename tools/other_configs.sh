@@ -1,8 +1,15 @@
-cd $GRAFT_REPO_ROOT
-for args in "--workload config3" "--workload config3 --act leaky_relu --regularizer bdd" "--workload config3 --dtype bf16" "--workload config3 --dtype bf16 --act leaky_relu --regularizer bdd" "--act leaky_relu --regularizer bdd --no-proxy" "--workload config4" "--dtype f32 --no-proxy"; do
-  echo "== bench.py $args"
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $args 2>gpurun_out/oc.err | python -c "
+#!/bin/bash
+# The step time of the other configurations bench.py knows (BASELINE.md section 2's GPU column), one line each.
+run() { echo -n "$* : "; python bench.py --steady "$@" 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; c = d['config']
-print('ms/step %.4f value %.4g %s scaling %s frac %.3f index_ms %s proxy %s' % (d['ms_per_step'], d['value'], d['unit'], d['scaling'], r['frac'], c.get('index_build_ms'), (c.get('strong_scaling_proxy') or {}).get('efficiency_at_8')))" || tail -5 gpurun_out/oc.err
-done
+d = json.loads(sys.stdin.read()); r = d.get('roofline') or {}
+print('ms/step %.4f' % d['ms_per_step'], 'value %.4g' % d['value'], 'frac %s' % r.get('frac'))"; }
+run --workload config3
+run --workload config3 --act leaky_relu --regularizer bdd
+run --workload config3 --dtype bf16
+run --workload config3 --dtype bf16 --act leaky_relu --regularizer bdd
+run --act leaky_relu --regularizer bdd
+run --dtype f32 --steps 5 --warmup 2
+python bench.py --workload config4 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('config4 : ms/step %.4f' % d['ms_per_step'], 'value %.4g' % d['value'])"
