@@ -11,7 +11,9 @@
 // weight slice in 128 VGPRs -- and a tile's rows are read by 4 waves per layer instead of 8 or 16 (LDS fragment traffic per tile:
 // 128 KB instead of 256-512 KB):
 //   * waves 0-3 run layer 1 on tile t while waves 4-7 run layer 2 on tile t - 1 (its input: layer 1's result of the previous
-//     iteration in a double-buffered LDS tile); one raw s_barrier per tile joins them;
+//     iteration in a double-buffered LDS tile), IN OPPOSITE PHASE: layer 1 multiplies, then runs its epilogue; layer 2 first
+//     finishes the sums of the previous iteration (kept in registers across the barrier), then multiplies -- on every SIMD one
+//     wave is in its MFMAs while the other is in its epilogue's VALU instructions; one raw s_barrier per tile joins them;
 //   * the X tiles come by LDS-DMA (two 1 KiB wave-instructions per wave and tile, no staging VGPRs) into a ring of kNS stages,
 //     kD tiles requested ahead; the image is the ring kernels' (unpadded, 16-byte pieces XOR-swizzled on the SOURCE address:
 //     LDS (row r, position q) holds piece q ^ (r & 15)), fragments are 16 ds_read_b128 per tile and wave with hand-counted
@@ -19,7 +21,7 @@
 //   * results leave STRAIGHT from the accumulators: the A rows of the MFMA tiles are the weight rows permuted so that a lane ends
 //     up with 8 consecutive columns of a row = one 16-byte store (bias, activation, masks and sign bits applied in registers);
 //     layer 1 writes the same 16-byte piece into the hand-off tile in the swizzled image, so layer 2 reads it like an X tile;
-//   * the sign-bit outputs are collected in 1 KiB LDS tiles and leave as one 16-byte-per-lane store a tile later.
+//   * the sign-bit outputs are collected in 1 KiB LDS tiles and leave a tile later, a quarter of the tile per wave of the layer;
 //   * the backward form (KEEP): the activation-mask bit tensors (mask0 on the input, mask1 on layer 1's result) travel as one
 //     1 KiB DMA per tile and mask next to the rows; mask0 is applied to a landed tile in place one tile AHEAD of its use (no
 //     second barrier; the counted wait then asks for tile t + 1), mask1 in layer 1's epilogue from the tile's bits in LDS.
@@ -28,7 +30,8 @@
 // vmcnt counts loads, stores and LDS-DMAs of a wave together, in issue order.  So that "tile t has landed" stays a COUNTED wait
 // with kD tiles in flight, every wave issues the same vector-memory operations per tile -- 2 row DMAs, then 4 result stores
 // (rows past the end and the idle role of the first / last iterations store into a dump area instead of being predicated
-// off) -- and the one extra operation (the sign-bit store of one wave per layer) only makes that wave's wait stricter.
+// off; with sign bits a fifth store, every wave its quarter of the tile) -- and the extra operations of the backward form (the
+// mask-bit DMAs, one wave per tile and mask) only make that wave's wait stricter.
 #include "dn_common.h"
 #include "dn_internal.h"
 
