@@ -142,14 +142,34 @@ __global__ __launch_bounds__(256) void wgrad_any_reduce_kernel(const float* __re
         const int64_t k = ((int64_t)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
         if (k >= K) return;
         float s = 0.f;
-        for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) s += cs_partial[(size_t)c * K + k];
+        int c = chunk_ptr[r];
+        const int ce = chunk_ptr[r + 1];
+        for (; c + 8 <= ce; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = cs_partial[(size_t)(c + j) * K + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; c < ce; ++c) s += cs_partial[(size_t)c * K + k];
         cs_out[(size_t)r * K + k] = s;
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
+    // eight loads in flight, added in chunk order (the same association as one at a time: a thread's chain of dependent
+    // round trips was 21 us per launch at config 4, for a 38 x 256 gradient)
     float s = 0.f;
-    for (int c = chunk_ptr[r]; c < chunk_ptr[r + 1]; ++c) s += partial[(size_t)c * elems + i];
+    int c = chunk_ptr[r];
+    const int ce = chunk_ptr[r + 1];
+    for (; c + 8 <= ce; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(c + k) * elems + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; c < ce; ++c) s += partial[(size_t)c * elems + i];
     out[(size_t)r * elems + i] = cvt<T>(s);
 }
 
