@@ -218,12 +218,22 @@ class GraphBatch:
 def graph_ptr_i32(data):
     """int32 node ranges per graph of a PyG-style batch (uses .ptr when present, else derives it from .batch)."""
     p = getattr(data, "ptr", None)
+    hit = getattr(data, "_dn_ptr_i32", None)                  # (kept on the batch object: one conversion per batch, not per readout)
+    if hit is not None and p is not None and hit[0] is p and hit[1] == p._version and hit[2].device == data.x.device:
+        return hit[2]
     if p is None:
         b = data.batch
         ng = int(b.max().item()) + 1 if b.numel() else 0
         cnt = torch.bincount(b, minlength=ng)
         p = torch.cat([torch.zeros(1, dtype=torch.long, device=cnt.device), torch.cumsum(cnt, 0)])
-    return p.to(device=data.x.device, dtype=torch.int32)
+    out = p.to(device=data.x.device, dtype=torch.int32)
+    src = getattr(data, "ptr", None)
+    if src is not None:
+        try:
+            data._dn_ptr_i32 = (src, src._version, out)
+        except Exception:                                     # (a batch object without settable attributes: just no cache)
+            pass
+    return out
 
 
 def _node_ptr_or_none(data):

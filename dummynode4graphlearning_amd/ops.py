@@ -1095,16 +1095,33 @@ class _SegmentReduce(torch.autograd.Function):
                   "dn_segment_max_bwd")
             return gin, None, None
         (ptr_,) = ctx.saved_tensors
-        S = ptr_.numel() - 1
-        # broadcast each graph's row back to its nodes: a row gather keyed by the node's graph id
-        seg_of_row = torch.repeat_interleave(torch.arange(S, device=g.device, dtype=I32),
-                                             (ptr_[1:] - ptr_[:-1]).long(), output_size=ctx.rows)
-        scale = None
-        if ctx.kind == "mean":
-            cnt = (ptr_[1:] - ptr_[:-1]).to(torch.float32).clamp(min=1.0)
-            scale = (1.0 / cnt).index_select(0, seg_of_row.long())
+        # broadcast each graph's row back to its nodes: a row gather keyed by the node's graph id (+ 1 / count for the mean)
+        seg_of_row, scale = _segment_rows(ptr_, ctx.rows, ctx.kind == "mean")
         gin = gather_segsum(g, seg_of_row, None, scale=scale)
         return gin, None, None
+
+
+_segment_rows_cache = {}
+
+
+def _segment_rows(ptr_, rows, want_scale):
+    """(graph id of every row [rows] int32, 1 / rows-of-its-graph per row or None) for a batch's graph_ptr -- five small launches,
+    kept per ptr tensor (id, version): every readout of every layer and step over the same batch object reuses them."""
+    key = (id(ptr_), ptr_._version, int(rows), ptr_.data_ptr())
+    hit = _segment_rows_cache.get(key)
+    if hit is None or hit[0]() is not ptr_:
+        S = ptr_.numel() - 1
+        lens = ptr_[1:] - ptr_[:-1]
+        seg = torch.repeat_interleave(torch.arange(S, device=ptr_.device, dtype=I32), lens.long(), output_size=int(rows))
+        if len(_segment_rows_cache) > 64:
+            _segment_rows_cache.clear()
+        import weakref
+        hit = [weakref.ref(ptr_), seg, None]
+        _segment_rows_cache[key] = hit
+    if want_scale and hit[2] is None:
+        cnt = (ptr_[1:] - ptr_[:-1]).to(torch.float32).clamp(min=1.0)
+        hit[2] = (1.0 / cnt).index_select(0, hit[1].long())
+    return hit[1], (hit[2] if want_scale else None)
 
 
 def segment_reduce(x, graph_ptr, kind="sum"):
@@ -1890,11 +1907,14 @@ class _BatchNormRowsFn(torch.autograd.Function):
         ctx.has_w, ctx.has_b = weight is not None, bias is not None
         ctx.wdtype = weight.dtype if weight is not None else None
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)                      # (no zero tensors for the statistics outputs' "gradients": 2 fills a call)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         x, mean, rstd, w32, b32 = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 8
         dy = dy.contiguous()
         N, C = x.shape
         dx = torch.empty_like(x)
