@@ -92,8 +92,8 @@ _SIGS = {
     "dn_rows_wgrad_any_f32": (ctypes.c_int, [P, P, c_i32, c_i32, c_i64, P, c_i64, P, P, P, P, c_sz, P]),
     "dn_rows_wgrad_any_bf16": (ctypes.c_int, [P, P, c_i32, c_i32, c_i64, P, c_i64, P, P, P, P, c_sz, P]),
     "dn_batchnorm_rows_workspace_bytes": (c_sz, [c_i64, c_i32]),
-    "dn_batchnorm_rows_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, c_f32, P, P, P, P, P, P, c_f32, c_i32, P, c_sz, P]),
-    "dn_batchnorm_rows_bf16": (ctypes.c_int, [P, c_i64, c_i32, P, P, c_f32, P, P, P, P, P, P, c_f32, c_i32, P, c_sz, P]),
+    "dn_batchnorm_rows_f32": (ctypes.c_int, [P, c_i64, c_i32, P, P, c_f32, P, P, P, P, P, P, c_f32, c_i32, P, P, c_sz, P]),
+    "dn_batchnorm_rows_bf16": (ctypes.c_int, [P, c_i64, c_i32, P, P, c_f32, P, P, P, P, P, P, c_f32, c_i32, P, P, c_sz, P]),
     "dn_batchnorm_rows_bwd_f32": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, c_i32, P, P, P, P, c_sz, P]),
     "dn_batchnorm_rows_bwd_bf16": (ctypes.c_int, [P, P, c_i64, c_i32, P, P, P, P, c_i32, P, P, P, P, c_sz, P]),
     "dn_edge_norm_f32": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i64] + [P] * 7 + [P]),

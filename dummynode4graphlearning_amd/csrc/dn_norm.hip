@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void colfinal_kernel(const float* __restric
                                                           const T* __restrict__ X, float eps, float* __restrict__ out0,
                                                           float* __restrict__ out1, float* __restrict__ out2,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          float momentum) {
+                                                          float momentum, long long* __restrict__ batches_tracked) {
     constexpr int SL = 8, CPB = kBlock / SL;                            // 32 columns per block
     __shared__ float r1[SL][CPB], r2[SL][CPB];
     const int cl = threadIdx.x % CPB, slice = threadIdx.x / CPB;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(kBlock) void colfinal_kernel(const float* __restric
         out0[c] = mean;
         out1[c] = var;
         out2[c] = rsqrtf(var + eps);
+        if (batches_tracked && c == 0) *batches_tracked += 1;          // (BatchNorm's num_batches_tracked buffer: no launch of its own)
         if (run_mean) {                                                 // torch's update: r = (1 - m) r + m * new, unbiased variance
             const float unb = var * ((float)N / (float)(N > 1 ? N - 1 : 1));
             run_mean[c] = run_mean[c] * (1.f - momentum) + momentum * mean;
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
 
 template <typename T>
 int bn_forward(const T* X, int64_t N, int32_t C, const float* w, const float* b, float eps, T* Y, float* mean, float* var, float* rstd,
-               float* run_mean, float* run_var, float momentum, int32_t relu, float* ws, size_t ws_bytes, hipStream_t st) {
+               float* run_mean, float* run_var, float momentum, int32_t relu, long long* batches_tracked, float* ws, size_t ws_bytes,
+               hipStream_t st) {
     DN_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "dn_batchnorm_rows: running_mean and running_var come together");
     DN_REQUIRE(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dn_batchnorm_rows: need N >= 1 and C a multiple of 4 in [4, 1024] (got %lld x %d)",
                (long long)N, C);
@@ -199,7 +201,7 @@ int bn_forward(const T* X, int64_t N, int32_t C, const float* w, const float* b,
     hipLaunchKernelGGL((colreduce_kernel<T, 0>), dim3((unsigned)nchunks), dim3(kBlock), (size_t)GPB * 2 * C * sizeof(float), st, X,
                        (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, C, ws);
     hipLaunchKernelGGL((colfinal_kernel<0, T>), dim3((unsigned)dn_cdiv(C, kBlock / 8)), dim3(kBlock), 0, st, (const float*)ws, nchunks, N, C, X,
-                       eps, mean, var, rstd, run_mean, run_var, momentum);
+                       eps, mean, var, rstd, run_mean, run_var, momentum, batches_tracked);
     const int64_t blocks = dn_cdiv(N * (C / 4), kBlock);
     hipLaunchKernelGGL((colapply_kernel<T, 0>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, st, X, (const T*)nullptr,
                        (const float*)mean, (const float*)rstd, w, b, (const float*)nullptr, (const float*)nullptr, relu, N, C, Y);
@@ -220,7 +222,7 @@ int bn_backward(const T* DY, const T* X, int64_t N, int32_t C, const float* mean
     hipLaunchKernelGGL((colreduce_kernel<T, 1>), dim3((unsigned)nchunks), dim3(kBlock), (size_t)GPB * 2 * C * sizeof(float), st, X, DY, mean,
                        rstd, w, b, relu, N, C, ws);
     hipLaunchKernelGGL((colfinal_kernel<1, T>), dim3((unsigned)dn_cdiv(C, kBlock / 8)), dim3(kBlock), 0, st, (const float*)ws, nchunks, N, C, X,
-                       0.f, s1, s2, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
+                       0.f, s1, s2, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, (long long*)nullptr);
     const int64_t blocks = dn_cdiv(N * (C / 4), kBlock);
     hipLaunchKernelGGL((colapply_kernel<T, 1>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, st, X, DY, mean, rstd, w,
                        b, (const float*)s1, (const float*)s2, relu, N, C, DX);
@@ -238,15 +240,15 @@ size_t dn_batchnorm_rows_workspace_bytes(int64_t N, int32_t C) {
 }
 int dn_batchnorm_rows_f32(const float* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, float* Y, float* mean,
                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
-                          void* workspace, size_t workspace_bytes, dn_stream_t stream) {
-    return bn_forward<float>(X, N, C, weight, bias, eps, Y, mean, var, rstd, running_mean, running_var, momentum, relu, (float*)workspace,
-                             workspace_bytes, (hipStream_t)stream);
+                          int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    return bn_forward<float>(X, N, C, weight, bias, eps, Y, mean, var, rstd, running_mean, running_var, momentum, relu,
+                             (long long*)num_batches_tracked, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 int dn_batchnorm_rows_bf16(const void* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, void* Y, float* mean,
                            float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
-                           void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                           int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     return bn_forward<bf16_t>((const bf16_t*)X, N, C, weight, bias, eps, (bf16_t*)Y, mean, var, rstd, running_mean, running_var, momentum,
-                              relu, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+                              relu, (long long*)num_batches_tracked, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 int dn_batchnorm_rows_bwd_f32(const float* DY, const float* X, int64_t N, int32_t C, const float* mean, const float* rstd,
                               const float* weight, const float* bias, int32_t relu, float* DX, float* sum_dy, float* sum_dy_xhat,

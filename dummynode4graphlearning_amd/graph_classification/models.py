@@ -45,10 +45,14 @@ def hip_batch_norm_forward(mod, x, relu):
         return F.relu(y) if relu else y
     w, b = (mod.weight, mod.bias) if mod.affine else (None, None)
     if mod.track_running_stats:
+        nbt = mod.num_batches_tracked
+        if mod.momentum is not None and mod.running_mean.dtype == torch.float32 and nbt.is_cuda and nbt.dtype == torch.int64:
+            # the running-statistics update and the batch counter ride in the statistics launch (six tiny launches otherwise)
+            return ops.batch_norm_rows(x, w, b, mod.eps, mod.running_mean, mod.running_var, mod.momentum, relu=relu,
+                                       batches_tracked=nbt)[0]
         with torch.no_grad():
             mod.num_batches_tracked += 1
         if mod.momentum is not None and mod.running_mean.dtype == torch.float32:
-            # the running-statistics update rides in the statistics launch (five tiny elementwise launches otherwise)
             return ops.batch_norm_rows(x, w, b, mod.eps, mod.running_mean, mod.running_var, mod.momentum, relu=relu)[0]
     y, mean, var = ops.batch_norm_rows(x, w, b, mod.eps, relu=relu)
     if mod.track_running_stats:

@@ -1886,9 +1886,12 @@ class _BatchNormRowsFn(torch.autograd.Function):
     """Training-mode BatchNorm over the rows of [N, C] (dn_batchnorm_rows_*): returns (y, mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.0, relu=False):
+    def forward(ctx, x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.0, relu=False, batches_tracked=None):
         x = x.contiguous()
         N, C = x.shape
+        if batches_tracked is not None:
+            require_gpu(batches_tracked)
+            assert batches_tracked.dtype == torch.int64 and batches_tracked.numel() == 1
         if running_mean is not None:
             assert running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
             assert running_mean.is_contiguous() and running_var.is_contiguous() and running_mean.numel() == C
@@ -1899,7 +1902,8 @@ class _BatchNormRowsFn(torch.autograd.Function):
         ws = _ws(lib().dn_batchnorm_rows_workspace_bytes(N, C), x.device)
         check(getattr(lib(), "dn_batchnorm_rows_" + _suffix(x))(ptr(x), N, C, ptr(w32), ptr(b32), float(eps), ptr(y), ptr(mean), ptr(var),
                                                                ptr(rstd), ptr(running_mean), ptr(running_var), float(momentum),
-                                                               1 if relu else 0, ptr(ws), ws.numel(), stream_ptr()),
+                                                               1 if relu else 0, ptr(batches_tracked), ptr(ws), ws.numel(),
+                                                               stream_ptr()),
               "dn_batchnorm_rows")
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, mean, rstd, w32 if w32 is not None else x.new_empty(0),
@@ -1914,7 +1918,7 @@ class _BatchNormRowsFn(torch.autograd.Function):
     def backward(ctx, dy, _dm, _dv):
         x, mean, rstd, w32, b32 = ctx.saved_tensors
         if dy is None:
-            return (None,) * 8
+            return (None,) * 9
         dy = dy.contiguous()
         N, C = x.shape
         dx = torch.empty_like(x)
@@ -1927,7 +1931,7 @@ class _BatchNormRowsFn(torch.autograd.Function):
                                                                    ws.numel(), stream_ptr()), "dn_batchnorm_rows_bwd")
         gw = s2.to(ctx.wdtype) if ctx.has_w else None
         gb = s1.to(ctx.wdtype if ctx.has_w else dy.dtype) if ctx.has_b else None
-        return dx, gw, gb, None, None, None, None, None
+        return dx, gw, gb, None, None, None, None, None, None
 
 
 def batch_norm_rows_supported(x):
@@ -1935,11 +1939,11 @@ def batch_norm_rows_supported(x):
             and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
 
 
-def batch_norm_rows(x, weight, bias, eps=1e-5, running_mean=None, running_var=None, momentum=0.0, relu=False):
+def batch_norm_rows(x, weight, bias, eps=1e-5, running_mean=None, running_var=None, momentum=0.0, relu=False, batches_tracked=None):
     """(y, batch mean, biased batch variance) of training-mode BatchNorm over the rows of x; relu: y = ReLU(BatchNorm(x)) in the
     same launches, forward and backward.  running_mean / running_var (fp32 buffers, optional) are updated in place by the
-    statistics launch: r = (1 - momentum) r + momentum * new, unbiased variance."""
-    return _BatchNormRowsFn.apply(x, weight, bias, eps, running_mean, running_var, momentum, relu)
+    statistics launch: r = (1 - momentum) r + momentum * new, unbiased variance; batches_tracked (int64 [1], optional): + 1."""
+    return _BatchNormRowsFn.apply(x, weight, bias, eps, running_mean, running_var, momentum, relu, batches_tracked)
 
 
 _single_rel_tables = {}

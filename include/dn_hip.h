@@ -544,14 +544,15 @@ int dn_rows_wgrad_any_bf16(const void* A, const void* G, int32_t K, int32_t N, i
  *   backward:  DY' = DY where Y > 0 (relu; Y is recomputed from X), else DY;  sum_dy [C] (= dbias), sum_dy_xhat [C] (= dweight)
  *              of DY';  DX = weight * rstd * (DY' - sum_dy / N - xhat * sum_dy_xhat / N)
  * fp32 statistics whatever the storage type; C a multiple of 4, <= 1024; deterministic.  running_mean / running_var (fp32 [C],
- * both or neither; NULL: skipped) receive torch's update r = (1 - momentum) r + momentum * new with the unbiased variance. */
+ * both or neither; NULL: skipped) receive torch's update r = (1 - momentum) r + momentum * new with the unbiased variance;
+ * num_batches_tracked (int64 [1] on the device, may be NULL) is incremented by the same launch (BatchNorm1d's buffer of that name). */
 size_t dn_batchnorm_rows_workspace_bytes(int64_t N, int32_t C);
 int dn_batchnorm_rows_f32(const float* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, float* Y, float* mean,
                           float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
-                          void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                          int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_batchnorm_rows_bf16(const void* X, int64_t N, int32_t C, const float* weight, const float* bias, float eps, void* Y, float* mean,
                            float* var, float* rstd, float* running_mean, float* running_var, float momentum, int32_t relu,
-                           void* workspace, size_t workspace_bytes, dn_stream_t stream);
+                           int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, dn_stream_t stream);
 int dn_batchnorm_rows_bwd_f32(const float* DY, const float* X, int64_t N, int32_t C, const float* mean, const float* rstd,
                               const float* weight, const float* bias, int32_t relu, float* DX, float* sum_dy, float* sum_dy_xhat,
                               void* workspace, size_t workspace_bytes, dn_stream_t stream);

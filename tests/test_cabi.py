@@ -99,7 +99,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     rc = L.dn_overflow_rows_add_bf16(None, 256, None, 6, 8, None, None, 5, 0, 0, None, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_batchnorm_rows_f32(ctypes.c_void_p(16), 8, 64, None, None, 1e-5, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
-                                 ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0.1, 0, ctypes.c_void_p(16), 1 << 20, None)
+                                 ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0.1, 0, None, ctypes.c_void_p(16), 1 << 20, None)
     assert rc == -1 and b"running_mean and running_var come together" in L.dn_last_error()
 
 

@@ -704,6 +704,18 @@ def test_batch_norm_rows_with_fused_relu_and_running_statistics(N, C):
         torch.testing.assert_close(bd.grad.cpu().double(), bn.bias.grad, rtol=1e-3, atol=1e-3 * max(1.0, N ** 0.5 / 10))
         torch.testing.assert_close(rm.cpu().double(), bn.running_mean, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(rv.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
+    # the module: BatchNorm1d's num_batches_tracked rides in the statistics launch (no launch of its own), state_dict parity
+    from dummynode4graphlearning_amd.graph_classification.models import HipBatchNorm1d
+    ref = torch.nn.BatchNorm1d(C)
+    mod = HipBatchNorm1d(C, fuse_relu=False).to(DEV)
+    mod.load_state_dict(ref.state_dict())
+    xs = torch.from_numpy(rng.standard_normal((max(N, 2), C)).astype(np.float32))
+    for _ in range(3):
+        mod(xs.to(DEV))
+        ref(xs)
+    assert int(mod.num_batches_tracked) == int(ref.num_batches_tracked) == 3
+    torch.testing.assert_close(mod.running_mean.cpu(), ref.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mod.running_var.cpu(), ref.running_var, rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
