@@ -504,6 +504,16 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
 // with one partial product per run of tiles was built on top of this kernel and measured: 1.1 GB fewer HBM reads per launch, the same
 // time -- docs/LAB_NOTES.md, round 3.)
 // -------------------------------------------------------------------------------------------------
+#ifdef DN_WG_STATS
+// diagnostic build (-DDN_WG_STATS): shader-clock cycles of the last launch per workgroup, waves 0 (issues its DMAs first) and 4
+// (multiplies first): {loop, wait + barrier, DMA issue, fragments + MFMAs + column sums}, and the loop's wall ticks (100 MHz)
+__device__ unsigned long long g_wg_stats[256][2][5];
+#define DN_WG_STAMP() __builtin_amdgcn_s_memtime()
+#define DN_WG_STAT(var, expr) var += (expr)
+#else
+#define DN_WG_STAMP() 0ull
+#define DN_WG_STAT(var, expr)
+#endif
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
                                                                    int32_t na1, const int32_t* __restrict__ ia,
                                                                    const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
@@ -535,38 +545,56 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
         p0 = ch_beg + Tc * TR + RW * wave;
         pe = min(ch_beg + Tc * TR + TR, ch_end) - 1;
     };
-    auto dma_idx = [&](int T) {                    // lanes 0..7: {ia, ig}[min(p0 + (lane & 3), pe)] -> ring (lane l lands at + 4 l)
+    // The index octet of a wave and tile sits in the ring as {ia0, ia2, ig0, ig2, ia1, ia3, ig1, ig3} (rows p0 .. p0 + 3 of the wave):
+    // the four values a lane needs for its two DMA pairs -- rows rin and 2 + rin of both operands -- are ONE 16-byte LDS read.
+    auto dma_idx = [&](int T) {                    // lanes 0..7 fetch one index each (lane l lands at + 4 l)
         int p0, pe;
         bool live;
         tile_rows(T, p0, pe, live);
-        const int pc = max(min(p0 + (lane & 3), pe), 0);
+        const int row = (lane >> 2) + 2 * (lane & 1);                      // lane l: row (l >> 2) + 2 (l & 1) of ia (l & 2 clear) / ig
+        const int pc = max(min(p0 + row, pe), 0);
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T % kSlots) * 32u));
-        if (lane < 8) glds4((lane < 4 ? ia : ig) + pc, dst);
+        if (lane < 8) glds4(((lane & 2) ? ig : ia) + pc, dst);
     };
     const int rin = lane / LPRW, cpos = lane % LPRW;
+    // Address of a row = base + index * 512 (+ the second source's displacement for indices >= n1): one 64-bit multiply-add, one
+    // compare and one 64-bit select.  (Round 3's form -- compare, base select, subtract, shift, add, zero-row select per operand
+    // behind two dependent LDS reads and two exec-masked regions -- was ~230 of a tile's ~790 timer ticks per wave: the address
+    // arithmetic, not the DMA instructions, is what the issue phase cost; ablations in docs/LAB_NOTES.md, round 4.)
+    const uint64_t dA = (uint64_t)(uintptr_t)A2 - (uint64_t)(uintptr_t)A - (uint64_t)(uint32_t)na1 * ROWB;   // (A2 == NULL: never selected)
+    const uint64_t dG = (uint64_t)(uintptr_t)G2 - (uint64_t)(uintptr_t)G - (uint64_t)(uint32_t)ng1 * ROWB;
+    int gch2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = RW * wave + 2 * j + rin;                            // row of the stage this lane fills
+        const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
+        gch2[j] = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;             // source byte offset inside the row
+    }
     auto issue = [&](int T) {                      // the 4 row DMAs of tile T (indices of tile T have landed)
         int p0, pe;
         bool live;
         tile_rows(T, p0, pe, live);
-        const int32_t* iv = &idxL[wave][T % kSlots][0];
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 iv = *reinterpret_cast<const i32x4*>(&idxL[wave][T % kSlots][4 * rin]);   // {ia[k], ia[2 + k], ig[k], ig[2 + k]}, k = rin
         const unsigned st = lds_base + (unsigned)(T % NST) * STB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = 2 * j + rin;                                     // my row of the wave's 4
-            const int rl = RW * wave + k;                                  // row of the stage this lane fills
-            const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
-            const int gch = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;   // source byte offset inside the row
+            // rows past the chunk's end (and whole tiles past it): G reads the zero row, so the pair adds nothing; A repeats the
+            // chunk's last row (the index was clamped), unless its column sums are wanted -- then it reads the zero row too
             const bool ok = live && p0 + k <= pe;
-            const int32_t ra = iv[k], rg = iv[4 + k];
-            const bool a2 = ra >= na1, g2 = rg >= ng1;
-            const uint64_t ba = a2 ? (uint64_t)(uintptr_t)A2 : (uint64_t)(uintptr_t)A;
-            const uint64_t bg = g2 ? (uint64_t)(uintptr_t)G2 : (uint64_t)(uintptr_t)G;
-            const uint64_t oa = (uint64_t)(uint32_t)(a2 ? ra - na1 : ra) * ROWB, og = (uint64_t)(uint32_t)(g2 ? rg - ng1 : rg) * ROWB;
-            const uint64_t pa = (ok ? ba + oa : (uint64_t)(uintptr_t)zero) + (uint64_t)gch;
-            const uint64_t pg = (ok ? bg + og : (uint64_t)(uintptr_t)zero) + (uint64_t)gch;
+            const int32_t ra = iv[j], rg = iv[2 + j];
+            uint64_t pa = (uint64_t)(uintptr_t)A + (uint64_t)(uint32_t)ra * ROWB + (ra >= na1 ? dA : 0ull);
+            uint64_t pg = (uint64_t)(uintptr_t)G + (uint64_t)(uint32_t)rg * ROWB + (rg >= ng1 ? dG : 0ull);
+            pg = ok ? pg : (uint64_t)(uintptr_t)zero;
+            if (colsum_of == 1) pa = ok ? pa : (uint64_t)(uintptr_t)zero;  // (wave-uniform condition)
             const unsigned da = st + (unsigned)(RW * wave + 2 * j) * ROWB;  // wave-uniform; lane l lands at + 16 l
-            glds16(reinterpret_cast<const char*>(pa), da);
-            glds16(reinterpret_cast<const char*>(pg), da + MATB);
+#if defined(DN_WG_STATS) && defined(DN_WG_ABL)
+            if (DN_WG_ABL & 1) { asm volatile("" :: "v"(pa), "v"(pg)); continue; }                       // (ablation: address math, no DMAs)
+            if (DN_WG_ABL & 2) { glds16(zero + lane * 16, da); glds16(zero + lane * 16, da + MATB); continue; }   // (DMAs from one row, no math)
+#endif
+            glds16(reinterpret_cast<const char*>(pa + (uint64_t)gch2[j]), da);
+            glds16(reinterpret_cast<const char*>(pg + (uint64_t)gch2[j]), da + MATB);
         }
     };
 
@@ -619,11 +647,19 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
     for (int T = 0; T < NST - 1; ++T) issue(T);
     wait_vmcnt<8>();                                                       // tile 0 has landed (the loop's count starts at tile 1)
     const bool dma_first = wave < 4;
+    unsigned long long st_bar = 0, st_dma = 0, st_mm = 0;
+    const unsigned long long l0 = DN_WG_STAMP();
+#ifdef DN_WG_STATS
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
     for (int t = 0; t < ntiles; ++t) {
+        const unsigned long long a0 = DN_WG_STAMP();
         // issued after the index octet of tile t+3 (two tiles ago): its tile's 4 row DMAs and last tile's kOps operations
         wait_vmcnt<kOps + 4>();                                            // rows of tile t, indices of tile t+3
         __builtin_amdgcn_s_barrier();                                      // everyone's have; stage of tile t-1 is free
+        const unsigned long long a1 = DN_WG_STAMP();
+        DN_WG_STAT(st_bar, a1 - a0);
         // the two waves of a SIMD (w and w + 4) take turns: one issues its DMAs while the other multiplies (issuing a DMA costs a
         // wave 100-185 cycles; in lock step the SIMD's matrix pipe would idle through both waves' issue phases)
         if (dma_first) {
@@ -631,6 +667,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
             issue(t + NST - 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long a2 = DN_WG_STAMP();
+        if (dma_first) DN_WG_STAT(st_dma, a2 - a1);
         char* sA = lds + (t % NST) * STB;
         const char* sG = sA + MATB;
         {
@@ -661,12 +699,21 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long a3 = DN_WG_STAMP();
+        DN_WG_STAT(st_mm, a3 - a2);
         if (!dma_first) {
             dma_idx(t + 5);
             issue(t + NST - 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my LDS reads of tile t are done before the next barrier
+        if (!dma_first) DN_WG_STAT(st_dma, DN_WG_STAMP() - a3);
     }
+#ifdef DN_WG_STATS
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_wg_stats[blockIdx.x][wave >> 2];
+        o[0] = DN_WG_STAMP() - l0; o[1] = st_bar; o[2] = st_dma; o[3] = st_mm; o[4] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
     wait_vmcnt<0>();                                                       // drain what is still in flight
     __builtin_amdgcn_s_barrier();
     flush((int)blockIdx.x);
@@ -1669,3 +1716,9 @@ int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b
 }
 
 }  // extern "C"
+
+#ifdef DN_WG_STATS
+extern "C" int dn_debug_wgrad_stats(unsigned long long* out) {             // diagnostic build only: 256 x 2 x 5 counters of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_stats), sizeof(g_wg_stats)) == hipSuccess ? 0 : -2;
+}
+#endif
