@@ -249,7 +249,7 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_row[64];        // 1 KiB of
 #ifndef DN_WGM_ABL
 #define DN_WGM_ABL 0        // diagnostic builds (DN_BUILD_EXTRA=-DDN_WGM_ABL=n): 1 no mask pass, 2 mask bits from the zero row
 #endif
-template <int H, bool MASKED>
+template <int H, bool MASKED, bool DENSE>
 __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t* __restrict__ A,
                                                                     const bf16_t* __restrict__ A2, int32_t na1,
                                                                     const int32_t* __restrict__ ia,
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     const int rin = lane / LPRW, cpos = lane % LPRW;
     int32_t nxa[RW], nxg[RW];                      // wave-uniform source rows of the next tile to issue
     auto load_idx = [&](int T) {                   // scalar loads (wave-uniform addresses), branch-free
+        if constexpr (DENSE) return;                // (both operands in row order: the addresses follow from the tile number)
         const int p0 = ch.beg + T * TR + RW * wave, pe = ch.end - 1;
         int32_t pc[RW];
 #pragma unroll
@@ -320,6 +321,22 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
             const int rl = RW * wave + RPI * j + rin;                      // row of the stage this lane fills
             const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
             const int gch = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;     // source byte offset inside the row
+            if constexpr (DENSE) {
+                // no index, no second source (the MLP's weight gradients): row p of both operands, or the zero row past the
+                // chunk's end -- one 64-bit multiply-add and one select per operand instead of the general path's ~25
+                // instructions per DMA pair (what the issue phase of these launches costs is this arithmetic: see rows_wgrad_ix_kernel)
+                const int p = ch.beg + T * TR + rl;
+                const bool okp = p < ch.end;
+                const uint64_t off = (uint64_t)(uint32_t)p * ROWB + (uint64_t)gch;
+                const uint64_t za = (uint64_t)(uintptr_t)zero + (uint64_t)gch;
+                const uint64_t pa = okp ? (uint64_t)(uintptr_t)A + off : za;
+                const uint64_t pg = okp ? (uint64_t)(uintptr_t)G + off : za;
+                const unsigned da = st + (unsigned)(RW * wave + RPI * j) * ROWB;
+                glds16(reinterpret_cast<const char*>(pa), da);
+                if constexpr (MASKED) pgs[j] = pg;
+                else glds16(reinterpret_cast<const char*>(pg), da + MATB);
+                continue;
+            }
             int32_t ra = nxa[RPI * j], rg = nxg[RPI * j];
 #pragma unroll
             for (int k = 1; k < RPI; ++k) {
@@ -1438,12 +1455,18 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
                     return DN_OK;
                 }
             }
-            if (maskBits)
-                hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, true>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
-                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope);
-            else
-                hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, false>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
-                                   na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope);
+            const bool dense = ia == nullptr && ig == nullptr && A2 == nullptr && G2 == nullptr;
+#define DN_WGRAD_DMA(M, D)                                                                                            \
+            hipLaunchKernelGGL((rows_wgrad_dma_kernel<HI, M, D>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2, \
+                               na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope)
+            if (maskBits) {                                                // (mask bits come with ia == NULL: dn_rows_wgrad_bf16)
+                if (dense) DN_WGRAD_DMA(true, true);
+                else DN_WGRAD_DMA(true, false);
+            } else {
+                if (dense) DN_WGRAD_DMA(false, true);
+                else DN_WGRAD_DMA(false, false);
+            }
+#undef DN_WGRAD_DMA
             DN_CHECK_LAUNCH();
             return DN_OK;
         }
