@@ -95,6 +95,24 @@ def test_rccl_bucket_and_syncbn_match_plain_step(nccl_world_of_one):
             torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5, msg=k)
 
 
+def test_rccl_average_of_a_bf16_bucket(nccl_world_of_one):
+    """bench.py's config-5 bucket is bf16 and FlatGradBucket averages inside the collective on RCCL (ReduceOp.AVG): the call must
+    be accepted for bf16 and, in a world of one, leave the gradients bit for bit."""
+    from dummynode4graphlearning_amd import parallel
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(256, 256, device=DEV).to(torch.bfloat16)) for _ in range(3)]
+    bucket = parallel.FlatGradBucket(params)
+    want = []
+    for p in params:
+        p.grad = torch.randn_like(p)
+        want.append(p.grad.clone())
+    bucket.all_reduce()
+    torch.cuda.synchronize()
+    for p, w in zip(params, want):
+        assert p.grad.data_ptr() != w.data_ptr() and torch.equal(p.grad, w)
+    assert params[0].grad.data_ptr() == bucket.flat.data_ptr()
+
+
 def test_overlapped_reducer_over_rccl_on_a_three_layer_stack(nccl_world_of_one):
     """parallel.OverlappedGradReducer on a 3-layer RGIN stack (the reference's depth, config.py rgin_num_layers): every layer's
     bucket leaves for RCCL from INSIDE backward, in reverse layer order, and the step equals the plain one."""
