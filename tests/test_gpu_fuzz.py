@@ -78,27 +78,30 @@ def test_randomised_parity_sweep():
         kind = rng.choice(["rgin", "rgcn"])
         self_loop = bool(rng.integers(0, 2))
         torch.manual_seed(int(rng.integers(0, 1 << 30)))
+        # (the reference CLI's defaults -- leaky_relu, bdd with 4 blocks: config.py:116,148,332,404 -- are in the mix)
+        act = str(rng.choice(["relu", "leaky_relu"]))
+        reg, nb = ("bdd", 4) if rng.integers(0, 3) == 0 else ("basis", -1)
         if kind == "rgin":
             nm = int(rng.choice([0, 2]))
-            layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_mlp_layers=nm, self_loop=self_loop, act_func="relu")
+            layer = RGINLayer(H, H, num_rels=R, regularizer=reg, num_bases=nb, num_mlp_layers=nm, self_loop=self_loop, act_func=act)
         else:
             norm = str(rng.choice(["none", "in", "both"]))
-            layer = RGCNLayer(H, H, num_rels=R, regularizer="basis", edge_norm=norm, self_loop=self_loop, act_func="relu")
+            layer = RGCNLayer(H, H, num_rels=R, regularizer=reg, num_bases=nb, edge_norm=norm, self_loop=self_loop, act_func=act)
         x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
         coef = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
         s_t, d_t, e_t = (torch.from_numpy(rs[k]) for k in ("src", "dst", "edge_label"))
         p = {k: v.detach().clone() for k, v in layer.named_parameters()}
         xr = x.clone().requires_grad_(True)
         if kind == "rgin":
-            ref_o = OL.rgin_layer(xr, s_t, d_t, e_t, p, regularizer="basis", num_rels=R, num_bases=-1, num_mlp_layers=nm, act="relu")
+            ref_o = OL.rgin_layer(xr, s_t, d_t, e_t, p, regularizer=reg, num_rels=R, num_bases=nb, num_mlp_layers=nm, act=act)
         else:
-            ref_o = OL.rgcn_layer(xr, s_t, d_t, e_t, p, regularizer="basis", num_rels=R, num_bases=-1, edge_norm=norm, act="relu")
+            ref_o = OL.rgcn_layer(xr, s_t, d_t, e_t, p, regularizer=reg, num_rels=R, num_bases=nb, edge_norm=norm, act=act)
         (ref_o * coef).sum().backward()
         dl = layer.to(DEV)
         xd = x.to(DEV).requires_grad_(True)
         out, _ = dl(BatchedGraph(s_t.to(DEV), d_t.to(DEV), N), xd, e_t.to(DEV))
         (out * coef.to(DEV)).sum().backward()
-        desc = (kind, H, "self_loop=%s" % self_loop, "N=%d E=%d R=%d" % (N, len(rs["src"]), R), "round %d" % rounds)
+        desc = (kind, H, act, reg, "self_loop=%s" % self_loop, "N=%d E=%d R=%d" % (N, len(rs["src"]), R), "round %d" % rounds)
         scale = float(ref_o.detach().abs().max().clamp(min=1e-6))
         e_out = float((out.detach().cpu() - ref_o.detach()).abs().max()) / scale
         assert e_out < 1e-4, desc + ("out", e_out)
