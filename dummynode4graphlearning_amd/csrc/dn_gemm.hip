@@ -74,6 +74,81 @@ __global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict
     }
 }
 
+// The fp32 product on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate -- bit for bit an fmaf
+// chain, so the GC models' 1e-4 parity through BatchNorm is untouched), any K and N: the first conv of a GC model (F = 5 .. 38
+// node features -> H hidden units), hidden sizes outside {64, 128, 256}, the [H, 2] classifier heads.  One 256-thread workgroup
+// per 64 x 64 output tile: wave w owns rows 16 w .. 16 w + 15 of the tile and all 64 columns (4 accumulators); the TRANSPOSED
+// product is formed (A operand = 16 columns of the weight, B operand = the wave's 16 rows), so a lane ends up with 4 consecutive
+// columns of one row = one 16-byte store.  Operands are staged through LDS in K-steps of 32 (zero-padded at the edges).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kThreads) void rows_gemm_mfma_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                      const float* __restrict__ bias, int32_t K, int32_t N,
+                                                                      int32_t transposed, const Piece* __restrict__ tiles,
+                                                                      float* __restrict__ Y) {
+    constexpr int KC = 32;
+    __shared__ float As[TM][KC + 1];                                     // [row][k]
+    __shared__ float Ws[KC][TN + 1];                                     // [k][n]
+    const Piece tl = tiles[blockIdx.x];
+    const int rows = tl.end - tl.beg;
+    if (rows <= 0) return;
+    const int n0 = blockIdx.y * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float* Wr = W + (size_t)tl.rel * K * N;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        for (int i = tid; i < TM * KC; i += kThreads) {                  // A tile: consecutive threads along k (contiguous in memory)
+            const int r = i / KC, k = i % KC;
+            As[r][k] = (r < rows && k0 + k < K) ? A[(size_t)(tl.beg + r) * K + k0 + k] : 0.f;
+        }
+        if (transposed) {                                                // W[rel][n][k]: consecutive threads along k
+            for (int i = tid; i < KC * TN; i += kThreads) {
+                const int n = i / KC, k = i % KC;
+                Ws[k][n] = (k0 + k < K && n0 + n < N) ? Wr[(size_t)(n0 + n) * K + k0 + k] : 0.f;
+            }
+        } else {                                                         // W[rel][k][n]: consecutive threads along n
+            for (int i = tid; i < KC * TN; i += kThreads) {
+                const int k = i / TN, n = i % TN;
+                Ws[k][n] = (k0 + k < K && n0 + n < N) ? Wr[(size_t)(k0 + k) * N + n0 + n] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int kend = (K - k0 < KC ? K - k0 : KC);
+        for (int kk = 0; kk < kend; kk += 4) {                           // (a step past K multiplies the zero padding)
+            const float b = As[16 * wave + j][kk + g];                   // B operand: row 16 w + j of the tile, k = kk + g
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[kk + g][16 * n + j], b, acc[n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // lane (j, g): row 16 w + j of the tile, columns n0 + 16 n + 4 g + (0 .. 3) for n = 0 .. 3
+    const int r = 16 * wave + j;
+    if (r >= rows) return;
+    float* yrow = Y + (size_t)(tl.beg + r) * N;
+    const float* brow = bias ? bias + (size_t)tl.rel * N : nullptr;
+    const bool vec = (N % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int c = n0 + 16 * n + 4 * g;
+        if (c >= N) continue;
+        float v[4] = {acc[n][0], acc[n][1], acc[n][2], acc[n][3]};
+        if (brow) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < N) v[i] += brow[c + i];
+        }
+        if (vec) *reinterpret_cast<float4*>(yrow + c) = make_float4(v[0], v[1], v[2], v[3]);   // (N % 4 == 0: c + 3 < N)
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < N) yrow[c + i] = v[i];
+        }
+    }
+}
+
 // partial[chunk][k0 : k0 + 64, n0 : n0 + 64] = sum_{p in chunk} A[p, k]^T G[p, n]
 template <typename T>
 __global__ __launch_bounds__(kThreads) void rows_wgrad_any_kernel(const T* __restrict__ A, const T* __restrict__ G, int32_t K,
@@ -179,6 +254,16 @@ int rows_gemm(const T* A, const T* W, const T* bias, int32_t K, int32_t N, int32
     DN_REQUIRE(K >= 1 && N >= 1 && num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_rows_gemm: bad sizes");
     if (num_tiles == 0) return DN_OK;
     DN_REQUIRE(A && W && tiles && Y, "dn_rows_gemm: NULL pointer");
+    if constexpr (sizeof(T) == 4) {                                       // fp32: exact-f32 MFMA tiles
+        static const int mfma = dn_knob("DN_GEMM_MFMA", 1);               // tuning build: 0 keeps the FMA tiles
+        if (mfma) {
+            hipLaunchKernelGGL(rows_gemm_mfma_f32_kernel, dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st,
+                               (const float*)A, (const float*)W, (const float*)bias, K, N, transposed,
+                               reinterpret_cast<const Piece*>(tiles), (float*)Y);
+            DN_CHECK_LAUNCH();
+            return DN_OK;
+        }
+    }
     hipLaunchKernelGGL((rows_gemm_kernel<T>), dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st, A, W, bias, K,
                        N, transposed, reinterpret_cast<const Piece*>(tiles), Y);
     DN_CHECK_LAUNCH();
