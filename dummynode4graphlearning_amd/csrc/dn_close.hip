@@ -233,11 +233,14 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
 
 // Tiles = the graphs of a batch (segment-complete tiles for the absorbed fold): segment j = the nodes seg_nodes[seg_ptr[j] ..
 // seg_ptr[j+1]) (a graph's nodes that feed its dummy node).  Block j = [first node of segment j (0 for j = 0), first node of
-// segment j + 1 (N for the last)).  Valid when every segment is a non-empty contiguous ascending run, the segments ascend and
-// every block has at most 32 nodes; then tile j = block j, fold record j = {local ids: 0 inside the segment, 255 outside;
-// first aux row = j; count = 1}.
+// segment j + 1 (N for the last)).  Valid when every segment is a non-empty contiguous ascending run, the segments ascend,
+// every block has at most 32 nodes AND the row the segment's product is added to (add_idx[j]: the dummy node) lies inside
+// block j -- the AGG unit of tile j is a read-modify-write of that row by the workgroup that STORED tile j, so a target in
+// another block (dummy node first, all dummy nodes at the end of the batch) would race with that block's owner.  Then
+// tile j = block j, fold record j = {local ids: 0 inside the segment, 255 outside; first aux row = j; count = 1}.
 __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
-                                        int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, int32_t* __restrict__ ok) {
+                                        const int32_t* __restrict__ add_idx, int32_t* __restrict__ tile_ptr,
+                                        int32_t* __restrict__ info, int32_t* __restrict__ ok) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > S) return;
     if (j == S) { tile_ptr[S] = N; return; }
@@ -256,6 +259,7 @@ __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __r
     }
     const int32_t b0 = j == 0 ? 0 : first;
     if (good) good = nxt - b0 <= 32 && nxt - b0 >= 1;
+    if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
     if (!good) { *ok = 0; return; }
     tile_ptr[j] = b0;
     uint8_t ids[32];
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             // (selects, not branches: a branch here keeps hipcc from holding the source addresses in registers)
             const uint64_t base0 = baseX + (ent ? dS : 0ull) + (agg ? dA : 0ull);      // (X, S or aux)
 #ifdef DN_TUNING_ENV
-            const uint32_t rmask = (flags & (ent ? 4 : 8)) ? 1023u : 0xffffffffu;   // (ablation: the rows come from L2)
+            const uint32_t rmask = (flags & (ent ? 4 : 8)) ? 1023u : ((ent && (flags & 128)) ? 0x1ffffu : 0xffffffffu);   // (ablation: the rows come from L2 / a 64 MB window)
 #else
             constexpr uint32_t rmask = 0xffffffffu;
 #endif
@@ -754,7 +758,7 @@ size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
     const int64_t M = (int64_t)num_wg * dn_cdiv(num_tiles, num_wg);
     // (the scan's temporary storage -- a look-back state per few thousand elements -- is bounded here without asking rocPRIM, so
     //  that the size query needs no device; dn_close_units_build_i32 checks the real requirement against it)
-    const size_t scan_tmp = 8192 + (size_t)(M + 1);
+    const size_t scan_tmp = 65536 + 4 * (size_t)(M + 1);                  // (rocPRIM 4.x asks for ~(M + 1) / 8 bytes + 2 KB here)
     return dn_align_up((size_t)(num_tiles + 1) * 4, 256) + 2 * dn_align_up((size_t)(M + 1) * 4, 256) + dn_align_up(scan_tmp, 256) + 512;
 }
 
@@ -786,9 +790,8 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
     wsp += dn_align_up((size_t)(M + 1) * 4, 256);
     size_t tb = 0;
     DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
-    DN_REQUIRE(tb <= 8192 + (size_t)(M + 1), "dn_close_units_build: scan storage %zu exceeds the reserved bound", tb);
-    if (M + 1 != T)                                                        // positions without a tile (T not a multiple of num_wg) and the total's slot
-        DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, (size_t)(M + 1) * 4, st));
+    DN_REQUIRE(tb <= 65536 + 4 * (size_t)(M + 1), "dn_close_units_build: scan storage %zu exceeds the reserved bound", tb);
+    DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, (size_t)(M + 1) * 4, st));          // positions without a tile (T not a multiple of num_wg) and the total's slot
     hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,
                        T, tile_ptr, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt, num_wg, Tper,
                        agg_units ? 1 : 0, ucnt);
@@ -802,7 +805,8 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
 }
 
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                                  int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok, dn_stream_t stream) {
+                                  const int32_t* add_idx, int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok,
+                                  dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_graph_tiles_build: bad sizes");
     DN_REQUIRE(dev_ok, "dn_fold_graph_tiles_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -811,7 +815,7 @@ int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t
     DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0, "dn_fold_graph_tiles_build: unaligned pointer");
     DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
     hipLaunchKernelGGL(fold_graph_tiles_kernel, dim3((unsigned)dn_cdiv(num_segments + 1, 256)), dim3(256), 0, st, (int32_t)N,
-                       (int32_t)num_segments, seg_ptr, seg_nodes, tile_ptr, fold_info, dev_ok);
+                       (int32_t)num_segments, seg_ptr, seg_nodes, add_idx, tile_ptr, fold_info, dev_ok);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -835,7 +839,7 @@ int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, co
     hipStream_t st = (hipStream_t)stream;
     static const int nt = dn_knob("DN_NT", 3);
     const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
-    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 31) << 2);
+    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
 #define DN_CLOSE_LAUNCH(F)                                                                                                         \
     hipLaunchKernelGGL((rows_close_ring_kernel<F>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X, (const bf16_t*)W, \

@@ -238,7 +238,6 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
     // ---------------------------------------------------------------------------------------------------- compute
     const bool relu = (flags & 1) != 0, nt_store = (flags & 2) != 0;
 #ifdef DN_TUNING_ENV
-    if ((flags & 512) && wave >= kCompute / 2) __builtin_amdgcn_s_setprio(1);   // (experiment: the younger compute half)
     if ((flags & 1024)) __builtin_amdgcn_s_setprio(2);                          // (experiment: compute over loaders)
 #endif
     const int n0 = 32 * wave;
@@ -301,7 +300,12 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
 #else
             if (p < pend) {
 #endif
-                u32x4* dst = reinterpret_cast<u32x4*>(Y + (size_t)p * kH + ocol);
+#ifdef DN_TUNING_ENV
+                const size_t yrow = (flags & 512) ? (size_t)(p & 0x1ffff) : (size_t)p;   // (experiment: Y inside a 64 MB window)
+#else
+                const size_t yrow = (size_t)p;
+#endif
+                u32x4* dst = reinterpret_cast<u32x4*>(Y + yrow * kH + ocol);
                 if (nt_store) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
             }
@@ -450,9 +454,14 @@ namespace dn_internal {
 int launch_transform_ring256(const void* X_, const void* X2, int32_t n1, const int32_t* idx, const void* Wn, const void* bias,
                              int32_t relu, int32_t nt_store, const void* mask_pos, const int32_t* tiles, int64_t num_tiles,
                              int64_t tiles_per_wg, void* Y, int32_t w_kn, float slope, hipStream_t st) {
+#ifdef DN_TUNING_ENV
+    if (tiles_per_wg <= 0 && dn_knob("DN_TF_RING_WGS", 0) > 0)             // (experiment: a table laid out [workgroups][tiles])
+        tiles_per_wg = dn_cdiv(num_tiles, dn_knob("DN_TF_RING_WGS", 0));
+#endif
     if (tiles_per_wg <= 0) tiles_per_wg = dn_cdiv(num_tiles, 256);       // one persistent workgroup per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
-    static const int abl = dn_knob("DN_TF_ABL", 0);   // tuning build only: 1 no stores, 2 gathers hit L2, 4 no MFMAs, 8 trivial LDS reads, 16 no row DMAs
+    const int abl = dn_knob("DN_TF_ABL", 0);   // tuning build only (read per call): 1 no stores, 2 gathers hit L2, 4 no MFMAs, 8 trivial LDS reads, 16 no row DMAs, 64 Y in a 64 MB window
+    if (dn_knob("DN_TF_NT", 1) == 0) nt_store = 0;
     const int32_t flags = (relu ? 1 : 0) | (nt_store ? 2 : 0) | (w_kn ? 4 : 0) | ((abl & 255) << 3);
 #define DN_RING_LAUNCH(M, I, E, X)                                                                                      \
     hipLaunchKernelGGL((rows_transform_ring_kernel<M, I, E, X>), dim3((unsigned)grid), dim3(kThreads), 0, st, (const bf16_t*)X_, \

@@ -5,6 +5,7 @@ current stream and autograd bookkeeping.  There is deliberately no CPU path.
 """
 import ctypes
 import os as _os
+import threading as _threading
 
 import torch
 
@@ -219,26 +220,44 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
 
 WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
 # fp32 matrix products: False = 3-term bf16 split on the fast MFMA path (1e-5-level agreement with exact f32, inside the
-# reference's 1e-4 bar), True = exact f32 MFMA (1/16 of the bf16 rate; the checker).  Settable at run time.
+# reference's 1e-4 bar), True = exact f32 MFMA (1/16 of the bf16 rate; the checker).  F32_EXACT is the PROCESS default (read once
+# from the environment; assignable); `with f32_exact(...)` overrides it for the calling THREAD only, and every autograd function
+# below records the mode its forward ran in and runs its backward in the same mode -- whatever thread autograd uses for it and
+# whether or not the `with` block has been left by then.
 F32_EXACT = _os.environ.get("DN_F32_EXACT", "0") == "1"
+_f32_tls = _threading.local()
+
+
+def f32_mode():
+    """The fp32 arithmetic a kernel launched NOW from this thread uses: the thread's f32_exact override, else ops.F32_EXACT."""
+    m = getattr(_f32_tls, "mode", None)
+    return F32_EXACT if m is None else m
 
 
 class f32_exact:
-    """Context manager: run the fp32 matrix kernels inside it on the exact-f32 MFMA (True) or on the bf16 split (False)."""
+    """Context manager: run the fp32 matrix kernels inside it on the exact-f32 MFMA (True) or on the bf16 split (False).
+    Thread-local; backward passes of work recorded inside it keep the mode (see F32_EXACT)."""
 
     def __init__(self, on=True):
         self.on = bool(on)
 
     def __enter__(self):
-        global F32_EXACT
-        self.old = F32_EXACT
-        F32_EXACT = self.on
+        self.old = getattr(_f32_tls, "mode", None)
+        _f32_tls.mode = self.on
         return self
 
     def __exit__(self, *exc):
-        global F32_EXACT
-        F32_EXACT = self.old
+        _f32_tls.mode = self.old
         return False
+
+
+def _backward_in_forward_mode(backward):
+    """Decorator of an autograd backward: run it in the fp32 mode its forward recorded (ctx.f32_mode)."""
+    def wrapped(ctx, *grads):
+        with f32_exact(ctx.f32_mode):
+            return backward(ctx, *grads)
+    wrapped.__doc__ = backward.__doc__
+    return wrapped
 
 
 def make_row_chunks(rel_ptr_host, device, chunk_rows=None):
@@ -288,7 +307,7 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
         if is_f32:
             check(lib().dn_rows_wgrad_f32(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                           ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out), int(colsum_of), ptr(colsum),
-                                          ptr(mask_a), ptr(a_out), 1 if F32_EXACT else 0, float(slope), ptr(ws), ws.numel(), stream_ptr()),
+                                          ptr(mask_a), ptr(a_out), 1 if f32_mode() else 0, float(slope), ptr(ws), ws.numel(), stream_ptr()),
                   "dn_rows_wgrad_f32")
         else:
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
@@ -399,7 +418,7 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
         n1 = X.shape[0] if X2 is not None else INT32_MAX
         if X.dtype == torch.float32:
             check(lib().dn_rows_transform_f32(ptr(X), ptr(X2), n1, ptr(idx), Hi, Ho, ptr(Wn), ptr(bias), 1 if relu else 0,
-                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if F32_EXACT else 0, float(slope),
+                                              ptr(mask_pos), ptr(tiles), ntiles, ptr(Y), 1 if f32_mode() else 0, float(slope),
                                               ptr(W_loop), int(loop_rel) if W_loop is not None else -1, int(bias_rel),
                                               1 if w_kn else 0, stream_ptr()),
                   "dn_rows_transform_f32")
@@ -528,19 +547,21 @@ def _num_cus(dev):
     return int(torch.cuda.get_device_properties(dev).multi_processor_count)
 
 
-def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None):
+def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
     """Tiles = the graphs of a batch, for the absorbed fold (dn_fold_graph_tiles_build_i32, one launch, no read-back):
-    -> (tile_ptr [S + 1], fold_info [S, 12], ok [1] device flag: non-zero when every graph has at most 32 nodes and the
-    segments are contiguous ascending runs)."""
-    require_gpu(seg_ptr, seg_nodes)
+    -> (tile_ptr [S + 1], fold_info [S, 12], ok [1] device flag: non-zero when every graph has at most 32 nodes, the
+    segments are contiguous ascending runs and -- add_idx [S] given -- every segment's target row lies inside its own tile:
+    the AGG unit of a tile is a read-modify-write by the workgroup that stored the tile)."""
+    require_gpu(seg_ptr, seg_nodes, add_idx)
     dev = seg_ptr.device
     S = int(seg_ptr.numel()) - 1
     tile_ptr = torch.empty(S + 1, dtype=I32, device=dev)
     info = torch.empty((max(S, 1), 12), dtype=I32, device=dev)
     if ok is None:
         ok = torch.zeros(1, dtype=I32, device=dev)
-    check(lib().dn_fold_graph_tiles_build_i32(int(num_nodes), S, ptr(seg_ptr), ptr(seg_nodes), ptr(tile_ptr), ptr(info), ptr(ok),
-                                              stream_ptr()), "dn_fold_graph_tiles_build_i32")
+    assert add_idx is None or (add_idx.dtype == I32 and add_idx.numel() == S and add_idx.is_contiguous())
+    check(lib().dn_fold_graph_tiles_build_i32(int(num_nodes), S, ptr(seg_ptr), ptr(seg_nodes), ptr(add_idx), ptr(tile_ptr),
+                                              ptr(info), ptr(ok), stream_ptr()), "dn_fold_graph_tiles_build_i32")
     return tile_ptr, info[:S], ok
 
 
@@ -1024,6 +1045,7 @@ class _RelAggTransform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, index, edge_scale):
+        ctx.f32_mode = f32_mode()
         x = x.contiguous()
         W = W.contiguous()
         ix = index
@@ -1039,6 +1061,7 @@ class _RelAggTransform(torch.autograd.Function):
         return agg
 
     @staticmethod
+    @_backward_in_forward_mode
     def backward(ctx, g):
         g = g.contiguous()
         A, W = ctx.saved_tensors
@@ -1324,6 +1347,9 @@ def _closing_tables(ix, kind="slots"):
              for d in ("f", "b")}
     dirs = ("f", "b")
 
+    def add_idx_of(direction, cand):
+        return (ix.row_out if direction == "f" else ix.row_in)[cand[1]:cand[2]].contiguous()
+
     def make_info(direction, cand):
         r, beg, end, n_aux = cand
         info = _Fold()
@@ -1333,7 +1359,7 @@ def _closing_tables(ix, kind="slots"):
         #                                                    one partial row, every tile boundary inside one another
         info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
         info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
-        info.add_idx = (ix.row_out if direction == "f" else ix.row_in)[beg:end].contiguous()
+        info.add_idx = add_idx_of(direction, cand)
         return info
 
     tabs = {}
@@ -1346,7 +1372,8 @@ def _closing_tables(ix, kind="slots"):
             for k, d in enumerate(dirs):
                 if cands[d] is not None:
                     aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if d == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
-                    gts[d] = build_graph_tiles(aux_ptr[:cands[d][3] + 1].contiguous(), aux_idx, N, ok=flags[2 + k:])
+                    gts[d] = build_graph_tiles(aux_ptr[:cands[d][3] + 1].contiguous(), aux_idx, N, ok=flags[2 + k:],
+                                               add_idx=add_idx_of(d, cands[d]))
             if gts:
                 h = flags.cpu().tolist()                             # synchronisation 1: can the fold be absorbed?
         need_parts = [d for k, d in enumerate(dirs) if cands[d] is not None and h[2 + k] == 0]
@@ -1370,11 +1397,12 @@ def _closing_tables(ix, kind="slots"):
     elif kind == "slots":
         for d in dirs:
             info = ix._fold[d]
+            enable = None
             if info is not None and info.fold_info is None:          # absorbed so far: the slot kernel needs the partial-row tables
-                flag = torch.zeros(1, dtype=I32, device=dev)         # (valid whenever the graph tiles were: same contiguity test)
-                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, flag)
+                enable = torch.zeros(1, dtype=I32, device=dev)       # (valid whenever the graph tiles were -- same contiguity test --
+                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, enable)   # but the rows are only dropped if so)
             drop = (info.beg, info.end) if info is not None else (0, 0)
-            tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop)
+            tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop, drop_enable=enable)
     for d in dirs:
         info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
@@ -1384,10 +1412,11 @@ def _closing_tables(ix, kind="slots"):
         elif info is not None and info.graph_tiles is not None:     # every graph inside one tile: the fold is absorbed
             ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
         else:
+            enable = None
             if info is not None and info.fold_info is None:
-                flag = torch.zeros(1, dtype=I32, device=dev)
-                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, flag)
-            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop)
+                enable = torch.zeros(1, dtype=I32, device=dev)
+                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, enable)
+            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, drop_enable=enable)
 
 
 def _row_index_slots(ix, direction):
@@ -1592,6 +1621,7 @@ class _RowTransformFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, W_loop, bias, index_set):
+        ctx.f32_mode = f32_mode()
         x = x.contiguous()
         H_out = W.shape[2]
         pw = PassWeights(W, W_loop, kn=True)
@@ -1608,6 +1638,7 @@ class _RowTransformFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_backward_in_forward_mode
     def backward(ctx, g):
         iset = ctx.index_set
         g = g.contiguous()
@@ -1729,7 +1760,7 @@ class _LinearActFn(torch.autograd.Function):
         tiles, _ = _dense_table(x.shape[0], x.device)
         # exact: None = module default, True / False, or "fwd" = exact products where errors propagate (forward, input
         # gradient), the 3-term split for the weight gradient (a leaf: its 1e-5 relative error goes nowhere)
-        ctx.exact = F32_EXACT if exact is None else bool(exact)
+        ctx.exact = f32_mode() if exact is None else bool(exact)
         ctx.exact_w = False if exact == "fwd" else ctx.exact
         with f32_exact(ctx.exact):
             y = rows_transform(x, weight.contiguous().unsqueeze(0), tiles, x.shape[0],
@@ -1791,6 +1822,7 @@ class _ReluMlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, slope, *wb):
+        ctx.f32_mode = f32_mode()
         n = len(wb) // 2
         x = x.contiguous()
         ctx.slope = slope = float(slope)
@@ -1812,6 +1844,7 @@ class _ReluMlpFn(torch.autograd.Function):
         return acts[-1]
 
     @staticmethod
+    @_backward_in_forward_mode
     def backward(ctx, gout):
         n, slope = ctx.n, ctx.slope
         saved = ctx.saved_tensors
@@ -1970,6 +2003,7 @@ class _LinearAnyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ctx.f32_mode = f32_mode()
         x = x.contiguous()
         tiles, _ = _single_rel_table(x.shape[0], x.device)
         y = rows_gemm(x, weight.contiguous().unsqueeze(0), tiles, transpose_w=True,          # W[0] is [N, K] = [out, in]
@@ -1979,6 +2013,7 @@ class _LinearAnyFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_backward_in_forward_mode
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()

@@ -191,33 +191,48 @@ class OverlappedGradReducer:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(gi)))
         self._arm()
 
+    # The ORDER of the collectives is the same on every rank whatever each rank's data does: groups leave in reverse forward
+    # order (last group first -- the order backward completes them in), and a group whose gradients are all there leaves only
+    # once every group behind it in that order has left.  A rank on which some parameter of a later group got no gradient (a
+    # data-dependent branch, an empty shard) therefore holds the earlier groups back until finish() instead of enqueuing its
+    # all-reduces in another order than its peers (a hang -- or, with equally sized per-layer buckets, layer A averaged with
+    # layer B).
     def _arm(self):
         for gi, b in enumerate(self.buckets):
             self._pending[gi] = {id(p) for p in b.params}
             self._works[gi], self._done[gi] = None, False
+        self._next = len(self.buckets) - 1              # the group whose collective must be issued next
         self.launched = []
 
     def _make_hook(self, gi):
         def hook(param):
-            pend = self._pending[gi]
-            pend.discard(id(param))
-            if not pend and not self._done[gi]:
-                self._launch(gi)
+            if self._done[gi]:
+                raise RuntimeError("OverlappedGradReducer: a gradient of group %d arrived after the group's all-reduce was "
+                                   "issued (a second backward() without finish(): the flat buffer already holds the AVERAGED "
+                                   "gradients). Call finish() after every backward(); accumulate micro-batches with a plain "
+                                   "FlatGradBucket and one all_reduce()." % gi)
+            self._pending[gi].discard(id(param))
+            self._drain()
         return hook
 
+    def _drain(self):
+        while self._next >= 0 and not self._pending[self._next]:
+            self._launch(self._next)
+
     def _launch(self, gi):
+        assert gi == self._next and not self._done[gi]
         waiting = sum(1 for gj, b in enumerate(self.buckets) if not self._done[gj] and gj != gi
                       for p in b.params if id(p) in self._pending[gj])
         self.launched.append((gi, waiting))
         self._done[gi] = True
+        self._next = gi - 1
         self._works[gi] = self.buckets[gi].all_reduce(async_op=True)
 
     def finish(self):
-        """Call after backward(): reduces the groups whose hooks never all fired (unused parameters), waits for every collective
-        and re-arms the hooks for the next step."""
-        for gi in range(len(self.buckets)):
-            if not self._done[gi]:
-                self._launch(gi)
+        """Call after backward(): reduces the groups that are still held back (a parameter without a gradient, in them or in a
+        group behind them) in the same fixed order, waits for every collective and re-arms the hooks for the next step."""
+        while self._next >= 0:
+            self._launch(self._next)
         for works in self._works:
             for w in works or ():
                 w.wait()

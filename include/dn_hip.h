@@ -407,8 +407,11 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * dn_fold_graph_tiles_build_i32 (one launch): the tiles of a batch of GRAPHS for the absorbed fold.  Segment j = the nodes
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) as in dn_fold_tables_build_i32; block j = [first node of segment j (0 for j = 0), first
  * node of segment j + 1 (N for the last)).  *dev_ok (device) stays non-zero when every segment is a non-empty contiguous
- * ascending run, the segments ascend and every block has at most 32 nodes; then tile_ptr [num_segments + 1] = the block starts
- * (tile j = block j) and fold_info [num_segments][12] = per tile {32 bytes: 0 for a node of the segment, 255 otherwise; j; 1; 0; 0}.
+ * ascending run, the segments ascend, every block has at most 32 nodes and (add_idx != NULL, device [num_segments]: the output
+ * row the segment's product is added to, i.e. the agg_idx of dn_rows_close_bf16) add_idx[j] lies inside block j -- the AGG unit
+ * of tile j is a read-modify-write of out[add_idx[j]] by the workgroup that stored tile j, so a target in another block (the
+ * dummy node in front of its graph, all dummy nodes at the end of the batch) keeps the partial rows + dn_fold_tail_bf16.  Then
+ * tile_ptr [num_segments + 1] = the block starts (tile j = block j) and fold_info [num_segments][12] = per tile {32 bytes: 0 for a node of the segment, 255 otherwise; j; 1; 0; 0}.
  *
  * dn_rows_close_bf16: one persistent workgroup per entry of unit_ptr (launch num_wg = the builder's).  W: the self-loop weight,
  * w_kn = 0: [H][H] with k contiguous (W_loop transposed, as dn_rows_selfsum_bf16 takes it), w_kn = 1: [k][n] as the
@@ -428,7 +431,8 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
                              int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream);
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                                  int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok, dn_stream_t stream);
+                                  const int32_t* add_idx, int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok,
+                                  dn_stream_t stream);
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,

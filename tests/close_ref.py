@@ -8,8 +8,9 @@ DEDUP_CAP = 256          # kCbCap in csrc/dn_close.hip: tiles with more raw list
 AGG_GAP = 8              # kAggGap: NOP units between a workgroup's tiles and its AGG units
 
 
-def graph_tiles_ref(seg_ptr, seg_nodes, N):
-    """dn_fold_graph_tiles_build_i32: -> (ok, tile_ptr [S+1], fold_info [S,12] int32)."""
+def graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=None):
+    """dn_fold_graph_tiles_build_i32: -> (ok, tile_ptr [S+1], fold_info [S,12] int32).  add_idx [S]: the row each segment's
+    product is added to; it must lie inside the segment's own block."""
     sp, sn = np.asarray(seg_ptr, dtype=np.int64), np.asarray(seg_nodes, dtype=np.int64)
     S = len(sp) - 1
     firsts, lasts = [], []
@@ -26,6 +27,8 @@ def graph_tiles_ref(seg_ptr, seg_nodes, N):
         if j + 1 < S and nxt <= lasts[j]:
             return False, None, None
         if not (1 <= nxt - b0 <= 32):
+            return False, None, None
+        if add_idx is not None and not (b0 <= int(add_idx[j]) < nxt):
             return False, None, None
         tile_ptr[j] = b0
         ids = np.array([0 if firsts[j] <= b0 + i <= lasts[j] else 255 for i in range(32)], dtype=np.uint8)

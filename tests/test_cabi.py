@@ -86,7 +86,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
                                     None)
     assert rc == -1 and b"32-node windows" in L.dn_last_error()
     ok = ctypes.c_int32(0)
-    rc = L.dn_fold_graph_tiles_build_i32(10, 2, None, None, None, None, ctypes.c_void_p(16), None)
+    rc = L.dn_fold_graph_tiles_build_i32(10, 2, None, None, None, None, None, ctypes.c_void_p(16), None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     assert L.dn_bdd_compose(None, 0, 4, 16, 16, 2, None, None) == 0
     rc = L.dn_bdd_compose(None, 3, 4, 16, 16, 3, ctypes.c_void_p(16), ctypes.c_void_p(16), None) if False else L.dn_bdd_extract(

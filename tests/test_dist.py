@@ -151,9 +151,9 @@ def _overlap_worker(rank, world, port, q):
             torch.manual_seed(0)
             return torch.nn.Sequential(torch.nn.Linear(6, 7), torch.nn.ReLU(), torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
         model, ref = make(), make()
-        unused = torch.nn.Parameter(torch.ones(4))                     # a group whose hooks never fire
-        layers = [model[0], model[2], model[4]]
-        reducer = OverlappedGradReducer([l.parameters() for l in layers] + [[unused]])
+        unused = torch.nn.Parameter(torch.ones(4))                     # a group whose hooks never fire: it goes FIRST (the groups
+        layers = [model[0], model[2], model[4]]                        # leave last-to-first, so it holds nobody back)
+        reducer = OverlappedGradReducer([[unused]] + [l.parameters() for l in layers])
         opt = torch.optim.SGD(list(model.parameters()) + [unused], lr=0.1)
         ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
         torch.manual_seed(1)
@@ -186,8 +186,60 @@ def test_overlapped_reducer_launches_each_layers_collective_inside_backward():
         for log in logs:
             # the three layer groups left in reverse layer order, from inside backward(); when the last layer's bucket left, the 4
             # parameters of the two layers below had no gradient yet (their backward had not run), then 2, then 0
-            assert [g for g, _ in log] == [2, 1, 0], log
+            assert [g for g, _ in log] == [3, 2, 1], log
             assert [w - 1 for _, w in log] == [4, 2, 0], log           # (-1: the never-used parameter stays pending)
+
+
+def _overlap_uneven_worker(rank, world, port, q):
+    """A parameter of the LAST group gets a gradient on rank 0 only (a data-dependent branch): the ranks must still issue their
+    collectives in the same order -- rank 1 holds every group back until finish() instead of sending layer 1 first."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dummynode4graphlearning_amd.parallel import OverlappedGradReducer
+        torch.manual_seed(0)
+        l0, l1 = torch.nn.Linear(5, 5), torch.nn.Linear(5, 5)          # equally sized buckets: a swapped order would not even fail
+        extra = torch.nn.Parameter(torch.full((5,), 0.5))              # part of the last group, used on rank 0 only
+        reducer = OverlappedGradReducer([l0.parameters(), list(l1.parameters()) + [extra]])
+        torch.manual_seed(1 + rank)
+        x = torch.randn(4, 5)
+        orders = []
+        for step in range(2):
+            for p in list(l0.parameters()) + list(l1.parameters()) + [extra]:
+                p.grad = None
+            def loss():
+                y = l1(torch.relu(l0(x)))
+                return ((y + extra) if rank == 0 else y).square().mean()
+            ps = list(l0.parameters()) + list(l1.parameters())
+            want = {id(p): g.detach().clone() for p, g in zip(ps, torch.autograd.grad(loss(), ps))}   # (no accumulation: no hooks)
+            loss().backward()
+            during = [g for g, _ in reducer.launched]
+            reducer.finish()
+            orders.append(during)
+            # averaged gradients: gather both ranks' local ones and compare
+            for p in list(l0.parameters()) + list(l1.parameters()):
+                both = [torch.zeros_like(want[id(p)]) for _ in range(world)]
+                dist.all_gather(both, want[id(p)])
+                assert torch.allclose(p.grad, (both[0] + both[1]) / 2, atol=1e-6)
+        raised = False
+        for p in list(l0.parameters()) + list(l1.parameters()) + [extra]:
+            p.grad = None
+        (l1(torch.relu(l0(x))) + extra).square().mean().backward()     # every group complete: all collectives have left ...
+        try:
+            (l1(torch.relu(l0(x))) + extra).square().mean().backward() # ... so a second backward without finish() must refuse
+        except RuntimeError as e:
+            raised = "finish()" in str(e)
+        reducer.finish()
+        q.put((rank, orders, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_keeps_one_collective_order_on_every_rank():
+    res = {r: (o, raised) for r, o, raised in _run_world(_overlap_uneven_worker)}
+    assert res[0][0] == [[1, 0], [1, 0]]                # rank 0: both groups left inside backward, last group first
+    assert res[1][0] == [[], []]                        # rank 1: `extra` never got a gradient -> everything waits for finish()
+    assert res[0][1] and res[1][1]
 
 
 def _syncbn_worker(rank, world, port, q):

@@ -132,6 +132,46 @@ def test_rows_close_against_the_slot_kernel_and_without_any_rows():
     assert float(((out.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max()) < 6e-3
 
 
+def test_non_finite_product_row_poisons_its_column_of_the_tile_and_nothing_else():
+    """The documented difference to the reference's index_add_ ("non-finite values"): the unit-stream launch sums
+    through a 0/1 selection-matrix MFMA, and 0 x NaN = NaN, so ONE non-finite element of a product row turns that COLUMN NaN for
+    every node of the 32-node tile whose entry unit holds the row -- and for nothing else: other columns of the tile, other tiles
+    and the nodes of other units stay finite and correct.  The slot kernel (DN_CLOSE_RING=0) confines it to the nodes that sum
+    the row, as the reference does."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(23)
+    N, P = 640, 1500
+    lists, ptr, rows, x, Y, W, b = _close_case(rng, N, P, "plain")
+    v, col = 100, 77                                                           # node 100 (tile 3) sums the poisoned row
+    bad = int(lists[v][0]) if len(lists[v]) > 1 else None
+    if bad is None:
+        lists[v] = np.array([5, P + v])
+        ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+        rows, bad = np.concatenate(lists), 5
+    Y = Y.clone()
+    Y[bad, col] = float("nan")
+    users = [u for u in range(N) if bad in lists[u][:-1]]
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    xd, Yd, Wd, bd = x.to(DEV), Y.to(DEV), W.to(DEV), b.to(DEV)
+    out = ops.rows_close(xd, Wd, bd, Yd, ops.build_close_units(lp, lr, N, P), w_kn=True).float().cpu()
+    nan = torch.isnan(out)
+    tiles = sorted({u // 32 for u in users})
+    want = torch.zeros_like(nan)
+    for t in tiles:
+        want[32 * t:32 * t + 32, col] = True
+    assert bool((nan & ~want).sum() == 0)                                      # nothing outside those tiles' column `col`
+    assert all(bool(nan[u, col]) for u in users)                               # the nodes that sum the row: NaN, as in the reference
+    Yc = Y.clone()
+    Yc[bad, col] = 0.0
+    ref = _ref_close(x, W, b, Yc, lists, P)
+    ok = ~want
+    assert float((((out.double() - ref).abs() / (ref.abs() + 1.0))[ok]).max()) < 6e-3
+    slots, over = ops.build_slot_table(lp, lr, N, P)
+    old = ops.rows_selfsum(xd, Wd.t().contiguous(), bd, Yd, None, slots, lists=(lp, lr, P, 0, 0, over)).float().cpu()
+    nan_old = torch.isnan(old)
+    assert sorted(int(u) for u in nan_old.any(1).nonzero().reshape(-1)) == sorted(users) and bool(nan_old[:, col].sum() == nan_old.sum())
+
+
 def test_parameter_layout_weights_give_the_same_bits_as_the_transposed_copy():
     """w_kn = 1 (weights read as the reference stores them, [in][out]) against w_kn = 0 on an explicit transposed copy: the ring
     transform (several relation switches per workgroup) and the fold tail, bit for bit; other widths refuse w_kn."""
@@ -196,8 +236,9 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G):
     lists, ptr, rows, seg_ptr, seg_nodes, dummies, N = _graph_batch(rng, sizes, P)
     S = len(sizes)
     sp, sn = torch.from_numpy(seg_ptr).to(DEV).int(), torch.from_numpy(seg_nodes).to(DEV).int()
-    tile_ptr, info, ok = ops.build_graph_tiles(sp, sn, N)
-    okr, tpr, infor = graph_tiles_ref(seg_ptr, seg_nodes, N)
+    tgt = torch.from_numpy(dummies).to(DEV).int()
+    tile_ptr, info, ok = ops.build_graph_tiles(sp, sn, N, add_idx=tgt)
+    okr, tpr, infor = graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=dummies)
     assert okr and int(ok.item()) != 0
     assert np.array_equal(tile_ptr.cpu().numpy(), tpr) and np.array_equal(info.cpu().numpy(), infor)
     lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
@@ -212,7 +253,6 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G):
     x, Y = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((P, H)))
     W, Wa = bf(rng.standard_normal((H, H)) / np.sqrt(H)), bf(rng.standard_normal((H, H)) / np.sqrt(H))
     b = bf(rng.standard_normal(H))
-    tgt = torch.from_numpy(dummies).to(DEV).int()
     for w_kn in (True, False):
         aux = torch.empty((S, H), dtype=torch.bfloat16, device=DEV)
         Wd, Wad = (W.to(DEV), Wa.to(DEV)) if w_kn else (W.t().contiguous().to(DEV), Wa.t().contiguous().to(DEV))
@@ -232,3 +272,9 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G):
     # a graph over 32 nodes: the verdict is "no" and the caller keeps the partial rows + tail
     big_ptr, big_nodes = torch.tensor([0, 40], device=DEV, dtype=torch.int32), torch.arange(40, device=DEV, dtype=torch.int32)
     assert int(ops.build_graph_tiles(big_ptr, big_nodes, 41)[2].item()) == 0
+    # a target row outside its segment's own block (the dummy node of graph j stored by another tile's workgroup): "no" as well --
+    # the AGG unit is a read-modify-write of that row by the workgroup that owns the tile
+    for bad in (np.roll(dummies, 1), np.full_like(dummies, N - 1), np.maximum(dummies - 32, 0)):
+        if S > 1 and not all(tpr[j] <= bad[j] < tpr[j + 1] for j in range(S)):
+            assert not graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=bad)[0]
+            assert int(ops.build_graph_tiles(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int())[2].item()) == 0

@@ -642,7 +642,10 @@ def test_bf16_step_is_bitwise_reproducible():
     gen = torch.Generator(device=DEV).manual_seed(9)
     x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
     coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
-    g = BatchedGraph(aug["src"], aug["dst"], N)
+    # the batch WITH its graph boundaries, as bench.py builds it: graph-local index, absorbed fold (AGG units), sweep tile order
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
     et = aug["edge_label"].long()
     runs = []
     for _ in range(4):
@@ -652,6 +655,91 @@ def test_bf16_step_is_bitwise_reproducible():
         out, _ = layer(g, x, et)
         out.backward(coef)
         runs.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    from dummynode4graphlearning_amd import ops
+    ix = g.row_index(et, R, True).parts[0][2]
+    assert ix.built_by == "local"
+    for d in "fb":
+        fold = ops._row_index_fold(ix, d, "units")
+        assert fold is not None and fold.graph_tiles is not None and fold.sweep_tiles is not None and ix.close_units(d).agg
     for r in runs[1:]:
         for a, b in zip(runs[0], r):
             assert torch.equal(a, b)
+
+
+def _dummy_layout_batch(rng, G, n, m, R, layout):
+    """G graphs of n real nodes + one dummy node, m random real edges (types 0 .. R-3), u -> dummy (R-2), dummy -> u (R-1).
+    layout "last": [u_1 .. u_n, d] per graph (train.py:416-426); "first": [d, u_1 .. u_n]; "end": every dummy node behind all
+    real nodes of the batch (no contiguous graph ranges)."""
+    src, dst, et, node_ptr, edge_ptr = [], [], [], [0], [0]
+    for j in range(G):
+        if layout == "end":
+            base, d = j * n, G * n + j
+            real = np.arange(base, base + n)
+        else:
+            base = j * (n + 1)
+            d = base + n if layout == "last" else base
+            real = np.arange(base, base + n) + (0 if layout == "last" else 1)
+        s, t = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+        src += [real[s], real, np.full(n, d)]
+        dst += [real[t], np.full(n, d), real]
+        et += [rng.integers(0, R - 2, size=m), np.full(n, R - 2), np.full(n, R - 1)]
+        node_ptr.append((j + 1) * (n + 1))
+        edge_ptr.append((j + 1) * (m + 2 * n))
+    cat = lambda a: torch.from_numpy(np.concatenate(a).astype(np.int64)).to(DEV)  # noqa: E731
+    return cat(src), cat(dst), cat(et), G * (n + 1), np.array(node_ptr), np.array(edge_ptr)
+
+
+@pytest.mark.parametrize("layout,G", [("first", 200), ("end", 2), ("end", 150), ("last", 200)])
+def test_absorbed_fold_only_where_the_dummy_row_belongs_to_its_own_tile(layout, G):
+    """The AGG units of the unit-stream closing launch add a graph's folded product to the dummy node's row as a plain
+    read-modify-write, which is only ordered when the SAME workgroup stored that row (its own tile).  Layouts that put the dummy
+    node elsewhere -- in front of its graph (the row then belongs to the previous tile), or all dummy nodes at the end of the
+    batch -- must get the verdict "no" from dn_fold_graph_tiles_build_i32 and take partial rows + dn_fold_tail_bf16: results
+    bit-identical to a run with the absorbed fold switched off (DN_CLOSE_AGG=0) and close to fp64; the reference's own layout
+    (dummy last, train.py:416-426) keeps the absorbed fold."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    rng = np.random.default_rng(G)
+    H, R, n, m = 256, 8, 20, 44
+    src, dst, et, N, node_ptr, edge_ptr = _dummy_layout_batch(rng, G, n, m, R, layout)
+    torch.manual_seed(4)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+
+    def run(agg_enabled):
+        old = ops.CLOSE_AGG_ENABLED
+        ops.CLOSE_AGG_ENABLED = agg_enabled
+        try:
+            kw = {}
+            if layout != "end":
+                t = lambda a: torch.from_numpy(a).to(DEV).int()  # noqa: E731
+                kw = dict(node_ptr=t(node_ptr), edge_ptr=t(edge_ptr))
+                g = BatchedGraph(src, dst, N, torch.full((G,), n + 1), torch.full((G,), m + 2 * n), **kw)
+            else:
+                g = BatchedGraph(src, dst, N)
+            for p in layer.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            out, _ = layer(g, x, et)
+            out.backward(coef)
+            ix = g.row_index(et, R, True).parts[0][2]
+            absorbed = [ix.close_units(d).agg for d in "fb"]
+            return absorbed, [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            ops.CLOSE_AGG_ENABLED = old
+
+    absorbed, got = run(True)
+    assert absorbed == ([True, True] if layout == "last" else [False, False]), absorbed
+    _, want = run(False)
+    if layout != "last":
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    else:                                                                # same sums up to the bf16 rounding of the collapsed rows
+        for a, b in zip(got, want):
+            assert _rel_l2(a, b) < 1e-2
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    ref = OL.rgin_layer(x0.double().cpu(), src.cpu(), dst.cpu(), et.cpu(), p64, regularizer="basis", num_rels=R, num_bases=-1,
+                        num_mlp_layers=2, act="relu")
+    assert _rel_l2(got[0], ref) < 3e-2
