@@ -77,6 +77,14 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
                  : "memory");
 }
 
+__device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {  // ... past this CU's L1 (a word another workgroup updates)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -120,6 +128,40 @@ __device__ __forceinline__ void dn_load_w_kn32(const __bf16* __restrict__ w, int
             wf[ks][n] = __builtin_bit_cast(dn_bf16x8, f);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// (the same, KC k-slabs per round trip instead of all KS at once: 8 KC staging registers instead of 8 KS -- for a reload in
+//  the middle of a kernel that has no registers to spare; KS / KC dependent round trips)
+template <int KS, int KC>
+__device__ __forceinline__ void dn_load_w_kn32_lean(const __bf16* __restrict__ w, int ldw, int n0, int lane, char* scratch,
+                                                    dn_bf16x8 (&wf)[KS][2]) {
+    typedef dn_short4v __attribute__((address_space(3))) * lds_tr;
+    const int r16 = lane >> 2, pc4 = lane & 3;
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += KC) {
+        dn_u32x4 raw[KC][2];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                raw[kk][h] = *reinterpret_cast<const dn_u32x4*>(w + (size_t)(32 * (k0 + kk) + 16 * h + r16) * ldw + n0 + 8 * pc4);
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            *reinterpret_cast<dn_u32x4*>(scratch + r16 * 64 + 16 * pc4) = raw[kk][0];
+            *reinterpret_cast<dn_u32x4*>(scratch + (16 + r16) * 64 + 16 * pc4) = raw[kk][1];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const char* a0 = scratch + (8 * g + q4) * 64 + 16 * p4 + 8 * n;
+                const dn_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+                const dn_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * 64));
+                const dn_short8v f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                wf[k0 + kk][n] = __builtin_bit_cast(dn_bf16x8, f);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 

@@ -631,6 +631,36 @@ def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
     return out
 
 
+def rows_fused(x, Wrel, W_loop, bias, S, row_src, tables, cu, agg, out=None, w_kn=False, state=None):
+    """Both launches of one conv direction in one (dn_rows_fused_bf16, H = 256 bf16): S[p] = x[row_src[p]] @ Wrel[rel p] for the
+    transform units of `tables` (unit_ptr, units, num_wg, num_chunks) and out[v] = x[v] @ W_loop (+ bias) + the rows of S that
+    cu lists for v, with the absorbed fold agg = (fold_info, W_agg, aux, agg_idx) as in rows_close.  state = (done [chunks], err [1])
+    int32 device tensors (allocated if None).  Returns (out, state)."""
+    require_gpu(x, Wrel, W_loop, bias, S, row_src, tables["unit_ptr"], tables["units"], cu.ent_row, cu.ent_mask)
+    N, H = x.shape
+    assert H == 256 and x.dtype == torch.bfloat16 and Wrel.dtype == x.dtype and W_loop.shape == (H, H) and Wrel.shape[1:] == (H, H)
+    assert S.dtype == x.dtype and S.shape[1] == H and S.is_contiguous() and row_src.dtype == I32 and N == cu.num_nodes
+    x, Wrel, W_loop = x.contiguous(), Wrel.contiguous(), W_loop.contiguous()
+    fi, wa, ax, ai = agg
+    require_gpu(fi, wa, ax, ai)
+    if out is None:
+        out = torch.empty((N, H), dtype=x.dtype, device=x.device)
+    if state is None:
+        state = (torch.zeros(tables["num_chunks"], dtype=I32, device=x.device), torch.zeros(4, dtype=I32, device=x.device))
+    done, err = state
+
+    def _launch():
+        check(lib().dn_rows_fused_bf16(ptr(x), H, ptr(Wrel), ptr(W_loop), 1 if w_kn else 0, ptr(bias), ptr(S), ptr(row_src),
+                                       ptr(tables["unit_ptr"]), ptr(tables["units"]), tables["num_wg"], ptr(cu.ent_row),
+                                       ptr(cu.ent_mask), N, ptr(out), ptr(fi), ptr(wa), ptr(ax), ptr(ai), ptr(done),
+                                       tables["num_chunks"], ptr(err), stream_ptr()), "dn_rows_fused_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_fused", _launch)
+    else:
+        _launch()
+    return out, state
+
+
 def wgrad_supported(A, G):
     return A.dtype == G.dtype and A.dtype in MFMA_DTYPES and A.shape[1] == G.shape[1] and A.shape[1] in (64, 128, 256)
 
