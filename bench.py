@@ -59,7 +59,7 @@ def shard_of(raw, rank, world):
 def build_batch(dev, seed, graphs, workload, shard=None):
     """shard = (rank, world): only that rank's graphs of the global batch go to the device."""
     from dummynode4graphlearning_amd import BatchedGraph, synthetic, transforms
-    raw = synthetic.config5(seed, graphs) if workload == "config5" else synthetic.config3(seed, graphs)
+    raw = {"config5": synthetic.config5, "config3": synthetic.config3, "proteins": synthetic.proteins_si}[workload](seed, graphs)
     if shard is not None:
         raw, _ = shard_of(raw, *shard)
     t = {k: torch.from_numpy(v).to(dev) for k, v in raw.items() if isinstance(v, np.ndarray)}
@@ -154,10 +154,11 @@ def dry_run(args, rank, world):
         dist.all_reduce(t)
     # the split every rank would take (host-side bookkeeping only: parallel.shard_graphs on the synthetic batch's sizes)
     shards = None
-    if args.workload in ("config5", "config3") and args.scaling == "strong":
+    if args.workload in ("config5", "config3", "proteins") and args.scaling == "strong":
         from dummynode4graphlearning_amd import synthetic
-        graphs = args.graphs or {"config5": 32768, "config3": 512}[args.workload]
-        raw = synthetic.config5(5, graphs) if args.workload == "config5" else synthetic.config3(3, graphs)
+        graphs = args.graphs or {"config5": 32768, "config3": 512, "proteins": 16384}[args.workload]
+        raw = {"config5": synthetic.config5, "config3": synthetic.config3, "proteins": synthetic.proteins_si}[args.workload](
+            {"config5": 5, "config3": 3, "proteins": 2}[args.workload], graphs)
         _, (g0, g1) = shard_of(raw, rank, world)
         mine = torch.tensor([g0, g1], dtype=torch.int64)
         allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
@@ -273,7 +274,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config5", choices=["config5", "config3", "config4"])
+    ap.add_argument("--workload", default="config5", choices=["config5", "config3", "config4", "proteins"],
+                    help="proteins: the config-5 layer (H = 256, R = 16, bf16) on 16384 PROTEINS-shaped graphs (mean 39, up to 620 nodes): "
+                         "graphs over 32 nodes, where the closing launch keeps partial rows + the fold tail")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only launch check: rendezvous over gloo, no product code")
     ap.add_argument("--graphs", type=int, default=0, help="graphs in the global batch (strong) / per GPU (weak); 0 = the workload's own size")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -321,6 +324,8 @@ def main():
 
     if args.workload == "config5":
         H, R, graphs, dtype = 256, 16, args.graphs or 32768, torch.bfloat16
+    elif args.workload == "proteins":
+        H, R, graphs, dtype = 256, 16, args.graphs or 16384, torch.bfloat16
     else:
         H, R, graphs, dtype = 64, 8, args.graphs or 512, torch.float32
     if args.hidden:
@@ -330,7 +335,7 @@ def main():
     s = 2 if dtype == torch.bfloat16 else 4
 
     strong = args.scaling == "strong"
-    seed0 = {"config5": 5, "config3": 3}[args.workload]
+    seed0 = {"config5": 5, "config3": 3, "proteins": 2}[args.workload]
     if strong:                                  # ONE global batch, this rank's contiguous graph range of it
         g, raw, aug_ms = build_batch(dev, seed0, graphs, args.workload, shard=(rank, world))
     else:                                       # weak: every rank its own full batch
@@ -457,6 +462,34 @@ def main():
                  "batch_ms_per_step": ms1, "efficiency_at_8": ms1 / (8.0 * ms8), "predicted_speedup_at_8": ms1 / ms8,
                  "note": "one GPU, no collective: t(batch) / (8 t(eighth)); the 2.5 MB gradient all-reduce of an 8-GPU step is not in it"}
         del p8, g8
+        # ... and with the collective: the RCCL all-reduce of the step's gradient bucket MEASURED in a world of one on this GPU
+        # (launch + kernel latency of the call the 8-GPU step makes; nothing crosses a link), plus what a ring over xGMI adds for
+        # these bytes (2 (W-1)/W x bytes over one 153 GB/s link at 80 %: MI355X_MICROARCH.md) -- a MODEL, no curve was measured
+        if not dist.is_initialized():
+            try:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+                flat = bucket.flat
+                for _ in range(5):
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                ea.record()
+                for _ in range(50):
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                eb.record()
+                torch.cuda.synchronize()
+                ar1 = ea.elapsed_time(eb) / 50
+                dist.destroy_process_group()
+                ring = 2.0 * (7.0 / 8.0) * bucket.bytes() / (0.8 * 153e9) * 1e3
+                proxy.update({"allreduce_world1_ms": ar1, "allreduce_ring_model_8gpu_ms": ar1 + ring,
+                              "predicted_speedup_at_8_incl_allreduce": ms1 / (ms8 + ar1 + ring)})
+            except Exception as exc:                    # (never lose the line to the rendezvous)
+                sys.stderr.write("[bench] world-of-one all-reduce not measured: %s\n" % exc)
 
     # fresh-batch leg (rank 0, one GPU): a training loop sees a new batch every step, so it pays the dummy augmentation and the
     # index build per step.  Sequentially that is `edges_per_s_incl_index_build`; here the NEXT batch's augmentation + index

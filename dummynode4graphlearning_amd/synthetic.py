@@ -74,3 +74,20 @@ def config2(seed=2, graphs=512):
 def config4(seed=4, graphs=512):
     """512 NCI1-shaped graphs per GPU."""
     return tu_shaped_batch(seed, graphs, lambda r: np.clip(round(r.normal(29.9, 13.6)), 3, 111), 1.08, 37, 0)
+
+
+def proteins_si(seed=2, graphs=16384, num_real_types=14):
+    """PROTEINS-shaped graphs (config 2's sizes: mean ~39 nodes, up to 620; ~1.86 undirected edges per node) as an SI-style batch
+    for the RGIN layer: real edge type ~ U{0..num_real_types-1}, +2 dummy relations after the SI dummy augmentation (R = 16).
+    What bench.py --workload proteins times: graphs over 32 nodes, where the closing launch cannot absorb the fold."""
+    b = config2(seed, graphs)
+    rng = np.random.default_rng(seed + 1000)
+    E, N = int(b["src"].shape[0]), int(b["node_ptr"][-1])
+    sizes, esizes = np.diff(b["node_ptr"]), np.diff(b["edge_ptr"])
+    b.update(edge_label=rng.integers(0, num_real_types, size=E, dtype=np.int64), node_label=rng.integers(0, 4, size=N, dtype=np.int64),
+             node_id=np.concatenate([np.arange(n, dtype=np.int64) for n in sizes]) if len(sizes) else np.zeros(0, np.int64),
+             edge_id=np.concatenate([np.arange(m, dtype=np.int64) for m in esizes]) if len(esizes) else np.zeros(0, np.int64),
+             max_nv=int(sizes.max()) if len(sizes) else 0, max_nvl=4, max_ne=int(esizes.max()) if len(esizes) else 0,
+             max_nel=num_real_types, num_rels=num_real_types + 2)
+    return b
+
