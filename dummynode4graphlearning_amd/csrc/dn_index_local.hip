@@ -16,8 +16,11 @@
 //                      the edges, taken with LDS atomics (no comparisons)
 //   (exclusive scan of the packed counts)
 //   ril_fill_kernel    every table, each entry at  scan offset + rank inside the graph.  The ranks are counts of edges that
-//                      compare lower in the (relation, key node, edge) order, taken by all lanes at once against ONE edge whose
-//                      packed words are wave-uniform (broadcast LDS read -> SGPRs): O(m^2) compares, no branch on the common path
+//                      compare lower in the (relation, key node, edge) order.  Round 5: for graphs of up to 256 edges whose
+//                      (relation, node) buckets fit an 11.5 KB table they come from bit sets in LDS (atomic OR, popcounts, one
+//                      prefix sum: fill_fast, no pair work -- the O(m^2) pass was 0.28 of the 0.94 ms a config-5 batch's index
+//                      cost); larger graphs: all lanes at once against ONE edge whose packed words are wave-uniform (broadcast
+//                      LDS read -> SGPRs), O(m^2) compares, no branch on the common path
 //
 // Graphs with more than kLocM edges or kLocNodes nodes, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
 // instead (host_status = 1): the caller then runs the general builder.
@@ -318,21 +321,69 @@ struct FillArgs {
     int32_t *row_in, *row_out, *aux_f_ptr, *aux_f_idx, *aux_b_ptr, *aux_b_idx, *dst_rows, *src_rows;
 };
 
+// What a pass over the graph's edges leaves per edge of this lane (one per 64-edge chunk) -- the five counts the tables' offsets
+// are made of -- and the writes they lead to.
+template <int NC>
+struct Ranks {
+    u32 w0[NC], w1[NC];
+    int rank_rel[NC], heads_before[NC], rank_d[NC], rank_s[NC], later_rows[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ void fill_emit(const Ranks<NC>& K, int lane, int m, int c0, int64_t g, int n0, const FillArgs& A) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c0 + c) * 64 + lane;
+        if (i >= m) continue;
+        const u32 w0 = K.w0[c], w1 = K.w1[c];
+        const int r = (int)(w0 >> 26), md = (int)((w1 >> 28) & 3u), hd = (int)((w1 >> 30) & 1u);
+        const int s = n0 + (int)((w1 >> 14) & 0x3fffu), d = n0 + (int)(w1 & 0x3fffu), kn = md == kTf ? s : d;
+        const int64_t at = (int64_t)r * A.G + g;
+        const int32_t row = A.S0[at] + (md == kEdge ? K.rank_rel[c] : K.heads_before[c]);
+        if (md == kEdge) {
+            A.row_in[row] = s; A.row_out[row] = d;
+        } else if (md == kAgg) {
+            const int32_t pos = A.S3[at] - A.b3 + K.rank_rel[c];            // among the AGG edges, (relation, dst, edge) order
+            A.aux_f_idx[pos] = s;
+            if (hd) {
+                const int32_t a = A.S1[at] - A.b1 + K.heads_before[c];
+                A.row_in[row] = (int32_t)A.N + a; A.row_out[row] = kn;
+                A.aux_f_ptr[a] = pos;
+                // node kn's list: per-edge entries, then its collapsed rows in row order, then the self loop (if any): counted
+                // from the END of the list, which the scan knows
+                A.dst_rows[A.Sf[kn + 1] - A.bf - A.self_loop - 1 - K.later_rows[c]] = row;
+            }
+        } else {
+            const int32_t pos = A.S4[at] - A.b4 + K.rank_rel[c];
+            A.aux_b_idx[pos] = d;
+            if (hd) {
+                const int32_t a = A.S2[at] - A.b2 + K.heads_before[c];
+                A.row_in[row] = kn; A.row_out[row] = (int32_t)A.N + a;
+                A.aux_b_ptr[a] = pos;
+                A.src_rows[A.Sb[kn + 1] - A.bb - A.self_loop - 1 - K.later_rows[c]] = row;
+            }
+        }
+        if (md != kAgg) A.dst_rows[A.Sf[d] - A.bf + K.rank_d[c]] = row;
+        if (md != kTf) A.src_rows[A.Sb[s] - A.bb + K.rank_s[c]] = row;
+    }
+}
+
 // my edges of this pass (one per chunk) against every edge j of the graph.  j's words are wave-uniform (SGPRs): the common
 // path is a handful of compares and conditional adds per lane with uniform weights (no branch); the two counts only collapsed
-// rows need sit behind a uniform branch that is taken for the few heads of collapsed relations.
+// rows need sit behind a uniform branch that is taken for the few heads of collapsed relations.  O(m^2): the form for graphs
+// the bit-set pass below does not take.
 template <int NC>
 __device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c0, int64_t g, int n0, const FillArgs& A) {
-    u32 w0[NC], w1[NC], rc[NC], dc[NC], sc[NC], ck[NC];
-    int rank_rel[NC], heads_before[NC], rank_d[NC], rank_s[NC], later_rows[NC];
+    Ranks<NC> K;
+    u32 rc[NC], dc[NC], sc[NC], ck[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int i = (c0 + c) * 64 + lane;
         const uint2 x = i < m ? X[i] : make_uint2(kSentinel0, kSentinel1);
-        w0[c] = x.x; w1[c] = x.y;
+        K.w0[c] = x.x; K.w1[c] = x.y;
         rc[c] = x.x >> 26; dc[c] = x.y & 0x3fffu; sc[c] = (x.y >> 14) & 0x3fffu;
         ck[c] = (((x.y >> 28) & 3u) << 16) | ((x.x >> 10) & 0xffffu);     // mode, key node
-        rank_rel[c] = heads_before[c] = rank_d[c] = rank_s[c] = later_rows[c] = 0;
+        K.rank_rel[c] = K.heads_before[c] = K.rank_d[c] = K.rank_s[c] = K.later_rows[c] = 0;
     }
     for_each_edge(X, m, [&](int, u32 j0, u32 j1) {
         const u32 rj = j0 >> 26, mdj = (j1 >> 28) & 3u, sj = (j1 >> 14) & 0x3fffu, dj = j1 & 0x3fffu;
@@ -340,54 +391,175 @@ __device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c
         const int nb = (mdj == kEdge || mdj == kAgg) ? 1 : 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const bool lt = j0 < w0[c];                                    // j before me in the (relation, key node, edge) order
-            rank_rel[c] += (lt & (rc[c] == rj)) ? 1 : 0;
-            rank_d[c] += (lt & (dc[c] == dj)) ? nf : 0;                    // per-edge forward entries of my destination before mine
-            rank_s[c] += (lt & (sc[c] == sj)) ? nb : 0;
+            const bool lt = j0 < K.w0[c];                                  // j before me in the (relation, key node, edge) order
+            K.rank_rel[c] += (lt & (rc[c] == rj)) ? 1 : 0;
+            K.rank_d[c] += (lt & (dc[c] == dj)) ? nf : 0;                  // per-edge forward entries of my destination before mine
+            K.rank_s[c] += (lt & (sc[c] == sj)) ? nb : 0;
         }
         if (((j1 >> 30) & 1u) != 0 && (mdj == kAgg || mdj == kTf)) {       // j heads a collapsed row (rare)
             const u32 kkj = j0 >> 10, ckj = (mdj << 16) | (kkj & 0xffffu);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                heads_before[c] += ((rc[c] == rj) & (kkj < (w0[c] >> 10))) ? 1 : 0;
-                later_rows[c] += ((ck[c] == ckj) & (rj > rc[c])) ? 1 : 0;  // collapsed rows of my mode at my key node after mine
+                K.heads_before[c] += ((rc[c] == rj) & (kkj < (K.w0[c] >> 10))) ? 1 : 0;
+                K.later_rows[c] += ((ck[c] == ckj) & (rj > rc[c])) ? 1 : 0; // collapsed rows of my mode at my key node after mine
             }
         }
     });
+    fill_emit<NC>(K, lane, m, c0, g, n0, A);
+}
+
+// The same five counts WITHOUT pair work, for a graph small enough for bit sets in this wavefront's LDS table T (kFastWords
+// words): m <= 256 edges, n R (MW + 1) <= kFastWords with MW = ceil(m / 32).  All of it is order-free (LDS atomic OR, popcounts,
+// one prefix sum), so the result is the O(m^2) pass's, bit for bit:
+//   1. E[bucket] = the set of edge numbers of bucket (relation, key node)              (n R buckets x MW words)
+//   2. start[bucket] = edges in the buckets before it (prefix sum of the popcounts)    -> an edge's POSITION in the (relation,
+//      key node, edge) order = start[my bucket] + (members of my bucket with a smaller edge number); rank inside the relation
+//      = position - start[first bucket of the relation]
+//   3. D[node] / S[node] = the set of POSITIONS of the per-edge forward / backward entries at that destination / source
+//      (over E's space, which is dead by then)  -> rank inside the node's list = members below my position
+//   4. the few heads of collapsed rows are compacted into a list; every lane walks it (the slow pass's rare branch).
+constexpr int kFastWords = 2944;     // 11.5 KB per wavefront (two workgroups of four per CU next to the edge slices)
+constexpr int kFastM = 256;
+// sets are MQ 16-byte quads wide (MQ = 1: up to 128 members, 2: up to 256): one or two ds_read_b128 per set, no loops over words
+__device__ __forceinline__ bool fast_fits(int m, int n, int R) {
+    const int MW = m <= 128 ? 4 : 8;
+    // (the bucket sets + start[] first, then -- over the same words -- the two position sets per node + 64 listed heads)
+    return m <= kFastM && n >= 1 && (int64_t)n * R * (MW + 1) <= kFastWords && (int64_t)2 * n * MW + 2 * 64 + 4 <= kFastWords;
+}
+template <int MQ>
+__device__ __forceinline__ int set_count(const u32* B) {
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(B + 4 * q);
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    return c;
+}
+template <int MQ>
+__device__ __forceinline__ int set_below(const u32* B, int p) {             // members of the set below position p
+    int c = 0;
+    const int wq = p >> 5;
+    const u32 part = (1u << (p & 31)) - 1u;
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(B + 4 * q);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wi = 4 * q + k;
+            c += __popc(w[k] & (wi < wq ? 0xffffffffu : (wi == wq ? part : 0u)));
+        }
+    }
+    return c;
+}
+template <int NC, int MQ>
+__device__ __forceinline__ void fill_fast(const uint2* X, u32* T, int lane, int m, int n, int R, int64_t g, int n0, const FillArgs& A) {
+    constexpr int MW = 4 * MQ;
+    const int NB = n * R;
+    u32* const St = T + NB * MW;                                            // start[bucket]
+    Ranks<NC> K;
+    int bucket[NC], pos[NC];
+    for (int w = lane; w < NB * MQ; w += 64) reinterpret_cast<uint4*>(T)[w] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int i = (c0 + c) * 64 + lane;
-        if (i >= m) continue;
-        const int r = (int)rc[c], md = (int)((w1[c] >> 28) & 3u), hd = (int)((w1[c] >> 30) & 1u);
-        const int s = n0 + (int)sc[c], d = n0 + (int)dc[c], kn = md == kTf ? s : d;
-        const int64_t at = (int64_t)r * A.G + g;
-        const int32_t row = A.S0[at] + (md == kEdge ? rank_rel[c] : heads_before[c]);
-        if (md == kEdge) {
-            A.row_in[row] = s; A.row_out[row] = d;
-        } else if (md == kAgg) {
-            const int32_t pos = A.S3[at] - A.b3 + rank_rel[c];              // among the AGG edges, (relation, dst, edge) order
-            A.aux_f_idx[pos] = s;
-            if (hd) {
-                const int32_t a = A.S1[at] - A.b1 + heads_before[c];
-                A.row_in[row] = (int32_t)A.N + a; A.row_out[row] = kn;
-                A.aux_f_ptr[a] = pos;
-                // node kn's list: per-edge entries, then its collapsed rows in row order, then the self loop (if any): counted
-                // from the END of the list, which the scan knows
-                A.dst_rows[A.Sf[kn + 1] - A.bf - A.self_loop - 1 - later_rows[c]] = row;
-            }
-        } else {
-            const int32_t pos = A.S4[at] - A.b4 + rank_rel[c];
-            A.aux_b_idx[pos] = d;
-            if (hd) {
-                const int32_t a = A.S2[at] - A.b2 + heads_before[c];
-                A.row_in[row] = kn; A.row_out[row] = (int32_t)A.N + a;
-                A.aux_b_ptr[a] = pos;
-                A.src_rows[A.Sb[kn + 1] - A.bb - A.self_loop - 1 - later_rows[c]] = row;
-            }
-        }
-        if (md != kAgg) A.dst_rows[A.Sf[d] - A.bf + rank_d[c]] = row;
-        if (md != kTf) A.src_rows[A.Sb[s] - A.bb + rank_s[c]] = row;
+        const int i = c * 64 + lane;
+        const uint2 x = i < m ? X[i] : make_uint2(kSentinel0, kSentinel1);
+        K.w0[c] = x.x; K.w1[c] = x.y;
+        K.rank_rel[c] = K.heads_before[c] = K.rank_d[c] = K.rank_s[c] = K.later_rows[c] = 0;
+        bucket[c] = i < m ? (int)(x.x >> 26) * n + (int)((x.x >> 10) & 0xffffu) : 0;
+        if (i < m) atomicOr(&T[bucket[c] * MW + (i >> 5)], 1u << (i & 31));
     }
+    __builtin_amdgcn_wave_barrier();
+    {   // start[]: every lane takes BPL consecutive buckets (their sizes requested together), one wave-wide exclusive sum joins them
+        constexpr int kBplMax = kFastWords / 5 / 64 + 1;                    // NB <= kFastWords / (MW + 1)
+        const int BPL = (NB + 63) >> 6, b0 = lane * BPL;
+        int sz[kBplMax];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < kBplMax; ++k) {
+            sz[k] = (k < BPL && b0 + k < NB) ? set_count<MQ>(T + (b0 + k) * MW) : 0;
+            mine += sz[k];
+        }
+        int run = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(run, d, 64);
+            if (lane >= d) run += o;
+        }
+        run -= mine;                                                       // edges in the buckets of the lanes before me
+#pragma unroll
+        for (int k = 0; k < kBplMax; ++k) {
+            if (k < BPL && b0 + k < NB) St[b0 + k] = (u32)run;
+            run += sz[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + lane;
+        pos[c] = 0;
+        if (i < m) {
+            pos[c] = (int)St[bucket[c]] + set_below<MQ>(T + bucket[c] * MW, i);
+            K.rank_rel[c] = pos[c] - (int)St[(int)(K.w0[c] >> 26) * n];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                                       // E is dead: its space holds D (n x MW) and S (n x MW) now
+    u32* const Dd = T;
+    u32* const Ss = T + n * MW;
+    uint2* const Hl = reinterpret_cast<uint2*>(T + 2 * n * MW);            // heads of collapsed rows (<= 64 kept here)
+    for (int w = lane; w < 2 * n * MQ; w += 64) reinterpret_cast<uint4*>(T)[w] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_wave_barrier();
+    int hn = 0;                                                            // heads listed so far (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + lane;
+        const u32 md = (K.w1[c] >> 28) & 3u;
+        const bool live = i < m;
+        if (live && (md == kEdge || md == kTf)) atomicOr(&Dd[(int)(K.w1[c] & 0x3fffu) * MW + (pos[c] >> 5)], 1u << (pos[c] & 31));
+        if (live && (md == kEdge || md == kAgg)) atomicOr(&Ss[(int)((K.w1[c] >> 14) & 0x3fffu) * MW + (pos[c] >> 5)], 1u << (pos[c] & 31));
+        const bool head = live && ((K.w1[c] >> 30) & 1u) != 0 && (md == kAgg || md == kTf);
+        const unsigned long long hb = __ballot(head);
+        const int at = hn + __popcll(hb & ((1ull << lane) - 1ull));
+        if (head && at < 64) Hl[at] = make_uint2(K.w0[c], K.w1[c]);
+        hn += __popcll(hb);
+    }
+    const bool many = hn > 64;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + lane;
+        if (i < m) {
+            K.rank_d[c] = set_below<MQ>(Dd + (int)(K.w1[c] & 0x3fffu) * MW, pos[c]);
+            K.rank_s[c] = set_below<MQ>(Ss + (int)((K.w1[c] >> 14) & 0x3fffu) * MW, pos[c]);
+        }
+    }
+    // the collapsed rows' two counts, against the heads only (or, a graph with more than 64 of them, against every edge as the
+    // O(m^2) pass does)
+    auto head_counts = [&](u32 j0, u32 j1) {
+        const u32 rj = j0 >> 26, mdj = (j1 >> 28) & 3u;
+        const u32 kkj = j0 >> 10, ckj = (mdj << 16) | (kkj & 0xffffu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32 rcc = K.w0[c] >> 26, ckc = (((K.w1[c] >> 28) & 3u) << 16) | ((K.w0[c] >> 10) & 0xffffu);
+            K.heads_before[c] += ((rcc == rj) & (kkj < (K.w0[c] >> 10))) ? 1 : 0;
+            K.later_rows[c] += ((ckc == ckj) & (rj > rcc)) ? 1 : 0;
+        }
+    };
+    if (!many) {
+        for (int k = 0; k < hn; ++k) {
+            const uint2 h = Hl[k];
+            head_counts(sgpr(h.x), sgpr(h.y));
+        }
+    } else {
+        for_each_edge(X, m, [&](int, u32 j0, u32 j1) {
+            const u32 mdj = (j1 >> 28) & 3u;
+            if (((j1 >> 30) & 1u) != 0 && (mdj == kAgg || mdj == kTf)) head_counts(j0, j1);
+        });
+    }
+    fill_emit<NC>(K, lane, m, 0, g, n0, A);
+    __builtin_amdgcn_wave_barrier();                                       // the next graph rewrites the table
 }
 
 __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
@@ -400,6 +572,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr, [R] modes, status */,
     const int32_t* __restrict__ bad) {
     __shared__ __attribute__((aligned(16))) LocLds L;
+    __shared__ __attribute__((aligned(16))) u32 ftab[kLocWaves][kFastWords];
     __shared__ int32_t s_mode[kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2* X = L.e[wave];
@@ -440,6 +613,13 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
                 dst_rows[A.Sf[v + 1] - A.bf - 1] = P + v;                  // the self loop closes every list
                 src_rows[A.Sb[v + 1] - A.bb - 1] = P + v;
             }
+        }
+        if (m > 0 && fast_fits(m, n1 - n0, R)) {                           // (wave-uniform) the bit-set pass: no pair work
+            const int nc = (m + 63) >> 6;
+            if (nc == 1) fill_fast<1, 1>(X, ftab[wave], lane, m, n1 - n0, R, g, n0, A);
+            else if (nc == 2) fill_fast<2, 1>(X, ftab[wave], lane, m, n1 - n0, R, g, n0, A);
+            else fill_fast<4, 2>(X, ftab[wave], lane, m, n1 - n0, R, g, n0, A);
+            continue;
         }
         for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
             const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);

@@ -14,7 +14,7 @@ for it in range(4):
     marker = torch.zeros(7, device=dev) + 1          # marks the start of a build in the trace
     ix = g.row_index(etype, R, True)
     for _, _, part in ix.parts:
-        part.slots("f"), part.slots("b")
+        ops.prepare_closing(part, 256 if w == "config5" else 64, torch.bfloat16)       # what bench.py's index_build_ms covers
     torch.cuda.synchronize()
 PY
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/idxk -o k -- python3 /tmp/idx_once.py $1 > /dev/null 2>&1
