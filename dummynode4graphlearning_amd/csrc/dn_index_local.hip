@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
     int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
     int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr, [R] modes, status */,
-    const int32_t* __restrict__ bad) {
+    const int32_t* __restrict__ bad, int32_t* __restrict__ rel_ptr_out /* may be NULL: [R + 2] = rel_ptr, then the end of the self-loop rows */) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ __attribute__((aligned(16))) u32 ftab[kLocWaves][kFastWords];
     __shared__ int32_t s_mode[kLocR];
@@ -595,7 +595,14 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
             dst_ptr[N] = tf_; dst_ptr[N + 1] = tf_;
             src_ptr[N] = tb_; src_ptr[N + 1] = tb_;
         }
-        if (threadIdx.x <= R) meta[5 + threadIdx.x] = threadIdx.x < R ? (G > 0 ? A.S0[(int64_t)threadIdx.x * G] : 0) : P;
+        if (threadIdx.x <= R) {
+            const int32_t rp = threadIdx.x < R ? (G > 0 ? A.S0[(int64_t)threadIdx.x * G] : 0) : P;
+            meta[5 + threadIdx.x] = rp;
+            if (rel_ptr_out != nullptr) {                                 // the same offsets for the device-side table builders: no upload
+                rel_ptr_out[threadIdx.x] = rp;
+                if (threadIdx.x == R) rel_ptr_out[R + 1] = P + (int32_t)N;
+            }
+        }
         // modes and the verdict ride in the same block: ONE device -> host copy per build (both are final before this launch)
         if (threadIdx.x < R) meta[5 + R + 1 + threadIdx.x] = mode[threadIdx.x];
         if (threadIdx.x == 0) meta[5 + 2 * R + 1] = *bad;
@@ -687,7 +694,7 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr,
                                  int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
                                  int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
-                                 void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                                 int32_t* rel_ptr_dev, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(G >= 0 && N >= 0 && R >= 1 && E >= 0, "dn_row_index_build_local: bad sizes");
     DN_REQUIRE(R <= kLocR, "dn_row_index_build_local: more than 64 relations (use dn_row_index_build_i32)");
     DN_REQUIRE(2 * E + N < 0x7fffffffLL && kSeg * R * G + 2 * (N + 1) + 1 < 0x7fffffffLL,
@@ -711,7 +718,7 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                          rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
                        dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
-                       src_ptr, src_rows, w.meta, w.bad);
+                       src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
     DN_CHECK_LAUNCH();
     int32_t h_meta[5 + 2 * kLocR + 2];
     DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 2), hipMemcpyDeviceToHost, st));

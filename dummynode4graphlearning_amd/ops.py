@@ -1227,8 +1227,10 @@ class RowIndex:
         host_rel = (ctypes.c_int32 * (R + 1))()
         host_modes = (ctypes.c_int32 * R)()
         self.built_by = "general"
+        rel_dev = None
         if try_local:
             require_gpu(node_ptr, edge_ptr)
+            rel_dev = e32(R + 2)                                      # the relation offsets as the device builder leaves them
             node_ptr, edge_ptr = node_ptr.to(I32).contiguous(), edge_ptr.to(I32).contiguous()
             G = int(node_ptr.numel()) - 1
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
@@ -1240,7 +1242,7 @@ class RowIndex:
                                                          1 if self_loop else 0, float(edge_frac), ptr(row_in), ptr(row_out),
                                                          ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr), ptr(aux_b_idx),
                                                          ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts, host_rel,
-                                                         host_modes, ctypes.byref(status), ptr(ws), ws.numel(), stream_ptr()),
+                                                         host_modes, ctypes.byref(status), ptr(rel_dev), ptr(ws), ws.numel(), stream_ptr()),
                       "dn_row_index_build_local_i32")
                 if status.value == 0:
                     self.built_by = "local"
@@ -1273,7 +1275,10 @@ class RowIndex:
         self.num_all_rels = R + (1 if self_loop else 0)
         self.rel_ptr_host = rel_ptr
         # tile / chunk tables on the device (the 18 relation offsets go up in one small copy; no host loops)
-        rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
+        if self.built_by == "local":                                 # (already on the device: no upload)
+            rel_ptr_d = rel_dev[:len(rel_ptr)]
+        else:
+            rel_ptr_d = torch.tensor(rel_ptr, dtype=I32).to(dev, non_blocking=True)
         self.rel_ptr_dev = rel_ptr_d                                # (reused by the fold tables: one upload per batch)
         self._tile_table = self._edge_tile_table = None             # built on first use: the folded bf16 path needs neither
         self._slots, self._units, self._fold = {}, {}, {}
@@ -1293,6 +1298,8 @@ def _conv_tiles_for(ix, fold, H, dtype):
     P, R = ix.num_edge_rows, ix.num_rels
     if not (SWEEP_ENABLED and dtype == torch.bfloat16 and H == 256 and R <= 64
             and P // 32 >= 8 * SWEEP_WG_PER_GROUP * SWEEP_MIN_TILES_PER_WG):
+        if fold.main_tiles is None:                                  # (built on first use: a batch on the sweep order never needs them)
+            fold.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << fold.rel)
         return fold.main_tiles
     if fold.sweep_tiles is None:
         fold.sweep_tiles = build_sweep_tables(ix.rel_ptr_dev, R, ix.row_in, ix.row_out, ix.num_nodes, P, skip_mask=1 << fold.rel)
@@ -1387,7 +1394,7 @@ def _closing_tables(ix, kind="slots"):
         info.fold_info = info.part_ptr = info.graph_tiles = None
         info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment starts
         #                                                    one partial row, every tile boundary inside one another
-        info.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << r)
+        info.main_tiles = None                               # plain relation-major tiles, built on first use (_conv_tiles_for)
         info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
         info.add_idx = add_idx_of(direction, cand)
         return info

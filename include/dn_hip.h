@@ -250,14 +250,16 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * of the packed counts: 3 kernels + 1 scan instead of ~60 launches.  R <= 64.  *host_status = 1 (outputs undefined) when the
  * batch does not qualify -- a graph with more than 1024 edges, an endpoint outside its graph's node range, a relation id
  * outside [0, R), ranges that do not tile [0, N) / [0, E): the caller then runs dn_row_index_build_i32.  Other arguments and
- * outputs as dn_row_index_build_i32.  Synchronises the stream (one read-back). */
+ * outputs as dn_row_index_build_i32.  rel_ptr_dev (device, may be NULL; round 5): [R + 2] = the relation offsets of host_rel_ptr
+ * followed by the end of the self-loop rows (P + N), for the device-side table builders -- no upload of what the device already
+ * has.  Synchronises the stream (one read-back). */
 size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E);
 int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr,
                                  const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
                                  int32_t self_loop, float edge_frac, int32_t* row_in, int32_t* row_out,
                                  int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx,
                                  int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
-                                 int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
+                                 int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status, int32_t* rel_ptr_dev,
                                  void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Tile / chunk tables of relation-major rows for dn_rows_transform_* (step = 32 rows) and dn_rows_wgrad_* (step = the

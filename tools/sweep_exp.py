@@ -62,7 +62,7 @@ def main():
     bias = torch.zeros(H, device=dev, dtype=torch.bfloat16)
     alg = 2.0 * (E * H * 2 + N * H * 2 + 8.0 * E)
     if a.ab:
-        plain = {d: ops._row_index_fold(ix, d).main_tiles for d in ("f", "b")}
+        plain = {d: ops.build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << ops._row_index_fold(ix, d).rel) for d in ("f", "b")}
         swept = {}
         for d in ("f", "b"):
             fold = ops._row_index_fold(ix, d)
@@ -86,7 +86,7 @@ def main():
         assert fold is not None
         idx_rows = ix.row_in if direction == "f" else ix.row_out
         skip = 1 << fold.rel if fold is not None else 0
-        base = fold.main_tiles if fold is not None else ix.edge_tile_table
+        base = (fold.main_tiles or ops.build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=skip)) if fold is not None else ix.edge_tile_table
         Y0 = None
         if a.only != "sweep":
             t0, Y0 = time_tf(idx_rows, base)
