@@ -241,33 +241,7 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
 __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
                                         const int32_t* __restrict__ add_idx, int32_t* __restrict__ tile_ptr,
                                         int32_t* __restrict__ info, int32_t* __restrict__ ok) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > S) return;
-    if (j == S) { tile_ptr[S] = N; return; }
-    const int32_t cnt = sptr[j + 1] - sptr[j];
-    bool good = cnt > 0;
-    int32_t first = 0, last = 0, nxt = N;
-    if (good) {
-        first = snodes[sptr[j]];
-        last = snodes[sptr[j + 1] - 1];
-        good = first >= 0 && last < N && last - first == cnt - 1;
-        for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
-        if (good && j + 1 < S) {
-            good = sptr[j + 2] > sptr[j + 1];
-            if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
-        }
-    }
-    const int32_t b0 = j == 0 ? 0 : first;
-    if (good) good = nxt - b0 <= 32 && nxt - b0 >= 1;
-    if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
-    if (!good) { *ok = 0; return; }
-    tile_ptr[j] = b0;
-    uint8_t ids[32];
-    for (int i = 0; i < 32; ++i) ids[i] = (b0 + i >= first && b0 + i <= last) ? 0 : 255;
-    int32_t* rec = info + (size_t)j * kFoldInfoWords;
-    for (int i = 0; i < 8; ++i)
-        rec[i] = (int32_t)((uint32_t)ids[4 * i] | ((uint32_t)ids[4 * i + 1] << 8) | ((uint32_t)ids[4 * i + 2] << 16) | ((uint32_t)ids[4 * i + 3] << 24));
-    rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 0; rec[11] = 0;
+    dn_fold_graph_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, tile_ptr, info, ok);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernel

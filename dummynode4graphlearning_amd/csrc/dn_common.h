@@ -217,6 +217,43 @@ __device__ __forceinline__ void dn_load_w_kn16(const __bf16* __restrict__ w, int
     }
 }
 
+// Tiles = the graphs of a batch (segment-complete tiles for the absorbed fold of dn_rows_close_bf16), one segment per call: segment j
+// = the nodes seg_nodes[seg_ptr[j] .. seg_ptr[j+1]); block j = [first node of segment j (0 for j = 0), first node of segment j + 1
+// (N for the last)).  Clears *ok unless the segment is a non-empty contiguous ascending run, the next segment starts behind it,
+// the block has at most 32 nodes and the row the segment's product is added to (add_idx[j], when given) lies inside the block;
+// else writes tile_ptr[j] and fold record j.  Shared by dn_fold_graph_tiles_build_i32 (dn_close.hip) and the graph-local index
+// builder (dn_index_local.hip), which runs it on the candidate relation it finds itself -- no second read-back.
+__device__ __forceinline__ void dn_fold_graph_tile_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                       const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
+                                                       int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, int32_t* __restrict__ ok) {
+    if (j > S) return;
+    if (j == S) { tile_ptr[S] = N; return; }
+    const int32_t cnt = sptr[j + 1] - sptr[j];
+    bool good = cnt > 0;
+    int32_t first = 0, last = 0, nxt = N;
+    if (good) {
+        first = snodes[sptr[j]];
+        last = snodes[sptr[j + 1] - 1];
+        good = first >= 0 && last < N && last - first == cnt - 1;
+        for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
+        if (good && j + 1 < S) {
+            good = sptr[j + 2] > sptr[j + 1];
+            if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
+        }
+    }
+    const int32_t b0 = j == 0 ? 0 : first;
+    if (good) good = nxt - b0 <= 32 && nxt - b0 >= 1;
+    if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
+    if (!good) { *ok = 0; return; }
+    tile_ptr[j] = b0;
+    uint8_t ids[32];
+    for (int i = 0; i < 32; ++i) ids[i] = (b0 + i >= first && b0 + i <= last) ? 0 : 255;
+    int32_t* rec = info + (size_t)j * 12;
+    for (int i = 0; i < 8; ++i)
+        rec[i] = (int32_t)((uint32_t)ids[4 * i] | ((uint32_t)ids[4 * i + 1] << 8) | ((uint32_t)ids[4 * i + 2] << 16) | ((uint32_t)ids[4 * i + 3] << 24));
+    rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 0; rec[11] = 0;
+}
+
 // ---- ReLU / leaky ReLU.  slope = 0: ReLU (max(v, 0): the negative side is an exact 0 whatever v is); slope > 0: leaky ReLU, the
 // reference's default activation (`leaky_relu`, slope 1 / 5.5: subgraph_isomorphism/utils/act.py:466, constants.py:10).  The backward
 // multiplies a gradient by 1 where the saved activation (or its sign bit) is > 0 and by `slope` elsewhere.

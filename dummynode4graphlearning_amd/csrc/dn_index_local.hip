@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
         }
         // modes and the verdict ride in the same block: ONE device -> host copy per build (both are final before this launch)
         if (threadIdx.x < R) meta[5 + R + 1 + threadIdx.x] = mode[threadIdx.x];
-        if (threadIdx.x == 0) meta[5 + 2 * R + 1] = *bad;
+        if (threadIdx.x == 0) { meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 1; meta[5 + 2 * R + 3] = 1; }   // (+ the two fold verdicts: "still valid")
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1, e0;
@@ -638,6 +638,31 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     }
 }
 
+// Can the closing launch ABSORB the fold of this batch (dn_rows_close_bf16 with AGG units)?  The question ops._closing_tables
+// used to ask with two more launches and a second read-back, answered here behind ril_fill_kernel with what the device already
+// knows (meta): the candidate is the ONE collapsed relation of the direction -- mode AGG forward (rows into few destinations: u ->
+// dummy), TF backward -- with rows, all of the direction's aux lists its own; its segments (the aux lists) must tile the batch as
+// dn_fold_graph_tile_one checks, the target of segment j being the relation's j-th row's output (forward) / input (backward) node.
+// tile_ptr [G + 1], info [G][12] as dn_fold_graph_tiles_build_i32 writes them; verdict -> meta[5 + 2 R + 2 + direction].
+__global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t self_loop, int32_t direction, int32_t* __restrict__ meta,
+                                        const int32_t* __restrict__ aux_ptr, const int32_t* __restrict__ aux_idx,
+                                        const int32_t* __restrict__ row_target, int32_t* __restrict__ tile_ptr,
+                                        int32_t* __restrict__ info) {
+    const int want = direction == 0 ? kAgg : kTf;
+    const int32_t n_aux = meta[1 + direction];
+    int32_t* ok = meta + 5 + 2 * R + 2 + direction;
+    int found = 0, rel = 0;
+    for (int r = 0; r < R; ++r)
+        if (meta[5 + R + 1 + r] == want && meta[5 + r + 1] > meta[5 + r]) { ++found; rel = r; }
+    const int32_t beg = meta[5 + rel], end = meta[5 + rel + 1];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!(self_loop && found == 1 && n_aux > 0 && end - beg == n_aux && (int64_t)n_aux <= G)) {
+        if (j == 0) *ok = 0;
+        return;
+    }
+    dn_fold_graph_tile_one(j, (int32_t)N, n_aux, aux_ptr, aux_idx, row_target + beg, tile_ptr, info, ok);
+}
+
 struct LocWs {
     int32_t *Er, *Dr, *Sr, *mode, *bad, *meta, *C, *S;
     uint8_t* hbits;
@@ -663,7 +688,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
     w.hbits = (uint8_t*)take((size_t)E);
-    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 2));
+    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4));
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
                                 rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) {
@@ -694,7 +719,9 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr,
                                  int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
                                  int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
-                                 int32_t* rel_ptr_dev, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+                                 int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
+                                 int32_t* fold_info_b, int32_t* host_absorb, void* workspace, size_t workspace_bytes,
+                                 dn_stream_t stream) {
     DN_REQUIRE(G >= 0 && N >= 0 && R >= 1 && E >= 0, "dn_row_index_build_local: bad sizes");
     DN_REQUIRE(R <= kLocR, "dn_row_index_build_local: more than 64 relations (use dn_row_index_build_i32)");
     DN_REQUIRE(2 * E + N < 0x7fffffffLL && kSeg * R * G + 2 * (N + 1) + 1 < 0x7fffffffLL,
@@ -720,9 +747,22 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                        dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
                        src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
     DN_CHECK_LAUNCH();
-    int32_t h_meta[5 + 2 * kLocR + 2];
-    DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 2), hipMemcpyDeviceToHost, st));
+    const bool verdicts = host_absorb != nullptr;
+    if (verdicts) {
+        DN_REQUIRE(tile_ptr_f && fold_info_f && tile_ptr_b && fold_info_b, "dn_row_index_build_local: host_absorb needs the four tile buffers");
+        DN_REQUIRE((reinterpret_cast<uintptr_t>(fold_info_f) | reinterpret_cast<uintptr_t>(fold_info_b)) % 16 == 0,
+                   "dn_row_index_build_local: unaligned fold_info");
+        const unsigned vg = (unsigned)dn_cdiv(G + 1, 256);
+        hipLaunchKernelGGL(ril_fold_verdict_kernel, dim3(vg), dim3(256), 0, st, G, N, (int32_t)R, self_loop, 0, w.meta, aux_f_ptr, aux_f_idx,
+                           row_out, tile_ptr_f, fold_info_f);
+        hipLaunchKernelGGL(ril_fold_verdict_kernel, dim3(vg), dim3(256), 0, st, G, N, (int32_t)R, self_loop, 1, w.meta, aux_b_ptr, aux_b_idx,
+                           row_in, tile_ptr_b, fold_info_b);
+        DN_CHECK_LAUNCH();
+    }
+    int32_t h_meta[5 + 2 * kLocR + 4];
+    DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 4), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
+    if (verdicts) { host_absorb[0] = h_meta[5 + 2 * R + 2]; host_absorb[1] = h_meta[5 + 2 * R + 3]; }
     *host_status = h_meta[5 + 2 * R + 1];
     for (int k = 0; k < 5; ++k) host_counts[k] = h_meta[k];
     for (int64_t r = 0; r <= R; ++r) host_rel_ptr[r] = h_meta[5 + r];

@@ -1227,12 +1227,16 @@ class RowIndex:
         host_rel = (ctypes.c_int32 * (R + 1))()
         host_modes = (ctypes.c_int32 * R)()
         self.built_by = "general"
+        self._absorb = None                                           # local builder: {direction: (tile_ptr, fold_info, verdict)}
         rel_dev = None
         if try_local:
             require_gpu(node_ptr, edge_ptr)
             rel_dev = e32(R + 2)                                      # the relation offsets as the device builder leaves them
             node_ptr, edge_ptr = node_ptr.to(I32).contiguous(), edge_ptr.to(I32).contiguous()
             G = int(node_ptr.numel()) - 1
+            # the absorbed-fold verdicts + graph tiles of both directions come out of the same call (and the same read-back)
+            gt_bufs = [(e32(G + 1), torch.empty((max(G, 1), 12), dtype=I32, device=dev)) for _ in range(2)]
+            host_absorb = (ctypes.c_int32 * 2)()
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
             nbytes = lib().dn_row_index_local_workspace_bytes(G, N, R, E)
             if nbytes:
@@ -1242,10 +1246,13 @@ class RowIndex:
                                                          1 if self_loop else 0, float(edge_frac), ptr(row_in), ptr(row_out),
                                                          ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr), ptr(aux_b_idx),
                                                          ptr(dst_ptr), ptr(dst_rows), ptr(src_ptr), ptr(src_rows), counts, host_rel,
-                                                         host_modes, ctypes.byref(status), ptr(rel_dev), ptr(ws), ws.numel(), stream_ptr()),
+                                                         host_modes, ctypes.byref(status), ptr(rel_dev), ptr(gt_bufs[0][0]),
+                                                         ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb,
+                                                         ptr(ws), ws.numel(), stream_ptr()),
                       "dn_row_index_build_local_i32")
                 if status.value == 0:
                     self.built_by = "local"
+                    self._absorb = {d: (gt_bufs[k][0], gt_bufs[k][1], int(host_absorb[k])) for k, d in enumerate(("f", "b"))}
             if self.built_by != "local":
                 _check_edge_types(etype, R)
         if self.built_by == "general":
@@ -1405,7 +1412,16 @@ def _closing_tables(ix, kind="slots"):
         flags = torch.zeros(4, dtype=I32, device=dev)                # [parts_f, parts_b, graph_tiles_f, graph_tiles_b]
         gts, parts = {}, {}
         h = hp = [0, 0, 0, 0]
-        if kind == "units" and CLOSE_AGG_ENABLED:
+        if kind == "units" and CLOSE_AGG_ENABLED and ix._absorb is not None:
+            # the graph-local index builder answered "can the fold be absorbed?" itself (same candidate rule, same test) and its
+            # verdicts came back with its one read-back: no launch, no synchronisation here
+            h = [0, 0, 0, 0]
+            for k, d in enumerate(dirs):
+                if cands[d] is not None:
+                    tp, fi, verdict = ix._absorb[d]
+                    gts[d] = (tp[:cands[d][3] + 1], fi[:cands[d][3]])
+                    h[2 + k] = verdict
+        elif kind == "units" and CLOSE_AGG_ENABLED:
             for k, d in enumerate(dirs):
                 if cands[d] is not None:
                     aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if d == "f" else (ix.aux_b_ptr, ix.aux_b_idx)

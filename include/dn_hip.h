@@ -252,7 +252,12 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * outside [0, R), ranges that do not tile [0, N) / [0, E): the caller then runs dn_row_index_build_i32.  Other arguments and
  * outputs as dn_row_index_build_i32.  rel_ptr_dev (device, may be NULL; round 5): [R + 2] = the relation offsets of host_rel_ptr
  * followed by the end of the self-loop rows (P + N), for the device-side table builders -- no upload of what the device already
- * has.  Synchronises the stream (one read-back). */
+ * has.  host_absorb (host int32 [2], may be NULL; round 5) with tile_ptr_f / _b (device [G + 1]) and fold_info_f / _b (device
+ * [G][12], 16-byte aligned): the builder also answers, per direction, whether dn_rows_close_bf16 can ABSORB the fold of this batch
+ * -- exactly one collapsed relation in the direction (mode AGG forward / TF backward) owning all the direction's aux lists, with
+ * a self loop, and its segments passing dn_fold_graph_tiles_build_i32's test with the relation's own rows as targets -- and
+ * leaves that call's tile_ptr / fold_info behind (host_absorb[d] != 0); the verdicts ride in the builder's ONE read-back.
+ * Synchronises the stream (one read-back). */
 size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E);
 int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr,
                                  const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype,
@@ -260,6 +265,8 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx,
                                  int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
                                  int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status, int32_t* rel_ptr_dev,
+                                 int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b, int32_t* fold_info_b,
+                                 int32_t* host_absorb,
                                  void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
 /* Tile / chunk tables of relation-major rows for dn_rows_transform_* (step = 32 rows) and dn_rows_wgrad_* (step = the

@@ -122,10 +122,10 @@ def test_local_index_and_async_table_entry_points_check_their_arguments(lib):
     counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 3)(), ctypes.c_int32(0)
     P16 = ctypes.c_void_p(16)
     rc = L.dn_row_index_build_local_i32(4, 10, 65, 20, P16, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
-                                        ctypes.byref(st), None, P16, 1 << 20, None)
+                                        ctypes.byref(st), None, None, None, None, None, None, P16, 1 << 20, None)
     assert rc == -1 and b"more than 64 relations" in L.dn_last_error()
     rc = L.dn_row_index_build_local_i32(4, 10, 3, 20, None, P16, P16, P16, P16, 1, 0.75, *([P16] * 10), counts, rel, modes,
-                                        ctypes.byref(st), None, P16, 1 << 20, None)
+                                        ctypes.byref(st), None, None, None, None, None, None, P16, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_slot_table_build_i32(10, 5, 6, P16, P16, 0, 0, None, None, None, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
