@@ -1459,6 +1459,9 @@ def _closing_tables(ix, kind="slots"):
     for d in dirs:
         info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
+        if (kind == "units" and info is not None and info.graph_tiles is None and CLOSE_AGG_ENABLED and ix._absorb is not None
+                and ix._absorb[d][2]):                                # (the slot tables came first: the builder's verdict still stands)
+            info.graph_tiles = (ix._absorb[d][0][:info.n + 1], ix._absorb[d][1][:info.n])
         if kind == "slots":
             slots, over = tabs[d]
             ix._slots[d] = (slots, (*lists[d], P, drop[0], drop[1], over))

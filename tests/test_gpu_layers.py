@@ -666,6 +666,38 @@ def test_bf16_step_is_bitwise_reproducible():
             assert torch.equal(a, b)
 
 
+def test_one_row_index_serves_both_closing_kinds():
+    """An H = 256 bf16 layer (unit-stream closing launch, fold absorbed into its AGG units) and an H = 128 bf16 layer (slot kernel +
+    partial rows + fold tail) on ONE BatchedGraph, i.e. one cached RowIndex: the second kind builds the tables it misses and
+    passes the fold verdict on as the slot builder's drop switch -- both layers match the oracle, in either order."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config5(seed=21, graphs=300)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R = int(aug["node_label"].numel()), raw["num_rels"]
+    et = aug["edge_label"].long()
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    for order in ((256, 128), (128, 256)):
+        g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+        for H in order:
+            torch.manual_seed(H)
+            layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+            gen = torch.Generator(device=DEV).manual_seed(H + 1)
+            x = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16).requires_grad_(True)
+            out, _ = layer(g, x, et)
+            out.backward(torch.ones_like(out))
+            p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+            ref = OL.rgin_layer_rel_grouped(x.detach().double().cpu(), aug["src"].long().cpu(), aug["dst"].long().cpu(), et.cpu(), p64, R,
+                                            act="relu", num_mlp_layers=2)
+            assert _rel_l2(out, ref) < 3e-2, (order, H, _rel_l2(out, ref))
+            assert bool(torch.isfinite(x.grad.float()).all())
+        ix = g.row_index(et, R, True).parts[0][2]
+        assert ix._units and ix._slots and all(ix._units[d].agg for d in "fb")          # one index, both kinds of tables
+
+
 def _dummy_layout_batch(rng, G, n, m, R, layout):
     """G graphs of n real nodes + one dummy node, m random real edges (types 0 .. R-3), u -> dummy (R-2), dummy -> u (R-1).
     layout "last": [u_1 .. u_n, d] per graph (train.py:416-426); "first": [d, u_1 .. u_n]; "end": every dummy node behind all
