@@ -363,7 +363,7 @@ def main():
             gb._cache.clear()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ix = gb.row_index(et, R, True) if fused else gb.rel_index(et, R)
+            ix = gb.row_index(et, R, True, closing_hint=(H, dtype)) if fused else gb.rel_index(et, R)
             if fused and dtype == torch.bfloat16:   # the closing tables and tile orders are part of the per-batch index cost
                 for _, _, part in ix.parts:
                     ops.prepare_closing(part, H, dtype)
@@ -507,7 +507,7 @@ def main():
                                            traw["node_label"], traw["edge_id"], traw["edge_label"], raw["max_nv"], raw["max_nvl"],
                                            raw["max_ne"], raw["max_nel"])
                 g._cache.clear()
-                ix = g.row_index(etype, R, True)
+                ix = g.row_index(etype, R, True, closing_hint=(H, dtype))
                 for _, _, part in ix.parts:
                     ops.prepare_closing(part, H, dtype)
                 return aug, ix

@@ -87,18 +87,39 @@ struct CbLds {
     int32_t plain;
 };
 
-__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t P, int32_t T, const int32_t* __restrict__ tile_ptr,
-                                                                      const int32_t* __restrict__ lptr,
-                                                                      const int32_t* __restrict__ lrows, int32_t drop_beg,
-                                                                      int32_t drop_end, const int32_t* __restrict__ drop_enable,
-                                                                      int32_t* __restrict__ ent_row, uint32_t* __restrict__ ent_mask,
-                                                                      int32_t* __restrict__ tile_cnt, int32_t G, int32_t Tper,
-                                                                      int32_t agg, int32_t* __restrict__ ucnt) {
+// Per-direction arguments of the two table kernels: blockIdx.y picks the direction (dn_conv_index_build_i32 builds the forward and the
+// backward stream of a batch in ONE set of launches; dn_close_units_build_i32 passes one).
+struct CbDir {
+    const int32_t *tile_ptr, *lptr, *lrows, *drop_enable, *dyn;
+    int32_t *ent_row, *tile_cnt, *ucnt, *unit_ptr;
+    uint32_t* ent_mask;
+    const int32_t* uoff;
+    Unit* units;
+    int32_t P, drop_beg, drop_end;
+};
+struct CbPair {
+    CbDir d[2];
+};
+
+__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, CbPair pr) {
     __shared__ __attribute__((aligned(16))) CbLds Ls[kCbWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (int)blockIdx.x * kCbWaves + wave;
     if (t >= T) return;                                                    // (no workgroup barrier below)
-    if (drop_enable != nullptr && *drop_enable == 0) drop_beg = drop_end = 0;
+    const CbDir& a = pr.d[blockIdx.y];
+    const int32_t* __restrict__ tile_ptr = a.tile_ptr;
+    const int32_t* __restrict__ lptr = a.lptr;
+    const int32_t* __restrict__ lrows = a.lrows;
+    int32_t* __restrict__ ent_row = a.ent_row;
+    uint32_t* __restrict__ ent_mask = a.ent_mask;
+    int32_t* __restrict__ tile_cnt = a.tile_cnt;
+    int32_t* __restrict__ ucnt = a.ucnt;
+    int32_t P = a.P, drop_beg = a.drop_beg, drop_end = a.drop_end;
+    if (a.dyn != nullptr) {                                                // queued behind the row index (dn_conv_index_build_i32): the
+        if (a.dyn[3] == 0) return;                                         // counts the host does not know yet; go = 0: nothing to do
+        P = a.dyn[0]; drop_beg = a.dyn[1]; drop_end = a.dyn[2];
+    }
+    if (a.drop_enable != nullptr && *a.drop_enable == 0) drop_beg = drop_end = 0;
     CbLds& L = Ls[wave];
     const int p0 = tile_ptr ? tile_ptr[t] : t * 32;
     const int pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N), nn = pend - p0;   // (a tile never has more than 32 nodes)
@@ -206,28 +227,33 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
 // as one stream); position k' = w * Tper + n holds tile n * G + w.  The entries kernel leaves each tile's unit count there, one
 // exclusive scan (rocPRIM) gives the offsets.
-__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, const int32_t* __restrict__ tile_ptr,
-                                  const int32_t* __restrict__ lptr, const int32_t* __restrict__ tile_cnt,
-                                  const int32_t* __restrict__ uoff, int32_t agg, Unit* __restrict__ units,
-                                  int32_t* __restrict__ unit_ptr) {
+__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, CbPair pr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= G) unit_ptr[t] = uoff[t * Tper];                             // (position G * Tper holds the total)
+    const CbDir& a = pr.d[blockIdx.y];
+    if (a.dyn != nullptr && a.dyn[3] == 0) return;
+    const int32_t* __restrict__ tile_ptr = a.tile_ptr;
+    const int32_t* __restrict__ lptr = a.lptr;
+    const int32_t* __restrict__ tile_cnt = a.tile_cnt;
+    const int32_t* __restrict__ uoff = a.uoff;
+    Unit* __restrict__ units = a.units;
+    const int32_t base = uoff[0];                                          // (both directions share one scan: the second starts at the first's total)
+    if (t <= G) a.unit_ptr[t] = uoff[t * Tper] - base;                     // (position G * Tper holds the total)
     if (t >= T) return;
     const int64_t w = t % G, n = t / G, k = w * Tper + n;
     const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
     const int32_t pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N);
     const int32_t c = tile_cnt[t], e0 = lptr[p0], rows = (pend - p0) << 8;
-    Unit* u = units + uoff[k];
+    Unit* u = units + (uoff[k] - base);
     const int ne = (c + 31) / 32;
     u[0] = Unit{(ne == 0 ? kUnitLast : 0) | rows, p0, pend, (int32_t)t};
     for (int i = 0; i < ne; ++i)
         u[1 + i] = Unit{kUnitEntry | (i == ne - 1 ? kUnitLast : 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), c), p0};
     if (agg && t + G >= T) {                                               // the workgroup's last tile: its NOP gap and AGG units
         const int32_t nw = (int32_t)n + 1;
-        Unit* a = u + 1 + ne;
-        for (int i = 0; i < kAggGap; ++i) a[i] = Unit{kUnitNop, 0, 1, 0};
-        a += kAggGap;
-        for (int i = 0; 32 * i < nw; ++i) a[i] = Unit{kUnitAgg | kUnitLast, 32 * i, min(32 * (i + 1), nw), 0};
+        Unit* q = u + 1 + ne;
+        for (int i = 0; i < kAggGap; ++i) q[i] = Unit{kUnitNop, 0, 1, 0};
+        q += kAggGap;
+        for (int i = 0; 32 * i < nw; ++i) q[i] = Unit{kUnitAgg | kUnitLast, 32 * i, min(32 * (i + 1), nw), 0};
     }
 }
 
@@ -721,6 +747,70 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
 
 }  // namespace
 
+namespace dn_internal {
+
+// dn_close_units_build_i32 for nd = 1 or 2 directions of one batch in ONE set of launches (same tiles count, lists and outputs per
+// direction).  dirs[k].dyn != NULL: {edge rows, dropped range, go} are read on the device (ril_plan_kernel's words) instead of
+// num_edge_rows / drop_beg / drop_end -- the launches are queued before the host knows them.  workspace: nd times
+// dn_close_units_workspace_bytes.
+int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int64_t num_list_entries, int64_t unit_capacity,
+                      int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 && num_tiles >= 0 &&
+               num_tiles < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_close_units_build: bad sizes");
+    for (int k = 0; k < nd; ++k) {
+        DN_REQUIRE(dirs[k].num_edge_rows >= 0, "dn_close_units_build: bad sizes");
+        DN_REQUIRE(dirs[k].tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the "
+                   "%lld 32-node windows", (long long)dn_cdiv(N, 32));
+        DN_REQUIRE(dirs[k].unit_ptr, "dn_close_units_build: NULL pointer");
+    }
+    if (N == 0 || num_tiles == 0) {
+        for (int k = 0; k < nd; ++k) DN_CHECK_HIP(hipMemsetAsync(dirs[k].unit_ptr, 0, sizeof(int32_t) * ((size_t)num_wg + 1), st));
+        return DN_OK;
+    }
+    DN_REQUIRE(workspace, "dn_close_units_build: NULL pointer");
+    for (int k = 0; k < nd; ++k) {
+        DN_REQUIRE(dirs[k].list_ptr && dirs[k].list_rows && dirs[k].units && dirs[k].ent_row && dirs[k].ent_mask, "dn_close_units_build: NULL pointer");
+        DN_REQUIRE(reinterpret_cast<uintptr_t>(dirs[k].units) % 16 == 0, "dn_close_units_build: unaligned pointer");
+    }
+    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
+    DN_REQUIRE(workspace_bytes >= (size_t)nd * dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "dn_close_units_build: unaligned pointer");
+    const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
+    const int64_t M = (int64_t)num_wg * Tper;
+    DN_REQUIRE((int64_t)nd * (unit_capacity + 1) < 0x7fffffffLL, "dn_close_units_build: unit tables too large");   // (one scan over both)
+    char* wsp = reinterpret_cast<char*>(workspace);
+    int32_t* tile_cnt[2] = {nullptr, nullptr};
+    for (int k = 0; k < nd; ++k) { tile_cnt[k] = reinterpret_cast<int32_t*>(wsp); wsp += dn_align_up((size_t)(T + 1) * 4, 256); }
+    const size_t ne = (size_t)nd * (size_t)(M + 1);                          // ucnt / uoff of the directions back to back: ONE scan
+    int32_t* ucnt = reinterpret_cast<int32_t*>(wsp);
+    wsp += dn_align_up(ne * 4, 256);
+    int32_t* uoff = reinterpret_cast<int32_t*>(wsp);
+    wsp += dn_align_up(ne * 4, 256);
+    size_t tb = 0;
+    DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ucnt, uoff, (int32_t)0, ne, rocprim::plus<int32_t>(), st));
+    DN_REQUIRE(tb <= (size_t)nd * (65536 + 4 * (size_t)(M + 1)), "dn_close_units_build: scan storage %zu exceeds the reserved bound", tb);
+    DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, ne * 4, st));                       // positions without a tile (T not a multiple of num_wg) and the totals' slots
+    CbPair pr;
+    for (int k = 0; k < 2; ++k) {
+        const CloseUnitsDir& d = dirs[k < nd ? k : 0];
+        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.ent_row, tile_cnt[k < nd ? k : 0],
+                        ucnt + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), d.unit_ptr, d.ent_mask,
+                        uoff + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), reinterpret_cast<Unit*>(d.units), d.num_edge_rows, d.drop_beg,
+                        d.drop_end};
+    }
+    hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves), (unsigned)nd), dim3(kCbWaves * 64), 0, st, (int32_t)N, T,
+                       num_wg, Tper, agg_units ? 1 : 0, pr);
+    DN_CHECK_LAUNCH();
+    DN_CHECK_HIP(rocprim::exclusive_scan(wsp, tb, ucnt, uoff, (int32_t)0, ne, rocprim::plus<int32_t>(), st));
+    const int64_t nthreads = T > num_wg + 1 ? T : num_wg + 1;
+    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(nthreads, 256), (unsigned)nd), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper,
+                       agg_units ? 1 : 0, pr);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // namespace dn_internal
+
 extern "C" {
 
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {
@@ -741,41 +831,10 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
                              int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream) {
-    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_edge_rows >= 0 && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 &&
-               num_tiles >= 0 && num_tiles < 0x7fffffffLL, "dn_close_units_build: bad sizes");
-    DN_REQUIRE(tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the %lld "
-               "32-node windows", (long long)dn_cdiv(N, 32));
-    DN_REQUIRE(unit_ptr, "dn_close_units_build: NULL pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (N == 0 || num_tiles == 0) { DN_CHECK_HIP(hipMemsetAsync(unit_ptr, 0, sizeof(int32_t) * ((size_t)num_wg + 1), st)); return DN_OK; }
-    DN_REQUIRE(list_ptr && list_rows && units && ent_row && ent_mask && workspace, "dn_close_units_build: NULL pointer");
-    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
-    DN_REQUIRE(workspace_bytes >= dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
-    DN_REQUIRE(reinterpret_cast<uintptr_t>(units) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
-               "dn_close_units_build: unaligned pointer");
-    const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
-    const int64_t M = (int64_t)num_wg * Tper;
-    char* wsp = reinterpret_cast<char*>(workspace);
-    int32_t* tile_cnt = reinterpret_cast<int32_t*>(wsp);
-    wsp += dn_align_up((size_t)(T + 1) * 4, 256);
-    int32_t* ucnt = reinterpret_cast<int32_t*>(wsp);
-    wsp += dn_align_up((size_t)(M + 1) * 4, 256);
-    int32_t* uoff = reinterpret_cast<int32_t*>(wsp);
-    wsp += dn_align_up((size_t)(M + 1) * 4, 256);
-    size_t tb = 0;
-    DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
-    DN_REQUIRE(tb <= 65536 + 4 * (size_t)(M + 1), "dn_close_units_build: scan storage %zu exceeds the reserved bound", tb);
-    DN_CHECK_HIP(hipMemsetAsync(ucnt, 0, (size_t)(M + 1) * 4, st));          // positions without a tile (T not a multiple of num_wg) and the total's slot
-    hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves)), dim3(kCbWaves * 64), 0, st, (int32_t)N, num_edge_rows,
-                       T, tile_ptr, list_ptr, list_rows, drop_beg, drop_end, drop_enable, ent_row, ent_mask, tile_cnt, num_wg, Tper,
-                       agg_units ? 1 : 0, ucnt);
-    DN_CHECK_LAUNCH();
-    DN_CHECK_HIP(rocprim::exclusive_scan(wsp, tb, ucnt, uoff, (int32_t)0, (size_t)(M + 1), rocprim::plus<int32_t>(), st));
-    const int64_t nthreads = T > num_wg + 1 ? T : num_wg + 1;
-    hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(nthreads, 256)), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper, tile_ptr,
-                       list_ptr, tile_cnt, uoff, agg_units ? 1 : 0, reinterpret_cast<Unit*>(units), unit_ptr);
-    DN_CHECK_LAUNCH();
-    return DN_OK;
+    const dn_internal::CloseUnitsDir d{tile_ptr, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, drop_enable, nullptr, unit_ptr,
+                                       units, ent_row, ent_mask};
+    return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, num_list_entries, unit_capacity, 1, &d, workspace,
+                                          workspace_bytes, (hipStream_t)stream);
 }
 
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,

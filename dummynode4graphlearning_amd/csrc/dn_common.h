@@ -244,7 +244,11 @@ __device__ __forceinline__ void dn_fold_graph_tile_one(int64_t j, int32_t N, int
     const int32_t b0 = j == 0 ? 0 : first;
     if (good) good = nxt - b0 <= 32 && nxt - b0 >= 1;
     if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
-    if (!good) { *ok = 0; return; }
+    if (!good) {                                   // device scope + completed before this lane goes on: a later workgroup of the SAME
+        __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // launch may read it (ril_fold_verdict_kernel's ticket)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     tile_ptr[j] = b0;
     uint8_t ids[32];
     for (int i = 0; i < 32; ++i) ids[i] = (b0 + i >= first && b0 + i <= last) ? 0 : 255;

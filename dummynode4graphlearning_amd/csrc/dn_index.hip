@@ -749,10 +749,27 @@ __global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_pt
 // tests/sweep_ref.py (wg_shares + the event ranks) line by line.
 constexpr int kSwGroups = 8, kSwMaxRel = 64, kSwMaxW = 64, kSwTile = 32;
 
+struct SwDir {
+    int32_t *table, *info;
+    const int32_t* dyn;
+    unsigned long long skip_mask;
+};
+struct SwPair {
+    SwDir d[2];
+};
+
 __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int32_t* __restrict__ rel_ptr,
                                                             const int32_t* __restrict__ row_in, const int32_t* __restrict__ row_out,
-                                                            int32_t N, int32_t W, int32_t S_cap, unsigned long long skip_mask,
-                                                            int32_t* __restrict__ table, int32_t* __restrict__ info) {
+                                                            int32_t N, int32_t W, int32_t S_cap, SwPair pr) {
+    // blockIdx.y picks the table (dn_conv_index_build_i32 builds the orders of both transform launches in one launch)
+    unsigned long long skip_mask = pr.d[blockIdx.y].skip_mask;
+    int32_t* __restrict__ table = pr.d[blockIdx.y].table;
+    int32_t* __restrict__ info = pr.d[blockIdx.y].info;
+    const int32_t* __restrict__ dyn = pr.d[blockIdx.y].dyn;
+    if (dyn != nullptr) {                                         // queued behind the row index: {relation to skip or -1, go} read on
+        if (dyn[1] == 0) return;                                  // the device; go = 0: nothing to do
+        skip_mask = dyn[0] >= 0 ? 1ull << dyn[0] : 0ull;
+    }
     __shared__ int32_t lo[kSwGroups + 1][kSwMaxRel];              // first row of relation r in group x
     __shared__ int32_t T[kSwGroups][kSwMaxRel];                   // tiles of (group, relation)
     __shared__ int32_t pure0[kSwGroups][kSwMaxRel + 1];           // first pure workgroup of relation r (prefix of the pure counts)
@@ -1042,6 +1059,33 @@ __global__ void fold_fill_kernel(int64_t n, const int32_t* __restrict__ ptr, con
         }
     }
 }
+
+namespace dn_internal {
+
+// dn_sweep_tables_build_i32 for nd = 1 or 2 tables over the same rows in one launch; dyn[k] != NULL: {relation to skip or -1, go}
+// are read on the device instead of skip_mask[k].
+int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out, int64_t num_nodes,
+                       int32_t workgroups_per_group, int32_t tiles_per_workgroup, int nd, const uint64_t* skip_mask,
+                       const int32_t* const* dyn, int32_t* const* table, int32_t* const* info, hipStream_t st) {
+    DN_REQUIRE(num_rels >= 1 && num_rels <= kSwMaxRel, "dn_sweep_tables_build: 1 <= num_rels <= 64");
+    DN_REQUIRE(workgroups_per_group >= 1 && workgroups_per_group <= kSwMaxW, "dn_sweep_tables_build: 1 <= workgroups_per_group <= 64");
+    DN_REQUIRE(tiles_per_workgroup >= 1 && num_nodes >= 0 && num_nodes < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_sweep_tables_build: bad sizes");
+    DN_REQUIRE(rel_ptr && row_in && row_out && table[0] && table[nd - 1], "dn_sweep_tables_build: NULL pointer");
+    const int64_t total = (int64_t)kSwGroups * workgroups_per_group * tiles_per_workgroup;
+    DN_REQUIRE(total < 0x7fffffffLL, "dn_sweep_tables_build: table too large");
+    const int64_t blocks = dn_cdiv(total, 256);
+    SwPair pr;
+    for (int k = 0; k < 2; ++k) {
+        const int q = k < nd ? k : 0;
+        pr.d[k] = SwDir{table[q], info ? info[q] : nullptr, dyn ? dyn[q] : nullptr, (unsigned long long)skip_mask[q]};
+    }
+    hipLaunchKernelGGL(sweep_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)nd), dim3(256), 0, st, num_rels, rel_ptr,
+                       row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup, pr);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+}  // namespace dn_internal
 
 extern "C" {
 
@@ -1436,18 +1480,9 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
 int dn_sweep_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out,
                               int64_t num_nodes, int32_t workgroups_per_group, int32_t tiles_per_workgroup, uint64_t skip_mask,
                               int32_t* table, int32_t* info, dn_stream_t stream) {
-    DN_REQUIRE(num_rels >= 1 && num_rels <= kSwMaxRel, "dn_sweep_tables_build: 1 <= num_rels <= 64");
-    DN_REQUIRE(workgroups_per_group >= 1 && workgroups_per_group <= kSwMaxW, "dn_sweep_tables_build: 1 <= workgroups_per_group <= 64");
-    DN_REQUIRE(tiles_per_workgroup >= 1 && num_nodes >= 0 && num_nodes < 0x7fffffffLL, "dn_sweep_tables_build: bad sizes");
-    DN_REQUIRE(rel_ptr && row_in && row_out && table, "dn_sweep_tables_build: NULL pointer");
-    const int64_t total = (int64_t)kSwGroups * workgroups_per_group * tiles_per_workgroup;
-    DN_REQUIRE(total < 0x7fffffffLL, "dn_sweep_tables_build: table too large");
-    const int64_t blocks = dn_cdiv(total, 256);
-    hipLaunchKernelGGL(sweep_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
-                       num_rels, rel_ptr, row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup,
-                       (unsigned long long)skip_mask, table, info);
-    DN_CHECK_LAUNCH();
-    return DN_OK;
+    DN_REQUIRE(table, "dn_sweep_tables_build: NULL pointer");
+    return dn_internal::sweep_tables_queue(num_rels, rel_ptr, row_in, row_out, num_nodes, workgroups_per_group, tiles_per_workgroup, 1,
+                                           &skip_mask, nullptr, &table, &info, (hipStream_t)stream);
 }
 
 int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t step, int64_t max_entries, int32_t* table,

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "dn_common.h"
+#include "dn_internal.h"
 #include "../../include/dn_hip.h"
 
 #include <rocprim/rocprim.hpp>
@@ -605,7 +606,10 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
         }
         // modes and the verdict ride in the same block: ONE device -> host copy per build (both are final before this launch)
         if (threadIdx.x < R) meta[5 + R + 1 + threadIdx.x] = mode[threadIdx.x];
-        if (threadIdx.x == 0) { meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 1; meta[5 + 2 * R + 3] = 1; }   // (+ the two fold verdicts: "still valid")
+        if (threadIdx.x == 0) {                                           // (+ the two fold verdicts: "still valid"; the verdict launch's ticket)
+            meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 1; meta[5 + 2 * R + 3] = 1;
+            meta[5 + 2 * R + 4 + dn_internal::kRilPlanWords] = 0;
+        }
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         int n0, n1, e0;
@@ -644,10 +648,52 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
 // dummy), TF backward -- with rows, all of the direction's aux lists its own; its segments (the aux lists) must tile the batch as
 // dn_fold_graph_tile_one checks, the target of segment j being the relation's j-th row's output (forward) / input (backward) node.
 // tile_ptr [G + 1], info [G][12] as dn_fold_graph_tiles_build_i32 writes them; verdict -> meta[5 + 2 R + 2 + direction].
-__global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t self_loop, int32_t direction, int32_t* __restrict__ meta,
-                                        const int32_t* __restrict__ aux_ptr, const int32_t* __restrict__ aux_idx,
-                                        const int32_t* __restrict__ row_target, int32_t* __restrict__ tile_ptr,
-                                        int32_t* __restrict__ info) {
+struct VdDir {
+    const int32_t *aux_ptr, *aux_idx, *row_target;
+    int32_t *tile_ptr, *info;
+};
+struct VdPair {
+    VdDir d[2];
+};
+
+// What the table builders behind the row index need from its counts, left ON THE DEVICE so that dn_conv_index_build_i32 can queue
+// them without waiting for the read-back: plan = meta + 5 + 2 R + 4, kRilPlanWords words
+//   [0..3] forward closing stream:  {edge rows P, first / end row of the folded relation (the rows the stream leaves out), go}
+//   [4..7] backward closing stream: the same
+//   [8..9] forward sweep order: {relation to skip (-1: none), go};  [10..11] backward sweep order
+// go = the build is valid (no graph raised the flag), the direction's fold can be absorbed (the verdicts below) and its segments
+// are the batch's G graphs -- the one case the queued builders are sized for; otherwise they do nothing.
+__device__ void ril_plan(int64_t G, int32_t R, int32_t* __restrict__ meta) {
+    int32_t* plan = meta + 5 + 2 * R + 4;
+    const int32_t P = meta[0], status = meta[5 + 2 * R + 1];
+    for (int d = 0; d < 2; ++d) {
+        const int want = d == 0 ? kAgg : kTf;
+        int rel = -1;
+        for (int r = 0; r < R; ++r)
+            if (meta[5 + R + 1 + r] == want && meta[5 + r + 1] > meta[5 + r]) rel = r;   // (exactly one when the verdict stands)
+        const int32_t verdict = __hip_atomic_load(meta + 5 + 2 * R + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t go = (status == 0 && verdict != 0 && rel >= 0 && (int64_t)meta[1 + d] == G) ? 1 : 0;
+        plan[4 * d] = P;
+        plan[4 * d + 1] = go ? meta[5 + rel] : 0;
+        plan[4 * d + 2] = go ? meta[5 + rel + 1] : 0;
+        plan[4 * d + 3] = go;
+        plan[8 + 2 * d] = go ? rel : -1;
+        plan[8 + 2 * d + 1] = go;
+    }
+}
+
+// Can the closing launch ABSORB the fold of this batch (dn_rows_close_bf16 with AGG units)?  The question ops._closing_tables
+// used to ask with two more launches and a second read-back, answered here behind ril_fill_kernel with what the device already
+// knows (meta), for both directions in one launch (blockIdx.y): the candidate is the ONE collapsed relation of the direction --
+// mode AGG forward (rows into few destinations: u -> dummy), TF backward -- with rows, all of the direction's aux lists its own;
+// its segments (the aux lists) must tile the batch as dn_fold_graph_tile_one checks, the target of segment j being the relation's
+// j-th row's output (forward) / input (backward) node.  tile_ptr [G + 1], info [G][12] as dn_fold_graph_tiles_build_i32 writes
+// them; verdict -> meta[5 + 2 R + 2 + direction].  want_plan: the workgroup that finishes LAST (a counter behind the plan words)
+// writes ril_plan's words -- every verdict has landed by then.
+__global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t self_loop, int32_t* __restrict__ meta, VdPair pr,
+                                        int32_t want_plan) {
+    const int direction = blockIdx.y;
+    const VdDir& a = pr.d[direction];
     const int want = direction == 0 ? kAgg : kTf;
     const int32_t n_aux = meta[1 + direction];
     int32_t* ok = meta + 5 + 2 * R + 2 + direction;
@@ -657,10 +703,22 @@ __global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t
     const int32_t beg = meta[5 + rel], end = meta[5 + rel + 1];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (!(self_loop && found == 1 && n_aux > 0 && end - beg == n_aux && (int64_t)n_aux <= G)) {
-        if (j == 0) *ok = 0;
-        return;
+        if (j == 0) {
+            __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        dn_fold_graph_tile_one(j, (int32_t)N, n_aux, a.aux_ptr, a.aux_idx, a.row_target + beg, a.tile_ptr, a.info, ok);
     }
-    dn_fold_graph_tile_one(j, (int32_t)N, n_aux, aux_ptr, aux_idx, row_target + beg, tile_ptr, info, ok);
+    if (!want_plan) return;
+    // (the verdict words are written and read with device-scope atomics -- no cache write-back per workgroup; everything else the
+    //  plan reads was written by the previous launch)
+    __syncthreads();                                                       // (every lane's verdict store has completed: it waited)
+    if (threadIdx.x == 0) {
+        int32_t* ticket = meta + 5 + 2 * R + 4 + dn_internal::kRilPlanWords;
+        if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(gridDim.x * gridDim.y) - 1)
+            ril_plan(G, R, meta);
+    }
 }
 
 struct LocWs {
@@ -688,7 +746,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
     w.hbits = (uint8_t*)take((size_t)E);
-    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4));
+    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4 + dn_internal::kRilPlanWords + 1));   // (+ the verdict launch's ticket)
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
                                 rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) {
@@ -702,6 +760,67 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
 }
 
 }  // namespace
+
+namespace dn_internal {
+
+// The launches of dn_row_index_build_local_i32 without its read-back: *meta_dev = the device words the host unpacks afterwards
+// (ril_unpack); plan: ril_plan's words behind them (needs verdicts).
+int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* src,
+              const int32_t* dst, const int32_t* etype, int32_t self_loop, float edge_frac, int32_t* row_in, int32_t* row_out,
+              int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows,
+              int32_t* src_ptr, int32_t* src_rows, int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f,
+              int32_t* tile_ptr_b, int32_t* fold_info_b, bool verdicts, bool plan, void* workspace, size_t workspace_bytes,
+              int32_t** meta_dev, hipStream_t st) {
+    DN_REQUIRE(G >= 0 && N >= 0 && R >= 1 && E >= 0, "dn_row_index_build_local: bad sizes");
+    DN_REQUIRE(R <= kLocR, "dn_row_index_build_local: more than 64 relations (use dn_row_index_build_i32)");
+    DN_REQUIRE(2 * E + N < 0x7fffffffLL && kSeg * R * G + 2 * (N + 1) + 1 < 0x7fffffffLL,
+               "dn_row_index_build_local: sizes must fit int32");
+    DN_REQUIRE(node_ptr && edge_ptr && row_in && row_out && aux_f_ptr && aux_b_ptr && dst_ptr && dst_rows && src_ptr && src_rows &&
+               workspace && meta_dev, "dn_row_index_build_local: NULL pointer");
+    DN_REQUIRE(E == 0 || (src && dst && etype && aux_f_idx && aux_b_idx), "dn_row_index_build_local: NULL pointer");
+    LocWs w;
+    size_t need = 0;
+    int rc = loc_layout((char*)workspace, workspace_bytes, need, w, G, N, R, E);
+    if (rc != DN_OK) return rc;
+    if (need > workspace_bytes) { dn_set_error("dn_row_index_build_local: workspace too small (%zu < %zu)", workspace_bytes, need); return DN_ERR_WORKSPACE; }
+    DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, w.zero_bytes, st));
+    const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
+    hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
+                       N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits);
+    hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, edge_frac, self_loop, node_ptr,
+                       edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.hbits, w.mode, w.C);
+    DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
+                                         rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
+                       dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
+                       src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
+    DN_CHECK_LAUNCH();
+    if (verdicts) {
+        DN_REQUIRE(tile_ptr_f && fold_info_f && tile_ptr_b && fold_info_b, "dn_row_index_build_local: the fold verdicts need the four tile buffers");
+        DN_REQUIRE((reinterpret_cast<uintptr_t>(fold_info_f) | reinterpret_cast<uintptr_t>(fold_info_b)) % 16 == 0,
+                   "dn_row_index_build_local: unaligned fold_info");
+        const unsigned vg = (unsigned)dn_cdiv(G + 1, 256);
+        VdPair pr;
+        pr.d[0] = VdDir{aux_f_ptr, aux_f_idx, row_out, tile_ptr_f, fold_info_f};
+        pr.d[1] = VdDir{aux_b_ptr, aux_b_idx, row_in, tile_ptr_b, fold_info_b};
+        hipLaunchKernelGGL(ril_fold_verdict_kernel, dim3(vg, 2), dim3(256), 0, st, G, N, (int32_t)R, self_loop, w.meta, pr, plan ? 1 : 0);
+        DN_CHECK_LAUNCH();
+    }
+    DN_REQUIRE(!plan || verdicts, "dn_row_index_build_local: the plan needs the fold verdicts");
+    *meta_dev = w.meta;
+    return DN_OK;
+}
+
+void ril_unpack(const int32_t* h_meta, int64_t R, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
+                int32_t* host_status, int32_t* host_absorb) {
+    if (host_absorb) { host_absorb[0] = h_meta[5 + 2 * R + 2]; host_absorb[1] = h_meta[5 + 2 * R + 3]; }
+    *host_status = h_meta[5 + 2 * R + 1];
+    for (int k = 0; k < 5; ++k) host_counts[k] = h_meta[k];
+    for (int64_t r = 0; r <= R; ++r) host_rel_ptr[r] = h_meta[5 + r];
+    for (int64_t r = 0; r < R; ++r) host_modes[r] = h_meta[5 + R + 1 + r];
+}
+
+}  // namespace dn_internal
 
 extern "C" {
 
@@ -722,51 +841,18 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
                                  int32_t* fold_info_b, int32_t* host_absorb, void* workspace, size_t workspace_bytes,
                                  dn_stream_t stream) {
-    DN_REQUIRE(G >= 0 && N >= 0 && R >= 1 && E >= 0, "dn_row_index_build_local: bad sizes");
-    DN_REQUIRE(R <= kLocR, "dn_row_index_build_local: more than 64 relations (use dn_row_index_build_i32)");
-    DN_REQUIRE(2 * E + N < 0x7fffffffLL && kSeg * R * G + 2 * (N + 1) + 1 < 0x7fffffffLL,
-               "dn_row_index_build_local: sizes must fit int32");
-    DN_REQUIRE(node_ptr && edge_ptr && row_in && row_out && aux_f_ptr && aux_b_ptr && dst_ptr && dst_rows && src_ptr && src_rows &&
-               host_counts && host_rel_ptr && host_modes && host_status && workspace, "dn_row_index_build_local: NULL pointer");
-    DN_REQUIRE(E == 0 || (src && dst && etype && aux_f_idx && aux_b_idx), "dn_row_index_build_local: NULL pointer");
+    DN_REQUIRE(host_counts && host_rel_ptr && host_modes && host_status, "dn_row_index_build_local: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
-    LocWs w;
-    size_t need = 0;
-    int rc = loc_layout((char*)workspace, workspace_bytes, need, w, G, N, R, E);
+    int32_t* meta = nullptr;
+    const int rc = dn_internal::ril_queue(G, N, R, E, node_ptr, edge_ptr, src, dst, etype, self_loop, edge_frac, row_in, row_out, aux_f_ptr,
+                                          aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows, src_ptr, src_rows, rel_ptr_dev, tile_ptr_f,
+                                          fold_info_f, tile_ptr_b, fold_info_b, host_absorb != nullptr, false, workspace, workspace_bytes,
+                                          &meta, st);
     if (rc != DN_OK) return rc;
-    if (need > workspace_bytes) { dn_set_error("dn_row_index_build_local: workspace too small (%zu < %zu)", workspace_bytes, need); return DN_ERR_WORKSPACE; }
-    DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, w.zero_bytes, st));
-    const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
-    hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
-                       N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits);
-    hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, edge_frac, self_loop, node_ptr,
-                       edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.hbits, w.mode, w.C);
-    DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
-                                         rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
-                       dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
-                       src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
-    DN_CHECK_LAUNCH();
-    const bool verdicts = host_absorb != nullptr;
-    if (verdicts) {
-        DN_REQUIRE(tile_ptr_f && fold_info_f && tile_ptr_b && fold_info_b, "dn_row_index_build_local: host_absorb needs the four tile buffers");
-        DN_REQUIRE((reinterpret_cast<uintptr_t>(fold_info_f) | reinterpret_cast<uintptr_t>(fold_info_b)) % 16 == 0,
-                   "dn_row_index_build_local: unaligned fold_info");
-        const unsigned vg = (unsigned)dn_cdiv(G + 1, 256);
-        hipLaunchKernelGGL(ril_fold_verdict_kernel, dim3(vg), dim3(256), 0, st, G, N, (int32_t)R, self_loop, 0, w.meta, aux_f_ptr, aux_f_idx,
-                           row_out, tile_ptr_f, fold_info_f);
-        hipLaunchKernelGGL(ril_fold_verdict_kernel, dim3(vg), dim3(256), 0, st, G, N, (int32_t)R, self_loop, 1, w.meta, aux_b_ptr, aux_b_idx,
-                           row_in, tile_ptr_b, fold_info_b);
-        DN_CHECK_LAUNCH();
-    }
     int32_t h_meta[5 + 2 * kLocR + 4];
-    DN_CHECK_HIP(hipMemcpyAsync(h_meta, w.meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 4), hipMemcpyDeviceToHost, st));
+    DN_CHECK_HIP(hipMemcpyAsync(h_meta, meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 4), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
-    if (verdicts) { host_absorb[0] = h_meta[5 + 2 * R + 2]; host_absorb[1] = h_meta[5 + 2 * R + 3]; }
-    *host_status = h_meta[5 + 2 * R + 1];
-    for (int k = 0; k < 5; ++k) host_counts[k] = h_meta[k];
-    for (int64_t r = 0; r <= R; ++r) host_rel_ptr[r] = h_meta[5 + r];
-    for (int64_t r = 0; r < R; ++r) host_modes[r] = h_meta[5 + R + 1 + r];
+    dn_internal::ril_unpack(h_meta, R, host_counts, host_rel_ptr, host_modes, host_status, host_absorb);
     return DN_OK;
 }
 

@@ -27,4 +27,33 @@ int launch_close8(const void* X, const void* W, int32_t w_kn, const void* bias, 
                   const int32_t* fold_info, const void* W_agg, void* aux, const int32_t* agg_idx, int32_t nt_store,
                   const void* Wrel, const int32_t* tidx, int32_t* done, int32_t num_chunks, int32_t* err, hipStream_t st);
 
+// ---- the per-batch index as ONE call (dn_conv_index.hip: dn_conv_index_build_i32) -- the builders' launches without their host sides
+constexpr int kRilPlanWords = 12;      // ril_plan_kernel's words behind the 5 + 2 R + 4 meta words of the graph-local row index
+
+// dn_index_local.hip
+int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* src,
+              const int32_t* dst, const int32_t* etype, int32_t self_loop, float edge_frac, int32_t* row_in, int32_t* row_out,
+              int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr, int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows,
+              int32_t* src_ptr, int32_t* src_rows, int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f,
+              int32_t* tile_ptr_b, int32_t* fold_info_b, bool verdicts, bool plan, void* workspace, size_t workspace_bytes,
+              int32_t** meta_dev, hipStream_t st);
+void ril_unpack(const int32_t* h_meta, int64_t R, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
+                int32_t* host_status, int32_t* host_absorb);
+
+// dn_close.hip
+struct CloseUnitsDir {                 // one direction's arguments of dn_close_units_build_i32 (dyn: see close_units_queue)
+    const int32_t *tile_ptr, *list_ptr, *list_rows;
+    int32_t num_edge_rows, drop_beg, drop_end;
+    const int32_t *drop_enable, *dyn;
+    int32_t *unit_ptr, *units, *ent_row;
+    uint32_t* ent_mask;
+};
+int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int64_t num_list_entries, int64_t unit_capacity,
+                      int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// dn_index.hip
+int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out, int64_t num_nodes,
+                       int32_t workgroups_per_group, int32_t tiles_per_workgroup, int nd, const uint64_t* skip_mask,
+                       const int32_t* const* dyn, int32_t* const* table, int32_t* const* info, hipStream_t st);
+
 }  // namespace dn_internal

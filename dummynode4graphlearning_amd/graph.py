@@ -130,12 +130,14 @@ class BatchedGraph:
             self._cache._rel.pop(0)
         return ix
 
-    def row_index(self, etype, num_rels, self_loop):
+    def row_index(self, etype, num_rels, self_loop, closing_hint=None):
+        """closing_hint = (H, dtype) of the rows the caller is about to pass: a fresh batch's index is then built with everything
+        its first step needs in one call (ops.RowIndex); a cached index is returned as it is."""
         for t, ver, r, ix in self._cache._rel:
             if t is etype and ver == etype._version and r == ("row", num_rels, self_loop):
                 return ix
         ix = ops.RowIndexSet(self._src, self._dst, etype, self._n, num_rels, self_loop,
-                             node_ptr=self.node_ptr(), edge_ptr=self.edge_ptr())
+                             node_ptr=self.node_ptr(), edge_ptr=self.edge_ptr(), closing_hint=closing_hint)
         self._cache._rel.append((etype, etype._version, ("row", num_rels, self_loop), ix))
         if len(self._cache._rel) > 4:
             self._cache._rel.pop(0)
@@ -270,8 +272,8 @@ def edge_index_of(data):
     return cache._edge_index
 
 
-def row_index_of(data, etype, num_rels, self_loop):
-    """Cached ops.RowIndexSet (bf16 matrix-core path) of a PyG-style batch."""
+def row_index_of(data, etype, num_rels, self_loop, closing_hint=None):
+    """Cached ops.RowIndexSet (bf16 matrix-core path) of a PyG-style batch.  closing_hint as BatchedGraph.row_index."""
     cache = getattr(data, "_cache", None)
     if cache is None:
         cache = _IndexCache()
@@ -286,7 +288,7 @@ def row_index_of(data, etype, num_rels, self_loop):
             return ix
     nptr = _node_ptr_or_none(data)
     ix = ops.RowIndexSet(data.edge_index[0], data.edge_index[1], etype, data.x.shape[0], num_rels, self_loop,
-                         node_ptr=nptr, edge_ptr=_edge_ptr_or_none(data, nptr))
+                         node_ptr=nptr, edge_ptr=_edge_ptr_or_none(data, nptr), closing_hint=closing_hint)
     cache._rel.append((etype, etype._version, tag, ix))
     if len(cache._rel) > 4:
         cache._rel.pop(0)

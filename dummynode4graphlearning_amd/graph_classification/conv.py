@@ -96,7 +96,7 @@ class RGCNConv(nn.Module):
     def forward(self, x, data, edge_type):
         if self.aggr == "add" and self.root is not None and ops.fused_path_supported(x, self.weight):
             # bf16: relation transform + root weight + bias in the row-factorised MFMA pipeline (as SI RGINLayer)
-            index = row_index_of(data, edge_type, self.num_relations, True)
+            index = row_index_of(data, edge_type, self.num_relations, True, closing_hint=(x.shape[1], x.dtype))
             return ops.rel_transform_fused(x, self.weight, self.bias, index, W_loop=self.root)
         index = rel_index_of(data, edge_type, self.num_relations)
         scale = None

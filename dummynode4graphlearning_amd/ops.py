@@ -1188,6 +1188,8 @@ def segment_reduce(x, graph_ptr, kind="sum"):
 # ----------------------------------------------------------------------------------------------
 # DN_LOCAL_INDEX=0: always the general (sort-based) row-index builder, also for batches with graph boundaries
 LOCAL_INDEX_ENABLED = _os.environ.get("DN_LOCAL_INDEX", "1") != "0"
+# DN_CONV_INDEX=0: never dn_conv_index_build_i32 -- row index, closing tables, sweep orders and chunk table by their own calls
+CONV_INDEX_ENABLED = _os.environ.get("DN_CONV_INDEX", "1") != "0"
 
 
 class RowIndex:
@@ -1204,11 +1206,15 @@ class RowIndex:
 
     EDGE, AGG, TF = 0, 1, 2
 
-    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75, node_ptr=None, edge_ptr=None):
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop=True, edge_frac=0.75, node_ptr=None, edge_ptr=None,
+                 closing_hint=None):
         """One C-ABI call + device-side tile tables.  With the batch's graph boundaries (node_ptr / edge_ptr, [G+1] each) the
         graph-local builder runs (dn_row_index_build_local_i32: one wavefront rank-sorts one graph in LDS, one scan); without
         them, or when the batch does not qualify (a graph over 1024 edges, more than 64 relations), the general one
-        (dn_row_index_build_i32: stable radix sorts + scans over the whole batch).  Both produce the same tables bit for bit."""
+        (dn_row_index_build_i32: stable radix sorts + scans over the whole batch).  Both produce the same tables bit for bit.
+        closing_hint = (H, dtype) of the rows the index will serve: for (256, bfloat16) with graph boundaries the WHOLE per-batch
+        index -- row index, unit streams of both closing launches, sweep orders, weight-gradient chunk table -- is one call with one
+        read-back (dn_conv_index_build_i32); whatever that call could not serve is built on first use as before."""
         require_gpu(src, dst, etype)
         dev = src.device
         N, R, E = int(num_nodes), int(num_rels), int(src.numel())
@@ -1229,6 +1235,7 @@ class RowIndex:
         self.built_by = "general"
         self._absorb = None                                           # local builder: {direction: (tile_ptr, fold_info, verdict)}
         rel_dev = None
+        pre = None                                                    # (tables dn_conv_index_build_i32 left behind, see below)
         if try_local:
             require_gpu(node_ptr, edge_ptr)
             rel_dev = e32(R + 2)                                      # the relation offsets as the device builder leaves them
@@ -1238,8 +1245,45 @@ class RowIndex:
             gt_bufs = [(e32(G + 1), torch.empty((max(G, 1), 12), dtype=I32, device=dev)) for _ in range(2)]
             host_absorb = (ctypes.c_int32 * 2)()
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
-            nbytes = lib().dn_row_index_local_workspace_bytes(G, N, R, E)
-            if nbytes:
+            one_call = (CONV_INDEX_ENABLED and closing_hint is not None and closing_hint[0] == 256
+                        and closing_hint[1] == torch.bfloat16 and self_loop and G >= 1 and N >= 1 and CLOSE_RING_ENABLED
+                        and CLOSE_AGG_ENABLED and FOLD_ENABLED)
+            nbytes = 0 if one_call else lib().dn_row_index_local_workspace_bytes(G, N, R, E)
+            if one_call:
+                num_wg = _num_cus(dev)
+                nbytes = lib().dn_conv_index_workspace_bytes(G, N, R, E, num_wg)
+            if one_call and nbytes:
+                cap = int(lib().dn_close_units_capacity(G, E + N, num_wg))
+                cus = []
+                for _ in range(2):
+                    cu = CloseUnits()
+                    cu.num_wg, cu.num_nodes, cu.agg, cu.num_tiles = num_wg, N, True, G
+                    cu.unit_ptr, cu.units = e32(num_wg + 1), torch.empty((cap, 4), dtype=I32, device=dev)
+                    cu.ent_row, cu.ent_mask = e32(E + N), e32(E + N)
+                    cus.append(cu)
+                Gw = 8 * SWEEP_WG_PER_GROUP
+                want_sweep = SWEEP_ENABLED and E // 32 >= Gw * SWEEP_MIN_TILES_PER_WG
+                S = int(1.06 * (E // 32 + 8 * R) / Gw) + 2 if want_sweep else 0
+                sweeps = [torch.empty((Gw * S, 4), dtype=I32, device=dev) for _ in range(2)] if want_sweep else [None, None]
+                chunk_cap = (E + N) // 256 + R + 3
+                chunk_tab, chunk_pp = torch.empty((chunk_cap, 4), dtype=I32, device=dev), e32(R + 2)
+                host_plan = (ctypes.c_int32 * 4)()
+                ws = _ws(nbytes, dev)
+                status = ctypes.c_int32(0)
+                check(lib().dn_conv_index_build_i32(
+                    G, N, R, E, ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype), 1, float(edge_frac), ptr(row_in),
+                    ptr(row_out), ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr), ptr(aux_b_idx), ptr(dst_ptr), ptr(dst_rows),
+                    ptr(src_ptr), ptr(src_rows), counts, host_rel, host_modes, ctypes.byref(status), ptr(rel_dev), ptr(gt_bufs[0][0]),
+                    ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cap, ptr(cus[0].unit_ptr),
+                    ptr(cus[0].units), ptr(cus[0].ent_row), ptr(cus[0].ent_mask), ptr(cus[1].unit_ptr), ptr(cus[1].units),
+                    ptr(cus[1].ent_row), ptr(cus[1].ent_mask), SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
+                    WGRAD_CHUNK_ROWS, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),
+                    "dn_conv_index_build_i32")
+                if status.value == 0:
+                    self.built_by = "local"
+                    self._absorb = {d: (gt_bufs[k][0], gt_bufs[k][1], int(host_absorb[k])) for k, d in enumerate(("f", "b"))}
+                    pre = (cus, sweeps, Gw * S, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]))
+            elif nbytes:
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
                 check(lib().dn_row_index_build_local_i32(G, N, R, E, ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype),
@@ -1291,7 +1335,20 @@ class RowIndex:
         self._slots, self._units, self._fold = {}, {}, {}
         # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size:
         # the smallest chunk that keeps ALL relations' chunks (each relation ends in a partial one) within one round of 256
-        self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
+        if pre is not None:
+            self.chunk_table = pre[3]
+            if pre[4] and pre[5]:                                    # both directions served: nothing is left for the first step
+                cands = {d: _fold_candidate(self, d) for d in ("f", "b")}
+                assert cands["f"] is not None and cands["b"] is not None and cands["f"][3] == cands["b"][3] == G
+                for k, d in enumerate(("f", "b")):
+                    info = _make_fold_info(self, d, cands[d])
+                    info.graph_tiles = (self._absorb[d][0], self._absorb[d][1])
+                    if pre[1][k] is not None and _sweep_wanted(self):
+                        info.sweep_tiles = (pre[1][k], pre[2])
+                    self._fold[d] = info
+                    self._units[d] = pre[0][k]
+        else:
+            self.chunk_table = build_row_tables(rel_ptr_d, self.num_all_rels, P_all, wgrad_chunk_rows(rel_ptr), want_ptr=True)
 
 
 def _conv_tiles(ix, fold, xs):
@@ -1301,10 +1358,15 @@ def _conv_tiles(ix, fold, xs):
     return _conv_tiles_for(ix, fold, xs.shape[1], xs.dtype)
 
 
+def _sweep_wanted(ix):
+    """Is the batch large enough for the L2-blocked order to matter (smaller launches fit the L2s anyway)?"""
+    return (SWEEP_ENABLED and ix.num_rels <= 64
+            and ix.num_edge_rows // 32 >= 8 * SWEEP_WG_PER_GROUP * SWEEP_MIN_TILES_PER_WG)
+
+
 def _conv_tiles_for(ix, fold, H, dtype):
     P, R = ix.num_edge_rows, ix.num_rels
-    if not (SWEEP_ENABLED and dtype == torch.bfloat16 and H == 256 and R <= 64
-            and P // 32 >= 8 * SWEEP_WG_PER_GROUP * SWEEP_MIN_TILES_PER_WG):
+    if not (dtype == torch.bfloat16 and H == 256 and _sweep_wanted(ix)):
         if fold.main_tiles is None:                                  # (built on first use: a batch on the sweep order never needs them)
             fold.main_tiles = build_row_tables(ix.rel_ptr_dev, ix.num_rels, ix.num_edge_rows, 32, skip_mask=1 << fold.rel)
         return fold.main_tiles
@@ -1361,6 +1423,24 @@ def _fold_candidate(ix, direction):
 CLOSE_AGG_ENABLED = _os.environ.get("DN_CLOSE_AGG", "1") != "0"
 
 
+def _fold_add_idx(ix, direction, cand):
+    """The node every segment's product is added to: the folded relation's rows' outputs (forward) / inputs (backward)."""
+    return (ix.row_out if direction == "f" else ix.row_in)[cand[1]:cand[2]].contiguous()
+
+
+def _make_fold_info(ix, direction, cand):
+    r, beg, end, n_aux = cand
+    info = _Fold()
+    info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
+    info.fold_info = info.part_ptr = info.graph_tiles = None
+    info.num_parts = int(2 * n_aux + ix.num_nodes // 32 + 1)   # upper bound of part_ptr[-1] without a read-back: every segment
+    #                                                            starts one partial row, every tile boundary inside one another
+    info.main_tiles = None                               # plain relation-major tiles, built on first use (_conv_tiles_for)
+    info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
+    info.add_idx = _fold_add_idx(ix, direction, cand)
+    return info
+
+
 def _queue_fold_tables(ix, direction, n_aux, flag):
     """dn_fold_tables_build_async_i32 for one direction (32-node tiles, fp32 partial rows): -> (fold_info, part_ptr); verdict in flag."""
     N, dev = ix.num_nodes, ix.row_in.device
@@ -1392,19 +1472,10 @@ def _closing_tables(ix, kind="slots"):
     dirs = ("f", "b")
 
     def add_idx_of(direction, cand):
-        return (ix.row_out if direction == "f" else ix.row_in)[cand[1]:cand[2]].contiguous()
+        return _fold_add_idx(ix, direction, cand)
 
     def make_info(direction, cand):
-        r, beg, end, n_aux = cand
-        info = _Fold()
-        info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-        info.fold_info = info.part_ptr = info.graph_tiles = None
-        info.num_parts = int(2 * n_aux + N // 32 + 1)      # upper bound of part_ptr[-1] without a read-back: every segment starts
-        #                                                    one partial row, every tile boundary inside one another
-        info.main_tiles = None                               # plain relation-major tiles, built on first use (_conv_tiles_for)
-        info.sweep_tiles = None                              # built on the first H = 256 launch (_conv_tiles)
-        info.add_idx = add_idx_of(direction, cand)
-        return info
+        return _make_fold_info(ix, direction, cand)
 
     tabs = {}
     if first:
@@ -1522,10 +1593,11 @@ class RowIndexSet:
     share.  (Rounds 1-2 could cut a batch into cache-resident sub-batches here; under-filled launches lost more than the
     Infinity Cache returned at every split -- DESIGN.md section 4 -- and the splitting was removed in round 3.)"""
 
-    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop, node_ptr=None, edge_ptr=None):
+    def __init__(self, src, dst, etype, num_nodes, num_rels, self_loop, node_ptr=None, edge_ptr=None, closing_hint=None):
         N = int(num_nodes)
         self.num_nodes, self.num_rels, self.self_loop = N, int(num_rels), bool(self_loop)
-        self.parts = [(0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop, node_ptr=node_ptr, edge_ptr=edge_ptr))]
+        self.parts = [(0, N, RowIndex(src, dst, etype, N, num_rels, self_loop=self_loop, node_ptr=node_ptr, edge_ptr=edge_ptr,
+                                      closing_hint=closing_hint))]
         self.max_rows = max(ix.num_rows for _, _, ix in self.parts)
         self.num_rows = sum(ix.num_rows for _, _, ix in self.parts)
         self.num_all_rels = self.num_rels + (1 if self_loop else 0)

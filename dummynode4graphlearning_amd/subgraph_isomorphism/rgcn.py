@@ -121,7 +121,7 @@ class RGCNLayer(nn.Module):
             elif self.edge_norm == "both":
                 s_in, s_out = g.ndata[INNORM].sqrt(), g.ndata[OUTNORM].sqrt()
             xin = node_feat if s_out is None else node_feat * s_out.to(node_feat.dtype)
-            index = g.row_index(edge_type, self.num_rels, self.self_loop)
+            index = g.row_index(edge_type, self.num_rels, self.self_loop, closing_hint=(xin.shape[1], xin.dtype))
             out = ops.rel_transform_fused(xin, W, None, index, W_loop=self.loop_weight if self.self_loop else None)
             if s_in is not None:
                 out = out * s_in.to(out.dtype)

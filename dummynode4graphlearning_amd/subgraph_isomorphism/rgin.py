@@ -120,7 +120,7 @@ class RGINLayer(nn.Module):
         W = dense_relation_weights(self)
         if ops.fused_path_supported(node_feat, W):
             # bf16: message pass, self loop (rgin.py:140-142) and bias in ONE row-factorised MFMA pipeline
-            index = g.row_index(edge_type, self.num_rels, self.self_loop)
+            index = g.row_index(edge_type, self.num_rels, self.self_loop, closing_hint=(node_feat.shape[1], node_feat.dtype))
             out = ops.rel_transform_fused(node_feat, W, self.bias if self.self_loop else None, index,
                                           W_loop=self.loop_weight if self.self_loop else None)
             if self.bias is not None and not self.self_loop:

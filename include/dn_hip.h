@@ -269,6 +269,36 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* host_absorb,
                                  void* workspace, size_t workspace_bytes, dn_stream_t stream);
 
+/* The per-batch index of the H = 256 bf16 conv path as ONE call on one arena (round 5) -- what dgl.batch + update_all pay per step
+ * in the reference (subgraph_isomorphism/dataset.py:1605-1611; models/rgin.py:156-160): dn_row_index_build_local_i32 (same
+ * arguments and outputs, rel_ptr_dev and the absorbed-fold buffers required) and, queued behind it BEFORE the one read-back,
+ *   - the unit streams of both closing launches with the graphs as tiles and the AGG units appended (dn_close_units_build_i32 with
+ *     tile_ptr_f / _b, agg_units = 1, the folded relation's rows dropped): unit_ptr_* [num_wg + 1], units_* [unit_capacity][4]
+ *     (16-byte aligned; unit_capacity >= dn_close_units_capacity(G, E + N, num_wg)), ent_row_* / ent_mask_* [E + N];
+ *   - the sweep orders of both transform launches with the folded relation skipped (dn_sweep_tables_build_i32):
+ *     sweep_f / sweep_b [8 * sweep_wg_per_group * sweep_tiles_per_wg][4]; sweep_tiles_per_wg = 0: none;
+ * the counts these builders need (edge rows, the folded relation and its row range) are read from device memory.  They serve ONE
+ * case -- host_plan[0] (forward) / host_plan[1] (backward) != 0: the build is valid, the direction's fold can be absorbed
+ * (host_absorb) and its segments are the batch's G graphs; for a direction with 0 its tables are left untouched and the caller
+ * builds them with the separate entry points.  After the read-back the split-K chunk table of the weight gradient over all rows
+ * (dn_row_tables_build_i32 with piece_ptr) is queued: host_plan[2] = rows per chunk -- the smallest multiple of 64 (>= 256, <=
+ * wgrad_max_chunk_rows) for which the chunks of all relations fit one round of wgrad_workgroups -- host_plan[3] = its entries
+ * (rows / chunk + relations + 1 <= chunk_capacity); chunk_table [chunk_capacity][4], chunk_ptr [R + 2].  *host_status != 0 as for
+ * dn_row_index_build_local_i32 (nothing else is valid).  workspace: 256-byte aligned.  Synchronises the stream once. */
+size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg);
+int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
+                            const int32_t* src, const int32_t* dst, const int32_t* etype, int32_t self_loop, float edge_frac,
+                            int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr,
+                            int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
+                            int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
+                            int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
+                            int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int64_t unit_capacity, int32_t* unit_ptr_f,
+                            int32_t* units_f, int32_t* ent_row_f, uint32_t* ent_mask_f, int32_t* unit_ptr_b, int32_t* units_b,
+                            int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t sweep_wg_per_group, int32_t sweep_tiles_per_wg,
+                            int32_t* sweep_f, int32_t* sweep_b, int32_t wgrad_workgroups, int32_t wgrad_max_chunk_rows,
+                            int64_t chunk_capacity, int32_t* chunk_table, int32_t* chunk_ptr, int32_t* host_plan, void* workspace,
+                            size_t workspace_bytes, dn_stream_t stream);
+
 /* Tile / chunk tables of relation-major rows for dn_rows_transform_* (step = 32 rows) and dn_rows_wgrad_* (step = the
  * split-K chunk size), built on the device from rel_ptr [num_rels + 1] (device): entry i = {rel, beg, end, 0}.  The caller
  * sizes `table` by the upper bound max_entries >= rows / step + num_rels; unused entries become empty pieces (beg == end) of

@@ -189,3 +189,135 @@ def test_local_builder_graphs_of_several_hundred_edges(seed):
     assert sizes.max() > 256 and sizes.max() <= 1024, sizes.max()
     a, b = _build(src, dst, et, int(nptr[-1]), 7, True, nptr, eptr)
     _same(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dn_conv_index_build_i32: row index + unit streams + sweep orders + chunk table in ONE call must leave what the separate calls do
+def _index_pair(src, dst, et, N, R, nptr, eptr):
+    """(one-call index, index by the separate builders + prepare_closing) of the same batch."""
+    from dummynode4graphlearning_amd import ops
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32, device=dev)  # noqa: E731
+    a = ops.RowIndex(t(src), t(dst), t(et), N, R, self_loop=True, node_ptr=t(nptr), edge_ptr=t(eptr),
+                     closing_hint=(256, torch.bfloat16))
+    b = ops.RowIndex(t(src), t(dst), t(et), N, R, self_loop=True, node_ptr=t(nptr), edge_ptr=t(eptr))
+    return a, b
+
+
+def _entry_positions(units):
+    """positions of ent_row / ent_mask that the ENTRY units of a stream cover"""
+    u = units[(units[:, 0] & 1) != 0]
+    if u.shape[0] == 0:
+        return np.zeros(0, np.int64)
+    return np.concatenate([np.arange(b, e) for b, e in zip(u[:, 1], u[:, 2])])
+
+
+def _tiles_per_workgroup(table, count):
+    """the non-empty tiles of every workgroup of a sweep table, in order"""
+    t = table.cpu().numpy().reshape(256, -1, 4)
+    assert t.shape[1] * 256 == count
+    return [[tuple(e[:3]) for e in w if e[2] > e[1]] for w in t]
+
+
+def _same_closing(a, b, served):
+    from dummynode4graphlearning_amd import ops
+    for f in FIELDS + ("rel_ptr_dev",):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert a.rel_ptr_host == b.rel_ptr_host and a.modes == b.modes and a.built_by == b.built_by
+    (ta, pa, ma), (tb, pb, mb) = a.chunk_table, b.chunk_table
+    assert ma == mb and torch.equal(ta[:ma], tb[:mb]) and torch.equal(pa[:a.num_all_rels + 1], pb[:b.num_all_rels + 1])
+    ops.prepare_closing(b, 256, torch.bfloat16)
+    absorbed = b.built_by == "local" and all(b._units[d].agg for d in "fb")
+    if served is not None:
+        assert absorbed == served
+    assert bool(a._units) == absorbed                                 # both folds absorbed: nothing left to build for the first step
+    ops.prepare_closing(a, 256, torch.bfloat16)
+    for d in "fb":
+        fa, fb_ = a._fold[d], b._fold[d]
+        assert (fa is None) == (fb_ is None)
+        if fa is not None:
+            assert (fa.rel, fa.beg, fa.end, fa.n) == (fb_.rel, fb_.beg, fb_.end, fb_.n) and torch.equal(fa.add_idx, fb_.add_idx)
+            assert (fa.graph_tiles is None) == (fb_.graph_tiles is None)
+            if fa.graph_tiles is not None:
+                for x, y in zip(fa.graph_tiles, fb_.graph_tiles):
+                    assert torch.equal(x[:fa.n], y[:fa.n])
+            assert (fa.sweep_tiles is None) == (fb_.sweep_tiles is None)
+            if fa.sweep_tiles is not None:
+                assert _tiles_per_workgroup(*fa.sweep_tiles) == _tiles_per_workgroup(*fb_.sweep_tiles)
+        ua, ub = a._units[d], b._units[d]
+        assert (ua.num_wg, ua.num_nodes, ua.num_tiles, ua.agg) == (ub.num_wg, ub.num_nodes, ub.num_tiles, ub.agg)
+        assert torch.equal(ua.unit_ptr, ub.unit_ptr)
+        n = int(ua.unit_ptr[-1])
+        xa, xb = ua.units[:n].cpu().numpy(), ub.units[:n].cpu().numpy()
+        assert np.array_equal(xa, xb)
+        pos = _entry_positions(xa)
+        for f in ("ent_row", "ent_mask"):
+            assert np.array_equal(getattr(ua, f).cpu().numpy()[pos], getattr(ub, f).cpu().numpy()[pos]), (d, f)
+
+
+@pytest.mark.parametrize("graphs", [1, 37, 300, 4096])
+def test_one_call_index_leaves_what_the_separate_builders_leave(graphs):
+    """config-5-shaped batches (every graph + its dummy node inside 32 nodes): everything is served by the one call -- 4,096 graphs
+    are enough rows for the sweep orders to be built too."""
+    from dummynode4graphlearning_amd import synthetic, transforms
+    raw = synthetic.config5(seed=graphs, graphs=graphs)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).cuda() for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N = int(aug["node_label"].numel())
+    a, b = _index_pair(aug["src"].cpu().numpy(), aug["dst"].cpu().numpy(), aug["edge_label"].cpu().numpy(), N, raw["num_rels"],
+                       aug["node_ptr"].cpu().numpy(), aug["edge_ptr"].cpu().numpy())
+    _same_closing(a, b, served=True if graphs > 1 else None)   # (one graph: every relation collapses, no single fold)
+    if graphs == 4096:
+        assert a._fold["f"].sweep_tiles is not None
+
+
+@pytest.mark.parametrize("case", ["large graphs", "no dummy", "random sizes", "over the LDS limit"])
+def test_one_call_index_where_it_cannot_serve(case):
+    """Batches the queued table builders are not sized for -- a graph over 32 nodes, no collapsed relation, a graph the local
+    builder rejects: the call must leave the row index (or hand over to the general builder) and touch nothing else; the tables
+    are then built on first use, as without the hint."""
+    rng = np.random.default_rng(77)
+    if case == "large graphs":
+        src, dst, et, nptr, eptr = _random_batch(rng, G=60, R=6, nmin=40, nmax=70, dens=2.0)
+    elif case == "no dummy":
+        src, dst, et, nptr, eptr = _random_batch(rng, G=200, R=6, nmin=3, nmax=20, dens=2.0, dummy=False)
+    elif case == "random sizes":
+        src, dst, et, nptr, eptr = _random_batch(rng, G=150, R=6, nmin=0, nmax=45, dens=3.0)
+    else:                                                             # one graph of 1,100 edges in front of 40 small ones: the local
+        src, dst, et, nptr, eptr = _random_batch(rng, G=40, R=6, nmin=3, nmax=20, dens=2.0)     # builder is tried and raises its flag
+        n0, m0 = 60, 1100
+        src = np.concatenate([rng.integers(0, n0, size=m0), src + n0])
+        dst = np.concatenate([rng.integers(0, n0, size=m0), dst + n0])
+        et = np.concatenate([rng.integers(0, 4, size=m0), et])
+        nptr, eptr = np.concatenate([[0], nptr + n0]), np.concatenate([[0], eptr + m0])
+    a, b = _index_pair(src, dst, et, int(nptr[-1]), 6, nptr, eptr)
+    if case == "over the LDS limit":
+        assert a.built_by == b.built_by == "general"
+    _same_closing(a, b, served=False)
+
+
+def test_layer_on_the_one_call_index_is_bitwise_the_layer_on_the_separate_builders():
+    from dummynode4graphlearning_amd import ops, synthetic, transforms
+    raw = synthetic.config5(seed=4, graphs=3000)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).cuda() for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R, H = int(aug["node_label"].numel()), raw["num_rels"], 256
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    W = (torch.randn(R, H, H, device="cuda", generator=gen) / 16).to(torch.bfloat16).requires_grad_(True)
+    Wl = (torch.randn(H, H, device="cuda", generator=gen) / 16).to(torch.bfloat16).requires_grad_(True)
+    bias = torch.randn(H, device="cuda", generator=gen).to(torch.bfloat16).requires_grad_(True)
+    x0 = torch.randn(N, H, device="cuda", generator=gen).to(torch.bfloat16)
+    gout = torch.randn(N, H, device="cuda", generator=gen).to(torch.bfloat16)
+    res = []
+    for hint in ((256, torch.bfloat16), None):
+        iset = ops.RowIndexSet(aug["src"], aug["dst"], aug["edge_label"], N, R, True, node_ptr=aug["node_ptr"],
+                               edge_ptr=aug["edge_ptr"], closing_hint=hint)
+        assert bool(iset.parts[0][2]._units) == (hint is not None)
+        x = x0.clone().requires_grad_(True)
+        out = ops.rel_transform_fused(x, W, bias, iset, W_loop=Wl)
+        gx, gW, gWl, gb = torch.autograd.grad(out, (x, W, Wl, bias), gout)
+        res.append((out.detach(), gx, gW, gWl, gb))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)

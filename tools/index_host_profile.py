@@ -22,7 +22,7 @@ et = g.edata["label"]
 
 def build():
     g._cache.clear()
-    ix = g.row_index(et, R, True)
+    ix = g.row_index(et, R, True, closing_hint=(H, dtype))
     if dtype == torch.bfloat16:
         for _, _, part in ix.parts:
             ops.prepare_closing(part, H, dtype)

@@ -12,7 +12,7 @@ etype = g.edata["label"]; R = {"config5": 16, "config3": 8}[w]
 for it in range(4):
     g._cache.clear(); torch.cuda.synchronize()
     marker = torch.zeros(7, device=dev) + 1          # marks the start of a build in the trace
-    ix = g.row_index(etype, R, True)
+    ix = g.row_index(etype, R, True, closing_hint=(256 if w == "config5" else 64, torch.bfloat16))
     for _, _, part in ix.parts:
         ops.prepare_closing(part, 256 if w == "config5" else 64, torch.bfloat16)       # what bench.py's index_build_ms covers
     torch.cuda.synchronize()
