@@ -30,6 +30,7 @@
 #include "dn_internal.h"
 #include "../../include/dn_hip.h"
 
+#include <cstddef>
 #include <cstring>
 #include <cstdlib>
 
@@ -138,7 +139,12 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
             if (lane < nn)
                 for (int i = my0; i < my1; ++i) L.node[i] = (uint8_t)lane;
         }
-        for (int i = lane; i < kCbSlots; i += 64) { L.key[i] = kEmpty; L.first[i] = kEmpty; L.mask[i] = 0u; }
+        {                                                                  // key / first = kEmpty, mask = 0: the three arrays lie back to back
+            static_assert(offsetof(CbLds, first) == 4 * kCbSlots && offsetof(CbLds, mask) == 8 * kCbSlots && kCbSlots % 4 == 0, "CbLds layout");
+            uint4* t4 = reinterpret_cast<uint4*>(L.key);
+            for (int i = lane; i < 3 * kCbSlots / 4; i += 64)
+                t4[i] = i < 2 * kCbSlots / 4 ? make_uint4(kEmpty, kEmpty, kEmpty, kEmpty) : make_uint4(0u, 0u, 0u, 0u);
+        }
         if (lane == 0) L.plain = 0;
         __builtin_amdgcn_wave_barrier();
         auto node_of = [&](int i) { return (int)L.node[i]; };
@@ -168,22 +174,24 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
         plain = L.plain != 0;
         if (!plain) {
             int n = 0;                                                     // emitted entries so far (wave-uniform)
+            bool repeats = false;                                          // some row has more than one entry (wave-uniform)
             for (int base = 0; base < raw; base += 64) {
                 const int i = base + lane;
-                bool emit = false;
+                bool emit = false, own = false;
                 int r = 0;
                 uint32_t m = 0;
                 if (i < raw) {
                     r = L.raw[i];
                     if (kept(r)) {
                         const int v = node_of(i);
-                        if (i > L.ptr[v] && L.raw[i - 1] == r) { emit = true; m = 1u << v; }
+                        if (i > L.ptr[v] && L.raw[i - 1] == r) { emit = true; own = true; m = 1u << v; }
                         else {
                             const uint32_t h = slot_of(r);
                             if (L.first[h] == (uint32_t)i) { emit = true; m = L.mask[h]; }
                         }
                     }
                 }
+                repeats = repeats || __ballot(own) != 0ull;
                 const unsigned long long b = __ballot(emit);
                 if (emit) {
                     const int at = n + __popcll(b & ((1ull << lane) - 1ull));
@@ -194,13 +202,21 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
             }
             if (lane < 4) L.srow[n + lane] = 0xffffffffu;                  // sentinels: the rank loop reads four rows at a time
             __builtin_amdgcn_wave_barrier();
+            // rank = entries with a lower row (+ the equal ones before me: only a row listed twice by one node has any).  The
+            // sentinels (0xffffffff) are never lower.
             for (int i = lane; i < n; i += 64) {
                 const uint32_t ri = L.srow[i];
                 int rank = 0;
                 for (int j = 0; j < n; j += 4) {
                     const uint4 q = *reinterpret_cast<const uint4*>(&L.srow[j]);
-                    rank += (q.x < ri || (q.x == ri && j < i)) + (q.y < ri || (q.y == ri && j + 1 < i)) +
-                            (q.z < ri || (q.z == ri && j + 2 < i)) + (q.w < ri || (q.w == ri && j + 3 < i));
+                    rank += (int)(q.x < ri) + (int)(q.y < ri) + (int)(q.z < ri) + (int)(q.w < ri);
+                }
+                if (repeats) {
+                    for (int j = 0; j < n; j += 4) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(&L.srow[j]);
+                        rank += (int)(q.x == ri && j < i) + (int)(q.y == ri && j + 1 < i) + (int)(q.z == ri && j + 2 < i) +
+                                (int)(q.w == ri && j + 3 < i);
+                    }
                 }
                 ent_row[lb + rank] = (int32_t)ri;
                 ent_mask[lb + rank] = L.smask[i];

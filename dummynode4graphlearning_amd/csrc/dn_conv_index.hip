@@ -81,18 +81,24 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
         const uint64_t no_mask[2] = {0, 0};
         const int32_t* dyn[2] = {plan + 8, plan + 10};
         int32_t* tables[2] = {sweep_f, sweep_b};
+        int32_t* info[2] = {meta + 5 + 2 * R + 4 + dn_internal::kRilPlanWords + 1, meta + 5 + 2 * R + 4 + dn_internal::kRilPlanWords + 3};
         rc = dn_internal::sweep_tables_queue((int32_t)R, rel_ptr_dev, row_in, row_out, N, sweep_wg_per_group, sweep_tiles_per_wg, 2,
-                                             no_mask, dyn, tables, nullptr, st);
+                                             no_mask, dyn, tables, info, st);
         if (rc != DN_OK) return rc;
     }
-    int32_t h_meta[5 + 2 * 64 + 4 + dn_internal::kRilPlanWords];
+    int32_t h_meta[5 + 2 * 64 + 4 + dn_internal::kRilPlanWords + 5];
     DN_REQUIRE(R <= 64, "dn_conv_index_build: more than 64 relations");
-    const size_t words = (size_t)(5 + 2 * R + 4 + dn_internal::kRilPlanWords);
+    const size_t words = (size_t)(5 + 2 * R + 4 + dn_internal::kRilPlanWords + 5);   // (+ the ticket and the sweep builder's 2 x 2 words)
     DN_CHECK_HIP(hipMemcpyAsync(h_meta, meta, sizeof(int32_t) * words, hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));                                   // the one read-back
     dn_internal::ril_unpack(h_meta, R, host_counts, host_rel_ptr, host_modes, host_status, host_absorb);
     const int32_t* hp = h_meta + 5 + 2 * R + 4;
-    host_plan[0] = hp[3]; host_plan[1] = hp[7]; host_plan[2] = 0; host_plan[3] = 0;
+    host_plan[0] = hp[3]; host_plan[1] = hp[7]; host_plan[2] = 0; host_plan[3] = 0; host_plan[4] = 0; host_plan[5] = 0;
+    if (sweep_tiles_per_wg > 0) {                                             // slots per workgroup of each order as the builder laid it out
+        const int32_t* si = hp + dn_internal::kRilPlanWords + 1;             // {0 sweep | 1 plain | 2 does not fit, slots of the fullest group} x 2
+        for (int d = 0; d < 2; ++d)
+            if (hp[3 + 4 * d]) host_plan[4 + d] = si[2 * d] == 0 ? (si[2 * d + 1] > 0 ? si[2 * d + 1] : 1) : (si[2 * d] == 1 ? sweep_tiles_per_wg : -1);
+    }
     if (*host_status != 0) return DN_OK;                                      // (the caller runs the general builder)
     // split-K chunk table of the weight gradient over ALL rows (the self loop as relation R): the smallest multiple of 64 rows
     // (>= 256) for which every relation's chunks -- each ends in a partial one -- fit one round of the workgroups

@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
     __shared__ int32_t crem[kSwGroups][kSwMaxRel + 1];            // prefix of the left-over tiles
     __shared__ int32_t Sx[kSwGroups], Wh[kSwGroups];
     __shared__ int32_t pp[kSwMaxRel + 1];                         // plain order: tiles before relation r
-    __shared__ int32_t s_plain;
+    __shared__ int32_t s_plain, s_stride;
     const int tid = threadIdx.x;
     auto key_of = [&](int32_t p) -> int32_t { const int32_t o = row_out[p]; return o < N ? o : row_in[p]; };
     for (int i = tid; i < (kSwGroups + 1) * R; i += blockDim.x) {
@@ -836,6 +836,9 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
     if (tid == 0) {
         int32_t smax = 0;
         for (int x = 0; x < kSwGroups; ++x) smax = max(smax, Sx[x]);
+        // queued behind the row index the table was sized by a bound of the rows (2x what they come to): its stride shrinks to the
+        // slots the fullest group needs -- empty slots cost the transform launch a ring stage each -- and info[1] tells the host
+        s_stride = (dyn != nullptr && smax <= S_cap) ? max(smax, 1) : S_cap;
         s_plain = smax > S_cap ? 1 : 0;                           // a group does not fit the table: plain order (valid as long as
         // the table holds all pp[R] tiles; info[0] = 2 reports a table that cannot even hold those -- rows would go untransformed)
         if (blockIdx.x == 0 && info) {
@@ -844,7 +847,8 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
         }
     }
     __syncthreads();
-    const int64_t total = (int64_t)kSwGroups * W * S_cap;
+    const int32_t stride = s_stride;
+    const int64_t total = (int64_t)kSwGroups * W * stride;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + tid; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int32_t rel = 0, beg = 0, end = 0;
         if (s_plain) {                                            // relation-major tiles, contiguous ranges per workgroup
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
                 end = min(beg + kSwTile, rel_ptr[rel + 1]);
             }
         } else {
-            const int32_t b = (int32_t)(e / S_cap), m = (int32_t)(e % S_cap);
+            const int32_t b = (int32_t)(e / stride), m = (int32_t)(e % stride);
             const int x = b % kSwGroups, j = b / kSwGroups;
             const int32_t S = Sx[x], np = pure0[x][R], RT = crem[x][R], wh = Wh[x];
             int r = -1;

@@ -746,7 +746,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
     w.hbits = (uint8_t*)take((size_t)E);
-    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4 + dn_internal::kRilPlanWords + 1));   // (+ the verdict launch's ticket)
+    w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4 + dn_internal::kRilPlanWords + 1 + 4));   // (+ the verdict launch's ticket, 2 x 2 words of the sweep builder)
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
                                 rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) {

@@ -1267,7 +1267,7 @@ class RowIndex:
                 sweeps = [torch.empty((Gw * S, 4), dtype=I32, device=dev) for _ in range(2)] if want_sweep else [None, None]
                 chunk_cap = (E + N) // 256 + R + 3
                 chunk_tab, chunk_pp = torch.empty((chunk_cap, 4), dtype=I32, device=dev), e32(R + 2)
-                host_plan = (ctypes.c_int32 * 4)()
+                host_plan = (ctypes.c_int32 * 6)()
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
                 check(lib().dn_conv_index_build_i32(
@@ -1282,7 +1282,10 @@ class RowIndex:
                 if status.value == 0:
                     self.built_by = "local"
                     self._absorb = {d: (gt_bufs[k][0], gt_bufs[k][1], int(host_absorb[k])) for k, d in enumerate(("f", "b"))}
-                    pre = (cus, sweeps, Gw * S, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]))
+                    # (the sweep tables were sized by a bound; the builder laid them out with the slots they need)
+                    sw = [(sweeps[k][:Gw * host_plan[4 + k]], Gw * int(host_plan[4 + k])) if want_sweep and host_plan[4 + k] > 0 else None
+                          for k in range(2)]
+                    pre = (cus, sw, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]))
             elif nbytes:
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
@@ -1336,15 +1339,15 @@ class RowIndex:
         # one workgroup per CU (the LDS-DMA ring fills a CU's LDS) for the split-K weight gradient whatever the batch size:
         # the smallest chunk that keeps ALL relations' chunks (each relation ends in a partial one) within one round of 256
         if pre is not None:
-            self.chunk_table = pre[3]
-            if pre[4] and pre[5]:                                    # both directions served: nothing is left for the first step
+            self.chunk_table = pre[2]
+            if pre[3] and pre[4]:                                    # both directions served: nothing is left for the first step
                 cands = {d: _fold_candidate(self, d) for d in ("f", "b")}
                 assert cands["f"] is not None and cands["b"] is not None and cands["f"][3] == cands["b"][3] == G
                 for k, d in enumerate(("f", "b")):
                     info = _make_fold_info(self, d, cands[d])
                     info.graph_tiles = (self._absorb[d][0], self._absorb[d][1])
                     if pre[1][k] is not None and _sweep_wanted(self):
-                        info.sweep_tiles = (pre[1][k], pre[2])
+                        info.sweep_tiles = pre[1][k]
                     self._fold[d] = info
                     self._units[d] = pre[0][k]
         else:

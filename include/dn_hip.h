@@ -276,14 +276,18 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
  *     tile_ptr_f / _b, agg_units = 1, the folded relation's rows dropped): unit_ptr_* [num_wg + 1], units_* [unit_capacity][4]
  *     (16-byte aligned; unit_capacity >= dn_close_units_capacity(G, E + N, num_wg)), ent_row_* / ent_mask_* [E + N];
  *   - the sweep orders of both transform launches with the folded relation skipped (dn_sweep_tables_build_i32):
- *     sweep_f / sweep_b [8 * sweep_wg_per_group * sweep_tiles_per_wg][4]; sweep_tiles_per_wg = 0: none;
+ *     sweep_f / sweep_b [8 * sweep_wg_per_group * sweep_tiles_per_wg][4] as CAPACITY (sized by E, a bound of the rows): the
+ *     builder lays each table out with the slots its fullest group needs, host_plan[4] / host_plan[5] (forward / backward) slots per
+ *     workgroup -- the table is [8 * sweep_wg_per_group * host_plan[4 + d]][4] -- or -1 when not even the plain order fits;
+ *     sweep_tiles_per_wg = 0: none;
  * the counts these builders need (edge rows, the folded relation and its row range) are read from device memory.  They serve ONE
  * case -- host_plan[0] (forward) / host_plan[1] (backward) != 0: the build is valid, the direction's fold can be absorbed
  * (host_absorb) and its segments are the batch's G graphs; for a direction with 0 its tables are left untouched and the caller
  * builds them with the separate entry points.  After the read-back the split-K chunk table of the weight gradient over all rows
  * (dn_row_tables_build_i32 with piece_ptr) is queued: host_plan[2] = rows per chunk -- the smallest multiple of 64 (>= 256, <=
  * wgrad_max_chunk_rows) for which the chunks of all relations fit one round of wgrad_workgroups -- host_plan[3] = its entries
- * (rows / chunk + relations + 1 <= chunk_capacity); chunk_table [chunk_capacity][4], chunk_ptr [R + 2].  *host_status != 0 as for
+ * (rows / chunk + relations + 1 <= chunk_capacity); chunk_table [chunk_capacity][4], chunk_ptr [R + 2]; host_plan: int32 [6].
+ * *host_status != 0 as for
  * dn_row_index_build_local_i32 (nothing else is valid).  workspace: 256-byte aligned.  Synchronises the stream once. */
 size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg);
 int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
