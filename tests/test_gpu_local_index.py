@@ -321,3 +321,21 @@ def test_layer_on_the_one_call_index_is_bitwise_the_layer_on_the_separate_builde
         res.append((out.detach(), gx, gW, gWl, gb))
     for u, v in zip(*res):
         assert torch.equal(u, v)
+
+
+def test_one_call_index_checks_its_workspace():
+    import ctypes
+    from dummynode4graphlearning_amd import _lib
+    L = _lib.lib()
+    G, N, R, E, wg = 4, 40, 6, 100, 256
+    need = L.dn_conv_index_workspace_bytes(G, N, R, E, wg)
+    assert need >= L.dn_row_index_local_workspace_bytes(G, N, R, E) + 2 * L.dn_close_units_workspace_bytes(G, wg)
+    cap = L.dn_close_units_capacity(G, E + N, wg)
+    counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * (R + 1))(), (ctypes.c_int32 * R)(), ctypes.c_int32(0)
+    absorb, plan = (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 6)()
+    P256 = ctypes.c_void_p(256)
+    for ws, nbytes, msg in ((P256, need - 1, b"workspace too small"), (ctypes.c_void_p(16), need, b"unaligned workspace")):
+        rc = L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), counts, rel, modes,
+                                       ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, cap, *([P256] * 8), 32, 8, P256, P256,
+                                       256, 4096, 64, P256, P256, plan, ws, nbytes, None)
+        assert rc == -1 and msg in L.dn_last_error(), L.dn_last_error()
