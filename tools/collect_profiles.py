@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "profiles"))
     ap.add_argument("--skip-lds", action="store_true")
+    ap.add_argument("--skip-others", action="store_true", help="config 5 only (no config-3 / PROTEINS / config-4 passes)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     tmp = os.path.join("/tmp", "dn_prof_" + a.tag)
@@ -233,6 +234,50 @@ def main():
             for k in sorted(agg):
                 c, act = agg[k]
                 f.write("%s,%d,%d,%.3f\n" % (k, c, act, c / act if act else 0.0))
+
+    # 6. the other configurations bench.py knows (the driver times config 5 alone): kernel statistics of the replayed step and LDS
+    #    conflicts of an eager run -- config 3 (the SI defaults' size: H = 64, 512 graphs of ~50 nodes) in bf16 and fp32, the
+    #    PROTEINS-shaped RGIN workload (H = 256, graphs over 32 nodes: the non-absorbed fold), config 4 (GC model step)
+    if not a.skip_others:
+        for name, extra in (("config3_bf16", ["--workload", "config3", "--dtype", "bf16"]), ("config3_f32", ["--workload", "config3"]),
+                            ("proteins", ["--workload", "proteins"]), ("config4", ["--workload", "config4"])):
+            d = os.path.join(tmp, "stats_" + name)
+            cmd = ["python3", bench] + extra + ["--steps", "20", "--warmup", "5", "--steady", "--no-cpu-baseline"]
+            r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "k", "--"] + cmd, cwd="/tmp")
+            try:
+                with open(one_csv(d, "kernel_stats.csv")) as f:
+                    body = f.read()
+            except SystemExit:
+                print("no kernel stats for", name, r.stderr[-500:])
+                continue
+            with open(os.path.join(a.out, "%s_%s_kernel_stats.csv" % (a.tag, name)), "w") as f:
+                f.write("# %s -- rocprofv3 --kernel-trace --stats --output-format csv -- %s\n" % (a.tag, " ".join(["python3", "bench.py"] + cmd[2:])))
+                f.write("# (whole process: batch and index build, warm-up, 20 timed replays of the captured step)\n")
+                f.write("# bench line of that run: %s\n" % (r.stdout.strip().splitlines()[-1][:600] if r.stdout.strip() else "n/a"))
+                f.write(body)
+            if a.skip_lds or name == "config4":
+                continue
+            d = os.path.join(tmp, "lds_" + name)
+            run(["rocprofv3", "--kernel-trace", "--pmc", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "--output-format", "csv", "-d", d,
+                 "-o", "p", "--", "python3", bench] + extra + ["--steps", "3", "--warmup", "1", "--steady", "--no-graph", "--no-cpu-baseline"],
+                cwd="/tmp")
+            agg = {}
+            try:
+                rows = counter_rows(one_csv(d, "counter_collection.csv"))
+            except SystemExit:
+                continue
+            for kname, ctrs, _, _ in rows:
+                k = kname.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+                e = agg.setdefault(k, [0.0, 0.0])
+                e[0] += ctrs.get("SQ_LDS_BANK_CONFLICT", 0.0)
+                e[1] += ctrs.get("SQ_LDS_IDX_ACTIVE", 0.0)
+            with open(os.path.join(a.out, "%s_%s_lds_bank_conflicts.csv" % (a.tag, name)), "w") as f:
+                f.write("# %s -- LDS bank conflicts of an eager run of bench.py %s (rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE), all launches incl. the index build\n" % (a.tag, " ".join(extra)))
+                f.write("kernel,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,conflict_fraction\n")
+                for k in sorted(agg):
+                    c, act = agg[k]
+                    if act > 0:
+                        f.write("%s,%d,%d,%.3f\n" % (k, c, act, c / act))
 
     # 1. the bench line itself, last, with the fresh traffic.json in place (bench.py reads profiles/<tag>_traffic.json)
     import shutil
