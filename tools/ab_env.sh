@@ -12,8 +12,8 @@ for v in "${VALS[@]}"; do
 import sys, json
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]; c = d["config"]
-print(sys.argv[2], "ms/step %.3f  frac %.4f  conv_ms %.3f  index %.3f  shard %.4f  shard index %.3f" % (
+print(sys.argv[2], "ms/step %.3f  frac %.4f  conv_ms %.3f  index %.3f  shard %.4f  shard index %.3f  fresh-batch overlapped %.3f ms" % (
     d["ms_per_step"], r["frac"], r["kernel_ms_per_step"], c["index_build_ms"], c["strong_scaling_proxy"]["shard_ms_per_step"],
-    c["strong_scaling_proxy"]["shard_index_build_ms"]))
+    c["strong_scaling_proxy"]["shard_index_build_ms"], c.get("fresh_batch_overlapped_ms_per_step") or 0))
 PY
 done
