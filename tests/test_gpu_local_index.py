@@ -339,3 +339,39 @@ def test_one_call_index_checks_its_workspace():
                                        ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, cap, *([P256] * 8), 32, 8, P256, P256,
                                        256, 4096, 64, P256, P256, plan, ws, nbytes, None)
         assert rc == -1 and msg in L.dn_last_error(), L.dn_last_error()
+
+
+def test_layer_asks_for_the_one_call_index():
+    """An H = 256 bf16 RGINLayer on a fresh BatchedGraph: the layer's closing hint makes the batch's index ONE library call -- none of
+    the separate table builders runs during the step."""
+    from dummynode4graphlearning_amd import BatchedGraph, _lib, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config5(seed=12, graphs=500)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).cuda() for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R, H = int(aug["node_label"].numel()), raw["num_rels"], 256
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+    torch.manual_seed(0)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").cuda().to(torch.bfloat16)
+    x = torch.randn(N, H, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    L = _lib.lib()
+    calls = {}
+    names = ("dn_conv_index_build_i32", "dn_row_index_build_local_i32", "dn_row_index_build_i32", "dn_close_units_build_i32",
+             "dn_sweep_tables_build_i32", "dn_fold_graph_tiles_build_i32", "dn_fold_tables_build_async_i32", "dn_slot_table_build_i32")
+    saved = {n: getattr(L, n) for n in names}
+    try:
+        for n in names:
+            def spy(*a, _n=n):
+                calls[_n] = calls.get(_n, 0) + 1
+                return saved[_n](*a)
+            setattr(L, n, spy)
+        out, _ = layer(g, x, aug["edge_label"].long())
+        out.backward(torch.ones_like(out))
+    finally:
+        for n in names:
+            setattr(L, n, saved[n])
+    assert calls == {"dn_conv_index_build_i32": 1}, calls
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(x.grad.float()).all())
