@@ -50,6 +50,23 @@ struct Unit {
 };                                     // AGG unit: the workgroup's tiles number [beg, end) (their segments' aux rows); NOP: nothing
 // flags: bit 0 entry unit, bit 1 last unit of its tile (epilogue), bit 2 AGG unit, bit 3 NOP unit, bits 8-15 rows of the tile
 constexpr int kUnitEntry = 1, kUnitLast = 2, kUnitAgg = 4, kUnitNop = 8;
+constexpr int kUnitXcd = 16;           // on an AGG unit: the workgroup's tiles follow the XCD order below (aux = the number of tiles)
+
+// Which tile is the n-th of workgroup w (of G)?
+//   order 0: w + G n -- the launch walks the batch upwards as ONE front;
+//   order 1 (G a multiple of 8): workgroup w = 8 j + x runs on XCD x (round-robin dispatch) and takes the tiles of the x-th EIGHTH of
+//   the batch, DOWNWARDS from its end: hi_x - 1 - (j + G/8 n).  The transform launch in front of this one walks the eighth of XCD x
+//   upwards (sweep order, dn_sweep_tables_build_i32), so the closing launch starts on the rows the transform wrote and gathered LAST
+//   -- still in that XCD's L2 and in the Infinity Cache (measured: transform + closing launch 743-746 -> 728-729 us at config 5).
+__host__ __device__ __forceinline__ int32_t cb_eighth(int x, int32_t T) { return (int32_t)(((int64_t)x * T) / 8); }
+__device__ __forceinline__ void cb_position(int32_t t, int32_t T, int32_t G, int32_t order, int32_t& w, int32_t& n, bool& last) {
+    if (!order) { w = t % G; n = t / G; last = (int64_t)t + G >= T; return; }
+    int x = (int)(((int64_t)t * 8) / T);
+    while (x < 7 && cb_eighth(x + 1, T) <= t) ++x;
+    const int32_t W8 = G >> 3, lo = cb_eighth(x, T), hi = cb_eighth(x + 1, T), r = hi - 1 - t;
+    w = 8 * (r % W8) + x; n = r / W8;
+    last = r + W8 >= hi - lo;
+}
 constexpr int kAggGap = 8;             // NOP units between a workgroup's last tile and its first AGG unit (>= the loaders' run-ahead)
 
 // ---------------------------------------------------------------------------------------------------------------- tables
@@ -102,7 +119,7 @@ struct CbPair {
     CbDir d[2];
 };
 
-__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, CbPair pr) {
+__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order, CbPair pr) {
     __shared__ __attribute__((aligned(16))) CbLds Ls[kCbWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (int)blockIdx.x * kCbWaves + wave;
@@ -126,9 +143,12 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     const int pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N), nn = pend - p0;   // (a tile never has more than 32 nodes)
     const int lb = lptr[p0], raw = lptr[pend] - lb;
     auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
-    // units of this tile in the workgroup-major table: one X unit + one per 32 entries; a workgroup's LAST tile (t + G >= T) also
-    // carries the workgroup's NOP gap and AGG units (one per 32 of its t / G + 1 tiles)
-    auto units_of = [&](int c) { return 1 + (c + 31) / 32 + ((agg && t + G >= T) ? kAggGap + (t / G + 1 + 31) / 32 : 0); };
+    // units of this tile in the workgroup-major table: one X unit + one per 32 entries; a workgroup's LAST tile also carries the
+    // workgroup's NOP gap and AGG units (one per 32 of its pn + 1 tiles)
+    int32_t pw, pn;
+    bool plast;
+    cb_position(t, T, G, order, pw, pn, plast);
+    auto units_of = [&](int c) { return 1 + (c + 31) / 32 + ((agg && plast) ? kAggGap + (pn + 1 + 31) / 32 : 0); };
     bool plain = raw > kCbCap;
     if (!plain) {
         const int my0 = lane <= nn ? lptr[p0 + lane] - lb : raw;
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
                 ent_row[lb + rank] = (int32_t)ri;
                 ent_mask[lb + rank] = L.smask[i];
             }
-            if (lane == 0) { tile_cnt[t] = n; ucnt[(int64_t)(t % G) * Tper + t / G] = units_of(n); }
+            if (lane == 0) { tile_cnt[t] = n; ucnt[(int64_t)pw * Tper + pn] = units_of(n); }
             return;
         }
     }
@@ -237,13 +257,13 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
         if (!kept(r)) continue;
         ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
     }
-    if (lane == 0) { tile_cnt[t] = total; ucnt[(int64_t)(t % G) * Tper + t / G] = units_of(total); }
+    if (lane == 0) { tile_cnt[t] = total; ucnt[(int64_t)pw * Tper + pn] = units_of(total); }
 }
 
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
-// as one stream); position k' = w * Tper + n holds tile n * G + w.  The entries kernel leaves each tile's unit count there, one
+// as one stream; order 1: see cb_position); position k' = w * Tper + n holds the n-th tile of workgroup w.  The entries kernel leaves each tile's unit count there, one
 // exclusive scan (rocPRIM) gives the offsets.
-__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, CbPair pr) {
+__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order, CbPair pr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const CbDir& a = pr.d[blockIdx.y];
     if (a.dyn != nullptr && a.dyn[3] == 0) return;
@@ -255,7 +275,10 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
     const int32_t base = uoff[0];                                          // (both directions share one scan: the second starts at the first's total)
     if (t <= G) a.unit_ptr[t] = uoff[t * Tper] - base;                     // (position G * Tper holds the total)
     if (t >= T) return;
-    const int64_t w = t % G, n = t / G, k = w * Tper + n;
+    int32_t w, n;
+    bool plast;
+    cb_position((int32_t)t, T, G, order, w, n, plast);
+    const int64_t k = (int64_t)w * Tper + n;
     const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
     const int32_t pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N);
     const int32_t c = tile_cnt[t], e0 = lptr[p0], rows = (pend - p0) << 8;
@@ -264,12 +287,12 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
     u[0] = Unit{(ne == 0 ? kUnitLast : 0) | rows, p0, pend, (int32_t)t};
     for (int i = 0; i < ne; ++i)
         u[1 + i] = Unit{kUnitEntry | (i == ne - 1 ? kUnitLast : 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), c), p0};
-    if (agg && t + G >= T) {                                               // the workgroup's last tile: its NOP gap and AGG units
+    if (agg && plast) {                                                    // the workgroup's last tile: its NOP gap and AGG units
         const int32_t nw = (int32_t)n + 1;
         Unit* q = u + 1 + ne;
         for (int i = 0; i < kAggGap; ++i) q[i] = Unit{kUnitNop, 0, 1, 0};
         q += kAggGap;
-        for (int i = 0; 32 * i < nw; ++i) q[i] = Unit{kUnitAgg | kUnitLast, 32 * i, min(32 * (i + 1), nw), 0};
+        for (int i = 0; 32 * i < nw; ++i) q[i] = Unit{kUnitAgg | kUnitLast | (order ? kUnitXcd : 0), 32 * i, min(32 * (i + 1), nw), order ? T : 0};
     }
 }
 
@@ -377,7 +400,8 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T0 % kIdxRing) * (4u * kRowsPerLoader)));
             if (fl & kUnitEntry) glds4(ent_row + pc, dst);                 // lane l lands at + 4 l: [unit][8 rows]
             else if (FOLD == 2 && (fl & kUnitAgg))                         // the aux row of my pc-th tile (= its segment)
-                idxR[q][T % kIdxRing][lane & 7] = wg + nwg * pc;
+                idxR[q][T % kIdxRing][lane & 7] =
+                    (fl & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * rp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * pc : wg + nwg * pc;
             else idxR[q][T % kIdxRing][lane & 7] = (fl & kUnitNop) ? 0 : pc;   // an X unit's rows are its nodes
             // membership masks of units T0 + 2 q, T0 + 2 q + 1, in the k order of the transposed reads:
             // position k = 8 g + 4 jh + qq  <->  row g + 16 jh + 4 qq of the unit
@@ -390,7 +414,9 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 const void* msrc = ok ? (const void*)(ent_mask + e) : (const void*)(g_close_zero + kk);
                 if constexpr (FOLD == 2) {                                 // an AGG unit's "masks" are the output rows of its 32 products
                     const int ord = mp[1] + kk;
-                    if ((mp[0] & kUnitAgg) && ord < mp[2]) msrc = agg_idx + (wg + nwg * ord);
+                    if ((mp[0] & kUnitAgg) && ord < mp[2])
+                        msrc = agg_idx + ((mp[0] & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * mp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * ord
+                                                             : wg + nwg * ord);
                 }
                 const unsigned mdst =
                     (unsigned)__builtin_amdgcn_readfirstlane((int)(mask_base + (unsigned)((T0 + 2 * q) % kMaskRing) * 128u));
@@ -769,10 +795,12 @@ namespace dn_internal {
 // direction).  dirs[k].dyn != NULL: {edge rows, dropped range, go} are read on the device (ril_plan_kernel's words) instead of
 // num_edge_rows / drop_beg / drop_end -- the launches are queued before the host knows them.  workspace: nd times
 // dn_close_units_workspace_bytes.
-int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int64_t num_list_entries, int64_t unit_capacity,
-                      int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
+                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 && num_tiles >= 0 &&
                num_tiles < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_close_units_build: bad sizes");
+    DN_REQUIRE(xcd_order == 0 || (xcd_order == 1 && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
+               "dn_close_units_build: the XCD order needs a multiple of 8 workgroups");
     for (int k = 0; k < nd; ++k) {
         DN_REQUIRE(dirs[k].num_edge_rows >= 0, "dn_close_units_build: bad sizes");
         DN_REQUIRE(dirs[k].tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the "
@@ -815,12 +843,12 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
                         d.drop_end};
     }
     hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves), (unsigned)nd), dim3(kCbWaves * 64), 0, st, (int32_t)N, T,
-                       num_wg, Tper, agg_units ? 1 : 0, pr);
+                       num_wg, Tper, agg_units ? 1 : 0, xcd_order, pr);
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(rocprim::exclusive_scan(wsp, tb, ucnt, uoff, (int32_t)0, ne, rocprim::plus<int32_t>(), st));
     const int64_t nthreads = T > num_wg + 1 ? T : num_wg + 1;
     hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(nthreads, 256), (unsigned)nd), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper,
-                       agg_units ? 1 : 0, pr);
+                       agg_units ? 1 : 0, xcd_order, pr);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -843,13 +871,13 @@ size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
 }
 
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
-                             int32_t agg_units, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
+                             int32_t agg_units, int32_t xcd_order, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
                              int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream) {
     const dn_internal::CloseUnitsDir d{tile_ptr, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, drop_enable, nullptr, unit_ptr,
                                        units, ent_row, ent_mask};
-    return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, num_list_entries, unit_capacity, 1, &d, workspace,
+    return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, xcd_order, num_list_entries, unit_capacity, 1, &d, workspace,
                                           workspace_bytes, (hipStream_t)stream);
 }
 

@@ -42,7 +42,7 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
                             int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
                             int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
                             int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
-                            int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int64_t unit_capacity, int32_t* unit_ptr_f,
+                            int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int32_t close_xcd_order, int64_t unit_capacity, int32_t* unit_ptr_f,
                             int32_t* units_f, int32_t* ent_row_f, uint32_t* ent_mask_f, int32_t* unit_ptr_b, int32_t* units_b,
                             int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t sweep_wg_per_group, int32_t sweep_tiles_per_wg,
                             int32_t* sweep_f, int32_t* sweep_b, int32_t wgrad_workgroups, int32_t wgrad_max_chunk_rows,
@@ -75,7 +75,7 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
     const dn_internal::CloseUnitsDir dirs[2] = {
         {tile_ptr_f, dst_ptr, dst_rows, 0, 0, 0, nullptr, plan, unit_ptr_f, units_f, ent_row_f, ent_mask_f},
         {tile_ptr_b, src_ptr, src_rows, 0, 0, 0, nullptr, plan + 4, unit_ptr_b, units_b, ent_row_b, ent_mask_b}};
-    rc = dn_internal::close_units_queue(N, num_wg, G, 1, E + N, unit_capacity, 2, dirs, ws_close, 2 * dn_align_up(a.close, 256), st);
+    rc = dn_internal::close_units_queue(N, num_wg, G, 1, close_xcd_order, E + N, unit_capacity, 2, dirs, ws_close, 2 * dn_align_up(a.close, 256), st);
     if (rc != DN_OK) return rc;
     if (sweep_tiles_per_wg > 0) {                                             // and both sweep orders in one launch
         const uint64_t no_mask[2] = {0, 0};

@@ -48,8 +48,8 @@ struct CloseUnitsDir {                 // one direction's arguments of dn_close_
     int32_t *unit_ptr, *units, *ent_row;
     uint32_t* ent_mask;
 };
-int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int64_t num_list_entries, int64_t unit_capacity,
-                      int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st);
+int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
+                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // dn_index.hip
 int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out, int64_t num_nodes,

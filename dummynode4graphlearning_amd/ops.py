@@ -540,7 +540,16 @@ CLOSE_RING_ENABLED = _os.environ.get("DN_CLOSE_RING", "1") != "0"
 
 class CloseUnits:
     """Tables of dn_rows_close_bf16 for one direction of a RowIndex (dn_close_units_build_i32)."""
-    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes", "num_tiles", "agg")
+    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes", "num_tiles", "agg", "order")
+
+
+# DN_CLOSE_ORDER=0: the closing launch walks the batch upwards as one front (workgroup w: tiles w, w + G, ...) instead of every XCD
+# walking its eighth of the batch downwards -- towards the rows the transform launch in front of it handled last
+CLOSE_XCD_ORDER = _os.environ.get("DN_CLOSE_ORDER", "1") != "0"
+
+
+def _close_order(num_wg):
+    return 1 if (CLOSE_XCD_ORDER and num_wg % 8 == 0) else 0
 
 
 def _num_cus(dev):
@@ -566,10 +575,12 @@ def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
 
 
 def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None, tile_ptr=None,
-                      agg=False):
+                      agg=False, order=None):
     """Per tile (32-node windows, or the node ranges tile_ptr gives) the distinct kept rows of its nodes' lists + membership
     masks, and the per-workgroup unit records the closing launch streams (three launches, no read-back).  Same filter as
-    build_slot_table.  agg: append every workgroup's AGG units (the absorbed fold, tile_ptr from build_graph_tiles)."""
+    build_slot_table.  agg: append every workgroup's AGG units (the absorbed fold, tile_ptr from build_graph_tiles).  order: 0 =
+    workgroup w takes tiles w, w + G, ...; 1 = every XCD walks its eighth of the batch downwards (include/dn_hip.h); None = 1 when
+    the number of workgroups allows it."""
     require_gpu(list_ptr, list_rows, tile_ptr)
     dev = list_rows.device
     N, P, L = int(num_nodes), int(num_edge_rows), int(list_rows.numel())
@@ -577,6 +588,7 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     cu = CloseUnits()
     cu.num_wg = int(num_wg) if num_wg else _num_cus(dev)
     cu.num_nodes, cu.agg = N, bool(agg)
+    cu.order = _close_order(cu.num_wg) if order is None else int(order)
     cu.num_tiles = T = (int(tile_ptr.numel()) - 1) if tile_ptr is not None else (N + 31) // 32
     assert not agg or tile_ptr is not None
     cap = int(lib().dn_close_units_capacity(T, L, cu.num_wg))
@@ -585,7 +597,7 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     cu.ent_row = torch.empty(max(L, 1), dtype=I32, device=dev)
     cu.ent_mask = torch.empty(max(L, 1), dtype=I32, device=dev)
     ws = _ws(lib().dn_close_units_workspace_bytes(T, cu.num_wg), dev)
-    check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(tile_ptr), T, 1 if agg else 0, ptr(list_ptr), ptr(list_rows), L,
+    check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(tile_ptr), T, 1 if agg else 0, cu.order, ptr(list_ptr), ptr(list_rows), L,
                                          int(drop[0]), int(drop[1]), ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap,
                                          ptr(cu.ent_row), ptr(cu.ent_mask), ptr(ws), ws.numel(), stream_ptr()),
           "dn_close_units_build_i32")
@@ -1257,7 +1269,7 @@ class RowIndex:
                 cus = []
                 for _ in range(2):
                     cu = CloseUnits()
-                    cu.num_wg, cu.num_nodes, cu.agg, cu.num_tiles = num_wg, N, True, G
+                    cu.num_wg, cu.num_nodes, cu.agg, cu.num_tiles, cu.order = num_wg, N, True, G, _close_order(num_wg)
                     cu.unit_ptr, cu.units = e32(num_wg + 1), torch.empty((cap, 4), dtype=I32, device=dev)
                     cu.ent_row, cu.ent_mask = e32(E + N), e32(E + N)
                     cus.append(cu)
@@ -1274,7 +1286,7 @@ class RowIndex:
                     G, N, R, E, ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype), 1, float(edge_frac), ptr(row_in),
                     ptr(row_out), ptr(aux_f_ptr), ptr(aux_f_idx), ptr(aux_b_ptr), ptr(aux_b_idx), ptr(dst_ptr), ptr(dst_rows),
                     ptr(src_ptr), ptr(src_rows), counts, host_rel, host_modes, ctypes.byref(status), ptr(rel_dev), ptr(gt_bufs[0][0]),
-                    ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cap, ptr(cus[0].unit_ptr),
+                    ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cus[0].order, cap, ptr(cus[0].unit_ptr),
                     ptr(cus[0].units), ptr(cus[0].ent_row), ptr(cus[0].ent_mask), ptr(cus[1].unit_ptr), ptr(cus[1].units),
                     ptr(cus[1].ent_row), ptr(cus[1].ent_mask), SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
                     WGRAD_CHUNK_ROWS, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),

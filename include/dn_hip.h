@@ -273,7 +273,7 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
  * in the reference (subgraph_isomorphism/dataset.py:1605-1611; models/rgin.py:156-160): dn_row_index_build_local_i32 (same
  * arguments and outputs, rel_ptr_dev and the absorbed-fold buffers required) and, queued behind it BEFORE the one read-back,
  *   - the unit streams of both closing launches with the graphs as tiles and the AGG units appended (dn_close_units_build_i32 with
- *     tile_ptr_f / _b, agg_units = 1, the folded relation's rows dropped): unit_ptr_* [num_wg + 1], units_* [unit_capacity][4]
+ *     tile_ptr_f / _b, agg_units = 1, xcd_order = close_xcd_order, the folded relation's rows dropped): unit_ptr_* [num_wg + 1], units_* [unit_capacity][4]
  *     (16-byte aligned; unit_capacity >= dn_close_units_capacity(G, E + N, num_wg)), ent_row_* / ent_mask_* [E + N];
  *   - the sweep orders of both transform launches with the folded relation skipped (dn_sweep_tables_build_i32):
  *     sweep_f / sweep_b [8 * sweep_wg_per_group * sweep_tiles_per_wg][4] as CAPACITY (sized by E, a bound of the rows): the
@@ -296,7 +296,7 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
                             int32_t* aux_b_idx, int32_t* dst_ptr, int32_t* dst_rows, int32_t* src_ptr, int32_t* src_rows,
                             int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes, int32_t* host_status,
                             int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
-                            int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int64_t unit_capacity, int32_t* unit_ptr_f,
+                            int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int32_t close_xcd_order, int64_t unit_capacity, int32_t* unit_ptr_f,
                             int32_t* units_f, int32_t* ent_row_f, uint32_t* ent_mask_f, int32_t* unit_ptr_b, int32_t* units_b,
                             int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t sweep_wg_per_group, int32_t sweep_tiles_per_wg,
                             int32_t* sweep_f, int32_t* sweep_b, int32_t wgrad_workgroups, int32_t wgrad_max_chunk_rows,
@@ -440,11 +440,17 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * list_rows as in dn_slot_table_build_i32, same num_edge_rows / drop range / drop_enable filter), sorted by row, are written to
  * ent_row with a 32-bit membership mask in ent_mask (bit i: node tile_ptr[t] + i adds the row; a row that ONE node lists twice
  * stays a second entry), from the offset list_ptr[tile_ptr[t]] onwards -- so ent_row / ent_mask need num_list_entries elements.
- * units [unit_capacity][4] int32 records {flags, beg, end, aux} in WORKGROUP-MAJOR order (workgroup w of num_wg takes tiles w,
- * w + num_wg, ...; its records are units[unit_ptr[w] .. unit_ptr[w+1])): per tile one X record {rows << 8 | 2 if no entries,
+ * units [unit_capacity][4] int32 records {flags, beg, end, aux} in WORKGROUP-MAJOR order (its records are
+ * units[unit_ptr[w] .. unit_ptr[w+1])).  xcd_order = 0: workgroup w of num_wg takes tiles w, w + num_wg, ... (one front walking the
+ * batch upwards); xcd_order = 1 (round 5; num_wg a multiple of 8): workgroup w = 8 j + x -- dispatched to XCD x -- takes the tiles
+ * of the x-th EIGHTH of the batch, [floor(x T / 8), floor((x + 1) T / 8)), DOWNWARDS from its end: end - 1 - (j + (num_wg / 8) n).
+ * The transform launch in front of the closing launch walks the eighth of XCD x upwards (dn_sweep_tables_build_i32), so the closing
+ * launch begins on the rows the transform wrote and gathered last (that XCD's L2, the Infinity Cache): -2 % on the pair at config 5.
+ * Per tile one X record {rows << 8 | 2 if no entries,
  * first node, end node, tile} followed by one record per 32 entries {rows << 8 | 1 | 2 on the last, first entry, end entry, first
  * node}; with agg_units != 0 a workgroup's tiles are followed by 8 records {8, 0, 1, 0} (a gap) and one record {4 | 2, n, n', 0}
- * per 32 of its tiles (the n-th .. n'-th of them): the AGG units of the absorbed fold below.
+ * ({4 | 2 | 16, n, n', num_tiles} with xcd_order = 1) per 32 of its tiles (the n-th .. n'-th of them): the AGG units of the absorbed
+ * fold below.
  * unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg).
  *
  * dn_fold_graph_tiles_build_i32 (one launch): the tiles of a batch of GRAPHS for the absorbed fold.  Segment j = the nodes
@@ -469,7 +475,7 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg);
 size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg);
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
-                             int32_t agg_units, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
+                             int32_t agg_units, int32_t xcd_order, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
                              int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream);

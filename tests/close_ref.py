@@ -38,8 +38,18 @@ def graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=None):
     return True, tile_ptr, info
 
 
-def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False):
+def tiles_of_workgroup(w, T, G, order):
+    """the tiles of workgroup w, in the order it takes them (include/dn_hip.h: xcd_order)"""
+    if not order:
+        return list(range(w, T, G))
+    x, j, W8 = w % 8, w // 8, G // 8
+    lo, hi = x * T // 8, (x + 1) * T // 8
+    return list(range(hi - 1 - j, lo - 1, -W8))
+
+
+def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False, order=0):
     """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])})."""
+    xcd_order = int(order)                             # (`order` is reused below for a sort permutation)
     lp, lr = np.asarray(list_ptr, dtype=np.int64), np.asarray(list_rows, dtype=np.int64)
     T = (N + 31) // 32 if tile_ptr is None else len(tile_ptr) - 1
     tp = np.minimum(np.arange(T + 1) * 32, N) if tile_ptr is None else np.asarray(tile_ptr, dtype=np.int64)
@@ -73,14 +83,10 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, ag
             order = sorted(range(len(ent_r)), key=lambda k: (ent_r[k], k))
             ent_r, ent_m = [ent_r[k] for k in order], [ent_m[k] for k in order]
         tiles[t] = (int(lp[p0]), ent_r, ent_m)
-    Tper = (T + G - 1) // G if T else 0
     unit_ptr, units = [0], []
     for w in range(G):
         nw = 0
-        for n in range(Tper):
-            t = n * G + w
-            if t >= T:
-                continue
+        for t in tiles_of_workgroup(w, T, G, xcd_order):
             nw += 1
             e0, ent_r, _ = tiles[t]
             c, p0, pend = len(ent_r), int(tp[t]), int(min(tp[t + 1], tp[t] + 32))
@@ -90,6 +96,6 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, ag
                 units.append([1 | (2 if i == ne - 1 else 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), c), p0])
         if agg and nw:
             units += [[8, 0, 1, 0]] * AGG_GAP
-            units += [[4 | 2, 32 * i, min(32 * (i + 1), nw), 0] for i in range((nw + 31) // 32)]
+            units += [[4 | 2 | (16 if xcd_order else 0), 32 * i, min(32 * (i + 1), nw), T if xcd_order else 0] for i in range((nw + 31) // 32)]
         unit_ptr.append(len(units))
     return np.array(unit_ptr, dtype=np.int64), np.array(units, dtype=np.int64).reshape(-1, 4), tiles

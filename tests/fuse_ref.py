@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 U_ENTRY, U_LAST, U_AGG, U_NOP, U_T, U_PUB, U_GATE = 1, 2, 4, 8, 16, 32, 64
+AGG_GAP = 8                                          # kAggGap (csrc/dn_close.hip, dn_fuse.hip)
 
 
 def relation_workgroups(tiles_per_rel, G):
@@ -104,8 +105,10 @@ def build(ix, direction, ops, chunk_tiles=1024, lead=2, only=None, gates=True):
                         first = False
                     recs += [tuple(int(v) for v in row) for row in tu]
                     n_c += len(tu)
-        if only != "T":
-            recs += [tuple(int(v) for v in row) for row in tails[w]]
+        if only != "T":                                  # the workgroup's gap + AGG units for ITS tiles (w, w + G, ...: dn_rows_fused_bf16's own rule)
+            nw = len(range(w, T, G))
+            if nw:
+                recs += [(U_NOP, 0, 1, 0)] * AGG_GAP + [(U_AGG | U_LAST, 32 * i, min(32 * (i + 1), nw), 0) for i in range((nw + 31) // 32)]
         out += recs
         ptr.append(len(out))
     arr = np.asarray(out, dtype=np.int64)

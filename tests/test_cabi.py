@@ -79,12 +79,15 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 0, *([None] * 7)) == 0
     assert L.dn_close_units_capacity(2, 320, 4) == 2 * 2 + 10 + 1 + 4 * 9 + 0
     assert L.dn_close_units_workspace_bytes(2, 4) > 0
-    rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 0, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0,
+    rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 0, 0, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0,
                                     None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    rc = L.dn_close_units_build_i32(100, 5, 4, None, 1, 0, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0,
+    rc = L.dn_close_units_build_i32(100, 5, 4, None, 1, 0, 0, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0,
                                     None)
     assert rc == -1 and b"32-node windows" in L.dn_last_error()
+    rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 0, 1, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, 0,
+                                    None)
+    assert rc == -1 and b"multiple of 8 workgroups" in L.dn_last_error()
     ok = ctypes.c_int32(0)
     rc = L.dn_fold_graph_tiles_build_i32(10, 2, None, None, None, None, None, ctypes.c_void_p(16), None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
@@ -153,7 +156,7 @@ def test_conv_index_entry_point_checks_its_arguments(lib):
 
     def call(G=G, host=counts, units=P256, cap=cap, sweep_s=8, sweep=P256, wgrad_rows=4096):
         return L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), host, rel, modes,
-                                         ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, cap, P256, units, P256, P256,
+                                         ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, 1, cap, P256, units, P256, P256,
                                          P256, P256, P256, P256, 32, sweep_s, sweep, sweep, 256, wgrad_rows, 64, P256, P256, plan, P256,
                                          1 << 30, None)
 

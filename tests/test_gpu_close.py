@@ -33,16 +33,17 @@ def _lists(rng, N, P, kind):
 
 
 @pytest.mark.parametrize("kind", ["plain", "shared", "repeat", "hub", "unsorted"])
-@pytest.mark.parametrize("N,G", [(1000, 256), (33, 4), (64, 1), (2500, 7)])
-def test_close_unit_tables_match_the_host_restatement(kind, N, G):
+@pytest.mark.parametrize("N,G,order", [(1000, 256, 0), (1000, 256, 1), (33, 4, 0), (64, 1, 0), (2500, 7, 0), (2500, 8, 1), (90, 16, 1),
+                                       (5000, 64, 1)])
+def test_close_unit_tables_match_the_host_restatement(kind, N, G, order):
     from dummynode4graphlearning_amd import ops
     rng = np.random.default_rng(N + G)
     P = 3 * N
     lists, ptr, rows = _lists(rng, N, P, kind)
     lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
     for drop in ((0, 0), (P // 3, P // 2)):
-        cu = ops.build_close_units(lp, lr, N, P, drop=drop, num_wg=G)
-        up, un, tiles = close_units_ref(ptr, rows, N, P, G, drop)
+        cu = ops.build_close_units(lp, lr, N, P, drop=drop, num_wg=G, order=order)
+        up, un, tiles = close_units_ref(ptr, rows, N, P, G, drop, order=order)
         got_up = cu.unit_ptr.cpu().numpy()
         assert np.array_equal(got_up, up), (got_up[:8], up[:8])
         assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
@@ -223,9 +224,9 @@ def _graph_batch(rng, sizes, P):
     return lists, ptr, np.concatenate(lists), np.array(seg_ptr), np.array(seg_nodes), np.array(dummies), base
 
 
-@pytest.mark.parametrize("G", [256, 5, 1])
+@pytest.mark.parametrize("G,order", [(256, 0), (256, 1), (5, 0), (1, 0), (8, 1), (48, 1)])
 @pytest.mark.parametrize("sizes_kind", ["config5", "mixed"])
-def test_absorbed_fold_tables_and_launch(sizes_kind, G):
+def test_absorbed_fold_tables_and_launch(sizes_kind, G, order):
     """Every graph inside one tile: dn_fold_graph_tiles_build_i32 + the unit tables with AGG units against the host restatement,
     and the launch -- out = x W_loop + b + list rows, aux[j] = bf16 column sum of graph j's real nodes, out[dummy_j] += aux[j] W_agg
     -- against fp64 (what dn_rows_close_bf16 + dn_fold_tail_bf16 compute in two launches)."""
@@ -242,8 +243,8 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G):
     assert okr and int(ok.item()) != 0
     assert np.array_equal(tile_ptr.cpu().numpy(), tpr) and np.array_equal(info.cpu().numpy(), infor)
     lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
-    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True)
-    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True)
+    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True, order=order)
+    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True, order=order)
     assert np.array_equal(cu.unit_ptr.cpu().numpy(), up)
     assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
     er, em = cu.ent_row.cpu().numpy(), cu.ent_mask.cpu().numpy().view(np.uint32)

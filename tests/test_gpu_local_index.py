@@ -336,7 +336,7 @@ def test_one_call_index_checks_its_workspace():
     P256 = ctypes.c_void_p(256)
     for ws, nbytes, msg in ((P256, need - 1, b"workspace too small"), (ctypes.c_void_p(16), need, b"unaligned workspace")):
         rc = L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), counts, rel, modes,
-                                       ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, cap, *([P256] * 8), 32, 8, P256, P256,
+                                       ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, 1, cap, *([P256] * 8), 32, 8, P256, P256,
                                        256, 4096, 64, P256, P256, plan, ws, nbytes, None)
         assert rc == -1 and msg in L.dn_last_error(), L.dn_last_error()
 
