@@ -779,6 +779,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
 #else
     constexpr bool abl_nostore = false, abl_hit = false;
 #endif
+    const bool w_kn = (relu & 32) != 0;             // bit 5: Wn[r] stored [k][n] (the parameter's own layout; NT == 1 widths only)
     relu &= 1;
     constexpr int SX = HI + kPad;                   // LDS row stride (elements) of the input tile
     constexpr int SY = HO + kPad;                   // ... of the output tile
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
     constexpr int PY = (NPY + kTfThreads - 1) / kTfThreads;
     static_assert(NT >= 1 && KS >= 1, "unsupported width");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * kTfRows * SX + kTfRows * SY + HO];
+    __shared__ __attribute__((aligned(16))) char wscr[NT == 1 ? (HO / 16) * 1024 : 16];   // transposition scratch of a [k][n] W, 1 KB per active wave
     auto bufX = [&](int b) -> bf16_t* { return lds + b * (kTfRows * SX); };
     bf16_t* bufY = lds + 2 * kTfRows * SX;
     bf16_t* biasL = lds + 2 * kTfRows * SX + kTfRows * SY;   // bias[rel]: each wave keeps ITS column slice here (no barrier)
@@ -859,12 +861,24 @@ __global__ __launch_bounds__(kTfThreads, (D == 1 ? 4 : 2)) void rows_transform_k
         if (tl.rel != cur_rel && wave_active) {     // (re)load this wave's weight slice: wave-uniform branch
             cur_rel = tl.rel;
             const bf16_t* w = Wn + (size_t)cur_rel * HO * HI;
+            bool done = false;
+            if constexpr (NT == 1) {
+                if (w_kn) {                             // [k = HI][n = HO]: 16-byte pieces along n, transposed through the wave's scratch
+                    bf16x8 wl[KS];
+                    dn_load_w_kn16<KS>(w, HO, n0, lane, wscr + (n0 / 16) * 1024, wl);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) wf[ks][0] = wl[ks];
+                    done = true;
+                }
+            }
+            if (!done) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     wf[ks][nt] = *reinterpret_cast<const bf16x8*>(w + (size_t)(n0 + nt * 16 + (lane & 15)) * HI + ks * 32 +
                                                                   8 * (lane >> 4));
+            }
             if (bias && lane < NT * 16) biasL[n0 + lane] = bias[(size_t)cur_rel * HO + n0 + lane];
             // pin the wait for the new weights INSIDE this (rare) branch: left to the compiler it sits in front of the MFMAs on
             // the common path as vmcnt(15) ... vmcnt(0), i.e. every tile waits there for the gather issued just above
@@ -1007,9 +1021,15 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
     auto rowbase = [&](int t) -> int { return (first + t * step) * kSsRows; };
 
     bf16x8 wf[KS];                                               // A operand: Wn rows n0 + (lane & 15), k = ks*32 + 8*(lane>>4)
+    if (nt & 2) {                                                // Wn stored [k][n] (`loop_weight` as it is): transposed through LDS
+        dn_load_w_kn16<KS>(Wn, H, n0, lane, reinterpret_cast<char*>(lds) + wave * 1024, wf);
+        __syncthreads();                                         // (lds holds the tiles from here on)
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+        for (int ks = 0; ks < KS; ++ks)
+            wf[ks] = *reinterpret_cast<const bf16x8*>(Wn + (size_t)(n0 + (lane & 15)) * H + ks * 32 + 8 * (lane >> 4));
+    }
+    nt &= 1;
     if (tid < H) biasL[tid] = bias ? (float)bias[tid] : 0.f;     // read back per tile: 4 fewer registers across the loop
 
     auto load_x = [&](int t) -> uint4 {
@@ -1145,7 +1165,7 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
 template <int H>
 int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const bf16_t* S, const bf16_t* S2, int32_t n1,
                    const int32_t* slots, int64_t N, bf16_t* out, const int32_t* fold_info, float* seg_part,
-                   hipStream_t st) {
+                   hipStream_t st, int32_t w_kn) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
@@ -1153,10 +1173,10 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     const int32_t tpw = (int32_t)(stride_tiles() ? 0 : tiles_per_wg);
     if (fold_info)
         hipLaunchKernelGGL((rows_selfsum_kernel<H, true>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, fold_info, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part);
     else
         hipLaunchKernelGGL((rows_selfsum_kernel<H, false>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, (nt >> 1) & 1, fold_info, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1346,7 +1366,8 @@ static int tf_wg_per_cu() {
 
 template <int HI, int HO>
 int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_t* idx, const bf16_t* Wn, const bf16_t* bias,
-                     int32_t relu, float slope, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st) {
+                     int32_t relu, float slope, const bf16_t* mask_pos, const Chunk* tiles, int64_t num_tiles, bf16_t* Y, hipStream_t st,
+                     int32_t w_kn = 0) {
     // contiguous tile ranges keep a workgroup inside one relation most of the time
     const int depth = tf_depth();
     // streaming (non-temporal) stores of the output rows: they are re-read only after ~1 GB of other traffic, so keeping
@@ -1355,6 +1376,7 @@ int launch_transform(const bf16_t* X, const bf16_t* X2, int32_t n1, const int32_
     relu = (relu ? 1 : 0) | ((nt & 1) ? 2 : 0) | ((nt & 4) ? 4 : 0);
     static const int abl = dn_knob("DN_TF_ABL", 0);
     relu |= (abl & 3) << 3;
+    relu |= w_kn ? 32 : 0;
     // workgroups per CU: a tile is 32 rows x 2*HI bytes, so narrower rows need more workgroups in flight to keep the same
     // bytes per CU outstanding (H = 128: 64 VGPRs, 26 KB LDS -> 4 fit; measured 2.24 -> 2.07 ms per step at H = 128)
     const int64_t per_cu = tf_wg_per_cu() > 0 ? tf_wg_per_cu() : (depth == 1 ? (HI <= 128 ? 4 : 2) : 1);
@@ -1684,15 +1706,15 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
     //  the ring kernel's loaders only tell the two sources apart through the row index)
     if (Hi == 256 && ring && (idx != nullptr || X2 == nullptr))
         return dn_internal::launch_transform_ring256(X, X2, n1, idx, Wn, bias, relu, nt_knob & 1, mask_pos, tiles, num_tiles, 0, Y, w_kn, act_slope, st);
-    if (w_kn) { dn_set_error("dn_rows_transform: w_kn = 1 is served by the H = 256 ring kernel only"); return DN_ERR_UNSUPPORTED; }
+    if (w_kn && Hi == 256) { dn_set_error("dn_rows_transform: at H = 256 w_kn = 1 is served by the ring kernel only"); return DN_ERR_UNSUPPORTED; }
     if (Hi == 256) return launch_transform<256, 256>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
-    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
-    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st);
+    if (Hi == 128) return launch_transform<128, 128>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st, w_kn);
+    return launch_transform<64, 64>(x, x2, n1, idx, w, b, relu, act_slope, mk, tl, num_tiles, (bf16_t*)Y, st, w_kn);
 }
 
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, const int32_t* fold_info,
-                         float* seg_part, dn_stream_t stream) {
+                         float* seg_part, int32_t w_kn, dn_stream_t stream) {
     DN_REQUIRE(fold_info == nullptr || seg_part != nullptr, "dn_rows_selfsum: fold_info needs seg_part");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_selfsum: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_selfsum: unsupported width %d (64/128/256 only)", H);
@@ -1706,9 +1728,9 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,
                  *s2 = (const bf16_t*)S2;
-    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
-    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
-    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st);
+    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
+    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
+    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
 }
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,

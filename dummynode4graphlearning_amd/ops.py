@@ -402,7 +402,7 @@ def rows_transform(X, Wn, tile_table, num_rows, idx=None, X2=None, bias=None, re
     require_gpu(X, Wn, tiles, idx, X2, bias, mask_pos, W_loop)
     assert X.dtype == Wn.dtype and X.dtype in (torch.bfloat16, torch.float32) and Wn.dim() == 3
     assert bias is None or bias.dtype == X.dtype
-    assert not w_kn or X.dtype == torch.float32 or Wn.shape[1] == Wn.shape[2] == 256
+    assert not w_kn or X.dtype == torch.float32 or (Wn.shape[1] == Wn.shape[2] and Wn.shape[1] in (64, 128, 256))
     assert (W_loop is None and bias_rel < 0) or X.dtype == torch.float32
     assert W_loop is None or (W_loop.dtype == X.dtype and W_loop.shape == Wn.shape[1:] and W_loop.is_contiguous() and loop_rel >= 0)
     assert Wn.is_contiguous() and (bias is None or bias.is_contiguous())
@@ -441,12 +441,12 @@ SELFSUM_SLOTS = 6
 SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 
-def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
+def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn=False):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
     seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
     folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, overflow): the per-node row
     lists the slot table was built from -- nodes with more rows than slots (-2 in their last slot) are finished from them by a
-    second small launch (dn_overflow_rows_add_bf16)."""
+    second small launch (dn_overflow_rows_add_bf16).  w_kn: Wn is given [in][out] (the parameter's own layout) instead."""
     require_gpu(x, Wn, bias, S, S2, slots)
     if seg is not None:
         require_gpu(*seg)
@@ -462,7 +462,7 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None):
     def _launch():
         check(lib().dn_rows_selfsum_bf16(ptr(x), H, ptr(Wn), ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                          ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out),
-                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, stream_ptr()),
+                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, 1 if w_kn else 0, stream_ptr()),
               "dn_rows_selfsum_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_selfsum", _launch)
@@ -1677,11 +1677,18 @@ class PassWeights:
         return PassWeights(a if self.loop is None else a[:-1], None if self.loop is None else a[-1], False)
 
 
+# DN_KN_SMALL=0: at H = 64 / 128 (bf16) the weights are concatenated and transposed in front of the forward launches, as before round 5
+KN_SMALL_ENABLED = _os.environ.get("DN_KN_SMALL", "1") != "0"
+
+
 def _kn_ok(xs):
-    """The launches that take [k][n] weights: bf16 H = 256 (ring transform, unit-stream closing launch, fold tail) and the
-    fp32 transform (any of its widths; it also takes the self-loop matrix and the bias where the parameters lie)."""
+    """The launches that take [k][n] weights: bf16 H = 256 (ring transform, unit-stream closing launch, fold tail), bf16 H = 64 /
+    128 (register-staged transform, slot kernel, fold tail) and the fp32 transform (any of its widths; it also takes the self-loop
+    matrix and the bias where the parameters lie)."""
     if xs.dtype == torch.float32:
         return xs.shape[1] in (64, 128, 256)
+    if xs.dtype == torch.bfloat16 and xs.shape[1] in (64, 128):
+        return KN_SMALL_ENABLED                      # round 5: the register-staged transform and the slot kernel read [k][n] too
     return xs.dtype == torch.bfloat16 and xs.shape[1] == 256 and CLOSE_RING_ENABLED
 
 
@@ -1690,9 +1697,8 @@ def _closing_launch(xs, W_loop, bias, Y, ix, direction, out, seg=None, w_kn=Fals
     overflow launch (dn_rows_selfsum_bf16, dn_overflow_rows_add_bf16)."""
     if _close_kind(xs) == "units":
         return rows_close(xs, W_loop, bias, Y, ix.close_units(direction), out=out, seg=seg, w_kn=w_kn)
-    assert not w_kn
     slots, lists = ix.slots(direction)
-    return rows_selfsum(xs, W_loop, bias, Y, None, slots, out=out, seg=seg, lists=lists)
+    return rows_selfsum(xs, W_loop, bias, Y, None, slots, out=out, seg=seg, lists=lists, w_kn=w_kn)
 
 
 def _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows):

@@ -388,7 +388,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
  * elements whose saved activation is <= 0 are multiplied by act_slope instead of zeroed.  0 = ReLU; 1 / 5.5 = the reference's
  * default `leaky_relu` (subgraph_isomorphism/utils/act.py:466, constants.py:10).  The same argument, with the same meaning for
  * their ReLU flags / masks / mask bits, is taken by dn_rows_wgrad_*, dn_rows_chain2_bf16 and dn_relu_bwd_*.
- * w_kn != 0 (Hi == 256 with idx != NULL or X2 == NULL only, DN_ERR_UNSUPPORTED otherwise): Wn[r] is stored [k][n] -- the layout
+ * w_kn != 0 (Hi == 256: with idx != NULL or X2 == NULL only, DN_ERR_UNSUPPORTED otherwise; Hi == 64 / 128: round 5, transposed through
+ * LDS at every change of relation): Wn[r] is stored [k][n] -- the layout
  * of the reference's `weight` parameter (rgin.py:61-67), so the forward pass needs no transposed copy of the weights. */
 int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int32_t* idx, int32_t Hi, int32_t Ho,
                            const void* Wn, const void* bias, int32_t relu, const void* mask_pos,
@@ -399,7 +400,8 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * i.e. the self-loop transform `th.matmul(node_feat, self.loop_weight)` + bias (subgraph_isomorphism/models/rgin.py:
  * 140-145, rgcn.py:168-182) fused with the per-node sum of the transformed rows (the reference's `fn.sum(msg, out)`
  * reduce, rgin.py:137 / rgcn.py:166) -- and, in the backward direction, the same for the input gradient.
- * Wn is [H][H] with k contiguous.  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
+ * Wn is [H][H] with k contiguous (w_kn = 0) or [k][n] as the parameter `loop_weight` stores it (w_kn = 1, round 5: no transposed
+ * copy in front of the launch).  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
  * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  A node with
  * more than num_slots rows carries -2 in its last slot (dn_slot_table_build_i32) and is finished by dn_overflow_rows_add_bf16
  * right after this launch.  num_slots must be 6.  H in {64, 128, 256}.
@@ -414,7 +416,7 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * operand); dn_fold_tail_bf16 adds a segment's partial rows in tile order: deterministic. */
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out,
-                         const int32_t* fold_info, float* seg_part, dn_stream_t stream);
+                         const int32_t* fold_info, float* seg_part, int32_t w_kn, dn_stream_t stream);
 
 /* Nodes with more rows than slots: out[v, :] += sum of the rows of v's list beyond the first num_slots - 1 kept ones, for every
  * node with overflow[v] != 0 (dn_slot_table_build_i32's byte per node).  The walk applies the table builder's filter (rows >= num_edge_rows

@@ -461,6 +461,42 @@ def test_ring_transform_at_every_short_pipeline_length(tiles_per_wg):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("H", [64, 128])
+def test_bf16_kernels_read_the_parameters_where_they_lie_at_the_default_widths(H):
+    """w_kn at H = 64 / 128 (round 5): dn_rows_transform_bf16 and dn_rows_selfsum_bf16 given `weight` [R, in, out] / `loop_weight`
+    [in, out] as the reference stores them (rgin.py:61-67) must produce, bit for bit, what they produce from the transposed copies
+    -- the fragments are the same, only their way into the registers differs (relation changes inside a workgroup included)."""
+    ops = _ops()
+    rng = np.random.default_rng(40 + H)
+    sizes = [0, 37, 1500, 1, 33, 64, 9000]
+    rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
+    R, P, N = len(sizes), rel_ptr[-1], 700
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16).to(DEV)  # noqa: E731
+    X, Wkn = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((R, H, H)) / np.sqrt(H))       # Wkn[r] = [in = k][out = n]
+    bias = bf(rng.standard_normal((R, H)))
+    idx = torch.from_numpy(rng.integers(0, N, size=P)).to(torch.int32).to(DEV)
+    tiles = ops.make_row_tiles(rel_ptr, DEV)
+    Wnk = Wkn.transpose(1, 2).contiguous()
+    for b, relu in ((None, False), (bias, True)):
+        a = ops.rows_transform(X, Wkn, tiles, P, idx=idx, bias=b, relu=relu, w_kn=True)
+        c = ops.rows_transform(X, Wnk, tiles, P, idx=idx, bias=b, relu=relu)
+        assert torch.equal(a, c)
+    ref = torch.einsum("pk,pkn->pn", X[idx.long()].double().cpu(),
+                       Wkn.double().cpu()[torch.repeat_interleave(torch.arange(R), torch.tensor(sizes))])
+    torch.testing.assert_close(ops.rows_transform(X, Wkn, tiles, P, idx=idx, w_kn=True).cpu().double(), ref, rtol=1e-2, atol=2e-2)
+    # the slot kernel (self loop + bias + row sums)
+    K = ops.SELFSUM_SLOTS
+    lists = [np.append(rng.integers(0, P, size=c), P + v) for v, c in enumerate(rng.integers(0, K + 1, size=N))]
+    ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(np.concatenate(lists)).to(DEV).int()
+    slots, over = ops.build_slot_table(lp, lr, N, P)
+    Y = bf(rng.standard_normal((P, H)))
+    Wl = bf(rng.standard_normal((H, H)) / np.sqrt(H))                                               # [in][out]
+    a = ops.rows_selfsum(X, Wl, bias[0], Y, None, slots, lists=(lp, lr, P, 0, 0, over), w_kn=True)
+    c = ops.rows_selfsum(X, Wl.t().contiguous(), bias[0], Y, None, slots, lists=(lp, lr, P, 0, 0, over))
+    assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("H", [64, 128, 256])
 def test_rows_selfsum_matches_reference(H):
     """dn_rows_selfsum_bf16: self-loop transform + bias + fixed-slot row sum (nodes with more rows than slots finished from
