@@ -441,6 +441,66 @@ def main():
         dist.all_reduce(te)
         e_glob = float(te.item())               # strong: the global batch's edges; weak: world x E
 
+    # roofline leg: the conv's gather-scatter launches alone (gather/segment-sum + gathered-row transform of the forward
+    # and of the input-gradient pass, exactly the launches the step makes), replayed as their own HIP graph and timed with
+    # HIP events on the launch stream
+    # (measured HERE, right behind the timed steps and in their memory state: behind the proxy and the fresh-batch leg -- a second
+    #  batch, a second index, a few GB of allocator traffic -- the same four launches ran 2-6 % slower on the same box than
+    #  in the step they belong to, whose own kernel trace agrees with this placement: profiles/r05_kernel_stats_step.csv vs _leg.csv)
+    def conv_gather_scatter():
+        with torch.no_grad():
+            from dummynode4graphlearning_amd.subgraph_isomorphism.rgin import dense_relation_weights
+            W = dense_relation_weights(layer)                       # (basis with num_bases == R: the parameter itself)
+            if fused:
+                # exactly what _RowTransformFn issues: the forward pass on the parameters as they are stored ([k][n]: no cat /
+                # transpose launches at H = 256 bf16), the input-gradient pass on W itself
+                fw = ops.PassWeights(W, layer.loop_weight, kn=True)
+                if not ops._kn_ok(x):
+                    fw = fw.nk()
+                bw = ops.PassWeights(W, layer.loop_weight, kn=False)
+                ybuf = index.ybuf(H, dtype, dev)
+                for n0, n1, ix in index.parts:
+                    ops.message_pass(x[n0:n1], fw, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
+                    ops.message_pass(gout[n0:n1], bw, None, ix, "b", ybuf, cg_out[n0:n1])
+            else:
+                A = ops.gather_segsum(x, index.src1, index.seg_ptr, index.num_segments)
+                ops.gather_segsum(A, index.sperm, index.dptr, N)
+                gy = ops.gather_segsum(gout, index.seg_dst, None)
+                ops.gather_segsum(gy, index.seg_by_src, index.optr, N)
+
+    cg_out = torch.empty((N, H), dtype=dtype, device=dev)
+    conv_gather_scatter()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    conv_gather_scatter()                               # eager pass: counts the launches (times include launch gaps)
+    ops.kernel_timer = None
+    n_launch = len(timer.records)
+    def graphed(fn):
+        """fn replayed from a HIP graph; falls back to the eager callable if the capture fails."""
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            return gr.replay
+        except Exception as exc:
+            sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
+            torch.cuda.synchronize()
+            return fn
+
+    replay_conv = graphed(conv_gather_scatter)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(args.steps, 5)
+    e0.record()
+    for _ in range(reps):
+        replay_conv()
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms_step = e0.elapsed_time(e1) / reps
+    ms_per_step = dt / args.steps * 1e3
+
     # strong-scaling proxy (rank 0, one GPU): ONE eighth of the global batch (the shard rank 0 of an 8-GPU run takes) on this
     # GPU -- step under HIP-graph replay incl. bucket.pack(), fresh-batch index build -- and the efficiency an 8-GPU run could
     # reach before the gradient all-reduce: t(batch) / (8 t(eighth)).  No multi-GPU curve is measured here.
@@ -525,62 +585,6 @@ def main():
         torch.cuda.synchronize()
         overlapped_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
-    # roofline leg: the conv's gather-scatter launches alone (gather/segment-sum + gathered-row transform of the forward
-    # and of the input-gradient pass, exactly the launches the step makes), replayed as their own HIP graph and timed with
-    # HIP events on the launch stream
-    def conv_gather_scatter():
-        with torch.no_grad():
-            from dummynode4graphlearning_amd.subgraph_isomorphism.rgin import dense_relation_weights
-            W = dense_relation_weights(layer)                       # (basis with num_bases == R: the parameter itself)
-            if fused:
-                # exactly what _RowTransformFn issues: the forward pass on the parameters as they are stored ([k][n]: no cat /
-                # transpose launches at H = 256 bf16), the input-gradient pass on W itself
-                fw = ops.PassWeights(W, layer.loop_weight, kn=True)
-                if not ops._kn_ok(x):
-                    fw = fw.nk()
-                bw = ops.PassWeights(W, layer.loop_weight, kn=False)
-                ybuf = index.ybuf(H, dtype, dev)
-                for n0, n1, ix in index.parts:
-                    ops.message_pass(x[n0:n1], fw, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
-                    ops.message_pass(gout[n0:n1], bw, None, ix, "b", ybuf, cg_out[n0:n1])
-            else:
-                A = ops.gather_segsum(x, index.src1, index.seg_ptr, index.num_segments)
-                ops.gather_segsum(A, index.sperm, index.dptr, N)
-                gy = ops.gather_segsum(gout, index.seg_dst, None)
-                ops.gather_segsum(gy, index.seg_by_src, index.optr, N)
-
-    cg_out = torch.empty((N, H), dtype=dtype, device=dev)
-    conv_gather_scatter()
-    torch.cuda.synchronize()
-    timer = ops.KernelTimer()
-    ops.kernel_timer = timer
-    conv_gather_scatter()                               # eager pass: counts the launches (times include launch gaps)
-    ops.kernel_timer = None
-    n_launch = len(timer.records)
-    def graphed(fn):
-        """fn replayed from a HIP graph; falls back to the eager callable if the capture fails."""
-        try:
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
-                fn()
-            gr.replay()
-            torch.cuda.synchronize()
-            return gr.replay
-        except Exception as exc:
-            sys.stderr.write("[bench] HIP graph capture failed (%s); timing eager launches\n" % exc)
-            torch.cuda.synchronize()
-            return fn
-
-    replay_conv = graphed(conv_gather_scatter)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(args.steps, 5)
-    e0.record()
-    for _ in range(reps):
-        replay_conv()
-    e1.record()
-    torch.cuda.synchronize()
-    kernel_ms_step = e0.elapsed_time(e1) / reps
-    ms_per_step = dt / args.steps * 1e3
 
     # roofline: algorithmic bytes of the layer's gather-scatter forward+backward (SURVEY.md 8d:
     # 2*(E*H*s + N*H*s + 8*E)) over the time of the launches that implement it
