@@ -175,7 +175,7 @@ def test_non_finite_product_row_poisons_its_column_of_the_tile_and_nothing_else(
 
 def test_parameter_layout_weights_give_the_same_bits_as_the_transposed_copy():
     """w_kn = 1 (weights read as the reference stores them, [in][out]) against w_kn = 0 on an explicit transposed copy: the ring
-    transform (several relation switches per workgroup) and the fold tail, bit for bit; other widths refuse w_kn."""
+    transform (several relation switches per workgroup) and the fold tail, bit for bit; unsupported widths refuse."""
     from dummynode4graphlearning_amd import ops
     from dummynode4graphlearning_amd._lib import DnHipError
     rng = np.random.default_rng(5)
@@ -204,9 +204,13 @@ def test_parameter_layout_weights_give_the_same_bits_as_the_transposed_copy():
     x1 = ops.fold_tail(part, part_ptr, nseg, W[2], tgt, o1, w_kn=True)
     x2 = ops.fold_tail(part, part_ptr, nseg, Wn[2].contiguous(), tgt, o2)
     assert torch.equal(o1, o2) and torch.equal(x1, x2)
+    # (H = 64 / 128 take w_kn too since round 5: tests/test_gpu_kernels.py); a width no MFMA kernel serves still refuses
     W64 = bf(rng.standard_normal((1, 64, 64)))
+    t64 = ops.make_row_tiles([0, 100], torch.device(DEV))
+    x64 = X[:, :64].contiguous()
+    assert torch.equal(ops.rows_transform(x64, W64, t64, 100, w_kn=True), ops.rows_transform(x64, W64.transpose(1, 2).contiguous(), t64, 100))
     with pytest.raises((DnHipError, AssertionError)):
-        ops.rows_transform(X[:, :64].contiguous(), W64, ops.make_row_tiles([0, 100], torch.device(DEV)), 100, w_kn=True)
+        ops.rows_transform(X[:, :96].contiguous(), bf(rng.standard_normal((1, 96, 96))), t64, 100, w_kn=True)
 
 
 def _graph_batch(rng, sizes, P):
