@@ -75,7 +75,7 @@ _SIGS = {
     "dn_rows_transform_bf16": (ctypes.c_int, [P, P, c_i32, P, c_i32, c_i32, P, P, c_i32, P, P, c_i64, P, c_i32, c_f32, P]),
     "dn_relu_bwd_bf16": (ctypes.c_int, [P, P, P, c_i64, c_f32, P]),
     "dn_rows_chain2_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, P, P, c_i32, c_f32, P]),
-    "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P, P, c_i32, P]),
+    "dn_rows_selfsum_bf16": (ctypes.c_int, [P, c_i32, P, P, P, P, c_i32, P, c_i32, c_i64, P, P, P, c_i32, P, P, c_i32, c_i32, c_i32, P]),
     "dn_overflow_rows_add_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, c_i64, P, P, c_i32, c_i32, c_i32, P, P]),
     "dn_close_units_capacity": (c_i64, [c_i64, c_i64, c_i32]),
     "dn_close_units_workspace_bytes": (c_sz, [c_i64, c_i32]),

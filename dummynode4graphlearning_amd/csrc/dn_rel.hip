@@ -992,7 +992,9 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
                                                              int32_t num_tiles, int32_t tiles_per_wg,
                                                              bf16_t* __restrict__ out, int32_t nt,
                                                              const int32_t* __restrict__ fold_info,
-                                                             float* __restrict__ seg_part) {
+                                                             float* __restrict__ seg_part, const int32_t* __restrict__ lptr,
+                                                             const int32_t* __restrict__ lrows, int32_t P_edge, int32_t drop_beg,
+                                                             int32_t drop_end) {
     constexpr int T = H * 4, K = kSsSlots;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int SX = H + kPad, SY = H + kPad;
@@ -1152,6 +1154,28 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
                     a[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
                 }
             }
+            if (lptr != nullptr && sid[K - 1] == -2) {
+                // a node with more rows than slots, finished HERE (small batches: the separate dn_overflow_rows_add_bf16 launch costs
+                // more than this walk -- dependent loads of a few nodes -- stalls; large ones keep the launch): the rows of its list
+                // behind the first K - 1 kept ones, in list order, same filter as the table builder
+                int kept = 0;
+                for (int i = lptr[p]; i < lptr[p + 1]; ++i) {
+                    const int r = lrows[i];
+                    if (r < P_edge && !(r >= drop_beg && r < drop_end)) {
+                        if (kept >= K - 1) {
+                            const bf16_t* base = r < n1 ? S + (size_t)r * H : S2 + (size_t)(r - n1) * H;
+                            const uint4 e = *reinterpret_cast<const uint4*>(base + pc * 8);
+                            const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                a[2 * q] += __uint_as_float(w[q] << 16);
+                                a[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+                            }
+                        }
+                        ++kept;
+                    }
+                }
+            }
             bf16x8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (bf16_t)a[i];
@@ -1165,7 +1189,8 @@ __global__ __launch_bounds__(H * 4) void rows_selfsum_kernel(const bf16_t* __res
 template <int H>
 int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const bf16_t* S, const bf16_t* S2, int32_t n1,
                    const int32_t* slots, int64_t N, bf16_t* out, const int32_t* fold_info, float* seg_part,
-                   hipStream_t st, int32_t w_kn) {
+                   hipStream_t st, int32_t w_kn, const int32_t* lptr, const int32_t* lrows, int32_t P_edge, int32_t drop_beg,
+                   int32_t drop_end) {
     const int64_t num_tiles = dn_cdiv(N, kSsRows);
     const int64_t tiles_per_wg = dn_cdiv(num_tiles, 256 * (1024 / (H * 4)));   // 16 waves per CU
     const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
@@ -1173,10 +1198,10 @@ int launch_selfsum(const bf16_t* X, const bf16_t* Wn, const bf16_t* bias, const 
     const int32_t tpw = (int32_t)(stride_tiles() ? 0 : tiles_per_wg);
     if (fold_info)
         hipLaunchKernelGGL((rows_selfsum_kernel<H, true>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part, lptr, lrows, P_edge, drop_beg, drop_end);
     else
         hipLaunchKernelGGL((rows_selfsum_kernel<H, false>), dim3((unsigned)grid), dim3(H * 4), 0, st, X, Wn, bias, S, S2, n1, slots,
-                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part);
+                           (int32_t)N, (int32_t)num_tiles, tpw, out, ((nt >> 1) & 1) | (w_kn ? 2 : 0), fold_info, seg_part, lptr, lrows, P_edge, drop_beg, drop_end);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1714,8 +1739,10 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
 
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out, const int32_t* fold_info,
-                         float* seg_part, int32_t w_kn, dn_stream_t stream) {
+                         float* seg_part, int32_t w_kn, const int32_t* list_ptr, const int32_t* list_rows, int32_t num_edge_rows,
+                         int32_t drop_beg, int32_t drop_end, dn_stream_t stream) {
     DN_REQUIRE(fold_info == nullptr || seg_part != nullptr, "dn_rows_selfsum: fold_info needs seg_part");
+    DN_REQUIRE((list_ptr == nullptr) == (list_rows == nullptr), "dn_rows_selfsum: list_ptr and list_rows go together");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL, "dn_rows_selfsum: bad row count");
     DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_selfsum: unsupported width %d (64/128/256 only)", H);
     DN_REQUIRE(num_slots == kSsSlots, "dn_rows_selfsum: the slot table must have %d columns", kSsSlots);
@@ -1728,9 +1755,9 @@ int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* b
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)Wn, *b = (const bf16_t*)bias, *s1 = (const bf16_t*)S,
                  *s2 = (const bf16_t*)S2;
-    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
-    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
-    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn);
+    if (H == 256) return launch_selfsum<256>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end);
+    if (H == 128) return launch_selfsum<128>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end);
+    return launch_selfsum<64>(x, w, b, s1, s2, n1, slots, N, (bf16_t*)out, fold_info, seg_part, st, w_kn, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end);
 }
 
 int dn_rows_chain2_bf16(const void* X, int32_t H, const void* W1n, const void* b1, int32_t relu1, const void* mask0_bits,

@@ -441,6 +441,12 @@ SELFSUM_SLOTS = 6
 SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 
 
+# DN_OVER_INSIDE_ROWS: up to this many nodes dn_rows_selfsum_bf16 finishes the nodes with more rows than slots itself (0: never).
+# Config-3-shaped batches, H = 64 bf16, step with the walk inside / as its own launch: 25.6 k nodes 0.0985 / 0.1067 ms, 38 k 0.114 /
+# 0.118, 51 k 0.123 / 0.127, 77 k 0.151 / 0.150, 102 k 0.182 / 0.175, 410 k 0.533 / 0.485
+OVERFLOW_INSIDE_MAX_ROWS = int(_os.environ.get("DN_OVER_INSIDE_ROWS", "65536"))
+
+
 def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn=False):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
     seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
@@ -459,16 +465,22 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn
         out = torch.empty((N, H), dtype=x.dtype, device=x.device)
     n1 = int(S.shape[0]) if S2 is not None else 0x7fffffff
 
+    # small batches: the nodes with more rows than slots are finished inside the launch (one launch less); large ones by the
+    # overflow launch below (the in-kernel walk stalls the tile pipeline: + 130 us at config 5)
+    inside = lists is not None and N <= OVERFLOW_INSIDE_MAX_ROWS and S is not None and S.numel() > 0
+    lin = lists if inside else (None, None, 0, 0, 0, None)
+
     def _launch():
         check(lib().dn_rows_selfsum_bf16(ptr(x), H, ptr(Wn), ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                          ptr(S2), n1, ptr(slots), SELFSUM_SLOTS, N, ptr(out),
-                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, 1 if w_kn else 0, stream_ptr()),
+                                         ptr(seg[0]) if seg else None, ptr(seg[1]) if seg else None, 1 if w_kn else 0,
+                                         ptr(lin[0]), ptr(lin[1]), int(lin[2]), int(lin[3]), int(lin[4]), stream_ptr()),
               "dn_rows_selfsum_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_selfsum", _launch)
     else:
         _launch()
-    if lists is not None:
+    if lists is not None and not inside:
         lp, lr, ner, db, de, over = lists
         require_gpu(lp, lr, over)
         _i32(lp, "list_ptr"), _i32(lr, "list_rows")

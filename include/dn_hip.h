@@ -404,7 +404,11 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * copy in front of the launch).  slots is an [N, num_slots] int32 table of row ids into Scat = S (rows [0, n1))
  * followed by S2 (row n1, n1+1, ...; S2 = NULL with n1 = INT32_MAX for none); negative ids are empty slots.  A node with
  * more than num_slots rows carries -2 in its last slot (dn_slot_table_build_i32) and is finished by dn_overflow_rows_add_bf16
- * right after this launch.  num_slots must be 6.  H in {64, 128, 256}.
+ * right after this launch -- or, with list_ptr / list_rows (the lists the slot table was built from, may be NULL) and the builder's
+ * filter (num_edge_rows, drop_beg, drop_end), INSIDE this launch (round 5): the node's thread walks its list and adds the rows behind
+ * the first num_slots - 1 kept ones in fp32 before the one rounding.  For small batches, where a second launch costs more than the
+ * walk; large ones keep dn_overflow_rows_add_bf16 (the walk stalled every other tile: + 130 us at config 5).  num_slots must be 6.
+ * H in {64, 128, 256}.
  * Folded pre-aggregation (fold_info != NULL): the launch also sums the X rows it reads per SEGMENT -- the input row of a
  * collapsed relation (all nodes of a graph -> its dummy node: one row per graph whose input is the sum of the graph's rows,
  * the reference's per-edge messages of the dummy edge type, rgin.py:102-120 on dataset.py:1563-1603's dummy edges) -- so the
@@ -416,7 +420,8 @@ int dn_rows_transform_bf16(const void* X, const void* X2, int32_t n1, const int3
  * operand); dn_fold_tail_bf16 adds a segment's partial rows in tile order: deterministic. */
 int dn_rows_selfsum_bf16(const void* X, int32_t H, const void* Wn, const void* bias, const void* S, const void* S2,
                          int32_t n1, const int32_t* slots, int32_t num_slots, int64_t N, void* out,
-                         const int32_t* fold_info, float* seg_part, int32_t w_kn, dn_stream_t stream);
+                         const int32_t* fold_info, float* seg_part, int32_t w_kn, const int32_t* list_ptr,
+                         const int32_t* list_rows, int32_t num_edge_rows, int32_t drop_beg, int32_t drop_end, dn_stream_t stream);
 
 /* Nodes with more rows than slots: out[v, :] += sum of the rows of v's list beyond the first num_slots - 1 kept ones, for every
  * node with overflow[v] != 0 (dn_slot_table_build_i32's byte per node).  The walk applies the table builder's filter (rows >= num_edge_rows

@@ -106,7 +106,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     rc = L.dn_bdd_compose(None, 3, 4, 16, 16, 3, ctypes.c_void_p(16), ctypes.c_void_p(16), None) if False else L.dn_bdd_extract(
         ctypes.c_void_p(16), 3, 4, 16, 16, 3, ctypes.c_void_p(16), None)
     assert rc == -1 and b"elem_bytes" in L.dn_last_error()
-    rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, 0, None)
+    rc = L.dn_rows_selfsum_bf16(*([None] * 1), 256, *([None] * 4), 0, None, 6, 8, None, ctypes.c_void_p(16), None, 0, None, None, 0, 0, 0, None)
     assert rc == -1 and b"fold_info needs seg_part" in L.dn_last_error()
     rc = L.dn_overflow_rows_add_bf16(None, 100, None, 6, 8, None, None, 5, 0, 0, None, None)
     assert rc == -1 and b"unsupported width" in L.dn_last_error()
