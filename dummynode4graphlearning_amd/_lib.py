@@ -82,7 +82,6 @@ _SIGS = {
     "dn_close_units_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, c_i64, c_i32, c_i32, P, P, c_i64, c_i32, c_i32, P, P, P, c_i64, P,
                                                 P, P, c_sz, P]),
     "dn_fold_graph_tiles_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P, P, P]),
-    "dn_rows_fused_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, P, c_i32, P, P, c_i64, P, P, P, P, P, P, c_i32, P, P]),
     "dn_rows_close_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, P, P, c_i32, P, P, c_i64, P, P, P, P, P, P, P]),
     "dn_bdd_compose": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),
     "dn_bdd_extract": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),

@@ -917,10 +917,6 @@ int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, co
     static const int nt = dn_knob("DN_NT", 3);
     const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
     const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2);
-    const int close8 = dn_knob("DN_CLOSE8", 0);                            // tuning build: the eight-wave form (dn_fuse.hip)
-    if (close8 && (agg || !fold_info))
-        return dn_internal::launch_close8(X, W, w_kn, bias, S, unit_ptr, units, num_wg, ent_row, ent_mask, N, out, fold_info, W_agg, aux,
-                                          agg_idx, (nt & 2) ? 1 : 0, nullptr, nullptr, nullptr, 0, nullptr, st);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
 #define DN_CLOSE_LAUNCH(F)                                                                                                         \
     hipLaunchKernelGGL((rows_close_ring_kernel<F>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X, (const bf16_t*)W, \

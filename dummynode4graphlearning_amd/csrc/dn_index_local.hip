@@ -716,8 +716,14 @@ __global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t
     __syncthreads();                                                       // (every lane's verdict store has completed: it waited)
     if (threadIdx.x == 0) {
         int32_t* ticket = meta + 5 + 2 * R + 4 + dn_internal::kRilPlanWords;
-        if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(gridDim.x * gridDim.y) - 1)
+        // Release side: every verdict store of this workgroup is a device-scope atomic that has COMPLETED (s_waitcnt vmcnt(0) in
+        // the storing lane, then the barrier above) before the ticket moves -- the hardware form of a release without the per-
+        // workgroup L2 write-back an agent-scope release fence costs here (20 -> 52 us for the launch).  Acquire side:
+        // only the LAST workgroup pays for a real fence before it reads the other workgroups' words.
+        if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(gridDim.x * gridDim.y) - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             ril_plan(G, R, meta);
+        }
     }
 }
 

@@ -19,14 +19,6 @@ int launch_chain2_ring256(const void* X, const void* W1n, const void* b1, const 
                           const void* mask0, const void* mask1, int64_t N, void* Y1, void* Y2, void* bits1, void* bits2,
                           float slope, hipStream_t st);
 
-// dn_fuse.hip: the unit stream of dn_rows_close_bf16 on eight self-loading waves (no fp32 partial rows: fold_info goes with W_agg /
-// aux / agg_idx or not at all).  Wrel != NULL: the FUSED launch -- the stream also holds transform units (rows tidx[p] of X times
-// Wrel[rel], written to S), gated on done[chunk] (num_chunks counters, zeroed here) -- dn_rows_fused_bf16.
-int launch_close8(const void* X, const void* W, int32_t w_kn, const void* bias, const void* S, const int32_t* unit_ptr,
-                  const int32_t* units, int32_t num_wg, const int32_t* ent_row, const uint32_t* ent_mask, int64_t N, void* out,
-                  const int32_t* fold_info, const void* W_agg, void* aux, const int32_t* agg_idx, int32_t nt_store,
-                  const void* Wrel, const int32_t* tidx, int32_t* done, int32_t num_chunks, int32_t* err, hipStream_t st);
-
 // ---- the per-batch index as ONE call (dn_conv_index.hip: dn_conv_index_build_i32) -- the builders' launches without their host sides
 constexpr int kRilPlanWords = 12;      // ril_plan_kernel's words behind the 5 + 2 R + 4 meta words of the graph-local row index
 

@@ -445,14 +445,19 @@ SELFSUM_ENABLED = _os.environ.get("DN_SELFSUM", "1") != "0"
 # Config-3-shaped batches, H = 64 bf16, step with the walk inside / as its own launch: 25.6 k nodes 0.0985 / 0.1067 ms, 38 k 0.114 /
 # 0.118, 51 k 0.123 / 0.127, 77 k 0.151 / 0.150, 102 k 0.182 / 0.175, 410 k 0.533 / 0.485
 OVERFLOW_INSIDE_MAX_ROWS = int(_os.environ.get("DN_OVER_INSIDE_ROWS", "65536"))
+# ... and only while no node's list is longer than this: the walk inside the slot kernel takes a list one entry at a time (dependent
+# loads) while the rest of the workgroup waits at a barrier, so one hub node with thousands of rows would stall its tile's pipeline;
+# dn_overflow_rows_add_bf16 ranks 64 entries per round trip
+OVERFLOW_INSIDE_MAX_LIST = int(_os.environ.get("DN_OVER_INSIDE_LIST", "64"))
 
 
 def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn=False):
     """out[v] = x[v] @ Wn^T (+ bias) + sum_k Scat[slots[v, k]]  (dn_rows_selfsum_bf16; Scat = S rows then S2 rows).
     seg = (fold_info int32 [ceil(N/32), 12], seg_part fp32 [n_part, H]): also write the per-(segment, tile) column sums of x (the
-    folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, overflow): the per-node row
-    lists the slot table was built from -- nodes with more rows than slots (-2 in their last slot) are finished from them by a
-    second small launch (dn_overflow_rows_add_bf16).  w_kn: Wn is given [in][out] (the parameter's own layout) instead."""
+    folded pre-aggregation, see the header).  lists = (list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, overflow[, longest
+    list]): the per-node row lists the slot table was built from -- nodes with more rows than slots (-2 in their last slot) are finished
+    from them inside the launch (small batches whose longest list is known and short) or by a second small launch
+    (dn_overflow_rows_add_bf16).  w_kn: Wn is given [in][out] (the parameter's own layout) instead."""
     require_gpu(x, Wn, bias, S, S2, slots)
     if seg is not None:
         require_gpu(*seg)
@@ -467,7 +472,8 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn
 
     # small batches: the nodes with more rows than slots are finished inside the launch (one launch less); large ones by the
     # overflow launch below (the in-kernel walk stalls the tile pipeline: + 130 us at config 5)
-    inside = lists is not None and N <= OVERFLOW_INSIDE_MAX_ROWS and S is not None and S.numel() > 0
+    inside = (lists is not None and N <= OVERFLOW_INSIDE_MAX_ROWS and S is not None and S.numel() > 0
+              and len(lists) > 6 and lists[6] is not None and lists[6] <= OVERFLOW_INSIDE_MAX_LIST)
     lin = lists if inside else (None, None, 0, 0, 0, None)
 
     def _launch():
@@ -481,7 +487,7 @@ def rows_selfsum(x, Wn, bias, S, S2, slots, out=None, seg=None, lists=None, w_kn
     else:
         _launch()
     if lists is not None and not inside:
-        lp, lr, ner, db, de, over = lists
+        lp, lr, ner, db, de, over = lists[:6]
         require_gpu(lp, lr, over)
         _i32(lp, "list_ptr"), _i32(lr, "list_rows")
         assert lp.numel() >= N + 1 and S2 is None and over.dtype == torch.uint8 and over.numel() >= N
@@ -653,36 +659,6 @@ def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
     else:
         _launch()
     return out
-
-
-def rows_fused(x, Wrel, W_loop, bias, S, row_src, tables, cu, agg, out=None, w_kn=False, state=None):
-    """Both launches of one conv direction in one (dn_rows_fused_bf16, H = 256 bf16): S[p] = x[row_src[p]] @ Wrel[rel p] for the
-    transform units of `tables` (unit_ptr, units, num_wg, num_chunks) and out[v] = x[v] @ W_loop (+ bias) + the rows of S that
-    cu lists for v, with the absorbed fold agg = (fold_info, W_agg, aux, agg_idx) as in rows_close.  state = (done [chunks], err [1])
-    int32 device tensors (allocated if None).  Returns (out, state)."""
-    require_gpu(x, Wrel, W_loop, bias, S, row_src, tables["unit_ptr"], tables["units"], cu.ent_row, cu.ent_mask)
-    N, H = x.shape
-    assert H == 256 and x.dtype == torch.bfloat16 and Wrel.dtype == x.dtype and W_loop.shape == (H, H) and Wrel.shape[1:] == (H, H)
-    assert S.dtype == x.dtype and S.shape[1] == H and S.is_contiguous() and row_src.dtype == I32 and N == cu.num_nodes
-    x, Wrel, W_loop = x.contiguous(), Wrel.contiguous(), W_loop.contiguous()
-    fi, wa, ax, ai = agg
-    require_gpu(fi, wa, ax, ai)
-    if out is None:
-        out = torch.empty((N, H), dtype=x.dtype, device=x.device)
-    if state is None:
-        state = (torch.zeros(tables["num_chunks"], dtype=I32, device=x.device), torch.zeros(4, dtype=I32, device=x.device))
-    done, err = state
-
-    def _launch():
-        check(lib().dn_rows_fused_bf16(ptr(x), H, ptr(Wrel), ptr(W_loop), 1 if w_kn else 0, ptr(bias), ptr(S), ptr(row_src),
-                                       ptr(tables["unit_ptr"]), ptr(tables["units"]), tables["num_wg"], ptr(cu.ent_row),
-                                       ptr(cu.ent_mask), N, ptr(out), ptr(fi), ptr(wa), ptr(ax), ptr(ai), ptr(done),
-                                       tables["num_chunks"], ptr(err), stream_ptr()), "dn_rows_fused_bf16")
-    if kernel_timer is not None:
-        kernel_timer.launch("rows_fused", _launch)
-    else:
-        _launch()
-    return out, state
 
 
 def wgrad_supported(A, G):
@@ -1480,6 +1456,17 @@ def _queue_fold_tables(ix, direction, n_aux, flag):
     return fold_info, part_ptr
 
 
+def _late_fold_tables(ix, direction, info):
+    """The 32-node-tile fold tables (fp32 partial rows) of a direction whose fold had been ABSORBED so far (a second closing kind on
+    the same index).  The builder repeats the contiguity test the graph tiles passed, so its verdict must be "valid": it is read back
+    and checked here instead of being handed on as a device flag that the slot builder honours and the overflow finishers (which drop
+    the folded rows unconditionally) would not."""
+    flag = torch.zeros(1, dtype=I32, device=ix.row_in.device)
+    info.fold_info, info.part_ptr = _queue_fold_tables(ix, direction, info.n, flag)
+    if int(flag.item()) == 0:
+        raise _lib.DnHipError("fold tables of direction %r are invalid although the graph tiles of the same segments were valid" % direction)
+
+
 def _closing_tables(ix, kind="slots"):
     """Tables of the closing launches of BOTH directions of a RowIndex.  Every builder leaves its verdict on the device; the host
     reads the verdicts of both directions in ONE copy (it picks the launch sequence by them).
@@ -1548,12 +1535,16 @@ def _closing_tables(ix, kind="slots"):
     elif kind == "slots":
         for d in dirs:
             info = ix._fold[d]
-            enable = None
             if info is not None and info.fold_info is None:          # absorbed so far: the slot kernel needs the partial-row tables
-                enable = torch.zeros(1, dtype=I32, device=dev)       # (valid whenever the graph tiles were -- same contiguity test --
-                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, enable)   # but the rows are only dropped if so)
+                _late_fold_tables(ix, d, info)
             drop = (info.beg, info.end) if info is not None else (0, 0)
-            tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop, drop_enable=enable)
+            tabs[d] = build_slot_table(*lists[d], N, P, K, drop=drop)
+    longest = {d: None for d in dirs}
+    if kind == "slots" and 0 < N <= OVERFLOW_INSIDE_MAX_ROWS:
+        # the longest list of each direction (one small read-back per batch, small batches only): rows_selfsum walks overflowing
+        # lists inside the launch only while they are short
+        mx = torch.stack([(lists[d][0][1:N + 1] - lists[d][0][:N]).max() for d in dirs]).tolist()
+        longest = {d: int(mx[k]) for k, d in enumerate(dirs)}
     for d in dirs:
         info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
@@ -1562,15 +1553,13 @@ def _closing_tables(ix, kind="slots"):
             info.graph_tiles = (ix._absorb[d][0][:info.n + 1], ix._absorb[d][1][:info.n])
         if kind == "slots":
             slots, over = tabs[d]
-            ix._slots[d] = (slots, (*lists[d], P, drop[0], drop[1], over))
+            ix._slots[d] = (slots, (*lists[d], P, drop[0], drop[1], over, longest[d]))
         elif info is not None and info.graph_tiles is not None:     # every graph inside one tile: the fold is absorbed
             ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
         else:
-            enable = None
             if info is not None and info.fold_info is None:
-                enable = torch.zeros(1, dtype=I32, device=dev)
-                info.fold_info, info.part_ptr = _queue_fold_tables(ix, d, info.n, enable)
-            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, drop_enable=enable)
+                _late_fold_tables(ix, d, info)
+            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop)
 
 
 def _row_index_slots(ix, direction):

@@ -182,6 +182,7 @@ class OverlappedGradReducer:
         if not self.buckets:
             raise ValueError("no parameter groups")
         self._pending = [set() for _ in self.buckets]
+        self._sync, self._poisoned = True, False
         self._works = [None] * len(self.buckets)
         self._done = [False] * len(self.buckets)
         self.launched = []
@@ -206,11 +207,17 @@ class OverlappedGradReducer:
 
     def _make_hook(self, gi):
         def hook(param):
+            if not self._sync:                          # no_sync(): gradients accumulate locally, nothing is counted or sent
+                return
+            if self._poisoned:
+                raise RuntimeError("OverlappedGradReducer: a previous backward() broke the step protocol; call reset() "
+                                   "(and zero the gradients) before the next step")
             if self._done[gi]:
+                self._poisoned = True                   # the flat buffer holds AVERAGED gradients + a local one: unusable
                 raise RuntimeError("OverlappedGradReducer: a gradient of group %d arrived after the group's all-reduce was "
                                    "issued (a second backward() without finish(): the flat buffer already holds the AVERAGED "
-                                   "gradients). Call finish() after every backward(); accumulate micro-batches with a plain "
-                                   "FlatGradBucket and one all_reduce()." % gi)
+                                   "gradients). Call finish() after every backward(); accumulate micro-batches under "
+                                   "no_sync() and let the last backward() reduce. The reducer stays unusable until reset()." % gi)
             self._pending[gi].discard(id(param))
             self._drain()
         return hook
@@ -228,9 +235,45 @@ class OverlappedGradReducer:
         self._next = gi - 1
         self._works[gi] = self.buckets[gi].all_reduce(async_op=True)
 
+    def no_sync(self):
+        """Context manager for gradient accumulation (torch DDP's no_sync): backward() calls inside it only ACCUMULATE into the
+        buckets' .grad views -- no hook counts, no collective.  The first backward() after the block reduces the sum:
+
+            with reducer.no_sync():
+                for mb in micro_batches[:-1]:
+                    loss(model(mb)).backward()
+            loss(model(micro_batches[-1])).backward(); reducer.finish()
+
+        Every rank must run the same number of backward() calls outside no_sync() (as with DDP)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            if any(self._done):
+                raise RuntimeError("OverlappedGradReducer.no_sync(): a step is in flight (call finish() first)")
+            prev, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = prev
+                self._arm()                             # the next backward() starts a fresh count
+        return _cm()
+
+    def reset(self):
+        """Re-arm WITHOUT communicating: waits for collectives already issued (their results are the caller's to discard, e.g.
+        with zero_grad()) and clears the poisoned state.  Call it on EVERY rank -- a rank that skips a collective its peers
+        issue would hang them."""
+        for works in self._works:
+            for w in works or ():
+                w.wait()
+        self._poisoned = False
+        self._arm()
+
     def finish(self):
         """Call after backward(): reduces the groups that are still held back (a parameter without a gradient, in them or in a
         group behind them) in the same fixed order, waits for every collective and re-arms the hooks for the next step."""
+        if self._poisoned:
+            raise RuntimeError("OverlappedGradReducer.finish(): the step protocol was broken (see the earlier error); call reset()")
         while self._next >= 0:
             self._launch(self._next)
         for works in self._works:

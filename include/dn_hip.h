@@ -489,24 +489,6 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
                                   const int32_t* add_idx, int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok,
                                   dn_stream_t stream);
-/* dn_rows_fused_bf16 (round 5): BOTH launches of one conv direction -- dn_rows_transform_bf16 over the edge rows and
- * dn_rows_close_bf16 -- as ONE persistent launch (rgin.py:156-160 is one update_all: message rgin.py:102-120 + reduce fn.sum +
- * apply rgin.py:137-146).  The unit stream of dn_rows_close_bf16 additionally holds TRANSFORM units {16 | flags, first row p, end
- * row, first row of S they are written to} (relation = bits 16-23 of flags; rows row_src[p] of X times Wrel[relation], [R][H][H] in
- * W_loop's layout, written to S with write-through stores), so that a workgroup alternates between the transform units of a later
- * chunk of the batch and the closing tiles of an earlier one and the product rows are read back while the Infinity Cache still
- * holds them.  Hand-off: flag 32 on a workgroup's last transform unit of a chunk (chunk = bits 24-31; every workgroup has one per
- * chunk, with zero rows if need be) -- once its stores have completed the workgroup adds 1 to done[chunk]; flag 64 on the first
- * closing unit of a chunk in a workgroup's stream (chunk = bits 16-31) -- its rows are requested once done[chunk] == num_wg.
- * A workgroup changes relation only at an EVEN position of its stream.  done [num_chunks] is zeroed by the call; *err (device) is
- * set to 1 if a wait exceeds 2 s (the launch then completes with wrong rows instead of hanging).  num_wg workgroups must be
- * resident together: num_wg <= the device's compute units.  fold_info / W_agg / aux / agg_idx: the absorbed fold exactly as in
- * dn_rows_close_bf16 (no fp32 partial rows here).  Same arithmetic and summation order as the two launches: bit-identical out / S. */
-int dn_rows_fused_bf16(const void* X, int32_t H, const void* Wrel, const void* W_loop, int32_t w_kn, const void* bias, void* S,
-                       const int32_t* row_src, const int32_t* unit_ptr, const int32_t* units, int32_t num_wg,
-                       const int32_t* ent_row, const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info,
-                       const void* W_agg, void* aux, const int32_t* agg_idx, int32_t* done, int32_t num_chunks, int32_t* err,
-                       dn_stream_t stream);
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,

@@ -91,17 +91,6 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     ok = ctypes.c_int32(0)
     rc = L.dn_fold_graph_tiles_build_i32(10, 2, None, None, None, None, None, ctypes.c_void_p(16), None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
-    # round-5 entry point (experimental: both launches of a conv direction as one)
-    rc = L.dn_rows_fused_bf16(None, 128, *([None] * 2), 0, *([None] * 5), 256, None, None, 8, *([None] * 6), 4, None, None)
-    assert rc == -1 and b"unsupported width" in L.dn_last_error()
-    rc = L.dn_rows_fused_bf16(None, 256, *([None] * 2), 0, *([None] * 5), 256, None, None, 8, *([None] * 6), 400, None, None)
-    assert rc == -1 and b"bad sizes" in L.dn_last_error()
-    rc = L.dn_rows_fused_bf16(None, 256, *([None] * 2), 0, *([None] * 5), 256, None, None, 8, None, None, ctypes.c_void_p(16), None, None,
-                              None, 4, None, None)
-    assert rc == -1 and b"go together" in L.dn_last_error()
-    assert L.dn_rows_fused_bf16(None, 256, *([None] * 2), 0, *([None] * 5), 256, None, None, 0, *([None] * 6), 4, None, None) == 0
-    rc = L.dn_rows_fused_bf16(None, 256, *([None] * 2), 0, *([None] * 5), 256, None, None, 8, *([None] * 6), 4, None, None)
-    assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     assert L.dn_bdd_compose(None, 0, 4, 16, 16, 2, None, None) == 0
     rc = L.dn_bdd_compose(None, 3, 4, 16, 16, 3, ctypes.c_void_p(16), ctypes.c_void_p(16), None) if False else L.dn_bdd_extract(
         ctypes.c_void_p(16), 3, 4, 16, 16, 3, ctypes.c_void_p(16), None)

@@ -229,8 +229,32 @@ def _overlap_uneven_worker(rank, world, port, q):
             (l1(torch.relu(l0(x))) + extra).square().mean().backward() # ... so a second backward without finish() must refuse
         except RuntimeError as e:
             raised = "finish()" in str(e)
+        try:                                                           # ... and the reducer stays unusable ...
+            reducer.finish()
+            raised = False
+        except RuntimeError as e:
+            raised = raised and "reset()" in str(e)
+        reducer.reset()                                                # ... until it is re-armed without communicating
+        # micro-batch accumulation: two backward() calls under no_sync() only accumulate, the third reduces the SUM
+        ps = list(l0.parameters()) + list(l1.parameters())
+        torch.manual_seed(7 + rank)
+        mbs = [torch.randn(4, 5) for _ in range(3)]
+        f = lambda xb: (l1(torch.relu(l0(xb))) + extra).square().mean()
+        want = [sum(gs) for gs in zip(*[torch.autograd.grad(f(xb), ps) for xb in mbs])]
+        for p in ps + [extra]:
+            p.grad = None
+        with reducer.no_sync():
+            for xb in mbs[:-1]:
+                f(xb).backward()
+                assert reducer.launched == []
+        f(mbs[-1]).backward()
         reducer.finish()
-        q.put((rank, orders, raised))
+        acc_ok = True
+        for p, w in zip(ps, want):
+            both = [torch.zeros_like(w) for _ in range(world)]
+            dist.all_gather(both, w.detach())
+            acc_ok = acc_ok and bool(torch.allclose(p.grad, (both[0] + both[1]) / 2, atol=1e-6))
+        q.put((rank, orders, raised and acc_ok))
     finally:
         dist.destroy_process_group()
 
