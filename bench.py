@@ -175,7 +175,7 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-def run_config4(args, rank, world, dev):
+def run_config4(args, rank, world, dev, emit=True):
     """BASELINE config 4: NCI1-shaped graphs + dummy nodes, GIN hidden 256 (default 2 layers), data parallel.
     One global batch of 512 x world graphs is cut into contiguous shards by parallel.shard_graphs (balanced by nodes +
     edges); every rank augments and runs its shard; BatchNorm statistics span the global batch (SyncBatchNorm1d); one
@@ -254,7 +254,7 @@ def run_config4(args, rank, world, dev):
         gE, gN = float(tot[0].item()), float(tot[1].item())
         # algorithmic bytes of the model's ONE GIN conv (default config: 2 layers = first_h + one GINConv), fwd + bwd
         alg = 2.0 * (gE * H * 4 + gN * H * 4 + 8.0 * gE)
-        print(json.dumps({
+        line = {
             "metric": "edges/sec fwd+bwd on dummy-augmented GIN model step (config 4)", "value": gE / (ms * 1e-3),
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -266,7 +266,129 @@ def run_config4(args, rank, world, dev):
             "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole training step of a 16 k-node batch per GPU: launch-bound, not a kernel roofline"},
-        }), flush=True)
+        }
+        if emit:
+            print(json.dumps(line), flush=True)
+        return line
+    return None
+
+
+def rgin_leg(dev, workload, dtype, steps, warmup, act="relu", regularizer="basis"):
+    """One more configuration on the N = 1 line (`secondary`): the RGINLayer step of `workload` in `dtype` -- batch, per-batch
+    index, captured step (forward + backward + bucket pack, replayed) and the conv's gather-scatter launches replayed on their
+    own, exactly as the main leg measures config 5 -- reduced to {ms, edges_per_s, launches_per_step, index_build_ms, roofline}."""
+    from dummynode4graphlearning_amd import ops
+    from dummynode4graphlearning_amd.parallel import FlatGradBucket
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    from dummynode4graphlearning_amd.subgraph_isomorphism.rgin import dense_relation_weights
+    H, R, graphs, seed = {"config3": (64, 8, 512, 3), "proteins": (256, 16, 16384, 2), "config5": (256, 16, 32768, 5)}[workload]
+    s = 2 if dtype == torch.bfloat16 else 4
+    g, raw, _ = build_batch(dev, seed, graphs, workload)
+    N, E = g.number_of_nodes(), g.number_of_edges()
+    et = g.edata["label"]
+    torch.manual_seed(1234)
+    layer = RGINLayer(H, H, num_rels=R, regularizer=regularizer, num_bases=4 if regularizer == "bdd" else -1, num_mlp_layers=2,
+                      act_func=act).to(dev).to(dtype)
+    bucket = FlatGradBucket(layer.parameters())
+    gen = torch.Generator(device=dev).manual_seed(100)
+    x = torch.randn(N, H, device=dev, generator=gen).to(dtype).requires_grad_(True)
+    gout = torch.randn(N, H, device=dev, generator=gen).to(dtype)
+
+    def build_index():
+        g._cache.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix = g.row_index(et, R, True, closing_hint=(H, dtype))
+        if dtype == torch.bfloat16:
+            for _, _, part in ix.parts:
+                ops.prepare_closing(part, H, dtype)
+        torch.cuda.synchronize()
+        return ix, (time.perf_counter() - t0) * 1e3
+
+    index, _ = build_index()
+    index, index_ms = build_index()
+
+    def compute():
+        bucket.zero(set_to_none=True)
+        x.grad = None
+        out, _ = layer(g, x, et)
+        out.backward(gout)
+        bucket.pack()
+
+    def conv():
+        with torch.no_grad():
+            W = dense_relation_weights(layer)
+            fw = ops.PassWeights(W, layer.loop_weight, kn=True)
+            if not ops._kn_ok(x):
+                fw = fw.nk()
+            bw = ops.PassWeights(W, layer.loop_weight, kn=False)
+            ybuf = index.ybuf(H, dtype, dev)
+            for n0, n1, ix in index.parts:
+                ops.message_pass(x[n0:n1], fw, layer.bias, ix, "f", ybuf, cg_out[n0:n1])
+                ops.message_pass(gout[n0:n1], bw, None, ix, "b", ybuf, cg_out[n0:n1])
+
+    def graphed(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            return gr.replay, True
+        except Exception as exc:
+            sys.stderr.write("[bench] HIP graph capture failed in a secondary leg (%s); timing eager launches\n" % exc)
+            torch.cuda.synchronize()
+            return fn, False
+
+    def timed(fn, reps, warm):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for _ in range(2):
+        compute()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    compute()                                           # eager pass: the library launches of the whole step
+    ops.kernel_timer = None
+    step_launches = len(timer.records)
+    step, is_graph = graphed(compute)
+    # (small steps: more replays for the same GPU time, as for the strong-scaling proxy)
+    mult = 8 if N < 200000 else 1
+    ms = timed(step, mult * steps, mult * warmup)
+    cg_out = torch.empty((N, H), dtype=dtype, device=dev)
+    conv()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    conv()
+    ops.kernel_timer = None
+    n_launch = len(timer.records)
+    replay_conv, _ = graphed(conv)
+    kms = timed(replay_conv, mult * max(steps, 5), 2)
+    alg = 2.0 * (E * H * s + N * H * s + 8.0 * E)
+    ach = alg / (kms * 1e-3) / 1e9
+    return {"workload": "%s: RGINLayer(%d,%d,R=%d,%s,%s) fwd+bwd, %d graphs, N=%d, E=%d, %s, SI dummy augmentation"
+                        % (workload, H, H, R, regularizer, act, graphs, N, E, "bf16" if dtype == torch.bfloat16 else "f32"),
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "ms": ms, "edges_per_s": E / (ms * 1e-3),
+            "index_build_ms": index_ms, "hip_graph": is_graph, "launches_per_step": step_launches, "conv_launches_per_step": n_launch,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "launches_per_step": n_launch, "kernel_ms_per_step": kms, "alg_bytes_per_step": alg,
+                         "note": "the conv's gather-scatter launches (both directions) replayed on their own, HIP events"}}
 
 
 def main():
@@ -291,6 +413,7 @@ def main():
     ap.add_argument("--regularizer", default="basis", choices=["basis", "bdd"],
                     help="relation-weight parameterisation (the reference CLI's default is bdd with 4 bases, config.py:145-158)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 4 / proteins legs of the default line")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     args = ap.parse_args()
     if args.steady:
@@ -646,6 +769,28 @@ def main():
                "note": "frac = compulsory HBM bytes / time / 8 TB/s; the gathered rows (l2_gather_GBps) are served by L2"}
         del x2, go2, ei, replay_gin
 
+    # the other configurations of BASELINE.json on the same line (rank 0, N = 1, default workload only): config 3 in the reference's
+    # own precision and in bf16, one rank of config 4, and the config-5 layer on PROTEINS-shaped graphs.  They run LAST: nothing
+    # above is timed behind them.
+    secondary = {}
+    if rank == 0 and world == 1 and args.workload == "config5" and not args.steady and not args.no_secondary and not args.graphs:
+        from types import SimpleNamespace
+        for key, (wl, dt_) in (("config3_f32", ("config3", torch.float32)), ("config3_bf16", ("config3", torch.bfloat16)),
+                               ("proteins_bf16", ("proteins", torch.bfloat16))):
+            try:
+                secondary[key] = rgin_leg(dev, wl, dt_, args.steps, args.warmup)
+            except Exception as exc:                    # (never lose the line to a secondary leg)
+                sys.stderr.write("[bench] secondary leg %s failed: %r\n" % (key, exc))
+            torch.cuda.empty_cache()
+        try:
+            c4 = run_config4(SimpleNamespace(graphs=0, hidden=0, no_graph=False, warmup=args.warmup, steps=8 * args.steps), 0, 1, dev,
+                             emit=False)
+            secondary["config4_one_rank"] = {"workload": c4["config"]["workload"], "dtype": c4["dtype"], "ms": c4["ms_per_step"],
+                                             "edges_per_s": c4["value"], "hip_graph": c4["config"]["hip_graph"],
+                                             "launches_per_step": None, "roofline": c4["roofline"]}
+        except Exception as exc:
+            sys.stderr.write("[bench] secondary leg config4 failed: %r\n" % (exc,))
+
     if rank == 0:
         line = {
             "metric": "edges/sec fwd+bwd on dummy-augmented RGIN conv", "value": e_glob / (ms_per_step * 1e-3),
@@ -675,6 +820,8 @@ def main():
         }
         if gin is not None:
             line["secondary"] = {"gin_conv_gather": gin}
+        if secondary:
+            line.setdefault("secondary", {}).update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw, H, R)
         print(json.dumps(line), flush=True)

@@ -51,6 +51,7 @@ struct Unit {
 // flags: bit 0 entry unit, bit 1 last unit of its tile (epilogue), bit 2 AGG unit, bit 3 NOP unit, bits 8-15 rows of the tile
 constexpr int kUnitEntry = 1, kUnitLast = 2, kUnitAgg = 4, kUnitNop = 8;
 constexpr int kUnitXcd = 16;           // on an AGG unit: the workgroup's tiles follow the XCD order below (aux = the number of tiles)
+constexpr int kUnitAggAbs = 32;        // on an AGG unit: [beg, end) are the aux rows (= graphs) themselves (order 2)
 
 // Which tile is the n-th of workgroup w (of G)?
 //   order 0: w + G n -- the launch walks the batch upwards as ONE front;
@@ -68,6 +69,36 @@ __device__ __forceinline__ void cb_position(int32_t t, int32_t T, int32_t G, int
     last = r + W8 >= hi - lo;
 }
 constexpr int kAggGap = 8;             // NOP units between a workgroup's last tile and its first AGG unit (>= the loaders' run-ahead)
+
+// Order 2 (round 6: graphs that span several tiles, dn_fold_graph_tiles_multi_build_i32).  The tiles are cut into G CHUNKS at graph
+// boundaries -- graph j (first tile tile_first[j]) belongs to chunk floor(tile_first[j] G / T) -- so that a graph's tiles follow
+// each other in ONE stream (the per-graph column sum accumulates across them in registers, the AGG unit's read-modify-write of
+// the dummy node's row stays inside the workgroup that stored it).  A chunk = a contiguous range of graphs = a contiguous range
+// of tiles, walked upwards; tables are laid out in tile order, unit_ptr is indexed by CHUNK, and the launch gives chunk
+// (w & 7) G/8 + (w >> 3) to workgroup w (G a multiple of 8: XCD x = the x-th eighth of the batch, as the transform's sweep order).
+__device__ __forceinline__ int32_t cb2_chunk(int32_t tile_first_j, int32_t T, int32_t G) { return (int32_t)(((int64_t)tile_first_j * G) / T); }
+__device__ __forceinline__ int32_t cb2_first_graph(int32_t c, int32_t T, int32_t G, const int32_t* __restrict__ tile_first, int32_t S) {
+    const int32_t want = (int32_t)(((int64_t)c * T + G - 1) / G);         // first j in [0, S] with tile_first[j] >= ceil(c T / G)
+    int32_t lo = 0, hi = S;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (tile_first[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// is tile t the last of its chunk?  -> the chunk's graphs [g_lo, g_hi)
+__device__ __forceinline__ bool cb2_last_of_chunk(int32_t t, int32_t T, int32_t G, const int32_t* __restrict__ tile_first,
+                                                  const int32_t* __restrict__ tile_graph, int32_t S, int32_t& g_lo, int32_t& g_hi) {
+    const int32_t j = tile_graph[t], c = cb2_chunk(tile_first[j], T, G);
+    if (t + 1 < T) {
+        const int32_t j1 = tile_graph[t + 1];
+        if (j1 == j || cb2_chunk(tile_first[j1], T, G) == c) return false;
+    }
+    g_lo = cb2_first_graph(c, T, G, tile_first, S);
+    g_hi = j + 1;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------------- tables
 constexpr int kCbWaves = 4;            // tiles per workgroup of the builder (one wavefront each)
@@ -109,6 +140,8 @@ struct CbLds {
 // backward stream of a batch in ONE set of launches; dn_close_units_build_i32 passes one).
 struct CbDir {
     const int32_t *tile_ptr, *lptr, *lrows, *drop_enable, *dyn;
+    const int32_t *tile_graph, *tile_first;                                // order 2: tile -> graph, graph -> first tile [S + 1]
+    int32_t S;
     int32_t *ent_row, *tile_cnt, *ucnt, *unit_ptr;
     uint32_t* ent_mask;
     const int32_t* uoff;
@@ -125,6 +158,11 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     const int t = (int)blockIdx.x * kCbWaves + wave;
     if (t >= T) return;                                                    // (no workgroup barrier below)
     const CbDir& a = pr.d[blockIdx.y];
+    if (order == 2) {                                                      // T was a bound: the tiles there are
+        if (a.dyn != nullptr && a.dyn[3] == 0) return;
+        T = a.tile_first[a.S];
+        if (t >= T) return;
+    }
     const int32_t* __restrict__ tile_ptr = a.tile_ptr;
     const int32_t* __restrict__ lptr = a.lptr;
     const int32_t* __restrict__ lrows = a.lrows;
@@ -145,9 +183,18 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     auto kept = [&](int r) { return r < P && !(r >= drop_beg && r < drop_end); };
     // units of this tile in the workgroup-major table: one X unit + one per 32 entries; a workgroup's LAST tile also carries the
     // workgroup's NOP gap and AGG units (one per 32 of its pn + 1 tiles)
-    int32_t pw, pn;
+    int32_t pw = 0, pn = 0;
     bool plast;
-    cb_position(t, T, G, order, pw, pn, plast);
+    int64_t upos;                                                          // where this tile's unit count goes (the scan's order)
+    if (order == 2) {
+        int32_t g_lo = 0, g_hi = 0;
+        plast = cb2_last_of_chunk(t, T, G, a.tile_first, a.tile_graph, a.S, g_lo, g_hi);
+        pn = g_hi - g_lo - 1;                                              // (pn + 1 = the chunk's graphs)
+        upos = t;
+    } else {
+        cb_position(t, T, G, order, pw, pn, plast);
+        upos = (int64_t)pw * Tper + pn;
+    }
     auto units_of = [&](int c) { return 1 + (c + 31) / 32 + ((agg && plast) ? kAggGap + (pn + 1 + 31) / 32 : 0); };
     bool plain = raw > kCbCap;
     if (!plain) {
@@ -241,7 +288,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
                 ent_row[lb + rank] = (int32_t)ri;
                 ent_mask[lb + rank] = L.smask[i];
             }
-            if (lane == 0) { tile_cnt[t] = n; ucnt[(int64_t)pw * Tper + pn] = units_of(n); }
+            if (lane == 0) { tile_cnt[t] = n; ucnt[upos] = units_of(n); }
             return;
         }
     }
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
         if (!kept(r)) continue;
         ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
     }
-    if (lane == 0) { tile_cnt[t] = total; ucnt[(int64_t)pw * Tper + pn] = units_of(total); }
+    if (lane == 0) { tile_cnt[t] = total; ucnt[upos] = units_of(total); }
 }
 
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
@@ -273,12 +320,21 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
     const int32_t* __restrict__ uoff = a.uoff;
     Unit* __restrict__ units = a.units;
     const int32_t base = uoff[0];                                          // (both directions share one scan: the second starts at the first's total)
-    if (t <= G) a.unit_ptr[t] = uoff[t * Tper] - base;                     // (position G * Tper holds the total)
-    if (t >= T) return;
-    int32_t w, n;
+    int32_t w = 0, n = 0, g_lo = 0, g_hi = 0;
     bool plast;
-    cb_position((int32_t)t, T, G, order, w, n, plast);
-    const int64_t k = (int64_t)w * Tper + n;
+    int64_t k;
+    if (order == 2) {
+        T = a.tile_first[a.S];                                             // (the argument was a bound)
+        if (t <= G) a.unit_ptr[t] = uoff[a.tile_first[cb2_first_graph((int32_t)t, T, G, a.tile_first, a.S)]] - base;   // unit_ptr by CHUNK
+        if (t >= T) return;
+        plast = cb2_last_of_chunk((int32_t)t, T, G, a.tile_first, a.tile_graph, a.S, g_lo, g_hi);
+        k = t;
+    } else {
+        if (t <= G) a.unit_ptr[t] = uoff[t * Tper] - base;                 // (position G * Tper holds the total)
+        if (t >= T) return;
+        cb_position((int32_t)t, T, G, order, w, n, plast);
+        k = (int64_t)w * Tper + n;
+    }
     const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
     const int32_t pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N);
     const int32_t c = tile_cnt[t], e0 = lptr[p0], rows = (pend - p0) << 8;
@@ -292,6 +348,11 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
         Unit* q = u + 1 + ne;
         for (int i = 0; i < kAggGap; ++i) q[i] = Unit{kUnitNop, 0, 1, 0};
         q += kAggGap;
+        if (order == 2) {                                                  // the chunk's graphs themselves
+            for (int i = 0; g_lo + 32 * i < g_hi; ++i)
+                q[i] = Unit{kUnitAgg | kUnitLast | kUnitAggAbs, g_lo + 32 * i, min(g_lo + 32 * (i + 1), g_hi), 0};
+            return;
+        }
         for (int i = 0; 32 * i < nw; ++i) q[i] = Unit{kUnitAgg | kUnitLast | (order ? kUnitXcd : 0), 32 * i, min(32 * (i + 1), nw), order ? T : 0};
     }
 }

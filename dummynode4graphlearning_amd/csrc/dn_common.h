@@ -255,7 +255,73 @@ __device__ __forceinline__ void dn_fold_graph_tile_one(int64_t j, int32_t N, int
     int32_t* rec = info + (size_t)j * 12;
     for (int i = 0; i < 8; ++i)
         rec[i] = (int32_t)((uint32_t)ids[4 * i] | ((uint32_t)ids[4 * i + 1] << 8) | ((uint32_t)ids[4 * i + 2] << 16) | ((uint32_t)ids[4 * i + 3] << 24));
-    rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 0; rec[11] = 0;
+    rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 2; rec[11] = 0;                // [10]: bit 0 = continues the previous tile's sum, bit 1 = completes it
+}
+
+// The same for graphs of ANY size (round 6): block j is cut into ceil(nodes / 32) consecutive tiles that the unit stream keeps in ONE
+// workgroup, the column sum of the segment accumulating across them.  Two passes around one exclusive scan:
+//   count: the validity test above without the 32-node limit; ntiles[j] = tiles of block j (0 for j = S and for a bad segment)
+//   (exclusive scan of ntiles [S + 1] -> tile_first [S + 1]; tile_first[S] = T)
+//   fill:  tile_ptr [T + 1], tile_graph [T], fold record per tile {local ids: 0 inside the segment, 255 outside; aux row = j;
+//          count = 1; bit 0 = not the block's first tile, bit 1 = its last}.  Does nothing when *ok == 0 (the bounds the caller sized
+//          the tables by -- T <= S + N / 32 -- only hold for a valid batch).
+__device__ __forceinline__ bool dn_fold_multi_block(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                    const int32_t* __restrict__ snodes, int32_t& first, int32_t& last, int32_t& b0,
+                                                    int32_t& nxt) {
+    const int32_t cnt = sptr[j + 1] - sptr[j];
+    bool good = cnt > 0;
+    first = last = 0; nxt = N;
+    if (good) {
+        first = snodes[sptr[j]];
+        last = snodes[sptr[j + 1] - 1];
+        good = first >= 0 && last < N && last - first == cnt - 1;
+        if (good && j + 1 < S) {
+            good = sptr[j + 2] > sptr[j + 1];
+            if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
+        }
+    }
+    b0 = j == 0 ? 0 : first;
+    return good && nxt - b0 >= 1;
+}
+__device__ __forceinline__ void dn_fold_multi_count_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                        const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
+                                                        int32_t* __restrict__ ntiles, int32_t* __restrict__ ok) {
+    if (j > S) return;
+    if (j == S) { ntiles[S] = 0; return; }
+    int32_t first, last, b0, nxt;
+    bool good = dn_fold_multi_block(j, N, S, sptr, snodes, first, last, b0, nxt);
+    for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
+    if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
+    ntiles[j] = good ? (nxt - b0 + 31) / 32 : 0;
+    if (!good) {
+        __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+__device__ __forceinline__ void dn_fold_multi_fill_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                       const int32_t* __restrict__ snodes, const int32_t* __restrict__ tile_first,
+                                                       int32_t* __restrict__ tile_ptr, int32_t* __restrict__ tile_graph,
+                                                       int32_t* __restrict__ info) {
+    if (j > S) return;
+    if (j == S) { tile_ptr[tile_first[S]] = N; return; }
+    int32_t first, last, b0, nxt;
+    if (!dn_fold_multi_block(j, N, S, sptr, snodes, first, last, b0, nxt)) return;
+    const int32_t t0 = tile_first[j], nt = tile_first[j + 1] - t0;
+    for (int32_t k = 0; k < nt; ++k) {
+        const int32_t p0 = b0 + 32 * k;
+        tile_ptr[t0 + k] = p0;
+        tile_graph[t0 + k] = (int32_t)j;
+        int32_t* rec = info + (size_t)(t0 + k) * 12;
+        for (int i = 0; i < 8; ++i) {
+            uint32_t w = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int32_t v = p0 + 4 * i + b;
+                w |= ((v >= first && v <= last && v < nxt) ? 0u : 255u) << (8 * b);
+            }
+            rec[i] = (int32_t)w;
+        }
+        rec[8] = (int32_t)j; rec[9] = 1; rec[10] = (k > 0 ? 1 : 0) | (k == nt - 1 ? 2 : 0); rec[11] = 0;
+    }
 }
 
 // ---- ReLU / leaky ReLU.  slope = 0: ReLU (max(v, 0): the negative side is an exact 0 whatever v is); slope > 0: leaky ReLU, the

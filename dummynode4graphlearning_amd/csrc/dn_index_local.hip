@@ -22,7 +22,15 @@
 //                      cost); larger graphs: all lanes at once against ONE edge whose packed words are wave-uniform (broadcast
 //                      LDS read -> SGPRs), O(m^2) compares, no branch on the common path
 //
-// Graphs with more than kLocM edges or kLocNodes nodes, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
+// Round 6: graphs that do not fit the bit-set pass no longer compare all pairs of edges (O(m^2) per graph: 2.7 ms for the fill pass
+// of 16,384 PROTEINS-shaped graphs).  Their ranks come from SORTS in LDS -- one bitonic sort of the packed (relation, key node,
+// edge) words gives every edge's position, two more of (node, position) words the ranks inside the nodes' lists, prefix counts of
+// the bucket starts the collapsed rows' numbers -- O(m log^2 m), identical tables.  And a graph over kLocM edges no longer sends
+// the WHOLE batch to the general builder: the one-wavefront kernels skip it and list it, and a second launch of each pass
+// (ril_stats_big_kernel / ril_fill_big_kernel: one 1024-thread workgroup per listed graph, the same sort code on 16 wavefronts)
+// takes graphs of up to kBigM - 1 edges and kBigNodes nodes.  An empty list costs two empty launches.
+//
+// Graphs beyond those limits, an endpoint outside the graph's node range or a relation id outside [0, R) raise a flag
 // instead (host_status = 1): the caller then runs the general builder.
 #include <cstring>
 #include <cstdlib>
@@ -35,11 +43,14 @@
 
 namespace {
 
-constexpr int kLocM = 1024;          // edges of one graph held in LDS
+constexpr int kLocM = 1024;          // edges of one graph held in one wavefront's LDS slice
+constexpr int kBigM = 8192;          // ... in a whole workgroup's (the listed graphs: kLocM < edges < kBigM)
+constexpr int kBigNodes = 8191;      // nodes of a listed graph (13-bit local ids next to 13-bit edge numbers)
+constexpr int kBigWaves = 16;        // wavefronts that share one listed graph
+constexpr int kBigGrid = 128;        // workgroups of the two launches over the list
 constexpr int kLocNodes = 1 << 14;   // nodes of one graph (local ids are packed into 14 bits)
 constexpr int kLocWaves = 4;         // graphs in flight per workgroup (one wavefront each)
 constexpr int kLocR = 64;            // relations (per-workgroup counters, one lane per relation)
-constexpr int kLocCG = 4;            // 64-edge chunks a lane keeps in registers per pass over the graph
 constexpr int kEdge = 0, kAgg = 1, kTf = 2;
 constexpr int kSeg = 5;              // packed count arrays over (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges
 typedef uint32_t u32;
@@ -61,6 +72,75 @@ __device__ __forceinline__ int mode_of(int32_t Er, int32_t Dr, int32_t Sr, float
     return Dr <= Sr ? kAgg : kTf;
 }
 __device__ __forceinline__ u32 sgpr(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---- the sort path: NW wavefronts (64 NW threads, `tid` among them) work on one graph's arrays in LDS.  NW = 1: the wavefront's own
+// slice, ordered by the in-order LDS queue (a scheduling barrier is enough); NW > 1: the whole workgroup, real barriers.
+template <int NW>
+__device__ __forceinline__ void coop_sync() {
+    if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+template <int NW>
+__device__ __forceinline__ bool coop_any(bool v) {
+    if constexpr (NW == 1) return __any(v) != 0;
+    else return __syncthreads_or(v ? 1 : 0) != 0;
+}
+// ascending bitonic sort of A[0 .. n), n a power of two >= 64 (the caller pads with 0xffffffff)
+template <int NW>
+__device__ __forceinline__ void bitonic_sort(u32* A, int n, int tid) {
+    constexpr int NT = 64 * NW;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n >> 1); t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // bit j clear
+                const int l = i | j;
+                const u32 a = A[i], b = A[l];
+                const bool up = (i & k) == 0;
+                const u32 lo = a < b ? a : b, hi = a < b ? b : a;
+                A[i] = up ? lo : hi;
+                A[l] = up ? hi : lo;
+            }
+            coop_sync<NW>();
+        }
+    }
+}
+__device__ __forceinline__ int lds_lower_bound(const u32* A, int n, u32 key) {   // first p in [0, n) with A[p] >= key (n: none)
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// exclusive scan of one value per thread, in thread order: sum (identity 0) or max (identity -1).  scratch: NW + 1 ints (NW > 1).
+template <int NW, bool MAX>
+__device__ __forceinline__ int coop_excl_scan(int v, int tid, int* scratch) {
+    const int lane = tid & 63;
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(s, d, 64);
+        if (lane >= d) s = MAX ? (o > s ? o : s) : s + o;
+    }
+    int excl = __shfl_up(s, 1, 64);
+    if (lane == 0) excl = MAX ? -1 : 0;
+    if constexpr (NW > 1) {
+        const int wave = tid >> 6;
+        if (lane == 63) scratch[wave] = s;
+        __syncthreads();
+        int carry = MAX ? -1 : 0;
+        for (int w = 0; w < wave; ++w) carry = MAX ? (scratch[w] > carry ? scratch[w] : carry) : carry + scratch[w];
+        __syncthreads();
+        excl = MAX ? (carry > excl ? carry : excl) : excl + carry;
+    }
+    return excl;
+}
+__device__ __forceinline__ int pow2_at_least(int m) {
+    int n = 64;
+    while (n < m) n <<= 1;
+    return n;
+}
 
 // body(j, w0, w1) for the edges j = 0 .. jend-1 (and possibly one more: a later edge or a sentinel -- every body is written so
 // that such an edge contributes nothing), their two words wave-uniform in SGPRs; two edges per LDS read, the next pair in flight
@@ -115,33 +195,57 @@ __device__ __forceinline__ int load_graph(uint2* X, int lane, int64_t g, int32_t
     return m;
 }
 
-template <int NC>
-__device__ __forceinline__ void stats_pass(const uint2* X, int lane, int m, int c0, int32_t (*cnt)[kLocR], uint8_t* hb) {
-    u32 kd[NC], ks[NC], dd[NC], ds[NC];
-    int mine[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        mine[c] = (c0 + c) * 64 + lane;
-        const uint2 x = mine[c] < m ? X[mine[c]] : make_uint2(0xfffffffeu, 0xfffffffeu);
-        kd[c] = x.x; ks[c] = x.y; dd[c] = 0; ds[c] = 0;
+// The statistics of a graph from two SORTS (graphs the hash table below does not take): the words (relation, destination, edge)
+// sorted, an edge is the first of its (relation, destination) pair exactly when its predecessor has another pair; the same with
+// the sources.  A: n words, F: m words (a flag byte per edge would do; words keep the accesses plain).  NBITS: bits of a local
+// node id, EB: bits of an edge number (6 + NBITS + EB <= 32).
+template <int NW, int EB, int NBITS>
+__device__ __forceinline__ void stats_sorted(u32* A, u32* F, int tid, int n0, int n1, int e0, int m, int32_t R,
+                                             const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                             const int32_t* __restrict__ etype, int32_t (*cnt)[kLocR], uint8_t* __restrict__ hbits,
+                                             int32_t* bad) {
+    constexpr int NT = 64 * NW;
+    constexpr u32 EM = (1u << EB) - 1u;
+    static_assert(6 + NBITS + EB <= 32, "packed word");
+    const int n = pow2_at_least(m);
+    bool oob = false;
+    for (int i = tid; i < n; i += NT) {
+        u32 key = 0xffffffffu;
+        if (i < m) {
+            const int r = etype[e0 + i], sv = src[e0 + i], d = dst[e0 + i];
+            const bool o = (sv < n0) | (sv >= n1) | (d < n0) | (d >= n1) | (r < 0) | (r >= R);
+            oob |= o;
+            if (!o) key = ((((u32)r << NBITS) | (u32)(d - n0)) << EB) | (u32)i;
+            F[i] = 0;
+        }
+        A[i] = key;
     }
-    for_each_edge(X, min(m, (c0 + NC) * 64), [&](int j, u32 dj, u32 sj) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const u32 later = (u32)(mine[c] > j);
-            dd[c] |= (u32)(kd[c] == dj) & later;                          // an earlier edge with my (relation, destination)
-            ds[c] |= (u32)(ks[c] == sj) & later;
-        }
-    });
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if (mine[c] < m) {
-            const int r = (int)(kd[c] >> 14);
-            hb[mine[c]] = (uint8_t)(dd[c] | (ds[c] << 1));                  // (read back by the two later passes: no second search)
-            atomicAdd(&cnt[0][r], 1);
-            if (dd[c] == 0) atomicAdd(&cnt[1][r], 1);
-            if (ds[c] == 0) atomicAdd(&cnt[2][r], 1);
-        }
+    if (coop_any<NW>(oob)) {                                               // (the graph is not taken: nothing has been counted)
+        if (tid == 0) atomicOr(bad, 1);
+        coop_sync<NW>();
+        return;
+    }
+    coop_sync<NW>();
+    bitonic_sort<NW>(A, n, tid);
+    for (int p = tid; p < m; p += NT)
+        if (p > 0 && (A[p] >> EB) == (A[p - 1] >> EB)) F[A[p] & EM] = 1u;  // an earlier edge has my (relation, destination)
+    coop_sync<NW>();
+    for (int i = tid; i < n; i += NT)
+        A[i] = i < m ? ((((u32)etype[e0 + i] << NBITS) | (u32)(src[e0 + i] - n0)) << EB) | (u32)i : 0xffffffffu;
+    coop_sync<NW>();
+    bitonic_sort<NW>(A, n, tid);
+    for (int p = tid; p < m; p += NT)
+        if (p > 0 && (A[p] >> EB) == (A[p - 1] >> EB)) F[A[p] & EM] |= 2u;
+    coop_sync<NW>();
+    for (int i = tid; i < m; i += NT) {
+        const u32 hb = F[i];
+        const int r = etype[e0 + i];
+        hbits[e0 + i] = (uint8_t)hb;                                       // (read back by the two later passes: no second search)
+        atomicAdd(&cnt[0][r], 1);
+        if ((hb & 1u) == 0) atomicAdd(&cnt[1][r], 1);
+        if ((hb & 2u) == 0) atomicAdd(&cnt[2][r], 1);
+    }
+    coop_sync<NW>();                                                       // the next graph overwrites the arrays
 }
 
 // The statistics of a graph with at most kHashM edges WITHOUT pair work: both keys of every edge -- (relation, destination) and
@@ -205,12 +309,21 @@ __device__ __forceinline__ void stats_hashed(u32* tab, int lane, int64_t g, int3
     __builtin_amdgcn_wave_barrier();                                       // the next graph re-initialises the table
 }
 
+// Which pass takes graph g?  0: nobody (flagged), 1: the one-wavefront kernels, 2: the listed-graph kernels.
+__device__ __forceinline__ int graph_class(int64_t g, const int32_t* node_ptr, const int32_t* edge_ptr, int64_t N, int64_t E) {
+    const int n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
+    // (ranges that leave [0, N) / [0, E) would index past the caller's arrays: never touch such a graph)
+    if (m < 0 || n1 < n0 || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) return 0;
+    if (m <= kLocM) return n1 - n0 <= kLocNodes ? 1 : 0;
+    return (m < kBigM && n1 - n0 <= kBigNodes) ? 2 : 0;
+}
+
 __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, int32_t R, const int32_t* __restrict__ node_ptr,
                                                                    const int32_t* __restrict__ edge_ptr,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                                    const int32_t* __restrict__ etype, int64_t N, int64_t E,
                                                                    int32_t* Er, int32_t* Dr, int32_t* Sr, int32_t* bad,
-                                                                   uint8_t* __restrict__ hbits) {
+                                                                   uint8_t* __restrict__ hbits, int32_t* __restrict__ big_list) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ int32_t cnt[3][kLocR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,20 +334,49 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         atomicOr(bad, 1);
     __syncthreads();
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
-        int n0, n1, e0;
-        if (edge_ptr[g + 1] - edge_ptr[g] <= kHashM) {                     // up to 256 edges: first occurrences through a hash table
+        const int cls = graph_class(g, node_ptr, edge_ptr, N, E);
+        if (cls == 0) {
+            if (lane == 0) atomicOr(bad, 1);
+            continue;
+        }
+        if (cls == 2) {                                                    // over this wavefront's slice: listed for ril_stats_big_kernel
+            if (lane == 0) big_list[1 + atomicAdd(big_list, 1)] = (int32_t)g;
+            continue;
+        }
+        const int m = edge_ptr[g + 1] - edge_ptr[g];
+        if (m <= kHashM) {                                                 // up to 256 edges: first occurrences through a hash table
             stats_hashed(reinterpret_cast<u32*>(X), lane, g, R, node_ptr, edge_ptr, src, dst, etype, N, E, cnt, hbits, bad);
             continue;
         }
-        const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, nullptr, nullptr, N, E, n0, n1, e0, bad);
-        if (m <= 0) continue;
-        for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
-            const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
-            if (nc == 1) stats_pass<1>(X, lane, m, c0, cnt, hbits + e0);
-            else if (nc == 2) stats_pass<2>(X, lane, m, c0, cnt, hbits + e0);
-            else stats_pass<kLocCG>(X, lane, m, c0, cnt, hbits + e0);
-        }
-        __builtin_amdgcn_wave_barrier();                                   // the next graph overwrites this wavefront's slice
+        u32* A = reinterpret_cast<u32*>(X);
+        stats_sorted<1, 10, 14>(A, A + kLocM, lane, node_ptr[g], node_ptr[g + 1], edge_ptr[g], m, R, src, dst, etype, cnt, hbits, bad);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * kLocR) {
+        const int k = threadIdx.x / kLocR, r = threadIdx.x % kLocR;
+        if (r < R && cnt[k][r] != 0) atomicAdd((k == 0 ? Er : k == 1 ? Dr : Sr) + r, cnt[k][r]);
+    }
+}
+
+// The same statistics for the listed graphs (kLocM < edges < kBigM): one workgroup of kBigWaves wavefronts per graph.
+// big_list[0] = their number (left by ril_stats_kernel), big_list[1 ...] = the graphs, in no particular order.
+__global__ __launch_bounds__(kBigWaves * 64) void ril_stats_big_kernel(int32_t R, const int32_t* __restrict__ node_ptr,
+                                                                       const int32_t* __restrict__ edge_ptr,
+                                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                                       const int32_t* __restrict__ etype, int32_t* Er, int32_t* Dr,
+                                                                       int32_t* Sr, int32_t* bad, uint8_t* __restrict__ hbits,
+                                                                       const int32_t* __restrict__ big_list) {
+    __shared__ __attribute__((aligned(16))) u32 A[kBigM];
+    __shared__ __attribute__((aligned(16))) u32 F[kBigM];
+    __shared__ int32_t cnt[3][kLocR];
+    const int nbig = big_list[0];
+    if ((int)blockIdx.x >= nbig) return;
+    if (threadIdx.x < 3 * kLocR) cnt[threadIdx.x / kLocR][threadIdx.x % kLocR] = 0;
+    __syncthreads();
+    for (int k = blockIdx.x; k < nbig; k += gridDim.x) {
+        const int64_t g = big_list[1 + k];
+        stats_sorted<kBigWaves, 13, 13>(A, F, (int)threadIdx.x, node_ptr[g], node_ptr[g + 1], edge_ptr[g], edge_ptr[g + 1] - edge_ptr[g], R,
+                                        src, dst, etype, cnt, hbits, bad);
     }
     __syncthreads();
     if (threadIdx.x < 3 * kLocR) {
@@ -275,7 +417,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_count_kernel(int64_t G, in
     const int my_mode = s_mode[lane];
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         const int n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0, n = n1 - n0;
-        if (m < 0 || m > kLocM || n < 0 || n > kLocNodes || n0 < 0 || n1 > N || e0 < 0 || (int64_t)e0 + m > E) continue;   // (flagged)
+        if (graph_class(g, node_ptr, edge_ptr, N, E) == 0) continue;        // (flagged)
         s_rel[wave][0][lane] = 0; s_rel[wave][1][lane] = 0;
         for (int v0 = 0; v0 < max(n, 1); v0 += kLocCnt) {
             for (int i = lane; i < kLocCnt; i += 64) cnt[i] = 0;
@@ -369,44 +511,134 @@ __device__ __forceinline__ void fill_emit(const Ranks<NC>& K, int lane, int m, i
     }
 }
 
-// my edges of this pass (one per chunk) against every edge j of the graph.  j's words are wave-uniform (SGPRs): the common
-// path is a handful of compares and conditional adds per lane with uniform weights (no branch); the two counts only collapsed
-// rows need sit behind a uniform branch that is taken for the few heads of collapsed relations.  O(m^2): the form for graphs
-// the bit-set pass below does not take.
-template <int NC>
-__device__ __forceinline__ void fill_pass(const uint2* X, int lane, int m, int c0, int64_t g, int n0, const FillArgs& A) {
-    Ranks<NC> K;
-    u32 rc[NC], dc[NC], sc[NC], ck[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c0 + c) * 64 + lane;
-        const uint2 x = i < m ? X[i] : make_uint2(kSentinel0, kSentinel1);
-        K.w0[c] = x.x; K.w1[c] = x.y;
-        rc[c] = x.x >> 26; dc[c] = x.y & 0x3fffu; sc[c] = (x.y >> 14) & 0x3fffu;
-        ck[c] = (((x.y >> 28) & 3u) << 16) | ((x.x >> 10) & 0xffffu);     // mode, key node
-        K.rank_rel[c] = K.heads_before[c] = K.rank_d[c] = K.rank_s[c] = K.later_rows[c] = 0;
+// One edge's table entries from its five ranks (fill_emit for a single edge).
+__device__ __forceinline__ void fill_emit_one(u32 r, u32 md, u32 hd, int s, int d, int rank_rel, int heads_before, int rank_d, int rank_s,
+                                              int later_rows, int64_t g, const FillArgs& A) {
+    const int kn = md == kTf ? s : d;
+    const int64_t at = (int64_t)r * A.G + g;
+    const int32_t row = A.S0[at] + (md == kEdge ? rank_rel : heads_before);
+    if (md == kEdge) {
+        A.row_in[row] = s; A.row_out[row] = d;
+    } else if (md == kAgg) {
+        const int32_t pos = A.S3[at] - A.b3 + rank_rel;
+        A.aux_f_idx[pos] = s;
+        if (hd) {
+            const int32_t a = A.S1[at] - A.b1 + heads_before;
+            A.row_in[row] = (int32_t)A.N + a; A.row_out[row] = kn;
+            A.aux_f_ptr[a] = pos;
+            A.dst_rows[A.Sf[kn + 1] - A.bf - A.self_loop - 1 - later_rows] = row;
+        }
+    } else {
+        const int32_t pos = A.S4[at] - A.b4 + rank_rel;
+        A.aux_b_idx[pos] = d;
+        if (hd) {
+            const int32_t a = A.S2[at] - A.b2 + heads_before;
+            A.row_in[row] = kn; A.row_out[row] = (int32_t)A.N + a;
+            A.aux_b_ptr[a] = pos;
+            A.src_rows[A.Sb[kn + 1] - A.bb - A.self_loop - 1 - later_rows] = row;
+        }
     }
-    for_each_edge(X, m, [&](int, u32 j0, u32 j1) {
-        const u32 rj = j0 >> 26, mdj = (j1 >> 28) & 3u, sj = (j1 >> 14) & 0x3fffu, dj = j1 & 0x3fffu;
-        const int nf = (mdj == kEdge || mdj == kTf) ? 1 : 0;               // j has a per-edge forward / backward list entry
-        const int nb = (mdj == kEdge || mdj == kAgg) ? 1 : 0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const bool lt = j0 < K.w0[c];                                  // j before me in the (relation, key node, edge) order
-            K.rank_rel[c] += (lt & (rc[c] == rj)) ? 1 : 0;
-            K.rank_d[c] += (lt & (dc[c] == dj)) ? nf : 0;                  // per-edge forward entries of my destination before mine
-            K.rank_s[c] += (lt & (sc[c] == sj)) ? nb : 0;
-        }
-        if (((j1 >> 30) & 1u) != 0 && (mdj == kAgg || mdj == kTf)) {       // j heads a collapsed row (rare)
-            const u32 kkj = j0 >> 10, ckj = (mdj << 16) | (kkj & 0xffffu);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                K.heads_before[c] += ((rc[c] == rj) & (kkj < (K.w0[c] >> 10))) ? 1 : 0;
-                K.later_rows[c] += ((ck[c] == ckj) & (rj > rc[c])) ? 1 : 0; // collapsed rows of my mode at my key node after mine
+    if (md != kAgg) A.dst_rows[A.Sf[d] - A.bf + rank_d] = row;
+    if (md != kTf) A.src_rows[A.Sb[s] - A.bb + rank_s] = row;
+}
+
+// B sorted ascending: words (node << PB | position) of the participating edges, 0xffffffff behind them.  An edge's rank inside
+// its node's run = its index in B minus the index of the run's first word.  Every thread takes n / (64 NW) consecutive words; the
+// run start it inherits comes from a max-scan over the threads.  store(position, rank).
+template <int NW, int PB, typename F>
+__device__ __forceinline__ void run_ranks(const u32* B, int n, int tid, int* scratch, F&& store) {
+    const int K = n / (64 * NW), q0 = tid * K;
+    int last = -1;
+    for (int k = 0; k < K; ++k) {
+        const int q = q0 + k;
+        if (q == 0 || (B[q - 1] >> PB) != (B[q] >> PB)) last = q;
+    }
+    int cur = coop_excl_scan<NW, true>(last, tid, scratch);
+    for (int k = 0; k < K; ++k) {
+        const int q = q0 + k;
+        const u32 key = B[q];
+        if (q == 0 || (B[q - 1] >> PB) != (key >> PB)) cur = q;
+        if (key != 0xffffffffu) store((int)(key & ((1u << PB) - 1u)), q - cur);
+    }
+}
+
+// The five counts from SORTS instead of pair work, for any graph the bit sets below do not take (and, on 16 wavefronts, for the
+// listed graphs).  X: the graph's edges as load_graph packs them with EB bits of edge number -- w0 = relation << 26 | key node <<
+// EB | edge, w1 = head << 30 | mode << 28 | source << 14 | destination.  A, B: n words each (n = the power of two >= m), rsv: R + 1.
+//   1. A = the w0 words sorted: an edge's index p in A is its POSITION in the (relation, key node, edge) order; rank inside the
+//      relation = p - rsv[relation] (rsv by binary search).  X[edge].x is free from here on (A holds the word): it takes the ranks.
+//   2. B = (destination << EB | p) of the edges with a per-edge forward entry, sorted: rank inside the destination's list = index
+//      in B - start of the destination's run (run_ranks).  The same with the sources for the backward lists.
+//   3. B = inclusive count of BUCKET STARTS (a new (relation, key node) in A): the number of a collapsed row inside its relation
+//      = buckets before it.
+//   4. the rows of OTHER collapsed relations of the same mode at the same key node that come after this one in the node's list
+//      (later_rows): one binary search per such relation, heads of collapsed rows only.
+template <int NW, int EB>
+__device__ __forceinline__ void fill_sorted(uint2* X, u32* A, u32* B, int* rsv, int* scratch, int tid, int m, int32_t R, int64_t g,
+                                            int n0, const FillArgs& Ar, const int32_t* s_mode) {
+    constexpr int NT = 64 * NW;
+    constexpr u32 EM = (1u << EB) - 1u, KM = (1u << (26 - EB)) - 1u;
+    const int n = pow2_at_least(m);
+    for (int i = tid; i < n; i += NT) {
+        A[i] = i < m ? X[i].x : 0xffffffffu;
+        if (i < m) X[i].x = 0u;
+    }
+    coop_sync<NW>();
+    bitonic_sort<NW>(A, n, tid);
+    for (int r = tid; r < R; r += NT) rsv[r] = lds_lower_bound(A, m, (u32)r << 26);
+    if (tid == 0) rsv[R] = m;
+    for (int pass = 0; pass < 2; ++pass) {                                 // 0: forward lists (by destination), 1: backward (by source)
+        for (int p = tid; p < n; p += NT) {
+            u32 key = 0xffffffffu;
+            if (p < m) {
+                const u32 w1 = X[A[p] & EM].y, md = (w1 >> 28) & 3u;
+                const bool part = pass == 0 ? (md == kEdge || md == kTf) : (md == kEdge || md == kAgg);
+                const u32 node = pass == 0 ? (w1 & 0x3fffu) : ((w1 >> 14) & 0x3fffu);
+                if (part) key = (node << EB) | (u32)p;
             }
+            B[p] = key;
         }
-    });
-    fill_emit<NC>(K, lane, m, c0, g, n0, A);
+        coop_sync<NW>();
+        bitonic_sort<NW>(B, n, tid);
+        if (pass == 0) run_ranks<NW, EB>(B, n, tid, scratch, [&](int p, int rank) { X[A[p] & EM].x = (u32)rank; });
+        else run_ranks<NW, EB>(B, n, tid, scratch, [&](int p, int rank) { X[A[p] & EM].x |= (u32)rank << 16; });
+        coop_sync<NW>();
+    }
+    {   // B[p] = bucket starts in A[0 .. p]
+        const int K = n / NT, q0 = tid * K;
+        int c = 0;
+        for (int k = 0; k < K; ++k) {
+            const int q = q0 + k;
+            if (q < m && (q == 0 || (A[q - 1] >> EB) != (A[q] >> EB))) ++c;
+        }
+        int run = coop_excl_scan<NW, false>(c, tid, scratch);
+        for (int k = 0; k < K; ++k) {
+            const int q = q0 + k;
+            if (q < m && (q == 0 || (A[q - 1] >> EB) != (A[q] >> EB))) ++run;
+            B[q] = (u32)run;
+        }
+    }
+    coop_sync<NW>();
+    for (int p = tid; p < m; p += NT) {
+        const u32 w0 = A[p];
+        const uint2 x = X[w0 & EM];
+        const u32 r = w0 >> 26, md = (x.y >> 28) & 3u, hd = (x.y >> 30) & 1u, kl = (w0 >> EB) & KM;
+        const int rs0 = rsv[r];
+        int heads_before = 0, later = 0;
+        if (md != kEdge) {
+            heads_before = (int)B[p] - 1 - (rs0 > 0 ? (int)B[rs0 - 1] : 0);
+            if (hd)
+                for (int r2 = (int)r + 1; r2 < R; ++r2) {
+                    if (s_mode[r2] != (int)md) continue;
+                    const u32 k2 = ((u32)r2 << 26) | (kl << EB);
+                    const int q = lds_lower_bound(A, m, k2);
+                    later += (q < m && (A[q] >> EB) == (k2 >> EB)) ? 1 : 0;
+                }
+        }
+        fill_emit_one(r, md, hd, n0 + (int)((x.y >> 14) & 0x3fffu), n0 + (int)(x.y & 0x3fffu), p - rs0, heads_before, (int)(x.x & 0xffffu),
+                      (int)(x.x >> 16), later, g, Ar);
+    }
+    coop_sync<NW>();                                                       // the next graph rewrites the arrays
 }
 
 // The same five counts WITHOUT pair work, for a graph small enough for bit sets in this wavefront's LDS table T (kFastWords
@@ -632,13 +864,68 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
             else fill_fast<4, 2>(X, ftab[wave], lane, m, n1 - n0, R, g, n0, A);
             continue;
         }
-        for (int c0 = 0; c0 * 64 < m; c0 += kLocCG) {
-            const int nc = min(kLocCG, (m - c0 * 64 + 63) / 64);
-            if (nc == 1) fill_pass<1>(X, lane, m, c0, g, n0, A);
-            else if (nc == 2) fill_pass<2>(X, lane, m, c0, g, n0, A);
-            else fill_pass<kLocCG>(X, lane, m, c0, g, n0, A);
+        if (m > 0) {                                                       // the sort pass (A, B, rsv over the bit-set table's words)
+            static_assert(2 * kLocM + kLocR + 1 <= kFastWords, "sort arrays");
+            u32* T = ftab[wave];
+            fill_sorted<1, 10>(X, T, T + kLocM, reinterpret_cast<int*>(T + 2 * kLocM), nullptr, lane, m, R, g, n0, A, s_mode);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The fill pass for the listed graphs (kLocM < edges < kBigM): one workgroup of kBigWaves wavefronts per graph, the sort pass with
+// 13-bit edge numbers.
+__global__ __launch_bounds__(kBigWaves * 64) void ril_fill_big_kernel(
+    int64_t G, int64_t N, int32_t R, int32_t self_loop, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const int32_t* __restrict__ etype,
+    const int32_t* __restrict__ mode, const uint8_t* __restrict__ hbits, const int32_t* __restrict__ S, int32_t* __restrict__ row_in,
+    int32_t* __restrict__ row_out, int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
+    int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
+    int32_t* __restrict__ src_rows, const int32_t* __restrict__ big_list) {
+    __shared__ __attribute__((aligned(16))) uint2 X[kBigM];
+    __shared__ __attribute__((aligned(16))) u32 Aw[kBigM];
+    __shared__ __attribute__((aligned(16))) u32 Bw[kBigM];
+    __shared__ int rsv[kLocR + 1];
+    __shared__ int scratch[kBigWaves + 1];
+    __shared__ int32_t s_mode[kLocR];
+    const int nbig = big_list[0];
+    if ((int)blockIdx.x >= nbig) return;
+    const int tid = threadIdx.x;
+    if (tid < kLocR) s_mode[tid] = tid < R ? mode[tid] : kEdge;
+    __syncthreads();
+    const int64_t RG = (int64_t)R * G;
+    FillArgs A;
+    A.G = G; A.N = N; A.self_loop = self_loop ? 1 : 0;
+    A.S0 = S; A.S1 = S + RG; A.S2 = S + 2 * RG; A.S3 = S + 3 * RG; A.S4 = S + 4 * RG; A.Sf = S + kSeg * RG; A.Sb = A.Sf + (N + 1);
+    A.b1 = A.S1[0]; A.b2 = A.S2[0]; A.b3 = A.S3[0]; A.b4 = A.S4[0]; A.bf = A.Sf[0]; A.bb = A.Sb[0];
+    A.row_in = row_in; A.row_out = row_out; A.aux_f_ptr = aux_f_ptr; A.aux_f_idx = aux_f_idx; A.aux_b_ptr = aux_b_ptr;
+    A.aux_b_idx = aux_b_idx; A.dst_rows = dst_rows; A.src_rows = src_rows;
+    const int32_t P = A.b1;
+    for (int k = blockIdx.x; k < nbig; k += gridDim.x) {
+        const int64_t g = big_list[1 + k];
+        const int n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g], m = edge_ptr[g + 1] - e0;
+        bool oob = false;
+        for (int i = tid; i < m; i += kBigWaves * 64) {
+            const int r = etype[e0 + i], sv = src[e0 + i], d = dst[e0 + i];
+            const bool o = (sv < n0) | (sv >= n1) | (d < n0) | (d >= n1) | (r < 0) | (r >= R);
+            oob |= o;
+            if (!o) {
+                const u32 sl = (u32)(sv - n0), dl = (u32)(d - n0), md = (u32)s_mode[r], hb = hbits[e0 + i];
+                const u32 head = ((md == kTf ? hb >> 1 : hb) & 1u) ^ 1u;
+                X[i] = make_uint2(((u32)r << 26) | ((md == kTf ? sl : dl) << 13) | (u32)i, (head << 30) | (md << 28) | (sl << 14) | dl);
+            }
+        }
+        if (__syncthreads_or(oob ? 1 : 0)) continue;                      // (flagged by the statistics pass: the tables stay unused)
+        for (int v = n0 + tid; v < n1; v += kBigWaves * 64) {
+            dst_ptr[v] = A.Sf[v] - A.bf;
+            src_ptr[v] = A.Sb[v] - A.bb;
+            if (self_loop) {
+                row_in[P + v] = v; row_out[P + v] = v;
+                dst_rows[A.Sf[v + 1] - A.bf - 1] = P + v;
+                src_rows[A.Sb[v + 1] - A.bb - 1] = P + v;
+            }
+        }
+        fill_sorted<kBigWaves, 13>(X, Aw, Bw, rsv, scratch, tid, m, R, g, n0, A, s_mode);
     }
 }
 
@@ -728,7 +1015,7 @@ __global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t
 }
 
 struct LocWs {
-    int32_t *Er, *Dr, *Sr, *mode, *bad, *meta, *C, *S;
+    int32_t *Er, *Dr, *Sr, *mode, *bad, *meta, *C, *S, *big;
     uint8_t* hbits;
     void* scan_tmp;
     size_t scan_tmp_bytes, zero_bytes;
@@ -752,6 +1039,7 @@ int loc_layout(char* base, size_t cap, size_t& need, LocWs& w, int64_t G, int64_
     w.S = (int32_t*)take(sizeof(int32_t) * (size_t)w.L);
     w.mode = (int32_t*)take(sizeof(int32_t) * kLocR);
     w.hbits = (uint8_t*)take((size_t)E);
+    w.big = (int32_t*)take(sizeof(int32_t) * (size_t)(G + 2));            // [0] the number of listed graphs, then the graphs
     w.meta = (int32_t*)take(sizeof(int32_t) * (size_t)(5 + 2 * kLocR + 4 + dn_internal::kRilPlanWords + 1 + 4));   // (+ the verdict launch's ticket, 2 x 2 words of the sweep builder)
     w.scan_tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, w.scan_tmp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)w.L,
@@ -790,9 +1078,16 @@ int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_pt
     if (rc != DN_OK) return rc;
     if (need > workspace_bytes) { dn_set_error("dn_row_index_build_local: workspace too small (%zu < %zu)", workspace_bytes, need); return DN_ERR_WORKSPACE; }
     DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, w.zero_bytes, st));
+    DN_CHECK_HIP(hipMemsetAsync(w.big, 0, sizeof(int32_t), st));
     const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
     hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
-                       N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits);
+                       N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits, w.big);
+    // (the graphs over one wavefront's LDS slice, if any: the list's length is only known on the device -- an empty list costs two
+    //  empty launches)
+    const bool may_big = E > kLocM;
+    if (may_big)
+        hipLaunchKernelGGL(ril_stats_big_kernel, dim3(kBigGrid), dim3(kBigWaves * 64), 0, st, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
+                           w.Er, w.Dr, w.Sr, w.bad, w.hbits, w.big);
     hipLaunchKernelGGL(ril_count_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, edge_frac, self_loop, node_ptr,
                        edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.hbits, w.mode, w.C);
     DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
@@ -800,6 +1095,10 @@ int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_pt
     hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
                        dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
                        src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
+    if (may_big)
+        hipLaunchKernelGGL(ril_fill_big_kernel, dim3(kBigGrid), dim3(kBigWaves * 64), 0, st, G, N, (int32_t)R, self_loop, node_ptr, edge_ptr,
+                           src, dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr,
+                           dst_rows, src_ptr, src_rows, w.big);
     DN_CHECK_LAUNCH();
     if (verdicts) {
         DN_REQUIRE(tile_ptr_f && fold_info_f && tile_ptr_b && fold_info_b, "dn_row_index_build_local: the fold verdicts need the four tile buffers");

@@ -1210,7 +1210,7 @@ class RowIndex:
                  closing_hint=None):
         """One C-ABI call + device-side tile tables.  With the batch's graph boundaries (node_ptr / edge_ptr, [G+1] each) the
         graph-local builder runs (dn_row_index_build_local_i32: one wavefront rank-sorts one graph in LDS, one scan); without
-        them, or when the batch does not qualify (a graph over 1024 edges, more than 64 relations), the general one
+        them, or when the batch does not qualify (a graph of 8192 edges or more, more than 64 relations), the general one
         (dn_row_index_build_i32: stable radix sorts + scans over the whole batch).  Both produce the same tables bit for bit.
         closing_hint = (H, dtype) of the rows the index will serve: for (256, bfloat16) with graph boundaries the WHOLE per-batch
         index -- row index, unit streams of both closing launches, sweep orders, weight-gradient chunk table -- is one call with one
@@ -1221,7 +1221,7 @@ class RowIndex:
         self.num_nodes, self.num_rels, self.num_edges, self.self_loop = N, R, E, bool(self_loop)
         try_local = node_ptr is not None and edge_ptr is not None and R <= 64 and LOCAL_INDEX_ENABLED
         if try_local:                                                 # (graphs over the LDS limit: do not even try)
-            try_local = E == 0 or E <= 1024 * (int(node_ptr.numel()) - 1)
+            try_local = E == 0 or E < 8192 * (int(node_ptr.numel()) - 1)
         if not try_local:
             _check_edge_types(etype, R)                               # (the local builder validates on the device)
         src, dst, etype = (t.to(I32).contiguous() for t in (src, dst, etype))

@@ -247,8 +247,10 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * edge_ptr[G] == E) -- the layout dgl.batch / the PyG collate produce (subgraph_isomorphism/dataset.py:1605-1611,
  * graph_classification main.py:245-247).  Every ordering the general builder establishes with device-wide radix sorts is local
  * to a graph in such a batch, so one wavefront rank-sorts one graph in LDS and the only batch-wide step is one exclusive scan
- * of the packed counts: 3 kernels + 1 scan instead of ~60 launches.  R <= 64.  *host_status = 1 (outputs undefined) when the
- * batch does not qualify -- a graph with more than 1024 edges, an endpoint outside its graph's node range, a relation id
+ * of the packed counts: 3 kernels + 1 scan instead of ~60 launches.  Graphs of more than 1024 edges (up to 8191 edges and 8191
+ * nodes; round 6) are taken by a second launch of the statistics and fill passes, one 1024-thread workgroup per graph -- a
+ * PER-GRAPH fallback: the rest of the batch stays on the one-wavefront kernels.  R <= 64.  *host_status = 1 (outputs undefined) when the
+ * batch does not qualify -- a graph of 8192 edges or more (or over 16384 nodes), an endpoint outside its graph's node range, a relation id
  * outside [0, R), ranges that do not tile [0, N) / [0, E): the caller then runs dn_row_index_build_i32.  Other arguments and
  * outputs as dn_row_index_build_i32.  rel_ptr_dev (device, may be NULL; round 5): [R + 2] = the relation offsets of host_rel_ptr
  * followed by the end of the self-loop rows (P + N), for the device-side table builders -- no upload of what the device already

@@ -99,14 +99,14 @@ def test_local_builder_config3_shape_and_layer():
 
 
 def test_local_builder_declines_and_falls_back():
-    """a graph over the LDS limit, an endpoint outside its graph, ranges that do not tile: the general builder runs"""
+    """a graph over the limit of the listed-graph pass, an endpoint outside its graph, ranges that do not tile: the general builder runs"""
     rng = np.random.default_rng(3)
-    # (1) one graph with 1500 edges
+    # (1) one graph with 8192 edges (one more than a workgroup's arrays take)
     n = 40
-    s, d = rng.integers(0, n, size=1500), rng.integers(0, n, size=1500)
+    s, d = rng.integers(0, n, size=8192), rng.integers(0, n, size=8192)
     src = np.concatenate([s, n + rng.integers(0, 5, size=10)]); dst = np.concatenate([d, n + rng.integers(0, 5, size=10)])
-    et = rng.integers(0, 4, size=1510)
-    a, b = _build(src, dst, et, n + 5, 4, True, [0, n, n + 5], [0, 1500, 1510])
+    et = rng.integers(0, 4, size=8202)
+    a, b = _build(src, dst, et, n + 5, 4, True, [0, n, n + 5], [0, 8192, 8202])
     assert b.built_by == "general"
     for f in FIELDS:
         assert torch.equal(getattr(a, f), getattr(b, f))
@@ -124,6 +124,61 @@ def test_local_builder_declines_and_falls_back():
     assert b.built_by == "general"
     for f in FIELDS:
         assert torch.equal(getattr(a, f), getattr(b, f))
+
+
+@pytest.mark.parametrize("edge_frac", [0.0, 0.75, 2.0])
+@pytest.mark.parametrize("seed", range(3))
+def test_local_builder_sort_pass_on_mid_size_graphs(seed, edge_frac):
+    """graphs of 257 .. 1024 edges (and smaller ones that do not fit the bit sets): ranks from sorts in one wavefront's LDS slice;
+    edge_frac 2.0 collapses EVERY relation (hundreds of collapsed rows per graph, several collapsed relations per node)"""
+    rng = np.random.default_rng(500 + seed)
+    R = int(rng.integers(3, 17))
+    src, dst, et, nptr, eptr = _random_batch(rng, G=40, R=R, nmin=0, nmax=int(rng.integers(150, 200)), dens=float(rng.uniform(1.5, 2.5)),
+                                             dummy=bool(seed % 2 == 0))
+    m = np.diff(eptr)
+    assert m.max() <= 1024 and (m > 256).any()
+    a, b = _build(src, dst, et, int(nptr[-1]), R, True, nptr, eptr, edge_frac=edge_frac)
+    _same(a, b)
+
+
+@pytest.mark.parametrize("edge_frac", [0.75, 2.0])
+def test_local_builder_takes_graphs_over_one_wavefronts_slice_one_by_one(edge_frac):
+    """a PER-GRAPH fallback: graphs of 1025 .. 8191 edges go to the listed-graph launches (one workgroup each), the small graphs
+    around them stay on the one-wavefront kernels -- and the tables equal the general builder's"""
+    rng = np.random.default_rng(77)
+    parts = []
+    for n, m_real, dummy in ((30, 50, True), (700, 2400, True), (12, 0, True), (1500, 5100, True), (3, 8185, False), (200, 900, True),
+                             (2600, 2980, True), (40, 8191, False), (31, 62, True)):
+        s = rng.integers(0, n, size=m_real); d = rng.integers(0, n, size=m_real); r = rng.integers(0, 5, size=m_real)
+        if dummy:
+            s = np.concatenate([s, np.arange(n), np.full(n, n)]); d = np.concatenate([d, np.full(n, n), np.arange(n)])
+            r = np.concatenate([r, np.full(n, 5), np.full(n, 6)])
+            n += 1
+        parts.append((n, s, d, r))
+    nptr = np.concatenate([[0], np.cumsum([p[0] for p in parts])])
+    eptr = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])])
+    src = np.concatenate([nptr[k] + p[1] for k, p in enumerate(parts)]); dst = np.concatenate([nptr[k] + p[2] for k, p in enumerate(parts)])
+    et = np.concatenate([p[3] for p in parts])
+    m = np.diff(eptr)
+    assert (m > 1024).sum() >= 5 and m.max() == 8191
+    a, b = _build(src, dst, et, int(nptr[-1]), 7, True, nptr, eptr, edge_frac=edge_frac)
+    _same(a, b)
+
+
+def test_local_builder_proteins_shaped_batch():
+    """the shape bench.py --workload proteins builds (graphs of 4 .. 620 nodes, R = 16, SI dummy augmentation): every size class
+    of the builder in one batch"""
+    from dummynode4graphlearning_amd import synthetic, transforms
+    dev = torch.device("cuda:0")
+    raw = synthetic.proteins_si(2, 2048)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(dev) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    m = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).cpu().numpy()
+    assert (m > 1024).any() and (m <= 256).any() and ((m > 256) & (m <= 1024)).any()
+    a, b = _build(aug["src"].cpu().numpy(), aug["dst"].cpu().numpy(), aug["edge_label"].cpu().numpy(), int(aug["node_label"].numel()), 16,
+                  True, aug["node_ptr"].cpu().numpy(), aug["edge_ptr"].cpu().numpy())
+    _same(a, b)
 
 
 def test_local_builder_empty_batch_and_edgeless_graphs():
