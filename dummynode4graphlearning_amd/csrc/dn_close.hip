@@ -370,6 +370,17 @@ __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __r
     dn_fold_graph_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, tile_ptr, info, ok);
 }
 
+__global__ void fold_multi_count_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
+                                        const int32_t* __restrict__ add_idx, int32_t* __restrict__ ntiles, int32_t* __restrict__ ok) {
+    dn_fold_multi_count_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, ntiles, ok);
+}
+__global__ void fold_multi_fill_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
+                                       const int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_ptr,
+                                       int32_t* __restrict__ tile_graph, int32_t* __restrict__ info, const int32_t* __restrict__ ok) {
+    if (*ok == 0) return;                                                  // (an invalid batch's tile count is not bounded by the tables' sizes)
+    dn_fold_multi_fill_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, tile_first, tile_ptr, tile_graph, info);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- kernel
 constexpr int kH = 256;
 constexpr int kRowB = 2 * kH;          // bytes per row
@@ -413,14 +424,17 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     __shared__ __attribute__((aligned(128))) int32_t recR[kLoaders][kRecRing][4];             // loader-private rings: unit records
     __shared__ __attribute__((aligned(256))) int32_t idxR[kLoaders][kIdxRing][kRowsPerLoader]; // ... and source rows
     __shared__ __attribute__((aligned(16))) char wscr[kCompute][2048];                         // transposition scratch of a [k][n] W
+    __shared__ __attribute__((aligned(16))) float segL[FOLD == 2 ? kCompute : 1][4][8];       // running column sums of a multi-tile graph
     typedef __attribute__((address_space(3))) char* lds_wp;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
     const unsigned desc_base = (unsigned)(uintptr_t)(lds_wp)&descL[0][0];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
-    const int u_beg = unit_ptr[wg];
-    const int nt = unit_ptr[wg + 1] - u_beg;
+    // (order 2: unit_ptr is indexed by CHUNK; workgroup 8 j + x -- XCD x -- takes chunk x nwg/8 + j)
+    const int ui = ((flags & 256) && (nwg & 7) == 0) ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg;
+    const int u_beg = unit_ptr[ui];
+    const int nt = unit_ptr[ui + 1] - u_beg;
     if (nt <= 0) return;
     units += u_beg;
 
@@ -462,7 +476,8 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
             if (fl & kUnitEntry) glds4(ent_row + pc, dst);                 // lane l lands at + 4 l: [unit][8 rows]
             else if (FOLD == 2 && (fl & kUnitAgg))                         // the aux row of my pc-th tile (= its segment)
                 idxR[q][T % kIdxRing][lane & 7] =
-                    (fl & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * rp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * pc : wg + nwg * pc;
+                    (fl & kUnitAggAbs) ? pc
+                    : (fl & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * rp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * pc : wg + nwg * pc;
             else idxR[q][T % kIdxRing][lane & 7] = (fl & kUnitNop) ? 0 : pc;   // an X unit's rows are its nodes
             // membership masks of units T0 + 2 q, T0 + 2 q + 1, in the k order of the transposed reads:
             // position k = 8 g + 4 jh + qq  <->  row g + 16 jh + 4 qq of the unit
@@ -476,8 +491,9 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                 if constexpr (FOLD == 2) {                                 // an AGG unit's "masks" are the output rows of its 32 products
                     const int ord = mp[1] + kk;
                     if ((mp[0] & kUnitAgg) && ord < mp[2])
-                        msrc = agg_idx + ((mp[0] & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * mp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * ord
-                                                             : wg + nwg * ord);
+                        msrc = agg_idx + ((mp[0] & kUnitAggAbs) ? ord
+                                          : (mp[0] & kUnitXcd) ? (int)(((int64_t)((wg & 7) + 1) * mp[3]) >> 3) - 1 - (wg >> 3) - (nwg >> 3) * ord
+                                                               : wg + nwg * ord);
                 }
                 const unsigned mdst =
                     (unsigned)__builtin_amdgcn_readfirstlane((int)(mask_base + (unsigned)((T0 + 2 * q) % kMaskRing) * 128u));
@@ -749,10 +765,23 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                                 if ((int)me < cnt)
                                     *reinterpret_cast<f32x4*>(seg_part + (size_t)(first + (int)me) * kH + ocol + 4 * n) = d;
                             }
-                        } else {                                           // the segment is complete: its sum IS the aux row
-                            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ind, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            if ((int)me < cnt) {
+                        } else {                                           // the segment is complete (with this tile): its sum IS the aux row
+                            // (a graph that spans several tiles -- fold record word 10: bit 0 = continues the previous X unit's sum,
+                            //  bit 1 = completes it: the running sum waits in this wave's 128 bytes of segL, not in registers; a
+                            //  graph inside one tile touches neither)
+                            const int fb = __builtin_amdgcn_readfirstlane(fr[10]);
+                            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                            if ((fb & 1) && j == 0) {
+                                c0 = *reinterpret_cast<const f32x4*>(&segL[wave][g][0]);
+                                c1 = *reinterpret_cast<const f32x4*>(&segL[wave][g][4]);
+                            }
+                            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ind, c0, 0, 0, 0);
+                            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ind, c1, 0, 0, 0);
+                            if (!(fb & 2) && j == 0) {
+                                *reinterpret_cast<f32x4*>(&segL[wave][g][0]) = d0;
+                                *reinterpret_cast<f32x4*>(&segL[wave][g][4]) = d1;
+                            }
+                            if ((int)me < cnt && (fb & 2)) {
                                 const u32x4 o = {pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
                                                  pack_bf16x2(d1[2], d1[3])};
                                 *reinterpret_cast<u32x4*>(aux + (size_t)(first + (int)me) * kH + ocol) = o;
@@ -860,10 +889,13 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
                       int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 && num_tiles >= 0 &&
                num_tiles < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_close_units_build: bad sizes");
-    DN_REQUIRE(xcd_order == 0 || (xcd_order == 1 && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
+    DN_REQUIRE(xcd_order == 0 || xcd_order == 2 || (xcd_order == 1 && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
                "dn_close_units_build: the XCD order needs a multiple of 8 workgroups");
     for (int k = 0; k < nd; ++k) {
         DN_REQUIRE(dirs[k].num_edge_rows >= 0, "dn_close_units_build: bad sizes");
+        DN_REQUIRE(xcd_order != 2 || (dirs[k].tile_ptr && dirs[k].tile_graph && dirs[k].tile_first && dirs[k].num_segments >= 1 &&
+                                      dirs[k].num_segments <= num_tiles),
+                   "dn_close_units_build: order 2 takes the tables of dn_fold_graph_tiles_multi_build_i32 (tile_ptr, tile_graph, tile_first)");
         DN_REQUIRE(dirs[k].tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the "
                    "%lld 32-node windows", (long long)dn_cdiv(N, 32));
         DN_REQUIRE(dirs[k].unit_ptr, "dn_close_units_build: NULL pointer");
@@ -881,7 +913,7 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     DN_REQUIRE(workspace_bytes >= (size_t)nd * dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "dn_close_units_build: unaligned pointer");
     const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
-    const int64_t M = (int64_t)num_wg * Tper;
+    const int64_t M = xcd_order == 2 ? (int64_t)T : (int64_t)num_wg * Tper;  // (order 2: the unit counts lie in tile order)
     DN_REQUIRE((int64_t)nd * (unit_capacity + 1) < 0x7fffffffLL, "dn_close_units_build: unit tables too large");   // (one scan over both)
     char* wsp = reinterpret_cast<char*>(workspace);
     int32_t* tile_cnt[2] = {nullptr, nullptr};
@@ -898,7 +930,8 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     CbPair pr;
     for (int k = 0; k < 2; ++k) {
         const CloseUnitsDir& d = dirs[k < nd ? k : 0];
-        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.ent_row, tile_cnt[k < nd ? k : 0],
+        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.tile_graph, d.tile_first, d.num_segments, d.ent_row,
+                        tile_cnt[k < nd ? k : 0],
                         ucnt + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), d.unit_ptr, d.ent_mask,
                         uoff + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), reinterpret_cast<Unit*>(d.units), d.num_edge_rows, d.drop_beg,
                         d.drop_end};
@@ -914,9 +947,52 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     return DN_OK;
 }
 
+int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx, int32_t* tile_first,
+                     int32_t* tile_ptr, int32_t* tile_graph, int32_t* fold_info, int32_t* dev_ok, void* workspace, size_t workspace_bytes,
+                     hipStream_t st) {
+    int32_t* ntiles = reinterpret_cast<int32_t*>(workspace);
+    char* tmp = reinterpret_cast<char*>(workspace) + dn_align_up((size_t)(S + 1) * 4, 256);
+    size_t tb = 0;
+    DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ntiles, tile_first, (int32_t)0, (size_t)(S + 1), rocprim::plus<int32_t>(), st));
+    DN_REQUIRE(dn_align_up((size_t)(S + 1) * 4, 256) + tb <= workspace_bytes, "dn_fold_graph_tiles_multi_build: workspace too small");
+    const unsigned grid = (unsigned)dn_cdiv(S + 1, 256);
+    hipLaunchKernelGGL(fold_multi_count_kernel, dim3(grid), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes, add_idx, ntiles, dev_ok);
+    DN_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, ntiles, tile_first, (int32_t)0, (size_t)(S + 1), rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(fold_multi_fill_kernel, dim3(grid), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes, tile_first, tile_ptr,
+                       tile_graph, fold_info, dev_ok);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
 }  // namespace dn_internal
 
 extern "C" {
+
+size_t dn_fold_graph_tiles_multi_workspace_bytes(int64_t num_segments) {
+    if (num_segments < 0 || num_segments >= INT32_MAX) { dn_set_error("dn_fold_graph_tiles_multi_workspace_bytes: bad sizes"); return 0; }
+    // (the scan's temporary storage bounded without asking rocPRIM, as in dn_close_units_workspace_bytes)
+    return dn_align_up((size_t)(num_segments + 1) * 4, 256) + 65536 + 4 * (size_t)(num_segments + 1) + 256;
+}
+
+int64_t dn_fold_graph_tiles_multi_capacity(int64_t N, int64_t num_segments) { return num_segments + N / 32 + 1; }
+
+int dn_fold_graph_tiles_multi_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                                        const int32_t* add_idx, int32_t* tile_first, int32_t* tile_ptr, int32_t* tile_graph,
+                                        int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok, void* workspace,
+                                        size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_graph_tiles_multi_build: bad sizes");
+    DN_REQUIRE(dev_ok, "dn_fold_graph_tiles_multi_build: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0 || num_segments == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0, sizeof(int32_t), st)); return DN_OK; }
+    DN_REQUIRE(seg_ptr && seg_nodes && tile_first && tile_ptr && tile_graph && fold_info && workspace, "dn_fold_graph_tiles_multi_build: NULL pointer");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
+               "dn_fold_graph_tiles_multi_build: unaligned pointer");
+    DN_REQUIRE(tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, num_segments), "dn_fold_graph_tiles_multi_build: tile tables too small");
+    DN_REQUIRE(workspace_bytes >= dn_fold_graph_tiles_multi_workspace_bytes(num_segments), "dn_fold_graph_tiles_multi_build: workspace too small");
+    DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
+    return dn_internal::fold_multi_queue(N, num_segments, seg_ptr, seg_nodes, add_idx, tile_first, tile_ptr, tile_graph, fold_info, dev_ok,
+                                         workspace, workspace_bytes, st);
+}
 
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {
     return 2 * num_tiles + num_list_entries / 32 + 1 + (int64_t)num_wg * (kAggGap + 1) + num_tiles / 32;
@@ -934,10 +1010,12 @@ size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
                              int32_t agg_units, int32_t xcd_order, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
-                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, void* workspace, size_t workspace_bytes,
+                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, const int32_t* tile_graph,
+                             const int32_t* tile_first, int64_t num_segments, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream) {
+    DN_REQUIRE(num_segments >= 0 && num_segments < INT32_MAX, "dn_close_units_build: bad sizes");
     const dn_internal::CloseUnitsDir d{tile_ptr, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, drop_enable, nullptr, unit_ptr,
-                                       units, ent_row, ent_mask};
+                                       units, ent_row, ent_mask, tile_graph, tile_first, (int32_t)num_segments};
     return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, xcd_order, num_list_entries, unit_capacity, 1, &d, workspace,
                                           workspace_bytes, (hipStream_t)stream);
 }
@@ -961,8 +1039,9 @@ int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
-                       const void* W_agg, void* aux, const int32_t* agg_idx, dn_stream_t stream) {
+                       const void* W_agg, void* aux, const int32_t* agg_idx, int32_t unit_order, dn_stream_t stream) {
     DN_REQUIRE(H == 256, "dn_rows_close: unsupported width %d (256 only; dn_rows_selfsum_bf16 serves 64 / 128)", H);
+    DN_REQUIRE(unit_order == 0 || unit_order == 1 || unit_order == 2, "dn_rows_close: unit_order must be the order the unit tables were built in");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096, "dn_rows_close: bad sizes");
     const bool agg = W_agg != nullptr || aux != nullptr || agg_idx != nullptr;
     DN_REQUIRE(fold_info == nullptr || seg_part != nullptr || agg, "dn_rows_close: fold_info needs seg_part (or W_agg / aux / agg_idx)");
@@ -977,7 +1056,7 @@ int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, co
     hipStream_t st = (hipStream_t)stream;
     static const int nt = dn_knob("DN_NT", 3);
     const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
-    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2);
+    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2) | (unit_order == 2 ? 256 : 0);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
 #define DN_CLOSE_LAUNCH(F)                                                                                                         \
     hipLaunchKernelGGL((rows_close_ring_kernel<F>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X, (const bf16_t*)W, \

@@ -558,7 +558,7 @@ CLOSE_RING_ENABLED = _os.environ.get("DN_CLOSE_RING", "1") != "0"
 
 class CloseUnits:
     """Tables of dn_rows_close_bf16 for one direction of a RowIndex (dn_close_units_build_i32)."""
-    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes", "num_tiles", "agg", "order")
+    __slots__ = ("unit_ptr", "units", "ent_row", "ent_mask", "num_wg", "num_nodes", "num_tiles", "agg", "order", "num_segments")
 
 
 # DN_CLOSE_ORDER=0: the closing launch walks the batch upwards as one front (workgroup w: tiles w, w + G, ...) instead of every XCD
@@ -592,13 +592,41 @@ def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
     return tile_ptr, info[:S], ok
 
 
+# DN_CLOSE_MULTI=0: graphs over 32 nodes keep the fp32 partial rows + dn_fold_tail_bf16 (rounds 4-5) instead of the multi-tile absorbed fold
+CLOSE_MULTI_ENABLED = _os.environ.get("DN_CLOSE_MULTI", "1") != "0"
+
+
+def build_graph_tiles_multi(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
+    """Tiles of a batch of graphs of ANY size for the absorbed fold (dn_fold_graph_tiles_multi_build_i32: two launches + a scan, no
+    read-back): every graph's block cut into consecutive tiles of at most 32 nodes.
+    -> (tile_ptr [cap + 1], fold_info [cap, 12], tile_graph [cap], tile_first [S + 1], cap, ok [1] device flag); the number of tiles
+    that exist is tile_first[S], on the device; cap bounds it."""
+    require_gpu(seg_ptr, seg_nodes, add_idx)
+    dev = seg_ptr.device
+    S, N = int(seg_ptr.numel()) - 1, int(num_nodes)
+    cap = int(lib().dn_fold_graph_tiles_multi_capacity(N, S))
+    tile_first = torch.empty(S + 1, dtype=I32, device=dev)
+    tile_ptr = torch.empty(cap + 1, dtype=I32, device=dev)
+    tile_graph = torch.empty(cap, dtype=I32, device=dev)
+    info = torch.empty((cap, 12), dtype=I32, device=dev)
+    if ok is None:
+        ok = torch.zeros(1, dtype=I32, device=dev)
+    assert add_idx is None or (add_idx.dtype == I32 and add_idx.numel() == S and add_idx.is_contiguous())
+    ws = _ws(lib().dn_fold_graph_tiles_multi_workspace_bytes(S), dev)
+    check(lib().dn_fold_graph_tiles_multi_build_i32(N, S, ptr(seg_ptr), ptr(seg_nodes), ptr(add_idx), ptr(tile_first), ptr(tile_ptr),
+                                                    ptr(tile_graph), ptr(info), cap, ptr(ok), ptr(ws), ws.numel(), stream_ptr()),
+          "dn_fold_graph_tiles_multi_build_i32")
+    return tile_ptr, info, tile_graph, tile_first, cap, ok
+
+
 def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None, tile_ptr=None,
-                      agg=False, order=None):
+                      agg=False, order=None, multi=None):
     """Per tile (32-node windows, or the node ranges tile_ptr gives) the distinct kept rows of its nodes' lists + membership
     masks, and the per-workgroup unit records the closing launch streams (three launches, no read-back).  Same filter as
     build_slot_table.  agg: append every workgroup's AGG units (the absorbed fold, tile_ptr from build_graph_tiles).  order: 0 =
     workgroup w takes tiles w, w + G, ...; 1 = every XCD walks its eighth of the batch downwards (include/dn_hip.h); None = 1 when
-    the number of workgroups allows it."""
+    the number of workgroups allows it.  multi = (tile_graph, tile_first, cap) of build_graph_tiles_multi (with its tile_ptr): order 2 --
+    graphs that span several tiles stay in one workgroup's stream, unit_ptr is indexed by chunk."""
     require_gpu(list_ptr, list_rows, tile_ptr)
     dev = list_rows.device
     N, P, L = int(num_nodes), int(num_edge_rows), int(list_rows.numel())
@@ -608,6 +636,13 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     cu.num_nodes, cu.agg = N, bool(agg)
     cu.order = _close_order(cu.num_wg) if order is None else int(order)
     cu.num_tiles = T = (int(tile_ptr.numel()) - 1) if tile_ptr is not None else (N + 31) // 32
+    cu.num_segments = T
+    tg = tf = None
+    if multi is not None:
+        tg, tf, cap_t = multi
+        require_gpu(tg, tf)
+        assert agg and tile_ptr is not None and cap_t == T and tg.numel() == T
+        cu.order, cu.num_segments = 2, int(tf.numel()) - 1
     assert not agg or tile_ptr is not None
     cap = int(lib().dn_close_units_capacity(T, L, cu.num_wg))
     cu.unit_ptr = torch.empty(cu.num_wg + 1, dtype=I32, device=dev)
@@ -617,7 +652,8 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     ws = _ws(lib().dn_close_units_workspace_bytes(T, cu.num_wg), dev)
     check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(tile_ptr), T, 1 if agg else 0, cu.order, ptr(list_ptr), ptr(list_rows), L,
                                          int(drop[0]), int(drop[1]), ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap,
-                                         ptr(cu.ent_row), ptr(cu.ent_mask), ptr(ws), ws.numel(), stream_ptr()),
+                                         ptr(cu.ent_row), ptr(cu.ent_mask), ptr(tg), ptr(tf), cu.num_segments if multi is not None else 0,
+                                         ptr(ws), ws.numel(), stream_ptr()),
           "dn_close_units_build_i32")
     return cu
 
@@ -626,8 +662,8 @@ def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
     """out[v] = x[v] @ W_loop (+ bias) + sum of the rows of S that cu lists for v  (dn_rows_close_bf16, H = 256).
     W: [out, in] (w_kn False, the transposed copy) or [in, out] as the parameter stores it (w_kn True).  seg as in rows_selfsum
     (fp32 partial rows for dn_fold_tail_bf16).  agg = (fold_info [T, 12], W_agg [H, H] in W's layout, aux [S, H] out, agg_idx [S]):
-    the absorbed fold -- cu built with build_graph_tiles' tiles and agg=True; aux[j] = the column sum of segment j (bf16),
-    out[agg_idx[j]] += aux[j] @ W_agg inside the same launch."""
+    the absorbed fold -- cu built with build_graph_tiles' (or build_graph_tiles_multi's) tiles and agg=True; aux[j] = the column sum
+    of segment j (bf16), out[agg_idx[j]] += aux[j] @ W_agg inside the same launch."""
     require_gpu(x, W, bias, S, cu.unit_ptr, cu.units, cu.ent_row, cu.ent_mask)
     N, H = x.shape
     assert H == 256 and x.dtype == torch.bfloat16 and W.shape == (H, H) and W.dtype == x.dtype and N == cu.num_nodes
@@ -645,15 +681,15 @@ def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
         fi, wa, ax, ai = agg
         assert fi.dtype == I32 and fi.shape == (cu.num_tiles, 12) and fi.is_contiguous()
         assert wa.dtype == x.dtype and wa.shape == (H, H) and wa.is_contiguous()
-        assert ax.dtype == x.dtype and ax.shape == (cu.num_tiles, H) and ax.is_contiguous()
-        assert ai.dtype == I32 and ai.numel() == cu.num_tiles and ai.is_contiguous()
+        assert ax.dtype == x.dtype and ax.shape == (cu.num_segments, H) and ax.is_contiguous()
+        assert ai.dtype == I32 and ai.numel() == cu.num_segments and ai.is_contiguous()
     if out is None:
         out = torch.empty((N, H), dtype=x.dtype, device=x.device)
 
     def _launch():
         check(lib().dn_rows_close_bf16(ptr(x), H, ptr(W), 1 if w_kn else 0, ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                        ptr(cu.unit_ptr), ptr(cu.units), cu.num_wg, ptr(cu.ent_row), ptr(cu.ent_mask), N, ptr(out),
-                                       ptr(fi), ptr(sp), ptr(wa), ptr(ax), ptr(ai), stream_ptr()), "dn_rows_close_bf16")
+                                       ptr(fi), ptr(sp), ptr(wa), ptr(ax), ptr(ai), cu.order, stream_ptr()), "dn_rows_close_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_close", _launch)
     else:
@@ -1257,7 +1293,7 @@ class RowIndex:
                 cus = []
                 for _ in range(2):
                     cu = CloseUnits()
-                    cu.num_wg, cu.num_nodes, cu.agg, cu.num_tiles, cu.order = num_wg, N, True, G, _close_order(num_wg)
+                    cu.num_wg, cu.num_nodes, cu.agg, cu.num_tiles, cu.order, cu.num_segments = num_wg, N, True, G, _close_order(num_wg), G
                     cu.unit_ptr, cu.units = e32(num_wg + 1), torch.empty((cap, 4), dtype=I32, device=dev)
                     cu.ent_row, cu.ent_mask = e32(E + N), e32(E + N)
                     cus.append(cu)
@@ -1435,7 +1471,7 @@ def _make_fold_info(ix, direction, cand):
     r, beg, end, n_aux = cand
     info = _Fold()
     info.rel, info.beg, info.end, info.n = r, beg, end, n_aux
-    info.fold_info = info.part_ptr = info.graph_tiles = None
+    info.fold_info = info.part_ptr = info.graph_tiles = info.multi = None
     info.num_parts = int(2 * n_aux + ix.num_nodes // 32 + 1)   # upper bound of part_ptr[-1] without a read-back: every segment
     #                                                            starts one partial row, every tile boundary inside one another
     info.main_tiles = None                               # plain relation-major tiles, built on first use (_conv_tiles_for)
@@ -1515,6 +1551,19 @@ def _closing_tables(ix, kind="slots"):
             if gts:
                 h = flags.cpu().tolist()                             # synchronisation 1: can the fold be absorbed?
         need_parts = [d for k, d in enumerate(dirs) if cands[d] is not None and h[2 + k] == 0]
+        multi = {}
+        if kind == "units" and CLOSE_AGG_ENABLED and CLOSE_MULTI_ENABLED and need_parts:
+            # a graph over 32 nodes: the absorbed fold over MULTI-TILE graphs (every graph's tiles in one workgroup's stream) where the
+            # segments pass the same test without the size limit; one read-back for both directions
+            mflags = torch.zeros(2, dtype=I32, device=dev)
+            for k, d in enumerate(dirs):
+                if d in need_parts:
+                    aux_ptr, aux_idx = (ix.aux_f_ptr, ix.aux_f_idx) if d == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+                    multi[d] = build_graph_tiles_multi(aux_ptr[:cands[d][3] + 1].contiguous(), aux_idx, N, ok=mflags[k:],
+                                                       add_idx=add_idx_of(d, cands[d]))
+            hm = mflags.cpu().tolist()
+            multi = {d: multi[d] for k, d in enumerate(dirs) if d in multi and hm[k] != 0}
+            need_parts = [d for d in need_parts if d not in multi]
         for d in need_parts:
             parts[d] = _queue_fold_tables(ix, d, cands[d][3], flags[dirs.index(d):])
         if kind == "slots":
@@ -1528,6 +1577,10 @@ def _closing_tables(ix, kind="slots"):
             if cands[d] is not None and h[2 + k] != 0:
                 info = make_info(d, cands[d])
                 info.graph_tiles = (gts[d][0], gts[d][1])
+            elif d in multi:
+                info = make_info(d, cands[d])
+                info.graph_tiles = (multi[d][0], multi[d][1])
+                info.multi = (multi[d][2], multi[d][3], multi[d][4])
             elif cands[d] is not None and hp[k] != 0:
                 info = make_info(d, cands[d])
                 info.fold_info, info.part_ptr = parts[d]
@@ -1555,7 +1608,7 @@ def _closing_tables(ix, kind="slots"):
             slots, over = tabs[d]
             ix._slots[d] = (slots, (*lists[d], P, drop[0], drop[1], over, longest[d]))
         elif info is not None and info.graph_tiles is not None:     # every graph inside one tile: the fold is absorbed
-            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True)
+            ix._units[d] = build_close_units(*lists[d], N, P, drop=drop, tile_ptr=info.graph_tiles[0], agg=True, multi=info.multi)
         else:
             if info is not None and info.fold_info is None:
                 _late_fold_tables(ix, d, info)
@@ -1589,7 +1642,7 @@ FOLD_ENABLED = _os.environ.get("DN_FOLD", "1") != "0"
 class _Fold:
     """Tables of one folded relation: rows [beg, end) of the row set, one per segment (graph)."""
     __slots__ = ("rel", "beg", "end", "n", "fold_info", "part_ptr", "num_parts", "main_tiles", "sweep_tiles", "add_idx",
-                 "graph_tiles")
+                 "graph_tiles", "multi")
 
 
 def _row_index_fold(ix, direction, kind="slots"):

@@ -33,9 +33,42 @@ def graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=None):
         tile_ptr[j] = b0
         ids = np.array([0 if firsts[j] <= b0 + i <= lasts[j] else 255 for i in range(32)], dtype=np.uint8)
         info[j, :8] = ids.view(np.int32)
-        info[j, 8], info[j, 9] = j, 1
+        info[j, 8], info[j, 9], info[j, 10] = j, 1, 2
     tile_ptr[S] = N
     return True, tile_ptr, info
+
+
+def graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=None):
+    """dn_fold_graph_tiles_multi_build_i32: -> (ok, tile_first [S+1], tile_ptr [T+1], tile_graph [T], fold_info [T,12]): every block cut
+    into consecutive tiles of at most 32 nodes (word 10: bit 0 = not the block's first tile, bit 1 = its last)."""
+    sp, sn = np.asarray(seg_ptr, dtype=np.int64), np.asarray(seg_nodes, dtype=np.int64)
+    S = len(sp) - 1
+    firsts, lasts = [], []
+    for j in range(S):
+        nodes = sn[sp[j]:sp[j + 1]]
+        if len(nodes) == 0 or np.any(np.diff(nodes) != 1) or nodes[0] < 0 or nodes[-1] >= N:
+            return False, None, None, None, None
+        firsts.append(int(nodes[0])); lasts.append(int(nodes[-1]))
+    tile_first, tile_ptr, tile_graph, info = [0], [], [], []
+    for j in range(S):
+        b0 = 0 if j == 0 else firsts[j]
+        nxt = firsts[j + 1] if j + 1 < S else N
+        if (j + 1 < S and nxt <= lasts[j]) or nxt - b0 < 1:
+            return False, None, None, None, None
+        if add_idx is not None and not (b0 <= int(add_idx[j]) < nxt):
+            return False, None, None, None, None
+        nt = (nxt - b0 + 31) // 32
+        for k in range(nt):
+            p0 = b0 + 32 * k
+            tile_ptr.append(p0); tile_graph.append(j)
+            ids = np.array([0 if (firsts[j] <= p0 + i <= lasts[j] and p0 + i < nxt) else 255 for i in range(32)], dtype=np.uint8)
+            rec = np.zeros(12, dtype=np.int32)
+            rec[:8] = ids.view(np.int32)
+            rec[8], rec[9], rec[10] = j, 1, (1 if k > 0 else 0) | (2 if k == nt - 1 else 0)
+            info.append(rec)
+        tile_first.append(len(tile_ptr))
+    tile_ptr.append(N)
+    return True, np.array(tile_first), np.array(tile_ptr), np.array(tile_graph), np.array(info, dtype=np.int32).reshape(-1, 12)
 
 
 def tiles_of_workgroup(w, T, G, order):
@@ -47,8 +80,9 @@ def tiles_of_workgroup(w, T, G, order):
     return list(range(hi - 1 - j, lo - 1, -W8))
 
 
-def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False, order=0):
-    """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])})."""
+def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False, order=0, multi=None):
+    """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])}).  order 2 with multi = (tile_graph,
+    tile_first): unit_ptr by CHUNK (graph j in chunk tile_first[j] G // T), units in tile order, AGG records over the graphs."""
     xcd_order = int(order)                             # (`order` is reused below for a sort permutation)
     lp, lr = np.asarray(list_ptr, dtype=np.int64), np.asarray(list_rows, dtype=np.int64)
     T = (N + 31) // 32 if tile_ptr is None else len(tile_ptr) - 1
@@ -84,6 +118,25 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, ag
             ent_r, ent_m = [ent_r[k] for k in order], [ent_m[k] for k in order]
         tiles[t] = (int(lp[p0]), ent_r, ent_m)
     unit_ptr, units = [0], []
+    if xcd_order == 2:
+        tg, tf = (np.asarray(a, dtype=np.int64) for a in multi)
+        S = len(tf) - 1
+        chunk_of = [int(tf[j]) * G // T for j in range(S)]
+        for c in range(G):
+            gs = [j for j in range(S) if chunk_of[j] == c]
+            for j in gs:
+                for t in range(int(tf[j]), int(tf[j + 1])):
+                    e0, ent_r, _ = tiles[t]
+                    cn, p0, pend = len(ent_r), int(tp[t]), int(min(tp[t + 1], tp[t] + 32))
+                    ne, rows = (cn + 31) // 32, (pend - p0) << 8
+                    units.append([(2 if ne == 0 else 0) | rows, p0, pend, t])
+                    for i in range(ne):
+                        units.append([1 | (2 if i == ne - 1 else 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), cn), p0])
+            if agg and gs:
+                units += [[8, 0, 1, 0]] * AGG_GAP
+                units += [[4 | 2 | 32, g0, min(g0 + 32, gs[-1] + 1), 0] for g0 in range(gs[0], gs[-1] + 1, 32)]
+            unit_ptr.append(len(units))
+        return np.array(unit_ptr, dtype=np.int64), np.array(units, dtype=np.int64).reshape(-1, 4), tiles
     for w in range(G):
         nw = 0
         for t in tiles_of_workgroup(w, T, G, xcd_order):

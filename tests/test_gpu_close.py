@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from close_ref import close_units_ref, graph_tiles_ref
+from close_ref import close_units_ref, graph_tiles_multi_ref, graph_tiles_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -283,3 +283,76 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G, order):
         if S > 1 and not all(tpr[j] <= bad[j] < tpr[j + 1] for j in range(S)):
             assert not graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=bad)[0]
             assert int(ops.build_graph_tiles(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int())[2].item()) == 0
+
+
+@pytest.mark.parametrize("G", [256, 8, 5, 1, 48])
+@pytest.mark.parametrize("sizes_kind", ["tu", "huge", "small"])
+def test_absorbed_fold_over_graphs_that_span_several_tiles(sizes_kind, G):
+    """TU-shaped batches (graphs of 1 .. 700 nodes; tu_data_processing.py:179-218 keeps whatever sizes a dataset has): every
+    graph's block cut into 32-node tiles that stay in ONE workgroup's stream (order 2).  Tables against the host restatement, the
+    launch -- out = x W_loop + b + list rows, aux[j] = bf16 column sum of graph j's real nodes accumulated ACROSS its tiles,
+    out[dummy_j] += aux[j] W_agg -- against fp64, bitwise run to run, and, on graphs within one tile, bit-identical to the
+    single-tile tables of round 4."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(G + len(sizes_kind))
+    if sizes_kind == "tu":
+        sizes = [int(np.clip(rng.lognormal(3.4, 0.7), 1, 700)) for _ in range(150)] + [700, 1, 31, 32, 33, 63, 64, 65]
+    elif sizes_kind == "huge":
+        sizes = [1500, 3, 900]
+    else:
+        sizes = list(rng.integers(1, 32, size=120))
+    H, P = 256, 4000
+    lists, ptr, rows, seg_ptr, seg_nodes, dummies, N = _graph_batch(rng, sizes, P)
+    S = len(sizes)
+    sp, sn = torch.from_numpy(seg_ptr).to(DEV).int(), torch.from_numpy(seg_nodes).to(DEV).int()
+    tgt = torch.from_numpy(dummies).to(DEV).int()
+    tile_ptr, info, tile_graph, tile_first, cap, ok = ops.build_graph_tiles_multi(sp, sn, N, add_idx=tgt)
+    okr, tfr, tpr, tgr, infor = graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=dummies)
+    assert okr and int(ok.item()) != 0
+    T = int(tfr[-1])
+    assert T <= cap and np.array_equal(tile_first.cpu().numpy(), tfr) and np.array_equal(tile_ptr.cpu().numpy()[:T + 1], tpr)
+    assert np.array_equal(tile_graph.cpu().numpy()[:T], tgr) and np.array_equal(info.cpu().numpy()[:T], infor)
+    lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
+    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True, multi=(tile_graph, tile_first, cap))
+    assert cu.order == 2 and cu.num_segments == S
+    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True, order=2, multi=(tgr, tfr))
+    assert np.array_equal(cu.unit_ptr.cpu().numpy(), up)
+    assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
+    er, em = cu.ent_row.cpu().numpy(), cu.ent_mask.cpu().numpy().view(np.uint32)
+    for t, (e0, r, m) in tiles.items():
+        assert list(er[e0:e0 + len(r)]) == r and list(em[e0:e0 + len(r)]) == m, t
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    x, Y = bf(rng.standard_normal((N, H))), bf(rng.standard_normal((P, H)))
+    W, Wa = bf(rng.standard_normal((H, H)) / np.sqrt(H)), bf(rng.standard_normal((H, H)) / np.sqrt(H))
+    b = bf(rng.standard_normal(H))
+    aux_ref = torch.stack([x[seg_nodes[seg_ptr[j]:seg_ptr[j + 1]]].double().sum(0) for j in range(S)])
+    outs = []
+    for w_kn in (True, False, True):
+        aux = torch.full((S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        Wd, Wad = (W.to(DEV), Wa.to(DEV)) if w_kn else (W.t().contiguous().to(DEV), Wa.t().contiguous().to(DEV))
+        out = ops.rows_close(x.to(DEV), Wd, b.to(DEV), Y.to(DEV), cu, w_kn=w_kn, agg=(info, Wad, aux, tgt))
+        outs.append((out.clone(), aux.clone()))
+        # (a 700-node sum of N(0,1) rows is ~26 wide: one bf16 rounding of it is 2^-9 relative)
+        assert float((aux.cpu().double() - aux_ref).abs().max() / aux_ref.abs().max()) < 5e-3
+        ref = _ref_close(x, W, b, Y, lists, P)
+        ref[dummies] += aux.cpu().double() @ Wa.double()
+        err = (out.cpu().double() - ref).abs() / (ref.abs() + 1.0)
+        real = np.setdiff1d(np.arange(N), dummies)
+        assert float(err[real].max()) < 8e-3, (w_kn, float(err[real].max()))
+        prod = (aux.cpu().double() @ Wa.double()).abs()
+        errd = (out.cpu().double() - ref)[dummies].abs() / (ref[dummies].abs() + prod + 1.0)
+        assert float(errd.max()) < 8e-3, (w_kn, float(errd.max()))
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])       # bitwise run to run
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # ... and in both weight layouts
+    if sizes_kind == "small":                              # every graph inside one tile: the same arithmetic as the single-tile tables
+        tp1, info1, ok1 = ops.build_graph_tiles(sp, sn, N, add_idx=tgt)
+        assert int(ok1.item()) != 0 and np.array_equal(tp1.cpu().numpy(), tpr) and np.array_equal(info1.cpu().numpy(), infor)
+        cu1 = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tp1, agg=True, order=0)
+        aux1 = torch.empty((S, H), dtype=torch.bfloat16, device=DEV)
+        out1 = ops.rows_close(x.to(DEV), W.to(DEV), b.to(DEV), Y.to(DEV), cu1, w_kn=True, agg=(info1, Wa.to(DEV), aux1, tgt))
+        assert torch.equal(out1, outs[0][0]) and torch.equal(aux1, outs[0][1])
+    # a target row outside its segment's own block: "no", as for the single-tile tables
+    if S > 1:
+        bad = np.roll(dummies, 1)
+        assert not graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=bad)[0]
+        assert int(ops.build_graph_tiles_multi(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int())[5].item()) == 0

@@ -775,3 +775,74 @@ def test_absorbed_fold_only_where_the_dummy_row_belongs_to_its_own_tile(layout, 
     ref = OL.rgin_layer(x0.double().cpu(), src.cpu(), dst.cpu(), et.cpu(), p64, regularizer="basis", num_rels=R, num_bases=-1,
                         num_mlp_layers=2, act="relu")
     assert _rel_l2(got[0], ref) < 3e-2
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_absorbed_fold_on_tu_shaped_batches_with_graphs_of_1_to_700_nodes(seed):
+    """north_star quotes the roofline on TU-shaped batches, and TU graphs are not all within 32 nodes (tu_data_processing.py:179-218;
+    PROTEINS reaches 620).  RGINLayer H = 256 bf16 on graphs of 1 .. 700 real nodes + the SI dummy node (train.py:404-474): both
+    directions take the ABSORBED fold over multi-tile graphs (unit order 2: four conv launches per step, no partial rows, no tail
+    launch), the graph-local index builder serves the batch -- its graphs of more than 1024 edges one by one --, and the step equals
+    the partial-row path of rounds 4-5 (DN_CLOSE_MULTI=0) up to the bf16 rounding of the collapsed rows, fp64 math within bf16
+    noise, and itself bit for bit."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    rng = np.random.default_rng(40 + seed)
+    H, R = 256, 8
+    sizes = [int(np.clip(rng.lognormal(3.4, 0.7), 1, 700)) for _ in range(90)] + [700, 1, 2, 31, 32, 33, 64, 65, 300]
+    src, dst, et, node_ptr, edge_ptr = [], [], [], [0], [0]
+    for n in sizes:
+        base, m = node_ptr[-1], int(1.9 * n)
+        s_, t_ = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+        src += [base + s_, base + np.arange(n), np.full(n, base + n)]
+        dst += [base + t_, np.full(n, base + n), base + np.arange(n)]
+        et += [rng.integers(0, R - 2, size=m), np.full(n, R - 2), np.full(n, R - 1)]
+        node_ptr.append(base + n + 1)
+        edge_ptr.append(edge_ptr[-1] + m + 2 * n)
+    cat = lambda a: torch.from_numpy(np.concatenate(a).astype(np.int64)).to(DEV)  # noqa: E731
+    src, dst, et, N, G = cat(src), cat(dst), cat(et), node_ptr[-1], len(sizes)
+    assert max(np.diff(edge_ptr)) > 1024
+    torch.manual_seed(4)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    t = lambda a: torch.tensor(a, device=DEV, dtype=torch.int32)  # noqa: E731
+
+    def run(multi):
+        old = ops.CLOSE_MULTI_ENABLED
+        ops.CLOSE_MULTI_ENABLED = multi
+        try:
+            g = BatchedGraph(src, dst, N, torch.tensor(np.diff(node_ptr)), torch.tensor(np.diff(edge_ptr)), node_ptr=t(node_ptr),
+                             edge_ptr=t(edge_ptr))
+            for p in layer.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            timer = ops.KernelTimer()
+            ops.kernel_timer = timer
+            try:
+                out, _ = layer(g, x, et)
+                out.backward(coef)
+            finally:
+                ops.kernel_timer = None
+            ix = g.row_index(et, R, True).parts[0][2]
+            tags = [r[0] for r in timer.records]
+            return ix, tags, [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            ops.CLOSE_MULTI_ENABLED = old
+
+    ix, tags, got = run(True)
+    assert ix.built_by == "local"
+    assert [ix.close_units(d).order for d in "fb"] == [2, 2] and all(ix.close_units(d).agg for d in "fb")
+    assert tags.count("rows_close") == 2 and "fold_tail" not in tags and tags.count("rows_transform:conv") == 2, tags
+    ix0, tags0, want = run(False)
+    assert tags0.count("fold_tail") == 2 and not any(ix0.close_units(d).agg for d in "fb")
+    for a, b in zip(got, want):
+        assert _rel_l2(a, b) < 1e-2
+    _, _, again = run(True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    ref = OL.rgin_layer(x0.double().cpu(), src.cpu(), dst.cpu(), et.cpu(), p64, regularizer="basis", num_rels=R, num_bases=-1,
+                        num_mlp_layers=2, act="relu")
+    assert _rel_l2(got[0], ref) < 3e-2
