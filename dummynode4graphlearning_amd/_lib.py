@@ -80,12 +80,11 @@ _SIGS = {
     "dn_close_units_capacity": (c_i64, [c_i64, c_i64, c_i32]),
     "dn_close_units_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "dn_close_units_build_i32": (ctypes.c_int, [c_i64, c_i32, c_i32, P, c_i64, c_i32, c_i32, P, P, c_i64, c_i32, c_i32, P, P, P, c_i64, P,
-                                                P, P, P, c_i64, P, c_sz, P]),
+                                                P, P, P, c_i32, P, c_sz, P]),
     "dn_fold_graph_tiles_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P, P, P]),
-    "dn_fold_graph_tiles_multi_workspace_bytes": (c_sz, [c_i64]),
-    "dn_fold_graph_tiles_multi_capacity": (c_i64, [c_i64, c_i64]),
-    "dn_fold_graph_tiles_multi_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, P, P, P, P, c_i64, P, P, c_sz, P]),
-    "dn_rows_close_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, P, P, c_i32, P, P, c_i64, P, P, P, P, P, P, c_i32, P]),
+    "dn_fold_graph_tiles_multi_capacity": (c_i64, [c_i64, c_i32]),
+    "dn_fold_graph_tiles_multi_build_i32": (ctypes.c_int, [c_i64, c_i64, P, P, P, c_i32, P, P, P, P, c_i64, P, P]),
+    "dn_rows_close_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, P, P, c_i32, P, P, c_i64, P, P, P, P, P, P, P]),
     "dn_bdd_compose": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),
     "dn_bdd_extract": (ctypes.c_int, [P, c_i64, c_i32, c_i32, c_i32, c_i32, P, P]),
     "dn_fold_tables_workspace_bytes": (c_sz, [c_i64]),

@@ -70,34 +70,39 @@ __device__ __forceinline__ void cb_position(int32_t t, int32_t T, int32_t G, int
 }
 constexpr int kAggGap = 8;             // NOP units between a workgroup's last tile and its first AGG unit (>= the loaders' run-ahead)
 
-// Order 2 (round 6: graphs that span several tiles, dn_fold_graph_tiles_multi_build_i32).  The tiles are cut into G CHUNKS at graph
-// boundaries -- graph j (first tile tile_first[j]) belongs to chunk floor(tile_first[j] G / T) -- so that a graph's tiles follow
-// each other in ONE stream (the per-graph column sum accumulates across them in registers, the AGG unit's read-modify-write of
-// the dummy node's row stays inside the workgroup that stored it).  A chunk = a contiguous range of graphs = a contiguous range
-// of tiles, walked upwards; tables are laid out in tile order, unit_ptr is indexed by CHUNK, and the launch gives chunk
-// (w & 7) G/8 + (w >> 3) to workgroup w (G a multiple of 8: XCD x = the x-th eighth of the batch, as the transform's sweep order).
-__device__ __forceinline__ int32_t cb2_chunk(int32_t tile_first_j, int32_t T, int32_t G) { return (int32_t)(((int64_t)tile_first_j * G) / T); }
-__device__ __forceinline__ int32_t cb2_first_graph(int32_t c, int32_t T, int32_t G, const int32_t* __restrict__ tile_first, int32_t S) {
-    const int32_t want = (int32_t)(((int64_t)c * T + G - 1) / G);         // first j in [0, S] with tile_first[j] >= ceil(c T / G)
-    int32_t lo = 0, hi = S;
+// Orders 2 / 3 (round 6: graphs of any size, dn_fold_graph_tiles_multi_build_i32).  The batch is cut into C = K G CHUNKS at graph
+// boundaries and a chunk into consecutive 32-node tiles (chunk_tile [C + 1]: first tile of a chunk, chunk_graph [C + 1]: its first
+// graph).  The chunks -- not the tiles -- are dealt to the workgroups, K each, by cb_position (order 2: as order 0, order 3: as order
+// 1), so a graph's tiles follow each other in ONE stream (the per-graph column sum continues from tile to tile inside the
+// workgroup, the AGG unit's read-modify-write of the dummy node's row stays inside the workgroup that stored it) while the launch
+// still sweeps the batch as a front of short runs.  A workgroup's AGG units (one per 32 graphs of each of its chunks: the aux rows
+// themselves) close its stream behind one gap.
+__device__ __forceinline__ int32_t cb2_chunk_of_tile(int32_t t, int32_t G, const int32_t* __restrict__ chunk_tile) {
+    int32_t lo = 0, hi = G;                                               // the last c with chunk_tile[c] <= t
     while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (tile_first[mid] < want) lo = mid + 1;
-        else hi = mid;
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (chunk_tile[mid] <= t) lo = mid;
+        else hi = mid - 1;
     }
     return lo;
 }
-// is tile t the last of its chunk?  -> the chunk's graphs [g_lo, g_hi)
-__device__ __forceinline__ bool cb2_last_of_chunk(int32_t t, int32_t T, int32_t G, const int32_t* __restrict__ tile_first,
-                                                  const int32_t* __restrict__ tile_graph, int32_t S, int32_t& g_lo, int32_t& g_hi) {
-    const int32_t j = tile_graph[t], c = cb2_chunk(tile_first[j], T, G);
-    if (t + 1 < T) {
-        const int32_t j1 = tile_graph[t + 1];
-        if (j1 == j || cb2_chunk(tile_first[j1], T, G) == c) return false;
+// the n-th tile (chunk) of workgroup w: the inverse of cb_position
+__device__ __forceinline__ int32_t cb_nth(int32_t w, int32_t n, int32_t T, int32_t G, int32_t order) {
+    if (!order) return w + G * n;
+    const int x = w & 7;
+    return cb_eighth(x + 1, T) - 1 - ((w >> 3) + (G >> 3) * n);
+}
+// gap + AGG units that close workgroup w's stream (0: it has no tiles)
+__device__ __forceinline__ int32_t cb2_tail_units(int32_t w, int32_t G, int32_t K, int32_t sub, const int32_t* __restrict__ chunk_tile,
+                                                  const int32_t* __restrict__ chunk_graph) {
+    int32_t ex = 0;
+    bool any = false;
+    for (int32_t n = 0; n < K; ++n) {
+        const int32_t c = cb_nth(w, n, G * K, G, sub);
+        ex += (chunk_graph[c + 1] - chunk_graph[c] + 31) / 32;
+        any = any || chunk_tile[c + 1] > chunk_tile[c];
     }
-    g_lo = cb2_first_graph(c, T, G, tile_first, S);
-    g_hi = j + 1;
-    return true;
+    return any ? kAggGap + ex : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- tables
@@ -140,8 +145,7 @@ struct CbLds {
 // backward stream of a batch in ONE set of launches; dn_close_units_build_i32 passes one).
 struct CbDir {
     const int32_t *tile_ptr, *lptr, *lrows, *drop_enable, *dyn;
-    const int32_t *tile_graph, *tile_first;                                // order 2: tile -> graph, graph -> first tile [S + 1]
-    int32_t S;
+    const int32_t *chunk_tile, *chunk_graph;                               // orders 2 / 3: first tile / first graph of every chunk [K G + 1]
     int32_t *ent_row, *tile_cnt, *ucnt, *unit_ptr;
     uint32_t* ent_mask;
     const int32_t* uoff;
@@ -158,9 +162,13 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     const int t = (int)blockIdx.x * kCbWaves + wave;
     if (t >= T) return;                                                    // (no workgroup barrier below)
     const CbDir& a = pr.d[blockIdx.y];
-    if (order == 2) {                                                      // T was a bound: the tiles there are
+    if (order >= 2) {                                                      // chunked: Tper = K chunks per workgroup; T was a bound
         if (a.dyn != nullptr && a.dyn[3] == 0) return;
-        T = a.tile_first[a.S];
+        if (agg && t < G && lane == 0) {                                   // (T >= K G >= G) the tail of workgroup t's stream
+            const int32_t ex = cb2_tail_units(t, G, Tper, order - 2, a.chunk_tile, a.chunk_graph);
+            if (ex) atomicAdd(&a.ucnt[(int64_t)t * Tper + Tper - 1], ex);
+        }
+        T = a.chunk_tile[G * Tper];
         if (t >= T) return;
     }
     const int32_t* __restrict__ tile_ptr = a.tile_ptr;
@@ -186,16 +194,18 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     int32_t pw = 0, pn = 0;
     bool plast;
     int64_t upos;                                                          // where this tile's unit count goes (the scan's order)
-    if (order == 2) {
-        int32_t g_lo = 0, g_hi = 0;
-        plast = cb2_last_of_chunk(t, T, G, a.tile_first, a.tile_graph, a.S, g_lo, g_hi);
-        pn = g_hi - g_lo - 1;                                              // (pn + 1 = the chunk's graphs)
-        upos = t;
+    if (order >= 2) {                                                      // the tile's CHUNK has a position; unit counts add up per chunk
+        cb_position(cb2_chunk_of_tile(t, G * Tper, a.chunk_tile), G * Tper, G, order - 2, pw, pn, plast);
+        plast = false;                                                     // (the tails were added above)
     } else {
         cb_position(t, T, G, order, pw, pn, plast);
-        upos = (int64_t)pw * Tper + pn;
     }
+    upos = (int64_t)pw * Tper + pn;
     auto units_of = [&](int c) { return 1 + (c + 31) / 32 + ((agg && plast) ? kAggGap + (pn + 1 + 31) / 32 : 0); };
+    auto put_units = [&](int c) {
+        if (order >= 2) atomicAdd(&ucnt[upos], units_of(c));
+        else ucnt[upos] = units_of(c);
+    };
     bool plain = raw > kCbCap;
     if (!plain) {
         const int my0 = lane <= nn ? lptr[p0 + lane] - lb : raw;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
                 ent_row[lb + rank] = (int32_t)ri;
                 ent_mask[lb + rank] = L.smask[i];
             }
-            if (lane == 0) { tile_cnt[t] = n; ucnt[upos] = units_of(n); }
+            if (lane == 0) { tile_cnt[t] = n; put_units(n); }
             return;
         }
     }
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
         if (!kept(r)) continue;
         ent_row[at] = r; ent_mask[at] = 1u << lane; ++at;
     }
-    if (lane == 0) { tile_cnt[t] = total; ucnt[upos] = units_of(total); }
+    if (lane == 0) { tile_cnt[t] = total; put_units(total); }
 }
 
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
@@ -320,15 +330,33 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
     const int32_t* __restrict__ uoff = a.uoff;
     Unit* __restrict__ units = a.units;
     const int32_t base = uoff[0];                                          // (both directions share one scan: the second starts at the first's total)
-    int32_t w = 0, n = 0, g_lo = 0, g_hi = 0;
+    int32_t w = 0, n = 0;
     bool plast;
     int64_t k;
-    if (order == 2) {
-        T = a.tile_first[a.S];                                             // (the argument was a bound)
-        if (t <= G) a.unit_ptr[t] = uoff[a.tile_first[cb2_first_graph((int32_t)t, T, G, a.tile_first, a.S)]] - base;   // unit_ptr by CHUNK
+    int32_t inner = 0;                                                     // units of the earlier tiles of my chunk (chunked orders)
+    if (order >= 2) {
+        const int32_t K = Tper, C = G * K, sub = order - 2;
+        T = a.chunk_tile[C];                                               // (the argument was a bound)
+        if (t <= G) a.unit_ptr[t] = uoff[t * K] - base;
+        if (agg && t < G) {                                                // the tail of workgroup t: the gap, then its chunks' AGG units
+            const int32_t ex = cb2_tail_units((int32_t)t, G, K, sub, a.chunk_tile, a.chunk_graph);
+            if (ex) {
+                Unit* q = units + (uoff[(t + 1) * K] - base - ex);
+                for (int i = 0; i < kAggGap; ++i) q[i] = Unit{kUnitNop, 0, 1, 0};
+                q += kAggGap;
+                for (int32_t nn = 0; nn < K; ++nn) {
+                    const int32_t c = cb_nth((int32_t)t, nn, C, G, sub);
+                    for (int32_t g0 = a.chunk_graph[c]; g0 < a.chunk_graph[c + 1]; g0 += 32)
+                        *q++ = Unit{kUnitAgg | kUnitLast | kUnitAggAbs, g0, min(g0 + 32, a.chunk_graph[c + 1]), 0};
+                }
+            }
+        }
         if (t >= T) return;
-        plast = cb2_last_of_chunk((int32_t)t, T, G, a.tile_first, a.tile_graph, a.S, g_lo, g_hi);
-        k = t;
+        const int32_t c = cb2_chunk_of_tile((int32_t)t, C, a.chunk_tile);
+        cb_position(c, C, G, sub, w, n, plast);
+        plast = false;
+        for (int32_t tt = a.chunk_tile[c]; tt < (int32_t)t; ++tt) inner += 1 + (tile_cnt[tt] + 31) / 32;
+        k = (int64_t)w * K + n;
     } else {
         if (t <= G) a.unit_ptr[t] = uoff[t * Tper] - base;                 // (position G * Tper holds the total)
         if (t >= T) return;
@@ -338,7 +366,7 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
     const int32_t p0 = tile_ptr ? tile_ptr[t] : (int32_t)t * 32;
     const int32_t pend = tile_ptr ? min(tile_ptr[t + 1], p0 + 32) : min(p0 + 32, N);
     const int32_t c = tile_cnt[t], e0 = lptr[p0], rows = (pend - p0) << 8;
-    Unit* u = units + (uoff[k] - base);
+    Unit* u = units + (uoff[k] - base + inner);
     const int ne = (c + 31) / 32;
     u[0] = Unit{(ne == 0 ? kUnitLast : 0) | rows, p0, pend, (int32_t)t};
     for (int i = 0; i < ne; ++i)
@@ -348,11 +376,6 @@ __global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper,
         Unit* q = u + 1 + ne;
         for (int i = 0; i < kAggGap; ++i) q[i] = Unit{kUnitNop, 0, 1, 0};
         q += kAggGap;
-        if (order == 2) {                                                  // the chunk's graphs themselves
-            for (int i = 0; g_lo + 32 * i < g_hi; ++i)
-                q[i] = Unit{kUnitAgg | kUnitLast | kUnitAggAbs, g_lo + 32 * i, min(g_lo + 32 * (i + 1), g_hi), 0};
-            return;
-        }
         for (int i = 0; 32 * i < nw; ++i) q[i] = Unit{kUnitAgg | kUnitLast | (order ? kUnitXcd : 0), 32 * i, min(32 * (i + 1), nw), order ? T : 0};
     }
 }
@@ -370,15 +393,61 @@ __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __r
     dn_fold_graph_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, tile_ptr, info, ok);
 }
 
-__global__ void fold_multi_count_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
-                                        const int32_t* __restrict__ add_idx, int32_t* __restrict__ ntiles, int32_t* __restrict__ ok) {
-    dn_fold_multi_count_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, ntiles, ok);
+__global__ void fold_multi_valid_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
+                                        const int32_t* __restrict__ add_idx, int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
+    if (gate != nullptr && *gate == 0) return;
+    dn_fold_multi_valid_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, ok);
 }
-__global__ void fold_multi_fill_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
-                                       const int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_ptr,
-                                       int32_t* __restrict__ tile_graph, int32_t* __restrict__ info, const int32_t* __restrict__ ok) {
-    if (*ok == 0) return;                                                  // (an invalid batch's tile count is not bounded by the tables' sizes)
-    dn_fold_multi_fill_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, tile_first, tile_ptr, tile_graph, info);
+// ONE workgroup: chunk c = the graphs whose blocks start in [ceil(c N / C), ceil((c + 1) N / C)); tiles per chunk, their prefix sums.
+// gate (may be NULL): a device word that must be non-zero for the tables to be wanted at all.
+constexpr int kChunkThreads = 1024, kChunkMax = 16384;
+__global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr,
+                                                                          const int32_t* __restrict__ snodes,
+                                                                          int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_graph,
+                                                                          const int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
+    __shared__ int32_t cg[kChunkMax + 1];
+    __shared__ int32_t wsum[kChunkThreads / 64];
+    if (*ok == 0 || (gate != nullptr && *gate == 0)) return;               // (an invalid batch's tables are never read)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c <= C; c += kChunkThreads)
+        cg[c] = c == C ? S : dn_fold_first_graph_from((int32_t)(((int64_t)c * N + C - 1) / C), N, S, sptr, snodes);
+    __syncthreads();
+    constexpr int K = kChunkMax / kChunkThreads;                          // consecutive chunks per thread
+    int32_t nt[K], mine = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = tid * K + k;
+        nt[k] = 0;
+        if (c < C) {
+            const int32_t n_lo = dn_fold_gstart(cg[c], N, S, sptr, snodes), n_hi = dn_fold_gstart(cg[c + 1], N, S, sptr, snodes);
+            nt[k] = (n_hi - n_lo + 31) / 32;
+        }
+        mine += nt[k];
+    }
+    int32_t run = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(run, d, 64);
+        if (lane >= d) run += o;
+    }
+    if (lane == 63) wsum[wave] = run;
+    __syncthreads();
+    int32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += wsum[w];
+    run += carry - mine;                                                   // tiles of the chunks before mine
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = tid * K + k;
+        if (c <= C) { chunk_tile[c] = run; chunk_graph[c] = cg[c]; }
+        run += nt[k];
+    }
+}
+__global__ void fold_multi_tiles_kernel(int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
+                                        const int32_t* __restrict__ chunk_tile, const int32_t* __restrict__ chunk_graph,
+                                        int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, const int32_t* __restrict__ ok,
+                                        const int32_t* __restrict__ gate) {
+    if (*ok == 0 || (gate != nullptr && *gate == 0)) return;
+    dn_fold_multi_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, C, sptr, snodes, chunk_tile, chunk_graph, tile_ptr, info);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernel
@@ -431,10 +500,8 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
-    // (order 2: unit_ptr is indexed by CHUNK; workgroup 8 j + x -- XCD x -- takes chunk x nwg/8 + j)
-    const int ui = ((flags & 256) && (nwg & 7) == 0) ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg;
-    const int u_beg = unit_ptr[ui];
-    const int nt = unit_ptr[ui + 1] - u_beg;
+    const int u_beg = unit_ptr[wg];
+    const int nt = unit_ptr[wg + 1] - u_beg;
     if (nt <= 0) return;
     units += u_beg;
 
@@ -749,6 +816,13 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                         id[i] = (w0[i] >> (8 * g)) & 0xffu;
                         id[4 + i] = (w1[i] >> (8 * g)) & 0xffu;
                     }
+                    // (FOLD 2: the sum a tile's first segment may continue -- requested in front of the transposed reads, so that
+                    //  one wait covers both; used or not is decided below)
+                    f32x4 sg0 = {0.f, 0.f, 0.f, 0.f}, sg1 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FOLD == 2) {
+                        sg0 = *reinterpret_cast<const f32x4*>(&segL[wave][g][0]);
+                        sg1 = *reinterpret_cast<const f32x4*>(&segL[wave][g][4]);
+                    }
                     bf16x8 a[2];
                     tr_frags(lds_base + sb, a);
                     for (int m0 = 0; m0 < cnt; m0 += 16) {                 // (more than 16 segments in 32 rows: graphs of 1-2 nodes)
@@ -765,23 +839,20 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
                                 if ((int)me < cnt)
                                     *reinterpret_cast<f32x4*>(seg_part + (size_t)(first + (int)me) * kH + ocol + 4 * n) = d;
                             }
-                        } else {                                           // the segment is complete (with this tile): its sum IS the aux row
-                            // (a graph that spans several tiles -- fold record word 10: bit 0 = continues the previous X unit's sum,
-                            //  bit 1 = completes it: the running sum waits in this wave's 128 bytes of segL, not in registers; a
-                            //  graph inside one tile touches neither)
+                        } else {                                           // a segment that is complete: its sum IS the aux row
+                            // (graphs of any size -- fold record word 10: bit 0 = the tile's FIRST segment continues the previous X
+                            //  unit's sum, bit 1 = its LAST segment ends in this tile.  A sum that goes on waits in this wave's 128
+                            //  bytes of segL, not in registers; graphs inside one tile touch neither)
                             const int fb = __builtin_amdgcn_readfirstlane(fr[10]);
-                            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                            if ((fb & 1) && j == 0) {
-                                c0 = *reinterpret_cast<const f32x4*>(&segL[wave][g][0]);
-                                c1 = *reinterpret_cast<const f32x4*>(&segL[wave][g][4]);
-                            }
+                            const bool carry = (fb & 1) && me == 0u;
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 c0 = carry ? sg0 : z, c1 = carry ? sg1 : z;
                             const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ind, c0, 0, 0, 0);
                             const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ind, c1, 0, 0, 0);
-                            if (!(fb & 2) && j == 0) {
+                            if (!(fb & 2) && (int)me == cnt - 1) {         // goes on in the next tile (a later X unit of this wave)
                                 *reinterpret_cast<f32x4*>(&segL[wave][g][0]) = d0;
                                 *reinterpret_cast<f32x4*>(&segL[wave][g][4]) = d1;
-                            }
-                            if ((int)me < cnt && (fb & 2)) {
+                            } else if ((int)me < cnt) {
                                 const u32x4 o = {pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
                                                  pack_bf16x2(d1[2], d1[3])};
                                 *reinterpret_cast<u32x4*>(aux + (size_t)(first + (int)me) * kH + ocol) = o;
@@ -889,13 +960,13 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
                       int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 && num_tiles >= 0 &&
                num_tiles < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_close_units_build: bad sizes");
-    DN_REQUIRE(xcd_order == 0 || xcd_order == 2 || (xcd_order == 1 && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
+    DN_REQUIRE(xcd_order == 0 || xcd_order == 2 || ((xcd_order == 1 || xcd_order == 3) && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
                "dn_close_units_build: the XCD order needs a multiple of 8 workgroups");
     for (int k = 0; k < nd; ++k) {
         DN_REQUIRE(dirs[k].num_edge_rows >= 0, "dn_close_units_build: bad sizes");
-        DN_REQUIRE(xcd_order != 2 || (dirs[k].tile_ptr && dirs[k].tile_graph && dirs[k].tile_first && dirs[k].num_segments >= 1 &&
-                                      dirs[k].num_segments <= num_tiles),
-                   "dn_close_units_build: order 2 takes the tables of dn_fold_graph_tiles_multi_build_i32 (tile_ptr, tile_graph, tile_first)");
+        DN_REQUIRE(xcd_order < 2 || (dirs[k].tile_ptr && dirs[k].chunk_tile && dirs[k].chunk_graph && dirs[k].chunks_per_wg >= 1 &&
+                                     (int64_t)dirs[k].chunks_per_wg * num_wg <= num_tiles && dirs[k].chunks_per_wg == dirs[0].chunks_per_wg),
+                   "dn_close_units_build: orders 2 / 3 take the tables of dn_fold_graph_tiles_multi_build_i32 (tile_ptr, chunk_tile, chunk_graph, chunks per workgroup)");
         DN_REQUIRE(dirs[k].tile_ptr != nullptr || num_tiles == dn_cdiv(N, 32), "dn_close_units_build: without tile_ptr the tiles are the "
                    "%lld 32-node windows", (long long)dn_cdiv(N, 32));
         DN_REQUIRE(dirs[k].unit_ptr, "dn_close_units_build: NULL pointer");
@@ -912,8 +983,9 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
     DN_REQUIRE(workspace_bytes >= (size_t)nd * dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "dn_close_units_build: unaligned pointer");
-    const int32_t T = (int32_t)num_tiles, Tper = (int32_t)dn_cdiv(T, num_wg);
-    const int64_t M = xcd_order == 2 ? (int64_t)T : (int64_t)num_wg * Tper;  // (order 2: the unit counts lie in tile order)
+    // (chunked orders: the scan runs over the workgroups' K chunk slots, Tper = K)
+    const int32_t T = (int32_t)num_tiles, Tper = xcd_order >= 2 ? dirs[0].chunks_per_wg : (int32_t)dn_cdiv(T, num_wg);
+    const int64_t M = (int64_t)num_wg * Tper;
     DN_REQUIRE((int64_t)nd * (unit_capacity + 1) < 0x7fffffffLL, "dn_close_units_build: unit tables too large");   // (one scan over both)
     char* wsp = reinterpret_cast<char*>(workspace);
     int32_t* tile_cnt[2] = {nullptr, nullptr};
@@ -930,7 +1002,7 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     CbPair pr;
     for (int k = 0; k < 2; ++k) {
         const CloseUnitsDir& d = dirs[k < nd ? k : 0];
-        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.tile_graph, d.tile_first, d.num_segments, d.ent_row,
+        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.chunk_tile, d.chunk_graph, d.ent_row,
                         tile_cnt[k < nd ? k : 0],
                         ucnt + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), d.unit_ptr, d.ent_mask,
                         uoff + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), reinterpret_cast<Unit*>(d.units), d.num_edge_rows, d.drop_beg,
@@ -947,19 +1019,17 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     return DN_OK;
 }
 
-int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx, int32_t* tile_first,
-                     int32_t* tile_ptr, int32_t* tile_graph, int32_t* fold_info, int32_t* dev_ok, void* workspace, size_t workspace_bytes,
-                     hipStream_t st) {
-    int32_t* ntiles = reinterpret_cast<int32_t*>(workspace);
-    char* tmp = reinterpret_cast<char*>(workspace) + dn_align_up((size_t)(S + 1) * 4, 256);
-    size_t tb = 0;
-    DN_CHECK_HIP(rocprim::exclusive_scan(nullptr, tb, ntiles, tile_first, (int32_t)0, (size_t)(S + 1), rocprim::plus<int32_t>(), st));
-    DN_REQUIRE(dn_align_up((size_t)(S + 1) * 4, 256) + tb <= workspace_bytes, "dn_fold_graph_tiles_multi_build: workspace too small");
-    const unsigned grid = (unsigned)dn_cdiv(S + 1, 256);
-    hipLaunchKernelGGL(fold_multi_count_kernel, dim3(grid), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes, add_idx, ntiles, dev_ok);
-    DN_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, ntiles, tile_first, (int32_t)0, (size_t)(S + 1), rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(fold_multi_fill_kernel, dim3(grid), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes, tile_first, tile_ptr,
-                       tile_graph, fold_info, dev_ok);
+int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx, int32_t num_chunks,
+                     int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok,
+                     const int32_t* gate, hipStream_t st) {
+    DN_REQUIRE(num_chunks >= 1 && num_chunks <= kChunkMax, "dn_fold_graph_tiles_multi_build: 1 .. %d chunks", kChunkMax);
+    DN_REQUIRE(tile_capacity >= N / 32 + num_chunks + 1, "dn_fold_graph_tiles_multi_build: tile tables too small");
+    hipLaunchKernelGGL(fold_multi_valid_kernel, dim3((unsigned)dn_cdiv(S, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes,
+                       add_idx, dev_ok, gate);
+    hipLaunchKernelGGL(fold_multi_chunks_kernel, dim3(1), dim3(kChunkThreads), 0, st, (int32_t)N, (int32_t)S, num_chunks, seg_ptr, seg_nodes,
+                       chunk_tile, chunk_graph, dev_ok, gate);
+    hipLaunchKernelGGL(fold_multi_tiles_kernel, dim3((unsigned)dn_cdiv(tile_capacity + 1, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S,
+                       num_chunks, seg_ptr, seg_nodes, chunk_tile, chunk_graph, tile_ptr, fold_info, dev_ok, gate);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -968,34 +1038,27 @@ int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t
 
 extern "C" {
 
-size_t dn_fold_graph_tiles_multi_workspace_bytes(int64_t num_segments) {
-    if (num_segments < 0 || num_segments >= INT32_MAX) { dn_set_error("dn_fold_graph_tiles_multi_workspace_bytes: bad sizes"); return 0; }
-    // (the scan's temporary storage bounded without asking rocPRIM, as in dn_close_units_workspace_bytes)
-    return dn_align_up((size_t)(num_segments + 1) * 4, 256) + 65536 + 4 * (size_t)(num_segments + 1) + 256;
-}
-
-int64_t dn_fold_graph_tiles_multi_capacity(int64_t N, int64_t num_segments) { return num_segments + N / 32 + 1; }
+int64_t dn_fold_graph_tiles_multi_capacity(int64_t N, int32_t num_chunks) { return N / 32 + num_chunks + 1; }
 
 int dn_fold_graph_tiles_multi_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                                        const int32_t* add_idx, int32_t* tile_first, int32_t* tile_ptr, int32_t* tile_graph,
-                                        int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok, void* workspace,
-                                        size_t workspace_bytes, dn_stream_t stream) {
+                                        const int32_t* add_idx, int32_t num_chunks, int32_t* chunk_tile, int32_t* chunk_graph,
+                                        int32_t* tile_ptr, int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok,
+                                        dn_stream_t stream) {
     DN_REQUIRE(N >= 0 && num_segments >= 0 && N < INT32_MAX && num_segments < INT32_MAX, "dn_fold_graph_tiles_multi_build: bad sizes");
     DN_REQUIRE(dev_ok, "dn_fold_graph_tiles_multi_build: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     if (N == 0 || num_segments == 0) { DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0, sizeof(int32_t), st)); return DN_OK; }
-    DN_REQUIRE(seg_ptr && seg_nodes && tile_first && tile_ptr && tile_graph && fold_info && workspace, "dn_fold_graph_tiles_multi_build: NULL pointer");
-    DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
-               "dn_fold_graph_tiles_multi_build: unaligned pointer");
-    DN_REQUIRE(tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, num_segments), "dn_fold_graph_tiles_multi_build: tile tables too small");
-    DN_REQUIRE(workspace_bytes >= dn_fold_graph_tiles_multi_workspace_bytes(num_segments), "dn_fold_graph_tiles_multi_build: workspace too small");
+    DN_REQUIRE(seg_ptr && seg_nodes && chunk_tile && chunk_graph && tile_ptr && fold_info, "dn_fold_graph_tiles_multi_build: NULL pointer");
+    DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0, "dn_fold_graph_tiles_multi_build: unaligned pointer");
     DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
-    return dn_internal::fold_multi_queue(N, num_segments, seg_ptr, seg_nodes, add_idx, tile_first, tile_ptr, tile_graph, fold_info, dev_ok,
-                                         workspace, workspace_bytes, st);
+    return dn_internal::fold_multi_queue(N, num_segments, seg_ptr, seg_nodes, add_idx, num_chunks, chunk_tile, chunk_graph, tile_ptr,
+                                         fold_info, tile_capacity, dev_ok, nullptr, st);
 }
 
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {
-    return 2 * num_tiles + num_list_entries / 32 + 1 + (int64_t)num_wg * (kAggGap + 1) + num_tiles / 32;
+    // X units + the rounding of the entry units, entry units, per workgroup the gap + the rounding of the AGG units, AGG units
+    // (order 2: one per 32 GRAPHS, and a tile may hold up to 32 of them)
+    return 2 * num_tiles + num_list_entries / 32 + 1 + (int64_t)num_wg * (kAggGap + 1) + num_tiles;
 }
 
 size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
@@ -1010,12 +1073,11 @@ size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg) {
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
                              int32_t agg_units, int32_t xcd_order, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
-                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, const int32_t* tile_graph,
-                             const int32_t* tile_first, int64_t num_segments, void* workspace, size_t workspace_bytes,
+                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, const int32_t* chunk_tile,
+                             const int32_t* chunk_graph, int32_t chunks_per_wg, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream) {
-    DN_REQUIRE(num_segments >= 0 && num_segments < INT32_MAX, "dn_close_units_build: bad sizes");
     const dn_internal::CloseUnitsDir d{tile_ptr, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, drop_enable, nullptr, unit_ptr,
-                                       units, ent_row, ent_mask, tile_graph, tile_first, (int32_t)num_segments};
+                                       units, ent_row, ent_mask, chunk_tile, chunk_graph, chunks_per_wg};
     return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, xcd_order, num_list_entries, unit_capacity, 1, &d, workspace,
                                           workspace_bytes, (hipStream_t)stream);
 }
@@ -1039,9 +1101,8 @@ int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
-                       const void* W_agg, void* aux, const int32_t* agg_idx, int32_t unit_order, dn_stream_t stream) {
+                       const void* W_agg, void* aux, const int32_t* agg_idx, dn_stream_t stream) {
     DN_REQUIRE(H == 256, "dn_rows_close: unsupported width %d (256 only; dn_rows_selfsum_bf16 serves 64 / 128)", H);
-    DN_REQUIRE(unit_order == 0 || unit_order == 1 || unit_order == 2, "dn_rows_close: unit_order must be the order the unit tables were built in");
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096, "dn_rows_close: bad sizes");
     const bool agg = W_agg != nullptr || aux != nullptr || agg_idx != nullptr;
     DN_REQUIRE(fold_info == nullptr || seg_part != nullptr || agg, "dn_rows_close: fold_info needs seg_part (or W_agg / aux / agg_idx)");
@@ -1056,7 +1117,7 @@ int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, co
     hipStream_t st = (hipStream_t)stream;
     static const int nt = dn_knob("DN_NT", 3);
     const int abl = dn_knob("DN_CLOSE_ABL", 0);   // tuning build only (read per call): 1 entry rows from L2, 2 x rows from L2, 4 no stores, 8 entry units not summed
-    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2) | (unit_order == 2 ? 256 : 0);
+    const int32_t flags = ((nt & 2) ? 2 : 0) | ((abl & 63) << 2);
     const bf16_t* s = S ? (const bf16_t*)S : (const bf16_t*)X;             // (no entry unit can exist without S; never dereferenced)
 #define DN_CLOSE_LAUNCH(F)                                                                                                         \
     hipLaunchKernelGGL((rows_close_ring_kernel<F>), dim3((unsigned)num_wg), dim3(kThreads), 0, st, (const bf16_t*)X, (const bf16_t*)W, \

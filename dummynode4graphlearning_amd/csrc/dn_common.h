@@ -258,70 +258,110 @@ __device__ __forceinline__ void dn_fold_graph_tile_one(int64_t j, int32_t N, int
     rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 2; rec[11] = 0;                // [10]: bit 0 = continues the previous tile's sum, bit 1 = completes it
 }
 
-// The same for graphs of ANY size (round 6): block j is cut into ceil(nodes / 32) consecutive tiles that the unit stream keeps in ONE
-// workgroup, the column sum of the segment accumulating across them.  Two passes around one exclusive scan:
-//   count: the validity test above without the 32-node limit; ntiles[j] = tiles of block j (0 for j = S and for a bad segment)
-//   (exclusive scan of ntiles [S + 1] -> tile_first [S + 1]; tile_first[S] = T)
-//   fill:  tile_ptr [T + 1], tile_graph [T], fold record per tile {local ids: 0 inside the segment, 255 outside; aux row = j;
-//          count = 1; bit 0 = not the block's first tile, bit 1 = its last}.  Does nothing when *ok == 0 (the bounds the caller sized
-//          the tables by -- T <= S + N / 32 -- only hold for a valid batch).
-__device__ __forceinline__ bool dn_fold_multi_block(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
-                                                    const int32_t* __restrict__ snodes, int32_t& first, int32_t& last, int32_t& b0,
-                                                    int32_t& nxt) {
+// The same for graphs of ANY size (round 6).  The batch is cut into C CHUNKS at graph boundaries -- graph j (block start b0_j)
+// belongs to chunk floor(b0_j C / N) -- and every chunk into consecutive 32-node tiles that run ACROSS the graphs inside it (the
+// last tile of a chunk is the only partial one: T <= N / 32 + C).  The unit stream keeps a chunk in ONE workgroup, so a segment's
+// column sum may continue from tile to tile in that workgroup (fold record word 10: bit 0 = the tile's FIRST segment continues the
+// previous tile's sum, bit 1 = its LAST segment is complete inside this tile), and the AGG unit's read-modify-write of the dummy
+// node's row stays inside the workgroup that stored it.
+//   valid:  the test of dn_fold_graph_tile_one without the 32-node limit, one segment per call
+//   chunks: chunk_graph [C + 1] (first graph of chunk c), chunk_tile [C + 1] (first tile; chunk_tile[C] = T) -- one workgroup
+//   tiles:  tile_ptr [T + 1], fold record per tile {local segment ids in order of appearance, 255 outside every segment; aux row of
+//           the first segment present = its graph; segments present; flags}
+__device__ __forceinline__ int32_t dn_fold_gstart(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                  const int32_t* __restrict__ snodes) {
+    return j <= 0 ? 0 : (j >= S ? N : snodes[sptr[j]]);                   // block j = [gstart(j), gstart(j + 1))
+}
+__device__ __forceinline__ void dn_fold_multi_valid_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                        const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
+                                                        int32_t* __restrict__ ok) {
+    if (j >= S) return;
     const int32_t cnt = sptr[j + 1] - sptr[j];
     bool good = cnt > 0;
-    first = last = 0; nxt = N;
+    int32_t first = 0, last = 0, nxt = N;
     if (good) {
         first = snodes[sptr[j]];
         last = snodes[sptr[j + 1] - 1];
         good = first >= 0 && last < N && last - first == cnt - 1;
+        for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
         if (good && j + 1 < S) {
             good = sptr[j + 2] > sptr[j + 1];
             if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
         }
     }
-    b0 = j == 0 ? 0 : first;
-    return good && nxt - b0 >= 1;
-}
-__device__ __forceinline__ void dn_fold_multi_count_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
-                                                        const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
-                                                        int32_t* __restrict__ ntiles, int32_t* __restrict__ ok) {
-    if (j > S) return;
-    if (j == S) { ntiles[S] = 0; return; }
-    int32_t first, last, b0, nxt;
-    bool good = dn_fold_multi_block(j, N, S, sptr, snodes, first, last, b0, nxt);
-    for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
+    const int32_t b0 = j == 0 ? 0 : first;
+    if (good) good = nxt - b0 >= 1;
     if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
-    ntiles[j] = good ? (nxt - b0 + 31) / 32 : 0;
     if (!good) {
         __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
-__device__ __forceinline__ void dn_fold_multi_fill_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
-                                                       const int32_t* __restrict__ snodes, const int32_t* __restrict__ tile_first,
-                                                       int32_t* __restrict__ tile_ptr, int32_t* __restrict__ tile_graph,
-                                                       int32_t* __restrict__ info) {
-    if (j > S) return;
-    if (j == S) { tile_ptr[tile_first[S]] = N; return; }
-    int32_t first, last, b0, nxt;
-    if (!dn_fold_multi_block(j, N, S, sptr, snodes, first, last, b0, nxt)) return;
-    const int32_t t0 = tile_first[j], nt = tile_first[j + 1] - t0;
-    for (int32_t k = 0; k < nt; ++k) {
-        const int32_t p0 = b0 + 32 * k;
-        tile_ptr[t0 + k] = p0;
-        tile_graph[t0 + k] = (int32_t)j;
-        int32_t* rec = info + (size_t)(t0 + k) * 12;
-        for (int i = 0; i < 8; ++i) {
-            uint32_t w = 0;
-            for (int b = 0; b < 4; ++b) {
-                const int32_t v = p0 + 4 * i + b;
-                w |= ((v >= first && v <= last && v < nxt) ? 0u : 255u) << (8 * b);
-            }
-            rec[i] = (int32_t)w;
-        }
-        rec[8] = (int32_t)j; rec[9] = 1; rec[10] = (k > 0 ? 1 : 0) | (k == nt - 1 ? 2 : 0); rec[11] = 0;
+// first graph j in [0, S] whose block starts at or behind node v (S: none)
+__device__ __forceinline__ int32_t dn_fold_first_graph_from(int32_t v, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                            const int32_t* __restrict__ snodes) {
+    int32_t lo = 0, hi = S;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (dn_fold_gstart(mid, N, S, sptr, snodes) < v) lo = mid + 1;
+        else hi = mid;
     }
+    return lo;
+}
+__device__ __forceinline__ void dn_fold_multi_tile_one(int64_t t, int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr,
+                                                       const int32_t* __restrict__ snodes, const int32_t* __restrict__ chunk_tile,
+                                                       const int32_t* __restrict__ chunk_graph, int32_t* __restrict__ tile_ptr,
+                                                       int32_t* __restrict__ info) {
+    const int32_t T = chunk_tile[C];
+    if (t > T) return;
+    if (t == T) { tile_ptr[T] = N; return; }
+    int32_t lo = 0, hi = C;                                                // the chunk of tile t: the last c with chunk_tile[c] <= t
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (chunk_tile[mid] <= (int32_t)t) lo = mid;
+        else hi = mid - 1;
+    }
+    const int32_t c = lo, g_lo = chunk_graph[c], g_hi = chunk_graph[c + 1];
+    const int32_t n_lo = dn_fold_gstart(g_lo, N, S, sptr, snodes), n_hi = dn_fold_gstart(g_hi, N, S, sptr, snodes);
+    const int32_t p0 = n_lo + 32 * ((int32_t)t - chunk_tile[c]), pend = p0 + 32 < n_hi ? p0 + 32 : n_hi;
+    tile_ptr[t] = p0;
+    // the graph of node p0: the last j in [g_lo, g_hi) with gstart(j) <= p0
+    int32_t a = g_lo, b = g_hi - 1;
+    while (a < b) {
+        const int32_t mid = (a + b + 1) >> 1;
+        if (dn_fold_gstart(mid, N, S, sptr, snodes) <= p0) a = mid;
+        else b = mid - 1;
+    }
+    int32_t jg = a, nxt = dn_fold_gstart(jg + 1, N, S, sptr, snodes), sfirst = snodes[sptr[jg]], slast = snodes[sptr[jg + 1] - 1];
+    int32_t first_seg = -1, last_seg = -1;
+    uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int i = 0; i < 32; ++i) {
+        const int32_t v = p0 + i;
+        uint32_t id = 255u;
+        if (v < pend) {
+            while (v >= nxt) {
+                ++jg;
+                nxt = dn_fold_gstart(jg + 1, N, S, sptr, snodes);
+                sfirst = snodes[sptr[jg]]; slast = snodes[sptr[jg + 1] - 1];
+            }
+            if (v >= sfirst && v <= slast) {
+                if (first_seg < 0) first_seg = jg;
+                last_seg = jg;
+                id = (uint32_t)(jg - first_seg);                           // (< 32: every segment present holds a node of the tile)
+            }
+        }
+        w[i >> 2] |= id << (8 * (i & 3));
+    }
+    int32_t* rec = info + (size_t)t * 12;
+    for (int i = 0; i < 8; ++i) rec[i] = (int32_t)w[i];
+    int32_t flags = 0;
+    if (first_seg >= 0) {
+        if (snodes[sptr[first_seg]] < p0) flags |= 1;                      // its first nodes lie in the previous tile
+        if (snodes[sptr[last_seg + 1] - 1] < pend) flags |= 2;             // its last node lies in this tile
+    }
+    rec[8] = first_seg < 0 ? 0 : first_seg;
+    rec[9] = first_seg < 0 ? 0 : last_seg - first_seg + 1;
+    rec[10] = flags; rec[11] = 0;
 }
 
 // ---- ReLU / leaky ReLU.  slope = 0: ReLU (max(v, 0): the negative side is an exact 0 whatever v is); slope > 0: leaky ReLU, the

@@ -39,13 +39,14 @@ struct CloseUnitsDir {                 // one direction's arguments of dn_close_
     const int32_t *drop_enable, *dyn;
     int32_t *unit_ptr, *units, *ent_row;
     uint32_t* ent_mask;
-    const int32_t *tile_graph = nullptr, *tile_first = nullptr;   // order 2 (multi-tile graphs): tile -> graph, graph -> first tile
-    int32_t num_segments = 0;                                      //   [num_segments + 1]; num_tiles is then a BOUND (tile_first[S] tiles exist)
+    const int32_t *chunk_tile = nullptr, *chunk_graph = nullptr;   // orders 2 / 3 (graphs of any size): first tile / first graph of every
+    int32_t chunks_per_wg = 0;                                     //   chunk [K num_wg + 1]; num_tiles is then a BOUND (chunk_tile[K num_wg] exist)
 };
-// (fold_multi_queue: dn_fold_graph_tiles_multi_build_i32 without its argument checks; gate != NULL: only when *gate != 0)
+// (dn_fold_graph_tiles_multi_build_i32 without its argument checks; gate != NULL: a device word that must be non-zero for the launches
+//  to do anything -- dn_conv_index_build_i32 queues them before it knows whether the batch wants them)
 int fold_multi_queue(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx,
-                     int32_t* tile_first, int32_t* tile_ptr, int32_t* tile_graph, int32_t* fold_info, int32_t* dev_ok, void* workspace,
-                     size_t workspace_bytes, hipStream_t st);
+                     int32_t num_chunks, int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info,
+                     int64_t tile_capacity, int32_t* dev_ok, const int32_t* gate, hipStream_t st);
 int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
                       int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st);
 

@@ -592,31 +592,45 @@ def build_graph_tiles(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
     return tile_ptr, info[:S], ok
 
 
+# DN_CLOSE_SINGLE=0 (experiments): never use the graphs-as-tiles tables of round 4, also where every graph fits one tile
+CLOSE_SINGLE_ENABLED = _os.environ.get("DN_CLOSE_SINGLE", "1") != "0"
 # DN_CLOSE_MULTI=0: graphs over 32 nodes keep the fp32 partial rows + dn_fold_tail_bf16 (rounds 4-5) instead of the multi-tile absorbed fold
 CLOSE_MULTI_ENABLED = _os.environ.get("DN_CLOSE_MULTI", "1") != "0"
 
 
-def build_graph_tiles_multi(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None):
-    """Tiles of a batch of graphs of ANY size for the absorbed fold (dn_fold_graph_tiles_multi_build_i32: two launches + a scan, no
-    read-back): every graph's block cut into consecutive tiles of at most 32 nodes.
-    -> (tile_ptr [cap + 1], fold_info [cap, 12], tile_graph [cap], tile_first [S + 1], cap, ok [1] device flag); the number of tiles
-    that exist is tile_first[S], on the device; cap bounds it."""
+# DN_CLOSE_CHUNK_TILES: 32-node tiles per chunk of the chunked closing launch (a chunk = a run of whole graphs that one workgroup
+# takes in one piece; every workgroup gets the same number of chunks, dealt in the front order of the single-tile tables)
+CLOSE_CHUNK_TILES = int(_os.environ.get("DN_CLOSE_CHUNK_TILES", "16"))
+
+
+def close_chunks(num_nodes, num_wg):
+    """Chunks of a batch for the chunked closing launch: K per workgroup, about CLOSE_CHUNK_TILES tiles each."""
+    k = int(round(num_nodes / 32.0 / num_wg / max(CLOSE_CHUNK_TILES, 1)))
+    return num_wg * max(1, min(k, 16383 // num_wg))
+
+
+def build_graph_tiles_multi(seg_ptr, seg_nodes, num_nodes, ok=None, add_idx=None, num_chunks=None):
+    """Tiles of a batch of graphs of ANY size for the absorbed fold (dn_fold_graph_tiles_multi_build_i32: three launches, no
+    read-back): the batch cut into num_chunks chunks at graph boundaries (one per workgroup of the closing launch), every chunk
+    into consecutive 32-node tiles that run across its graphs.
+    -> (tile_ptr [cap + 1], fold_info [cap, 12], chunk_tile [C + 1], chunk_graph [C + 1], cap, ok [1] device flag); the number of
+    tiles that exist is chunk_tile[C], on the device; cap bounds it."""
     require_gpu(seg_ptr, seg_nodes, add_idx)
     dev = seg_ptr.device
     S, N = int(seg_ptr.numel()) - 1, int(num_nodes)
-    cap = int(lib().dn_fold_graph_tiles_multi_capacity(N, S))
-    tile_first = torch.empty(S + 1, dtype=I32, device=dev)
+    C = int(num_chunks) if num_chunks else close_chunks(N, _num_cus(dev))
+    cap = int(lib().dn_fold_graph_tiles_multi_capacity(N, C))
+    chunk_tile = torch.empty(C + 1, dtype=I32, device=dev)
+    chunk_graph = torch.empty(C + 1, dtype=I32, device=dev)
     tile_ptr = torch.empty(cap + 1, dtype=I32, device=dev)
-    tile_graph = torch.empty(cap, dtype=I32, device=dev)
     info = torch.empty((cap, 12), dtype=I32, device=dev)
     if ok is None:
         ok = torch.zeros(1, dtype=I32, device=dev)
     assert add_idx is None or (add_idx.dtype == I32 and add_idx.numel() == S and add_idx.is_contiguous())
-    ws = _ws(lib().dn_fold_graph_tiles_multi_workspace_bytes(S), dev)
-    check(lib().dn_fold_graph_tiles_multi_build_i32(N, S, ptr(seg_ptr), ptr(seg_nodes), ptr(add_idx), ptr(tile_first), ptr(tile_ptr),
-                                                    ptr(tile_graph), ptr(info), cap, ptr(ok), ptr(ws), ws.numel(), stream_ptr()),
+    check(lib().dn_fold_graph_tiles_multi_build_i32(N, S, ptr(seg_ptr), ptr(seg_nodes), ptr(add_idx), C, ptr(chunk_tile), ptr(chunk_graph),
+                                                    ptr(tile_ptr), ptr(info), cap, ptr(ok), stream_ptr()),
           "dn_fold_graph_tiles_multi_build_i32")
-    return tile_ptr, info, tile_graph, tile_first, cap, ok
+    return tile_ptr, info, chunk_tile, chunk_graph, cap, ok
 
 
 def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0), drop_enable=None, num_wg=None, tile_ptr=None,
@@ -625,8 +639,9 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     masks, and the per-workgroup unit records the closing launch streams (three launches, no read-back).  Same filter as
     build_slot_table.  agg: append every workgroup's AGG units (the absorbed fold, tile_ptr from build_graph_tiles).  order: 0 =
     workgroup w takes tiles w, w + G, ...; 1 = every XCD walks its eighth of the batch downwards (include/dn_hip.h); None = 1 when
-    the number of workgroups allows it.  multi = (tile_graph, tile_first, cap) of build_graph_tiles_multi (with its tile_ptr): order 2 --
-    graphs that span several tiles stay in one workgroup's stream, unit_ptr is indexed by chunk."""
+    the number of workgroups allows it.  multi = (chunk_tile, chunk_graph, cap, num_segments) of build_graph_tiles_multi (with its
+    tile_ptr; its num_chunks = K num_wg): orders 2 / 3 -- the chunks are dealt to the workgroups as orders 0 / 1 deal tiles, so a
+    graph's tiles stay in one workgroup's stream."""
     require_gpu(list_ptr, list_rows, tile_ptr)
     dev = list_rows.device
     N, P, L = int(num_nodes), int(num_edge_rows), int(list_rows.numel())
@@ -638,11 +653,13 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     cu.num_tiles = T = (int(tile_ptr.numel()) - 1) if tile_ptr is not None else (N + 31) // 32
     cu.num_segments = T
     tg = tf = None
+    kper = 0
     if multi is not None:
-        tg, tf, cap_t = multi
+        tg, tf, cap_t, nseg = multi
         require_gpu(tg, tf)
-        assert agg and tile_ptr is not None and cap_t == T and tg.numel() == T
-        cu.order, cu.num_segments = 2, int(tf.numel()) - 1
+        kper = (int(tg.numel()) - 1) // cu.num_wg
+        assert agg and tile_ptr is not None and cap_t == T and tg.numel() == kper * cu.num_wg + 1 == tf.numel() and kper >= 1
+        cu.order, cu.num_segments = 2 + _close_order(cu.num_wg), int(nseg)
     assert not agg or tile_ptr is not None
     cap = int(lib().dn_close_units_capacity(T, L, cu.num_wg))
     cu.unit_ptr = torch.empty(cu.num_wg + 1, dtype=I32, device=dev)
@@ -652,8 +669,7 @@ def build_close_units(list_ptr, list_rows, num_nodes, num_edge_rows, drop=(0, 0)
     ws = _ws(lib().dn_close_units_workspace_bytes(T, cu.num_wg), dev)
     check(lib().dn_close_units_build_i32(N, P, cu.num_wg, ptr(tile_ptr), T, 1 if agg else 0, cu.order, ptr(list_ptr), ptr(list_rows), L,
                                          int(drop[0]), int(drop[1]), ptr(drop_enable), ptr(cu.unit_ptr), ptr(cu.units), cap,
-                                         ptr(cu.ent_row), ptr(cu.ent_mask), ptr(tg), ptr(tf), cu.num_segments if multi is not None else 0,
-                                         ptr(ws), ws.numel(), stream_ptr()),
+                                         ptr(cu.ent_row), ptr(cu.ent_mask), ptr(tg), ptr(tf), kper, ptr(ws), ws.numel(), stream_ptr()),
           "dn_close_units_build_i32")
     return cu
 
@@ -689,7 +705,7 @@ def rows_close(x, W, bias, S, cu, out=None, seg=None, w_kn=False, agg=None):
     def _launch():
         check(lib().dn_rows_close_bf16(ptr(x), H, ptr(W), 1 if w_kn else 0, ptr(bias), ptr(S) if S is not None and S.numel() else None,
                                        ptr(cu.unit_ptr), ptr(cu.units), cu.num_wg, ptr(cu.ent_row), ptr(cu.ent_mask), N, ptr(out),
-                                       ptr(fi), ptr(sp), ptr(wa), ptr(ax), ptr(ai), cu.order, stream_ptr()), "dn_rows_close_bf16")
+                                       ptr(fi), ptr(sp), ptr(wa), ptr(ax), ptr(ai), stream_ptr()), "dn_rows_close_bf16")
     if kernel_timer is not None:
         kernel_timer.launch("rows_close", _launch)
     else:
@@ -1281,7 +1297,7 @@ class RowIndex:
             gt_bufs = [(e32(G + 1), torch.empty((max(G, 1), 12), dtype=I32, device=dev)) for _ in range(2)]
             host_absorb = (ctypes.c_int32 * 2)()
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
-            one_call = (CONV_INDEX_ENABLED and closing_hint is not None and closing_hint[0] == 256
+            one_call = (CONV_INDEX_ENABLED and CLOSE_SINGLE_ENABLED and closing_hint is not None and closing_hint[0] == 256
                         and closing_hint[1] == torch.bfloat16 and self_loop and G >= 1 and N >= 1 and CLOSE_RING_ENABLED
                         and CLOSE_AGG_ENABLED and FOLD_ENABLED)
             nbytes = 0 if one_call else lib().dn_row_index_local_workspace_bytes(G, N, R, E)
@@ -1550,6 +1566,8 @@ def _closing_tables(ix, kind="slots"):
                                                add_idx=add_idx_of(d, cands[d]))
             if gts:
                 h = flags.cpu().tolist()                             # synchronisation 1: can the fold be absorbed?
+        if not CLOSE_SINGLE_ENABLED:
+            h = [h[0], h[1], 0, 0]
         need_parts = [d for k, d in enumerate(dirs) if cands[d] is not None and h[2 + k] == 0]
         multi = {}
         if kind == "units" and CLOSE_AGG_ENABLED and CLOSE_MULTI_ENABLED and need_parts:
@@ -1580,7 +1598,7 @@ def _closing_tables(ix, kind="slots"):
             elif d in multi:
                 info = make_info(d, cands[d])
                 info.graph_tiles = (multi[d][0], multi[d][1])
-                info.multi = (multi[d][2], multi[d][3], multi[d][4])
+                info.multi = (multi[d][2], multi[d][3], multi[d][4], cands[d][3])
             elif cands[d] is not None and hp[k] != 0:
                 info = make_info(d, cands[d])
                 info.fold_info, info.part_ptr = parts[d]
@@ -1601,8 +1619,8 @@ def _closing_tables(ix, kind="slots"):
     for d in dirs:
         info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
-        if (kind == "units" and info is not None and info.graph_tiles is None and CLOSE_AGG_ENABLED and ix._absorb is not None
-                and ix._absorb[d][2]):                                # (the slot tables came first: the builder's verdict still stands)
+        if (kind == "units" and info is not None and info.graph_tiles is None and CLOSE_AGG_ENABLED and CLOSE_SINGLE_ENABLED
+                and ix._absorb is not None and ix._absorb[d][2]):                                # (the slot tables came first: the builder's verdict still stands)
             info.graph_tiles = (ix._absorb[d][0][:info.n + 1], ix._absorb[d][1][:info.n])
         if kind == "slots":
             slots, over = tabs[d]

@@ -460,7 +460,7 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * node}; with agg_units != 0 a workgroup's tiles are followed by 8 records {8, 0, 1, 0} (a gap) and one record {4 | 2, n, n', 0}
  * ({4 | 2 | 16, n, n', num_tiles} with xcd_order = 1) per 32 of its tiles (the n-th .. n'-th of them): the AGG units of the absorbed
  * fold below.
- * unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg).
+ * unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg) = 3 num_tiles + num_list_entries / 32 + 1 + 9 num_wg.
  *
  * dn_fold_graph_tiles_build_i32 (one launch): the tiles of a batch of GRAPHS for the absorbed fold.  Segment j = the nodes
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) as in dn_fold_tables_build_i32; block j = [first node of segment j (0 for j = 0), first
@@ -471,21 +471,22 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * dummy node in front of its graph, all dummy nodes at the end of the batch) keeps the partial rows + dn_fold_tail_bf16.  Then
  * tile_ptr [num_segments + 1] = the block starts (tile j = block j) and fold_info [num_segments][12] = per tile {32 bytes: 0 for a node of the segment, 255 otherwise; j; 1; 2; 0}.
  *
- * dn_fold_graph_tiles_multi_build_i32 (round 6; two launches around one scan): the same for graphs of ANY size -- TU graphs are
+ * dn_fold_graph_tiles_multi_build_i32 (round 6; three launches, no read-back): the same for graphs of ANY size -- TU graphs are
  * not all within 32 nodes (graph_classification/data_processing/tu_data_processing.py:179-218 keeps whatever sizes the dataset
- * has; PROTEINS reaches 620).  Block j is cut into ceil(nodes / 32) consecutive tiles: tile_first [num_segments + 1] (graph ->
- * its first tile; tile_first[num_segments] = T, the tile count, known on the device only), tile_ptr [T + 1], tile_graph [T],
- * fold_info [T][12] = per tile {32 id bytes; j; 1; bit 0 = continues the previous tile's column sum | bit 1 = completes it; 0}.
- * The tables must hold tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, num_segments) = num_segments + N / 32 + 1 tiles
- * (the bound for a valid batch; nothing is written for an invalid one: *dev_ok = 0).  Same validity test as above without the
- * 32-node limit.  dn_close_units_build_i32 with xcd_order = 2 takes these tables (tile_ptr, tile_graph, tile_first,
- * num_segments; num_tiles = the capacity the tables were sized by) and cuts the tiles into num_wg CHUNKS at graph boundaries --
- * graph j belongs to chunk floor(tile_first[j] num_wg / T) -- so that a graph's tiles follow each other in ONE stream: the
- * segment's column sum accumulates across them in the workgroup's registers (fp32, one rounding) and the AGG unit's
- * read-modify-write of out[add_idx[j]] stays inside the workgroup that stored that row.  unit_ptr is then indexed by CHUNK (units
- * in tile order; AGG records {4 | 2 | 32, first graph, end graph, 0}: the aux rows themselves) and dn_rows_close_bf16 with
- * unit_order = 2 gives chunk (w & 7) num_wg / 8 + (w >> 3) to workgroup w (num_wg a multiple of 8; else chunk w): XCD x walks the
- * x-th eighth of the batch upwards.
+ * has; PROTEINS reaches 620).  The batch is cut into num_chunks CHUNKS at graph boundaries -- graph j (block start b0_j) belongs to
+ * chunk floor(b0_j num_chunks / N) -- and every chunk into consecutive 32-node tiles that run ACROSS the graphs inside it (only a
+ * chunk's last tile is partial: T <= N / 32 + num_chunks).  chunk_tile [num_chunks + 1] = a chunk's first tile (chunk_tile[num_chunks]
+ * = T, known on the device only), chunk_graph [num_chunks + 1] = its first graph, tile_ptr [T + 1], fold_info [T][12] = per tile
+ * {32 bytes: the local number of the node's segment in order of appearance, 255 outside every segment; the first such segment (=
+ * graph = aux row); how many; bit 0 = the first one continues the previous tile's column sum | bit 1 = the last one ends in this
+ * tile; 0}.  The tables must hold tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, num_chunks) tiles; nothing is written for
+ * an invalid batch (*dev_ok = 0).  Same validity test as above without the 32-node limit.  num_chunks < 16384.
+ * dn_close_units_build_i32 with xcd_order = 2 / 3 takes these tables (tile_ptr, chunk_tile, chunk_graph, chunks_per_wg = K with
+ * num_chunks = K num_wg; num_tiles = the capacity the tables were sized by) and deals the CHUNKS to the workgroups as xcd_order 0 / 1
+ * deal tiles (K each), so that a graph's tiles stay in ONE stream: a segment's column sum continues from tile to tile in the
+ * workgroup (fp32, one rounding) and the AGG unit's read-modify-write of out[add_idx[j]] stays inside the workgroup that stored
+ * that row -- while the launch still sweeps the batch as a front of short runs.  A workgroup's stream = the tiles of its chunks,
+ * the gap, and per chunk one AGG record {4 | 2 | 32, first graph, end graph, 0} per 32 graphs (the aux rows themselves).
  *
  * dn_rows_close_bf16: one persistent workgroup per entry of unit_ptr (launch num_wg = the builder's).  W: the self-loop weight,
  * w_kn = 0: [H][H] with k contiguous (W_loop transposed, as dn_rows_selfsum_bf16 takes it), w_kn = 1: [k][n] as the
@@ -496,29 +497,27 @@ int dn_overflow_rows_add_bf16(const void* S, int32_t H, const uint8_t* overflow,
  * caller: the collapsed relation's operand of dn_rows_wgrad_bf16), and the workgroup's AGG units multiply its segments' aux rows
  * by W_agg (same layout flag as W) and add each product to out[agg_idx[segment]] -- what dn_fold_tail_bf16 does, inside this
  * launch.  A non-finite element of S turns its column of the whole tile into NaN (0 x Inf inside the selection product).
- * unit_order: the xcd_order the unit tables were built with (0 / 1: unit_ptr by workgroup; 2: by chunk, multi-tile graphs).
  * H must be 256. */
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg);
 size_t dn_close_units_workspace_bytes(int64_t num_tiles, int32_t num_wg);
 int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, const int32_t* tile_ptr, int64_t num_tiles,
                              int32_t agg_units, int32_t xcd_order, const int32_t* list_ptr, const int32_t* list_rows, int64_t num_list_entries,
                              int32_t drop_beg, int32_t drop_end, const int32_t* drop_enable, int32_t* unit_ptr, int32_t* units,
-                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, const int32_t* tile_graph,
-                             const int32_t* tile_first, int64_t num_segments, void* workspace, size_t workspace_bytes,
+                             int64_t unit_capacity, int32_t* ent_row, uint32_t* ent_mask, const int32_t* chunk_tile,
+                             const int32_t* chunk_graph, int32_t chunks_per_wg, void* workspace, size_t workspace_bytes,
                              dn_stream_t stream);
-size_t dn_fold_graph_tiles_multi_workspace_bytes(int64_t num_segments);
-int64_t dn_fold_graph_tiles_multi_capacity(int64_t N, int64_t num_segments);
+int64_t dn_fold_graph_tiles_multi_capacity(int64_t N, int32_t num_chunks);
 int dn_fold_graph_tiles_multi_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
-                                        const int32_t* add_idx, int32_t* tile_first, int32_t* tile_ptr, int32_t* tile_graph,
-                                        int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok, void* workspace,
-                                        size_t workspace_bytes, dn_stream_t stream);
+                                        const int32_t* add_idx, int32_t num_chunks, int32_t* chunk_tile, int32_t* chunk_graph,
+                                        int32_t* tile_ptr, int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok,
+                                        dn_stream_t stream);
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,
                                   const int32_t* add_idx, int32_t* tile_ptr, int32_t* fold_info, int32_t* dev_ok,
                                   dn_stream_t stream);
 int dn_rows_close_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* bias, const void* S,
                        const int32_t* unit_ptr, const int32_t* units, int32_t num_wg, const int32_t* ent_row,
                        const uint32_t* ent_mask, int64_t N, void* out, const int32_t* fold_info, float* seg_part,
-                       const void* W_agg, void* aux, const int32_t* agg_idx, int32_t unit_order, dn_stream_t stream);
+                       const void* W_agg, void* aux, const int32_t* agg_idx, dn_stream_t stream);
 
 /* Tables of a folded pre-aggregation (one-shot index build, like dn_slot_table_build_i32): segment j = the rows
  * seg_nodes[seg_ptr[j] .. seg_ptr[j+1]) (dn_row_index_build_i32's aux_f_ptr/aux_f_idx or aux_b_ptr/aux_b_idx: the nodes of a graph

@@ -38,9 +38,9 @@ def graph_tiles_ref(seg_ptr, seg_nodes, N, add_idx=None):
     return True, tile_ptr, info
 
 
-def graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=None):
-    """dn_fold_graph_tiles_multi_build_i32: -> (ok, tile_first [S+1], tile_ptr [T+1], tile_graph [T], fold_info [T,12]): every block cut
-    into consecutive tiles of at most 32 nodes (word 10: bit 0 = not the block's first tile, bit 1 = its last)."""
+def graph_tiles_multi_ref(seg_ptr, seg_nodes, N, C, add_idx=None):
+    """dn_fold_graph_tiles_multi_build_i32: -> (ok, chunk_tile [C+1], chunk_graph [C+1], tile_ptr [T+1], fold_info [T,12]): C chunks cut at
+    graph boundaries (graph j in chunk b0_j C // N), every chunk cut into consecutive 32-node tiles that run across its graphs."""
     sp, sn = np.asarray(seg_ptr, dtype=np.int64), np.asarray(seg_nodes, dtype=np.int64)
     S = len(sp) - 1
     firsts, lasts = [], []
@@ -49,26 +49,37 @@ def graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=None):
         if len(nodes) == 0 or np.any(np.diff(nodes) != 1) or nodes[0] < 0 or nodes[-1] >= N:
             return False, None, None, None, None
         firsts.append(int(nodes[0])); lasts.append(int(nodes[-1]))
-    tile_first, tile_ptr, tile_graph, info = [0], [], [], []
+    gstart = [0 if j == 0 else firsts[j] for j in range(S)] + [N]
     for j in range(S):
-        b0 = 0 if j == 0 else firsts[j]
-        nxt = firsts[j + 1] if j + 1 < S else N
-        if (j + 1 < S and nxt <= lasts[j]) or nxt - b0 < 1:
+        if (j + 1 < S and gstart[j + 1] <= lasts[j]) or gstart[j + 1] - gstart[j] < 1:
             return False, None, None, None, None
-        if add_idx is not None and not (b0 <= int(add_idx[j]) < nxt):
+        if add_idx is not None and not (gstart[j] <= int(add_idx[j]) < gstart[j + 1]):
             return False, None, None, None, None
-        nt = (nxt - b0 + 31) // 32
-        for k in range(nt):
-            p0 = b0 + 32 * k
-            tile_ptr.append(p0); tile_graph.append(j)
-            ids = np.array([0 if (firsts[j] <= p0 + i <= lasts[j] and p0 + i < nxt) else 255 for i in range(32)], dtype=np.uint8)
+    chunk_graph = [next((j for j in range(S) if gstart[j] >= -(-c * N // C)), S) for c in range(C)] + [S]
+    chunk_tile, tile_ptr, info = [0], [], []
+    for c in range(C):
+        n_lo, n_hi = gstart[chunk_graph[c]], gstart[chunk_graph[c + 1]]
+        for p0 in range(n_lo, n_hi, 32):
+            pend = min(p0 + 32, n_hi)
+            tile_ptr.append(p0)
+            ids, present = [], []
+            for v in range(p0, p0 + 32):
+                j = max(k for k in range(chunk_graph[c], chunk_graph[c + 1]) if gstart[k] <= v) if v < pend else -1
+                if v < pend and firsts[j] <= v <= lasts[j]:
+                    if j not in present:
+                        present.append(j)
+                    ids.append(j - present[0])
+                else:
+                    ids.append(255)
             rec = np.zeros(12, dtype=np.int32)
-            rec[:8] = ids.view(np.int32)
-            rec[8], rec[9], rec[10] = j, 1, (1 if k > 0 else 0) | (2 if k == nt - 1 else 0)
+            rec[:8] = np.array(ids, dtype=np.uint8).view(np.int32)
+            if present:
+                rec[8], rec[9] = present[0], present[-1] - present[0] + 1
+                rec[10] = (1 if firsts[present[0]] < p0 else 0) | (2 if lasts[present[-1]] < pend else 0)
             info.append(rec)
-        tile_first.append(len(tile_ptr))
+        chunk_tile.append(len(tile_ptr))
     tile_ptr.append(N)
-    return True, np.array(tile_first), np.array(tile_ptr), np.array(tile_graph), np.array(info, dtype=np.int32).reshape(-1, 12)
+    return True, np.array(chunk_tile), np.array(chunk_graph), np.array(tile_ptr), np.array(info, dtype=np.int32).reshape(-1, 12)
 
 
 def tiles_of_workgroup(w, T, G, order):
@@ -81,8 +92,9 @@ def tiles_of_workgroup(w, T, G, order):
 
 
 def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, agg=False, order=0, multi=None):
-    """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])}).  order 2 with multi = (tile_graph,
-    tile_first): unit_ptr by CHUNK (graph j in chunk tile_first[j] G // T), units in tile order, AGG records over the graphs."""
+    """-> (unit_ptr [G+1], units [U,4], tiles: {t: (first entry offset, [rows], [masks])}).  orders 2 / 3 with multi = (chunk_tile,
+    chunk_graph), K G + 1 entries each: the CHUNKS are dealt to the workgroups as orders 0 / 1 deal tiles; a workgroup's stream = the
+    tiles of its chunks, the gap, one AGG record per 32 graphs of each chunk."""
     xcd_order = int(order)                             # (`order` is reused below for a sort permutation)
     lp, lr = np.asarray(list_ptr, dtype=np.int64), np.asarray(list_rows, dtype=np.int64)
     T = (N + 31) // 32 if tile_ptr is None else len(tile_ptr) - 1
@@ -118,23 +130,23 @@ def close_units_ref(list_ptr, list_rows, N, P, G, drop=(0, 0), tile_ptr=None, ag
             ent_r, ent_m = [ent_r[k] for k in order], [ent_m[k] for k in order]
         tiles[t] = (int(lp[p0]), ent_r, ent_m)
     unit_ptr, units = [0], []
-    if xcd_order == 2:
-        tg, tf = (np.asarray(a, dtype=np.int64) for a in multi)
-        S = len(tf) - 1
-        chunk_of = [int(tf[j]) * G // T for j in range(S)]
-        for c in range(G):
-            gs = [j for j in range(S) if chunk_of[j] == c]
-            for j in gs:
-                for t in range(int(tf[j]), int(tf[j + 1])):
+    if xcd_order >= 2:
+        ct, cg = (np.asarray(a, dtype=np.int64) for a in multi)
+        C = len(ct) - 1
+        for w in range(G):
+            mine = tiles_of_workgroup(w, C, G, xcd_order - 2)
+            for c in mine:
+                for t in range(int(ct[c]), int(ct[c + 1])):
                     e0, ent_r, _ = tiles[t]
                     cn, p0, pend = len(ent_r), int(tp[t]), int(min(tp[t + 1], tp[t] + 32))
                     ne, rows = (cn + 31) // 32, (pend - p0) << 8
                     units.append([(2 if ne == 0 else 0) | rows, p0, pend, t])
                     for i in range(ne):
                         units.append([1 | (2 if i == ne - 1 else 0) | rows, e0 + 32 * i, e0 + min(32 * (i + 1), cn), p0])
-            if agg and gs:
+            if agg and any(ct[c + 1] > ct[c] for c in mine):
                 units += [[8, 0, 1, 0]] * AGG_GAP
-                units += [[4 | 2 | 32, g0, min(g0 + 32, gs[-1] + 1), 0] for g0 in range(gs[0], gs[-1] + 1, 32)]
+                for c in mine:
+                    units += [[4 | 2 | 32, g0, min(g0 + 32, int(cg[c + 1])), 0] for g0 in range(int(cg[c]), int(cg[c + 1]), 32)]
             unit_ptr.append(len(units))
         return np.array(unit_ptr, dtype=np.int64), np.array(units, dtype=np.int64).reshape(-1, 4), tiles
     for w in range(G):

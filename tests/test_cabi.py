@@ -69,17 +69,15 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     rc = L.dn_fold_tables_build_i32(10, 2, None, None, None, None, ctypes.byref(ok), None, 0, None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     # round-4 entry points
-    rc = L.dn_rows_close_bf16(None, 128, None, 0, None, None, None, None, 256, None, None, 8, *([None] * 6), 0, None)
+    rc = L.dn_rows_close_bf16(None, 128, None, 0, None, None, None, None, 256, None, None, 8, *([None] * 7))
     assert rc == -1 and b"unsupported width" in L.dn_last_error()
-    rc = L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 8, *([None] * 6), 0, None)
+    rc = L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 8, *([None] * 7))
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     rc = L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 8, None, None, None, ctypes.c_void_p(16),
-                              None, None, 0, None)
+                              None, None, None)
     assert rc == -1 and b"absorbed fold" in L.dn_last_error()
-    rc = L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 8, *([None] * 6), 3, None)
-    assert rc == -1 and b"unit_order" in L.dn_last_error()
-    assert L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 0, *([None] * 6), 0, None) == 0
-    assert L.dn_close_units_capacity(2, 320, 4) == 2 * 2 + 10 + 1 + 4 * 9 + 0
+    assert L.dn_rows_close_bf16(None, 256, None, 0, None, None, None, None, 256, None, None, 0, *([None] * 7)) == 0
+    assert L.dn_close_units_capacity(2, 320, 4) == 2 * 2 + 10 + 1 + 4 * 9 + 2
     assert L.dn_close_units_workspace_bytes(2, 4) > 0
     rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 0, 0, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, None, 0, None, 0,
                                     None)
@@ -94,11 +92,11 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     rc = L.dn_fold_graph_tiles_build_i32(10, 2, None, None, None, None, None, ctypes.c_void_p(16), None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     # round-6 entry points: graphs that span several tiles
-    rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 1, 2, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, None, 0,
-                                    None, 0, None)
-    assert rc == -1 and b"order 2" in L.dn_last_error()
-    assert L.dn_fold_graph_tiles_multi_capacity(100, 3) == 3 + 3 + 1 and L.dn_fold_graph_tiles_multi_workspace_bytes(3) > 0
-    rc = L.dn_fold_graph_tiles_multi_build_i32(10, 2, None, None, None, None, None, None, None, 0, ctypes.c_void_p(16), None, 0, None)
+    rc = L.dn_close_units_build_i32(10, 5, 4, None, 1, 1, 2, None, None, 3, 0, 0, None, ctypes.c_void_p(16), None, 0, None, None, None, None,
+                                    0, None, 0, None)
+    assert rc == -1 and b"orders 2 / 3" in L.dn_last_error()
+    assert L.dn_fold_graph_tiles_multi_capacity(100, 8) == 3 + 8 + 1
+    rc = L.dn_fold_graph_tiles_multi_build_i32(10, 2, None, None, None, 8, None, None, None, None, 0, ctypes.c_void_p(16), None)
     assert rc == -1 and b"NULL pointer" in L.dn_last_error()
     assert L.dn_bdd_compose(None, 0, 4, 16, 16, 2, None, None) == 0
     rc = L.dn_bdd_compose(None, 3, 4, 16, 16, 3, ctypes.c_void_p(16), ctypes.c_void_p(16), None) if False else L.dn_bdd_extract(

@@ -285,14 +285,14 @@ def test_absorbed_fold_tables_and_launch(sizes_kind, G, order):
             assert int(ops.build_graph_tiles(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int())[2].item()) == 0
 
 
-@pytest.mark.parametrize("G", [256, 8, 5, 1, 48])
+@pytest.mark.parametrize("G,K", [(256, 1), (8, 3), (5, 2), (1, 1), (48, 4), (16, 1)])
 @pytest.mark.parametrize("sizes_kind", ["tu", "huge", "small"])
-def test_absorbed_fold_over_graphs_that_span_several_tiles(sizes_kind, G):
+def test_absorbed_fold_over_graphs_that_span_several_tiles(sizes_kind, G, K):
     """TU-shaped batches (graphs of 1 .. 700 nodes; tu_data_processing.py:179-218 keeps whatever sizes a dataset has): every
-    graph's block cut into 32-node tiles that stay in ONE workgroup's stream (order 2).  Tables against the host restatement, the
+    workgroup takes a CHUNK of graphs whose nodes are cut into consecutive 32-node tiles (order 2).  Tables against the host restatement, the
     launch -- out = x W_loop + b + list rows, aux[j] = bf16 column sum of graph j's real nodes accumulated ACROSS its tiles,
     out[dummy_j] += aux[j] W_agg -- against fp64, bitwise run to run, and, on graphs within one tile, bit-identical to the
-    single-tile tables of round 4."""
+    single-tile tables of round 4 up to summation order."""
     from dummynode4graphlearning_amd import ops
     rng = np.random.default_rng(G + len(sizes_kind))
     if sizes_kind == "tu":
@@ -306,16 +306,16 @@ def test_absorbed_fold_over_graphs_that_span_several_tiles(sizes_kind, G):
     S = len(sizes)
     sp, sn = torch.from_numpy(seg_ptr).to(DEV).int(), torch.from_numpy(seg_nodes).to(DEV).int()
     tgt = torch.from_numpy(dummies).to(DEV).int()
-    tile_ptr, info, tile_graph, tile_first, cap, ok = ops.build_graph_tiles_multi(sp, sn, N, add_idx=tgt)
-    okr, tfr, tpr, tgr, infor = graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=dummies)
+    tile_ptr, info, chunk_tile, chunk_graph, cap, ok = ops.build_graph_tiles_multi(sp, sn, N, add_idx=tgt, num_chunks=G * K)
+    okr, ctr, cgr, tpr, infor = graph_tiles_multi_ref(seg_ptr, seg_nodes, N, G * K, add_idx=dummies)
     assert okr and int(ok.item()) != 0
-    T = int(tfr[-1])
-    assert T <= cap and np.array_equal(tile_first.cpu().numpy(), tfr) and np.array_equal(tile_ptr.cpu().numpy()[:T + 1], tpr)
-    assert np.array_equal(tile_graph.cpu().numpy()[:T], tgr) and np.array_equal(info.cpu().numpy()[:T], infor)
+    T = int(ctr[-1])
+    assert T <= cap and T <= N // 32 + G * K and np.array_equal(chunk_tile.cpu().numpy(), ctr) and np.array_equal(chunk_graph.cpu().numpy(), cgr)
+    assert np.array_equal(tile_ptr.cpu().numpy()[:T + 1], tpr) and np.array_equal(info.cpu().numpy()[:T], infor)
     lp, lr = torch.from_numpy(ptr).to(DEV).int(), torch.from_numpy(rows).to(DEV).int()
-    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True, multi=(tile_graph, tile_first, cap))
-    assert cu.order == 2 and cu.num_segments == S
-    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True, order=2, multi=(tgr, tfr))
+    cu = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tile_ptr, agg=True, multi=(chunk_tile, chunk_graph, cap, S))
+    assert cu.order == (3 if G % 8 == 0 else 2) and cu.num_segments == S
+    up, un, tiles = close_units_ref(ptr, rows, N, P, G, tile_ptr=tpr, agg=True, order=cu.order, multi=(ctr, cgr))
     assert np.array_equal(cu.unit_ptr.cpu().numpy(), up)
     assert np.array_equal(cu.units.cpu().numpy()[:len(un)], un)
     er, em = cu.ent_row.cpu().numpy(), cu.ent_mask.cpu().numpy().view(np.uint32)
@@ -344,15 +344,16 @@ def test_absorbed_fold_over_graphs_that_span_several_tiles(sizes_kind, G):
         assert float(errd.max()) < 8e-3, (w_kn, float(errd.max()))
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])       # bitwise run to run
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # ... and in both weight layouts
-    if sizes_kind == "small":                              # every graph inside one tile: the same arithmetic as the single-tile tables
-        tp1, info1, ok1 = ops.build_graph_tiles(sp, sn, N, add_idx=tgt)
-        assert int(ok1.item()) != 0 and np.array_equal(tp1.cpu().numpy(), tpr) and np.array_equal(info1.cpu().numpy(), infor)
+    if sizes_kind == "small":                              # every graph inside one tile: the single-tile tables of round 4 agree
+        tp1, info1, ok1 = ops.build_graph_tiles(sp, sn, N, add_idx=tgt)        # (other tiles: same sums up to fp32 summation order)
+        assert int(ok1.item()) != 0
         cu1 = ops.build_close_units(lp, lr, N, P, num_wg=G, tile_ptr=tp1, agg=True, order=0)
         aux1 = torch.empty((S, H), dtype=torch.bfloat16, device=DEV)
         out1 = ops.rows_close(x.to(DEV), W.to(DEV), b.to(DEV), Y.to(DEV), cu1, w_kn=True, agg=(info1, Wa.to(DEV), aux1, tgt))
-        assert torch.equal(out1, outs[0][0]) and torch.equal(aux1, outs[0][1])
+        assert float((aux1.double() - outs[0][1].double()).abs().max() / aux_ref.abs().max()) < 4e-3
+        assert float(((out1.double() - outs[0][0].double()).abs() / (out1.double().abs() + 1.0)).max()) < 2e-2
     # a target row outside its segment's own block: "no", as for the single-tile tables
     if S > 1:
         bad = np.roll(dummies, 1)
-        assert not graph_tiles_multi_ref(seg_ptr, seg_nodes, N, add_idx=bad)[0]
-        assert int(ops.build_graph_tiles_multi(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int())[5].item()) == 0
+        assert not graph_tiles_multi_ref(seg_ptr, seg_nodes, N, G * K, add_idx=bad)[0]
+        assert int(ops.build_graph_tiles_multi(sp, sn, N, add_idx=torch.from_numpy(bad).to(DEV).int(), num_chunks=G * K)[5].item()) == 0

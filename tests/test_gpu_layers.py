@@ -833,7 +833,7 @@ def test_absorbed_fold_on_tu_shaped_batches_with_graphs_of_1_to_700_nodes(seed):
 
     ix, tags, got = run(True)
     assert ix.built_by == "local"
-    assert [ix.close_units(d).order for d in "fb"] == [2, 2] and all(ix.close_units(d).agg for d in "fb")
+    assert [ix.close_units(d).order for d in "fb"] == [3, 3] and all(ix.close_units(d).agg for d in "fb")
     assert tags.count("rows_close") == 2 and "fold_tail" not in tags and tags.count("rows_transform:conv") == 2, tags
     ix0, tags0, want = run(False)
     assert tags0.count("fold_tail") == 2 and not any(ix0.close_units(d).agg for d in "fb")

@@ -1,4 +1,4 @@
-# GPU box: kernels of ONE fresh-batch index build (RowIndex + closing tables), in order.  usage: bash tools/index_kernels.sh config3|config5
+# GPU box: kernels of ONE fresh-batch index build (RowIndex + closing tables), in order.  usage: bash tools/index_kernels.sh config3|config5|proteins
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/idxk
 cat > /tmp/idx_once.py <<'PY'
 import os, sys, torch
@@ -7,14 +7,14 @@ import bench
 from dummynode4graphlearning_amd import ops
 w = sys.argv[1]
 dev = torch.device("cuda:0")
-g, raw, aug_ms = bench.build_batch(dev, {"config5": 5, "config3": 3}[w], {"config5": 32768, "config3": 512}[w], w)
-etype = g.edata["label"]; R = {"config5": 16, "config3": 8}[w]
+g, raw, aug_ms = bench.build_batch(dev, {"config5": 5, "config3": 3, "proteins": 2}[w], {"config5": 32768, "config3": 512, "proteins": 16384}[w], w)
+etype = g.edata["label"]; R = {"config5": 16, "config3": 8, "proteins": 16}[w]
 for it in range(4):
     g._cache.clear(); torch.cuda.synchronize()
     marker = torch.zeros(7, device=dev) + 1          # marks the start of a build in the trace
-    ix = g.row_index(etype, R, True, closing_hint=(256 if w == "config5" else 64, torch.bfloat16))
+    ix = g.row_index(etype, R, True, closing_hint=(64 if w == "config3" else 256, torch.bfloat16))
     for _, _, part in ix.parts:
-        ops.prepare_closing(part, 256 if w == "config5" else 64, torch.bfloat16)       # what bench.py's index_build_ms covers
+        ops.prepare_closing(part, 64 if w == "config3" else 256, torch.bfloat16)       # what bench.py's index_build_ms covers
     torch.cuda.synchronize()
 PY
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/idxk -o k -- python3 /tmp/idx_once.py $1 > /dev/null 2>&1
