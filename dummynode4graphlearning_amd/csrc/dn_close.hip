@@ -30,6 +30,7 @@
 #include "dn_internal.h"
 #include "../../include/dn_hip.h"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstring>
 #include <cstdlib>
@@ -146,6 +147,7 @@ struct CbLds {
 struct CbDir {
     const int32_t *tile_ptr, *lptr, *lrows, *drop_enable, *dyn;
     const int32_t *chunk_tile, *chunk_graph;                               // orders 2 / 3: first tile / first graph of every chunk [K G + 1]
+    const int32_t* tile_ptr_alt;                                           // dyn[3] == 2: the chunked tables' tile_ptr (see CbAlt)
     int32_t *ent_row, *tile_cnt, *ucnt, *unit_ptr;
     uint32_t* ent_mask;
     const int32_t* uoff;
@@ -155,15 +157,25 @@ struct CbDir {
 struct CbPair {
     CbDir d[2];
 };
+// A second table form the SAME launches can build instead, picked per direction by the device word dyn[3] (ril_plan's go: 1 = the
+// launch arguments' order over tile_ptr, 2 = this chunked order over tile_ptr_alt): dn_conv_index_build_i32 queues ONE set of
+// launches before it knows whether every graph of the batch fits a tile.  order 0: no alternative.
+struct CbAlt {
+    int32_t order, chunks_per_wg, tile_bound;
+};
 
-__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order, CbPair pr) {
+__global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order,
+                                                                      CbPair pr, CbAlt alt) {
     __shared__ __attribute__((aligned(16))) CbLds Ls[kCbWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (int)blockIdx.x * kCbWaves + wave;
+    CbDir a = pr.d[blockIdx.y];
+    if (a.dyn != nullptr) {
+        if (a.dyn[3] == 0) return;                                         // go = 0: nothing to do
+        if (a.dyn[3] == 2) { order = alt.order; Tper = alt.chunks_per_wg; T = alt.tile_bound; a.tile_ptr = a.tile_ptr_alt; }
+    }
     if (t >= T) return;                                                    // (no workgroup barrier below)
-    const CbDir& a = pr.d[blockIdx.y];
     if (order >= 2) {                                                      // chunked: Tper = K chunks per workgroup; T was a bound
-        if (a.dyn != nullptr && a.dyn[3] == 0) return;
         if (agg && t < G && lane == 0) {                                   // (T >= K G >= G) the tail of workgroup t's stream
             const int32_t ex = cb2_tail_units(t, G, Tper, order - 2, a.chunk_tile, a.chunk_graph);
             if (ex) atomicAdd(&a.ucnt[(int64_t)t * Tper + Tper - 1], ex);
@@ -180,8 +192,7 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
     int32_t* __restrict__ ucnt = a.ucnt;
     int32_t P = a.P, drop_beg = a.drop_beg, drop_end = a.drop_end;
     if (a.dyn != nullptr) {                                                // queued behind the row index (dn_conv_index_build_i32): the
-        if (a.dyn[3] == 0) return;                                         // counts the host does not know yet; go = 0: nothing to do
-        P = a.dyn[0]; drop_beg = a.dyn[1]; drop_end = a.dyn[2];
+        P = a.dyn[0]; drop_beg = a.dyn[1]; drop_end = a.dyn[2];            // counts the host does not know yet
     }
     if (a.drop_enable != nullptr && *a.drop_enable == 0) drop_beg = drop_end = 0;
     CbLds& L = Ls[wave];
@@ -320,10 +331,13 @@ __global__ __launch_bounds__(kCbWaves * 64) void close_entries_kernel(int32_t N,
 // Unit offsets in WORKGROUP-MAJOR order: workgroup w of G takes the tiles w, w + G, ... (round robin: the launch sweeps the nodes
 // as one stream; order 1: see cb_position); position k' = w * Tper + n holds the n-th tile of workgroup w.  The entries kernel leaves each tile's unit count there, one
 // exclusive scan (rocPRIM) gives the offsets.
-__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order, CbPair pr) {
+__global__ void close_fill_kernel(int32_t N, int32_t T, int32_t G, int32_t Tper, int32_t agg, int32_t order, CbPair pr, CbAlt alt) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const CbDir& a = pr.d[blockIdx.y];
-    if (a.dyn != nullptr && a.dyn[3] == 0) return;
+    CbDir a = pr.d[blockIdx.y];
+    if (a.dyn != nullptr) {
+        if (a.dyn[3] == 0) return;
+        if (a.dyn[3] == 2) { order = alt.order; Tper = alt.chunks_per_wg; T = alt.tile_bound; a.tile_ptr = a.tile_ptr_alt; }
+    }
     const int32_t* __restrict__ tile_ptr = a.tile_ptr;
     const int32_t* __restrict__ lptr = a.lptr;
     const int32_t* __restrict__ tile_cnt = a.tile_cnt;
@@ -395,11 +409,11 @@ __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __r
 
 __global__ void fold_multi_valid_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
                                         const int32_t* __restrict__ add_idx, int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
-    if (gate != nullptr && *gate == 0) return;
+    if (gate != nullptr && *gate != 2) return;
     dn_fold_multi_valid_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, ok);
 }
 // ONE workgroup: chunk c = the graphs whose blocks start in [ceil(c N / C), ceil((c + 1) N / C)); tiles per chunk, their prefix sums.
-// gate (may be NULL): a device word that must be non-zero for the tables to be wanted at all.
+// gate (may be NULL): a device word that must be 2 (ril_plan's "chunked tiles") for the tables to be wanted at all.
 constexpr int kChunkThreads = 1024, kChunkMax = 16384;
 __global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr,
                                                                           const int32_t* __restrict__ snodes,
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_
                                                                           const int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
     __shared__ int32_t cg[kChunkMax + 1];
     __shared__ int32_t wsum[kChunkThreads / 64];
-    if (*ok == 0 || (gate != nullptr && *gate == 0)) return;               // (an invalid batch's tables are never read)
+    if (*ok == 0 || (gate != nullptr && *gate != 2)) return;               // (an invalid batch's tables are never read)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c <= C; c += kChunkThreads)
         cg[c] = c == C ? S : dn_fold_first_graph_from((int32_t)(((int64_t)c * N + C - 1) / C), N, S, sptr, snodes);
@@ -446,7 +460,7 @@ __global__ void fold_multi_tiles_kernel(int32_t N, int32_t S, int32_t C, const i
                                         const int32_t* __restrict__ chunk_tile, const int32_t* __restrict__ chunk_graph,
                                         int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, const int32_t* __restrict__ ok,
                                         const int32_t* __restrict__ gate) {
-    if (*ok == 0 || (gate != nullptr && *gate == 0)) return;
+    if (*ok == 0 || (gate != nullptr && *gate != 2)) return;
     dn_fold_multi_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, C, sptr, snodes, chunk_tile, chunk_graph, tile_ptr, info);
 }
 
@@ -956,8 +970,12 @@ namespace dn_internal {
 // direction).  dirs[k].dyn != NULL: {edge rows, dropped range, go} are read on the device (ril_plan_kernel's words) instead of
 // num_edge_rows / drop_beg / drop_end -- the launches are queued before the host knows them.  workspace: nd times
 // dn_close_units_workspace_bytes.
+// alt_order != 0 (dn_conv_index_build_i32): the same launches can build the CHUNKED tables instead (order alt_order over dirs[k].tile_ptr_alt
+// / chunk_tile / chunk_graph / chunks_per_wg, alt_num_tiles = the bound those tables were sized by), picked per direction on the device
+// by dyn[3] (1: the primary form, 2: the alternative); capacities and the workspace must cover max(num_tiles, alt_num_tiles).
 int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
-                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st,
+                      int32_t alt_order, int64_t alt_num_tiles) {
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && num_wg > 0 && num_wg <= 4096 && num_list_entries >= 0 && num_tiles >= 0 &&
                num_tiles < 0x7fffffffLL && (nd == 1 || nd == 2), "dn_close_units_build: bad sizes");
     DN_REQUIRE(xcd_order == 0 || xcd_order == 2 || ((xcd_order == 1 || xcd_order == 3) && num_wg % 8 == 0 && num_tiles < 0x0fffffffLL),
@@ -980,16 +998,27 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
         DN_REQUIRE(dirs[k].list_ptr && dirs[k].list_rows && dirs[k].units && dirs[k].ent_row && dirs[k].ent_mask, "dn_close_units_build: NULL pointer");
         DN_REQUIRE(reinterpret_cast<uintptr_t>(dirs[k].units) % 16 == 0, "dn_close_units_build: unaligned pointer");
     }
-    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(num_tiles, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
-    DN_REQUIRE(workspace_bytes >= (size_t)nd * dn_close_units_workspace_bytes(num_tiles, num_wg), "dn_close_units_build: workspace too small");
+    CbAlt alt{0, 0, 0};
+    if (alt_order != 0) {
+        DN_REQUIRE((alt_order == 2 || (alt_order == 3 && num_wg % 8 == 0)) && xcd_order < 2 && alt_num_tiles > 0 && alt_num_tiles < 0x0fffffffLL,
+                   "dn_close_units_build: the alternative form is a chunked order behind a plain one");
+        for (int k = 0; k < nd; ++k)
+            DN_REQUIRE(dirs[k].dyn && dirs[k].tile_ptr_alt && dirs[k].chunk_tile && dirs[k].chunk_graph && dirs[k].chunks_per_wg >= 1 &&
+                       (int64_t)dirs[k].chunks_per_wg * num_wg <= alt_num_tiles && dirs[k].chunks_per_wg == dirs[0].chunks_per_wg,
+                       "dn_close_units_build: the alternative form needs dyn and the chunked tables");
+        alt = CbAlt{alt_order, dirs[0].chunks_per_wg, (int32_t)alt_num_tiles};
+    }
+    const int64_t Tmax = alt_order != 0 && alt_num_tiles > num_tiles ? alt_num_tiles : num_tiles;
+    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(Tmax, num_list_entries, num_wg), "dn_close_units_build: unit table too small");
+    DN_REQUIRE(workspace_bytes >= (size_t)nd * dn_close_units_workspace_bytes(Tmax, num_wg), "dn_close_units_build: workspace too small");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "dn_close_units_build: unaligned pointer");
     // (chunked orders: the scan runs over the workgroups' K chunk slots, Tper = K)
     const int32_t T = (int32_t)num_tiles, Tper = xcd_order >= 2 ? dirs[0].chunks_per_wg : (int32_t)dn_cdiv(T, num_wg);
-    const int64_t M = (int64_t)num_wg * Tper;
+    const int64_t M = std::max((int64_t)num_wg * Tper, (int64_t)num_wg * alt.chunks_per_wg);
     DN_REQUIRE((int64_t)nd * (unit_capacity + 1) < 0x7fffffffLL, "dn_close_units_build: unit tables too large");   // (one scan over both)
     char* wsp = reinterpret_cast<char*>(workspace);
     int32_t* tile_cnt[2] = {nullptr, nullptr};
-    for (int k = 0; k < nd; ++k) { tile_cnt[k] = reinterpret_cast<int32_t*>(wsp); wsp += dn_align_up((size_t)(T + 1) * 4, 256); }
+    for (int k = 0; k < nd; ++k) { tile_cnt[k] = reinterpret_cast<int32_t*>(wsp); wsp += dn_align_up((size_t)(Tmax + 1) * 4, 256); }
     const size_t ne = (size_t)nd * (size_t)(M + 1);                          // ucnt / uoff of the directions back to back: ONE scan
     int32_t* ucnt = reinterpret_cast<int32_t*>(wsp);
     wsp += dn_align_up(ne * 4, 256);
@@ -1002,30 +1031,31 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     CbPair pr;
     for (int k = 0; k < 2; ++k) {
         const CloseUnitsDir& d = dirs[k < nd ? k : 0];
-        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.chunk_tile, d.chunk_graph, d.ent_row,
+        pr.d[k] = CbDir{d.tile_ptr, d.list_ptr, d.list_rows, d.drop_enable, d.dyn, d.chunk_tile, d.chunk_graph, d.tile_ptr_alt, d.ent_row,
                         tile_cnt[k < nd ? k : 0],
                         ucnt + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), d.unit_ptr, d.ent_mask,
                         uoff + (size_t)(k < nd ? k : 0) * (size_t)(M + 1), reinterpret_cast<Unit*>(d.units), d.num_edge_rows, d.drop_beg,
                         d.drop_end};
     }
-    hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(T, kCbWaves), (unsigned)nd), dim3(kCbWaves * 64), 0, st, (int32_t)N, T,
-                       num_wg, Tper, agg_units ? 1 : 0, xcd_order, pr);
+    hipLaunchKernelGGL(close_entries_kernel, dim3((unsigned)dn_cdiv(Tmax, kCbWaves), (unsigned)nd), dim3(kCbWaves * 64), 0, st, (int32_t)N, T,
+                       num_wg, Tper, agg_units ? 1 : 0, xcd_order, pr, alt);
     DN_CHECK_LAUNCH();
     DN_CHECK_HIP(rocprim::exclusive_scan(wsp, tb, ucnt, uoff, (int32_t)0, ne, rocprim::plus<int32_t>(), st));
-    const int64_t nthreads = T > num_wg + 1 ? T : num_wg + 1;
+    const int64_t nthreads = Tmax > num_wg + 1 ? Tmax : num_wg + 1;
     hipLaunchKernelGGL(close_fill_kernel, dim3((unsigned)dn_cdiv(nthreads, 256), (unsigned)nd), dim3(256), 0, st, (int32_t)N, T, num_wg, Tper,
-                       agg_units ? 1 : 0, xcd_order, pr);
+                       agg_units ? 1 : 0, xcd_order, pr, alt);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
 
 int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx, int32_t num_chunks,
                      int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok,
-                     const int32_t* gate, hipStream_t st) {
-    DN_REQUIRE(num_chunks >= 1 && num_chunks <= kChunkMax, "dn_fold_graph_tiles_multi_build: 1 .. %d chunks", kChunkMax);
+                     const int32_t* gate, bool with_valid, hipStream_t st) {
+    DN_REQUIRE(num_chunks >= 1 && num_chunks < kChunkMax, "dn_fold_graph_tiles_multi_build: 1 .. %d chunks", kChunkMax - 1);
     DN_REQUIRE(tile_capacity >= N / 32 + num_chunks + 1, "dn_fold_graph_tiles_multi_build: tile tables too small");
-    hipLaunchKernelGGL(fold_multi_valid_kernel, dim3((unsigned)dn_cdiv(S, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr, seg_nodes,
-                       add_idx, dev_ok, gate);
+    if (with_valid)
+        hipLaunchKernelGGL(fold_multi_valid_kernel, dim3((unsigned)dn_cdiv(S, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr,
+                           seg_nodes, add_idx, dev_ok, gate);
     hipLaunchKernelGGL(fold_multi_chunks_kernel, dim3(1), dim3(kChunkThreads), 0, st, (int32_t)N, (int32_t)S, num_chunks, seg_ptr, seg_nodes,
                        chunk_tile, chunk_graph, dev_ok, gate);
     hipLaunchKernelGGL(fold_multi_tiles_kernel, dim3((unsigned)dn_cdiv(tile_capacity + 1, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S,
@@ -1052,7 +1082,7 @@ int dn_fold_graph_tiles_multi_build_i32(int64_t N, int64_t num_segments, const i
     DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0, "dn_fold_graph_tiles_multi_build: unaligned pointer");
     DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
     return dn_internal::fold_multi_queue(N, num_segments, seg_ptr, seg_nodes, add_idx, num_chunks, chunk_tile, chunk_graph, tile_ptr,
-                                         fold_info, tile_capacity, dev_ok, nullptr, st);
+                                         fold_info, tile_capacity, dev_ok, nullptr, true, st);
 }
 
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {
@@ -1079,7 +1109,7 @@ int dn_close_units_build_i32(int64_t N, int32_t num_edge_rows, int32_t num_wg, c
     const dn_internal::CloseUnitsDir d{tile_ptr, list_ptr, list_rows, num_edge_rows, drop_beg, drop_end, drop_enable, nullptr, unit_ptr,
                                        units, ent_row, ent_mask, chunk_tile, chunk_graph, chunks_per_wg};
     return dn_internal::close_units_queue(N, num_wg, num_tiles, agg_units, xcd_order, num_list_entries, unit_capacity, 1, &d, workspace,
-                                          workspace_bytes, (hipStream_t)stream);
+                                          workspace_bytes, (hipStream_t)stream, 0, 0);
 }
 
 int dn_fold_graph_tiles_build_i32(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes,

@@ -258,6 +258,71 @@ __device__ __forceinline__ void dn_fold_graph_tile_one(int64_t j, int32_t N, int
     rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 2; rec[11] = 0;                // [10]: bit 0 = continues the previous tile's sum, bit 1 = completes it
 }
 
+// Are the runs snodes[beg .. beg + cnt) consecutive integers?  One run per lane of a CONVERGED wavefront (lanes without one pass
+// want = false); the lanes walk each run together (coalesced), instead of every lane walking its own -- a 600-node graph next to
+// 63 small ones would keep its wavefront 600 dependent loads long.
+__device__ __forceinline__ bool dn_wave_runs_contiguous(bool want, int32_t beg, int32_t cnt, const int32_t* __restrict__ snodes) {
+    const int lane = (int)(threadIdx.x & 63);
+    bool good = true;
+    unsigned long long todo = __ballot(want && cnt > 1);
+    while (todo) {
+        const int sl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int32_t b = __shfl(beg, sl, 64), c = __shfl(cnt, sl, 64);
+        bool ok = true;
+        for (int32_t e = lane; e + 1 < c; e += 64) ok = ok && snodes[b + e + 1] == snodes[b + e] + 1;
+        const bool all = __all(ok) != 0;
+        if (lane == sl) good = all;
+    }
+    return good;
+}
+
+// BOTH verdicts of a batch's segments in one pass (the graph-local index builder's verdict launch): *ok starts as 3; an invalid
+// segment clears it, a valid one whose block has more than 32 nodes clears bit 0 (no graphs-as-tiles tables: dn_fold_graph_tile_one)
+// and leaves bit 1 (chunked tiles: dn_fold_multi_*); a block within 32 nodes gets its single-tile record.  Called by EVERY lane of a
+// converged wavefront (active: the lane has an index j <= S).
+__device__ __forceinline__ void dn_fold_verdicts_one(bool active, int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
+                                                     const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
+                                                     int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, int32_t* __restrict__ ok) {
+    const bool seg = active && j < S;
+    int32_t beg = 0, cnt = 0, first = 0, last = 0, nxt = N;
+    if (seg) { beg = sptr[j]; cnt = sptr[j + 1] - beg; }
+    bool good = seg && cnt > 0;
+    if (good) {
+        first = snodes[beg];
+        last = snodes[beg + cnt - 1];
+        good = first >= 0 && last < N && last - first == cnt - 1;
+    }
+    const bool runs = dn_wave_runs_contiguous(good, beg, cnt, snodes);
+    good = good && runs;
+    if (good && j + 1 < S) {
+        good = sptr[j + 2] > sptr[j + 1];
+        if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
+    }
+    const int32_t b0 = j == 0 ? 0 : first;
+    if (good) good = nxt - b0 >= 1;
+    if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
+    if (seg) {
+        if (!good) {
+            __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (nxt - b0 > 32) {
+            __hip_atomic_fetch_and(ok, ~1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            tile_ptr[j] = b0;
+            int32_t* rec = info + (size_t)j * 12;
+            for (int i = 0; i < 8; ++i) {
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) w |= ((b0 + 4 * i + b >= first && b0 + 4 * i + b <= last) ? 0u : 255u) << (8 * b);
+                rec[i] = (int32_t)w;
+            }
+            rec[8] = (int32_t)j; rec[9] = 1; rec[10] = 2; rec[11] = 0;
+        }
+    }
+    if (active && j == S) tile_ptr[S] = N;
+}
+
 // The same for graphs of ANY size (round 6).  The batch is cut into C CHUNKS at graph boundaries -- graph j (block start b0_j)
 // belongs to chunk floor(b0_j C / N) -- and every chunk into consecutive 32-node tiles that run ACROSS the graphs inside it (the
 // last tile of a chunk is the only partial one: T <= N / 32 + C).  The unit stream keeps a chunk in ONE workgroup, so a segment's
@@ -272,27 +337,29 @@ __device__ __forceinline__ int32_t dn_fold_gstart(int64_t j, int32_t N, int32_t 
                                                   const int32_t* __restrict__ snodes) {
     return j <= 0 ? 0 : (j >= S ? N : snodes[sptr[j]]);                   // block j = [gstart(j), gstart(j + 1))
 }
+// (called by every lane of a converged wavefront: the contiguity walk is shared, dn_wave_runs_contiguous)
 __device__ __forceinline__ void dn_fold_multi_valid_one(int64_t j, int32_t N, int32_t S, const int32_t* __restrict__ sptr,
                                                         const int32_t* __restrict__ snodes, const int32_t* __restrict__ add_idx,
                                                         int32_t* __restrict__ ok) {
-    if (j >= S) return;
-    const int32_t cnt = sptr[j + 1] - sptr[j];
-    bool good = cnt > 0;
-    int32_t first = 0, last = 0, nxt = N;
+    const bool seg = j < S;
+    int32_t beg = 0, cnt = 0, first = 0, last = 0, nxt = N;
+    if (seg) { beg = sptr[j]; cnt = sptr[j + 1] - beg; }
+    bool good = seg && cnt > 0;
     if (good) {
-        first = snodes[sptr[j]];
-        last = snodes[sptr[j + 1] - 1];
+        first = snodes[beg];
+        last = snodes[beg + cnt - 1];
         good = first >= 0 && last < N && last - first == cnt - 1;
-        for (int32_t e = sptr[j]; good && e + 1 < sptr[j + 1]; ++e) good = snodes[e + 1] == snodes[e] + 1;
-        if (good && j + 1 < S) {
-            good = sptr[j + 2] > sptr[j + 1];
-            if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
-        }
+    }
+    const bool runs = dn_wave_runs_contiguous(good, beg, cnt, snodes);
+    good = good && runs;
+    if (good && j + 1 < S) {
+        good = sptr[j + 2] > sptr[j + 1];
+        if (good) { nxt = snodes[sptr[j + 1]]; good = nxt > last; }
     }
     const int32_t b0 = j == 0 ? 0 : first;
     if (good) good = nxt - b0 >= 1;
     if (good && add_idx != nullptr) good = add_idx[j] >= b0 && add_idx[j] < nxt;
-    if (!good) {
+    if (seg && !good) {
         __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

@@ -20,9 +20,10 @@ struct Arena {
     size_t ril, close;
 };
 
-bool arena_sizes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg, Arena& a) {
+// (the closing tables' tiles: the batch's G graphs, or -- a graph over 32 nodes -- the chunked tiles, at most tile_capacity)
+bool arena_sizes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg, int64_t tile_capacity, Arena& a) {
     a.ril = dn_row_index_local_workspace_bytes(G, N, R, E);
-    a.close = dn_close_units_workspace_bytes(G, num_wg);
+    a.close = dn_close_units_workspace_bytes(G > tile_capacity ? G : tile_capacity, num_wg);
     return a.ril != 0 && a.close != 0;
 }
 
@@ -30,9 +31,9 @@ bool arena_sizes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg, Are
 
 extern "C" {
 
-size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg) {
+size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg, int64_t tile_capacity) {
     Arena a;
-    if (!arena_sizes(G, N, R, E, num_wg, a)) return 0;
+    if (!arena_sizes(G, N, R, E, num_wg, tile_capacity, a)) return 0;
     return dn_align_up(a.ril, 256) + 2 * dn_align_up(a.close, 256) + 256;
 }
 
@@ -44,7 +45,10 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
                             int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
                             int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int32_t close_xcd_order, int64_t unit_capacity, int32_t* unit_ptr_f,
                             int32_t* units_f, int32_t* ent_row_f, uint32_t* ent_mask_f, int32_t* unit_ptr_b, int32_t* units_b,
-                            int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t sweep_wg_per_group, int32_t sweep_tiles_per_wg,
+                            int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t chunks_per_wg, int64_t tile_capacity, int32_t* chunk_tile_f,
+                            int32_t* chunk_graph_f, int32_t* tile_ptr_mf, int32_t* fold_info_mf, int32_t* chunk_tile_b,
+                            int32_t* chunk_graph_b, int32_t* tile_ptr_mb, int32_t* fold_info_mb, int32_t sweep_wg_per_group,
+                            int32_t sweep_tiles_per_wg,
                             int32_t* sweep_f, int32_t* sweep_b, int32_t wgrad_workgroups, int32_t wgrad_max_chunk_rows,
                             int64_t chunk_capacity, int32_t* chunk_table, int32_t* chunk_ptr, int32_t* host_plan, void* workspace,
                             size_t workspace_bytes, dn_stream_t stream) {
@@ -56,10 +60,16 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
     DN_REQUIRE(sweep_tiles_per_wg == 0 || (sweep_f && sweep_b), "dn_conv_index_build: NULL pointer");
     DN_REQUIRE(wgrad_workgroups >= 1 && wgrad_max_chunk_rows >= 256 && wgrad_max_chunk_rows % 64 == 0 && chunk_table && chunk_ptr,
                "dn_conv_index_build: bad chunk-table arguments");
-    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(G, E + N, num_wg), "dn_conv_index_build: unit table too small");
+    // chunks_per_wg = 0: no chunked form (batches with a graph over 32 nodes are then left to the caller, as in round 5)
+    const bool chunked = chunks_per_wg > 0;
+    DN_REQUIRE(!chunked || (chunk_tile_f && chunk_graph_f && tile_ptr_mf && fold_info_mf && chunk_tile_b && chunk_graph_b && tile_ptr_mb &&
+                            fold_info_mb && tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, chunks_per_wg * num_wg)),
+               "dn_conv_index_build: the chunked form needs its eight tables, sized by dn_fold_graph_tiles_multi_capacity");
+    if (!chunked) tile_capacity = 0;
+    DN_REQUIRE(unit_capacity >= dn_close_units_capacity(G > tile_capacity ? G : tile_capacity, E + N, num_wg), "dn_conv_index_build: unit table too small");
     Arena a;
-    DN_REQUIRE(arena_sizes(G, N, R, E, num_wg, a), "dn_conv_index_build: bad sizes");
-    DN_REQUIRE(workspace_bytes >= dn_conv_index_workspace_bytes(G, N, R, E, num_wg), "dn_conv_index_build: workspace too small");
+    DN_REQUIRE(arena_sizes(G, N, R, E, num_wg, tile_capacity, a), "dn_conv_index_build: bad sizes");
+    DN_REQUIRE(workspace_bytes >= dn_conv_index_workspace_bytes(G, N, R, E, num_wg, tile_capacity), "dn_conv_index_build: workspace too small");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "dn_conv_index_build: unaligned workspace");
     hipStream_t st = (hipStream_t)stream;
     char* ws = reinterpret_cast<char*>(workspace);
@@ -70,12 +80,26 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
                                     fold_info_f, tile_ptr_b, fold_info_b, true, true, ws, a.ril, &meta, st);
     if (rc != DN_OK) return rc;
     const int32_t* plan = meta + 5 + 2 * R + 4;
-    // the unit streams of both directions in one set of launches: tiles = the graphs, AGG units appended; edge rows / dropped range /
-    // go from the device
+    // a graph over 32 nodes (go = 2 on the device): the chunked tiles of both directions -- the verdict launch has done the validity
+    // test, the aux lists are the segments, the verdict words double as the builders' "valid" words
+    if (chunked) {
+        int32_t* verdict = meta + 5 + 2 * R + 2;
+        rc = dn_internal::fold_multi_queue(N, G, aux_f_ptr, aux_f_idx, nullptr, chunks_per_wg * num_wg, chunk_tile_f, chunk_graph_f, tile_ptr_mf,
+                                           fold_info_mf, tile_capacity, verdict, plan + 3, false, st);
+        if (rc != DN_OK) return rc;
+        rc = dn_internal::fold_multi_queue(N, G, aux_b_ptr, aux_b_idx, nullptr, chunks_per_wg * num_wg, chunk_tile_b, chunk_graph_b, tile_ptr_mb,
+                                           fold_info_mb, tile_capacity, verdict + 1, plan + 7, false, st);
+        if (rc != DN_OK) return rc;
+    }
+    // the unit streams of both directions in one set of launches, AGG units appended; edge rows / dropped range / go from the device:
+    // go = 1: tiles = the graphs, go = 2: the chunked tiles
     const dn_internal::CloseUnitsDir dirs[2] = {
-        {tile_ptr_f, dst_ptr, dst_rows, 0, 0, 0, nullptr, plan, unit_ptr_f, units_f, ent_row_f, ent_mask_f},
-        {tile_ptr_b, src_ptr, src_rows, 0, 0, 0, nullptr, plan + 4, unit_ptr_b, units_b, ent_row_b, ent_mask_b}};
-    rc = dn_internal::close_units_queue(N, num_wg, G, 1, close_xcd_order, E + N, unit_capacity, 2, dirs, ws_close, 2 * dn_align_up(a.close, 256), st);
+        {tile_ptr_f, dst_ptr, dst_rows, 0, 0, 0, nullptr, plan, unit_ptr_f, units_f, ent_row_f, ent_mask_f, chunk_tile_f, chunk_graph_f,
+         chunks_per_wg, tile_ptr_mf},
+        {tile_ptr_b, src_ptr, src_rows, 0, 0, 0, nullptr, plan + 4, unit_ptr_b, units_b, ent_row_b, ent_mask_b, chunk_tile_b, chunk_graph_b,
+         chunks_per_wg, tile_ptr_mb}};
+    rc = dn_internal::close_units_queue(N, num_wg, G, 1, close_xcd_order, E + N, unit_capacity, 2, dirs, ws_close, 2 * dn_align_up(a.close, 256), st,
+                                        chunked ? 2 + close_xcd_order : 0, tile_capacity);
     if (rc != DN_OK) return rc;
     if (sweep_tiles_per_wg > 0) {                                             // and both sweep orders in one launch
         const uint64_t no_mask[2] = {0, 0};
@@ -94,10 +118,13 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
     dn_internal::ril_unpack(h_meta, R, host_counts, host_rel_ptr, host_modes, host_status, host_absorb);
     const int32_t* hp = h_meta + 5 + 2 * R + 4;
     host_plan[0] = hp[3]; host_plan[1] = hp[7]; host_plan[2] = 0; host_plan[3] = 0; host_plan[4] = 0; host_plan[5] = 0;
+    if (!chunked)                                                             // (go = 2 without the chunked tables: nothing was built)
+        for (int d = 0; d < 2; ++d)
+            if (host_plan[d] == 2) host_plan[d] = 0;
     if (sweep_tiles_per_wg > 0) {                                             // slots per workgroup of each order as the builder laid it out
         const int32_t* si = hp + dn_internal::kRilPlanWords + 1;             // {0 sweep | 1 plain | 2 does not fit, slots of the fullest group} x 2
         for (int d = 0; d < 2; ++d)
-            if (hp[3 + 4 * d]) host_plan[4 + d] = si[2 * d] == 0 ? (si[2 * d + 1] > 0 ? si[2 * d + 1] : 1) : (si[2 * d] == 1 ? sweep_tiles_per_wg : -1);
+            if (host_plan[d]) host_plan[4 + d] = si[2 * d] == 0 ? (si[2 * d + 1] > 0 ? si[2 * d + 1] : 1) : (si[2 * d] == 1 ? sweep_tiles_per_wg : -1);
     }
     if (*host_status != 0) return DN_OK;                                      // (the caller runs the general builder)
     // split-K chunk table of the weight gradient over ALL rows (the self loop as relation R): the smallest multiple of 64 rows

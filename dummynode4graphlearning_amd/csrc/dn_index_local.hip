@@ -839,7 +839,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
         // modes and the verdict ride in the same block: ONE device -> host copy per build (both are final before this launch)
         if (threadIdx.x < R) meta[5 + R + 1 + threadIdx.x] = mode[threadIdx.x];
         if (threadIdx.x == 0) {                                           // (+ the two fold verdicts: "still valid"; the verdict launch's ticket)
-            meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 1; meta[5 + 2 * R + 3] = 1;
+            meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 3; meta[5 + 2 * R + 3] = 3;    // (bit 0: graphs as tiles, bit 1: chunked tiles)
             meta[5 + 2 * R + 4 + dn_internal::kRilPlanWords] = 0;
         }
     }
@@ -945,7 +945,8 @@ struct VdPair {
 
 // What the table builders behind the row index need from its counts, left ON THE DEVICE so that dn_conv_index_build_i32 can queue
 // them without waiting for the read-back: plan = meta + 5 + 2 R + 4, kRilPlanWords words
-//   [0..3] forward closing stream:  {edge rows P, first / end row of the folded relation (the rows the stream leaves out), go}
+//   [0..3] forward closing stream:  {edge rows P, first / end row of the folded relation (the rows the stream leaves out), go:
+//          1 = the graphs are the tiles, 2 = chunked tiles over graphs of any size}
 //   [4..7] backward closing stream: the same
 //   [8..9] forward sweep order: {relation to skip (-1: none), go};  [10..11] backward sweep order
 // go = the build is valid (no graph raised the flag), the direction's fold can be absorbed (the verdicts below) and its segments
@@ -959,13 +960,14 @@ __device__ void ril_plan(int64_t G, int32_t R, int32_t* __restrict__ meta) {
         for (int r = 0; r < R; ++r)
             if (meta[5 + R + 1 + r] == want && meta[5 + r + 1] > meta[5 + r]) rel = r;   // (exactly one when the verdict stands)
         const int32_t verdict = __hip_atomic_load(meta + 5 + 2 * R + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t go = (status == 0 && verdict != 0 && rel >= 0 && (int64_t)meta[1 + d] == G) ? 1 : 0;
+        // go: 0 nothing, 1 the graphs are the tiles (every block within 32 nodes), 2 chunked tiles (graphs of any size)
+        const int32_t go = (status == 0 && verdict != 0 && rel >= 0 && (int64_t)meta[1 + d] == G) ? ((verdict & 1) ? 1 : 2) : 0;
         plan[4 * d] = P;
         plan[4 * d + 1] = go ? meta[5 + rel] : 0;
         plan[4 * d + 2] = go ? meta[5 + rel + 1] : 0;
         plan[4 * d + 3] = go;
         plan[8 + 2 * d] = go ? rel : -1;
-        plan[8 + 2 * d + 1] = go;
+        plan[8 + 2 * d + 1] = go ? 1 : 0;
     }
 }
 
@@ -994,8 +996,8 @@ __global__ void ril_fold_verdict_kernel(int64_t G, int64_t N, int32_t R, int32_t
             __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    } else {
-        dn_fold_graph_tile_one(j, (int32_t)N, n_aux, a.aux_ptr, a.aux_idx, a.row_target + beg, a.tile_ptr, a.info, ok);
+    } else {                                                               // (the same branch for the whole launch: full wavefronts inside)
+        dn_fold_verdicts_one(j <= n_aux, j, (int32_t)N, n_aux, a.aux_ptr, a.aux_idx, a.row_target + beg, a.tile_ptr, a.info, ok);
     }
     if (!want_plan) return;
     // (the verdict words are written and read with device-scope atomics -- no cache write-back per workgroup; everything else the

@@ -41,14 +41,17 @@ struct CloseUnitsDir {                 // one direction's arguments of dn_close_
     uint32_t* ent_mask;
     const int32_t *chunk_tile = nullptr, *chunk_graph = nullptr;   // orders 2 / 3 (graphs of any size): first tile / first graph of every
     int32_t chunks_per_wg = 0;                                     //   chunk [K num_wg + 1]; num_tiles is then a BOUND (chunk_tile[K num_wg] exist)
+    const int32_t* tile_ptr_alt = nullptr;                         // close_units_queue's alternative form: the chunked tables' tile_ptr
 };
-// (dn_fold_graph_tiles_multi_build_i32 without its argument checks; gate != NULL: a device word that must be non-zero for the launches
-//  to do anything -- dn_conv_index_build_i32 queues them before it knows whether the batch wants them)
+// (dn_fold_graph_tiles_multi_build_i32 without its argument checks; gate != NULL: a device word that must be 2 -- ril_plan's "chunked
+//  tiles" -- for the launches to do anything: dn_conv_index_build_i32 queues them before it knows whether the batch wants them;
+//  with_valid = false: the validity launch is left out, the caller's dev_ok word already holds the verdict)
 int fold_multi_queue(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx,
                      int32_t num_chunks, int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info,
-                     int64_t tile_capacity, int32_t* dev_ok, const int32_t* gate, hipStream_t st);
+                     int64_t tile_capacity, int32_t* dev_ok, const int32_t* gate, bool with_valid, hipStream_t st);
 int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
-                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st);
+                      int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st,
+                      int32_t alt_order, int64_t alt_num_tiles);
 
 // dn_index.hip
 int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* row_in, const int32_t* row_out, int64_t num_nodes,

@@ -1303,9 +1303,14 @@ class RowIndex:
             nbytes = 0 if one_call else lib().dn_row_index_local_workspace_bytes(G, N, R, E)
             if one_call:
                 num_wg = _num_cus(dev)
-                nbytes = lib().dn_conv_index_workspace_bytes(G, N, R, E, num_wg)
+                # (a graph over 32 nodes: the same call builds the chunked tiles and their unit streams instead; which, is decided on the device)
+                kper = close_chunks(N, num_wg) // num_wg if CLOSE_MULTI_ENABLED else 0
+                tcap = int(lib().dn_fold_graph_tiles_multi_capacity(N, kper * num_wg)) if kper else 0
+                nbytes = lib().dn_conv_index_workspace_bytes(G, N, R, E, num_wg, tcap)
             if one_call and nbytes:
-                cap = int(lib().dn_close_units_capacity(G, E + N, num_wg))
+                cap = int(lib().dn_close_units_capacity(max(G, tcap), E + N, num_wg))
+                mt = [(e32(kper * num_wg + 1), e32(kper * num_wg + 1), e32(tcap + 1), torch.empty((max(tcap, 1), 12), dtype=I32, device=dev))
+                      if kper else (None, None, None, None) for _ in range(2)]
                 cus = []
                 for _ in range(2):
                     cu = CloseUnits()
@@ -1328,7 +1333,8 @@ class RowIndex:
                     ptr(src_ptr), ptr(src_rows), counts, host_rel, host_modes, ctypes.byref(status), ptr(rel_dev), ptr(gt_bufs[0][0]),
                     ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cus[0].order, cap, ptr(cus[0].unit_ptr),
                     ptr(cus[0].units), ptr(cus[0].ent_row), ptr(cus[0].ent_mask), ptr(cus[1].unit_ptr), ptr(cus[1].units),
-                    ptr(cus[1].ent_row), ptr(cus[1].ent_mask), SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
+                    ptr(cus[1].ent_row), ptr(cus[1].ent_mask), kper, tcap, ptr(mt[0][0]), ptr(mt[0][1]), ptr(mt[0][2]), ptr(mt[0][3]),
+                    ptr(mt[1][0]), ptr(mt[1][1]), ptr(mt[1][2]), ptr(mt[1][3]), SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
                     WGRAD_CHUNK_ROWS, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),
                     "dn_conv_index_build_i32")
                 if status.value == 0:
@@ -1337,7 +1343,7 @@ class RowIndex:
                     # (the sweep tables were sized by a bound; the builder laid them out with the slots they need)
                     sw = [(sweeps[k][:Gw * host_plan[4 + k]], Gw * int(host_plan[4 + k])) if want_sweep and host_plan[4 + k] > 0 else None
                           for k in range(2)]
-                    pre = (cus, sw, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]))
+                    pre = (cus, sw, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]), mt, tcap)
             elif nbytes:
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
@@ -1397,7 +1403,13 @@ class RowIndex:
                 assert cands["f"] is not None and cands["b"] is not None and cands["f"][3] == cands["b"][3] == G
                 for k, d in enumerate(("f", "b")):
                     info = _make_fold_info(self, d, cands[d])
-                    info.graph_tiles = (self._absorb[d][0], self._absorb[d][1])
+                    if pre[3 + k] == 2:                              # a graph over 32 nodes: the call left the chunked form behind
+                        ct, cg, tpm, fim = pre[5][k]
+                        info.graph_tiles = (tpm, fim)
+                        info.multi = (ct, cg, pre[6], G)
+                        pre[0][k].order, pre[0][k].num_tiles = 2 + _close_order(pre[0][k].num_wg), pre[6]
+                    else:
+                        info.graph_tiles = (self._absorb[d][0], self._absorb[d][1])
                     if pre[1][k] is not None and _sweep_wanted(self):
                         info.sweep_tiles = pre[1][k]
                     self._fold[d] = info
@@ -1555,9 +1567,9 @@ def _closing_tables(ix, kind="slots"):
             h = [0, 0, 0, 0]
             for k, d in enumerate(dirs):
                 if cands[d] is not None:
-                    tp, fi, verdict = ix._absorb[d]
+                    tp, fi, verdict = ix._absorb[d]                      # (bit 0: every block within 32 nodes; bit 1: valid without that limit)
                     gts[d] = (tp[:cands[d][3] + 1], fi[:cands[d][3]])
-                    h[2 + k] = verdict
+                    h[2 + k] = verdict & 1
         elif kind == "units" and CLOSE_AGG_ENABLED:
             for k, d in enumerate(dirs):
                 if cands[d] is not None:
@@ -1620,7 +1632,7 @@ def _closing_tables(ix, kind="slots"):
         info = ix._fold[d]
         drop = (info.beg, info.end) if info is not None else (0, 0)
         if (kind == "units" and info is not None and info.graph_tiles is None and CLOSE_AGG_ENABLED and CLOSE_SINGLE_ENABLED
-                and ix._absorb is not None and ix._absorb[d][2]):                                # (the slot tables came first: the builder's verdict still stands)
+                and ix._absorb is not None and (ix._absorb[d][2] & 1)):                                # (the slot tables came first: the builder's verdict still stands)
             info.graph_tiles = (ix._absorb[d][0][:info.n + 1], ix._absorb[d][1][:info.n])
         if kind == "slots":
             slots, over = tabs[d]

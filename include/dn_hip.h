@@ -258,7 +258,8 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * [G][12], 16-byte aligned): the builder also answers, per direction, whether dn_rows_close_bf16 can ABSORB the fold of this batch
  * -- exactly one collapsed relation in the direction (mode AGG forward / TF backward) owning all the direction's aux lists, with
  * a self loop, and its segments passing dn_fold_graph_tiles_build_i32's test with the relation's own rows as targets -- and
- * leaves that call's tile_ptr / fold_info behind (host_absorb[d] != 0); the verdicts ride in the builder's ONE read-back.
+ * leaves that call's tile_ptr / fold_info behind (host_absorb[d] bit 0); bit 1 (round 6): the segments pass the test WITHOUT the
+ * 32-node limit (dn_fold_graph_tiles_multi_build_i32 would say yes); the verdicts ride in the builder's ONE read-back.
  * Synchronises the stream (one read-back). */
 size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E);
 int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr,
@@ -282,16 +283,22 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
  *     builder lays each table out with the slots its fullest group needs, host_plan[4] / host_plan[5] (forward / backward) slots per
  *     workgroup -- the table is [8 * sweep_wg_per_group * host_plan[4 + d]][4] -- or -1 when not even the plain order fits;
  *     sweep_tiles_per_wg = 0: none;
- * the counts these builders need (edge rows, the folded relation and its row range) are read from device memory.  They serve ONE
- * case -- host_plan[0] (forward) / host_plan[1] (backward) != 0: the build is valid, the direction's fold can be absorbed
- * (host_absorb) and its segments are the batch's G graphs; for a direction with 0 its tables are left untouched and the caller
- * builds them with the separate entry points.  After the read-back the split-K chunk table of the weight gradient over all rows
+ * the counts these builders need (edge rows, the folded relation and its row range) are read from device memory.  They serve the
+ * batches whose fold can be absorbed -- host_plan[0] (forward) / host_plan[1] (backward) != 0: the build is valid, the direction
+ * has its one collapsed relation (host_absorb != 0: bit 0 = every block within 32 nodes, bit 1 = the segments pass the test without
+ * that limit) and its segments are the batch's G graphs.  host_plan[d] = 1: the tables above, the graphs as tiles.  host_plan[d] = 2
+ * (round 6; a graph over 32 nodes, chunks_per_wg > 0): the SAME launches have built the chunked form instead -- chunk_tile_* /
+ * chunk_graph_* [chunks_per_wg * num_wg + 1], tile_ptr_m* [tile_capacity + 1], fold_info_m* [tile_capacity][12] as
+ * dn_fold_graph_tiles_multi_build_i32 leaves them (tile_capacity >= dn_fold_graph_tiles_multi_capacity(N, chunks_per_wg * num_wg)),
+ * unit streams in order 2 + close_xcd_order (unit_capacity and the workspace then cover max(G, tile_capacity) tiles); which form was
+ * needed is decided on the device.  For a direction with 0 its tables are left untouched and the caller builds them with the
+ * separate entry points.  chunks_per_wg = 0: no chunked form (the eight pointers may be NULL).  After the read-back the split-K chunk table of the weight gradient over all rows
  * (dn_row_tables_build_i32 with piece_ptr) is queued: host_plan[2] = rows per chunk -- the smallest multiple of 64 (>= 256, <=
  * wgrad_max_chunk_rows) for which the chunks of all relations fit one round of wgrad_workgroups -- host_plan[3] = its entries
  * (rows / chunk + relations + 1 <= chunk_capacity); chunk_table [chunk_capacity][4], chunk_ptr [R + 2]; host_plan: int32 [6].
  * *host_status != 0 as for
  * dn_row_index_build_local_i32 (nothing else is valid).  workspace: 256-byte aligned.  Synchronises the stream once. */
-size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg);
+size_t dn_conv_index_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E, int32_t num_wg, int64_t tile_capacity);
 int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr,
                             const int32_t* src, const int32_t* dst, const int32_t* etype, int32_t self_loop, float edge_frac,
                             int32_t* row_in, int32_t* row_out, int32_t* aux_f_ptr, int32_t* aux_f_idx, int32_t* aux_b_ptr,
@@ -300,7 +307,10 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
                             int32_t* rel_ptr_dev, int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b,
                             int32_t* fold_info_b, int32_t* host_absorb, int32_t num_wg, int32_t close_xcd_order, int64_t unit_capacity, int32_t* unit_ptr_f,
                             int32_t* units_f, int32_t* ent_row_f, uint32_t* ent_mask_f, int32_t* unit_ptr_b, int32_t* units_b,
-                            int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t sweep_wg_per_group, int32_t sweep_tiles_per_wg,
+                            int32_t* ent_row_b, uint32_t* ent_mask_b, int32_t chunks_per_wg, int64_t tile_capacity, int32_t* chunk_tile_f,
+                            int32_t* chunk_graph_f, int32_t* tile_ptr_mf, int32_t* fold_info_mf, int32_t* chunk_tile_b,
+                            int32_t* chunk_graph_b, int32_t* tile_ptr_mb, int32_t* fold_info_mb, int32_t sweep_wg_per_group,
+                            int32_t sweep_tiles_per_wg,
                             int32_t* sweep_f, int32_t* sweep_b, int32_t wgrad_workgroups, int32_t wgrad_max_chunk_rows,
                             int64_t chunk_capacity, int32_t* chunk_table, int32_t* chunk_ptr, int32_t* host_plan, void* workspace,
                             size_t workspace_bytes, dn_stream_t stream);

@@ -142,23 +142,25 @@ def test_conv_index_entry_point_checks_its_arguments(lib):
     """dn_conv_index_build_i32 (the whole per-batch index in one call): sizes, pointers and capacities are checked before the first
     launch (the workspace checks need a device for the scan's size query: tests/test_gpu_local_index.py)"""
     L = lib.lib()
-    assert L.dn_conv_index_workspace_bytes(4, 10, 65, 20, 256) == 0                                          # R > 64
-    assert L.dn_conv_index_workspace_bytes(4, 10, 3, 20, 0) == 0                                             # no workgroups
+    assert L.dn_conv_index_workspace_bytes(4, 10, 65, 20, 256, 0) == 0                                       # R > 64
+    assert L.dn_conv_index_workspace_bytes(4, 10, 3, 20, 0, 0) == 0                                        # no workgroups
     G, N, R, E, wg = 4, 40, 6, 100, 256
     cap = L.dn_close_units_capacity(G, E + N, wg)
     counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * (R + 1))(), (ctypes.c_int32 * R)(), ctypes.c_int32(0)
     absorb, plan = (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 6)()
     P256 = ctypes.c_void_p(256)
 
-    def call(G=G, host=counts, units=P256, cap=cap, sweep_s=8, sweep=P256, wgrad_rows=4096):
+    def call(G=G, host=counts, units=P256, cap=cap, sweep_s=8, sweep=P256, wgrad_rows=4096, kper=0, tcap=0, mt=None):
         return L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), host, rel, modes,
                                          ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, 1, cap, P256, units, P256, P256,
-                                         P256, P256, P256, P256, 32, sweep_s, sweep, sweep, 256, wgrad_rows, 64, P256, P256, plan, P256,
-                                         1 << 30, None)
+                                         P256, P256, P256, P256, kper, tcap, *([mt] * 8), 32, sweep_s, sweep, sweep, 256, wgrad_rows, 64,
+                                         P256, P256, plan, P256, 1 << 30, None)
 
+    tc = L.dn_fold_graph_tiles_multi_capacity(N, 2 * wg)
     for kw, msg in ((dict(G=0), b"bad sizes"), (dict(host=None), b"NULL pointer"), (dict(units=None), b"NULL pointer"),
                     (dict(cap=cap - 1), b"unit table too small"), (dict(sweep=None), b"NULL pointer"),
-                    (dict(wgrad_rows=100), b"bad chunk-table arguments")):
+                    (dict(wgrad_rows=100), b"bad chunk-table arguments"), (dict(kper=2, tcap=tc), b"chunked form needs"),
+                    (dict(kper=2, tcap=tc - 1, mt=P256), b"chunked form needs"), (dict(kper=2, tcap=tc, mt=P256), b"unit table too small")):
         assert call(**kw) == -1 and msg in L.dn_last_error(), (kw, L.dn_last_error())
 
 

@@ -283,9 +283,10 @@ def _same_closing(a, b, served):
     assert ma == mb and torch.equal(ta[:ma], tb[:mb]) and torch.equal(pa[:a.num_all_rels + 1], pb[:b.num_all_rels + 1])
     ops.prepare_closing(b, 256, torch.bfloat16)
     absorbed = b.built_by == "local" and all(b._units[d].agg for d in "fb")
-    if served is not None:
-        assert absorbed == served
-    assert bool(a._units) == absorbed                                 # both folds absorbed: nothing left to build for the first step
+    if served is not None:                                            # served: the one call left nothing to build for the first step
+        assert bool(a._units) == served and (absorbed or not served)  # (the separate builders may absorb where the call does not serve:
+    else:                                                             #  empty graphs between the others -- fewer segments than graphs)
+        assert bool(a._units) == absorbed
     ops.prepare_closing(a, 256, torch.bfloat16)
     for d in "fb":
         fa, fb_ = a._fold[d], b._fold[d]
@@ -293,14 +294,21 @@ def _same_closing(a, b, served):
         if fa is not None:
             assert (fa.rel, fa.beg, fa.end, fa.n) == (fb_.rel, fb_.beg, fb_.end, fb_.n) and torch.equal(fa.add_idx, fb_.add_idx)
             assert (fa.graph_tiles is None) == (fb_.graph_tiles is None)
-            if fa.graph_tiles is not None:
+            assert (fa.multi is None) == (fb_.multi is None)
+            if fa.multi is not None:                                  # the chunked form: T tiles exist (on the device), the tables hold more
+                assert torch.equal(fa.multi[0], fb_.multi[0]) and torch.equal(fa.multi[1], fb_.multi[1]) and fa.multi[2:] == fb_.multi[2:]
+                T = int(fa.multi[0][-1])
+                assert torch.equal(fa.graph_tiles[0][:T + 1], fb_.graph_tiles[0][:T + 1])
+                assert torch.equal(fa.graph_tiles[1][:T], fb_.graph_tiles[1][:T])
+            elif fa.graph_tiles is not None:
                 for x, y in zip(fa.graph_tiles, fb_.graph_tiles):
                     assert torch.equal(x[:fa.n], y[:fa.n])
             assert (fa.sweep_tiles is None) == (fb_.sweep_tiles is None)
             if fa.sweep_tiles is not None:
                 assert _tiles_per_workgroup(*fa.sweep_tiles) == _tiles_per_workgroup(*fb_.sweep_tiles)
         ua, ub = a._units[d], b._units[d]
-        assert (ua.num_wg, ua.num_nodes, ua.num_tiles, ua.agg) == (ub.num_wg, ub.num_nodes, ub.num_tiles, ub.agg)
+        assert (ua.num_wg, ua.num_nodes, ua.num_tiles, ua.agg, ua.order, ua.num_segments) == (ub.num_wg, ub.num_nodes, ub.num_tiles, ub.agg,
+                                                                                            ub.order, ub.num_segments)
         assert torch.equal(ua.unit_ptr, ub.unit_ptr)
         n = int(ua.unit_ptr[-1])
         xa, xb = ua.units[:n].cpu().numpy(), ub.units[:n].cpu().numpy()
@@ -327,21 +335,42 @@ def test_one_call_index_leaves_what_the_separate_builders_leave(graphs):
         assert a._fold["f"].sweep_tiles is not None
 
 
-@pytest.mark.parametrize("case", ["large graphs", "no dummy", "random sizes", "over the LDS limit"])
+@pytest.mark.parametrize("case", ["large graphs", "tu sizes", "one large graph"])
+def test_one_call_index_serves_graphs_over_32_nodes_with_the_chunked_form(case):
+    """A graph over 32 nodes no longer sends the batch to the separate builders: the same queued launches build the CHUNKED tiles
+    and their unit streams (decided on the device); tables equal to what the separate entry points build."""
+    rng = np.random.default_rng(78)
+    if case == "large graphs":
+        src, dst, et, nptr, eptr = _random_batch(rng, G=60, R=6, nmin=40, nmax=70, dens=2.0)
+    elif case == "tu sizes":
+        src, dst, et, nptr, eptr = _random_batch(rng, G=300, R=6, nmin=1, nmax=200, dens=1.5)
+    else:
+        src, dst, et, nptr, eptr = _random_batch(rng, G=90, R=6, nmin=3, nmax=20, dens=2.0)
+        n0 = 500
+        s0 = np.concatenate([rng.integers(0, n0, size=700), np.arange(n0), np.full(n0, n0)])
+        d0 = np.concatenate([rng.integers(0, n0, size=700), np.full(n0, n0), np.arange(n0)])
+        e0 = np.concatenate([rng.integers(0, 4, size=700), np.full(n0, 4), np.full(n0, 5)])
+        src, dst, et = np.concatenate([s0, src + n0 + 1]), np.concatenate([d0, dst + n0 + 1]), np.concatenate([e0, et])
+        nptr, eptr = np.concatenate([[0], nptr + n0 + 1]), np.concatenate([[0], eptr + len(s0)])
+    a, b = _index_pair(src, dst, et, int(nptr[-1]), 6, nptr, eptr)
+    assert a.built_by == b.built_by == "local"
+    _same_closing(a, b, served=True)
+    assert all(a._units[d].order >= 2 and b._units[d].order >= 2 for d in "fb")
+
+
+@pytest.mark.parametrize("case", ["no dummy", "random sizes", "over the LDS limit"])
 def test_one_call_index_where_it_cannot_serve(case):
-    """Batches the queued table builders are not sized for -- a graph over 32 nodes, no collapsed relation, a graph the local
+    """Batches the queued table builders do not serve -- no collapsed relation, empty graphs between the others, a graph the local
     builder rejects: the call must leave the row index (or hand over to the general builder) and touch nothing else; the tables
     are then built on first use, as without the hint."""
     rng = np.random.default_rng(77)
-    if case == "large graphs":
-        src, dst, et, nptr, eptr = _random_batch(rng, G=60, R=6, nmin=40, nmax=70, dens=2.0)
-    elif case == "no dummy":
+    if case == "no dummy":
         src, dst, et, nptr, eptr = _random_batch(rng, G=200, R=6, nmin=3, nmax=20, dens=2.0, dummy=False)
     elif case == "random sizes":
         src, dst, et, nptr, eptr = _random_batch(rng, G=150, R=6, nmin=0, nmax=45, dens=3.0)
-    else:                                                             # one graph of 1,100 edges in front of 40 small ones: the local
+    else:                                                             # one graph of 9,000 edges in front of 40 small ones: the local
         src, dst, et, nptr, eptr = _random_batch(rng, G=40, R=6, nmin=3, nmax=20, dens=2.0)     # builder is tried and raises its flag
-        n0, m0 = 60, 1100
+        n0, m0 = 60, 9000
         src = np.concatenate([rng.integers(0, n0, size=m0), src + n0])
         dst = np.concatenate([rng.integers(0, n0, size=m0), dst + n0])
         et = np.concatenate([rng.integers(0, 4, size=m0), et])
@@ -383,16 +412,18 @@ def test_one_call_index_checks_its_workspace():
     from dummynode4graphlearning_amd import _lib
     L = _lib.lib()
     G, N, R, E, wg = 4, 40, 6, 100, 256
-    need = L.dn_conv_index_workspace_bytes(G, N, R, E, wg)
+    need = L.dn_conv_index_workspace_bytes(G, N, R, E, wg, 0)
     assert need >= L.dn_row_index_local_workspace_bytes(G, N, R, E) + 2 * L.dn_close_units_workspace_bytes(G, wg)
+    assert L.dn_conv_index_workspace_bytes(G, N, R, E, wg, 5000) >= (L.dn_row_index_local_workspace_bytes(G, N, R, E)
+                                                                    + 2 * L.dn_close_units_workspace_bytes(5000, wg))
     cap = L.dn_close_units_capacity(G, E + N, wg)
     counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * (R + 1))(), (ctypes.c_int32 * R)(), ctypes.c_int32(0)
     absorb, plan = (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 6)()
     P256 = ctypes.c_void_p(256)
     for ws, nbytes, msg in ((P256, need - 1, b"workspace too small"), (ctypes.c_void_p(16), need, b"unaligned workspace")):
         rc = L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), counts, rel, modes,
-                                       ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, 1, cap, *([P256] * 8), 32, 8, P256, P256,
-                                       256, 4096, 64, P256, P256, plan, ws, nbytes, None)
+                                       ctypes.byref(st), P256, P256, P256, P256, P256, absorb, wg, 1, cap, *([P256] * 8), 0, 0, *([None] * 8),
+                                       32, 8, P256, P256, 256, 4096, 64, P256, P256, plan, ws, nbytes, None)
         assert rc == -1 and msg in L.dn_last_error(), L.dn_last_error()
 
 
