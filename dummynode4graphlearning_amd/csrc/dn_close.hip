@@ -407,21 +407,25 @@ __global__ void fold_graph_tiles_kernel(int32_t N, int32_t S, const int32_t* __r
     dn_fold_graph_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, tile_ptr, info, ok);
 }
 
-__global__ void fold_multi_valid_kernel(int32_t N, int32_t S, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
-                                        const int32_t* __restrict__ add_idx, int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
-    if (gate != nullptr && *gate != 2) return;
-    dn_fold_multi_valid_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, sptr, snodes, add_idx, ok);
-}
-// ONE workgroup: chunk c = the graphs whose blocks start in [ceil(c N / C), ceil((c + 1) N / C)); tiles per chunk, their prefix sums.
+struct FmPair {                        // the directions of one batch share the launches (blockIdx.y)
+    dn_internal::FoldMultiDir d[2];
+};
 // gate (may be NULL): a device word that must be 2 (ril_plan's "chunked tiles") for the tables to be wanted at all.
+__global__ void fold_multi_valid_kernel(int32_t N, int32_t S, FmPair pr) {
+    const dn_internal::FoldMultiDir& a = pr.d[blockIdx.y];
+    if (a.gate != nullptr && *a.gate != 2) return;
+    dn_fold_multi_valid_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, a.seg_ptr, a.seg_nodes, a.add_idx, a.dev_ok);
+}
+// ONE workgroup per direction: chunk c = the graphs whose blocks start in [ceil(c N / C), ceil((c + 1) N / C)); tiles per chunk, their
+// prefix sums.
 constexpr int kChunkThreads = 1024, kChunkMax = 16384;
-__global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr,
-                                                                          const int32_t* __restrict__ snodes,
-                                                                          int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_graph,
-                                                                          const int32_t* __restrict__ ok, const int32_t* __restrict__ gate) {
+__global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_t N, int32_t S, int32_t C, FmPair pr) {
     __shared__ int32_t cg[kChunkMax + 1];
     __shared__ int32_t wsum[kChunkThreads / 64];
-    if (*ok == 0 || (gate != nullptr && *gate != 2)) return;               // (an invalid batch's tables are never read)
+    const dn_internal::FoldMultiDir& a = pr.d[blockIdx.x];
+    if (*a.dev_ok == 0 || (a.gate != nullptr && *a.gate != 2)) return;    // (an invalid batch's tables are never read)
+    const int32_t* __restrict__ sptr = a.seg_ptr;
+    const int32_t* __restrict__ snodes = a.seg_nodes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c <= C; c += kChunkThreads)
         cg[c] = c == C ? S : dn_fold_first_graph_from((int32_t)(((int64_t)c * N + C - 1) / C), N, S, sptr, snodes);
@@ -452,16 +456,15 @@ __global__ __launch_bounds__(kChunkThreads) void fold_multi_chunks_kernel(int32_
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = tid * K + k;
-        if (c <= C) { chunk_tile[c] = run; chunk_graph[c] = cg[c]; }
+        if (c <= C) { a.chunk_tile[c] = run; a.chunk_graph[c] = cg[c]; }
         run += nt[k];
     }
 }
-__global__ void fold_multi_tiles_kernel(int32_t N, int32_t S, int32_t C, const int32_t* __restrict__ sptr, const int32_t* __restrict__ snodes,
-                                        const int32_t* __restrict__ chunk_tile, const int32_t* __restrict__ chunk_graph,
-                                        int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info, const int32_t* __restrict__ ok,
-                                        const int32_t* __restrict__ gate) {
-    if (*ok == 0 || (gate != nullptr && *gate != 2)) return;
-    dn_fold_multi_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, C, sptr, snodes, chunk_tile, chunk_graph, tile_ptr, info);
+__global__ void fold_multi_tiles_kernel(int32_t N, int32_t S, int32_t C, FmPair pr) {
+    const dn_internal::FoldMultiDir& a = pr.d[blockIdx.y];
+    if (*a.dev_ok == 0 || (a.gate != nullptr && *a.gate != 2)) return;
+    dn_fold_multi_tile_one((int64_t)blockIdx.x * blockDim.x + threadIdx.x, N, S, C, a.seg_ptr, a.seg_nodes, a.chunk_tile, a.chunk_graph,
+                           a.tile_ptr, a.fold_info);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernel
@@ -1048,18 +1051,17 @@ int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_
     return DN_OK;
 }
 
-int fold_multi_queue(int64_t N, int64_t S, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx, int32_t num_chunks,
-                     int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info, int64_t tile_capacity, int32_t* dev_ok,
-                     const int32_t* gate, bool with_valid, hipStream_t st) {
+int fold_multi_queue(int64_t N, int64_t S, int nd, const FoldMultiDir* dirs, int32_t num_chunks, int64_t tile_capacity, bool with_valid,
+                     hipStream_t st) {
     DN_REQUIRE(num_chunks >= 1 && num_chunks < kChunkMax, "dn_fold_graph_tiles_multi_build: 1 .. %d chunks", kChunkMax - 1);
-    DN_REQUIRE(tile_capacity >= N / 32 + num_chunks + 1, "dn_fold_graph_tiles_multi_build: tile tables too small");
+    DN_REQUIRE(tile_capacity >= N / 32 + num_chunks + 1 && (nd == 1 || nd == 2), "dn_fold_graph_tiles_multi_build: tile tables too small");
+    FmPair pr;
+    for (int k = 0; k < 2; ++k) pr.d[k] = dirs[k < nd ? k : 0];
     if (with_valid)
-        hipLaunchKernelGGL(fold_multi_valid_kernel, dim3((unsigned)dn_cdiv(S, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S, seg_ptr,
-                           seg_nodes, add_idx, dev_ok, gate);
-    hipLaunchKernelGGL(fold_multi_chunks_kernel, dim3(1), dim3(kChunkThreads), 0, st, (int32_t)N, (int32_t)S, num_chunks, seg_ptr, seg_nodes,
-                       chunk_tile, chunk_graph, dev_ok, gate);
-    hipLaunchKernelGGL(fold_multi_tiles_kernel, dim3((unsigned)dn_cdiv(tile_capacity + 1, 256)), dim3(256), 0, st, (int32_t)N, (int32_t)S,
-                       num_chunks, seg_ptr, seg_nodes, chunk_tile, chunk_graph, tile_ptr, fold_info, dev_ok, gate);
+        hipLaunchKernelGGL(fold_multi_valid_kernel, dim3((unsigned)dn_cdiv(S, 256), (unsigned)nd), dim3(256), 0, st, (int32_t)N, (int32_t)S, pr);
+    hipLaunchKernelGGL(fold_multi_chunks_kernel, dim3((unsigned)nd), dim3(kChunkThreads), 0, st, (int32_t)N, (int32_t)S, num_chunks, pr);
+    hipLaunchKernelGGL(fold_multi_tiles_kernel, dim3((unsigned)dn_cdiv(tile_capacity + 1, 256), (unsigned)nd), dim3(256), 0, st, (int32_t)N,
+                       (int32_t)S, num_chunks, pr);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }
@@ -1081,8 +1083,8 @@ int dn_fold_graph_tiles_multi_build_i32(int64_t N, int64_t num_segments, const i
     DN_REQUIRE(seg_ptr && seg_nodes && chunk_tile && chunk_graph && tile_ptr && fold_info, "dn_fold_graph_tiles_multi_build: NULL pointer");
     DN_REQUIRE(reinterpret_cast<uintptr_t>(fold_info) % 16 == 0, "dn_fold_graph_tiles_multi_build: unaligned pointer");
     DN_CHECK_HIP(hipMemsetAsync(dev_ok, 0x01, sizeof(int32_t), st));             // any non-zero value: "still valid"
-    return dn_internal::fold_multi_queue(N, num_segments, seg_ptr, seg_nodes, add_idx, num_chunks, chunk_tile, chunk_graph, tile_ptr,
-                                         fold_info, tile_capacity, dev_ok, nullptr, true, st);
+    const dn_internal::FoldMultiDir d{seg_ptr, seg_nodes, add_idx, chunk_tile, chunk_graph, tile_ptr, fold_info, dev_ok, nullptr};
+    return dn_internal::fold_multi_queue(N, num_segments, 1, &d, num_chunks, tile_capacity, true, st);
 }
 
 int64_t dn_close_units_capacity(int64_t num_tiles, int64_t num_list_entries, int32_t num_wg) {

@@ -84,11 +84,10 @@ int dn_conv_index_build_i32(int64_t G, int64_t N, int64_t R, int64_t E, const in
     // test, the aux lists are the segments, the verdict words double as the builders' "valid" words
     if (chunked) {
         int32_t* verdict = meta + 5 + 2 * R + 2;
-        rc = dn_internal::fold_multi_queue(N, G, aux_f_ptr, aux_f_idx, nullptr, chunks_per_wg * num_wg, chunk_tile_f, chunk_graph_f, tile_ptr_mf,
-                                           fold_info_mf, tile_capacity, verdict, plan + 3, false, st);
-        if (rc != DN_OK) return rc;
-        rc = dn_internal::fold_multi_queue(N, G, aux_b_ptr, aux_b_idx, nullptr, chunks_per_wg * num_wg, chunk_tile_b, chunk_graph_b, tile_ptr_mb,
-                                           fold_info_mb, tile_capacity, verdict + 1, plan + 7, false, st);
+        const dn_internal::FoldMultiDir fm[2] = {
+            {aux_f_ptr, aux_f_idx, nullptr, chunk_tile_f, chunk_graph_f, tile_ptr_mf, fold_info_mf, verdict, plan + 3},
+            {aux_b_ptr, aux_b_idx, nullptr, chunk_tile_b, chunk_graph_b, tile_ptr_mb, fold_info_mb, verdict + 1, plan + 7}};
+        rc = dn_internal::fold_multi_queue(N, G, 2, fm, chunks_per_wg * num_wg, tile_capacity, false, st);
         if (rc != DN_OK) return rc;
     }
     // the unit streams of both directions in one set of launches, AGG units appended; edge rows / dropped range / go from the device:

@@ -85,9 +85,62 @@ __device__ __forceinline__ bool coop_any(bool v) {
     if constexpr (NW == 1) return __any(v) != 0;
     else return __syncthreads_or(v ? 1 : 0) != 0;
 }
-// ascending bitonic sort of A[0 .. n), n a power of two >= 64 (the caller pads with 0xffffffff)
+// One wavefront, NE keys per lane (key index = 64 r + lane): the bitonic network without LDS traffic -- partners 64 or more apart are
+// two registers of the same lane, closer ones are exchanged lane to lane (ds_bpermute).  The LDS form below took ~300 cycles per stage
+// (read -> compare -> write, one dependent round trip each); this one is bound by the exchange's latency across NE independent keys.
+template <int NE>
+__device__ __forceinline__ void wave_sort_regs(u32 (&v)[NE], int lane) {
+#pragma unroll 1
+    for (int k = 2; k <= NE * 64; k <<= 1) {
+#pragma unroll
+        for (int rj = NE / 2; rj >= 1; rj >>= 1) {
+            if (rj * 64 < k) {                                             // stage j = 64 rj of this k (k >= 128: the direction is r's)
+#pragma unroll
+                for (int r = 0; r < NE; ++r)
+                    if ((r & rj) == 0) {
+                        const bool up = ((r * 64) & k) == 0;
+                        const u32 a = v[r], b = v[r | rj];
+                        const u32 lo = a < b ? a : b, hi = a < b ? b : a;
+                        v[r] = up ? lo : hi;
+                        v[r | rj] = up ? hi : lo;
+                    }
+            }
+        }
+#pragma unroll 1
+        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
+            const bool lower = (lane & j) == 0;
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                const u32 o = (u32)__shfl_xor((int)v[r], j, 64);
+                const bool up = (((r * 64) | lane) & k) == 0;
+                const u32 mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+                v[r] = (lower == up) ? mn : mx;
+            }
+        }
+    }
+}
+template <int NE>
+__device__ __forceinline__ void wave_sort_lds(u32* A, int lane) {
+    u32 v[NE];
+#pragma unroll
+    for (int r = 0; r < NE; ++r) v[r] = A[r * 64 + lane];
+    wave_sort_regs<NE>(v, lane);
+#pragma unroll
+    for (int r = 0; r < NE; ++r) A[r * 64 + lane] = v[r];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ascending bitonic sort of A[0 .. n), n a power of two >= 64 (the caller pads with 0xffffffff); one wavefront: n <= 1024
 template <int NW>
 __device__ __forceinline__ void bitonic_sort(u32* A, int n, int tid) {
+    if constexpr (NW == 1) {
+        if (n <= 64) wave_sort_lds<1>(A, tid);
+        else if (n == 128) wave_sort_lds<2>(A, tid);
+        else if (n == 256) wave_sort_lds<4>(A, tid);
+        else if (n == 512) wave_sort_lds<8>(A, tid);
+        else wave_sort_lds<16>(A, tid);
+        return;
+    }
     constexpr int NT = 64 * NW;
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {

@@ -43,12 +43,17 @@ struct CloseUnitsDir {                 // one direction's arguments of dn_close_
     int32_t chunks_per_wg = 0;                                     //   chunk [K num_wg + 1]; num_tiles is then a BOUND (chunk_tile[K num_wg] exist)
     const int32_t* tile_ptr_alt = nullptr;                         // close_units_queue's alternative form: the chunked tables' tile_ptr
 };
-// (dn_fold_graph_tiles_multi_build_i32 without its argument checks; gate != NULL: a device word that must be 2 -- ril_plan's "chunked
-//  tiles" -- for the launches to do anything: dn_conv_index_build_i32 queues them before it knows whether the batch wants them;
-//  with_valid = false: the validity launch is left out, the caller's dev_ok word already holds the verdict)
-int fold_multi_queue(int64_t N, int64_t num_segments, const int32_t* seg_ptr, const int32_t* seg_nodes, const int32_t* add_idx,
-                     int32_t num_chunks, int32_t* chunk_tile, int32_t* chunk_graph, int32_t* tile_ptr, int32_t* fold_info,
-                     int64_t tile_capacity, int32_t* dev_ok, const int32_t* gate, bool with_valid, hipStream_t st);
+// (dn_fold_graph_tiles_multi_build_i32 without its argument checks, for one or both directions of a batch in ONE set of launches;
+//  gate != NULL: a device word that must be 2 -- ril_plan's "chunked tiles" -- for the launches to do anything:
+//  dn_conv_index_build_i32 queues them before it knows whether the batch wants them; with_valid = false: the validity launch is left
+//  out, dev_ok already holds the verdict)
+struct FoldMultiDir {
+    const int32_t *seg_ptr, *seg_nodes, *add_idx;
+    int32_t *chunk_tile, *chunk_graph, *tile_ptr, *fold_info, *dev_ok;
+    const int32_t* gate;
+};
+int fold_multi_queue(int64_t N, int64_t num_segments, int nd, const FoldMultiDir* dirs, int32_t num_chunks, int64_t tile_capacity,
+                     bool with_valid, hipStream_t st);
 int close_units_queue(int64_t N, int32_t num_wg, int64_t num_tiles, int32_t agg_units, int32_t xcd_order, int64_t num_list_entries,
                       int64_t unit_capacity, int nd, const CloseUnitsDir* dirs, void* workspace, size_t workspace_bytes, hipStream_t st,
                       int32_t alt_order, int64_t alt_num_tiles);

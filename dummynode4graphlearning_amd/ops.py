@@ -1309,8 +1309,20 @@ class RowIndex:
                 nbytes = lib().dn_conv_index_workspace_bytes(G, N, R, E, num_wg, tcap)
             if one_call and nbytes:
                 cap = int(lib().dn_close_units_capacity(max(G, tcap), E + N, num_wg))
-                mt = [(e32(kper * num_wg + 1), e32(kper * num_wg + 1), e32(tcap + 1), torch.empty((max(tcap, 1), 12), dtype=I32, device=dev))
-                      if kper else (None, None, None, None) for _ in range(2)]
+                # the chunked form's eight tables out of ONE allocation (most batches never look at them: views are made on demand)
+                mt_sizes = (kper * num_wg + 1, kper * num_wg + 1, tcap + 1, 12 * max(tcap, 1))
+                mt_off, acc = [], 0
+                for _ in range(2):
+                    for n_ in mt_sizes:
+                        mt_off.append(acc)
+                        acc += (n_ + 3) // 4 * 4                        # (16-byte aligned pieces)
+                mt_arena = e32(acc) if kper else None
+                mt_ptr = [ctypes.c_void_p(mt_arena.data_ptr() + 4 * o) if kper else None for o in mt_off]
+
+                def mt_views(k):
+                    o = mt_off[4 * k:4 * k + 4]
+                    return (mt_arena[o[0]:o[0] + mt_sizes[0]], mt_arena[o[1]:o[1] + mt_sizes[1]], mt_arena[o[2]:o[2] + mt_sizes[2]],
+                            mt_arena[o[3]:o[3] + mt_sizes[3]].view(max(tcap, 1), 12))
                 cus = []
                 for _ in range(2):
                     cu = CloseUnits()
@@ -1333,8 +1345,7 @@ class RowIndex:
                     ptr(src_ptr), ptr(src_rows), counts, host_rel, host_modes, ctypes.byref(status), ptr(rel_dev), ptr(gt_bufs[0][0]),
                     ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cus[0].order, cap, ptr(cus[0].unit_ptr),
                     ptr(cus[0].units), ptr(cus[0].ent_row), ptr(cus[0].ent_mask), ptr(cus[1].unit_ptr), ptr(cus[1].units),
-                    ptr(cus[1].ent_row), ptr(cus[1].ent_mask), kper, tcap, ptr(mt[0][0]), ptr(mt[0][1]), ptr(mt[0][2]), ptr(mt[0][3]),
-                    ptr(mt[1][0]), ptr(mt[1][1]), ptr(mt[1][2]), ptr(mt[1][3]), SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
+                    ptr(cus[1].ent_row), ptr(cus[1].ent_mask), kper, tcap, *mt_ptr, SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
                     WGRAD_CHUNK_ROWS, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),
                     "dn_conv_index_build_i32")
                 if status.value == 0:
@@ -1343,7 +1354,7 @@ class RowIndex:
                     # (the sweep tables were sized by a bound; the builder laid them out with the slots they need)
                     sw = [(sweeps[k][:Gw * host_plan[4 + k]], Gw * int(host_plan[4 + k])) if want_sweep and host_plan[4 + k] > 0 else None
                           for k in range(2)]
-                    pre = (cus, sw, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]), mt, tcap)
+                    pre = (cus, sw, (chunk_tab, chunk_pp, int(host_plan[3])), int(host_plan[0]), int(host_plan[1]), mt_views, tcap)
             elif nbytes:
                 ws = _ws(nbytes, dev)
                 status = ctypes.c_int32(0)
@@ -1404,7 +1415,7 @@ class RowIndex:
                 for k, d in enumerate(("f", "b")):
                     info = _make_fold_info(self, d, cands[d])
                     if pre[3 + k] == 2:                              # a graph over 32 nodes: the call left the chunked form behind
-                        ct, cg, tpm, fim = pre[5][k]
+                        ct, cg, tpm, fim = pre[5](k)
                         info.graph_tiles = (tpm, fim)
                         info.multi = (ct, cg, pre[6], G)
                         pre[0][k].order, pre[0][k].num_tiles = 2 + _close_order(pre[0][k].num_wg), pre[6]
