@@ -59,6 +59,9 @@ _SIGS = {
     "dn_row_index_build_local_i32": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, P, P, P, P, P, c_i32, c_f32] + [P] * 10 +
                                      [ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32), P, P, P, P, P, ctypes.POINTER(c_i32), P, c_sz, P]),
+    "dn_conv_graphs_max_nodes": (c_i32, []),
+    "dn_conv_graphs_max_edges": (c_i32, []),
+    "dn_conv_graphs_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, c_i32, P, P, P, P, P, c_i64, c_i64, P, P, P, P, P, P]),
     "dn_conv_index_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i32, c_i64]),
     "dn_conv_index_build_i32": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, P, P, P, P, P, c_i32, c_f32] + [P] * 10 +
                                 [ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),

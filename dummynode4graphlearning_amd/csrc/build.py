@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["dn_runtime.hip", "dn_segment.hip", "dn_index.hip", "dn_index_local.hip", "dn_conv_index.hip", "dn_graphsum.hip", "dn_rel.hip", "dn_rel_ring.hip", "dn_close.hip", "dn_chain2.hip", "dn_weights.hip", "dn_rel_f32.hip", "dn_gemm.hip", "dn_norm.hip"]
+SOURCES = ["dn_runtime.hip", "dn_segment.hip", "dn_index.hip", "dn_index_local.hip", "dn_conv_index.hip", "dn_graphsum.hip", "dn_rel.hip", "dn_rel_ring.hip", "dn_close.hip", "dn_conv_graph.hip", "dn_chain2.hip", "dn_weights.hip", "dn_rel_f32.hip", "dn_gemm.hip", "dn_norm.hip"]
 HEADERS = ["dn_common.h", "dn_internal.h", os.path.join(ROOT, "include", "dn_hip.h")]
 LIB = os.path.join(PKG, "libdn_hip.so")
 OBJDIR = os.path.join(HERE, "_obj")

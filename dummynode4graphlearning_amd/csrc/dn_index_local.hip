@@ -386,12 +386,15 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         (node_ptr[0] != 0 || edge_ptr[0] != 0 || node_ptr[G] != N || edge_ptr[G] != E))
         atomicOr(bad, 1);
     __syncthreads();
+    int max_n = 0, max_m = 0;                                            // the largest graph this wavefront has seen
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
         const int cls = graph_class(g, node_ptr, edge_ptr, N, E);
         if (cls == 0) {
             if (lane == 0) atomicOr(bad, 1);
             continue;
         }
+        max_n = max(max_n, node_ptr[g + 1] - node_ptr[g]);
+        max_m = max(max_m, edge_ptr[g + 1] - edge_ptr[g]);
         if (cls == 2) {                                                    // over this wavefront's slice: listed for ril_stats_big_kernel
             if (lane == 0) big_list[1 + atomicAdd(big_list, 1)] = (int32_t)g;
             continue;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         u32* A = reinterpret_cast<u32*>(X);
         stats_sorted<1, 10, 14>(A, A + kLocM, lane, node_ptr[g], node_ptr[g + 1], edge_ptr[g], m, R, src, dst, etype, cnt, hbits, bad);
     }
+    if (lane == 0 && max_n > 0) { atomicMax(bad + 1, max_n); atomicMax(bad + 2, max_m); }     // (bad[1], bad[2]: zeroed with bad)
     __syncthreads();
     if (threadIdx.x < 3 * kLocR) {
         const int k = threadIdx.x / kLocR, r = threadIdx.x % kLocR;
@@ -894,6 +898,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
         if (threadIdx.x == 0) {                                           // (+ the two fold verdicts: "still valid"; the verdict launch's ticket)
             meta[5 + 2 * R + 1] = *bad; meta[5 + 2 * R + 2] = 3; meta[5 + 2 * R + 3] = 3;    // (bit 0: graphs as tiles, bit 1: chunked tiles)
             meta[5 + 2 * R + 4 + dn_internal::kRilPlanWords] = 0;
+            meta[5 + 2 * R + 4 + 12] = bad[1]; meta[5 + 2 * R + 4 + 13] = bad[2];   // the largest graph: nodes, edges
         }
     }
     for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
@@ -1173,7 +1178,10 @@ int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_pt
 
 void ril_unpack(const int32_t* h_meta, int64_t R, int64_t* host_counts, int32_t* host_rel_ptr, int32_t* host_modes,
                 int32_t* host_status, int32_t* host_absorb) {
-    if (host_absorb) { host_absorb[0] = h_meta[5 + 2 * R + 2]; host_absorb[1] = h_meta[5 + 2 * R + 3]; }
+    if (host_absorb) {
+        host_absorb[0] = h_meta[5 + 2 * R + 2]; host_absorb[1] = h_meta[5 + 2 * R + 3];
+        host_absorb[2] = h_meta[5 + 2 * R + 4 + 12]; host_absorb[3] = h_meta[5 + 2 * R + 4 + 13];
+    }
     *host_status = h_meta[5 + 2 * R + 1];
     for (int k = 0; k < 5; ++k) host_counts[k] = h_meta[k];
     for (int64_t r = 0; r <= R; ++r) host_rel_ptr[r] = h_meta[5 + r];
@@ -1209,8 +1217,8 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                           fold_info_f, tile_ptr_b, fold_info_b, host_absorb != nullptr, false, workspace, workspace_bytes,
                                           &meta, st);
     if (rc != DN_OK) return rc;
-    int32_t h_meta[5 + 2 * kLocR + 4];
-    DN_CHECK_HIP(hipMemcpyAsync(h_meta, meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 4), hipMemcpyDeviceToHost, st));
+    int32_t h_meta[5 + 2 * kLocR + 4 + dn_internal::kRilPlanWords];
+    DN_CHECK_HIP(hipMemcpyAsync(h_meta, meta, sizeof(int32_t) * (size_t)(5 + 2 * R + 4 + dn_internal::kRilPlanWords), hipMemcpyDeviceToHost, st));
     DN_CHECK_HIP(hipStreamSynchronize(st));
     dn_internal::ril_unpack(h_meta, R, host_counts, host_rel_ptr, host_modes, host_status, host_absorb);
     return DN_OK;

@@ -20,7 +20,8 @@ int launch_chain2_ring256(const void* X, const void* W1n, const void* b1, const 
                           float slope, hipStream_t st);
 
 // ---- the per-batch index as ONE call (dn_conv_index.hip: dn_conv_index_build_i32) -- the builders' launches without their host sides
-constexpr int kRilPlanWords = 12;      // ril_plan_kernel's words behind the 5 + 2 R + 4 meta words of the graph-local row index
+constexpr int kRilPlanWords = 14;      // ril_plan's 12 words behind the 5 + 2 R + 4 meta words of the graph-local row index, then the
+                                       // largest graph's nodes and edges (ril_fill_kernel)
 
 // dn_index_local.hip
 int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* src,

@@ -1285,6 +1285,8 @@ class RowIndex:
         host_rel = (ctypes.c_int32 * (R + 1))()
         host_modes = (ctypes.c_int32 * R)()
         self.built_by = "general"
+        self.max_graph = None                                         # local builder: (nodes, edges) of the batch's largest graph
+        self.raw = None                                               # ... and (src, dst, etype, node_ptr, edge_ptr) int32
         self._absorb = None                                           # local builder: {direction: (tile_ptr, fold_info, verdict)}
         rel_dev = None
         pre = None                                                    # (tables dn_conv_index_build_i32 left behind, see below)
@@ -1295,7 +1297,7 @@ class RowIndex:
             G = int(node_ptr.numel()) - 1
             # the absorbed-fold verdicts + graph tiles of both directions come out of the same call (and the same read-back)
             gt_bufs = [(e32(G + 1), torch.empty((max(G, 1), 12), dtype=I32, device=dev)) for _ in range(2)]
-            host_absorb = (ctypes.c_int32 * 2)()
+            host_absorb = (ctypes.c_int32 * 4)()                       # fold verdicts f / b, the largest graph's nodes / edges
             assert G >= 0 and int(edge_ptr.numel()) == G + 1
             one_call = (CONV_INDEX_ENABLED and CLOSE_SINGLE_ENABLED and closing_hint is not None and closing_hint[0] == 256
                         and closing_hint[1] == torch.bfloat16 and self_loop and G >= 1 and N >= 1 and CLOSE_RING_ENABLED
@@ -1351,6 +1353,7 @@ class RowIndex:
                 if status.value == 0:
                     self.built_by = "local"
                     self._absorb = {d: (gt_bufs[k][0], gt_bufs[k][1], int(host_absorb[k])) for k, d in enumerate(("f", "b"))}
+                    self.max_graph = (int(host_absorb[2]), int(host_absorb[3]))
                     # (the sweep tables were sized by a bound; the builder laid them out with the slots they need)
                     sw = [(sweeps[k][:Gw * host_plan[4 + k]], Gw * int(host_plan[4 + k])) if want_sweep and host_plan[4 + k] > 0 else None
                           for k in range(2)]
@@ -1369,6 +1372,9 @@ class RowIndex:
                 if status.value == 0:
                     self.built_by = "local"
                     self._absorb = {d: (gt_bufs[k][0], gt_bufs[k][1], int(host_absorb[k])) for k, d in enumerate(("f", "b"))}
+                    self.max_graph = (int(host_absorb[2]), int(host_absorb[3]))
+            if self.built_by == "local":                              # the batch itself, for the launches that take graphs whole
+                self.raw = (src, dst, etype, node_ptr, edge_ptr)
             if self.built_by != "local":
                 _check_edge_types(etype, R)
         if self.built_by == "general":
@@ -1816,6 +1822,50 @@ def _message_pass_folded(xs, pw, bias, ix, direction, ybuf, out, idx_rows):
     return fold_tail(part, fold.part_ptr, fold.n, pw.rel[fold.rel], fold.add_idx, out, w_kn=pw.kn)
 
 
+# DN_CONV_GRAPHS=0: H = 64 bf16 batches of small graphs keep the row-factorised launches (transform, closing launch, fold tail)
+CONV_GRAPHS_ENABLED = _os.environ.get("DN_CONV_GRAPHS", "1") != "0"
+
+
+def conv_graphs_ok(xs, pw, ix):
+    """Can dn_conv_graphs_bf16 take this pass?  bf16 rows of width 64, square weights with a self loop, a batch the graph-local
+    index builder has seen (it reports the largest graph), every graph within 64 nodes / 1024 edges, at most 16 relations."""
+    if not (CONV_GRAPHS_ENABLED and xs.dtype == torch.bfloat16 and xs.shape[1] == 64 and pw.loop is not None and ix.self_loop
+            and ix.raw is not None and ix.max_graph is not None and ix.num_rels <= 16 and tuple(pw.rel.shape[1:]) == (64, 64)):
+        return False
+    return 0 < ix.max_graph[0] <= 64 and ix.max_graph[1] <= 1024
+
+
+def conv_graphs(xs, pw, bias, ix, direction, out):
+    """One direction of the conv over ix's batch as ONE launch (dn_conv_graphs_bf16, one workgroup per graph, every relation edge
+    by edge).  Returns the pre-aggregated rows the weight gradient's collapsed relation takes (per-graph column sums of xs, written
+    by the same launch where the direction's aux lists are the graphs' segments; else one gather launch)."""
+    src, dst, etype, node_ptr, edge_ptr = ix.raw
+    key_in, key_out = (src, dst) if direction == "f" else (dst, src)
+    aux_idx, aux_ptr, n_aux = (ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if direction == "f" else (ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)
+    G, N, H = int(node_ptr.numel()) - 1, ix.num_nodes, 64
+    require_gpu(xs, pw.rel, pw.loop, bias, out)
+    assert xs.is_contiguous() and out.is_contiguous() and out.shape == xs.shape and pw.rel.is_contiguous() and pw.loop.is_contiguous()
+    if getattr(ix, "_cg_err", None) is None:
+        ix._cg_err = torch.zeros(1, dtype=I32, device=xs.device)
+    cand = _fold_candidate(ix, direction) if n_aux else None
+    inside = (cand is not None and cand[3] == G and n_aux == G and ix._absorb is not None and ix._absorb[direction][2] != 0)
+    aux = torch.empty((n_aux, H), dtype=xs.dtype, device=xs.device) if inside else None
+    sp = aux_ptr[:n_aux + 1].contiguous() if inside else None
+
+    def _launch():
+        check(lib().dn_conv_graphs_bf16(ptr(xs), H, ptr(pw.rel), 1 if pw.kn else 0, ptr(pw.loop), ptr(bias), ix.num_rels, ptr(node_ptr),
+                                        ptr(edge_ptr), ptr(key_in), ptr(key_out), ptr(etype), G, N, ptr(out), ptr(sp),
+                                        ptr(aux_idx) if inside else None, ptr(aux), ptr(ix._cg_err), stream_ptr()),
+              "dn_conv_graphs_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("conv_graphs", _launch)
+    else:
+        _launch()
+    if n_aux and not inside:
+        aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux)
+    return aux
+
+
 def message_pass(xs, pw, bias, ix, direction, ybuf, out):
     """One direction of the row-factorised pass over one RowIndex -- the launches that ARE the layer's gather-scatter:
          'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          pw = the weights (PassWeights), [k][n] or W^T
@@ -1828,6 +1878,8 @@ def message_pass(xs, pw, bias, ix, direction, ybuf, out):
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
+    if conv_graphs_ok(xs, pw, ix):
+        return conv_graphs(xs, pw, bias, ix, direction, out)
     f32_direct = xs.dtype == torch.float32 and _kn_ok(xs) and pw.rel.shape[1] == pw.rel.shape[2]
     if pw.kn and not (f32_direct or (_kn_ok(xs) and _selfsum_ok(ix, xs))):
         pw = pw.nk()

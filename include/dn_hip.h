@@ -259,7 +259,8 @@ int dn_row_index_build_i32(int64_t N, int64_t R, int64_t E, const int32_t* src, 
  * -- exactly one collapsed relation in the direction (mode AGG forward / TF backward) owning all the direction's aux lists, with
  * a self loop, and its segments passing dn_fold_graph_tiles_build_i32's test with the relation's own rows as targets -- and
  * leaves that call's tile_ptr / fold_info behind (host_absorb[d] bit 0); bit 1 (round 6): the segments pass the test WITHOUT the
- * 32-node limit (dn_fold_graph_tiles_multi_build_i32 would say yes); the verdicts ride in the builder's ONE read-back.
+ * 32-node limit (dn_fold_graph_tiles_multi_build_i32 would say yes); host_absorb[2] / [3] = the nodes / edges of the batch's
+ * largest graph (what dn_conv_graphs_bf16 asks before it takes a batch); host_absorb: int32 [4]; all ride in the builder's ONE read-back.
  * Synchronises the stream (one read-back). */
 size_t dn_row_index_local_workspace_bytes(int64_t G, int64_t N, int64_t R, int64_t E);
 int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_ptr,
@@ -271,6 +272,27 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
                                  int32_t* tile_ptr_f, int32_t* fold_info_f, int32_t* tile_ptr_b, int32_t* fold_info_b,
                                  int32_t* host_absorb,
                                  void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
+/* One launch per direction of a relational conv on a batch of SMALL graphs at the reference's default width (round 6; H = 64
+ * bf16, the CLI default `--hid_dim` of subgraph_isomorphism/config.py:456-461, BASELINE config 3):
+ *   out[v, :] = sum_{e: key_out[e] = v} X[key_in[e], :] @ W[etype[e]] + X[v, :] @ W_loop (+ bias)
+ * = message UDF + fn.sum + self loop of rgin.py:102-160 / rgcn.py:160-196 with (key_in, key_out) = (src, dst); the input gradient
+ * with (dst, src) and w_kn = 0.  W [num_rels][H][H] and W_loop [H][H]: w_kn = 1: stored [k][n] (the parameters `weight` /
+ * `loop_weight` as they are: out = x @ W); w_kn = 0: the same memory read as [n][k] (out = x @ W^T: the input-gradient pass on the
+ * untransposed parameters).  One workgroup takes one graph straight from the batch's raw arrays (node_ptr / edge_ptr [num_graphs + 1],
+ * key_in / key_out / etype [E], global node ids, every edge inside its graph's node range): no row index, no intermediate rows in
+ * HBM; every relation is taken edge by edge.  Limits: every graph within dn_conv_graphs_max_nodes() = 64 nodes and
+ * dn_conv_graphs_max_edges() = 1024 edges (ask dn_row_index_build_local_i32's host_absorb[2..3]), num_rels <= 16; a graph outside
+ * them, or an edge outside its graph / relation range, sets *dev_err (device int32, OR-ed; its rows are left unwritten).
+ * aux (may be NULL): [num_graphs][H], aux[j] = bf16 column sum of the INPUT rows of segment j = nodes seg_nodes[seg_ptr[j] ..
+ * seg_ptr[j+1]) (a contiguous run inside graph j: the pre-aggregated operand dn_rows_wgrad_bf16 takes for a collapsed relation).
+ * fp32 accumulation in a fixed order (bitwise repeatable), every per-edge product rounded to bf16 once, the output row once. */
+int32_t dn_conv_graphs_max_nodes(void);
+int32_t dn_conv_graphs_max_edges(void);
+int dn_conv_graphs_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* W_loop, const void* bias, int32_t num_rels,
+                        const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* key_in, const int32_t* key_out,
+                        const int32_t* etype, int64_t num_graphs, int64_t N, void* out, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                        void* aux, int32_t* dev_err, dn_stream_t stream);
 
 /* The per-batch index of the H = 256 bf16 conv path as ONE call on one arena (round 5) -- what dgl.batch + update_all pay per step
  * in the reference (subgraph_isomorphism/dataset.py:1605-1611; models/rgin.py:156-160): dn_row_index_build_local_i32 (same

@@ -147,7 +147,7 @@ def test_conv_index_entry_point_checks_its_arguments(lib):
     G, N, R, E, wg = 4, 40, 6, 100, 256
     cap = L.dn_close_units_capacity(G, E + N, wg)
     counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * (R + 1))(), (ctypes.c_int32 * R)(), ctypes.c_int32(0)
-    absorb, plan = (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 6)()
+    absorb, plan = (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 6)()
     P256 = ctypes.c_void_p(256)
 
     def call(G=G, host=counts, units=P256, cap=cap, sweep_s=8, sweep=P256, wgrad_rows=4096, kper=0, tcap=0, mt=None):

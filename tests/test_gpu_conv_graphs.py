@@ -1,0 +1,143 @@
+"""dn_conv_graphs_bf16 (csrc/dn_conv_graph.hip): one launch per direction of the relational conv on batches of small graphs at the
+reference's default width H = 64 (subgraph_isomorphism/config.py:456-461; BASELINE config 3) -- against fp64 math on the same bf16
+operands, against the row-factorised launches it replaces, and bitwise against itself."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(rng, G, R, nmax, dens, dummy=True, empty=False):
+    """graphs of 1 .. nmax real nodes (+ the SI dummy node with relations R-2 / R-1), multi-edges and self loops included"""
+    src, dst, et, nptr, eptr = [], [], [], [0], [0]
+    for g in range(G):
+        n = int(rng.integers(0 if empty else 1, nmax + 1))
+        base = nptr[-1]
+        m = int(rng.integers(0, max(1, int(dens * n)) + 1)) if n else 0
+        if m:
+            src += list(base + rng.integers(0, n, size=m)); dst += list(base + rng.integers(0, n, size=m))
+            et += list(rng.integers(0, max(1, R - 2), size=m))
+        if dummy and n:
+            src += list(base + np.arange(n)) + [base + n] * n
+            dst += [base + n] * n + list(base + np.arange(n))
+            et += [R - 2] * n + [R - 1] * n
+            n += 1
+        nptr.append(base + n); eptr.append(len(src))
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), device=DEV)  # noqa: E731
+    return t(src), t(dst), t(et), nptr, eptr
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("R,nmax,dens,G", [(8, 49, 2.1, 64), (16, 63, 3.0, 40), (3, 20, 6.0, 300), (5, 63, 12.0, 7), (1, 5, 1.0, 1)])
+def test_conv_graphs_matches_fp64_in_both_directions(R, nmax, dens, G):
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(R * 100 + G)
+    src, dst, et, nptr, eptr = _batch(rng, G, R, nmax, dens, dummy=R >= 3, empty=G > 100)
+    N, H = nptr[-1], 64
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)  # noqa: E731
+    ix = ops.RowIndex(src, dst, et, N, R, self_loop=True, node_ptr=i32(nptr), edge_ptr=i32(eptr))
+    assert ix.built_by == "local" and ix.max_graph == (max(np.diff(nptr)), max(np.diff(eptr)))
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    W = (torch.randn(R, H, H, device=DEV, generator=gen) / 8).to(torch.bfloat16)
+    Wl = (torch.randn(H, H, device=DEV, generator=gen) / 8).to(torch.bfloat16)
+    b = torch.randn(H, device=DEV, generator=gen).to(torch.bfloat16)
+    for direction, kn, bias in (("f", True, b), ("b", False, None), ("f", False, None)):
+        pw = ops.PassWeights(W, Wl, kn=kn)
+        assert ops.conv_graphs_ok(x, pw, ix)
+        out = torch.full((N, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        aux = ops.conv_graphs(x, pw, bias, ix, direction, out)
+        out2 = torch.empty_like(out)
+        aux2 = ops.conv_graphs(x, pw, bias, ix, direction, out2)
+        assert int(ix._cg_err.item()) == 0
+        assert torch.equal(out, out2) and (aux is None or torch.equal(aux, aux2))         # bitwise run to run
+        a, o = (src, dst) if direction == "f" else (dst, src)
+        Wd = W.double() if kn else W.double().transpose(1, 2)                            # kn False: the same memory read as [n][k]
+        Wld = Wl.double() if kn else Wl.double().t()
+        ref = x.double() @ Wld + (bias.double() if bias is not None else 0.0)
+        if src.numel():
+            msg = torch.bmm(x.double()[a].unsqueeze(1), Wd[et]).squeeze(1)
+            ref.index_add_(0, o, msg)
+        assert _rel_l2(out, ref) < 6e-3, (direction, kn, _rel_l2(out, ref))
+        n_aux = ix.num_aux_f if direction == "f" else ix.num_aux_b
+        if n_aux:
+            ap, ai = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
+            want = ops.gather_segsum(x, ai, ap, n_aux)
+            assert aux is not None and _rel_l2(aux, want) < 4e-3
+
+
+def test_rgin_layer_at_the_default_width_takes_one_launch_per_direction():
+    """RGINLayer(64, 64) bf16 on a config-3-shaped batch: the conv is ONE launch per direction (no transform / closing / tail
+    launches), the step equals the row-factorised launches up to bf16 rounding and fp64 within bf16 noise, bitwise repeatable."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    import oracle.layers as OL
+    raw = synthetic.config3(seed=3, graphs=96)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R, H = int(aug["node_label"].numel()), 8, 64
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    et = aug["edge_label"].long()
+    torch.manual_seed(5)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func="relu").to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+
+    def run(enabled):
+        old = ops.CONV_GRAPHS_ENABLED
+        ops.CONV_GRAPHS_ENABLED = enabled
+        try:
+            g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+            for p in layer.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            timer = ops.KernelTimer()
+            ops.kernel_timer = timer
+            try:
+                out, _ = layer(g, x, et)
+                out.backward(coef)
+            finally:
+                ops.kernel_timer = None
+            return [r[0] for r in timer.records], [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            ops.CONV_GRAPHS_ENABLED = old
+
+    tags, got = run(True)
+    assert tags.count("conv_graphs") == 2 and not any(t in tags for t in ("rows_selfsum", "rows_close", "fold_tail", "rows_transform:conv")), tags
+    tags0, want = run(False)
+    assert "conv_graphs" not in tags0 and len(tags0) >= len(tags) + 4
+    assert _rel_l2(got[0], want[0]) < 1e-2
+    # (gradients pass two ReLU masks: elements within bf16 noise of 0 flip between the two roundings of the conv's sums -- both paths
+    #  sit 5-6 % from fp64 math on this batch, 6.5 % from each other; the conv's own backward is held to 6e-3 in the test above)
+    for a, b in zip(got[1:], want[1:]):
+        assert _rel_l2(a, b) < 0.12
+    _, again = run(True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    ref = OL.rgin_layer(x0.double().cpu(), aug["src"].long().cpu(), aug["dst"].long().cpu(), et.cpu(), p64, regularizer="basis", num_rels=R,
+                        num_bases=-1, num_mlp_layers=2, act="relu")
+    assert _rel_l2(got[0], ref) < 3e-2
+
+
+def test_batches_outside_the_limits_keep_the_row_factorised_launches():
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(9)
+    src, dst, et, nptr, eptr = _batch(rng, 6, 4, 80, 2.0)              # a graph over 64 nodes is likely; force one
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)  # noqa: E731
+    ix = ops.RowIndex(src, dst, et, nptr[-1], 4, self_loop=True, node_ptr=i32(nptr), edge_ptr=i32(eptr))
+    x = torch.zeros(nptr[-1], 64, device=DEV, dtype=torch.bfloat16)
+    pw = ops.PassWeights(torch.zeros(4, 64, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16), kn=True)
+    assert ops.conv_graphs_ok(x, pw, ix) == (max(np.diff(nptr)) <= 64)
+    ixg = ops.RowIndex(src, dst, et, nptr[-1], 4, self_loop=True)        # no graph boundaries: the general builder, no whole-graph launch
+    assert not ops.conv_graphs_ok(x, pw, ixg)
+    assert not ops.conv_graphs_ok(x.float(), pw, ix) and not ops.conv_graphs_ok(torch.zeros(nptr[-1], 128, device=DEV, dtype=torch.bfloat16), pw, ix)

@@ -418,7 +418,7 @@ def test_one_call_index_checks_its_workspace():
                                                                     + 2 * L.dn_close_units_workspace_bytes(5000, wg))
     cap = L.dn_close_units_capacity(G, E + N, wg)
     counts, rel, modes, st = (ctypes.c_int64 * 5)(), (ctypes.c_int32 * (R + 1))(), (ctypes.c_int32 * R)(), ctypes.c_int32(0)
-    absorb, plan = (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 6)()
+    absorb, plan = (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 6)()
     P256 = ctypes.c_void_p(256)
     for ws, nbytes, msg in ((P256, need - 1, b"workspace too small"), (ctypes.c_void_p(16), need, b"unaligned workspace")):
         rc = L.dn_conv_index_build_i32(G, N, R, E, P256, P256, P256, P256, P256, 1, 0.75, *([P256] * 10), counts, rel, modes,
