@@ -17,6 +17,12 @@ LIB_PATH = os.environ.get("DN_HIP_LIB") or os.path.join(_HERE, "libdn_hip.so")
 c_i32, c_i64, c_f32, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 P = ctypes.c_void_p
 
+class WgradJob(ctypes.Structure):
+    """dn_wgrad_job of include/dn_hip.h (one weight gradient of a dn_rows_wgrad_multi_bf16 launch)."""
+    _fields_ = [("A", P), ("A2", P), ("idx_a", P), ("G", P), ("G2", P), ("idx_g", P), ("mask_a_bits", P), ("na1", c_i32), ("ng1", c_i32),
+                ("colsum_of", c_i32), ("first_rel", c_i32), ("row0", c_i32), ("act_slope", c_f32)]
+
+
 # name -> (restype, argtypes); mirrors include/dn_hip.h one to one
 _SIGS = {
     "dn_version": (ctypes.c_int, []),
@@ -59,6 +65,7 @@ _SIGS = {
     "dn_row_index_build_local_i32": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, P, P, P, P, P, c_i32, c_f32] + [P] * 10 +
                                      [ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32), P, P, P, P, P, ctypes.POINTER(c_i32), P, c_sz, P]),
+    "dn_rows_wgrad_multi_bf16": (ctypes.c_int, [ctypes.POINTER(WgradJob), c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P, c_sz, P]),
     "dn_conv_graphs_max_nodes": (c_i32, []),
     "dn_conv_graphs_max_edges": (c_i32, []),
     "dn_conv_graphs_bf16": (ctypes.c_int, [P, c_i32, P, c_i32, P, P, c_i32, P, P, P, P, P, c_i64, c_i64, P, P, P, P, P, P]),

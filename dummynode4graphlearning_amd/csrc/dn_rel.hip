@@ -60,20 +60,14 @@ __device__ __forceinline__ uint32_t positive_bits(const uint4& v) {             
     return bits;
 }
 
-// partial[chunk][k][n] = sum_{p in chunk} A[ia[p]][k] * G[ig[p]][n]
+// partial[chunk][k][n] = sum_{p in chunk} A[ia[p]][k] * G[ig[p]][n]   (the chunk = this workgroup's: ch)
 template <int HI, int HO>
-__global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __restrict__ A,
-                                                                const bf16_t* __restrict__ A2, int32_t na1,
-                                                                const int32_t* __restrict__ ia,
-                                                                const bf16_t* __restrict__ G,
-                                                                const bf16_t* __restrict__ G2, int32_t ng1,
-                                                                const int32_t* __restrict__ ig,
-                                                                const Chunk* __restrict__ chunks,
-                                                                float* __restrict__ partial, int32_t colsum_of,
-                                                                float* __restrict__ colsum_partial,
-                                                                const bf16_t* __restrict__ maskA,
-                                                                bf16_t* __restrict__ A_out,
-                                                                const uint8_t* __restrict__ maskBits, float slope) {
+__device__ __forceinline__ void rows_wgrad_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int32_t na1,
+                                                const int32_t* __restrict__ ia, const bf16_t* __restrict__ G,
+                                                const bf16_t* __restrict__ G2, int32_t ng1, const int32_t* __restrict__ ig,
+                                                const Chunk ch, float* __restrict__ partial, int32_t colsum_of,
+                                                float* __restrict__ colsum_partial, const bf16_t* __restrict__ maskA,
+                                                bf16_t* __restrict__ A_out, const uint8_t* __restrict__ maskBits, float slope) {
     constexpr int SA = HI + kPad, SG = HO + kPad;
     constexpr int MT = HI / 2 / 16, NT = HO / 4 / 16;           // 16x16 tiles per wave
     constexpr int NPA = kTileRows * HI / 8, NPG = kTileRows * HO / 8;   // 16-byte pieces per tile
@@ -84,7 +78,6 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
     auto bufA = [&](int b) -> bf16_t* { return lds + b * (kTileRows * SA); };
     auto bufG = [&](int b) -> bf16_t* { return lds + 2 * kTileRows * SA + b * (kTileRows * SG); };
 
-    const Chunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;                     // wave position in the output tile
     const int k0 = wm * (HI / 2), n0 = wn * (HO / 4);
@@ -204,7 +197,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                 const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
                 out[(size_t)k * HO + c] = acc[m][n][i];
             }
-    if (colsum_of != 0) {
+    if (colsum_of != 0 || (colsum_partial != nullptr && tid < HI)) {   // (a job without column sums in a multi-job launch: zeros)
         // every thread owns column chunk (tid % (H/8)) in all of its pieces: fold the threads of a chunk through LDS
         constexpr int HC = HI;                                  // square: HI == HO
         constexpr int TPC = kWgThreads / (HC / 8);              // threads per column chunk
@@ -224,6 +217,53 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
             colsum_partial[(size_t)blockIdx.x * HC + tid] = sum;
         }
     }
+}
+
+template <int HI, int HO>
+__global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __restrict__ A,
+                                                                const bf16_t* __restrict__ A2, int32_t na1,
+                                                                const int32_t* __restrict__ ia,
+                                                                const bf16_t* __restrict__ G,
+                                                                const bf16_t* __restrict__ G2, int32_t ng1,
+                                                                const int32_t* __restrict__ ig,
+                                                                const Chunk* __restrict__ chunks,
+                                                                float* __restrict__ partial, int32_t colsum_of,
+                                                                float* __restrict__ colsum_partial,
+                                                                const bf16_t* __restrict__ maskA,
+                                                                bf16_t* __restrict__ A_out,
+                                                                const uint8_t* __restrict__ maskBits, float slope) {
+    rows_wgrad_body<HI, HO>(A, A2, na1, ia, G, G2, ng1, ig, chunks[blockIdx.x], partial, colsum_of, colsum_partial, maskA, A_out, maskBits, slope);
+}
+
+// Several weight gradients in ONE launch (round 6: a whole RGIN layer's -- the conv's R + 1 matrices over gathered rows, the two MLP
+// layers' over dense rows -- where every launch is latency: BASELINE config 3).  The jobs' relations are numbered through
+// (first_rel) and their rows laid end to end in one virtual row space (row0), so that ONE chunk table covers them; a workgroup
+// finds its job by its chunk's relation.
+struct WgJob {
+    const bf16_t *A, *A2;
+    const int32_t* ia;
+    const bf16_t *G, *G2;
+    const int32_t* ig;
+    const uint8_t* maskBits;
+    int32_t na1, ng1, colsum_of, first_rel, row0;
+    float slope;
+};
+struct WgJobs {
+    WgJob j[3];
+    int32_t n;
+};
+template <int HI, int HO>
+__global__ __launch_bounds__(kWgThreads) void rows_wgrad_multi_kernel(WgJobs jobs, const Chunk* __restrict__ chunks,
+                                                                      float* __restrict__ partial, float* __restrict__ colsum_partial) {
+    Chunk ch = chunks[blockIdx.x];
+    int k = 0;
+    if (jobs.n > 1 && ch.rel >= jobs.j[1].first_rel) k = 1;
+    if (jobs.n > 2 && ch.rel >= jobs.j[2].first_rel) k = 2;
+    // (selects between the three argument sets, not an indexed read: the struct lives in kernel-argument SGPRs)
+    const WgJob J = k == 0 ? jobs.j[0] : (k == 1 ? jobs.j[1] : jobs.j[2]);
+    ch.beg -= J.row0; ch.end -= J.row0;
+    rows_wgrad_body<HI, HO>(J.A, J.A2, J.na1, J.ia, J.G, J.G2, J.ng1, J.ig, ch, partial, J.colsum_of, colsum_partial, nullptr, nullptr,
+                            J.maskBits, J.slope);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1705,6 +1745,54 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
     else
         hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile,
                            (bf16_t*)out, csp, Hi, out_colsum, (bf16_t*)out_colsum_lp);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                             const int32_t* chunk_ptr, void* out, int32_t out_is_f32, float* out_colsum, void* out_colsum_lp,
+                             void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+    DN_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= 3, "dn_rows_wgrad_multi: 1 .. 3 jobs");
+    DN_REQUIRE(H == 64 || H == 128, "dn_rows_wgrad_multi: unsupported width %d (64 / 128: the widths whose launches are latency)", H);
+    DN_REQUIRE(R >= 1 && num_chunks >= 0, "dn_rows_wgrad_multi: bad sizes");
+    DN_REQUIRE(out && chunk_ptr && out_colsum, "dn_rows_wgrad_multi: NULL pointer");
+    DN_REQUIRE(num_chunks == 0 || (chunks && workspace), "dn_rows_wgrad_multi: NULL pointer");
+    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * ((size_t)H * H + H) * sizeof(float), "dn_rows_wgrad_multi: workspace too small");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out_colsum)) % 16 == 0,
+               "dn_rows_wgrad_multi: workspace / out_colsum must be 16-byte aligned");
+    WgJobs wj;
+    wj.n = num_jobs;
+    for (int k = 0; k < 3; ++k) {
+        const dn_wgrad_job& q = jobs[k < num_jobs ? k : 0];
+        DN_REQUIRE(q.A && q.G, "dn_rows_wgrad_multi: NULL operand");
+        DN_REQUIRE((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.G) | reinterpret_cast<uintptr_t>(q.A2) |
+                    reinterpret_cast<uintptr_t>(q.G2)) % 16 == 0, "dn_rows_wgrad_multi: unaligned input");
+        DN_REQUIRE(q.A2 != nullptr || q.na1 == 0x7fffffff, "dn_rows_wgrad_multi: A2 == NULL requires na1 == INT32_MAX");
+        DN_REQUIRE(q.G2 != nullptr || q.ng1 == 0x7fffffff, "dn_rows_wgrad_multi: G2 == NULL requires ng1 == INT32_MAX");
+        DN_REQUIRE(q.colsum_of >= 0 && q.colsum_of <= 2 && q.first_rel >= 0 && q.row0 >= 0, "dn_rows_wgrad_multi: bad job");
+        DN_REQUIRE(q.mask_a_bits == nullptr || (q.A2 == nullptr && q.idx_a == nullptr), "dn_rows_wgrad_multi: mask_a_bits excludes A2 / idx_a");
+        DN_REQUIRE(k == 0 || k >= num_jobs || q.first_rel > jobs[k - 1].first_rel, "dn_rows_wgrad_multi: jobs must ascend in first_rel");
+        wj.j[k] = WgJob{(const bf16_t*)q.A, (const bf16_t*)q.A2, q.idx_a, (const bf16_t*)q.G, (const bf16_t*)q.G2, q.idx_g,
+                        (const uint8_t*)q.mask_a_bits, q.na1, q.ng1, q.colsum_of, q.first_rel, q.row0, q.act_slope};
+    }
+    DN_REQUIRE(jobs[0].first_rel == 0, "dn_rows_wgrad_multi: the first job starts at relation 0");
+    hipStream_t st = (hipStream_t)stream;
+    const Chunk* ch = reinterpret_cast<const Chunk*>(chunks);
+    float* ws = (float*)workspace;
+    const int64_t tile = (int64_t)H * H;
+    float* csp = ws + (size_t)num_chunks * tile;
+    if (num_chunks > 0) {
+        if (H == 128) hipLaunchKernelGGL((rows_wgrad_multi_kernel<128, 128>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, wj, ch, ws, csp);
+        else hipLaunchKernelGGL((rows_wgrad_multi_kernel<64, 64>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, wj, ch, ws, csp);
+        DN_CHECK_LAUNCH();
+    }
+    dim3 grid((unsigned)(dn_cdiv(tile, 128) + dn_cdiv(H, 128)), (unsigned)R);
+    if (out_is_f32)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile, (float*)out, csp, H,
+                           out_colsum, (float*)out_colsum_lp);
+    else
+        hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)workspace, chunk_ptr, tile, (bf16_t*)out, csp,
+                           H, out_colsum, (bf16_t*)out_colsum_lp);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -325,6 +325,43 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
     return out
 
 
+def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
+    """Several weight gradients in ONE launch + ONE reduce (dn_rows_wgrad_multi_bf16, bf16, H = 64 / 128).  jobs: dicts with A, G
+    (and optionally A2, G2, idx_a, idx_g, mask_a_bits, colsum_of, slope), first_rel, row0 -- relations numbered through, rows laid
+    end to end in one virtual row space that chunk_table covers.  -> (out [num_rels, H, H], colsum [num_rels, H]) in out_dtype."""
+    chunks, chunk_ptr, nchunks = chunk_table
+    dev = jobs[0]["A"].device
+    arr = (_lib.WgradJob * len(jobs))()
+    keep = []
+    for k, jb in enumerate(jobs):
+        A, G = jb["A"], jb["G"]
+        require_gpu(A, G, jb.get("A2"), jb.get("G2"), jb.get("idx_a"), jb.get("idx_g"), jb.get("mask_a_bits"))
+        assert A.dtype == G.dtype == torch.bfloat16 and A.shape[1] == G.shape[1] == H and A.is_contiguous() and G.is_contiguous()
+        keep.append(jb)
+        pv = lambda t: (t.data_ptr() if t is not None else None)  # noqa: E731
+        arr[k].A, arr[k].A2, arr[k].idx_a = pv(A), pv(jb.get("A2")), pv(jb.get("idx_a"))
+        arr[k].G, arr[k].G2, arr[k].idx_g = pv(G), pv(jb.get("G2")), pv(jb.get("idx_g"))
+        arr[k].mask_a_bits = pv(jb.get("mask_a_bits"))
+        arr[k].na1 = A.shape[0] if jb.get("A2") is not None else INT32_MAX
+        arr[k].ng1 = G.shape[0] if jb.get("G2") is not None else INT32_MAX
+        arr[k].colsum_of, arr[k].first_rel, arr[k].row0 = int(jb.get("colsum_of", 0)), int(jb["first_rel"]), int(jb["row0"])
+        arr[k].act_slope = float(jb.get("slope", 0.0))
+    out = torch.empty((num_rels, H, H), dtype=out_dtype, device=dev)
+    colsum = torch.empty((num_rels, H), dtype=torch.float32, device=dev)
+    colsum_lp = torch.empty((num_rels, H), dtype=out_dtype, device=dev) if out_dtype != torch.float32 else None
+    ws = _ws(lib().dn_rows_wgrad_workspace_bytes(nchunks, H, H), dev)
+
+    def _launch():
+        check(lib().dn_rows_wgrad_multi_bf16(arr, len(jobs), H, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
+                                             1 if out_dtype == torch.float32 else 0, ptr(colsum), ptr(colsum_lp), ptr(ws), ws.numel(),
+                                             stream_ptr()), "dn_rows_wgrad_multi_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_wgrad_multi", _launch)
+    else:
+        _launch()
+    return out, (colsum_lp if colsum_lp is not None else colsum)
+
+
 def wgrad_chunk_rows(rel_ptr_host, workgroups=256):
     """Rows per split-K chunk of the weight gradient over relation-major rows: the smallest multiple of 64 (>= 256) for which the
     chunks of all relations -- every relation ends in a partial chunk -- fit ONE round of `workgroups`; batches too large for
@@ -2181,6 +2218,70 @@ class _ReluMlpFn(torch.autograd.Function):
                                    mask_pos=acts[i] if i > 0 else None, slope=slope, w_kn=kn)   # masked for the activation below
         grads[0] = g if ctx.needs_input_grad[0] else None
         return tuple(grads)
+
+
+# DN_LAYER_SMALL=0: an H = 64 bf16 RGIN layer on small graphs stays a chain of separate autograd functions (conv, MLP)
+LAYER_SMALL_ENABLED = _os.environ.get("DN_LAYER_SMALL", "1") != "0"
+
+
+def rgin_layer_small_ok(x, W, W_loop, bias, linears, index_set):
+    """Can a whole RGIN layer (conv + bias + 2-layer MLP + activations) run as _RginLayerSmallFn?  bf16, H = 64, square, self loop,
+    two square Linears, a batch dn_conv_graphs_bf16 takes."""
+    if not (LAYER_SMALL_ENABLED and CHAIN2_ENABLED and W_loop is not None and len(linears) == 2 and len(index_set.parts) == 1):
+        return False
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 64 and W.dtype == x.dtype
+            and all(l.weight.dtype == x.dtype and tuple(l.weight.shape) == (64, 64) for l in linears)):
+        return False
+    return conv_graphs_ok(x, PassWeights(W, W_loop, kn=True), index_set.parts[0][2])
+
+
+class _RginLayerSmallFn(torch.autograd.Function):
+    """act(lin2(act(lin1(conv(x))))) of an RGIN layer at the reference's default width on a batch of small graphs (rgin.py:102-160 +
+    50-57, BASELINE config 3) as SEVEN launches a step: forward = the conv (dn_conv_graphs_bf16) + the MLP chain
+    (dn_rows_chain2_bf16); backward = the chain's input gradients, the conv's input gradient (the same launch on the transposed
+    weights), ONE weight-gradient launch for the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_bf16) + its reduce --
+    where the separate autograd functions need 11 launches plus the casts between them."""
+
+    @staticmethod
+    def forward(ctx, x, slope, index_set, W, W_loop, bias, w1, b1, w2, b2):
+        ctx.f32_mode = f32_mode()
+        x = x.contiguous()
+        ix = index_set.parts[0][2]
+        h = torch.empty_like(x)
+        aux = conv_graphs(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", h)
+        h1, h2, bits1, bits2 = rows_chain2(h, w1, b1, True, w2, b2, True, want_bits=True, slope=float(slope))
+        ctx.ix, ctx.slope = ix, float(slope)
+        ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
+        ctx.save_for_backward(x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
+        return h2
+
+    @staticmethod
+    @_backward_in_forward_mode
+    def backward(ctx, gout):
+        ix, slope = ctx.ix, ctx.slope
+        x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux = ctx.saved_tensors
+        g = gout.contiguous()
+        N, H, R = x.shape[0], 64, W.shape[0]
+        g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True), slope=slope)
+        gx = torch.empty_like(x)
+        aux_b = conv_graphs(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", gx)
+        # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
+        if getattr(ix, "_layer_chunks", None) is None:
+            P_all = ix.num_rows
+            vptr_host = list(ix.rel_ptr_host) + [P_all + N, P_all + 2 * N]
+            vptr = torch.cat([ix.rel_ptr_dev[:R + 2], torch.tensor([P_all + N, P_all + 2 * N], dtype=I32, device=x.device)])
+            ix._layer_chunks = build_row_tables(vptr, R + 3, P_all + 2 * N, wgrad_chunk_rows(vptr_host), want_ptr=True)
+        jobs = [dict(A=x, A2=aux if ctx.has[3] else None, idx_a=ix.row_in, G=g0, G2=aux_b, idx_g=ix.row_out, colsum_of=2, first_rel=0, row0=0),
+                dict(A=g1, G=h, colsum_of=1, first_rel=R + 1, row0=ix.num_rows),
+                dict(A=g, G=h1, colsum_of=1, mask_a_bits=bits2, slope=slope, first_rel=R + 2, row0=ix.num_rows + N)]
+        gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, W.dtype)
+        return (gx, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1], cs[R + 1] if ctx.has[1] else None, gw[R + 2],
+                cs[R + 2] if ctx.has[2] else None)
+
+
+def rgin_layer_small(x, W, W_loop, bias, linears, slope, index_set):
+    return _RginLayerSmallFn.apply(x, float(slope), index_set, W, W_loop, bias, linears[0].weight, linears[0].bias, linears[1].weight,
+                                   linears[1].bias)
 
 
 def relu_mlp_supported(x, linears):

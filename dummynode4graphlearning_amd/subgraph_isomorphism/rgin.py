@@ -121,6 +121,9 @@ class RGINLayer(nn.Module):
         if ops.fused_path_supported(node_feat, W):
             # bf16: message pass, self loop (rgin.py:140-142) and bias in ONE row-factorised MFMA pipeline
             index = g.row_index(edge_type, self.num_rels, self.self_loop, closing_hint=(node_feat.shape[1], node_feat.dtype))
+            small = self._small_layer(node_feat, W, index)
+            if small is not None:
+                return self.drop(small), edge_type
             out = ops.rel_transform_fused(node_feat, W, self.bias if self.self_loop else None, index,
                                           W_loop=self.loop_weight if self.self_loop else None)
             if self.bias is not None and not self.self_loop:
@@ -140,6 +143,21 @@ class RGINLayer(nn.Module):
             out = self.act(out)                                     # activation after the MLP (twice if MLP empty)
         out = self.drop(out)
         return out, edge_type
+
+    def _small_layer(self, node_feat, W, index):
+        """The whole layer -- conv, bias, Linear-act-Linear-act -- as ops.rgin_layer_small where it applies (bf16, the reference's default
+        width 64 (config.py:456-461), a batch of small graphs, the MLP a plain Linear / activation chain with the layer's own `relu` /
+        `leaky_relu`): seven launches a training step instead of eleven.  None: take the general route."""
+        if not self.self_loop:
+            return None
+        mods = list(self.mlp)
+        linears = [m for m in mods if isinstance(m, nn.Linear)]
+        slope = _fused_slope(self.act)
+        if slope is None or len(mods) != 3 or not all(isinstance(m, nn.Linear) or _fused_slope(m) == slope for m in mods):
+            return None
+        if not ops.rgin_layer_small_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
+            return None
+        return ops.rgin_layer_small(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
 
     def _run_mlp(self, out):
         """self.mlp(out), with every Linear (and the ReLU / leaky ReLU that follows it -- including the layer's final activation)

@@ -408,6 +408,26 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
                        const void* mask_a_bits, void* out_colsum_lp, float act_slope, void* workspace, size_t workspace_bytes,
                        dn_stream_t stream);
 
+/* Several weight gradients in ONE launch + ONE reduce (round 6): the jobs' relations are numbered through -- job k owns relations
+ * [first_rel_k, first_rel_{k+1}) of R -- and their rows lie end to end in one virtual row space (job k's row p is virtual row row0_k
+ * + p), so ONE chunk table (dn_row_tables_build_i32 over the virtual relation offsets) and one chunk_ptr cover them; operands,
+ * indices, colsum_of, mask_a_bits and act_slope per job as in dn_rows_wgrad_bf16 (no mask_a / a_out here).  out [R][H][H],
+ * out_colsum [R][H] fp32 (zeros for a job with colsum_of = 0), out_colsum_lp [R][H] in out's type or NULL.  H = 64 / 128: the
+ * widths at which a layer's three weight-gradient launches and their reduces are launch latency (BASELINE config 3: the whole
+ * backward of an RGIN layer then needs one weight-gradient launch, subgraph_isomorphism/models/rgin.py:50-67,102-160). */
+typedef struct dn_wgrad_job {
+    const void *A, *A2;
+    const int32_t* idx_a;
+    const void *G, *G2;
+    const int32_t* idx_g;
+    const void* mask_a_bits;
+    int32_t na1, ng1, colsum_of, first_rel, row0;
+    float act_slope;
+} dn_wgrad_job;
+int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                             const int32_t* chunk_ptr, void* out, int32_t out_is_f32, float* out_colsum, void* out_colsum_lp,
+                             void* workspace, size_t workspace_bytes, dn_stream_t stream);
+
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU
  * Xcat is the virtual concatenation of X (rows [0, n1)) and X2 (rows n1, n1+1, ...): an index i >= n1 reads

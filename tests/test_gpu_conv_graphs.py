@@ -112,9 +112,20 @@ def test_rgin_layer_at_the_default_width_takes_one_launch_per_direction():
             ops.CONV_GRAPHS_ENABLED = old
 
     tags, got = run(True)
-    assert tags.count("conv_graphs") == 2 and not any(t in tags for t in ("rows_selfsum", "rows_close", "fold_tail", "rows_transform:conv")), tags
+    # the whole step: conv + MLP chain forward, chain + conv backward, ONE weight-gradient launch (+ its reduce)
+    assert sorted(tags) == ["conv_graphs", "conv_graphs", "rows_chain2", "rows_chain2", "rows_wgrad_multi"], tags
+    old_small = ops.LAYER_SMALL_ENABLED
+    ops.LAYER_SMALL_ENABLED = False                       # the same conv launches under the separate autograd functions: same
+    try:                                                  # forward bit for bit, gradients up to the split-K grouping
+        tags1, sep = run(True)
+    finally:
+        ops.LAYER_SMALL_ENABLED = old_small
+    assert tags1.count("conv_graphs") == 2 and tags1.count("rows_wgrad") == 3 and "rows_wgrad_multi" not in tags1
+    assert torch.equal(got[0], sep[0]) and torch.equal(got[1], sep[1])
+    for a, b in zip(got[2:], sep[2:]):
+        assert _rel_l2(a, b) < 2e-3
     tags0, want = run(False)
-    assert "conv_graphs" not in tags0 and len(tags0) >= len(tags) + 4
+    assert "conv_graphs" not in tags0 and len(tags0) >= len(tags) + 6
     assert _rel_l2(got[0], want[0]) < 1e-2
     # (gradients pass two ReLU masks: elements within bf16 noise of 0 flip between the two roundings of the conv's sums -- both paths
     #  sit 5-6 % from fp64 math on this batch, 6.5 % from each other; the conv's own backward is held to 6e-3 in the test above)
