@@ -1869,7 +1869,7 @@ def conv_graphs_ok(xs, pw, ix):
     if not (CONV_GRAPHS_ENABLED and xs.dtype == torch.bfloat16 and xs.shape[1] == 64 and pw.loop is not None and ix.self_loop
             and ix.raw is not None and ix.max_graph is not None and ix.num_rels <= 16 and tuple(pw.rel.shape[1:]) == (64, 64)):
         return False
-    return 0 < ix.max_graph[0] <= 64 and ix.max_graph[1] <= 1024
+    return 0 < ix.max_graph[0] <= 64 and ix.max_graph[1] <= 1024 and ix.num_edges > 0       # (no edges: nothing to point the launch at)
 
 
 def conv_graphs(xs, pw, bias, ix, direction, out):
@@ -1883,7 +1883,7 @@ def conv_graphs(xs, pw, bias, ix, direction, out):
     require_gpu(xs, pw.rel, pw.loop, bias, out)
     assert xs.is_contiguous() and out.is_contiguous() and out.shape == xs.shape and pw.rel.is_contiguous() and pw.loop.is_contiguous()
     if getattr(ix, "_cg_err", None) is None:
-        ix._cg_err = torch.zeros(1, dtype=I32, device=xs.device)
+        ix._cg_err = torch.zeros(16, dtype=I32, device=xs.device)
     cand = _fold_candidate(ix, direction) if n_aux else None
     inside = (cand is not None and cand[3] == G and n_aux == G and ix._absorb is not None and ix._absorb[direction][2] != 0)
     aux = torch.empty((n_aux, H), dtype=xs.dtype, device=xs.device) if inside else None
@@ -1901,6 +1901,69 @@ def conv_graphs(xs, pw, bias, ix, direction, out):
     if n_aux and not inside:
         aux = gather_segsum(xs, aux_idx, aux_ptr, n_aux)
     return aux
+
+
+def _graphs_aux(ix, direction, xs):
+    """(inside, aux tensor or None, seg_ptr or None, seg_nodes or None) for the whole-graph launches: the direction's aux lists are the
+    graphs' segments (one collapsed relation, one row per graph) -> the launch writes the column sums itself."""
+    aux_idx, aux_ptr, n_aux = (ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f) if direction == "f" else (ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)
+    G = int(ix.raw[3].numel()) - 1
+    cand = _fold_candidate(ix, direction) if n_aux else None
+    inside = (cand is not None and cand[3] == G and n_aux == G and ix._absorb is not None and ix._absorb[direction][2] != 0)
+    if not inside:
+        return False, None, None, None
+    return True, torch.empty((n_aux, xs.shape[1]), dtype=xs.dtype, device=xs.device), aux_ptr[:n_aux + 1].contiguous(), aux_idx
+
+
+def layer_graphs_fwd(x, W, W_loop, bias, w1, b1, w2, b2, slope, ix):
+    """A whole RGIN layer forward on ix's batch of small graphs in ONE launch (dn_layer_graphs_fwd_bf16).
+    -> (h conv rows, h1, h2, bits1, bits2, aux)."""
+    src, dst, etype, node_ptr, edge_ptr = ix.raw
+    G, N, H = int(node_ptr.numel()) - 1, ix.num_nodes, 64
+    require_gpu(x, W, W_loop, bias, w1, b1, w2, b2)
+    assert x.is_contiguous() and W.is_contiguous() and W_loop.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    if getattr(ix, "_cg_err", None) is None:
+        ix._cg_err = torch.zeros(16, dtype=I32, device=x.device)
+    inside, aux, sp, sn = _graphs_aux(ix, "f", x)
+    h, h1, h2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    bits1 = torch.empty((N, H // 8), dtype=torch.uint8, device=x.device)
+    bits2 = torch.empty((N, H // 8), dtype=torch.uint8, device=x.device)
+
+    def _launch():
+        check(lib().dn_layer_graphs_fwd_bf16(ptr(x), H, ptr(W), ptr(W_loop), ptr(bias), ix.num_rels, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                             float(slope), ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype), G, N, ptr(h), ptr(h1),
+                                             ptr(h2), ptr(bits1), ptr(bits2), ptr(sp), ptr(sn), ptr(aux), ptr(ix._cg_err), stream_ptr()),
+              "dn_layer_graphs_fwd_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("layer_graphs_fwd", _launch)
+    else:
+        _launch()
+    if ix.num_aux_f and not inside:
+        aux = gather_segsum(x, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f)
+    return h, h1, h2, bits1, bits2, aux
+
+
+def layer_graphs_bwd(g, W, W_loop, w1, w2, slope, bits1, bits2, ix):
+    """... and its input gradients in ONE launch (dn_layer_graphs_bwd_bf16).  -> (g1, g0, gx, aux_b)."""
+    src, dst, etype, node_ptr, edge_ptr = ix.raw
+    G, N, H = int(node_ptr.numel()) - 1, ix.num_nodes, 64
+    require_gpu(g, W, W_loop, w1, w2, bits1, bits2)
+    assert g.is_contiguous() and W.is_contiguous() and W_loop.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    g1, g0, gx = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+    inside, aux_b, sp, sn = _graphs_aux(ix, "b", g)
+
+    def _launch():
+        check(lib().dn_layer_graphs_bwd_bf16(ptr(g), H, ptr(W), ptr(W_loop), ix.num_rels, ptr(w1), ptr(w2), float(slope), ptr(bits1),
+                                             ptr(bits2), ptr(node_ptr), ptr(edge_ptr), ptr(src), ptr(dst), ptr(etype), G, N, ptr(g1), ptr(g0),
+                                             ptr(gx), ptr(sp), ptr(sn), ptr(aux_b), ptr(ix._cg_err), stream_ptr()),
+              "dn_layer_graphs_bwd_bf16")
+    if kernel_timer is not None:
+        kernel_timer.launch("layer_graphs_bwd", _launch)
+    else:
+        _launch()
+    if ix.num_aux_b and not inside:
+        aux_b = gather_segsum(g0, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)
+    return g1, g0, gx, aux_b
 
 
 def message_pass(xs, pw, bias, ix, direction, ybuf, out):
@@ -2220,6 +2283,8 @@ class _ReluMlpFn(torch.autograd.Function):
         return tuple(grads)
 
 
+# DN_LAYER_GRAPHS=0: inside _RginLayerSmallFn the conv and the MLP chain stay separate launches (dn_conv_graphs_bf16 + dn_rows_chain2_bf16)
+LAYER_GRAPHS_ENABLED = _os.environ.get("DN_LAYER_GRAPHS", "1") != "0"
 # DN_LAYER_SMALL=0: an H = 64 bf16 RGIN layer on small graphs stays a chain of separate autograd functions (conv, MLP)
 LAYER_SMALL_ENABLED = _os.environ.get("DN_LAYER_SMALL", "1") != "0"
 
@@ -2247,9 +2312,13 @@ class _RginLayerSmallFn(torch.autograd.Function):
         ctx.f32_mode = f32_mode()
         x = x.contiguous()
         ix = index_set.parts[0][2]
-        h = torch.empty_like(x)
-        aux = conv_graphs(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", h)
-        h1, h2, bits1, bits2 = rows_chain2(h, w1, b1, True, w2, b2, True, want_bits=True, slope=float(slope))
+        if LAYER_GRAPHS_ENABLED:
+            h, h1, h2, bits1, bits2, aux = layer_graphs_fwd(x, W.contiguous(), W_loop.contiguous(), bias, w1.contiguous(), b1,
+                                                            w2.contiguous(), b2, float(slope), ix)
+        else:
+            h = torch.empty_like(x)
+            aux = conv_graphs(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", h)
+            h1, h2, bits1, bits2 = rows_chain2(h, w1, b1, True, w2, b2, True, want_bits=True, slope=float(slope))
         ctx.ix, ctx.slope = ix, float(slope)
         ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
         ctx.save_for_backward(x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
@@ -2262,9 +2331,13 @@ class _RginLayerSmallFn(torch.autograd.Function):
         x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux = ctx.saved_tensors
         g = gout.contiguous()
         N, H, R = x.shape[0], 64, W.shape[0]
-        g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True), slope=slope)
-        gx = torch.empty_like(x)
-        aux_b = conv_graphs(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", gx)
+        if LAYER_GRAPHS_ENABLED:
+            g1, g0, gx, aux_b = layer_graphs_bwd(g, W.contiguous(), W_loop.contiguous(), w1.contiguous(), w2.contiguous(), slope, bits1, bits2,
+                                                 ix)
+        else:
+            g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True), slope=slope)
+            gx = torch.empty_like(x)
+            aux_b = conv_graphs(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", gx)
         # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
         if getattr(ix, "_layer_chunks", None) is None:
             P_all = ix.num_rows

@@ -287,6 +287,24 @@ int dn_row_index_build_local_i32(int64_t G, int64_t N, int64_t R, int64_t E, con
  * aux (may be NULL): [num_graphs][H], aux[j] = bf16 column sum of the INPUT rows of segment j = nodes seg_nodes[seg_ptr[j] ..
  * seg_ptr[j+1]) (a contiguous run inside graph j: the pre-aggregated operand dn_rows_wgrad_bf16 takes for a collapsed relation).
  * fp32 accumulation in a fixed order (bitwise repeatable), every per-edge product rounded to bf16 once, the output row once. */
+/* dn_layer_graphs_fwd_bf16 / _bwd_bf16: a whole RGIN layer (rgin.py:102-160 + the MLP of rgin.py:50-57,147-151: Linear - act - Linear
+ * - act with act = ReLU (act_slope 0) or leaky ReLU) around the same per-graph conv, ONE launch each way:
+ *   fwd: conv_out = conv(X) (+ bias), mid = act(conv_out @ W1^T + b1), out = act(mid @ W2^T + b2); bits1 / bits2 [N][H / 8] = the
+ *        sign bits (> 0) of mid / out; aux as in dn_conv_graphs_bf16 (column sums of X).  W / W_loop stored [k][n] (the parameters),
+ *        W1 / W2 [out][in] (nn.Linear.weight).
+ *   bwd: G = the gradient of out: g_mid = mask1(mask2(G) @ W2), g_conv = g_mid @ W1, g_in = the conv's input gradient of g_conv
+ *        (edges dst -> src, W read transposed); aux = column sums of g_conv over the segments (the weight gradient's operand).
+ * Same limits, error flag and numerics as dn_conv_graphs_bf16; every row tensor [N][H] bf16. */
+int dn_layer_graphs_fwd_bf16(const void* X, int32_t H, const void* W, const void* W_loop, const void* bias, int32_t num_rels,
+                             const void* W1, const void* b1, const void* W2, const void* b2, float act_slope, const int32_t* node_ptr,
+                             const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype, int64_t num_graphs,
+                             int64_t N, void* conv_out, void* mid, void* out, void* bits1, void* bits2, const int32_t* seg_ptr,
+                             const int32_t* seg_nodes, void* aux, int32_t* dev_err, dn_stream_t stream);
+int dn_layer_graphs_bwd_bf16(const void* G, int32_t H, const void* W, const void* W_loop, int32_t num_rels, const void* W1,
+                             const void* W2, float act_slope, const void* bits1, const void* bits2, const int32_t* node_ptr,
+                             const int32_t* edge_ptr, const int32_t* src, const int32_t* dst, const int32_t* etype, int64_t num_graphs,
+                             int64_t N, void* g_mid, void* g_conv, void* g_in, const int32_t* seg_ptr, const int32_t* seg_nodes,
+                             void* aux, int32_t* dev_err, dn_stream_t stream);
 int32_t dn_conv_graphs_max_nodes(void);
 int32_t dn_conv_graphs_max_edges(void);
 int dn_conv_graphs_bf16(const void* X, int32_t H, const void* W, int32_t w_kn, const void* W_loop, const void* bias, int32_t num_rels,

@@ -55,7 +55,7 @@ def test_conv_graphs_matches_fp64_in_both_directions(R, nmax, dens, G):
         aux = ops.conv_graphs(x, pw, bias, ix, direction, out)
         out2 = torch.empty_like(out)
         aux2 = ops.conv_graphs(x, pw, bias, ix, direction, out2)
-        assert int(ix._cg_err.item()) == 0
+        assert int(ix._cg_err[0].item()) == 0
         assert torch.equal(out, out2) and (aux is None or torch.equal(aux, aux2))         # bitwise run to run
         a, o = (src, dst) if direction == "f" else (dst, src)
         Wd = W.double() if kn else W.double().transpose(1, 2)                            # kn False: the same memory read as [n][k]
@@ -70,6 +70,46 @@ def test_conv_graphs_matches_fp64_in_both_directions(R, nmax, dens, G):
             ap, ai = (ix.aux_f_ptr, ix.aux_f_idx) if direction == "f" else (ix.aux_b_ptr, ix.aux_b_idx)
             want = ops.gather_segsum(x, ai, ap, n_aux)
             assert aux is not None and _rel_l2(aux, want) < 4e-3
+
+
+@pytest.mark.parametrize("R,nmax,dens,G,slope", [(8, 49, 2.1, 64, 0.0), (16, 63, 3.0, 30, 1 / 5.5), (3, 20, 5.0, 200, 0.0)])
+def test_layer_launches_match_fp64_stage_by_stage(R, nmax, dens, G, slope):
+    """dn_layer_graphs_fwd_bf16 / _bwd_bf16: every stage against fp64 math on the launch's own stored operands (conv rows, layer-1 rows,
+    their sign bits; masked gradient, dgrad 2, dgrad 1, the conv's input gradient, the column sums the weight gradient takes)."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(R + G)
+    src, dst, et, nptr, eptr = _batch(rng, G, R, nmax, dens)
+    N, H = nptr[-1], 64
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)  # noqa: E731
+    ix = ops.RowIndex(src, dst, et, N, R, self_loop=True, node_ptr=i32(nptr), edge_ptr=i32(eptr))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    rnd = lambda *sh, sc=1.0: (torch.randn(*sh, device=DEV, generator=gen) * sc).to(torch.bfloat16)  # noqa: E731
+    x, W, Wl, b = rnd(N, H), rnd(R, H, H, sc=1 / 8), rnd(H, H, sc=1 / 8), rnd(H)
+    w1, b1, w2, b2 = rnd(H, H, sc=1 / 8), rnd(H), rnd(H, H, sc=1 / 8), rnd(H)
+    act = lambda v: torch.where(v > 0, v, v * slope)  # noqa: E731
+    h, h1, h2, bits1, bits2, aux = ops.layer_graphs_fwd(x, W, Wl, b, w1, b1, w2, b2, slope, ix)
+    assert int(ix._cg_err[0].item()) == 0
+    ref = x.double() @ Wl.double() + b.double()
+    ref.index_add_(0, dst, torch.bmm(x.double()[src].unsqueeze(1), W.double()[et]).squeeze(1))
+    assert _rel_l2(h, ref) < 6e-3
+    assert _rel_l2(h1, act(h.double() @ w1.double().t() + b1.double())) < 4e-3
+    assert _rel_l2(h2, act(h1.double() @ w2.double().t() + b2.double())) < 4e-3
+    unpack = lambda bits: ((bits.unsqueeze(-1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(N, H).bool()  # noqa: E731
+    assert torch.equal(unpack(bits1), h1 > 0) and torch.equal(unpack(bits2), h2 > 0)
+    assert _rel_l2(aux, ops.gather_segsum(x, ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f)) < 4e-3
+    g = rnd(N, H)
+    g1, g0, gx, aux_b = ops.layer_graphs_bwd(g, W, Wl, w1, w2, slope, bits1, bits2, ix)
+    assert int(ix._cg_err[0].item()) == 0
+    gm = torch.where(unpack(bits2), g.double(), (g.double() * slope).to(torch.bfloat16).double())
+    t = gm @ w2.double()
+    assert _rel_l2(g1, torch.where(unpack(bits1), t, t * slope)) < 4e-3
+    assert _rel_l2(g0, g1.double() @ w1.double()) < 4e-3
+    refx = g0.double() @ Wl.double().t()
+    refx.index_add_(0, src, torch.bmm(g0.double()[dst].unsqueeze(1), W.double().transpose(1, 2)[et]).squeeze(1))
+    assert _rel_l2(gx, refx) < 6e-3
+    assert _rel_l2(aux_b, ops.gather_segsum(g0, ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b)) < 4e-3
+    again = ops.layer_graphs_bwd(g, W, Wl, w1, w2, slope, bits1, bits2, ix)
+    assert all(torch.equal(u, v) for u, v in zip((g1, g0, gx, aux_b), again))
 
 
 def test_rgin_layer_at_the_default_width_takes_one_launch_per_direction():
@@ -112,18 +152,24 @@ def test_rgin_layer_at_the_default_width_takes_one_launch_per_direction():
             ops.CONV_GRAPHS_ENABLED = old
 
     tags, got = run(True)
-    # the whole step: conv + MLP chain forward, chain + conv backward, ONE weight-gradient launch (+ its reduce)
-    assert sorted(tags) == ["conv_graphs", "conv_graphs", "rows_chain2", "rows_chain2", "rows_wgrad_multi"], tags
-    old_small = ops.LAYER_SMALL_ENABLED
-    ops.LAYER_SMALL_ENABLED = False                       # the same conv launches under the separate autograd functions: same
-    try:                                                  # forward bit for bit, gradients up to the split-K grouping
+    # the whole step in THREE library calls: the layer forward, its input gradients, ONE weight-gradient launch (+ its reduce)
+    assert tags == ["layer_graphs_fwd", "layer_graphs_bwd", "rows_wgrad_multi"], tags
+    old_lg, old_small = ops.LAYER_GRAPHS_ENABLED, ops.LAYER_SMALL_ENABLED
+    try:
+        ops.LAYER_GRAPHS_ENABLED = False                  # the conv launch + the separate MLP chain launches inside the same function:
+        tags2, two = run(True)                            # the same arithmetic up to the activation's rounding point
+        ops.LAYER_SMALL_ENABLED = False                   # ... and under the separate autograd functions (three weight-gradient launches)
         tags1, sep = run(True)
     finally:
-        ops.LAYER_SMALL_ENABLED = old_small
+        ops.LAYER_GRAPHS_ENABLED, ops.LAYER_SMALL_ENABLED = old_lg, old_small
+    assert sorted(tags2) == ["conv_graphs", "conv_graphs", "rows_chain2", "rows_chain2", "rows_wgrad_multi"], tags2
     assert tags1.count("conv_graphs") == 2 and tags1.count("rows_wgrad") == 3 and "rows_wgrad_multi" not in tags1
-    assert torch.equal(got[0], sep[0]) and torch.equal(got[1], sep[1])
-    for a, b in zip(got[2:], sep[2:]):
+    assert torch.equal(two[0], sep[0]) and torch.equal(two[1], sep[1])
+    for a, b in zip(two[2:], sep[2:]):
         assert _rel_l2(a, b) < 2e-3
+    assert _rel_l2(got[0], two[0]) < 4e-3
+    for a, b in zip(got[1:], two[1:]):
+        assert _rel_l2(a, b) < 0.08
     tags0, want = run(False)
     assert "conv_graphs" not in tags0 and len(tags0) >= len(tags) + 6
     assert _rel_l2(got[0], want[0]) < 1e-2
