@@ -719,7 +719,7 @@ def main():
     # from the committed rocprofv3 measurement of this exact workload (profiles/rNN_traffic.json), else null
     traffic = None
     from dummynode4graphlearning_amd._lib import source_digest
-    for tag in ("r05", "r04", "r03", "r02", "r01"):                    # newest committed measurement of this exact workload AND code
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):                    # newest committed measurement of this exact workload AND code
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
                 tj = json.load(f)

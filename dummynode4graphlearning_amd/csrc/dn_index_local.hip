@@ -50,6 +50,7 @@ constexpr int kBigWaves = 16;        // wavefronts that share one listed graph
 constexpr int kBigGrid = 128;        // workgroups of the two launches over the list
 constexpr int kLocNodes = 1 << 14;   // nodes of one graph (local ids are packed into 14 bits)
 constexpr int kLocWaves = 4;         // graphs in flight per workgroup (one wavefront each)
+constexpr int kLocShare = 16;        // consecutive graphs a workgroup owns per round (its wavefronts take them one at a time)
 constexpr int kLocR = 64;            // relations (per-workgroup counters, one lane per relation)
 constexpr int kEdge = 0, kAgg = 1, kTf = 2;
 constexpr int kSeg = 5;              // packed count arrays over (relation, graph): rows, AGG rows, TF rows, AGG edges, TF edges
@@ -387,7 +388,19 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         atomicOr(bad, 1);
     __syncthreads();
     int max_n = 0, max_m = 0;                                            // the largest graph this wavefront has seen
-    for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
+    // (a workgroup owns kLocShare consecutive graphs per round and its wavefronts take them one at a time from an LDS counter:
+    //  TU-shaped batches mix 10-edge and 1,000-edge graphs whose sorts differ a hundredfold, and a fixed pair per wavefront left
+    //  three wavefronts waiting for the unlucky one.  A device-wide counter instead serialises: 32,768 atomics on one word took 0.5 ms)
+    __shared__ int take;
+    for (int64_t base = (int64_t)blockIdx.x * kLocShare; base < G; base += (int64_t)gridDim.x * kLocShare) {
+      if (threadIdx.x == 0) take = 0;
+      __syncthreads();
+      for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&take, 1);
+        k = __shfl(k, 0, 64);
+        const int64_t g = base + k;
+        if (k >= kLocShare || g >= G) break;
         const int cls = graph_class(g, node_ptr, edge_ptr, N, E);
         if (cls == 0) {
             if (lane == 0) atomicOr(bad, 1);
@@ -406,8 +419,15 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_stats_kernel(int64_t G, in
         }
         u32* A = reinterpret_cast<u32*>(X);
         stats_sorted<1, 10, 14>(A, A + kLocM, lane, node_ptr[g], node_ptr[g + 1], edge_ptr[g], m, R, src, dst, etype, cnt, hbits, bad);
+      }
+      __syncthreads();                                                     // (the counter is reset for the next round)
     }
-    if (lane == 0 && max_n > 0) { atomicMax(bad + 1, max_n); atomicMax(bad + 2, max_m); }     // (bad[1], bad[2]: zeroed with bad)
+    // (bad[1], bad[2], zeroed with bad: the batch's largest graph.  Thousands of wavefronts raising the same two words serialise --
+    //  0.2 ms at config 5 -- so a wavefront only asks when the word it reads is still below its own value)
+    if (lane == 0 && max_n > 0) {
+        if (max_n > __hip_atomic_load(bad + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bad + 1, max_n);
+        if (max_m > __hip_atomic_load(bad + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bad + 2, max_m);
+    }
     __syncthreads();
     if (threadIdx.x < 3 * kLocR) {
         const int k = threadIdx.x / kLocR, r = threadIdx.x % kLocR;
@@ -860,7 +880,7 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
     int32_t* __restrict__ aux_f_ptr, int32_t* __restrict__ aux_f_idx, int32_t* __restrict__ aux_b_ptr,
     int32_t* __restrict__ aux_b_idx, int32_t* __restrict__ dst_ptr, int32_t* __restrict__ dst_rows, int32_t* __restrict__ src_ptr,
     int32_t* __restrict__ src_rows, int32_t* __restrict__ meta /* [5] totals, [R + 1] rel_ptr, [R] modes, status */,
-    const int32_t* __restrict__ bad, int32_t* __restrict__ rel_ptr_out /* may be NULL: [R + 2] = rel_ptr, then the end of the self-loop rows */) {
+    int32_t* __restrict__ bad, int32_t* __restrict__ rel_ptr_out /* may be NULL: [R + 2] = rel_ptr, then the end of the self-loop rows */) {
     __shared__ __attribute__((aligned(16))) LocLds L;
     __shared__ __attribute__((aligned(16))) u32 ftab[kLocWaves][kFastWords];
     __shared__ int32_t s_mode[kLocR];
@@ -901,7 +921,16 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
             meta[5 + 2 * R + 4 + 12] = bad[1]; meta[5 + 2 * R + 4 + 13] = bad[2];   // the largest graph: nodes, edges
         }
     }
-    for (int64_t g = (int64_t)blockIdx.x * kLocWaves + wave; g < G; g += (int64_t)gridDim.x * kLocWaves) {
+    __shared__ int take;                                                 // (graphs of a workgroup's share one at a time: see ril_stats_kernel)
+    for (int64_t base = (int64_t)blockIdx.x * kLocShare; base < G; base += (int64_t)gridDim.x * kLocShare) {
+      if (threadIdx.x == 0) take = 0;
+      __syncthreads();
+      for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&take, 1);
+        k = __shfl(k, 0, 64);
+        const int64_t g = base + k;
+        if (k >= kLocShare || g >= G) break;
         int n0, n1, e0;
         const int m = load_graph(X, lane, g, R, node_ptr, edge_ptr, src, dst, etype, s_mode, hbits, N, E, n0, n1, e0, nullptr);
         if (m < 0) continue;
@@ -928,6 +957,8 @@ __global__ __launch_bounds__(kLocWaves * 64) void ril_fill_kernel(
             fill_sorted<1, 10>(X, T, T + kLocM, reinterpret_cast<int*>(T + 2 * kLocM), nullptr, lane, m, R, g, n0, A, s_mode);
         }
         __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
     }
 }
 
@@ -1140,7 +1171,8 @@ int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_pt
     DN_CHECK_HIP(hipMemsetAsync(w.Er, 0, w.zero_bytes, st));
     DN_CHECK_HIP(hipMemsetAsync(w.big, 0, sizeof(int32_t), st));
     const unsigned grid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocWaves) < 2048 ? dn_cdiv(G, kLocWaves) : 2048) : 1);
-    hipLaunchKernelGGL(ril_stats_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
+    const unsigned sgrid = (unsigned)(G > 0 ? (dn_cdiv(G, kLocShare) < 2048 ? dn_cdiv(G, kLocShare) : 2048) : 1);   // (stats / fill: shares)
+    hipLaunchKernelGGL(ril_stats_kernel, dim3(sgrid), dim3(kLocWaves * 64), 0, st, G, (int32_t)R, node_ptr, edge_ptr, src, dst, etype,
                        N, E, w.Er, w.Dr, w.Sr, w.bad, w.hbits, w.big);
     // (the graphs over one wavefront's LDS slice, if any: the list's length is only known on the device -- an empty list costs two
     //  empty launches)
@@ -1152,7 +1184,7 @@ int ril_queue(int64_t G, int64_t N, int64_t R, int64_t E, const int32_t* node_pt
                        edge_ptr, src, dst, etype, w.Er, w.Dr, w.Sr, w.hbits, w.mode, w.C);
     DN_CHECK_HIP(rocprim::exclusive_scan(w.scan_tmp, w.scan_tmp_bytes, (const int32_t*)w.C, w.S, (int32_t)0, (size_t)w.L,
                                          rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(ril_fill_kernel, dim3(grid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
+    hipLaunchKernelGGL(ril_fill_kernel, dim3(sgrid), dim3(kLocWaves * 64), 0, st, G, N, E, (int32_t)R, self_loop, node_ptr, edge_ptr, src,
                        dst, etype, w.mode, w.hbits, w.S, row_in, row_out, aux_f_ptr, aux_f_idx, aux_b_ptr, aux_b_idx, dst_ptr, dst_rows,
                        src_ptr, src_rows, w.meta, w.bad, rel_ptr_dev);
     if (may_big)
