@@ -45,7 +45,7 @@ STEP = [
 ]
 CONV_ROWS = (0, 1, 8, 9)
 OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_close_ring_kernel",
-        "rows_selfsum_kernel", "fold_tail_kernel", "rows_chain2_ring_kernel", "rows_chain2_kernel", "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
+        "rows_selfsum_kernel", "fold_tail_kernel", "conv_graphs_kernel", "rows_wgrad_multi_kernel", "rows_chain2_ring_kernel", "rows_chain2_kernel", "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
         "wgrad_reduce_kernel")
 
 
