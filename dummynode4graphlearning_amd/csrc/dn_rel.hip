@@ -30,6 +30,13 @@ struct Chunk {
     int32_t rel, beg, end, pad;
 };
 
+// colsum_of as the C entry takes it: operand (0 none, 1 A, 2 G) | (relation + 1) << 8 -- column sums of ONE relation's rows only
+// (0 in bits 8..: of every relation's).  What a chunk of relation `rel` has to sum: the operand, or nothing (its sums are zeros).
+__device__ __forceinline__ int32_t colsum_for(int32_t colsum_arg, int32_t rel) {
+    const int32_t only = colsum_arg >> 8;
+    return (only == 0 || rel + 1 == only) ? (colsum_arg & 0xff) : 0;
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int stride, int col0, int lane) {
     // fragment of a K-strided operand: element j of lane l = tile[8*(l>>4) + j][col0 + (l&15)]
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -232,7 +239,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ maskA,
                                                                 bf16_t* __restrict__ A_out,
                                                                 const uint8_t* __restrict__ maskBits, float slope) {
-    rows_wgrad_body<HI, HO>(A, A2, na1, ia, G, G2, ng1, ig, chunks[blockIdx.x], partial, colsum_of, colsum_partial, maskA, A_out, maskBits, slope);
+    const Chunk ch = chunks[blockIdx.x];
+    rows_wgrad_body<HI, HO>(A, A2, na1, ia, G, G2, ng1, ig, ch, partial, colsum_for(colsum_of, ch.rel), colsum_partial, maskA, A_out, maskBits, slope);
 }
 
 // Several weight gradients in ONE launch (round 6: a whole RGIN layer's -- the conv's R + 1 matrices over gathered rows, the two MLP
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ G2, int32_t ng1,
                                                                     const int32_t* __restrict__ ig,
                                                                     const Chunk* __restrict__ chunks,
-                                                                    float* __restrict__ partial, int32_t colsum_of,
+                                                                    float* __restrict__ partial, int32_t colsum_arg,
                                                                     float* __restrict__ colsum_partial,
                                                                     const uint8_t* __restrict__ maskBits, float slope) {
     static_assert(H == 256 || H == 128, "unsupported width");
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
     const Chunk ch = chunks[blockIdx.x];
+    const int32_t colsum_all = colsum_arg & 0xff, colsum_of = colsum_for(colsum_arg, ch.rel);   // (a chunk of another relation: zeros)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
     // ---- prologue: NST-1 tiles in flight (chunk tables never hold empty chunks; guard anyway: pe must be a valid row) ----
     if (ntiles <= 0) {
         for (int i = tid; i < H * H; i += kWgThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
-        if (colsum_of != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
+        if (colsum_all != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
         return;
     }
     load_idx(0);
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_dma_kernel(const bf16_t
                 const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
                 out[(size_t)k * H + c] = acc[m][n][i];
             }
-    if (colsum_of != 0) {
+    if (colsum_all != 0) {
         constexpr int TPC = kWgThreads / LPRW;                             // threads per column chunk
         float* red = reinterpret_cast<float*>(lds);
         const int ochunk = (MASKED && colsum_of == 1) ? mchunk : cchunk;    // (masked: summed where the piece was masked)
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
                                                                    int32_t ng1, const int32_t* __restrict__ ig,
                                                                    const Chunk* __restrict__ chunks, float* __restrict__ partial,
-                                                                   int32_t colsum_of, float* __restrict__ colsum_partial) {
+                                                                   int32_t colsum_arg, float* __restrict__ colsum_partial) {
     constexpr int H = 256, TR = 32, NST = 4, ROWB = 2 * H, MATB = TR * ROWB, STB = 2 * MATB;
     constexpr int LPRW = H / 8, RW = TR / 8;       // 32 lanes per row; 4 rows of each operand per wave and tile
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
@@ -590,6 +599,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const Chunk ch = chunks[blockIdx.x];
+    const int32_t colsum_all = colsum_arg & 0xff, colsum_of = colsum_for(colsum_arg, ch.rel);
     const int ntiles = (ch.end - ch.beg + TR - 1) / TR;
     const int32_t ch_beg = ch.beg, ch_end = ch.end;
     const char* zero = reinterpret_cast<const char*>(g_zero_row);
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
     // ---- prologue --------------------------------------------------------------------------------------------------
     if (ntiles <= 0) {
         for (int i = tid; i < H * H; i += kWgThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
-        if (colsum_of != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
+        if (colsum_all != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
         return;
     }
 #pragma unroll 1
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
     wait_vmcnt<0>();                                                       // drain what is still in flight
     __builtin_amdgcn_s_barrier();
     flush((int)blockIdx.x);
-    if (colsum_of != 0) {
+    if (colsum_all != 0) {
         constexpr int TPC = kWgThreads / LPRW;
         float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -783,6 +793,366 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
         if (tid < H) {
             float sum = 0.f;
             for (int sl = 0; sl < TPC; ++sl) sum += red[sl * H + tid];
+            colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// rows_wgrad_ls_kernel ("loader-specialised", H = 256): the ring of the two kernels above with the ROLES of a tile's work on
+// separate waves, as in the ring transform (dn_rel_ring.hip): 12 waves per workgroup, 3 per SIMD --
+//   * waves 8..11 (loaders) issue every LDS-DMA of a tile (8 rows of each operand per loader, the index octets two groups ahead
+//     through a per-wave LDS ring), apply the activation mask to a landed tile in place (MODE 2) and take the column sums;
+//   * waves 0..7 (compute) do nothing but fragment reads and MFMAs (128 x 64 of the 256 x 256 product each, as above).
+// Why: with the rows cache-resident (indices folded into 1 MB, tools/wgrad_local_exp.py) the kernels above still need 1.09 us per
+// tile and workgroup against 0.49 of MFMA work -- every wave's tile was [wait, barrier, 4-5 DMA issues at 60-185 cycles each +
+// their address arithmetic, 24 fragment reads, 32 MFMAs, column sums], two such streams per SIMD; the launch was bound by its
+// own instruction stream (docs/LAB_NOTES.md, round 6), which is why neither fewer HBM bytes nor cache residency made it faster.
+// Same tiles in the same order, the same MFMA per tile and accumulator, the same partition of the column sums: results are
+// bit-identical to the kernels above.
+//   MODE 0: gathered operands (both index arrays; second sources A2 / G2), 1: both operands in row order, 2: row order + the A
+//   operand masked by bits (dn_rows_wgrad_bf16's maskBits).
+// vmcnt: a loader issues per tile ONE group, [index octet of tile s + 7] [8 row pieces of tile s + 3] behind barrier s (MODE 0;
+// 8 pieces in the other modes, + the tile's mask bits on loader s & 3 between the A and G pieces in MODE 2).
+// -------------------------------------------------------------------------------------------------
+constexpr int kLsCompute = 8, kLsLoaders = 4, kLsThreads = 64 * (kLsCompute + kLsLoaders);
+
+template <int MODE>
+__global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
+                                                                   int32_t na1, const int32_t* __restrict__ ia,
+                                                                   const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
+                                                                   int32_t ng1, const int32_t* __restrict__ ig,
+                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                   int32_t colsum_arg, float* __restrict__ colsum_partial,
+                                                                   const uint8_t* __restrict__ maskBits, float slope) {
+    constexpr bool GATHER = MODE == 0, MASKED = MODE == 2;
+    constexpr int H = 256, TR = 32, NST = 4, ROWB = 2 * H, MATB = TR * ROWB, BITB = MASKED ? 1024 : 0, STB = 2 * MATB + BITB;
+    constexpr int LPRW = H / 8;                    // 32 lanes per row
+    constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
+    constexpr int kSlots = 8;                      // per-loader ring of index octets (16 words a slot)
+    constexpr int kGroup = GATHER ? 9 : 8;         // vector-memory operations of a loader's group (without the mask bits)
+    __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
+    __shared__ __attribute__((aligned(64))) int32_t idxL[GATHER ? kLsLoaders : 1][kSlots][16];
+    __shared__ __attribute__((aligned(128))) uint64_t adrL[kLsLoaders][kSlots][16];   // per loader and tile: the 16 row addresses
+    typedef __attribute__((address_space(3))) char* lds_wp;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Chunk ch = chunks[blockIdx.x];
+    const int32_t colsum_all = colsum_arg & 0xff, colsum_of = colsum_for(colsum_arg, ch.rel);   // (a chunk of another relation: zeros)
+    const int ntiles = (ch.end - ch.beg + TR - 1) / TR;
+    const int32_t ch_beg = ch.beg, ch_end = ch.end;
+    if (ntiles <= 0) {                             // (chunk tables never hold empty chunks; guard anyway)
+        for (int i = tid; i < H * H; i += kLsThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
+        if (colsum_all != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
+        return;
+    }
+    // column sums: loader thread lt stands for the two threads (crow = lt / 32 and 8 + lt / 32, chunk lt % 32) of the 512-thread
+    // kernels above -- rows crow, crow + 16 of every tile, in this order
+    float cs[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[s][i] = 0.f;
+    int ochunk[2] = {0, 0};
+
+    if (wave >= kLsCompute) {
+        // ------------------------------------------------------------------------------------------------ loaders
+        const int q = wave - kLsCompute;
+        const int rin = lane / LPRW, cpos = lane % LPRW;
+        const char* zero = reinterpret_cast<const char*>(g_zero_row);
+        const unsigned idx_base = (unsigned)(uintptr_t)(lds_wp)&idxL[GATHER ? q : 0][0][0];
+        int gch[4];                                // source byte offset inside the row, per piece (the XOR swizzle of the image)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rl = 8 * q + 2 * j + rin;
+            const int f = (rl & 3) | (((rl >> 3) & 1) << 2);
+            gch[j] = ((((cpos >> 1) ^ f) << 1) | (cpos & 1)) * 16;
+        }
+        auto tile_rows = [&](int T, int& p0, int& pe, bool& live) {
+            live = T < ntiles;
+            const int Tc = min(T, ntiles - 1);
+            p0 = ch_beg + Tc * TR + 8 * q;
+            pe = min(ch_beg + Tc * TR + TR, ch_end) - 1;
+        };
+        // a loader's index octet of a tile in its ring: {ia0 ia2 ia4 ia6 | ia1 ia3 ia5 ia7 | ig0 ig2 ig4 ig6 | ig1 ig3 ig5 ig7} (rows
+        // p0 .. p0 + 7): the four indices of an operand a lane needs -- rows 2 j + rin -- are ONE 16-byte LDS read
+        auto dma_idx = [&](int T) {
+            if constexpr (!GATHER) return;
+            int p0, pe;
+            bool live;
+            tile_rows(T, p0, pe, live);
+            const int k = 2 * (lane & 3) + ((lane >> 2) & 1);
+            const int pc = max(min(p0 + k, pe), 0);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(idx_base + (unsigned)(T % kSlots) * 64u));
+            if (lane < 16) glds4(((lane & 8) ? ig : ia) + pc, dst);
+        };
+        // Row addresses are worked out ONCE per row, not once per lane: lanes 0..15 of a loader hold its 16 rows of a tile (lane l:
+        // operand l >> 3, row 2 (l & 3) + ((l >> 2) & 1): the order of the index octet), compute base + index * 512 (+ the second
+        // source's displacement; the zero row past the chunk's end) and put the 64-bit address into the loader's address ring a
+        // tile ahead of its use; a DMA's lanes then read their row's address back (the four of an operand are two 16-byte reads)
+        // and add the in-row offset.  (Per lane and piece -- a 64-bit multiply-add, compares and four selects, x 8 -- the loaders'
+        // VALU work per tile was longer than the MFMA waves' tile: those instructions issue in the gaps the MFMAs leave.)
+        const uint64_t dA = (uint64_t)(uintptr_t)A2 - (uint64_t)(uintptr_t)A - (uint64_t)(uint32_t)na1 * ROWB;   // (A2 == NULL: never selected)
+        const uint64_t dG = (uint64_t)(uintptr_t)G2 - (uint64_t)(uintptr_t)G - (uint64_t)(uint32_t)ng1 * ROWB;
+        const int l16 = lane & 15;
+        const bool isg = (l16 & 8) != 0;
+        const int krow = 2 * (l16 & 3) + ((l16 >> 2) & 1);
+        const uint64_t obase = isg ? (uint64_t)(uintptr_t)G : (uint64_t)(uintptr_t)A;
+        const uint64_t odisp = isg ? dG : dA;
+        const int32_t on1 = isg ? ng1 : na1;
+        auto addr_pass = [&](int T) {
+            uint64_t ad;
+            if constexpr (GATHER) {
+                int p0, pe;
+                bool live;
+                tile_rows(T, p0, pe, live);
+                // rows past the chunk's end (and whole tiles past it): G reads the zero row, so the pair adds nothing; A repeats
+                // the chunk's last row (the index was clamped), unless its column sums are wanted -- then it reads the zero row too
+                const bool ok = live && p0 + krow <= pe;
+                const int32_t r = idxL[q][T % kSlots][l16];
+                ad = obase + (uint64_t)(uint32_t)r * ROWB + (r >= on1 ? odisp : 0ull);
+                ad = (!ok && (isg || colsum_of == 1)) ? (uint64_t)(uintptr_t)zero : ad;
+            } else {
+                const int p = ch_beg + T * TR + 8 * q + krow;
+                ad = p < ch_end ? obase + (uint64_t)(uint32_t)p * ROWB : (uint64_t)(uintptr_t)zero;
+            }
+            if (lane < 16) adrL[q][T % kSlots][l16] = ad;
+        };
+        auto issue = [&](int T) {                  // the row pieces of tile T (its addresses are in the ring)
+            const unsigned st = lds_base + (unsigned)(T % NST) * STB;
+            uint64_t pas[4], pgs[4];
+            {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2* ap = reinterpret_cast<const u64x2*>(&adrL[q][T % kSlots][4 * rin]);
+                const u64x2* gp = reinterpret_cast<const u64x2*>(&adrL[q][T % kSlots][8 + 4 * rin]);
+                const u64x2 a01 = ap[0], a23 = ap[1], g01 = gp[0], g23 = gp[1];
+                pas[0] = a01[0] + (uint64_t)gch[0]; pas[1] = a01[1] + (uint64_t)gch[1];
+                pas[2] = a23[0] + (uint64_t)gch[2]; pas[3] = a23[1] + (uint64_t)gch[3];
+                pgs[0] = g01[0] + (uint64_t)gch[0]; pgs[1] = g01[1] + (uint64_t)gch[1];
+                pgs[2] = g23[0] + (uint64_t)gch[2]; pgs[3] = g23[1] + (uint64_t)gch[3];
+            }
+            if constexpr (MASKED) {
+                // [A pieces] [the tile's mask bits: 32 rows x 32 bytes = ONE full-width piece, by loader T & 3] [G pieces]: masking a
+                // tile needs its A pieces and bits only
+#pragma unroll
+                for (int j = 0; j < 4; ++j) glds16(reinterpret_cast<const char*>(pas[j]), st + (unsigned)(8 * q + 2 * j) * ROWB);
+                if (q == (T & 3)) {
+                    const int p = ch_beg + T * TR + lane / 2;
+                    const char* pb = p >= ch_end ? zero + lane * 16
+                                                 : reinterpret_cast<const char*>(maskBits) + (size_t)p * (H / 8) + (lane % 2) * 16;
+                    glds16(pb, st + 2 * MATB);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) glds16(reinterpret_cast<const char*>(pgs[j]), st + (unsigned)(8 * q + 2 * j) * ROWB + MATB);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned da = st + (unsigned)(8 * q + 2 * j) * ROWB;  // wave-uniform; lane l lands at + 16 l
+                    glds16(reinterpret_cast<const char*>(pas[j]), da);
+                    glds16(reinterpret_cast<const char*>(pgs[j]), da + MATB);
+                }
+            }
+        };
+        // my four pieces of a landed tile (rows crow, crow + 16 for crow = lt / 32 and 8 + lt / 32): LDS byte offsets and, for the
+        // masked operand, the 8 columns a piece holds (the image is swizzled: position q of row r holds chunk q ^ f(r))
+        const int crowL = 2 * q + rin;             // = lt / 32
+        int coff[2], mchunk[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r = crowL + 8 * s;
+            const int f = (r & 3) | (((r >> 3) & 1) << 2);
+            const int pos = (((cpos >> 1) ^ f) << 1) | (cpos & 1);
+            coff[s] = r * ROWB + pos * 16;                                  // column sums: chunk cpos of rows r, r + 16
+            mchunk[s] = pos;                                               // mask pass: position cpos of rows r, r + 16 holds chunk `pos`
+            ochunk[s] = (MASKED && colsum_of == 1) ? pos : cpos;
+        }
+        auto add8 = [&](float* c, const uint4& v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c[2 * i] += __uint_as_float(w[i] << 16);
+                c[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+            }
+        };
+        auto mask_tile = [&](int T) {              // the A rows of tile T, in place (+ their column sums, from the registers they pass through)
+            char* sT = lds + (T % NST) * STB;
+            const uint8_t* sB = reinterpret_cast<const uint8_t*>(sT + 2 * MATB);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = crowL + 8 * s + 16 * j;
+                    uint4* pp = reinterpret_cast<uint4*>(sT + r * ROWB + cpos * 16);
+                    const uint4 v = dn_keep_or_scale_bits(*pp, sB[r * (H / 8) + mchunk[s]], slope);
+                    *pp = v;
+                    if (colsum_of == 1) add8(cs[s], v);
+                }
+        };
+        auto colsum_tile = [&](int T) {
+            if (colsum_of == 0 || (MASKED && colsum_of == 1)) return;
+            const char* M = lds + (T % NST) * STB + (colsum_of == 1 ? 0 : MATB);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) add8(cs[s], *reinterpret_cast<const uint4*>(M + coff[s] + 16 * j * ROWB));
+        };
+
+        // ---- prologue: three tiles in flight ----
+        if constexpr (GATHER) {
+#pragma unroll 1
+            for (int T = 0; T < 4; ++T) dma_idx(T);
+            wait_vmcnt<0>();
+        }
+#pragma unroll 1
+        for (int T = 0; T < 4; ++T) addr_pass(T);
+#pragma unroll 1
+        for (int s = -3; s < 0; ++s) {
+            dma_idx(s + 7);
+            issue(s + 3);
+        }
+        if constexpr (MASKED) {
+            wait_vmcnt<4 + 2 * kGroup>();                                  // my A pieces (and the bits) of tile 0 have landed
+            __builtin_amdgcn_s_barrier();
+            mask_tile(0);
+        }
+        unsigned long long st_vm = 0, st_bar = 0, st_is = 0, st_cs = 0;
+        const unsigned long long l0 = DN_WG_STAMP();
+#pragma unroll 1
+        for (int t = 0; t < ntiles; ++t) {
+            const unsigned long long a0 = DN_WG_STAMP();
+            // MODE 2: all of tile t and the A pieces + bits of tile t + 1 (its G pieces and tile t + 2 stay in flight)
+            if constexpr (MASKED) wait_vmcnt<4 + kGroup>();
+            else wait_vmcnt<2 * kGroup>();                                 // my pieces of tile t (and the octet of tile t + 3) have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my LDS reads / mask writes of the last interval are done
+            const unsigned long long a1 = DN_WG_STAMP();
+            __builtin_amdgcn_s_barrier();                                  // everyone's have; the stage of tile t - 1 is free
+            const unsigned long long a2 = DN_WG_STAMP();
+            dma_idx(t + 7);
+            issue(t + 3);
+            addr_pass(t + 4);                                              // (its index octet came with the group of barrier t - 3)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long a3 = DN_WG_STAMP();
+            if constexpr (MASKED) mask_tile(t + 1);                        // (a zero tile past the end stays zero)
+            colsum_tile(t);
+            __builtin_amdgcn_sched_barrier(0);
+            DN_WG_STAT(st_vm, a1 - a0); DN_WG_STAT(st_bar, a2 - a1); DN_WG_STAT(st_is, a3 - a2); DN_WG_STAT(st_cs, DN_WG_STAMP() - a3);
+        }
+#ifdef DN_WG_STATS
+        if (q == 0 && lane == 0 && blockIdx.x < 256) {
+            unsigned long long* o = g_wg_stats[blockIdx.x][1];
+            o[0] = DN_WG_STAMP() - l0; o[1] = st_vm; o[2] = st_bar; o[3] = st_is; o[4] = st_cs;
+        }
+#endif
+        wait_vmcnt<0>();                                                   // drain the zero tiles still in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (colsum_all != 0) {
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[(crowL + 8 * s) * H + ochunk[s] * 8 + i] = cs[s][i];
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ compute
+        const int wm = wave >> 2, wn = wave & 3;
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+        const int fsw = fq | ((fg & 1) << 2);
+        const int frow = (8 * fg + fq) * ROWB + 8 * fp;
+        // LDS byte address of this lane's part of fragment `slot` = stage | row (bits 9+) | (slot ^ fsw) << 5 | 8 fp: bit fields, so
+        // the address of slot s0 + m is the address of slot s0 XOR m << 5 -- one register per operand instead of one per fragment
+        const unsigned a_lane = lds_base + (unsigned)(frow + (((wm * MT) ^ fsw) << 5));
+        const unsigned b_lane = lds_base + (unsigned)(MATB + frow + (((wn * NT) ^ fsw) << 5));
+        // Fragment reads by inline asm with hand-counted waits (hipcc serialises them: one fragment, lgkmcnt(0), four MFMAs): a
+        // tile's four G fragments and three A fragments go out behind the barrier, row m of the MFMAs waits for ITS fragment only
+        // and the A fragment three rows on is requested right behind it.
+        struct Frag { short4v lo, hi; };
+#define DN_TR_READ(fr, addr) do {                                                                                   \
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"((fr).lo) : "v"(addr));                                  \
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"((fr).hi) : "v"(addr));                      \
+        } while (0)
+        static_assert(4 * ROWB == 2048, "offset of the fragment's second half");
+        auto val = [](const Frag& f) -> bf16x8 {
+            const short8v v = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        if constexpr (MASKED) __builtin_amdgcn_s_barrier();                // (the loaders' barrier in front of mask_tile(0))
+        unsigned long long sc_bar = 0;
+        const unsigned long long c_l0 = DN_WG_STAMP();
+#ifdef DN_WG_STATS
+        const unsigned long long c_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll 1
+        for (int t = 0; t < ntiles; ++t) {
+            const unsigned va = a_lane + (unsigned)(t % NST) * STB, vb = b_lane + (unsigned)(t % NST) * STB;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long c0 = DN_WG_STAMP();
+            __builtin_amdgcn_s_barrier();                                  // tile t is in LDS (and masked)
+            DN_WG_STAT(sc_bar, DN_WG_STAMP() - c0);
+            Frag fb[NT], fa[3];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned ad = vb ^ (unsigned)(n << 5);
+                DN_TR_READ(fb[n], ad);
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const unsigned ad = va ^ (unsigned)(m << 5);
+                DN_TR_READ(fa[m], ad);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                Frag& f = fa[m % 3];
+                // reads requested behind fragment m: the next two A fragments (while there are any)
+                if (m == 0)
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.lo), "+v"(f.hi), "+v"(fb[0].lo), "+v"(fb[0].hi), "+v"(fb[1].lo), "+v"(fb[1].hi),
+                                 "+v"(fb[2].lo), "+v"(fb[2].hi), "+v"(fb[3].lo), "+v"(fb[3].hi));
+                else if (m < MT - 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.lo), "+v"(f.hi));
+                else if (m == MT - 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f.lo), "+v"(f.hi));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi));
+                const bf16x8 av = val(f);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, val(fb[n]), acc[m][n], 0, 0, 0);
+                if (m + 3 < MT) {
+                    const unsigned ad = va ^ (unsigned)((m + 3) << 5);
+                    DN_TR_READ(f, ad);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef DN_TR_READ
+#ifdef DN_WG_STATS
+        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+            unsigned long long* o = g_wg_stats[blockIdx.x][0];
+            o[0] = DN_WG_STAMP() - c_l0; o[1] = sc_bar; o[2] = 0; o[3] = 0; o[4] = __builtin_amdgcn_s_memrealtime() - c_rt0;
+        }
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* out = partial + (size_t)blockIdx.x * H * H;
+        const int k0 = wm * (H / 2), n0 = wn * (H / 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
+                    out[(size_t)k * H + c] = acc[m][n][i];
+                }
+    }
+    if (colsum_all != 0) {
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds);
+        if (tid < H) {
+            float sum = 0.f;
+            for (int sl = 0; sl < 16; ++sl) sum += red[sl * H + tid];
             colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
         }
     }
@@ -1528,6 +1898,12 @@ int wgrad_ix_mode() {                              // tuning build: DN_WGRAD_IX=
     return mode;
 }
 
+// DN_WGRAD_LS (tuning build): bit 0 gathered operands, bit 1 row order, bit 2 row order + mask bits on rows_wgrad_ls_kernel
+int wgrad_ls_mode() {
+    static const int mode = dn_knob("DN_WGRAD_LS", 3);
+    return mode;
+}
+
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
@@ -1535,6 +1911,21 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
         if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
             if constexpr (HI == 256) {
+                const bool dense_ls = ia == nullptr && ig == nullptr && A2 == nullptr && G2 == nullptr;
+                const int ls = wgrad_ls_mode();
+                const int ls_mode = (maskBits == nullptr && ia != nullptr && ig != nullptr) ? ((ls & 1) ? 0 : -1)
+                                    : (dense_ls ? (maskBits ? ((ls & 4) ? 2 : -1) : ((ls & 2) ? 1 : -1)) : -1);
+                if (ls_mode >= 0) {                                        // loaders and MFMA waves apart
+#define DN_WGRAD_LS(M)                                                                                                  \
+                    hipLaunchKernelGGL((rows_wgrad_ls_kernel<M>), dim3((unsigned)num_chunks), dim3(kLsThreads), 0, st, A, A2, na1, ia, \
+                                       G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope)
+                    if (ls_mode == 0) DN_WGRAD_LS(0);
+                    else if (ls_mode == 1) DN_WGRAD_LS(1);
+                    else DN_WGRAD_LS(2);
+#undef DN_WGRAD_LS
+                    DN_CHECK_LAUNCH();
+                    return DN_OK;
+                }
                 if (maskBits == nullptr && ia != nullptr && ig != nullptr && wgrad_ix_mode()) {   // gathered operands: index ring
                     hipLaunchKernelGGL(rows_wgrad_ix_kernel, dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, A, A2,
                                        na1, ia, G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial);
@@ -1708,7 +2099,8 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
                "dn_rows_wgrad: mask_a_bits excludes mask_a / A2 / idx_a (the bit-masked operand is read in row order)");
     DN_REQUIRE(a_out == nullptr || (mask_a != nullptr && idx_a == nullptr), "dn_rows_wgrad: a_out needs mask_a and idx_a == NULL");
     DN_REQUIRE((reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(a_out)) % 16 == 0, "dn_rows_wgrad: unaligned mask");
-    DN_REQUIRE(colsum_of >= 0 && colsum_of <= 2 && (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
+    DN_REQUIRE(colsum_of >= 0 && (colsum_of & 0xff) <= 2 && (colsum_of >> 8) <= R && ((colsum_of & 0xff) != 0 || (colsum_of >> 8) == 0) &&
+               (colsum_of == 0 || out_colsum != nullptr), "dn_rows_wgrad: bad colsum arguments");
     DN_REQUIRE(A2 != nullptr || na1 == 0x7fffffff, "dn_rows_wgrad: A2 == NULL requires na1 == INT32_MAX");
     DN_REQUIRE(G2 != nullptr || ng1 == 0x7fffffff, "dn_rows_wgrad: G2 == NULL requires ng1 == INT32_MAX");
     DN_REQUIRE(R >= 0 && num_chunks >= 0, "dn_rows_wgrad: negative size");

@@ -218,7 +218,11 @@ def edge_norm(mode, self_loop, src, dst, in_deg, out_deg):
     return in_norm.view(-1, 1), (out_norm.view(-1, 1) if out_norm is not None else None), en
 
 
-WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))
+WGRAD_CHUNK_ROWS = int(_os.environ.get("DN_WGRAD_CHUNK", "4096"))            # step of the chunk tables cut without a look at the relation sizes
+# Chunk tables cut WITH the relation sizes (wgrad_chunk_rows, the one-call index, the dense tables) take the smallest chunk for which
+# the launch is ONE round of workgroups, up to this many rows (config 5: 775 chunks of 4,096 rows = 3.03 rounds of 256 workgroups and
+# 203 MB of partial products became 245 chunks of 12,864 rows and 64 MB: conv weight gradient + reduce 534 -> 473 us, round 6)
+WGRAD_CHUNK_CAP = max(WGRAD_CHUNK_ROWS, int(_os.environ.get("DN_WGRAD_CHUNK_CAP", "65536")))
 # fp32 matrix products: False = 3-term bf16 split on the fast MFMA path (1e-5-level agreement with exact f32, inside the
 # reference's 1e-4 bar), True = exact f32 MFMA (1/16 of the bf16 rate; the checker).  F32_EXACT is the PROCESS default (read once
 # from the environment; assignable); `with f32_exact(...)` overrides it for the calling THREAD only, and every autograd function
@@ -279,11 +283,12 @@ INT32_MAX = 0x7fffffff
 
 
 def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=None, A2=None, G2=None, colsum_of=0,
-               mask_a=None, a_out=None, mask_a_bits=None, colsum_lp=False, slope=0.0):
+               mask_a=None, a_out=None, mask_a_bits=None, colsum_lp=False, slope=0.0, colsum_rel=None):
     """out[r] = sum_{p in relation r} Acat[idx_a[p]]^T Gcat[idx_g[p]]  (dn_rows_wgrad_bf16; bf16 in, fp32 accumulate).
     Acat = [A; A2], Gcat = [G; G2] (virtual concatenations).  colsum_of = 1|2 additionally returns the fp32 per-relation
     column sums [R, H] of operand A|G (the bias gradient); colsum_lp: return them in out's dtype instead (bf16 output: written
-    by the reduce launch itself, so the bias gradient needs no cast launch)."""
+    by the reduce launch itself, so the bias gradient needs no cast launch); colsum_rel (bf16): the column sums of that relation's
+    rows only, the other rows of the result are zeros."""
     chunks, chunk_ptr, nchunks = chunk_table
     require_gpu(A, G, idx_a, idx_g, chunks, chunk_ptr, A2, G2, mask_a, a_out, mask_a_bits)
     assert A.dtype == G.dtype and A.dtype in (torch.bfloat16, torch.float32)
@@ -312,7 +317,9 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
         else:
             check(lib().dn_rows_wgrad_bf16(ptr(A), ptr(A2), na1, ptr(idx_a), ptr(G), ptr(G2), ng1, ptr(idx_g), Hi, Ho, num_rels,
                                            ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
-                                           1 if out_dtype == torch.float32 else 0, int(colsum_of), ptr(colsum), ptr(mask_a),
+                                           1 if out_dtype == torch.float32 else 0,
+                                           int(colsum_of) | (((int(colsum_rel) + 1) << 8) if (colsum_of and colsum_rel is not None) else 0),
+                                           ptr(colsum), ptr(mask_a),
                                            ptr(a_out), ptr(mask_a_bits), ptr(colsum_lp), float(slope), ptr(ws), ws.numel(), stream_ptr()),
                   "dn_rows_wgrad_bf16")
 
@@ -365,16 +372,16 @@ def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
 def wgrad_chunk_rows(rel_ptr_host, workgroups=256):
     """Rows per split-K chunk of the weight gradient over relation-major rows: the smallest multiple of 64 (>= 256) for which the
     chunks of all relations -- every relation ends in a partial chunk -- fit ONE round of `workgroups`; batches too large for
-    that keep WGRAD_CHUNK_ROWS (several rounds).  (A 1/8 shard of config 5 cut by rows / 256 alone made 270 chunks: a second
-    round for 14 workgroups, 138 us instead of 80.)"""
+    that (over 256 x WGRAD_CHUNK_CAP rows) keep WGRAD_CHUNK_CAP and run several rounds.  (A 1/8 shard of config 5 cut by rows / 256
+    alone made 270 chunks: a second round for 14 workgroups, 138 us instead of 80.)"""
     sizes = [int(b) - int(a) for a, b in zip(rel_ptr_host[:-1], rel_ptr_host[1:]) if int(b) > int(a)]
     total = sum(sizes)
     if total == 0:
         return 256
     c = max(256, -(-total // workgroups // 64) * 64)
-    while c < WGRAD_CHUNK_ROWS and sum(-(-n // c) for n in sizes) > workgroups:
+    while c < WGRAD_CHUNK_CAP and sum(-(-n // c) for n in sizes) > workgroups:
         c += 64
-    return min(c, WGRAD_CHUNK_ROWS)
+    return min(c, WGRAD_CHUNK_CAP)
 
 
 def build_row_tables(rel_ptr_dev, num_rels, num_rows, step, want_ptr=False, skip_mask=0):
@@ -1385,7 +1392,7 @@ class RowIndex:
                     ptr(gt_bufs[0][1]), ptr(gt_bufs[1][0]), ptr(gt_bufs[1][1]), host_absorb, num_wg, cus[0].order, cap, ptr(cus[0].unit_ptr),
                     ptr(cus[0].units), ptr(cus[0].ent_row), ptr(cus[0].ent_mask), ptr(cus[1].unit_ptr), ptr(cus[1].units),
                     ptr(cus[1].ent_row), ptr(cus[1].ent_mask), kper, tcap, *mt_ptr, SWEEP_WG_PER_GROUP, S, ptr(sweeps[0]), ptr(sweeps[1]), 256,
-                    WGRAD_CHUNK_ROWS, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),
+                    WGRAD_CHUNK_CAP, chunk_cap, ptr(chunk_tab), ptr(chunk_pp), host_plan, ptr(ws), ws.numel(), stream_ptr()),
                     "dn_conv_index_build_i32")
                 if status.value == 0:
                     self.built_by = "local"
@@ -2058,7 +2065,8 @@ class _RowTransformFn(torch.autograd.Function):
                 aux = auxs[part] if ix.num_aux_f else None
                 # bias gradient = column sum of g over the self-loop rows (one per node), folded into the same kernel
                 gw, cs = rows_wgrad(xs, gs, ix.chunk_table, R_all, idx_a=ix.row_in, idx_g=ix.row_out, A2=aux,
-                                    G2=aux_b, out_dtype=W.dtype if single else torch.float32, colsum_of=2, colsum_lp=single)
+                                    G2=aux_b, out_dtype=W.dtype if single else torch.float32, colsum_of=2, colsum_lp=single,
+                                    colsum_rel=R_all - 1)                  # (gb = cs32[-1] below: the other relations' sums are not used)
                 gW32 = gw if gW32 is None else gW32.add_(gw)
                 cs32 = cs if cs32 is None else cs32.add_(cs)
         gW = gL = gb = None
@@ -2138,7 +2146,7 @@ def _dense_table(n_rows, dev):
     if t is None:
         # split-K chunks sized for ONE round of 256 workgroups whatever the row count (a 20 k-row GC batch with 4096-row chunks
         # would run its weight gradient on five workgroups; 378 chunks of a 1 M-row batch would run one and a half rounds)
-        chunk = max(256, min(WGRAD_CHUNK_ROWS, -(-int(n_rows) // 256 // 64) * 64))
+        chunk = max(256, min(WGRAD_CHUNK_CAP, -(-int(n_rows) // 256 // 64) * 64))
         t = (make_row_tiles([0, int(n_rows)], dev), make_row_chunks([0, int(n_rows)], dev, chunk_rows=chunk))
         if len(_dense_tables) > 8:
             _dense_tables.clear()

@@ -410,7 +410,9 @@ int dn_slot_table_build_i32(int64_t N, int32_t num_edge_rows, int32_t K, const i
  * idx_a / idx_g may be NULL (row p itself); A2/na1 and G2/ng1 give each operand a second row source exactly as
  * in dn_rows_transform_bf16.  Supported: Hi == Ho in {64, 128, 256}.  out is fp32 or bf16.
  * colsum_of = 1 (A) or 2 (G) also returns out_colsum[r, :] = sum over relation r's rows of that operand (fp32 [R, H]):
- * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL).
+ * the bias gradient, taken from the rows while they are staged (0 = off, out_colsum may be NULL).  dn_rows_wgrad_bf16 takes
+ * (r + 1) << 8 on top: the column sums of relation r's rows ONLY (the other rows of out_colsum are returned as zeros) -- the
+ * reference's bias sees one relation's rows (the self loop's, rgin.py:156-160), and summing the rest costs a sixth of the launch.
  * mask_a (may be NULL; needs A2 == NULL): A rows are first zeroed where mask_a[row, k] <= 0 (ReLU backward folded into the
  * staging); a_out (may be NULL; needs idx_a == NULL) receives those masked rows, so the elementwise pass disappears.
  * mask_a_bits (may be NULL; excludes mask_a, A2 and idx_a: the bit-masked operand is read in row order): the same mask as
