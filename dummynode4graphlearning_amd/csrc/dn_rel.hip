@@ -824,7 +824,8 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
                                                                    int32_t ng1, const int32_t* __restrict__ ig,
                                                                    const Chunk* __restrict__ chunks, float* __restrict__ partial,
                                                                    int32_t colsum_arg, float* __restrict__ colsum_partial,
-                                                                   const uint8_t* __restrict__ maskBits, float slope) {
+                                                                   const uint8_t* __restrict__ maskBits, float slope,
+                                                                   const int32_t* __restrict__ chunk_ptr) {
     constexpr bool GATHER = MODE == 0, MASKED = MODE == 2;
     constexpr int H = 256, TR = 32, NST = 4, ROWB = 2 * H, MATB = TR * ROWB, BITB = MASKED ? 1024 : 0, STB = 2 * MATB + BITB;
     constexpr int LPRW = H / 8;                    // 32 lanes per row
@@ -840,8 +841,23 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Chunk ch = chunks[blockIdx.x];
     const int32_t colsum_all = colsum_arg & 0xff, colsum_of = colsum_for(colsum_arg, ch.rel);   // (a chunk of another relation: zeros)
-    const int ntiles = (ch.end - ch.beg + TR - 1) / TR;
-    const int32_t ch_beg = ch.beg, ch_end = ch.end;
+    // Tile T of this workgroup = rows [ch_beg + T * t_step, + 32) below ch_end.  chunk_ptr == NULL: the chunk's rows, t_step = 32.
+    // chunk_ptr given (MODE 0): the K chunks of a relation are taken as K INTERLEAVED pieces of the relation's rows -- piece k =
+    // tiles k, k + K, k + 2 K, ... -- so that all workgroups walk the node range at the same pace and the relations that share an
+    // x / g row ask for it within a few tiles of each other (the partial of chunk i is then the sum over piece i's tiles; the
+    // reduce adds a relation's partials as before).
+    int32_t ch_beg = ch.beg, ch_end = ch.end, t_step = TR;
+    int ntiles = (ch.end - ch.beg + TR - 1) / TR;
+    if (GATHER && chunk_ptr != nullptr) {
+        const int32_t c0 = chunk_ptr[ch.rel], c1 = chunk_ptr[ch.rel + 1];
+        ntiles = 0;
+        if ((int32_t)blockIdx.x >= c0 && (int32_t)blockIdx.x < c1) {         // (entries past the last chunk: empty pieces)
+            ch_beg = chunks[c0].beg + TR * ((int32_t)blockIdx.x - c0);
+            ch_end = chunks[c1 - 1].end;
+            t_step = TR * (c1 - c0);
+            ntiles = ch_beg < ch_end ? (ch_end - ch_beg + t_step - 1) / t_step : 0;
+        }
+    }
     if (ntiles <= 0) {                             // (chunk tables never hold empty chunks; guard anyway)
         for (int i = tid; i < H * H; i += kLsThreads) partial[(size_t)blockIdx.x * H * H + i] = 0.f;
         if (colsum_all != 0 && tid < H) colsum_partial[(size_t)blockIdx.x * H + tid] = 0.f;
@@ -872,8 +888,8 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
         auto tile_rows = [&](int T, int& p0, int& pe, bool& live) {
             live = T < ntiles;
             const int Tc = min(T, ntiles - 1);
-            p0 = ch_beg + Tc * TR + 8 * q;
-            pe = min(ch_beg + Tc * TR + TR, ch_end) - 1;
+            p0 = ch_beg + Tc * t_step + 8 * q;
+            pe = min(ch_beg + Tc * t_step + TR, ch_end) - 1;
         };
         // a loader's index octet of a tile in its ring: {ia0 ia2 ia4 ia6 | ia1 ia3 ia5 ia7 | ig0 ig2 ig4 ig6 | ig1 ig3 ig5 ig7} (rows
         // p0 .. p0 + 7): the four indices of an operand a lane needs -- rows 2 j + rin -- are ONE 16-byte LDS read
@@ -967,12 +983,15 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
             mchunk[s] = pos;                                               // mask pass: position cpos of rows r, r + 16 holds chunk `pos`
             ochunk[s] = (MASKED && colsum_of == 1) ? pos : cpos;
         }
-        auto add8 = [&](float* c, const uint4& v) {
+        auto add8 = [&](float* c, const uint4& v) {   // (pairs: one v_pk_add_f32 per dword)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                c[2 * i] += __uint_as_float(w[i] << 16);
-                c[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                const f32x2 a = {c[2 * i], c[2 * i + 1]}, b = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+                const f32x2 r = a + b;
+                c[2 * i] = r[0];
+                c[2 * i + 1] = r[1];
             }
         };
         auto mask_tile = [&](int T) {              // the A rows of tile T, in place (+ their column sums, from the registers they pass through)
@@ -1898,6 +1917,11 @@ int wgrad_ix_mode() {                              // tuning build: DN_WGRAD_IX=
     return mode;
 }
 
+int wgrad_il_mode() {                              // tuning build: DN_WGRAD_IL=0 keeps a relation's chunks contiguous
+    static const int mode = dn_knob("DN_WGRAD_IL", 1);
+    return mode;
+}
+
 // DN_WGRAD_LS (tuning build): bit 0 gathered operands, bit 1 row order, bit 2 row order + mask bits on rows_wgrad_ls_kernel
 int wgrad_ls_mode() {
     static const int mode = dn_knob("DN_WGRAD_LS", 3);
@@ -1907,7 +1931,8 @@ int wgrad_ls_mode() {
 template <int HI, int HO>
 int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* ia, const bf16_t* G, const bf16_t* G2,
                  int32_t ng1, const int32_t* ig, const Chunk* chunks, int64_t num_chunks, float* partial, int32_t colsum_of,
-                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, float slope, hipStream_t st) {
+                 float* cs_partial, const bf16_t* maskA, bf16_t* A_out, const uint8_t* maskBits, float slope, hipStream_t st,
+                 const int32_t* chunk_ptr = nullptr) {
     if constexpr (HI == HO && (HI == 256 || HI == 128)) {
         if (maskA == nullptr && A_out == nullptr && wgrad_dma_mode() >= (HI == 256 ? 1 : 2)) {
             if constexpr (HI == 256) {
@@ -1918,7 +1943,8 @@ int launch_wgrad(const bf16_t* A, const bf16_t* A2, int32_t na1, const int32_t* 
                 if (ls_mode >= 0) {                                        // loaders and MFMA waves apart
 #define DN_WGRAD_LS(M)                                                                                                  \
                     hipLaunchKernelGGL((rows_wgrad_ls_kernel<M>), dim3((unsigned)num_chunks), dim3(kLsThreads), 0, st, A, A2, na1, ia, \
-                                       G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope)
+                                       G, G2, ng1, ig, chunks, partial, colsum_of, cs_partial, maskBits, slope,                     \
+                                       (M == 0 && wgrad_il_mode()) ? chunk_ptr : nullptr)
                     if (ls_mode == 0) DN_WGRAD_LS(0);
                     else if (ls_mode == 1) DN_WGRAD_LS(1);
                     else DN_WGRAD_LS(2);
@@ -2123,7 +2149,7 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
         const bf16_t* mk = (const bf16_t*)mask_a;
         bf16_t* ao = (bf16_t*)a_out;
         const uint8_t* mb = (const uint8_t*)mask_a_bits;
-        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
+        if (Hi == 256) rc = launch_wgrad<256, 256>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st, chunk_ptr);
         else if (Hi == 128) rc = launch_wgrad<128, 128>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
         else rc = launch_wgrad<64, 64>(a, a2, na1, idx_a, g, g2, ng1, idx_g, ch, num_chunks, ws, colsum_of, csp, mk, ao, mb, act_slope, st);
         if (rc != DN_OK) return rc;

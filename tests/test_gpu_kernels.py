@@ -588,6 +588,60 @@ def test_rows_wgrad_with_bit_mask_and_chain2(H):
     assert float((g0.cpu().double() - rg0).abs().max() / rg0.abs().max()) < 6e-3
 
 
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 95, 97, 1000, 8191, 70001])
+def test_wgrad_ring_kernel_with_loader_waves_at_every_pipeline_length(rows):
+    """rows_wgrad_ls_kernel (csrc/dn_rel.hip: four loader waves, eight MFMA waves; H = 256 bf16) from one row -- every look-ahead
+    tile past the end -- to many tiles per workgroup with ragged ends, in its three forms: gathered operands with second sources
+    (the conv's weight gradient; a relation's chunks taken as interleaved pieces, some of them EMPTY when a relation has fewer
+    tiles than chunks, and a table with unused entries behind the last chunk), rows in order (the MLP's), rows in order with the
+    A operand masked by bits.  Against fp64 sums of the same bf16 operands; column sums of every relation and of one relation
+    only (dn_rows_wgrad_bf16's colsum_of | (relation + 1) << 8); run-to-run bitwise equal."""
+    ops = _ops()
+    H, R = 256, 4
+    rng = np.random.default_rng(rows)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    d = lambda t: t.to(DEV)  # noqa: E731
+    sizes = [rows, 0, max(1, rows // 7), 3 * rows + 5]
+    rel_ptr = [0] + [int(v) for v in np.cumsum(sizes)]
+    P, NA, NG = rel_ptr[-1], 700, 900
+    A, A2, G, G2 = bf(rng.standard_normal((NA, H))), bf(rng.standard_normal((300, H))), bf(rng.standard_normal((NG, H))), bf(rng.standard_normal((200, H)))
+    ia = torch.from_numpy(rng.integers(0, NA + 300, size=P)).to(torch.int32)
+    ig = torch.from_numpy(rng.integers(0, NG + 200, size=P)).to(torch.int32)
+    Acat, Gcat = torch.cat([A, A2]).double(), torch.cat([G, G2]).double()
+    ref = torch.stack([Acat[ia[a:b].long()].t() @ Gcat[ig[a:b].long()] for a, b in zip(rel_ptr[:-1], rel_ptr[1:])])
+    cs_ref = torch.stack([Gcat[ig[a:b].long()].sum(0) for a, b in zip(rel_ptr[:-1], rel_ptr[1:])])
+    scale = max(1.0, float(ref.abs().max()))
+    # a device-built table (an upper bound of entries: empty pieces behind the last chunk) and a host-built one with small chunks
+    rel_ptr_d = torch.tensor(rel_ptr, dtype=torch.int32, device=DEV)
+    for table in (ops.build_row_tables(rel_ptr_d, R, P, 256, want_ptr=True), ops.make_row_chunks(rel_ptr, DEV, chunk_rows=64),
+                  ops.make_row_chunks(rel_ptr, DEV, chunk_rows=1 << 20)):
+        kw = dict(idx_a=d(ia), idx_g=d(ig), A2=d(A2), G2=d(G2), out_dtype=torch.float32)
+        got, cs = ops.rows_wgrad(d(A), d(G), table, R, colsum_of=2, **kw)
+        assert float((got.cpu().double() - ref).abs().max()) / scale < 1e-5
+        assert float((cs.cpu().double() - cs_ref).abs().max()) < 1e-3 * max(1.0, float(cs_ref.abs().max()))
+        got1, cs1 = ops.rows_wgrad(d(A), d(G), table, R, colsum_of=2, colsum_rel=3, **kw)
+        assert torch.equal(got, got1) and torch.equal(cs1[3], cs[3]) and not cs1[:3].any()
+        again, cs_again = ops.rows_wgrad(d(A), d(G), table, R, colsum_of=2, **kw)
+        assert torch.equal(got, again) and torch.equal(cs, cs_again)
+    # rows in order: plain, and with the A operand masked by bits (+ the masked operand's column sums)
+    M = min(P, 650)
+    bits = torch.from_numpy(rng.integers(0, 256, size=(M, H // 8)).astype(np.uint8))
+    keep = ((bits.unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(M, H).bool()
+    _, dense = ops._dense_table(M, torch.device(DEV))
+    a, g = A[:M].contiguous(), G[:M].contiguous()
+    got, cs = ops.rows_wgrad(d(a), d(g), dense, 1, out_dtype=torch.float32, colsum_of=1)
+    ref2 = a.double().t() @ g.double()
+    assert float((got[0].cpu().double() - ref2).abs().max()) / max(1.0, float(ref2.abs().max())) < 1e-5
+    assert float((cs[0].cpu().double() - a.double().sum(0)).abs().max()) < 1e-3 * max(1.0, float(a.double().sum(0).abs().max()))
+    for slope in (0.0, 0.25):
+        am = torch.where(keep, a.double(), a.double() * slope)
+        got, cs = ops.rows_wgrad(d(a), d(g), dense, 1, out_dtype=torch.float32, colsum_of=1, mask_a_bits=d(bits), slope=slope)
+        am = torch.where(keep, a, (a.float() * slope).to(torch.bfloat16)).double()      # (the scaled rows are rounded to bf16 in the tile)
+        ref3 = am.t() @ g.double()
+        assert float((got[0].cpu().double() - ref3).abs().max()) / max(1.0, float(ref3.abs().max())) < 1e-5
+        assert float((cs[0].cpu().double() - am.sum(0)).abs().max()) < 1e-3 * max(1.0, float(am.sum(0).abs().max()))
+
+
 @pytest.mark.parametrize("N", [1, 31, 32, 33, 257, 8191, 8224, 300001])
 @pytest.mark.parametrize("slope", [0.0, 1.0 / 5.5])
 def test_chain2_ring_kernel_at_every_pipeline_length(N, slope):
