@@ -217,13 +217,14 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32_kernel(const float* _
 // 3-term split twin of the weight gradient: the four bf16 tiles Ah, Al, Gh, Gl of a 32-row stage sit row-major in LDS
 // ([32][H + 8], as the bf16 kernel's), fragments come through the transposing LDS read, three MFMAs per (m, n) pair.
 template <int H>
-__global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* __restrict__ A, const float* __restrict__ A2,
-                                                                   int32_t na1, const int32_t* __restrict__ ia,
-                                                                   const float* __restrict__ G, const float* __restrict__ G2,
-                                                                   int32_t ng1, const int32_t* __restrict__ ig,
-                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
-                                                                   int32_t colsum_of, float* __restrict__ colsum_partial,
-                                                                   const float* __restrict__ maskA, float* __restrict__ A_out, float slope) {
+__device__ __forceinline__ void rows_wgrad_f32s_body(const float* __restrict__ A, const float* __restrict__ A2,
+                                                     int32_t na1, const int32_t* __restrict__ ia,
+                                                     const float* __restrict__ G, const float* __restrict__ G2,
+                                                     int32_t ng1, const int32_t* __restrict__ ig,
+                                                     const Chunk ch, float* __restrict__ partial,
+                                                     int32_t colsum_of, float* __restrict__ colsum_partial,
+                                                     const float* __restrict__ maskA, float* __restrict__ A_out, float slope,
+                                                     bool zero_colsum) {
     constexpr int S = H + 8;                                    // bf16 elements per LDS row
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
     constexpr int NP = kRows * H / 4;                           // 4-float pieces per operand tile
@@ -231,7 +232,6 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* 
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 4 * kRows * S];
     auto tile = [&](int b, int which) -> bf16_t* { return lds + (b * 4 + which) * (kRows * S); };   // 0 Ah, 1 Al, 2 Gh, 3 Gl
 
-    const Chunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = (wave >> 2) * (H / 2), n0 = (wave & 3) * (H / 4);
     const int ntiles = (ch.end - ch.beg + kRows - 1) / kRows;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* 
                 const int k = k0 + m * 16 + (lane >> 4) * 4 + i, c = n0 + n * 16 + (lane & 15);
                 out[(size_t)k * H + c] = acc[m][n][i];
             }
-    if (colsum_of != 0) {
+    if (colsum_of != 0 || zero_colsum) {                         // (a job without column sums in a multi-job launch: zeros)
         constexpr int TPC = kThreads / (H / 4);
         float* red = reinterpret_cast<float*>(lds);
         const int cchunk = tid % (H / 4), slot = tid / (H / 4);
@@ -352,6 +352,43 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* 
             colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
         }
     }
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                                   int32_t na1, const int32_t* __restrict__ ia,
+                                                                   const float* __restrict__ G, const float* __restrict__ G2,
+                                                                   int32_t ng1, const int32_t* __restrict__ ig,
+                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                   int32_t colsum_of, float* __restrict__ colsum_partial,
+                                                                   const float* __restrict__ maskA, float* __restrict__ A_out, float slope) {
+    rows_wgrad_f32s_body<H>(A, A2, na1, ia, G, G2, ng1, ig, chunks[blockIdx.x], partial, colsum_of, colsum_partial, maskA, A_out, slope, false);
+}
+
+// Several weight gradients in one launch (dn_rows_wgrad_multi_f32; as rows_wgrad_multi_kernel of dn_rel.hip): the jobs' relations are
+// numbered through, their rows lie end to end in one virtual row space that the chunk table covers; a chunk finds its job by its
+// relation (selects between the argument sets, not an indexed read: the struct lives in kernel-argument SGPRs).
+struct WgJobF {
+    const float *A, *A2;
+    const int32_t* ia;
+    const float *G, *G2;
+    const int32_t* ig;
+    int32_t na1, ng1, colsum_of, first_rel, row0;
+};
+struct WgJobsF {
+    WgJobF j[3];
+    int32_t n;
+};
+template <int H>
+__global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_multi_kernel(WgJobsF jobs, const Chunk* __restrict__ chunks,
+                                                                         float* __restrict__ partial, float* __restrict__ colsum_partial) {
+    Chunk ch = chunks[blockIdx.x];
+    int k = 0;
+    if (jobs.n > 1 && ch.rel >= jobs.j[1].first_rel) k = 1;
+    if (jobs.n > 2 && ch.rel >= jobs.j[2].first_rel) k = 2;
+    const WgJobF J = k == 0 ? jobs.j[0] : (k == 1 ? jobs.j[1] : jobs.j[2]);
+    ch.beg -= J.row0; ch.end -= J.row0;
+    rows_wgrad_f32s_body<H>(J.A, J.A2, J.na1, J.ia, J.G, J.G2, J.ng1, J.ig, ch, partial, J.colsum_of, colsum_partial, nullptr, nullptr, 0.f, true);
 }
 
 // out[r] = sum of chunk partials (same slice-parallel fixed-order fold as the bf16 library's reducer)
@@ -771,6 +808,49 @@ int dn_rows_wgrad_f32(const float* A, const float* A2, int32_t na1, const int32_
     const float* cspc = colsum_of ? csp : nullptr;
     dim3 grid((unsigned)(dn_cdiv(tile, 32) + (cspc ? dn_cdiv(Hi, 32) : 0)), (unsigned)R);
     hipLaunchKernelGGL(wgrad_reduce_f32_kernel, grid, dim3(256), 0, st, (const float*)ws, chunk_ptr, tile, out, cspc, Hi, out_colsum);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                            const int32_t* chunk_ptr, float* out, float* out_colsum, void* workspace, size_t workspace_bytes,
+                            dn_stream_t stream) {
+    DN_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= 3, "dn_rows_wgrad_multi_f32: 1 .. 3 jobs");
+    DN_REQUIRE(H == 64 || H == 128, "dn_rows_wgrad_multi_f32: unsupported width %d (64 / 128: the widths whose launches are latency)", H);
+    DN_REQUIRE(R >= 1 && num_chunks >= 0, "dn_rows_wgrad_multi_f32: bad sizes");
+    DN_REQUIRE(out && chunk_ptr && out_colsum, "dn_rows_wgrad_multi_f32: NULL pointer");
+    DN_REQUIRE(num_chunks == 0 || (chunks && workspace), "dn_rows_wgrad_multi_f32: NULL pointer");
+    DN_REQUIRE(workspace_bytes >= (size_t)num_chunks * ((size_t)H * H + H) * sizeof(float), "dn_rows_wgrad_multi_f32: workspace too small");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out_colsum)) % 16 == 0,
+               "dn_rows_wgrad_multi_f32: workspace / out_colsum must be 16-byte aligned");
+    WgJobsF wj;
+    wj.n = num_jobs;
+    for (int k = 0; k < 3; ++k) {
+        const dn_wgrad_job& q = jobs[k < num_jobs ? k : 0];
+        DN_REQUIRE(q.A && q.G, "dn_rows_wgrad_multi_f32: NULL operand");
+        DN_REQUIRE((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.G) | reinterpret_cast<uintptr_t>(q.A2) |
+                    reinterpret_cast<uintptr_t>(q.G2)) % 16 == 0, "dn_rows_wgrad_multi_f32: unaligned input");
+        DN_REQUIRE(q.A2 != nullptr || q.na1 == 0x7fffffff, "dn_rows_wgrad_multi_f32: A2 == NULL requires na1 == INT32_MAX");
+        DN_REQUIRE(q.G2 != nullptr || q.ng1 == 0x7fffffff, "dn_rows_wgrad_multi_f32: G2 == NULL requires ng1 == INT32_MAX");
+        DN_REQUIRE(q.colsum_of >= 0 && q.colsum_of <= 2 && q.first_rel >= 0 && q.row0 >= 0, "dn_rows_wgrad_multi_f32: bad job");
+        DN_REQUIRE(q.mask_a_bits == nullptr, "dn_rows_wgrad_multi_f32: no masks here (the fp32 rows arrive masked)");
+        DN_REQUIRE(k == 0 || k >= num_jobs || q.first_rel > jobs[k - 1].first_rel, "dn_rows_wgrad_multi_f32: jobs must ascend in first_rel");
+        wj.j[k] = WgJobF{(const float*)q.A, (const float*)q.A2, q.idx_a, (const float*)q.G, (const float*)q.G2, q.idx_g, q.na1, q.ng1,
+                         q.colsum_of, q.first_rel, q.row0};
+    }
+    DN_REQUIRE(jobs[0].first_rel == 0, "dn_rows_wgrad_multi_f32: the first job starts at relation 0");
+    hipStream_t st = (hipStream_t)stream;
+    const Chunk* ch = reinterpret_cast<const Chunk*>(chunks);
+    float* ws = (float*)workspace;
+    const int64_t tile = (int64_t)H * H;
+    float* csp = ws + (size_t)num_chunks * tile;
+    if (num_chunks > 0) {
+        if (H == 128) hipLaunchKernelGGL((rows_wgrad_f32s_multi_kernel<128>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, wj, ch, ws, csp);
+        else hipLaunchKernelGGL((rows_wgrad_f32s_multi_kernel<64>), dim3((unsigned)num_chunks), dim3(kThreads), 0, st, wj, ch, ws, csp);
+        DN_CHECK_LAUNCH();
+    }
+    dim3 grid((unsigned)(dn_cdiv(tile, 32) + dn_cdiv(H, 32)), (unsigned)R);
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, grid, dim3(256), 0, st, (const float*)ws, chunk_ptr, tile, out, (const float*)csp, H, out_colsum);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -333,7 +333,7 @@ def rows_wgrad(A, G, chunk_table, num_rels, idx_a=None, idx_g=None, out_dtype=No
 
 
 def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
-    """Several weight gradients in ONE launch + ONE reduce (dn_rows_wgrad_multi_bf16, bf16, H = 64 / 128).  jobs: dicts with A, G
+    """Several weight gradients in ONE launch + ONE reduce (dn_rows_wgrad_multi_bf16 / _f32 on the bf16 split, H = 64 / 128).  jobs: dicts with A, G
     (and optionally A2, G2, idx_a, idx_g, mask_a_bits, colsum_of, slope), first_rel, row0 -- relations numbered through, rows laid
     end to end in one virtual row space that chunk_table covers.  -> (out [num_rels, H, H], colsum [num_rels, H]) in out_dtype."""
     chunks, chunk_ptr, nchunks = chunk_table
@@ -343,7 +343,8 @@ def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
     for k, jb in enumerate(jobs):
         A, G = jb["A"], jb["G"]
         require_gpu(A, G, jb.get("A2"), jb.get("G2"), jb.get("idx_a"), jb.get("idx_g"), jb.get("mask_a_bits"))
-        assert A.dtype == G.dtype == torch.bfloat16 and A.shape[1] == G.shape[1] == H and A.is_contiguous() and G.is_contiguous()
+        assert A.dtype == G.dtype == jobs[0]["A"].dtype and A.dtype in (torch.bfloat16, torch.float32)
+        assert A.shape[1] == G.shape[1] == H and A.is_contiguous() and G.is_contiguous()
         keep.append(jb)
         pv = lambda t: (t.data_ptr() if t is not None else None)  # noqa: E731
         arr[k].A, arr[k].A2, arr[k].idx_a = pv(A), pv(jb.get("A2")), pv(jb.get("idx_a"))
@@ -353,12 +354,19 @@ def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
         arr[k].ng1 = G.shape[0] if jb.get("G2") is not None else INT32_MAX
         arr[k].colsum_of, arr[k].first_rel, arr[k].row0 = int(jb.get("colsum_of", 0)), int(jb["first_rel"]), int(jb["row0"])
         arr[k].act_slope = float(jb.get("slope", 0.0))
+    is_f32 = jobs[0]["A"].dtype == torch.float32
+    if is_f32:
+        assert out_dtype == torch.float32 and not f32_mode() and all(jb.get("mask_a_bits") is None for jb in jobs)
     out = torch.empty((num_rels, H, H), dtype=out_dtype, device=dev)
     colsum = torch.empty((num_rels, H), dtype=torch.float32, device=dev)
     colsum_lp = torch.empty((num_rels, H), dtype=out_dtype, device=dev) if out_dtype != torch.float32 else None
     ws = _ws(lib().dn_rows_wgrad_workspace_bytes(nchunks, H, H), dev)
 
     def _launch():
+        if is_f32:                                                          # fp32 rows on the 3-term bf16 split
+            check(lib().dn_rows_wgrad_multi_f32(arr, len(jobs), H, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out), ptr(colsum),
+                                                ptr(ws), ws.numel(), stream_ptr()), "dn_rows_wgrad_multi_f32")
+            return
         check(lib().dn_rows_wgrad_multi_bf16(arr, len(jobs), H, num_rels, ptr(chunks), nchunks, ptr(chunk_ptr), ptr(out),
                                              1 if out_dtype == torch.float32 else 0, ptr(colsum), ptr(colsum_lp), ptr(ws), ws.numel(),
                                              stream_ptr()), "dn_rows_wgrad_multi_bf16")
@@ -2358,6 +2366,80 @@ class _RginLayerSmallFn(torch.autograd.Function):
         gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, W.dtype)
         return (gx, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1], cs[R + 1] if ctx.has[1] else None, gw[R + 2],
                 cs[R + 2] if ctx.has[2] else None)
+
+
+LAYER_F32_ENABLED = _os.environ.get("DN_LAYER_F32", "1") != "0"
+
+
+def rgin_layer_f32_ok(x, W, W_loop, bias, linears, index_set):
+    """Can a whole fp32 RGIN layer run as _RginLayerF32Fn?  The reference's precision on the bf16 split (not the exact-f32 mode),
+    H = 64 / 128, square, self loop, two square Linears, one part."""
+    if not (LAYER_F32_ENABLED and W_loop is not None and len(linears) == 2 and len(index_set.parts) == 1 and not f32_mode()):
+        return False
+    H = x.shape[1] if x.dim() == 2 else 0
+    ok = lambda t: t is None or (t.is_cuda and t.dtype == torch.float32)  # noqa: E731
+    return (x.is_cuda and x.dtype == torch.float32 and H in (64, 128) and x.shape[0] > 0 and tuple(W.shape[1:]) == (H, H)
+            and W.dtype == x.dtype and tuple(W_loop.shape) == (H, H) and ok(W_loop) and ok(bias)
+            and all(ok(l.weight) and ok(l.bias) and tuple(l.weight.shape) == (H, H) for l in linears)
+            and index_set.parts[0][2].num_rows > 0 and _kn_ok(x))
+
+
+class _RginLayerF32Fn(torch.autograd.Function):
+    """act(lin2(act(lin1(conv(x))))) of an RGIN layer in the reference's own precision (fp32 on the 3-term bf16 split) at H = 64 / 128
+    (rgin.py:102-160 + 50-57; BASELINE config 3 as the reference runs it) as ONE autograd function: the forward launches are those of
+    _RowTransformFn + _ReluMlpFn; the backward masks the incoming gradient once (dn_relu_bwd_f32), runs the two input-gradient launches
+    (the inner mask in the first one's epilogue), the conv's input-gradient pass, and then ONE weight-gradient launch + ONE reduce for
+    the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_f32) where the separate functions take three of each."""
+
+    @staticmethod
+    def forward(ctx, x, slope, index_set, W, W_loop, bias, w1, b1, w2, b2):
+        ctx.f32_mode = f32_mode()
+        x = x.contiguous()
+        ix = index_set.parts[0][2]
+        N, H = x.shape
+        slope = float(slope)
+        h = torch.empty_like(x)
+        aux = message_pass(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", index_set.ybuf(H, x.dtype, x.device), h)
+        tiles, _ = _dense_table(N, x.device)
+        h1 = rows_transform(h, w1.contiguous().unsqueeze(0), tiles, N, bias=None if b1 is None else b1.contiguous().view(1, -1), relu=True,
+                            slope=slope)
+        h2 = rows_transform(h1, w2.contiguous().unsqueeze(0), tiles, N, bias=None if b2 is None else b2.contiguous().view(1, -1), relu=True,
+                            slope=slope)
+        ctx.index_set, ctx.slope = index_set, slope
+        ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
+        ctx.save_for_backward(x, h, h1, h2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
+        return h2
+
+    @staticmethod
+    @_backward_in_forward_mode
+    def backward(ctx, gout):
+        iset, slope = ctx.index_set, ctx.slope
+        ix = iset.parts[0][2]
+        x, h, h1, h2, W, W_loop, w1, w2, aux = ctx.saved_tensors
+        N, H, R = x.shape[0], x.shape[1], W.shape[0]
+        tiles, _ = _dense_table(N, x.device)
+        gm2 = relu_bwd(gout.contiguous(), h2, slope)                        # the outer activation's mask
+        gm1 = rows_transform(gm2, w2.contiguous().unsqueeze(0), tiles, N, mask_pos=h1, slope=slope, w_kn=True)   # masked for the inner one
+        g0 = rows_transform(gm1, w1.contiguous().unsqueeze(0), tiles, N, w_kn=True)
+        gx = torch.empty_like(x)
+        aux_b = message_pass(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", iset.ybuf(H, x.dtype, x.device), gx)
+        # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
+        if getattr(ix, "_layer_chunks", None) is None:
+            P_all = ix.num_rows
+            vptr_host = list(ix.rel_ptr_host) + [P_all + N, P_all + 2 * N]
+            vptr = torch.cat([ix.rel_ptr_dev[:R + 2], torch.tensor([P_all + N, P_all + 2 * N], dtype=I32, device=x.device)])
+            ix._layer_chunks = build_row_tables(vptr, R + 3, P_all + 2 * N, wgrad_chunk_rows(vptr_host), want_ptr=True)
+        jobs = [dict(A=x, A2=aux if ctx.has[3] else None, idx_a=ix.row_in, G=g0, G2=aux_b, idx_g=ix.row_out, colsum_of=2, first_rel=0, row0=0),
+                dict(A=gm1, G=h, colsum_of=1, first_rel=R + 1, row0=ix.num_rows),
+                dict(A=gm2, G=h1, colsum_of=1, first_rel=R + 2, row0=ix.num_rows + N)]
+        gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, torch.float32)
+        return (gx, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1], cs[R + 1] if ctx.has[1] else None, gw[R + 2],
+                cs[R + 2] if ctx.has[2] else None)
+
+
+def rgin_layer_f32(x, W, W_loop, bias, linears, slope, index_set):
+    return _RginLayerF32Fn.apply(x, float(slope), index_set, W, W_loop, bias, linears[0].weight, linears[0].bias, linears[1].weight,
+                                 linears[1].bias)
 
 
 def rgin_layer_small(x, W, W_loop, bias, linears, slope, index_set):

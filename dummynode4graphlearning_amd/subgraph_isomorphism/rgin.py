@@ -155,9 +155,12 @@ class RGINLayer(nn.Module):
         slope = _fused_slope(self.act)
         if slope is None or len(mods) != 3 or not all(isinstance(m, nn.Linear) or _fused_slope(m) == slope for m in mods):
             return None
-        if not ops.rgin_layer_small_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
-            return None
-        return ops.rgin_layer_small(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
+        if ops.rgin_layer_small_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
+            return ops.rgin_layer_small(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
+        if ops.rgin_layer_f32_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
+            # the reference's own precision: the same launches as the separate functions, ONE weight-gradient launch in the backward
+            return ops.rgin_layer_f32(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
+        return None
 
     def _run_mlp(self, out):
         """self.mlp(out), with every Linear (and the ReLU / leaky ReLU that follows it -- including the layer's final activation)

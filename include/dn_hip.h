@@ -447,6 +447,14 @@ typedef struct dn_wgrad_job {
 int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
                              const int32_t* chunk_ptr, void* out, int32_t out_is_f32, float* out_colsum, void* out_colsum_lp,
                              void* workspace, size_t workspace_bytes, dn_stream_t stream);
+/* The same for fp32 rows on the 3-term bf16 split (dn_rows_wgrad_f32 with precision 0): A / A2 / G / G2 of a job are float tensors,
+ * mask_a_bits must be NULL (the reference-precision layer masks its gradient rows in the launches in front: dn_relu_bwd_f32 and
+ * dn_rows_transform_f32's mask_pos), act_slope is unused.  out [R][H][H] and out_colsum [R][H] fp32.  H = 64 / 128.  With this the
+ * backward of an fp32 RGIN layer at the reference's default width (config.py:456-461) takes one weight-gradient launch and one
+ * reduce instead of three of each (rgin.py:102-160's three parameter groups: weight / loop_weight + bias, mlp[0], mlp[2]). */
+int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
+                            const int32_t* chunk_ptr, float* out, float* out_colsum, void* workspace, size_t workspace_bytes,
+                            dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU

@@ -186,6 +186,68 @@ def test_rgin_layer_at_the_default_width_takes_one_launch_per_direction():
     assert _rel_l2(got[0], ref) < 3e-2
 
 
+@pytest.mark.parametrize("H,act", [(64, "relu"), (64, "leaky_relu"), (128, "relu")])
+def test_fp32_rgin_layer_takes_one_weight_gradient_launch(H, act):
+    """RGINLayer(H, H) in the reference's own precision (fp32 on the bf16 split) on a config-3-shaped batch: ONE autograd function whose
+    backward ends in ONE weight-gradient launch + reduce for the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_f32) --
+    the same forward launches and, up to the fp32 summation order of the weight gradients, the same numbers as the separate functions;
+    against the fp64 oracle at the goldens' tolerance; bitwise repeatable; the exact-f32 mode keeps the separate functions."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    import oracle.layers as OL
+    raw = synthetic.config3(seed=4, graphs=64)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R = int(aug["node_label"].numel()), 8
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    et = aug["edge_label"].long()
+    torch.manual_seed(6)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func=act).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x0 = torch.randn(N, H, device=DEV, generator=gen)
+    coef = torch.randn(N, H, device=DEV, generator=gen)
+
+    def run():
+        g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+        for p in layer.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            out, _ = layer(g, x, et)
+            out.backward(coef)
+        finally:
+            ops.kernel_timer = None
+        return [r[0] for r in timer.records], [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+    tags, got = run()
+    assert tags.count("rows_wgrad_multi") == 1 and "rows_wgrad" not in tags, tags
+    old = ops.LAYER_F32_ENABLED
+    try:
+        ops.LAYER_F32_ENABLED = False
+        tags1, sep = run()
+    finally:
+        ops.LAYER_F32_ENABLED = old
+    assert tags1.count("rows_wgrad") == 3 and "rows_wgrad_multi" not in tags1, tags1
+    assert len(tags) == len(tags1) - 2                                  # two weight-gradient calls fewer (the mask launch is not a timed call)
+    assert torch.equal(got[0], sep[0])                                  # the same forward launches
+    for a, b in zip(got[1:], sep[1:]):
+        assert _rel_l2(a, b) < 2e-5
+    _, again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    ref = OL.rgin_layer(x0.double().cpu(), aug["src"].long().cpu(), aug["dst"].long().cpu(), et.cpu(), p64, regularizer="basis", num_rels=R,
+                        num_bases=-1, num_mlp_layers=2, act=act)
+    assert float((got[0].double().cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    with ops.f32_exact(True):                                           # the exact-f32 checker mode: the separate functions
+        tags2, _ = run()
+    assert "rows_wgrad_multi" not in tags2
+
+
 def test_batches_outside_the_limits_keep_the_row_factorised_launches():
     from dummynode4graphlearning_amd import ops
     rng = np.random.default_rng(9)

@@ -67,13 +67,17 @@ def _run_si_goldens(z, meta, BatchedGraph):
     from dummynode4graphlearning_amd import ops
     worst = 0.0
     calls = {"mlp": 0, "bdd": 0}
-    orig_mlp, orig_bdd = ops.relu_mlp, ops.bdd_dense
+    orig_mlp, orig_bdd, orig_layer = ops.relu_mlp, ops.bdd_dense, ops.rgin_layer_f32
     ops.relu_mlp = lambda *a, **k: (calls.__setitem__("mlp", calls["mlp"] + 1), orig_mlp(*a, **k))[1]
     ops.bdd_dense = lambda *a, **k: (calls.__setitem__("bdd", calls["bdd"] + 1), orig_bdd(*a, **k))[1]
+    # (H = 64 / 128 with a self loop and a two-layer MLP: the whole layer as ONE function on the same kernels -- ops.rgin_layer_f32)
+    ops.rgin_layer_f32 = lambda *a, **k: (calls.__setitem__("mlp", calls["mlp"] + 1), calls.__setitem__("layer", calls.get("layer", 0) + 1),
+                                          orig_layer(*a, **k))[2]
     try:
         worst = _run_si_goldens_inner(z, meta, BatchedGraph, calls)
     finally:
-        ops.relu_mlp, ops.bdd_dense = orig_mlp, orig_bdd
+        ops.relu_mlp, ops.bdd_dense, ops.rgin_layer_f32 = orig_mlp, orig_bdd, orig_layer
+    assert ops.f32_mode() or calls.get("layer", 0) > 0, "no golden case took the one-function fp32 layer"
     return worst
 
 
