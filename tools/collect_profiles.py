@@ -36,17 +36,17 @@ STEP = [
     ("rows_wgrad_dma_kernel", "MLP wgrad 2 (LDS-DMA ring, outer ReLU mask from bits)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_chain2_ring_kernel", "MLP input gradients: outer mask, dgrad 2, inner mask, dgrad 1 in one pass (masks from bits, by DMA)"),
-    ("rows_wgrad_dma_kernel", "MLP wgrad 1 (LDS-DMA ring)"),
+    ("rows_wgrad_ls_kernel", "MLP wgrad 1 (LDS-DMA ring, loader waves + MFMA waves)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
     ("rows_transform_ring_kernel", "conv transform bwd, edge rows except the collapsed dummy relation (gathers g rows)"),
     ("rows_close_ring_kernel", "closing launch bwd (unit stream): self-loop transform + per-src row sums + per-graph column sums of g -> aux rows + AGG units"),
-    ("rows_wgrad_ix_kernel", "conv wgrad (LDS-DMA ring, row indices by LDS-DMA; gathers x and g rows, + bias colsum)"),
+    ("rows_wgrad_ls_kernel", "conv wgrad (LDS-DMA ring, loader waves + MFMA waves; gathers x and g rows, interleaved pieces, + bias colsum of the self-loop rows)"),
     ("wgrad_reduce_kernel", "wgrad reduce"),
 ]
 CONV_ROWS = (0, 1, 8, 9)
 OURS = ("gather_segsum_vec_kernel", "overflow_rows_add_kernel", "rows_transform_ring_kernel", "rows_transform_kernel", "rows_close_ring_kernel",
-        "rows_selfsum_kernel", "fold_tail_kernel", "conv_graphs_kernel", "rows_wgrad_multi_kernel", "rows_chain2_ring_kernel", "rows_chain2_kernel", "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
-        "wgrad_reduce_kernel")
+        "rows_selfsum_kernel", "fold_tail_kernel", "conv_graphs_kernel", "rows_wgrad_multi_kernel", "rows_chain2_ring_kernel", "rows_chain2_kernel", "rows_wgrad_ls_kernel", "rows_wgrad_ix_kernel", "rows_wgrad_dma_kernel", "rows_wgrad_kernel",
+        "rows_wgrad_f32s_multi_kernel", "wgrad_reduce_kernel")
 
 
 def short(name):
