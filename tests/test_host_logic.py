@@ -201,3 +201,31 @@ def test_tu_reader_rejects_multi_column_attribute_files(tmp_path):
         tu_io.read_raw(str(d))
 
 
+
+
+def test_weight_gradient_chunks_fit_one_round_of_workgroups():
+    """ops.wgrad_chunk_rows / ops.close_chunks (host arithmetic behind the chunk tables of dn_rows_wgrad_* and the chunked closing
+    launch): the smallest multiple of 64 rows (>= 256) for which every relation's chunks -- each relation ends in a partial one --
+    fit ONE round of 256 workgroups, up to the cap; config 5's relation sizes give 245 chunks where 4,096-row chunks gave 775."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        R = int(rng.integers(1, 20))
+        sizes = [int(rng.integers(0, 400000)) for _ in range(R)]
+        ptr = [0] + list(np.cumsum(sizes))
+        c = ops.wgrad_chunk_rows(ptr)
+        n = sum(-(-s // c) for s in sizes if s > 0)
+        assert c % 64 == 0 and 256 <= c <= ops.WGRAD_CHUNK_CAP
+        assert n <= 256 or c == ops.WGRAD_CHUNK_CAP
+        if c > 256 and n <= 256:                                       # minimal: 64 rows fewer would need a second round
+            total = sum(sizes)
+            lower = max(256, -(-total // 256 // 64) * 64)
+            assert c == lower or sum(-(-s // (c - 64)) for s in sizes if s > 0) > 256
+    sizes5 = [131072] * 16 + [1015808]                                  # config 5's shape: 16 relations of ~equal size + the self loop
+    c5 = ops.wgrad_chunk_rows([0] + list(np.cumsum(sizes5)))
+    assert sum(-(-s // c5) for s in sizes5) <= 256 < sum(-(-s // 4096) for s in sizes5)
+    assert ops.wgrad_chunk_rows([0, 0, 0]) == 256
+    for N, wg in ((1015808, 256), (645196, 256), (31, 256), (25600, 128)):
+        C = ops.close_chunks(N, wg)                                     # chunks of the batch: a whole number per workgroup, < 16,384,
+        assert C % wg == 0 and wg <= C < 16384                          # about CLOSE_CHUNK_TILES tiles each once the batch is that large
+        assert C == wg or abs(N / 32.0 / C - ops.CLOSE_CHUNK_TILES) <= ops.CLOSE_CHUNK_TILES / 2
