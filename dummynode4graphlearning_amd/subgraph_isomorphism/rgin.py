@@ -184,6 +184,14 @@ class RGINLayer(nn.Module):
                         i += 1
                     else:
                         act_done = True
+            elif isinstance(m, nn.BatchNorm1d) and m.training and ops.batch_norm_rows_supported(out) and out.shape[0] > 1:
+                # --rep_rgin_batch_norm (rgin.py:53-54): statistics, running buffers, normalisation and the ReLU behind it on the HIP
+                # BatchNorm kernels (dn_batchnorm_rows_*: three small launches each way) instead of a torch / MIOpen module + activation
+                from ..graph_classification.models import hip_batch_norm_forward
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                out = hip_batch_norm_forward(m, out, fuse)
+                if fuse:
+                    i += 1
             else:
                 out = m(out)
             i += 1

@@ -38,7 +38,21 @@ def act_fn(name):
         return F.gelu
     if name == "elu":
         return F.elu
+    if name == "selu":
+        return F.selu
     raise NotImplementedError(name)
+
+
+def batch_norm_train(weight, bias, eps=1e-5):
+    """Training-mode BatchNorm1d over the rows (torch.nn.BatchNorm1d as the reference's MLP holds it, SI models/rgin.py:53-54):
+    y = (x - mean) / sqrt(biased var + eps) * weight + bias.  Returns the callable rgin_layer's mlp_bn takes; it records the batch
+    statistics it saw (mean, UNBIASED var: what the running buffers are updated with)."""
+    def f(x):
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        f.stats = (mean.detach(), x.var(0, unbiased=True).detach())
+        return (x - mean) / th.sqrt(var + eps) * weight + bias
+    return f
 
 
 def segment_sum(rows, index, num_segments):

@@ -25,6 +25,8 @@ The reference's Python is imported unmodified, with the absent third-party modul
                        called on a stub self: residual, pattern zero-mask, graph mask / gate paths, outputs + gradients
   si_layers.npz        a-8 RGINLayer / a-10 RGCNLayer: seeded initial weights, inputs, outputs and
                        all gradients over the regulariser x act x self_loop x edge_norm grid
+  si_layers_bn.npz     a-8 (round 6) RGINLayer with batch_norm=True in training mode (outputs, gradients, BatchNorm buffers after
+                       the step) and the activations gelu / selu / elu at a matrix-core width
 
 usage: python tests/golden/make_golden.py
 """
@@ -656,14 +658,9 @@ def make_si_rep_nets():
     print("si_rep_nets.npz: %d cases" % len(meta))
 
 
-def make_si_layers():
-    _si_modules()
-    rgin = importlib.import_module("models.rgin")
-    rgcn = importlib.import_module("models.rgcn")
-    out = {}
-    meta = []
-    rng = np.random.default_rng(11)
-
+def _si_layer_case(out, rng, tag, layer_cls, kw, N, E, H_in, seed, buffers=False):
+    """One reference-run layer case (shared by make_si_layers and make_si_layers_bn; the random stream is consumed exactly as the
+    nested helpers of make_si_layers consumed it, so si_layers.npz regenerates bit for bit)."""
     def graph(N, E, R):
         u = rng.integers(0, N, size=E)
         v = rng.integers(0, N, size=E)
@@ -671,7 +668,7 @@ def make_si_layers():
         t = rng.integers(0, R, size=E)
         return u.astype(np.int64), v.astype(np.int64), t.astype(np.int64)
 
-    def run(tag, layer_cls, kw, N, E, H_in, seed):
+    if True:
         R = kw["num_rels"]
         th.manual_seed(seed)
         layer = layer_cls(H_in, kw.pop("hidden_dim"), **kw)
@@ -692,6 +689,9 @@ def make_si_layers():
             g = S.FakeDGLGraph(u, v, N)
             layer.train()
             layer.zero_grad()
+            for mod in layer.modules():                                  # a rejected draw must not leave its batch in the running statistics
+                if isinstance(mod, th.nn.modules.batchnorm._BatchNorm):
+                    mod.reset_running_stats()
             del kink[:]
             o, _ = layer(g, x, th.from_numpy(t))
             if not hooks or not kink or min(kink) >= 2e-5:
@@ -708,6 +708,21 @@ def make_si_layers():
         for k, p in layer.named_parameters():
             out[tag + "/param/" + k] = p.detach().numpy()
             out[tag + "/grad/" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+        if buffers:                                 # BatchNorm running statistics / batch counter AFTER the training-mode step
+            for k, b in layer.named_buffers():
+                out[tag + "/buffer/" + k] = b.detach().numpy()
+
+
+def make_si_layers():
+    _si_modules()
+    rgin = importlib.import_module("models.rgin")
+    rgcn = importlib.import_module("models.rgcn")
+    out = {}
+    meta = []
+    rng = np.random.default_rng(11)
+
+    def run(tag, layer_cls, kw, N, E, H_in, seed):
+        _si_layer_case(out, rng, tag, layer_cls, kw, N, E, H_in, seed)
 
     cid = 0
     for reg, nb, R in (("none", -1, 3), ("basis", -1, 6), ("basis", 2, 6), ("bdd", 4, 6)):
@@ -769,6 +784,31 @@ def make_si_layers():
     print("si_layers.npz: %d cases" % len(meta))
 
 
+def make_si_layers_bn():
+    """a-8, the optional parts of the reference MLP (round 6): RGINLayer with `batch_norm=True` (--rep_rgin_batch_norm, config.py:139;
+    models/rgin.py:50-57: Linear, BatchNorm1d, act, Linear) in training mode -- outputs, every gradient and the BatchNorm buffers after
+    the step -- and the activations of utils/act.py:457-474 beyond relu / leaky_relu / tanh at a matrix-core width."""
+    _si_modules()
+    rgin = importlib.import_module("models.rgin")
+    out, meta = {}, []
+    rng = np.random.default_rng(61)
+    cid = 0
+    grid = [(16, 6, "basis", -1, "relu", True, 24, 96), (16, 6, "bdd", 4, "leaky_relu", True, 24, 96), (16, 3, "none", -1, "tanh", True, 24, 96),
+            (64, 8, "basis", -1, "relu", True, 300, 1200), (64, 8, "bdd", 4, "leaky_relu", True, 300, 1200),
+            (128, 4, "basis", -1, "relu", True, 200, 800),
+            (64, 8, "basis", -1, "gelu", False, 300, 1200), (64, 8, "basis", -1, "selu", False, 300, 1200),
+            (64, 8, "basis", -1, "elu", False, 300, 1200), (64, 8, "basis", -1, "gelu", True, 300, 1200)]
+    for H_, R_, reg, nb, act, bn, N_, E_ in grid:
+        tag = "rginbn%02d" % cid
+        kw = dict(hidden_dim=H_, num_rels=R_, regularizer=reg, num_bases=nb, num_mlp_layers=2, self_loop=True, act_func=act, batch_norm=bn)
+        meta.append(dict(tag=tag, kind="rgin", input_dim=H_, seed=4000 + cid, N=N_, E=E_, **kw))
+        _si_layer_case(out, rng, tag, rgin.RGINLayer, dict(kw), N_, E_, H_, 4000 + cid, buffers=True)
+        cid += 1
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "si_layers_bn.npz"), **out)
+    print("si_layers_bn.npz: %d cases" % len(meta))
+
+
 if __name__ == "__main__":
     make_gc()
     make_tu_files()
@@ -780,3 +820,4 @@ if __name__ == "__main__":
     make_si_pred()
     make_si_rep_nets()
     make_si_layers()
+    make_si_layers_bn()

@@ -38,7 +38,7 @@ def _build(m):
     kw = dict(num_rels=m["num_rels"], regularizer=m["regularizer"], num_bases=m["num_bases"],
               self_loop=m["self_loop"], act_func=m["act_func"])
     if m["kind"] == "rgin":
-        return RGINLayer(m["input_dim"], m["hidden_dim"], num_mlp_layers=m["num_mlp_layers"], **kw)
+        return RGINLayer(m["input_dim"], m["hidden_dim"], num_mlp_layers=m["num_mlp_layers"], batch_norm=bool(m.get("batch_norm", False)), **kw)
     return RGCNLayer(m["input_dim"], m["hidden_dim"], edge_norm=m["edge_norm"], **kw)
 
 
@@ -58,6 +58,54 @@ def test_si_layers_match_reference_goldens(golden_dir, exact):
         ops.F32_EXACT = old_mode
     print("fp32 mode %s: worst rel_max over %d golden cases: %.3e" % ("exact" if exact else "bf16x3 split", len(meta), worst))
     assert worst < (5e-6 if exact else RTOL)
+
+
+def test_si_layers_with_batch_norm_and_other_activations_match_reference_goldens(golden_dir):
+    """si_layers_bn.npz (round 6, reference-run): RGINLayer with batch_norm=True (--rep_rgin_batch_norm, rgin.py:50-57) in training mode
+    and the activations gelu / selu / elu at a matrix-core width, at 1e-4: outputs, every gradient, the BatchNorm buffers after the step.
+    Path: the BatchNorm (and a ReLU behind it) runs on the HIP BatchNorm kernels, the Linears on the MFMA Linear kernels."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops
+    z = np.load(os.path.join(golden_dir, "si_layers_bn.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    calls = {"bn": 0, "lin": 0}
+    orig_bn, orig_lin = ops.batch_norm_rows, ops.linear_act
+    ops.batch_norm_rows = lambda *a, **k: (calls.__setitem__("bn", calls["bn"] + 1), orig_bn(*a, **k))[1]
+    ops.linear_act = lambda *a, **k: (calls.__setitem__("lin", calls["lin"] + 1), orig_lin(*a, **k))[1]
+    worst = 0.0
+    try:
+        for m in meta:
+            tag = m["tag"]
+            before = dict(calls)
+            layer = _build(m)
+            sd = {k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/param/")}
+            missing = layer.load_state_dict(sd, strict=False)            # (the buffers start from torch's defaults, as the reference's did)
+            assert not missing.unexpected_keys and all("running_" in k or "num_batches" in k for k in missing.missing_keys), missing
+            layer = layer.to(DEV).train()
+            u, v, t = (torch.from_numpy(z[tag + "/" + k]).to(DEV) for k in ("u", "v", "t"))
+            g = BatchedGraph(u, v, m["N"])
+            x = torch.from_numpy(z[tag + "/x"]).to(DEV).requires_grad_(True)
+            out, _ = layer(g, x, t)
+            if m["batch_norm"]:
+                assert calls["bn"] == before["bn"] + 1, (tag, "BatchNorm did not take the HIP kernels")
+                if m["hidden_dim"] in (64, 128):
+                    assert calls["lin"] == before["lin"] + 2, (tag, "the Linears did not take the MFMA kernels")
+            (out * torch.from_numpy(z[tag + "/coef"]).to(DEV)).sum().backward()
+            errs = {"out": _rel_max(out, torch.from_numpy(z[tag + "/out"])), "grad_x": _rel_max(x.grad, torch.from_numpy(z[tag + "/grad_x"]))}
+            for k, p in layer.named_parameters():
+                ref = z[tag + "/grad/" + k]
+                if ref.size and np.abs(ref).max() > 1e-5:
+                    errs["grad " + k] = _rel_max(p.grad, torch.from_numpy(ref))
+                elif ref.size:                                           # a shift in front of a BatchNorm (the conv's bias, mlp.0.bias): the
+                    assert float(p.grad.abs().max()) < 1e-4, (tag, k)    # gradient is zero up to rounding noise on either side
+            for k, b in layer.named_buffers():
+                errs["buffer " + k] = _rel_max(b.float(), torch.from_numpy(z[tag + "/buffer/" + k]).float())
+            for k, e in errs.items():
+                assert e < RTOL, "%s %s rel_max %.3e" % (tag, k, e)
+                worst = max(worst, e)
+    finally:
+        ops.batch_norm_rows, ops.linear_act = orig_bn, orig_lin
+    assert calls["bn"] >= 6
+    print("worst rel_max over %d BatchNorm / activation golden cases: %.3e" % (len(meta), worst))
 
 
 def _run_si_goldens(z, meta, BatchedGraph):

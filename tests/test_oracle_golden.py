@@ -200,6 +200,34 @@ def test_si_layers_match_reference_outputs_and_grads(golden_dir):
             th.testing.assert_close(t_.grad, th.from_numpy(ref), rtol=1e-4, atol=1e-5, msg=tag + " " + k)
 
 
+def test_si_layers_with_batch_norm_and_other_activations_match_reference(golden_dir):
+    """si_layers_bn.npz (round 6): RGINLayer with batch_norm=True in training mode (models/rgin.py:50-57, --rep_rgin_batch_norm) and the
+    activations gelu / selu / elu at a matrix-core width -- outputs, every gradient, the BatchNorm buffers after the step."""
+    z = np.load(os.path.join(golden_dir, "si_layers_bn.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    assert sum(m["batch_norm"] for m in meta) >= 5 and {m["act_func"] for m in meta} >= {"relu", "leaky_relu", "tanh", "gelu", "selu", "elu"}
+    for m in meta:
+        tag = m["tag"]
+        p = {k[len(tag) + 7:]: th.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(tag + "/param/")}
+        x = th.from_numpy(z[tag + "/x"]).clone().requires_grad_(True)
+        u, v, t = (th.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
+        bn = [OL.batch_norm_train(p["mlp.1.weight"], p["mlp.1.bias"])] if m["batch_norm"] else None
+        out = OL.rgin_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"], num_bases=m["num_bases"],
+                            num_mlp_layers=m["num_mlp_layers"], act=m["act_func"], mlp_bn=bn)
+        (out * th.from_numpy(z[tag + "/coef"])).sum().backward()
+        th.testing.assert_close(out.detach(), th.from_numpy(z[tag + "/out"]), rtol=1e-4, atol=2e-5, msg=tag)
+        th.testing.assert_close(x.grad, th.from_numpy(z[tag + "/grad_x"]), rtol=1e-4, atol=2e-5, msg=tag)
+        for k, t_ in p.items():
+            ref = z[tag + "/grad/" + k]
+            if ref.size:
+                th.testing.assert_close(t_.grad, th.from_numpy(ref), rtol=2e-4, atol=2e-5, msg=tag + " " + k)
+        if m["batch_norm"]:                                             # buffers: momentum 0.1 from (0, 1), one step
+            mean, uvar = bn[0].stats
+            th.testing.assert_close(0.1 * mean, th.from_numpy(z[tag + "/buffer/mlp.1.running_mean"]), rtol=1e-4, atol=1e-6, msg=tag)
+            th.testing.assert_close(0.9 + 0.1 * uvar, th.from_numpy(z[tag + "/buffer/mlp.1.running_var"]), rtol=1e-4, atol=1e-6, msg=tag)
+            assert int(z[tag + "/buffer/mlp.1.num_batches_tracked"]) == 1
+
+
 def test_agg_first_form_equals_reference_formulation(golden_dir):
     """aggregate-then-transform == the reference's per-edge transform (basis, full)."""
     z, meta = _layer_cases(golden_dir)
