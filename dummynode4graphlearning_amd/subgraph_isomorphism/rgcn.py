@@ -139,7 +139,15 @@ class RGCNLayer(nn.Module):
         if self.bias is not None:
             out = out + self.bias
         if self.bn is not None:
-            out = self.bn(out)
+            if self.bn.training and ops.batch_norm_rows_supported(out) and out.shape[0] > 1:
+                # --rep_rgcn_batch_norm (rgcn.py:52-53, 185-187): statistics, buffers, normalisation and a ReLU behind it on the HIP kernels
+                from ..graph_classification.models import hip_batch_norm_forward
+                fuse = isinstance(self.act, nn.ReLU)
+                out = hip_batch_norm_forward(self.bn, out, fuse)
+                if fuse:
+                    return self.drop(out), edge_type
+            else:
+                out = self.bn(out)
         out = self.act(out)
         out = self.drop(out)
         return out, edge_type

@@ -804,6 +804,14 @@ def make_si_layers_bn():
         meta.append(dict(tag=tag, kind="rgin", input_dim=H_, seed=4000 + cid, N=N_, E=E_, **kw))
         _si_layer_case(out, rng, tag, rgin.RGINLayer, dict(kw), N_, E_, H_, 4000 + cid, buffers=True)
         cid += 1
+    # RGCNLayer with batch_norm=True (--rep_rgcn_batch_norm; models/rgcn.py:52-53, 185-186: BatchNorm1d between the bias and the activation)
+    rgcn = importlib.import_module("models.rgcn")
+    for H_, R_, norm, act, N_, E_ in ((16, 4, "in", "relu", 24, 96), (64, 8, "both", "relu", 300, 1200), (64, 8, "none", "leaky_relu", 300, 1200)):
+        tag = "rgcnbn%02d" % cid
+        kw = dict(hidden_dim=H_, num_rels=R_, regularizer="basis", num_bases=-1, edge_norm=norm, self_loop=True, act_func=act, batch_norm=True)
+        meta.append(dict(tag=tag, kind="rgcn", input_dim=H_, seed=4000 + cid, N=N_, E=E_, **kw))
+        _si_layer_case(out, rng, tag, rgcn.RGCNLayer, dict(kw), N_, E_, H_, 4000 + cid, buffers=True)
+        cid += 1
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "si_layers_bn.npz"), **out)
     print("si_layers_bn.npz: %d cases" % len(meta))

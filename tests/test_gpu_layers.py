@@ -39,7 +39,7 @@ def _build(m):
               self_loop=m["self_loop"], act_func=m["act_func"])
     if m["kind"] == "rgin":
         return RGINLayer(m["input_dim"], m["hidden_dim"], num_mlp_layers=m["num_mlp_layers"], batch_norm=bool(m.get("batch_norm", False)), **kw)
-    return RGCNLayer(m["input_dim"], m["hidden_dim"], edge_norm=m["edge_norm"], **kw)
+    return RGCNLayer(m["input_dim"], m["hidden_dim"], edge_norm=m["edge_norm"], batch_norm=bool(m.get("batch_norm", False)), **kw)
 
 
 @pytest.mark.parametrize("exact", [False, True])
@@ -61,8 +61,8 @@ def test_si_layers_match_reference_goldens(golden_dir, exact):
 
 
 def test_si_layers_with_batch_norm_and_other_activations_match_reference_goldens(golden_dir):
-    """si_layers_bn.npz (round 6, reference-run): RGINLayer with batch_norm=True (--rep_rgin_batch_norm, rgin.py:50-57) in training mode
-    and the activations gelu / selu / elu at a matrix-core width, at 1e-4: outputs, every gradient, the BatchNorm buffers after the step.
+    """si_layers_bn.npz (round 6, reference-run): RGINLayer / RGCNLayer with batch_norm=True (--rep_rgin_batch_norm, rgin.py:50-57;
+    --rep_rgcn_batch_norm, rgcn.py:52-53) in training mode and the activations gelu / selu / elu at a matrix-core width, at 1e-4: outputs, every gradient, the BatchNorm buffers after the step.
     Path: the BatchNorm (and a ReLU behind it) runs on the HIP BatchNorm kernels, the Linears on the MFMA Linear kernels."""
     from dummynode4graphlearning_amd import BatchedGraph, ops
     z = np.load(os.path.join(golden_dir, "si_layers_bn.npz"))
@@ -87,16 +87,17 @@ def test_si_layers_with_batch_norm_and_other_activations_match_reference_goldens
             out, _ = layer(g, x, t)
             if m["batch_norm"]:
                 assert calls["bn"] == before["bn"] + 1, (tag, "BatchNorm did not take the HIP kernels")
-                if m["hidden_dim"] in (64, 128):
+                if m["hidden_dim"] in (64, 128) and m["kind"] == "rgin":
                     assert calls["lin"] == before["lin"] + 2, (tag, "the Linears did not take the MFMA kernels")
             (out * torch.from_numpy(z[tag + "/coef"]).to(DEV)).sum().backward()
             errs = {"out": _rel_max(out, torch.from_numpy(z[tag + "/out"])), "grad_x": _rel_max(x.grad, torch.from_numpy(z[tag + "/grad_x"]))}
+            scale = max(float(np.abs(z[tag + "/grad/" + k]).max()) for k, _ in layer.named_parameters() if z[tag + "/grad/" + k].size)
             for k, p in layer.named_parameters():
                 ref = z[tag + "/grad/" + k]
-                if ref.size and np.abs(ref).max() > 1e-5:
+                if ref.size and np.abs(ref).max() > 1e-5 * scale:
                     errs["grad " + k] = _rel_max(p.grad, torch.from_numpy(ref))
                 elif ref.size:                                           # a shift in front of a BatchNorm (the conv's bias, mlp.0.bias): the
-                    assert float(p.grad.abs().max()) < 1e-4, (tag, k)    # gradient is zero up to rounding noise on either side
+                    assert float(p.grad.abs().max()) < 1e-4 * scale, (tag, k)   # gradient is zero up to rounding noise on either side
             for k, b in layer.named_buffers():
                 errs["buffer " + k] = _rel_max(b.float(), torch.from_numpy(z[tag + "/buffer/" + k]).float())
             for k, e in errs.items():
@@ -104,7 +105,7 @@ def test_si_layers_with_batch_norm_and_other_activations_match_reference_goldens
                 worst = max(worst, e)
     finally:
         ops.batch_norm_rows, ops.linear_act = orig_bn, orig_lin
-    assert calls["bn"] >= 6
+    assert calls["bn"] >= 9
     print("worst rel_max over %d BatchNorm / activation golden cases: %.3e" % (len(meta), worst))
 
 

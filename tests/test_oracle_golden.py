@@ -211,9 +211,14 @@ def test_si_layers_with_batch_norm_and_other_activations_match_reference(golden_
         p = {k[len(tag) + 7:]: th.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(tag + "/param/")}
         x = th.from_numpy(z[tag + "/x"]).clone().requires_grad_(True)
         u, v, t = (th.from_numpy(z[tag + "/" + k]) for k in ("u", "v", "t"))
-        bn = [OL.batch_norm_train(p["mlp.1.weight"], p["mlp.1.bias"])] if m["batch_norm"] else None
-        out = OL.rgin_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"], num_bases=m["num_bases"],
-                            num_mlp_layers=m["num_mlp_layers"], act=m["act_func"], mlp_bn=bn)
+        bname = "mlp.1" if m["kind"] == "rgin" else "bn"
+        bn = [OL.batch_norm_train(p[bname + ".weight"], p[bname + ".bias"])] if m["batch_norm"] else None
+        if m["kind"] == "rgin":
+            out = OL.rgin_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"], num_bases=m["num_bases"],
+                                num_mlp_layers=m["num_mlp_layers"], act=m["act_func"], mlp_bn=bn)
+        else:
+            out = OL.rgcn_layer(x, u, v, t, p, regularizer=m["regularizer"], num_rels=m["num_rels"], num_bases=m["num_bases"],
+                                edge_norm=m["edge_norm"], act=m["act_func"], bn=bn[0])
         (out * th.from_numpy(z[tag + "/coef"])).sum().backward()
         th.testing.assert_close(out.detach(), th.from_numpy(z[tag + "/out"]), rtol=1e-4, atol=2e-5, msg=tag)
         th.testing.assert_close(x.grad, th.from_numpy(z[tag + "/grad_x"]), rtol=1e-4, atol=2e-5, msg=tag)
@@ -223,9 +228,9 @@ def test_si_layers_with_batch_norm_and_other_activations_match_reference(golden_
                 th.testing.assert_close(t_.grad, th.from_numpy(ref), rtol=2e-4, atol=2e-5, msg=tag + " " + k)
         if m["batch_norm"]:                                             # buffers: momentum 0.1 from (0, 1), one step
             mean, uvar = bn[0].stats
-            th.testing.assert_close(0.1 * mean, th.from_numpy(z[tag + "/buffer/mlp.1.running_mean"]), rtol=1e-4, atol=1e-6, msg=tag)
-            th.testing.assert_close(0.9 + 0.1 * uvar, th.from_numpy(z[tag + "/buffer/mlp.1.running_var"]), rtol=1e-4, atol=1e-6, msg=tag)
-            assert int(z[tag + "/buffer/mlp.1.num_batches_tracked"]) == 1
+            th.testing.assert_close(0.1 * mean, th.from_numpy(z[tag + "/buffer/%s.running_mean" % bname]), rtol=1e-4, atol=1e-6, msg=tag)
+            th.testing.assert_close(0.9 + 0.1 * uvar, th.from_numpy(z[tag + "/buffer/%s.running_var" % bname]), rtol=1e-4, atol=1e-6, msg=tag)
+            assert int(z[tag + "/buffer/%s.num_batches_tracked" % bname]) == 1
 
 
 def test_agg_first_form_equals_reference_formulation(golden_dir):
