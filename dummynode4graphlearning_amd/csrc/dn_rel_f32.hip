@@ -373,7 +373,9 @@ struct WgJobF {
     const int32_t* ia;
     const float *G, *G2;
     const int32_t* ig;
+    const float* maskA;
     int32_t na1, ng1, colsum_of, first_rel, row0;
+    float slope;
 };
 struct WgJobsF {
     WgJobF j[3];
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void rows_wgrad_f32s_multi_kernel(WgJobsF
     if (jobs.n > 2 && ch.rel >= jobs.j[2].first_rel) k = 2;
     const WgJobF J = k == 0 ? jobs.j[0] : (k == 1 ? jobs.j[1] : jobs.j[2]);
     ch.beg -= J.row0; ch.end -= J.row0;
-    rows_wgrad_f32s_body<H>(J.A, J.A2, J.na1, J.ia, J.G, J.G2, J.ng1, J.ig, ch, partial, J.colsum_of, colsum_partial, nullptr, nullptr, 0.f, true);
+    rows_wgrad_f32s_body<H>(J.A, J.A2, J.na1, J.ia, J.G, J.G2, J.ng1, J.ig, ch, partial, J.colsum_of, colsum_partial, J.maskA, nullptr, J.slope, true);
 }
 
 // out[r] = sum of chunk partials (same slice-parallel fixed-order fold as the bf16 library's reducer)
@@ -714,6 +716,167 @@ __global__ __launch_bounds__(kThreads, 2) void rows_transform_f32s_kernel(
     }
 }
 
+// Two dense layers in one pass over fp32 rows on the 3-term split (dn_rows_chain2_f32; H = 64 / 128: the widths whose launches are
+// chains of latency):  X0 = mask0 ? keep-or-scale(X, mask0) : X;  Y1 = mask1 ? keep-or-scale(epi1(X0 W1), mask1) : epi1(X0 W1);
+// Y2 = epi2(Y1 W2), epi = (+ bias) then the optional activation.  Serves the forward of the reference MLP (Linear-act-Linear-act,
+// rgin.py:50-57: no masks, both biases) and the backward's input-gradient chain (mask0 = the saved output: the outer activation's
+// mask, W1 = Linear 2's weight as stored ([k][n]), mask1 = the saved hidden rows, W2 = Linear 1's weight) -- one launch where the
+// separate ones were two (forward) and three (backward: dn_relu_bwd_f32 + two dn_rows_transform_f32).  Per 32-row tile: rows -> hi / lo
+// bf16 tiles in LDS (the next tile's rows are in flight under this one), stage-1 MFMAs, the fp32 tile through LDS to Y1 and -- split
+// again -- to the stage-2 operand tiles, stage-2 MFMAs, the tile through LDS to Y2.  Both weight slices stay in registers.
+template <int H>
+__global__ __launch_bounds__(kThreads, 2) void rows_chain2_f32s_kernel(const float* __restrict__ X, const float* __restrict__ W1,
+                                                                       const float* __restrict__ b1, int32_t relu1,
+                                                                       const float* __restrict__ mask0, const float* __restrict__ mask1,
+                                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                       int32_t relu2, int32_t N, int32_t tiles_per_wg,
+                                                                       float* __restrict__ Y1, float* __restrict__ Y2, int32_t w_kn,
+                                                                       float slope) {
+    static_assert(H == 64 || H == 128, "unsupported width");
+    constexpr int SX = H + 8;                                   // bf16 elements per LDS row of an operand tile
+    constexpr int SY = H + 4;                                   // floats per LDS row of the output tile
+    constexpr int KS = H / 32;
+    constexpr int NT = 1;                                       // a wave owns 16 output columns (H / 16 of the 8 waves are active)
+    constexpr int MT = kRows / 16;
+    constexpr int NP = kRows * H / 4;
+    constexpr int P = (NP + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) bf16_t ldx[2 * 2 * kRows * SX];   // stage-1 operand tiles: [buffer][hi / lo]
+    __shared__ __attribute__((aligned(16))) bf16_t ldz[2 * kRows * SX];       // stage-2 operand tiles: [hi / lo]
+    __shared__ __attribute__((aligned(16))) float ldy[kRows * SY];
+    auto bufX = [&](int b, int lo) -> bf16_t* { return ldx + (b * 2 + lo) * (kRows * SX); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wave * 16;
+    const bool wave_active = n0 < H;
+    const int num_tiles = (N + kRows - 1) / kRows;
+    const int t_beg = blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_beg + tiles_per_wg, num_tiles);
+    if (t_beg >= t_end) return;
+
+    bf16x8 wh1[KS], wl1[KS], wh2[KS], wl2[KS];
+    auto load_w = [&](const float* w, bool kn, bf16x8* wh, bf16x8* wl) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int n = n0 + (lane & 15), k = ks * 32 + 8 * (lane >> 4);
+            if (kn) {                                           // [k][n] as the parameter is stored
+                const float* wp = w + (size_t)k * H + n;
+                split8(make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]), make_float4(wp[4 * H], wp[5 * H], wp[6 * H], wp[7 * H]), wh[ks], wl[ks]);
+            } else {
+                const float* wp = w + (size_t)n * H + k;
+                split8(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wh[ks], wl[ks]);
+            }
+        }
+    };
+    if (wave_active) {
+        load_w(W1, (w_kn & 1) != 0, wh1, wl1);
+        load_w(W2, (w_kn & 2) != 0, wh2, wl2);
+    }
+    float4 rx[P], rm[P];
+    auto load_rows = [&](int t) {                               // the tile's rows (and their mask rows) into registers
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, p = t * kRows + piece / (H / 4), c = piece % (H / 4);
+            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rm[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (piece < NP && p < N) {
+                rx[j] = *reinterpret_cast<const float4*>(X + (size_t)p * H + c * 4);
+                if (mask0) rm[j] = *reinterpret_cast<const float4*>(mask0 + (size_t)p * H + c * 4);
+            }
+        }
+    };
+    auto keep = [&](float4& v, const float4& mk) {
+        v.x = mk.x > 0.f ? v.x : dn_neg(v.x, slope); v.y = mk.y > 0.f ? v.y : dn_neg(v.y, slope);
+        v.z = mk.z > 0.f ? v.z : dn_neg(v.z, slope); v.w = mk.w > 0.f ? v.w : dn_neg(v.w, slope);
+    };
+    auto store_rows = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            if (piece < NP) {
+                if (mask0) keep(rx[j], rm[j]);
+                bf16x4 h, l;
+                split4(rx[j], h, l);
+                *reinterpret_cast<bf16x4*>(bufX(b, 0) + r * SX + c * 4) = h;
+                *reinterpret_cast<bf16x4*>(bufX(b, 1) + r * SX + c * 4) = l;
+            }
+        }
+    };
+    // one stage: acc = W (registers) x the hi / lo tiles, epilogue (bias, activation) into the fp32 tile
+    auto stage = [&](const bf16_t* xh, const bf16_t* xl, const bf16x8* wh, const bf16x8* wl, const float* bias, int32_t relu) {
+        if (!wave_active) return;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 fh[MT], fl[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                fh[m] = *reinterpret_cast<const bf16x8*>(xh + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+                fl[m] = *reinterpret_cast<const bf16x8*>(xl + (m * 16 + (lane & 15)) * SX + ks * 32 + 8 * (lane >> 4));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], fh[m], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], fl[m], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], fh[m], acc[m], 0, 0, 0);
+            }
+        }
+        const int col = n0 + 4 * (lane >> 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float4 v = make_float4(acc[m][0] + bv.x, acc[m][1] + bv.y, acc[m][2] + bv.z, acc[m][3] + bv.w);
+            if (relu) { v.x = dn_act(v.x, slope); v.y = dn_act(v.y, slope); v.z = dn_act(v.z, slope); v.w = dn_act(v.w, slope); }
+            *reinterpret_cast<float4*>(ldy + (m * 16 + (lane & 15)) * SY + col) = v;
+        }
+    };
+    load_rows(t_beg);
+    store_rows(0);
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int b = (t - t_beg) & 1;
+        if (t + 1 < t_end) load_rows(t + 1);                    // in flight under both stages of this tile
+        float4 m1[P];
+        if (mask1) {                                            // ... as are this tile's stage-1 mask rows
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int piece = tid + j * kThreads, p = t * kRows + piece / (H / 4), c = piece % (H / 4);
+                m1[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (piece < NP && p < N) m1[j] = *reinterpret_cast<const float4*>(mask1 + (size_t)p * H + c * 4);
+            }
+        }
+        stage(bufX(b, 0), bufX(b, 1), wh1, wl1, b1, relu1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {                           // Y1 out, and split into the stage-2 operand tiles
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            const int p = t * kRows + r;
+            if (piece < NP) {
+                float4 v = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
+                if (mask1) keep(v, m1[j]);
+                if (p < N) *reinterpret_cast<float4*>(Y1 + (size_t)p * H + c * 4) = v;
+                else v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bf16x4 h, l;
+                split4(v, h, l);
+                *reinterpret_cast<bf16x4*>(ldz + r * SX + c * 4) = h;
+                *reinterpret_cast<bf16x4*>(ldz + kRows * SX + r * SX + c * 4) = l;
+            }
+        }
+        __syncthreads();
+        stage(ldz, ldz + kRows * SX, wh2, wl2, b2, relu2);
+        if (t + 1 < t_end) store_rows(b ^ 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
+            const int p = t * kRows + r;
+            if (piece < NP && p < N) *reinterpret_cast<float4*>(Y2 + (size_t)p * H + c * 4) = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
                                                            float4* __restrict__ out, int64_t n4, float slope) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -833,10 +996,11 @@ int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t 
         DN_REQUIRE(q.A2 != nullptr || q.na1 == 0x7fffffff, "dn_rows_wgrad_multi_f32: A2 == NULL requires na1 == INT32_MAX");
         DN_REQUIRE(q.G2 != nullptr || q.ng1 == 0x7fffffff, "dn_rows_wgrad_multi_f32: G2 == NULL requires ng1 == INT32_MAX");
         DN_REQUIRE(q.colsum_of >= 0 && q.colsum_of <= 2 && q.first_rel >= 0 && q.row0 >= 0, "dn_rows_wgrad_multi_f32: bad job");
-        DN_REQUIRE(q.mask_a_bits == nullptr, "dn_rows_wgrad_multi_f32: no masks here (the fp32 rows arrive masked)");
+        DN_REQUIRE(q.mask_a_bits == nullptr || (q.A2 == nullptr && q.idx_a == nullptr && reinterpret_cast<uintptr_t>(q.mask_a_bits) % 16 == 0),
+                   "dn_rows_wgrad_multi_f32: a mask excludes A2 / idx_a");
         DN_REQUIRE(k == 0 || k >= num_jobs || q.first_rel > jobs[k - 1].first_rel, "dn_rows_wgrad_multi_f32: jobs must ascend in first_rel");
-        wj.j[k] = WgJobF{(const float*)q.A, (const float*)q.A2, q.idx_a, (const float*)q.G, (const float*)q.G2, q.idx_g, q.na1, q.ng1,
-                         q.colsum_of, q.first_rel, q.row0};
+        wj.j[k] = WgJobF{(const float*)q.A, (const float*)q.A2, q.idx_a, (const float*)q.G, (const float*)q.G2, q.idx_g,
+                         (const float*)q.mask_a_bits, q.na1, q.ng1, q.colsum_of, q.first_rel, q.row0, q.act_slope};
     }
     DN_REQUIRE(jobs[0].first_rel == 0, "dn_rows_wgrad_multi_f32: the first job starts at relation 0");
     hipStream_t st = (hipStream_t)stream;
@@ -851,6 +1015,31 @@ int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t 
     }
     dim3 grid((unsigned)(dn_cdiv(tile, 32) + dn_cdiv(H, 32)), (unsigned)R);
     hipLaunchKernelGGL(wgrad_reduce_f32_kernel, grid, dim3(256), 0, st, (const float*)ws, chunk_ptr, tile, out, (const float*)csp, H, out_colsum);
+    DN_CHECK_LAUNCH();
+    return DN_OK;
+}
+
+int dn_rows_chain2_f32(const float* X, int32_t H, const float* W1, const float* b1, int32_t relu1, const float* mask0, const float* mask1,
+                       const float* W2, const float* b2, int32_t relu2, int64_t N, float* Y1, float* Y2, int32_t w_kn, float act_slope,
+                       dn_stream_t stream) {
+    DN_REQUIRE(H == 64 || H == 128, "dn_rows_chain2_f32: unsupported width %d (64 / 128 only)", H);
+    DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && w_kn >= 0 && w_kn <= 3, "dn_rows_chain2_f32: bad arguments");
+    if (N == 0) return DN_OK;
+    DN_REQUIRE(X && W1 && W2 && Y1 && Y2, "dn_rows_chain2_f32: NULL pointer");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2) |
+                reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(mask0) |
+                reinterpret_cast<uintptr_t>(mask1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) % 16 == 0,
+               "dn_rows_chain2_f32: unaligned pointer");
+    const int64_t num_tiles = dn_cdiv(N, (int64_t)kRows);
+    const int64_t tiles_per_wg = dn_cdiv(num_tiles, (int64_t)512);            // two workgroups per CU
+    const int64_t grid = dn_cdiv(num_tiles, tiles_per_wg);
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 64)
+        hipLaunchKernelGGL((rows_chain2_f32s_kernel<64>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, W1, b1, relu1, mask0, mask1, W2, b2,
+                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope);
+    else
+        hipLaunchKernelGGL((rows_chain2_f32s_kernel<128>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, W1, b1, relu1, mask0, mask1, W2, b2,
+                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

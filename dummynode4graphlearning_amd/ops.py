@@ -355,8 +355,10 @@ def rows_wgrad_multi(jobs, chunk_table, num_rels, H, out_dtype):
         arr[k].colsum_of, arr[k].first_rel, arr[k].row0 = int(jb.get("colsum_of", 0)), int(jb["first_rel"]), int(jb["row0"])
         arr[k].act_slope = float(jb.get("slope", 0.0))
     is_f32 = jobs[0]["A"].dtype == torch.float32
-    if is_f32:
-        assert out_dtype == torch.float32 and not f32_mode() and all(jb.get("mask_a_bits") is None for jb in jobs)
+    if is_f32:                                                              # (a job's mask is then the saved activation itself: float [rows, H])
+        assert out_dtype == torch.float32 and not f32_mode()
+        assert all(jb.get("mask_a_bits") is None or (jb["mask_a_bits"].dtype == torch.float32 and jb["mask_a_bits"].shape == jb["A"].shape
+                                                     and jb["mask_a_bits"].is_contiguous()) for jb in jobs)
     out = torch.empty((num_rels, H, H), dtype=out_dtype, device=dev)
     colsum = torch.empty((num_rels, H), dtype=torch.float32, device=dev)
     colsum_lp = torch.empty((num_rels, H), dtype=out_dtype, device=dev) if out_dtype != torch.float32 else None
@@ -584,6 +586,28 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     else:
         _launch()
     return (Y1, Y2, bits1, bits2) if want_bits else (Y1, Y2)
+
+
+def rows_chain2_f32(x, W1n, b1, relu1, W2n, b2, relu2, mask0=None, mask1=None, w_kn=(False, False), slope=0.0):
+    """(Y1, Y2) of two dense layers in one pass over fp32 rows (dn_rows_chain2_f32, 3-term split, H = 64 / 128): Y1 = epi1(m0(x) @ W1n^T)
+    masked by mask1, Y2 = epi2(Y1 @ W2n^T); mask0 / mask1: float [N, H] saved activations (keep where > 0, else x slope)."""
+    x, W1n, W2n = x.contiguous(), W1n.contiguous(), W2n.contiguous()
+    require_gpu(x, W1n, b1, W2n, b2, mask0, mask1)
+    N, H = x.shape
+    assert x.dtype == torch.float32 and H in (64, 128) and W1n.shape == (H, H) and W2n.shape == (H, H) and not f32_mode()
+    for m in (mask0, mask1):
+        assert m is None or (m.dtype == torch.float32 and m.shape == (N, H) and m.is_contiguous())
+    Y1, Y2 = torch.empty_like(x), torch.empty_like(x)
+
+    def _launch():
+        check(lib().dn_rows_chain2_f32(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask0), ptr(mask1), ptr(W2n), ptr(b2),
+                                       1 if relu2 else 0, N, ptr(Y1), ptr(Y2), (1 if w_kn[0] else 0) | (2 if w_kn[1] else 0), float(slope),
+                                       stream_ptr()), "dn_rows_chain2_f32")
+    if kernel_timer is not None:
+        kernel_timer.launch("rows_chain2", _launch)
+    else:
+        _launch()
+    return Y1, Y2
 
 
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0), drop_enable=None):
@@ -2369,6 +2393,7 @@ class _RginLayerSmallFn(torch.autograd.Function):
 
 
 LAYER_F32_ENABLED = _os.environ.get("DN_LAYER_F32", "1") != "0"
+CHAIN2_F32_ENABLED = _os.environ.get("DN_CHAIN2_F32", "1") != "0"          # 0: the fp32 layer function keeps one launch per Linear
 
 
 def rgin_layer_f32_ok(x, W, W_loop, bias, linears, index_set):
@@ -2400,11 +2425,14 @@ class _RginLayerF32Fn(torch.autograd.Function):
         slope = float(slope)
         h = torch.empty_like(x)
         aux = message_pass(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", index_set.ybuf(H, x.dtype, x.device), h)
-        tiles, _ = _dense_table(N, x.device)
-        h1 = rows_transform(h, w1.contiguous().unsqueeze(0), tiles, N, bias=None if b1 is None else b1.contiguous().view(1, -1), relu=True,
-                            slope=slope)
-        h2 = rows_transform(h1, w2.contiguous().unsqueeze(0), tiles, N, bias=None if b2 is None else b2.contiguous().view(1, -1), relu=True,
-                            slope=slope)
+        if CHAIN2_F32_ENABLED:
+            h1, h2 = rows_chain2_f32(h, w1, b1, True, w2, b2, True, slope=slope)
+        else:
+            tiles, _ = _dense_table(N, x.device)
+            h1 = rows_transform(h, w1.contiguous().unsqueeze(0), tiles, N, bias=None if b1 is None else b1.contiguous().view(1, -1), relu=True,
+                                slope=slope)
+            h2 = rows_transform(h1, w2.contiguous().unsqueeze(0), tiles, N, bias=None if b2 is None else b2.contiguous().view(1, -1), relu=True,
+                                slope=slope)
         ctx.index_set, ctx.slope = index_set, slope
         ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
         ctx.save_for_backward(x, h, h1, h2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
@@ -2417,10 +2445,17 @@ class _RginLayerF32Fn(torch.autograd.Function):
         ix = iset.parts[0][2]
         x, h, h1, h2, W, W_loop, w1, w2, aux = ctx.saved_tensors
         N, H, R = x.shape[0], x.shape[1], W.shape[0]
-        tiles, _ = _dense_table(N, x.device)
-        gm2 = relu_bwd(gout.contiguous(), h2, slope)                        # the outer activation's mask
-        gm1 = rows_transform(gm2, w2.contiguous().unsqueeze(0), tiles, N, mask_pos=h1, slope=slope, w_kn=True)   # masked for the inner one
-        g0 = rows_transform(gm1, w1.contiguous().unsqueeze(0), tiles, N, w_kn=True)
+        g = gout.contiguous()
+        if CHAIN2_F32_ENABLED:
+            # outer mask, dgrad 2, inner mask, dgrad 1 in ONE launch; the weight gradient of Linear 2 masks g itself (mask = the saved output)
+            gm1, g0 = rows_chain2_f32(g, w2, None, False, w1, None, False, mask0=h2, mask1=h1, w_kn=(True, True), slope=slope)
+            job2 = dict(A=g, G=h1, colsum_of=1, mask_a_bits=h2, slope=slope)
+        else:
+            tiles, _ = _dense_table(N, x.device)
+            gm2 = relu_bwd(g, h2, slope)                                    # the outer activation's mask
+            gm1 = rows_transform(gm2, w2.contiguous().unsqueeze(0), tiles, N, mask_pos=h1, slope=slope, w_kn=True)   # masked for the inner one
+            g0 = rows_transform(gm1, w1.contiguous().unsqueeze(0), tiles, N, w_kn=True)
+            job2 = dict(A=gm2, G=h1, colsum_of=1)
         gx = torch.empty_like(x)
         aux_b = message_pass(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", iset.ybuf(H, x.dtype, x.device), gx)
         # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
@@ -2431,7 +2466,7 @@ class _RginLayerF32Fn(torch.autograd.Function):
             ix._layer_chunks = build_row_tables(vptr, R + 3, P_all + 2 * N, wgrad_chunk_rows(vptr_host), want_ptr=True)
         jobs = [dict(A=x, A2=aux if ctx.has[3] else None, idx_a=ix.row_in, G=g0, G2=aux_b, idx_g=ix.row_out, colsum_of=2, first_rel=0, row0=0),
                 dict(A=gm1, G=h, colsum_of=1, first_rel=R + 1, row0=ix.num_rows),
-                dict(A=gm2, G=h1, colsum_of=1, first_rel=R + 2, row0=ix.num_rows + N)]
+                dict(first_rel=R + 2, row0=ix.num_rows + N, **job2)]
         gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, torch.float32)
         return (gx, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1], cs[R + 1] if ctx.has[1] else None, gw[R + 2],
                 cs[R + 2] if ctx.has[2] else None)

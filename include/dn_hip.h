@@ -447,14 +447,27 @@ typedef struct dn_wgrad_job {
 int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
                              const int32_t* chunk_ptr, void* out, int32_t out_is_f32, float* out_colsum, void* out_colsum_lp,
                              void* workspace, size_t workspace_bytes, dn_stream_t stream);
-/* The same for fp32 rows on the 3-term bf16 split (dn_rows_wgrad_f32 with precision 0): A / A2 / G / G2 of a job are float tensors,
- * mask_a_bits must be NULL (the reference-precision layer masks its gradient rows in the launches in front: dn_relu_bwd_f32 and
- * dn_rows_transform_f32's mask_pos), act_slope is unused.  out [R][H][H] and out_colsum [R][H] fp32.  H = 64 / 128.  With this the
+/* The same for fp32 rows on the 3-term bf16 split (dn_rows_wgrad_f32 with precision 0): A / A2 / G / G2 of a job are float tensors;
+ * a job's mask_a_bits, when not NULL, points to a FLOAT tensor [rows of A, H] -- the saved activation, dn_rows_wgrad_f32's mask_a:
+ * A rows are kept where it is > 0 and multiplied by act_slope elsewhere (needs A2 == NULL and idx_a == NULL).  out [R][H][H] and
+ * out_colsum [R][H] fp32.  H = 64 / 128.  With this the
  * backward of an fp32 RGIN layer at the reference's default width (config.py:456-461) takes one weight-gradient launch and one
  * reduce instead of three of each (rgin.py:102-160's three parameter groups: weight / loop_weight + bias, mlp[0], mlp[2]). */
 int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t H, int64_t R, const int32_t* chunks, int64_t num_chunks,
                             const int32_t* chunk_ptr, float* out, float* out_colsum, void* workspace, size_t workspace_bytes,
                             dn_stream_t stream);
+
+/* Two dense layers in ONE pass over fp32 rows (3-term bf16 split; H = 64 / 128):
+ *   X0 = mask0 ? keep_or_scale(X, mask0) : X;   Y1 = keep_or_scale?(epi1(X0 @ W1n^T), mask1);   Y2 = epi2(Y1 @ W2n^T)
+ * epi = (+ bias) then the optional activation (relu flag, act_slope as in dn_rows_transform_f32); mask0 / mask1 (may be NULL) are
+ * float tensors [N, H]: elements are kept where the mask is > 0 and multiplied by act_slope elsewhere.  w_kn bit i: weight i is given
+ * [in][out] (the parameter of the OTHER direction as stored) instead of [out][in].  Forward of the reference MLP
+ * (subgraph_isomorphism/models/rgin.py:50-57: Linear, act, Linear + the layer's activation :147-151) and -- with mask0 = the saved
+ * output, W1n = Linear 2's weight, mask1 = the saved hidden rows, W2n = Linear 1's weight, w_kn = 3 -- autograd's input-gradient
+ * chain through both, each as one launch (the fp32 twin of dn_rows_chain2_bf16; its masks are the saved activations, not bits). */
+int dn_rows_chain2_f32(const float* X, int32_t H, const float* W1n, const float* b1, int32_t relu1, const float* mask0,
+                       const float* mask1, const float* W2n, const float* b2, int32_t relu2, int64_t N, float* Y1, float* Y2,
+                       int32_t w_kn, float act_slope, dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU

@@ -642,6 +642,43 @@ def test_wgrad_ring_kernel_with_loader_waves_at_every_pipeline_length(rows):
         assert float((cs[0].cpu().double() - am.sum(0)).abs().max()) < 1e-3 * max(1.0, float(am.sum(0).abs().max()))
 
 
+@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 1000, 16385, 70001])
+def test_chain2_f32_forward_and_backward_chain(H, N):
+    """dn_rows_chain2_f32 (two dense layers in one pass over fp32 rows, 3-term split): the forward of the reference MLP
+    (Linear-act-Linear-act, biases) and the backward's input-gradient chain (outer mask from the saved output, dgrad 2 on the weight as
+    stored, inner mask from the saved hidden rows, dgrad 1) for ReLU and leaky ReLU, from one row to several tiles per workgroup with a
+    ragged last tile -- against fp64 math at the goldens' tolerance; equal to the separate launches up to the split's rounding."""
+    ops = _ops()
+    rng = np.random.default_rng(N + H)
+    f = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    d = lambda t: t.to(DEV)  # noqa: E731
+    x, g = f(rng.standard_normal((N, H))), f(rng.standard_normal((N, H)))
+    W1, W2 = f(rng.standard_normal((H, H)) / np.sqrt(H)), f(rng.standard_normal((H, H)) / np.sqrt(H))
+    b1, b2 = f(rng.standard_normal(H) * 0.1), f(rng.standard_normal(H) * 0.1)
+    for slope in (0.0, 1.0 / 5.5):
+        act = lambda t: torch.where(t > 0, t, t * slope)  # noqa: E731
+        h1, h2 = ops.rows_chain2_f32(d(x), d(W1), d(b1), True, d(W2), d(b2), True, slope=slope)
+        r1 = act(x.double() @ W1.double().t() + b1.double())
+        r2 = act(h1.cpu().double() @ W2.double().t() + b2.double())       # from the stored hidden rows
+        assert float((h1.cpu().double() - r1).abs().max()) <= 1e-4 * max(1.0, float(r1.abs().max()))
+        assert float((h2.cpu().double() - r2).abs().max()) <= 1e-4 * max(1.0, float(r2.abs().max()))
+        tiles, _ = ops._dense_table(N, torch.device(DEV))
+        s1 = ops.rows_transform(d(x), d(W1).unsqueeze(0), tiles, N, bias=d(b1).view(1, -1), relu=True, slope=slope)
+        assert float((h1 - s1).abs().max()) <= 2e-5 * max(1.0, float(s1.abs().max()))
+        # backward chain on the weights as stored ([out][in] read as [k][n])
+        g1, g0 = ops.rows_chain2_f32(d(g), d(W2), None, False, d(W1), None, False, mask0=h2, mask1=h1, w_kn=(True, True), slope=slope)
+        keep2, keep1 = (h2.cpu() > 0), (h1.cpu() > 0)
+        gm = torch.where(keep2, g.double(), g.double() * slope)
+        t = gm @ W2.double()
+        rg1 = torch.where(keep1, t, t * slope)
+        rg0 = g1.cpu().double() @ W1.double()
+        assert float((g1.cpu().double() - rg1).abs().max()) <= 1e-4 * max(1.0, float(rg1.abs().max()))
+        assert float((g0.cpu().double() - rg0).abs().max()) <= 1e-4 * max(1.0, float(rg0.abs().max()))
+        again = ops.rows_chain2_f32(d(g), d(W2), None, False, d(W1), None, False, mask0=h2, mask1=h1, w_kn=(True, True), slope=slope)
+        assert torch.equal(again[0], g1) and torch.equal(again[1], g0)
+
+
 @pytest.mark.parametrize("N", [1, 31, 32, 33, 257, 8191, 8224, 300001])
 @pytest.mark.parametrize("slope", [0.0, 1.0 / 5.5])
 def test_chain2_ring_kernel_at_every_pipeline_length(N, slope):
