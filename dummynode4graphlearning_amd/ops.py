@@ -2268,6 +2268,15 @@ class _ReluMlpFn(torch.autograd.Function):
             ctx.has_bias = [wb[1] is not None, wb[3] is not None]
             ctx.save_for_backward(x, h1, bits1, bits2, wb[0], wb[2])      # the output itself is not kept: only its sign bits
             return h2
+        if (n == 2 and CHAIN2_F32_ENABLED and x.dtype == torch.float32 and x.shape[1] in (64, 128) and not f32_mode()
+                and all(t is None or t.dtype == torch.float32 for t in wb)):
+            # fp32 (the reference's precision) at H = 64 / 128: both Linears in one launch each way (dn_rows_chain2_f32); the saved
+            # activations are the masks
+            h1, h2 = rows_chain2_f32(x, wb[0], wb[1], True, wb[2], wb[3], True, slope=slope)
+            ctx.n, ctx.chain = n, "f32"
+            ctx.has_bias = [wb[1] is not None, wb[3] is not None]
+            ctx.save_for_backward(x, h1, h2, wb[0], wb[2])
+            return h2
         tiles, _ = _dense_table(x.shape[0], x.device)
         acts = [x]
         for i in range(n):
@@ -2286,6 +2295,19 @@ class _ReluMlpFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         g = gout.contiguous()
         grads = [None] * (2 + 2 * n)
+        if ctx.chain == "f32":
+            x0, h1, h2, w1, w2 = saved
+            _, chunks = _dense_table(x0.shape[0], x0.device)
+            gw2, cs2 = rows_wgrad(g, h1, chunks, 1, out_dtype=w2.dtype, colsum_of=1, mask_a=h2, slope=slope)
+            g1, g0 = rows_chain2_f32(g, w2, None, False, w1, None, False, mask0=h2, mask1=h1, w_kn=(True, True), slope=slope)
+            gw1, cs1 = rows_wgrad(g1, x0, chunks, 1, out_dtype=w1.dtype, colsum_of=1)
+            grads[2], grads[4] = gw1[0], gw2[0]
+            if ctx.has_bias[0]:
+                grads[3] = cs1[0].to(g.dtype)
+            if ctx.has_bias[1]:
+                grads[5] = cs2[0].to(g.dtype)
+            grads[0] = g0 if ctx.needs_input_grad[0] else None
+            return tuple(grads)
         if ctx.chain:
             x0, h1, bits1, bits2, w1, w2 = saved
             _, chunks = _dense_table(x0.shape[0], x0.device)

@@ -251,6 +251,49 @@ def test_rep_net_residual_and_gate(golden_dir):
     assert _rel_max(got, cur) < RTOL
 
 
+@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("slope", [0.0, 1 / 5.5])
+def test_two_layer_fp32_mlp_takes_the_chain_launches(H, slope):
+    """ops.relu_mlp, two Linears, fp32 on the bf16 split at H = 64 / 128: ONE launch each way for the Linears (dn_rows_chain2_f32) and
+    two weight-gradient launches; the same numbers as one launch per Linear (forward: up to the split's rounding of the stored hidden
+    rows -- here bit-equal inputs give results within 2e-5; gradients likewise)."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(7 + H)
+    N = 2500
+    x0 = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(DEV)
+    gout = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(DEV)
+    lins = [torch.nn.Linear(H, H).to(DEV) for _ in range(2)]
+
+    def run():
+        for l in lins:
+            l.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            y = ops.relu_mlp(x, lins, slope)
+            y.backward(gout)
+        finally:
+            ops.kernel_timer = None
+        return [r[0] for r in timer.records], [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for l in lins for p in l.parameters()]
+
+    tags, got = run()
+    assert tags == ["rows_chain2", "rows_wgrad", "rows_chain2", "rows_wgrad"], tags
+    old = ops.CHAIN2_F32_ENABLED
+    try:
+        ops.CHAIN2_F32_ENABLED = False
+        tags1, sep = run()
+    finally:
+        ops.CHAIN2_F32_ENABLED = old
+    assert "rows_chain2" not in tags1 and len(tags1) == 6
+    for a, b in zip(got, sep):
+        assert _rel_l2(a, b) < 2e-5
+    with ops.f32_exact(True):                                           # the exact-f32 checker mode keeps one launch per Linear
+        tags2, exact = run()
+    assert "rows_chain2" not in tags2
+    assert _rel_l2(got[0], exact[0]) < 2e-5
+
+
 @pytest.mark.parametrize("slope", [0.0, 1 / 5.5])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_relu_mlp_matches_torch_autograd(dt, slope):
