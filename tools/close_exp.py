@@ -50,7 +50,7 @@ for d in ("f", "b"):
 
     res = {}
     for _ in range(rounds):
-        for abl in (0, 16, 0, 16):
+        for abl in ([int(v) for v in os.environ["ABLS"].split(",")] if os.environ.get("ABLS") else (0, 16, 0, 16)):
             res.setdefault(abl, []).append(timed(abl))
     for abl, v in res.items():
         print("  DN_CLOSE_ABL=%2d: %s us (min %.1f)" % (abl, " ".join("%.1f" % t for t in v), min(v)))
