@@ -311,6 +311,12 @@ def gcn_edge_index_of(data):
         keep = src != dst
         ar = torch.arange(data.x.shape[0], device=src.device, dtype=src.dtype)
         ix = ops.EdgeIndex(torch.cat([src[keep], ar]), torch.cat([dst[keep], ar]), data.x.shape[0], node_ptr=_node_ptr_or_none(data))
+        # (once per batch, so that the conv's forward has no boolean indexing -- a nonzero + host sync per call, and a sort-based
+        #  index_put in its backward -- and stays capturable: positions of the kept / dropped edges, the dropped edges' nodes)
+        all_kept = bool(keep.all())
+        ix.gcn_keep_idx = None if all_kept else keep.nonzero().view(-1)
+        ix.gcn_drop_idx = None if all_kept else (~keep).nonzero().view(-1)
+        ix.gcn_drop_src = None if all_kept else src[~keep]
         hit = (ix, keep, data.edge_index.shape[1])
         cache._gcn = hit
     return hit[0], hit[1]

@@ -144,15 +144,20 @@ class GCNConv(nn.Module):
         else:
             ew = edge_weight.to(torch.float32)
             loop_w = torch.ones(N, dtype=torch.float32, device=x.device)
-            if not bool(keep.all()):
-                loop_w = loop_w.index_put((data.edge_index[0][~keep],), ew[~keep])
-            w = torch.cat([ew[keep], loop_w])
+            if index.gcn_keep_idx is None:                      # no self loops in the batch (every dummy-augmented TU batch): nothing dropped
+                w = torch.cat([ew, loop_w])
+            else:                                               # (positions cached with the index: no boolean indexing per call)
+                loop_w = loop_w.index_put((index.gcn_drop_src,), ew.index_select(0, index.gcn_drop_idx))
+                w = torch.cat([ew.index_select(0, index.gcn_keep_idx), loop_w])
         # weighted in-degree through the CSR gather (ops.edge_sum: fixed summation order per node, no float atomics -- the
         # trainable dummy-edge weight flows through it, so torch's index_add would make the step non-reproducible)
         deg = ops.edge_sum(w.view(-1, 1), index).view(-1)
         dis = deg.pow(-0.5)
-        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
-        norm = dis[index.src.long()] * w * dis[index.dst.long()]
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).view(-1, 1)
+        # dis[src] * w * dis[dst] with the gathers' backward as segment sums over the index's own CSR / CSC (torch's indexing backward
+        # sorts the 10^5 indices on every call -- 19 merge launches -- and the whole step stops being capturable)
+        norm = (ops.gather_rows(dis, index.src, (index.out_ptr, index.out_perm)).view(-1) * w
+                * ops.gather_rows(dis, index.dst, (index.in_ptr, index.in_perm)).view(-1))
         out = ops.neighbor_sum(self.lin(x), index, 0.0, edge_scale=norm)
         return out + self.bias if self.bias is not None else out
 

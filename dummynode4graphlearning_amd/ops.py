@@ -822,6 +822,8 @@ class _SplitCSR:
         deg_main = torch.where(hub, torch.zeros_like(deg), deg)
         self.ptr_main = torch.cat([deg_main.new_zeros(1), torch.cumsum(deg_main, 0)]).to(I32)
         self.keep = keep
+        # (positions once, so that a scaled sum has no boolean indexing per call: nonzero + host sync, not capturable)
+        self.keep_pos, self.hub_pos = torch.nonzero(keep).reshape(-1), torch.nonzero(~keep).reshape(-1)
         self.idx_main = idx[keep].contiguous()
         # hub pass: entries of hub h in HUB_SPLIT-sized chunks
         hdeg = deg[hub_ids]
@@ -842,7 +844,7 @@ class _SplitCSR:
             return gather_segsum(x, self.idx, self.ptr, self.num_segments, scale=scale, self_in=self_in, self_coef=self_coef)
         sc_main = sc_hub = None
         if scale is not None:
-            sc_main, sc_hub = scale[self.keep].contiguous(), scale[~self.keep].contiguous()
+            sc_main, sc_hub = scale.index_select(0, self.keep_pos), scale.index_select(0, self.hub_pos)
         out = gather_segsum(x, self.idx_main, self.ptr_main, self.num_segments, scale=sc_main, self_in=self_in,
                             self_coef=self_coef)
         part = gather_segsum(x, self.idx_hub, self.chunk_ptr, self.chunk_ptr.numel() - 1, scale=sc_hub)

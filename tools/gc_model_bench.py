@@ -26,15 +26,19 @@ def batch_of(raw, labels, F_):
     G = node_ptr.numel() - 1
     batch = torch.repeat_interleave(torch.arange(G, device=dev), node_ptr[1:] - node_ptr[:-1])
     y = torch.randint(0, 2, (G,), device=dev)
-    return GraphBatch(x, torch.stack([aug["src"].long(), aug["dst"].long()]), batch, y=y, ptr=node_ptr)
+    return GraphBatch(x, torch.stack([aug["src"].long(), aug["dst"].long()]), batch, y=y, ptr=node_ptr,
+                      is_dummy_node=aug["is_dummy_node"].bool(), is_dummy_edge=aug["is_dummy_edge"].bool())
 
 
-def run(name, raw, labels, F_, H, layers):
+def run(name, raw, labels, F_, H, layers, kind="GIN"):
     data = batch_of(raw, labels, F_)
+    extra = {"num_layers": layers, "train_eps": False}
+    if kind == "GraphSAGE":
+        extra["aggregation"] = "max"                # the segment-max kernels (dn_gather_segmax_*)
     args = SimpleNamespace(num_features=data.x.shape[1], hidden_dim=H, num_classes=2, dropout_ratio=0.0,
-                           additional={"num_layers": layers, "train_eps": False}, epochs=1, device=dev, dummy_weight=0)
+                           additional=extra, epochs=1, device=dev, dummy_weight=1.0 if kind == "GCN" else 0)   # GCN: the trainable dummy-edge weight (dn_edge_dot_*)
     torch.manual_seed(0)
-    model = GC.GIN(args).to(dev).train()
+    model = getattr(GC, kind)(args).to(dev).train()
 
     def step():
         for p in model.parameters():
@@ -64,10 +68,14 @@ def run(name, raw, labels, F_, H, layers):
         rep = float("nan")
         print("   (HIP graph capture failed: %s)" % exc)
     E, N = data.edge_index.shape[1], data.x.shape[0]
-    print("%s GIN %d-layer H=%d step, N=%d E=%d: eager %.3f ms (%.1f M edges/s), HIP-graph replay %.3f ms (%.1f M edges/s)"
-          % (name, layers, H, N, E, eager * 1e3, E / eager / 1e6, rep * 1e3, E / rep / 1e6))
+    print("%s %s %d-layer H=%d step, N=%d E=%d: eager %.3f ms (%.1f M edges/s), HIP-graph replay %.3f ms (%.1f M edges/s)"
+          % (name, kind, layers, H, N, E, eager * 1e3, E / eager / 1e6, rep * 1e3, E / rep / 1e6))
 
 
-run("config 1", synthetic.config1(), 7, 8, 64, 3)
-run("config 2", synthetic.config2(), 3, 5, 128, 2)
-run("config 4 (one rank)", synthetic.config4(), 37, 38, 256, 2)
+if "--f1" in sys.argv:              # the f-1 models: GCN with the trainable dummy-edge weight, GraphSAGE with max aggregation
+    run("config 2", synthetic.config2(), 3, 5, 128, 2, kind="GCN")
+    run("config 2", synthetic.config2(), 3, 5, 128, 2, kind="GraphSAGE")
+else:
+    run("config 1", synthetic.config1(), 7, 8, 64, 3)
+    run("config 2", synthetic.config2(), 3, 5, 128, 2)
+    run("config 4 (one rank)", synthetic.config4(), 37, 38, 256, 2)
