@@ -67,7 +67,7 @@ _SIGS = {
                                       ctypes.POINTER(c_i32), P, P, P, P, P, ctypes.POINTER(c_i32), P, c_sz, P]),
     "dn_rows_wgrad_multi_bf16": (ctypes.c_int, [ctypes.POINTER(WgradJob), c_i32, c_i32, c_i64, P, c_i64, P, P, c_i32, P, P, P, c_sz, P]),
     "dn_rows_wgrad_multi_f32": (ctypes.c_int, [ctypes.POINTER(WgradJob), c_i32, c_i32, c_i64, P, c_i64, P, P, P, P, c_sz, P]),
-    "dn_rows_chain2_f32": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, c_i32, c_f32, P]),
+    "dn_rows_chain2_f32": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, P, P, c_i32, c_i64, P, P, c_i32, c_f32, P, P, P]),
     "dn_layer_graphs_fwd_bf16": (ctypes.c_int, [P, c_i32, P, P, P, c_i32, P, P, P, P, c_f32, P, P, P, P, P, c_i64, c_i64, P, P, P, P, P, P, P,
                                                 P, P, P]),
     "dn_layer_graphs_bwd_bf16": (ctypes.c_int, [P, c_i32, P, P, c_i32, P, P, c_f32, P, P, P, P, P, P, P, c_i64, c_i64, P, P, P, P, P, P, P,

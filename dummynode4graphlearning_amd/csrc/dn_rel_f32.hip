@@ -731,7 +731,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_chain2_f32s_kernel(const flo
                                                                        const float* __restrict__ W2, const float* __restrict__ b2,
                                                                        int32_t relu2, int32_t N, int32_t tiles_per_wg,
                                                                        float* __restrict__ Y1, float* __restrict__ Y2, int32_t w_kn,
-                                                                       float slope) {
+                                                                       float slope, const float* __restrict__ residual,
+                                                                       float* __restrict__ Y2_plus) {
     static_assert(H == 64 || H == 128, "unsupported width");
     constexpr int SX = H + 8;                                   // bf16 elements per LDS row of an operand tile
     constexpr int SY = H + 4;                                   // floats per LDS row of the output tile
@@ -837,6 +838,15 @@ __global__ __launch_bounds__(kThreads, 2) void rows_chain2_f32s_kernel(const flo
     for (int t = t_beg; t < t_end; ++t) {
         const int b = (t - t_beg) & 1;
         if (t + 1 < t_end) load_rows(t + 1);                    // in flight under both stages of this tile
+        float4 rs[P];
+        if (residual) {                                         // ... as are the rows the output is added to (Y2_plus = Y2 + residual)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int piece = tid + j * kThreads, p = t * kRows + piece / (H / 4), c = piece % (H / 4);
+                rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (piece < NP && p < N) rs[j] = *reinterpret_cast<const float4*>(residual + (size_t)p * H + c * 4);
+            }
+        }
         float4 m1[P];
         if (mask1) {                                            // ... as are this tile's stage-1 mask rows
 #pragma unroll
@@ -871,7 +881,12 @@ __global__ __launch_bounds__(kThreads, 2) void rows_chain2_f32s_kernel(const flo
         for (int j = 0; j < P; ++j) {
             const int piece = tid + j * kThreads, r = piece / (H / 4), c = piece % (H / 4);
             const int p = t * kRows + r;
-            if (piece < NP && p < N) *reinterpret_cast<float4*>(Y2 + (size_t)p * H + c * 4) = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
+            if (piece < NP && p < N) {
+                const float4 v = *reinterpret_cast<const float4*>(ldy + r * SY + c * 4);
+                *reinterpret_cast<float4*>(Y2 + (size_t)p * H + c * 4) = v;
+                if (residual)
+                    *reinterpret_cast<float4*>(Y2_plus + (size_t)p * H + c * 4) = make_float4(v.x + rs[j].x, v.y + rs[j].y, v.z + rs[j].z, v.w + rs[j].w);
+            }
         }
         __syncthreads();
     }
@@ -1021,7 +1036,9 @@ int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t 
 
 int dn_rows_chain2_f32(const float* X, int32_t H, const float* W1, const float* b1, int32_t relu1, const float* mask0, const float* mask1,
                        const float* W2, const float* b2, int32_t relu2, int64_t N, float* Y1, float* Y2, int32_t w_kn, float act_slope,
-                       dn_stream_t stream) {
+                       const float* residual, float* Y2_plus, dn_stream_t stream) {
+    DN_REQUIRE((residual == nullptr) == (Y2_plus == nullptr), "dn_rows_chain2_f32: residual and Y2_plus come together");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(Y2_plus)) % 16 == 0, "dn_rows_chain2_f32: unaligned pointer");
     DN_REQUIRE(H == 64 || H == 128, "dn_rows_chain2_f32: unsupported width %d (64 / 128 only)", H);
     DN_REQUIRE(N >= 0 && N < 0x7fffffffLL && w_kn >= 0 && w_kn <= 3, "dn_rows_chain2_f32: bad arguments");
     if (N == 0) return DN_OK;
@@ -1036,10 +1053,10 @@ int dn_rows_chain2_f32(const float* X, int32_t H, const float* W1, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (H == 64)
         hipLaunchKernelGGL((rows_chain2_f32s_kernel<64>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, W1, b1, relu1, mask0, mask1, W2, b2,
-                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope);
+                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope, residual, Y2_plus);
     else
         hipLaunchKernelGGL((rows_chain2_f32s_kernel<128>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, W1, b1, relu1, mask0, mask1, W2, b2,
-                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope);
+                           relu2, (int32_t)N, (int32_t)tiles_per_wg, Y1, Y2, w_kn, act_slope, residual, Y2_plus);
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

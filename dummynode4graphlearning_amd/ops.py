@@ -588,26 +588,29 @@ def rows_chain2(x, W1n, b1, relu1, W2n, b2, relu2, mask0_bits=None, mask1_bits=N
     return (Y1, Y2, bits1, bits2) if want_bits else (Y1, Y2)
 
 
-def rows_chain2_f32(x, W1n, b1, relu1, W2n, b2, relu2, mask0=None, mask1=None, w_kn=(False, False), slope=0.0):
+def rows_chain2_f32(x, W1n, b1, relu1, W2n, b2, relu2, mask0=None, mask1=None, w_kn=(False, False), slope=0.0, residual=None):
     """(Y1, Y2) of two dense layers in one pass over fp32 rows (dn_rows_chain2_f32, 3-term split, H = 64 / 128): Y1 = epi1(m0(x) @ W1n^T)
     masked by mask1, Y2 = epi2(Y1 @ W2n^T); mask0 / mask1: float [N, H] saved activations (keep where > 0, else x slope)."""
     x, W1n, W2n = x.contiguous(), W1n.contiguous(), W2n.contiguous()
     require_gpu(x, W1n, b1, W2n, b2, mask0, mask1)
     N, H = x.shape
+    require_gpu(residual)
     assert x.dtype == torch.float32 and H in (64, 128) and W1n.shape == (H, H) and W2n.shape == (H, H) and not f32_mode()
     for m in (mask0, mask1):
         assert m is None or (m.dtype == torch.float32 and m.shape == (N, H) and m.is_contiguous())
     Y1, Y2 = torch.empty_like(x), torch.empty_like(x)
+    assert residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape and residual.is_contiguous())
+    Ysum = torch.empty_like(x) if residual is not None else None      # residual given: also returns Y2 + residual
 
     def _launch():
         check(lib().dn_rows_chain2_f32(ptr(x), H, ptr(W1n), ptr(b1), 1 if relu1 else 0, ptr(mask0), ptr(mask1), ptr(W2n), ptr(b2),
                                        1 if relu2 else 0, N, ptr(Y1), ptr(Y2), (1 if w_kn[0] else 0) | (2 if w_kn[1] else 0), float(slope),
-                                       stream_ptr()), "dn_rows_chain2_f32")
+                                       ptr(residual), ptr(Ysum), stream_ptr()), "dn_rows_chain2_f32")
     if kernel_timer is not None:
         kernel_timer.launch("rows_chain2", _launch)
     else:
         _launch()
-    return Y1, Y2
+    return (Y1, Y2, Ysum) if residual is not None else (Y1, Y2)
 
 
 def build_slot_table(list_ptr, list_rows, num_nodes, num_edge_rows, K=SELFSUM_SLOTS, drop=(0, 0), drop_enable=None):
@@ -2007,7 +2010,7 @@ def layer_graphs_bwd(g, W, W_loop, w1, w2, slope, bits1, bits2, ix):
     return g1, g0, gx, aux_b
 
 
-def message_pass(xs, pw, bias, ix, direction, ybuf, out):
+def message_pass(xs, pw, bias, ix, direction, ybuf, out, add_in=None):
     """One direction of the row-factorised pass over one RowIndex -- the launches that ARE the layer's gather-scatter:
          'f':  out[v] = sum_{rows p -> v} (in_row(p) @ W[rel p])          pw = the weights (PassWeights), [k][n] or W^T
          'b':  out[u] = sum_{rows p <- u} (g_row(p)  @ W[rel p]^T)        pw = W per relation as it is ([n = in][k = out])
@@ -2019,9 +2022,10 @@ def message_pass(xs, pw, bias, ix, direction, ybuf, out):
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_f_idx, ix.aux_f_ptr, ix.num_aux_f, ix.row_in, ix.dst_rows, ix.dst_ptr
     else:
         aux_idx, aux_ptr, n_aux, idx_rows, lst, lptr = ix.aux_b_idx, ix.aux_b_ptr, ix.num_aux_b, ix.row_out, ix.src_rows, ix.src_ptr
+    f32_direct = xs.dtype == torch.float32 and _kn_ok(xs) and pw.rel.shape[1] == pw.rel.shape[2]
+    assert add_in is None or f32_direct        # (add_in: rows added to the result by the closing gather -- the fp32 path only)
     if conv_graphs_ok(xs, pw, ix):
         return conv_graphs(xs, pw, bias, ix, direction, out)
-    f32_direct = xs.dtype == torch.float32 and _kn_ok(xs) and pw.rel.shape[1] == pw.rel.shape[2]
     if pw.kn and not (f32_direct or (_kn_ok(xs) and _selfsum_ok(ix, xs))):
         pw = pw.nk()
     if _selfsum_ok(ix, xs) and _row_index_fold(ix, direction, _close_kind(xs)) is not None:
@@ -2039,7 +2043,7 @@ def message_pass(xs, pw, bias, ix, direction, ybuf, out):
         R = pw.rel.shape[0]
         Y = rows_transform(xs, pw.rel, ix.tile_table, ix.num_rows, idx=idx_rows, X2=aux, bias=bias, tag="conv", out=ybuf,
                            w_kn=pw.kn, W_loop=pw.loop, loop_rel=R, bias_rel=R if bias is not None else -1)
-        gather_segsum(Y, lst, lptr, ix.num_nodes, out=out)
+        gather_segsum(Y, lst, lptr, ix.num_nodes, out=out, self_in=add_in, self_coef=1.0 if add_in is not None else 0.0)
         return aux
     Wmat = pw.all_nk()
     bias_all = None
@@ -2441,7 +2445,7 @@ class _RginLayerF32Fn(torch.autograd.Function):
     the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_f32) where the separate functions take three of each."""
 
     @staticmethod
-    def forward(ctx, x, slope, index_set, W, W_loop, bias, w1, b1, w2, b2):
+    def forward(ctx, x, slope, index_set, W, W_loop, bias, w1, b1, w2, b2, residual=False):
         ctx.f32_mode = f32_mode()
         x = x.contiguous()
         ix = index_set.parts[0][2]
@@ -2449,7 +2453,11 @@ class _RginLayerF32Fn(torch.autograd.Function):
         slope = float(slope)
         h = torch.empty_like(x)
         aux = message_pass(x, PassWeights(W, W_loop, kn=True), bias, ix, "f", index_set.ybuf(H, x.dtype, x.device), h)
-        if CHAIN2_F32_ENABLED:
+        ctx.residual = bool(residual)
+        out = None
+        if CHAIN2_F32_ENABLED and residual:             # x + layer(x): the sum leaves the MLP launch next to the activation
+            h1, h2, out = rows_chain2_f32(h, w1, b1, True, w2, b2, True, slope=slope, residual=x)
+        elif CHAIN2_F32_ENABLED:
             h1, h2 = rows_chain2_f32(h, w1, b1, True, w2, b2, True, slope=slope)
         else:
             tiles, _ = _dense_table(N, x.device)
@@ -2460,6 +2468,10 @@ class _RginLayerF32Fn(torch.autograd.Function):
         ctx.index_set, ctx.slope = index_set, slope
         ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
         ctx.save_for_backward(x, h, h1, h2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
+        if residual:
+            if out is None:
+                out = h2 + x
+            return out
         return h2
 
     @staticmethod
@@ -2481,7 +2493,9 @@ class _RginLayerF32Fn(torch.autograd.Function):
             g0 = rows_transform(gm1, w1.contiguous().unsqueeze(0), tiles, N, w_kn=True)
             job2 = dict(A=gm2, G=h1, colsum_of=1)
         gx = torch.empty_like(x)
-        aux_b = message_pass(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", iset.ybuf(H, x.dtype, x.device), gx)
+        # (residual: the gradient of x + layer(x) is g + the layer's input gradient -- g rides in the conv's closing gather)
+        aux_b = message_pass(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", iset.ybuf(H, x.dtype, x.device), gx,
+                             add_in=g if ctx.residual else None)
         # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
         if getattr(ix, "_layer_chunks", None) is None:
             P_all = ix.num_rows
@@ -2493,12 +2507,13 @@ class _RginLayerF32Fn(torch.autograd.Function):
                 dict(first_rel=R + 2, row0=ix.num_rows + N, **job2)]
         gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, torch.float32)
         return (gx, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1], cs[R + 1] if ctx.has[1] else None, gw[R + 2],
-                cs[R + 2] if ctx.has[2] else None)
+                cs[R + 2] if ctx.has[2] else None, None)
 
 
-def rgin_layer_f32(x, W, W_loop, bias, linears, slope, index_set):
+def rgin_layer_f32(x, W, W_loop, bias, linears, slope, index_set, residual=False):
+    """residual: return x + layer(x) (the representation nets' residual connection) from the same launches."""
     return _RginLayerF32Fn.apply(x, float(slope), index_set, W, W_loop, bias, linears[0].weight, linears[0].bias, linears[1].weight,
-                                 linears[1].bias)
+                                 linears[1].bias, bool(residual))
 
 
 def rgin_layer_small(x, W, W_loop, bias, linears, slope, index_set):

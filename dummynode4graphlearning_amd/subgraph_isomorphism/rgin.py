@@ -113,15 +113,26 @@ class RGINLayer(nn.Module):
     def self_loop(self):
         return hasattr(self, "loop_weight") and self.loop_weight is not None
 
-    def forward(self, g, node_feat, edge_type):
+    def forward_residual(self, g, node_feat, edge_type):
+        """node_feat + forward(g, node_feat, edge_type)[0] -- the representation nets' residual connection (rgin.py:243-245) -- from
+        the layer's own launches where they can carry it (the fp32 layer function with dropout off), else the plain sum."""
+        fuse = self.input_dim == self.hidden_dim and (self.drop.p == 0.0 or not self.training)
+        out, edge_type = self.forward(g, node_feat, edge_type, _residual=fuse)
+        if getattr(self, "_residual_done", False):
+            self._residual_done = False
+            return out, edge_type
+        return node_feat + out, edge_type
+
+    def forward(self, g, node_feat, edge_type, _residual=False):
         # side effects on the graph as in rgin.py:126-135,160
         g.ndata[NODEFEAT] = node_feat
         g.edata[EDGETYPE] = edge_type
+        self._residual_done = False
         W = dense_relation_weights(self)
         if ops.fused_path_supported(node_feat, W):
             # bf16: message pass, self loop (rgin.py:140-142) and bias in ONE row-factorised MFMA pipeline
             index = g.row_index(edge_type, self.num_rels, self.self_loop, closing_hint=(node_feat.shape[1], node_feat.dtype))
-            small = self._small_layer(node_feat, W, index)
+            small = self._small_layer(node_feat, W, index, _residual)
             if small is not None:
                 return self.drop(small), edge_type
             out = ops.rel_transform_fused(node_feat, W, self.bias if self.self_loop else None, index,
@@ -144,7 +155,7 @@ class RGINLayer(nn.Module):
         out = self.drop(out)
         return out, edge_type
 
-    def _small_layer(self, node_feat, W, index):
+    def _small_layer(self, node_feat, W, index, residual=False):
         """The whole layer -- conv, bias, Linear-act-Linear-act -- as ops.rgin_layer_small where it applies (bf16, the reference's default
         width 64 (config.py:456-461), a batch of small graphs, the MLP a plain Linear / activation chain with the layer's own `relu` /
         `leaky_relu`): seven launches a training step instead of eleven.  None: take the general route."""
@@ -159,7 +170,9 @@ class RGINLayer(nn.Module):
             return ops.rgin_layer_small(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
         if ops.rgin_layer_f32_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
             # the reference's own precision: the same launches as the separate functions, ONE weight-gradient launch in the backward
-            return ops.rgin_layer_f32(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
+            # (residual: node_feat + layer(node_feat) leaves the MLP launch; forward_residual is told through _residual_done)
+            self._residual_done = bool(residual)
+            return ops.rgin_layer_f32(node_feat, W, self.loop_weight, self.bias, linears, slope, index, residual=residual)
         return None
 
     def _run_mlp(self, out):
@@ -240,6 +253,10 @@ class RGINRepNet(nn.Module):
         if mask is None and gate is None:
             outputs = [g_emb]
             for layer in self.rgin:
+                if self.rep_residual and layer.input_dim == layer.hidden_dim:
+                    o, etype = layer.forward_residual(graph, outputs[-1], etype)      # (= outputs[-1] + layer(...), fused where it can be)
+                    outputs.append(o)
+                    continue
                 o, etype = layer(graph, outputs[-1], etype)
                 outputs.append(outputs[-1] + o if self.rep_residual and outputs[-1].size() == o.size() else o)
             return outputs[-1]

@@ -464,10 +464,12 @@ int dn_rows_wgrad_multi_f32(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t 
  * [in][out] (the parameter of the OTHER direction as stored) instead of [out][in].  Forward of the reference MLP
  * (subgraph_isomorphism/models/rgin.py:50-57: Linear, act, Linear + the layer's activation :147-151) and -- with mask0 = the saved
  * output, W1n = Linear 2's weight, mask1 = the saved hidden rows, W2n = Linear 1's weight, w_kn = 3 -- autograd's input-gradient
- * chain through both, each as one launch (the fp32 twin of dn_rows_chain2_bf16; its masks are the saved activations, not bits). */
+ * chain through both, each as one launch (the fp32 twin of dn_rows_chain2_bf16; its masks are the saved activations, not bits).
+ * residual / Y2_plus (both or neither; float [N, H]): Y2_plus = Y2 + residual is written next to Y2 -- the representation net's
+ * residual connection (rgin.py:243-245: `outputs[-1] + o`) without a launch of its own; Y2 stays the activation the backward masks by. */
 int dn_rows_chain2_f32(const float* X, int32_t H, const float* W1n, const float* b1, int32_t relu1, const float* mask0,
                        const float* mask1, const float* W2n, const float* b2, int32_t relu2, int64_t N, float* Y1, float* Y2,
-                       int32_t w_kn, float act_slope, dn_stream_t stream);
+                       int32_t w_kn, float act_slope, const float* residual, float* Y2_plus, dn_stream_t stream);
 
 /* Relation-wise transform of gathered rows on the matrix cores (bf16 in, fp32 acc, bf16 out):
  *   Y[p, n] = epi( sum_k Xcat[idx[p], k] * Wn[rel(p)][n][k] ),  epi = (+ bias[rel(p)][n]) then optional ReLU

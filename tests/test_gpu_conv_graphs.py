@@ -258,6 +258,54 @@ def test_fp32_rgin_layer_takes_one_weight_gradient_launch(H, act):
     assert "rows_wgrad_multi" not in tags2
 
 
+def test_fp32_rep_net_carries_the_residual_in_the_layer_launches():
+    """RGINRepNet (3 layers, residual: the reference's default, config.py:345-347) in fp32 at H = 64: `outputs[-1] + layer(...)`
+    (rgin.py:243-245) leaves the layer's MLP launch and the residual's gradient rides in the conv's closing gather -- no elementwise
+    add launches; the same numbers as the separate functions with torch adds (forward bit-equal per layer chain, gradients to the
+    split's rounding)."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINRepNet
+    raw = synthetic.config3(seed=8, graphs=48)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N = int(aug["node_label"].numel())
+    torch.manual_seed(9)
+    net = RGINRepNet(64, 8, num_layers=3, regularizer="basis", act_func="relu").to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x0 = torch.randn(N, 64, device=DEV, generator=gen)
+    coef = torch.randn(N, 64, device=DEV, generator=gen)
+
+    def run():
+        g = BatchedGraph(aug["src"], aug["dst"], N, edata={"label": aug["edge_label"]})
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            out = net.get_graph_rep(g, x)
+            out.backward(coef)
+        finally:
+            ops.kernel_timer = None
+        return [r[0] for r in timer.records], [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+    tags, got = run()
+    assert tags.count("rows_chain2") == 6 and tags.count("rows_wgrad_multi") == 3, tags
+    old = ops.LAYER_F32_ENABLED
+    try:
+        ops.LAYER_F32_ENABLED = False
+        tags1, sep = run()
+    finally:
+        ops.LAYER_F32_ENABLED = old
+    assert "rows_wgrad_multi" not in tags1
+    for a, b in zip(got, sep):
+        assert _rel_l2(a, b) < 2e-5
+    _, again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+
+
 def test_batches_outside_the_limits_keep_the_row_factorised_launches():
     from dummynode4graphlearning_amd import ops
     rng = np.random.default_rng(9)
