@@ -157,15 +157,26 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
                                                           int64_t N, int32_t C, T* __restrict__ out) {
     const int64_t total = N * (C / 4);
     const float invN = 1.f / (float)N;
+    // a thread's column group is the same in every trip of the loop when the stride is a multiple of C / 4 (C / 4 divides 256 for
+    // C = 64 .. 1024 in powers of two): its per-column constants are loaded once, not per element (ten loads per 16-byte piece)
+    const bool fixed = (kBlock % (C / 4)) == 0;
+    float cm[4], cr[4], cg[4], cb[4], c1[4], c2[4];
+    auto consts = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cm[k] = mean[c + k]; cr[k] = rstd[c + k]; cg[k] = w ? w[c + k] : 1.f; cb[k] = b ? b[c + k] : 0.f;
+            c1[k] = MODE == 1 ? s1[c + k] * invN : 0.f; c2[k] = MODE == 1 ? s2[c + k] * invN : 0.f;
+        }
+    };
+    if (fixed) consts((int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) % (C / 4)) * 4);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int c = (int)(i % (C / 4)) * 4;
+        if (!fixed) consts((int)(i % (C / 4)) * 4);
         float x[4], o[4];
         V4<T>::load(X + i * 4, x);
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float g = w ? w[c + k] : 1.f, bb = b ? b[c + k] : 0.f;
-                o[k] = fmaf((x[k] - mean[c + k]) * rstd[c + k], g, bb);
+                o[k] = fmaf((x[k] - cm[k]) * cr[k], cg[k], cb[k]);
                 if (relu) o[k] = fmaxf(o[k], 0.f);
             }
         } else {
@@ -173,12 +184,11 @@ __global__ __launch_bounds__(kBlock) void colapply_kernel(const T* __restrict__ 
             V4<T>::load(DY + i * 4, dy);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float g = w ? w[c + k] : 1.f;
-                const float xh = (x[k] - mean[c + k]) * rstd[c + k];
+                const float xh = (x[k] - cm[k]) * cr[k];
                 // (as a product: hipcc 7.0 turns `cond ? 0.f : dy[k]` here into "dy[k] = 0; if (!cond) {}" -- the gradient vanished)
-                const float keep = (relu && !(fmaf(xh, g, b ? b[c + k] : 0.f) > 0.f)) ? 0.f : 1.f;
+                const float keep = (relu && !(fmaf(xh, cg[k], cb[k]) > 0.f)) ? 0.f : 1.f;
                 const float d = dy[k] * keep;
-                o[k] = g * rstd[c + k] * (d - s1[c + k] * invN - xh * s2[c + k] * invN);
+                o[k] = cg[k] * cr[k] * (d - c1[k] - xh * c2[k]);
             }
         }
         V4<T>::store(out + i * 4, o);
