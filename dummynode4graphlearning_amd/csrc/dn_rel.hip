@@ -817,29 +817,33 @@ __global__ __launch_bounds__(kWgThreads) void rows_wgrad_ix_kernel(const bf16_t*
 // -------------------------------------------------------------------------------------------------
 constexpr int kLsCompute = 8, kLsLoaders = 4, kLsThreads = 64 * (kLsCompute + kLsLoaders);
 
+// The body takes its LDS from the kernel that calls it (a kernel serving several MODEs -- rows_wgrad_ls_multi_kernel -- declares it
+// once, for the largest): lds = NST stages of [A rows | G rows | mask bits (MODE 2)], idxL / adrL = the loaders' index and address
+// rings.  ch: the workgroup's chunk with rows and relation LOCAL to the job (a multi-job launch lays the jobs' rows end to end:
+// row0 = where this job's begin in the chunk table, vrel = the chunk's relation as the table and chunk_ptr number it).
+constexpr int kLsStageBytes = 2 * 32 * 512, kLsStages = 4, kLsSlots = 8;
 template <int MODE>
-__global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
-                                                                   int32_t na1, const int32_t* __restrict__ ia,
-                                                                   const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
-                                                                   int32_t ng1, const int32_t* __restrict__ ig,
-                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
-                                                                   int32_t colsum_arg, float* __restrict__ colsum_partial,
-                                                                   const uint8_t* __restrict__ maskBits, float slope,
-                                                                   const int32_t* __restrict__ chunk_ptr) {
+__device__ __forceinline__ void wgrad_ls_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
+                                              int32_t na1, const int32_t* __restrict__ ia,
+                                              const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
+                                              int32_t ng1, const int32_t* __restrict__ ig,
+                                              const Chunk* __restrict__ chunks, const Chunk ch, int32_t vrel, int32_t row0,
+                                              float* __restrict__ partial,
+                                              int32_t colsum_arg, float* __restrict__ colsum_partial,
+                                              const uint8_t* __restrict__ maskBits, float slope,
+                                              const int32_t* __restrict__ chunk_ptr, char* lds, int32_t (*idxL)[kLsSlots][16],
+                                              uint64_t (*adrL)[kLsSlots][16]) {
     constexpr bool GATHER = MODE == 0, MASKED = MODE == 2;
-    constexpr int H = 256, TR = 32, NST = 4, ROWB = 2 * H, MATB = TR * ROWB, BITB = MASKED ? 1024 : 0, STB = 2 * MATB + BITB;
+    constexpr int H = 256, TR = 32, NST = kLsStages, ROWB = 2 * H, MATB = TR * ROWB, BITB = MASKED ? 1024 : 0, STB = 2 * MATB + BITB;
+    static_assert(2 * MATB == kLsStageBytes, "stage size");
     constexpr int LPRW = H / 8;                    // 32 lanes per row
     constexpr int MT = H / 2 / 16, NT = H / 4 / 16;
-    constexpr int kSlots = 8;                      // per-loader ring of index octets (16 words a slot)
+    constexpr int kSlots = kLsSlots;               // per-loader ring of index octets (16 words a slot)
     constexpr int kGroup = GATHER ? 9 : 8;         // vector-memory operations of a loader's group (without the mask bits)
-    __shared__ __attribute__((aligned(1024))) char lds[NST * STB];
-    __shared__ __attribute__((aligned(64))) int32_t idxL[GATHER ? kLsLoaders : 1][kSlots][16];
-    __shared__ __attribute__((aligned(128))) uint64_t adrL[kLsLoaders][kSlots][16];   // per loader and tile: the 16 row addresses
     typedef __attribute__((address_space(3))) char* lds_wp;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_wp)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Chunk ch = chunks[blockIdx.x];
     const int32_t colsum_all = colsum_arg & 0xff, colsum_of = colsum_for(colsum_arg, ch.rel);   // (a chunk of another relation: zeros)
     // Tile T of this workgroup = rows [ch_beg + T * t_step, + 32) below ch_end.  chunk_ptr == NULL: the chunk's rows, t_step = 32.
     // chunk_ptr given (MODE 0): the K chunks of a relation are taken as K INTERLEAVED pieces of the relation's rows -- piece k =
@@ -849,11 +853,11 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
     int32_t ch_beg = ch.beg, ch_end = ch.end, t_step = TR;
     int ntiles = (ch.end - ch.beg + TR - 1) / TR;
     if (GATHER && chunk_ptr != nullptr) {
-        const int32_t c0 = chunk_ptr[ch.rel], c1 = chunk_ptr[ch.rel + 1];
+        const int32_t c0 = chunk_ptr[vrel], c1 = chunk_ptr[vrel + 1];
         ntiles = 0;
         if ((int32_t)blockIdx.x >= c0 && (int32_t)blockIdx.x < c1) {         // (entries past the last chunk: empty pieces)
-            ch_beg = chunks[c0].beg + TR * ((int32_t)blockIdx.x - c0);
-            ch_end = chunks[c1 - 1].end;
+            ch_beg = chunks[c0].beg - row0 + TR * ((int32_t)blockIdx.x - c0);
+            ch_end = chunks[c1 - 1].end - row0;
             t_step = TR * (c1 - c0);
             ntiles = ch_beg < ch_end ? (ch_end - ch_beg + t_step - 1) / t_step : 0;
         }
@@ -1175,6 +1179,52 @@ __global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t*
             colsum_partial[(size_t)blockIdx.x * H + tid] = sum;
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2,
+                                                                   int32_t na1, const int32_t* __restrict__ ia,
+                                                                   const bf16_t* __restrict__ G, const bf16_t* __restrict__ G2,
+                                                                   int32_t ng1, const int32_t* __restrict__ ig,
+                                                                   const Chunk* __restrict__ chunks, float* __restrict__ partial,
+                                                                   int32_t colsum_arg, float* __restrict__ colsum_partial,
+                                                                   const uint8_t* __restrict__ maskBits, float slope,
+                                                                   const int32_t* __restrict__ chunk_ptr) {
+    __shared__ __attribute__((aligned(1024))) char lds[kLsStages * (kLsStageBytes + (MODE == 2 ? 1024 : 0))];
+    __shared__ __attribute__((aligned(64))) int32_t idxL[MODE == 0 ? kLsLoaders : 1][kLsSlots][16];
+    __shared__ __attribute__((aligned(128))) uint64_t adrL[kLsLoaders][kLsSlots][16];   // per loader and tile: the 16 row addresses
+    const Chunk ch = chunks[blockIdx.x];
+    wgrad_ls_body<MODE>(A, A2, na1, ia, G, G2, ng1, ig, chunks, ch, ch.rel, 0, partial, colsum_arg, colsum_partial, maskBits, slope,
+                        chunk_ptr, lds, idxL, adrL);
+}
+
+// Several weight gradients of H = 256 in ONE launch (rows_wgrad_multi_kernel's contract, above): the conv's gathered rows (MODE 0),
+// Linear rows in row order (MODE 1) and with the activation mask as bits (MODE 2) -- a workgroup takes the body of its chunk's
+// job.  Why at this width, where no launch is latency: the Linears' gradients alone are HBM-bound (1 GB of rows that no one reads
+// twice, 229-249 us at config 5) and the conv's MFMA-bound on rows the L2s serve (431 us); side by side in one launch the dense
+// rows stream under the conv's matrix work, and the launch writes ONE round of partial tiles instead of three.
+__global__ __launch_bounds__(kLsThreads) void rows_wgrad_ls_multi_kernel(WgJobs jobs, const Chunk* __restrict__ chunks,
+                                                                         float* __restrict__ partial, float* __restrict__ colsum_partial,
+                                                                         const int32_t* __restrict__ chunk_ptr) {
+    __shared__ __attribute__((aligned(1024))) char lds[kLsStages * (kLsStageBytes + 1024)];
+    __shared__ __attribute__((aligned(64))) int32_t idxL[kLsLoaders][kLsSlots][16];
+    __shared__ __attribute__((aligned(128))) uint64_t adrL[kLsLoaders][kLsSlots][16];
+    Chunk ch = chunks[blockIdx.x];
+    int k = 0;
+    if (jobs.n > 1 && ch.rel >= jobs.j[1].first_rel) k = 1;
+    if (jobs.n > 2 && ch.rel >= jobs.j[2].first_rel) k = 2;
+    const WgJob J = k == 0 ? jobs.j[0] : (k == 1 ? jobs.j[1] : jobs.j[2]);
+    const int32_t vrel = ch.rel;
+    ch.beg -= J.row0; ch.end -= J.row0; ch.rel -= J.first_rel;
+    if (J.ia != nullptr)
+        wgrad_ls_body<0>(J.A, J.A2, J.na1, J.ia, J.G, J.G2, J.ng1, J.ig, chunks, ch, vrel, J.row0, partial, J.colsum_of, colsum_partial,
+                         nullptr, 0.f, chunk_ptr, lds, idxL, adrL);
+    else if (J.maskBits != nullptr)
+        wgrad_ls_body<2>(J.A, nullptr, 0x7fffffff, nullptr, J.G, nullptr, 0x7fffffff, nullptr, chunks, ch, vrel, J.row0, partial,
+                         J.colsum_of, colsum_partial, J.maskBits, J.slope, nullptr, lds, idxL, adrL);
+    else
+        wgrad_ls_body<1>(J.A, nullptr, 0x7fffffff, nullptr, J.G, nullptr, 0x7fffffff, nullptr, chunks, ch, vrel, J.row0, partial,
+                         J.colsum_of, colsum_partial, nullptr, 0.f, nullptr, lds, idxL, adrL);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2171,7 +2221,7 @@ int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t
                              const int32_t* chunk_ptr, void* out, int32_t out_is_f32, float* out_colsum, void* out_colsum_lp,
                              void* workspace, size_t workspace_bytes, dn_stream_t stream) {
     DN_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= 3, "dn_rows_wgrad_multi: 1 .. 3 jobs");
-    DN_REQUIRE(H == 64 || H == 128, "dn_rows_wgrad_multi: unsupported width %d (64 / 128: the widths whose launches are latency)", H);
+    DN_REQUIRE(H == 64 || H == 128 || H == 256, "dn_rows_wgrad_multi: unsupported width %d (64 / 128 / 256)", H);
     DN_REQUIRE(R >= 1 && num_chunks >= 0, "dn_rows_wgrad_multi: bad sizes");
     DN_REQUIRE(out && chunk_ptr && out_colsum, "dn_rows_wgrad_multi: NULL pointer");
     DN_REQUIRE(num_chunks == 0 || (chunks && workspace), "dn_rows_wgrad_multi: NULL pointer");
@@ -2187,9 +2237,14 @@ int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t
                     reinterpret_cast<uintptr_t>(q.G2)) % 16 == 0, "dn_rows_wgrad_multi: unaligned input");
         DN_REQUIRE(q.A2 != nullptr || q.na1 == 0x7fffffff, "dn_rows_wgrad_multi: A2 == NULL requires na1 == INT32_MAX");
         DN_REQUIRE(q.G2 != nullptr || q.ng1 == 0x7fffffff, "dn_rows_wgrad_multi: G2 == NULL requires ng1 == INT32_MAX");
-        DN_REQUIRE(q.colsum_of >= 0 && q.colsum_of <= 2 && q.first_rel >= 0 && q.row0 >= 0, "dn_rows_wgrad_multi: bad job");
+        // (H = 256: colsum_of may name ONE relation of the job whose rows are summed -- (relation + 1) << 8, as dn_rows_wgrad_bf16 takes it)
+        DN_REQUIRE(q.colsum_of >= 0 && (q.colsum_of & 0xff) <= 2 && (H == 256 || q.colsum_of <= 2) && q.first_rel >= 0 && q.row0 >= 0,
+                   "dn_rows_wgrad_multi: bad job");
         DN_REQUIRE(q.mask_a_bits == nullptr || (q.A2 == nullptr && q.idx_a == nullptr), "dn_rows_wgrad_multi: mask_a_bits excludes A2 / idx_a");
         DN_REQUIRE(k == 0 || k >= num_jobs || q.first_rel > jobs[k - 1].first_rel, "dn_rows_wgrad_multi: jobs must ascend in first_rel");
+        // H = 256 (rows_wgrad_ls_multi_kernel): a job is gathered on both sides, or in row order on both (with or without mask bits)
+        DN_REQUIRE(H != 256 || ((q.idx_a != nullptr) == (q.idx_g != nullptr) && (q.idx_a != nullptr || (q.A2 == nullptr && q.G2 == nullptr))),
+                   "dn_rows_wgrad_multi: at H = 256 a job has both index arrays or neither (and second sources only with them)");
         wj.j[k] = WgJob{(const bf16_t*)q.A, (const bf16_t*)q.A2, q.idx_a, (const bf16_t*)q.G, (const bf16_t*)q.G2, q.idx_g,
                         (const uint8_t*)q.mask_a_bits, q.na1, q.ng1, q.colsum_of, q.first_rel, q.row0, q.act_slope};
     }
@@ -2200,7 +2255,10 @@ int dn_rows_wgrad_multi_bf16(const dn_wgrad_job* jobs, int32_t num_jobs, int32_t
     const int64_t tile = (int64_t)H * H;
     float* csp = ws + (size_t)num_chunks * tile;
     if (num_chunks > 0) {
-        if (H == 128) hipLaunchKernelGGL((rows_wgrad_multi_kernel<128, 128>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, wj, ch, ws, csp);
+        if (H == 256)
+            hipLaunchKernelGGL(rows_wgrad_ls_multi_kernel, dim3((unsigned)num_chunks), dim3(kLsThreads), 0, st, wj, ch, ws, csp,
+                               wgrad_il_mode() ? chunk_ptr : (const int32_t*)nullptr);
+        else if (H == 128) hipLaunchKernelGGL((rows_wgrad_multi_kernel<128, 128>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, wj, ch, ws, csp);
         else hipLaunchKernelGGL((rows_wgrad_multi_kernel<64, 64>), dim3((unsigned)num_chunks), dim3(kWgThreads), 0, st, wj, ch, ws, csp);
         DN_CHECK_LAUNCH();
     }

@@ -2420,6 +2420,114 @@ class _RginLayerSmallFn(torch.autograd.Function):
                 cs[R + 2] if ctx.has[2] else None)
 
 
+# DN_LAYER_WIDE=0: an H = 256 bf16 RGIN layer stays a chain of separate autograd functions (conv, MLP), three weight-gradient launches
+LAYER_WIDE_ENABLED = _os.environ.get("DN_LAYER_WIDE", "1") != "0"
+# ... as it does above this many rows (the conv's + the two Linears'): every weight gradient of the layer is HBM-bound, so ONE launch
+# saves the fixed costs of two (partial tiles written and reduced, ring fill and drain: 40 us of a 0.53-ms step on an eighth of
+# config 5 -- one rank's share at 8 GPUs) and nothing else; on the whole batch (6.2 M rows) the mixed launch measured 25-55 us SLOWER
+# than the three -- the gathered rows' share of Infinity-Cache hits does not survive the Linears' streams (docs/LAB_NOTES.md)
+WIDE_LAYER_MAX_ROWS = int(_os.environ.get("DN_WIDE_MAX_ROWS", str(2 << 20)))
+
+
+WIDE_DENSE_WEIGHT = float(_os.environ.get("DN_WIDE_DENSE_WEIGHT", "2"))
+
+
+def wide_layer_chunks(rel_ptr_host, n_nodes, device, workgroups=256, dense_weight=None):
+    """Split-K chunk table of _RginLayerWideFn's ONE weight-gradient launch: the conv's relation-major rows (rel_ptr_host: R + 1
+    relations, the self loop last), then the two Linears' n_nodes rows each, in one virtual row space.  A workgroup's time is its
+    tile count x what a tile of its kind costs, and a tile of rows in row order -- streamed from HBM, no second reader -- costs about
+    twice a tile of gathered rows (which the L2s and the Infinity Cache serve in part): the Linears' chunks hold 1 / dense_weight of
+    the rows of a conv chunk, and the chunk size is the smallest for which everything fits ONE round of `workgroups`.
+    -> (chunks [C, 4] int32, chunk_ptr [R + 4] int32, C), as make_row_chunks."""
+    w = float(dense_weight if dense_weight is not None else WIDE_DENSE_WEIGHT)
+    conv = [int(b) - int(a) for a, b in zip(rel_ptr_host[:-1], rel_ptr_host[1:])]
+    P_all, n = int(rel_ptr_host[-1]), int(n_nodes)
+    dense_step = lambda c: max(64, int(c / w) // 32 * 32)                   # noqa: E731
+    count = lambda c: sum(-(-m // c) for m in conv if m > 0) + 2 * (-(-n // dense_step(c)))   # noqa: E731
+    c = max(256, -(-int((sum(conv) + 2 * w * n) // workgroups) // 64) * 64)
+    while c < WGRAD_CHUNK_CAP and count(c) > workgroups:
+        c += 64
+    c = min(c, WGRAD_CHUNK_CAP)
+    steps = [c] * len(conv) + [dense_step(c)] * 2
+    vptr = [int(v) for v in rel_ptr_host] + [P_all + n, P_all + 2 * n]
+    chunks, cptr = [], [0]
+    for r, step in enumerate(steps):
+        a, b = vptr[r], vptr[r + 1]
+        while a < b:
+            e = min(a + step, b)
+            chunks.append((r, a, e, 0))
+            a = e
+        cptr.append(len(chunks))
+    ch = torch.tensor(chunks if chunks else [(0, 0, 0, 0)], dtype=I32).reshape(-1, 4)
+    return ch.to(device), torch.tensor(cptr, dtype=I32).to(device), len(chunks)
+
+
+def rgin_layer_wide_ok(x, W, W_loop, bias, linears, index_set):
+    """Can a whole RGIN layer run as _RginLayerWideFn?  bf16, H = 256, square, self loop, two square Linears, one index part on the
+    closing-launch path (the benchmarked configuration: BASELINE config 5)."""
+    if not (LAYER_WIDE_ENABLED and CHAIN2_ENABLED and W_loop is not None and len(linears) == 2 and len(index_set.parts) == 1):
+        return False
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and W.dtype == x.dtype
+            and tuple(W.shape[1:]) == (256, 256) and x.shape[0] > 0
+            and all(l.weight.dtype == x.dtype and tuple(l.weight.shape) == (256, 256) for l in linears)):
+        return False
+    ix = index_set.parts[0][2]
+    return _selfsum_ok(ix, x) and 0 < ix.num_rows and ix.num_rows + 2 * x.shape[0] <= WIDE_LAYER_MAX_ROWS
+
+
+class _RginLayerWideFn(torch.autograd.Function):
+    """act(lin2(act(lin1(conv(x))))) of an RGIN layer at H = 256 in bf16 (rgin.py:102-160 + 50-57, BASELINE config 5) with the
+    launches of the separate functions (_RowTransformFn: transform + closing launch per direction; _ReluMlpFn: one chain launch per
+    direction) and ONE weight-gradient launch for the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_bf16 at H = 256)
+    at the end of the backward pass: the Linears' rows, which no one reads twice, stream from HBM under the conv's matrix work on
+    rows the L2s serve, and one round of partial tiles is written and reduced instead of three."""
+
+    @staticmethod
+    def forward(ctx, x, slope, index_set, W, W_loop, bias, w1, b1, w2, b2):
+        ctx.f32_mode = f32_mode()
+        x = x.contiguous()
+        ix = index_set.parts[0][2]
+        pw = PassWeights(W, W_loop, kn=True)
+        if not _kn_ok(x):
+            pw = pw.nk()
+        h = torch.empty_like(x)
+        aux = message_pass(x, pw, bias, ix, "f", index_set.ybuf(256, x.dtype, x.device), h)
+        h1, h2, bits1, bits2 = rows_chain2(h, w1, b1, True, w2, b2, True, want_bits=True, slope=float(slope))
+        ctx.index_set, ctx.slope = index_set, float(slope)
+        ctx.has = (bias is not None, b1 is not None, b2 is not None, aux is not None)
+        ctx.save_for_backward(x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux if aux is not None else x.new_empty(0))
+        return h2
+
+    @staticmethod
+    @_backward_in_forward_mode
+    def backward(ctx, gout):
+        iset, slope = ctx.index_set, ctx.slope
+        ix = iset.parts[0][2]
+        x, h, h1, bits1, bits2, W, W_loop, w1, w2, aux = ctx.saved_tensors
+        g = gout.contiguous()
+        N, H, R = x.shape[0], 256, W.shape[0]
+        g1, g0 = rows_chain2(g, w2, None, False, w1, None, False, mask0_bits=bits2, mask1_bits=bits1, w_kn=(True, True), slope=slope)
+        gx = torch.empty_like(x)
+        aux_b = message_pass(g0, PassWeights(W, W_loop, kn=False), None, ix, "b", iset.ybuf(H, g.dtype, g.device), gx)
+        # the conv's rows (relation-major, the self loop as relation R), then the two Linears' dense rows, in one virtual row space
+        if getattr(ix, "_layer_chunks", None) is None:
+            ix._layer_chunks = wide_layer_chunks(list(ix.rel_ptr_host)[:R + 2], N, x.device)
+        # (bias gradient = column sum of g0 over the self-loop rows: relation R of the first job)
+        jobs = [dict(A=x, A2=aux if ctx.has[3] else None, idx_a=ix.row_in, G=g0, G2=aux_b, idx_g=ix.row_out,
+                     colsum_of=2 | ((R + 1) << 8), first_rel=0, row0=0),
+                dict(A=g1, G=h, colsum_of=1, first_rel=R + 1, row0=ix.num_rows),
+                dict(A=g, G=h1, colsum_of=1, mask_a_bits=bits2, slope=slope, first_rel=R + 2, row0=ix.num_rows + N)]
+        gw, cs = rows_wgrad_multi(jobs, ix._layer_chunks, R + 3, H, W.dtype)
+        return (gx if ctx.needs_input_grad[0] else None, None, None, gw[:R], gw[R], cs[R] if ctx.has[0] else None, gw[R + 1],
+                cs[R + 1] if ctx.has[1] else None, gw[R + 2], cs[R + 2] if ctx.has[2] else None)
+
+
+def rgin_layer_wide(x, W, W_loop, bias, linears, slope, index_set):
+    """The whole RGIN layer of rgin_layer_wide_ok's case as one autograd function (_RginLayerWideFn)."""
+    return _RginLayerWideFn.apply(x, float(slope), index_set, W, W_loop, bias, linears[0].weight, linears[0].bias,
+                                  linears[1].weight, linears[1].bias)
+
+
 LAYER_F32_ENABLED = _os.environ.get("DN_LAYER_F32", "1") != "0"
 CHAIN2_F32_ENABLED = _os.environ.get("DN_CHAIN2_F32", "1") != "0"          # 0: the fp32 layer function keeps one launch per Linear
 

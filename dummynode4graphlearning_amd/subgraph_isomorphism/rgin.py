@@ -168,6 +168,9 @@ class RGINLayer(nn.Module):
             return None
         if ops.rgin_layer_small_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
             return ops.rgin_layer_small(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
+        if ops.rgin_layer_wide_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
+            # H = 256 in bf16: the launches of the general route with ONE weight-gradient launch for the conv and both Linears
+            return ops.rgin_layer_wide(node_feat, W, self.loop_weight, self.bias, linears, slope, index)
         if ops.rgin_layer_f32_ok(node_feat, W, self.loop_weight, self.bias, linears, index):
             # the reference's own precision: the same launches as the separate functions, ONE weight-gradient launch in the backward
             # (residual: node_feat + layer(node_feat) leaves the MLP launch; forward_residual is told through _residual_done)

@@ -434,7 +434,13 @@ int dn_rows_wgrad_bf16(const void* A, const void* A2, int32_t na1, const int32_t
  * indices, colsum_of, mask_a_bits and act_slope per job as in dn_rows_wgrad_bf16 (no mask_a / a_out here).  out [R][H][H],
  * out_colsum [R][H] fp32 (zeros for a job with colsum_of = 0), out_colsum_lp [R][H] in out's type or NULL.  H = 64 / 128: the
  * widths at which a layer's three weight-gradient launches and their reduces are launch latency (BASELINE config 3: the whole
- * backward of an RGIN layer then needs one weight-gradient launch, subgraph_isomorphism/models/rgin.py:50-67,102-160). */
+ * backward of an RGIN layer then needs one weight-gradient launch, subgraph_isomorphism/models/rgin.py:50-67,102-160).
+ * H = 256 (rows_wgrad_ls_multi_kernel): a job is gathered on both sides (idx_a and idx_g; second sources allowed), or in row order
+ * on both, with or without mask_a_bits; colsum_of may carry (relation + 1) << 8 -- a relation of THAT job, counted from its
+ * first_rel -- as in dn_rows_wgrad_bf16; any chunk table over the virtual rows serves (the host side gives the row-order jobs
+ * chunks of half the rows: ops.wide_layer_chunks).  One launch for a layer's three gradients pays on small batches only -- an
+ * eighth of BASELINE config 5, one rank's share at 8 GPUs: 175 -> 150 us -- where the fixed costs of a launch count; every one of
+ * them is HBM-bound. */
 typedef struct dn_wgrad_job {
     const void *A, *A2;
     const int32_t* idx_a;

@@ -318,3 +318,59 @@ def test_batches_outside_the_limits_keep_the_row_factorised_launches():
     ixg = ops.RowIndex(src, dst, et, nptr[-1], 4, self_loop=True)        # no graph boundaries: the general builder, no whole-graph launch
     assert not ops.conv_graphs_ok(x, pw, ixg)
     assert not ops.conv_graphs_ok(x.float(), pw, ix) and not ops.conv_graphs_ok(torch.zeros(nptr[-1], 128, device=DEV, dtype=torch.bfloat16), pw, ix)
+
+
+@pytest.mark.parametrize("act,graphs", [("relu", 96), ("leaky_relu", 700)])
+def test_wide_rgin_layer_takes_one_weight_gradient_launch(act, graphs):
+    """RGINLayer(256, 256) in bf16 (BASELINE config 5's layer) as ONE autograd function whose backward ends in ONE weight-gradient
+    launch + reduce for the conv's R + 1 matrices and both Linears (dn_rows_wgrad_multi_bf16 at H = 256: gathered rows, rows in row
+    order and rows masked by bits side by side in one grid) -- the same forward and input-gradient launches as the separate functions
+    (bitwise equal), the weight gradients equal up to the fp32 summation order of their split-K partials (other chunk boundaries);
+    bitwise repeatable."""
+    from dummynode4graphlearning_amd import BatchedGraph, ops, synthetic, transforms
+    from dummynode4graphlearning_amd.subgraph_isomorphism import RGINLayer
+    raw = synthetic.config3(seed=9, graphs=graphs)
+    keys = ("node_ptr", "edge_ptr", "src", "dst", "node_id", "node_label", "edge_id", "edge_label")
+    aug = transforms.dummy_augment_si(*(torch.from_numpy(raw[k]).to(DEV) for k in keys), raw["max_nv"], raw["max_nvl"], raw["max_ne"],
+                                      raw["max_nel"])
+    N, R, H = int(aug["node_label"].numel()), 8, 256
+    bnn = (aug["node_ptr"][1:] - aug["node_ptr"][:-1]).long()
+    bne = (aug["edge_ptr"][1:] - aug["edge_ptr"][:-1]).long()
+    et = aug["edge_label"].long()
+    torch.manual_seed(6)
+    layer = RGINLayer(H, H, num_rels=R, regularizer="basis", num_bases=-1, num_mlp_layers=2, act_func=act).to(DEV).to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x0 = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+    coef = torch.randn(N, H, device=DEV, generator=gen).to(torch.bfloat16)
+
+    def run():
+        g = BatchedGraph(aug["src"], aug["dst"], N, bnn, bne, node_ptr=aug["node_ptr"], edge_ptr=aug["edge_ptr"])
+        for p in layer.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            out, _ = layer(g, x, et)
+            out.backward(coef)
+        finally:
+            ops.kernel_timer = None
+        return ([r[0] for r in timer.records],
+                [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters() if p.grad is not None])
+
+    tags, got = run()
+    assert tags.count("rows_wgrad_multi") == 1 and "rows_wgrad" not in tags, tags
+    old = ops.LAYER_WIDE_ENABLED
+    try:
+        ops.LAYER_WIDE_ENABLED = False
+        tags1, sep = run()
+    finally:
+        ops.LAYER_WIDE_ENABLED = old
+    assert tags1.count("rows_wgrad") == 3 and "rows_wgrad_multi" not in tags1, tags1
+    assert len(tags) == len(tags1) - 2 and len(got) == len(sep)
+    assert torch.equal(got[0], sep[0]) and torch.equal(got[1], sep[1])      # the same launches for the output and the input gradient
+    for a, b in zip(got[2:], sep[2:]):
+        assert bool(torch.isfinite(a.float()).all()) and _rel_l2(a, b) < 4e-3   # (bf16 results of fp32 sums in another order)
+    _, again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)

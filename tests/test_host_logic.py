@@ -229,3 +229,33 @@ def test_weight_gradient_chunks_fit_one_round_of_workgroups():
         C = ops.close_chunks(N, wg)                                     # chunks of the batch: a whole number per workgroup, < 16,384,
         assert C % wg == 0 and wg <= C < 16384                          # about CLOSE_CHUNK_TILES tiles each once the batch is that large
         assert C == wg or abs(N / 32.0 / C - ops.CLOSE_CHUNK_TILES) <= ops.CLOSE_CHUNK_TILES / 2
+
+
+def test_wide_layer_chunks_cover_the_virtual_rows_in_one_round():
+    """ops.wide_layer_chunks (the chunk table of the H = 256 layer's ONE weight-gradient launch): the conv's relations and the two
+    Linears' rows end to end, every virtual row in exactly one chunk of its relation, chunk_ptr the running count, one round of 256
+    workgroups up to the cap, and the Linears' chunks 1 / dense_weight the size of the conv's."""
+    from dummynode4graphlearning_amd import ops
+    rng = np.random.default_rng(1)
+    dev = torch.device("cpu")
+    for trial in range(30):
+        R = int(rng.integers(1, 18))
+        sizes = [int(rng.integers(0, 60000)) for _ in range(R)]
+        N = int(rng.integers(1, 120000))
+        ptr = [0] + [int(v) for v in np.cumsum(sizes + [N])]            # the self loop: one row per node, the last relation
+        ch, cp, n = ops.wide_layer_chunks(ptr, N, dev)
+        ch, cp = ch.numpy(), cp.numpy()
+        vptr = ptr + [ptr[-1] + N, ptr[-1] + 2 * N]
+        assert cp.shape[0] == len(vptr) and cp[0] == 0 and cp[-1] == n == ch.shape[0]
+        assert n <= 256 or int((ch[:, 2] - ch[:, 1]).max()) == ops.WGRAD_CHUNK_CAP
+        for r in range(len(vptr) - 1):
+            mine = ch[cp[r]:cp[r + 1]]
+            assert (mine[:, 0] == r).all()
+            if vptr[r + 1] == vptr[r]:
+                assert mine.shape[0] == 0
+                continue
+            assert mine[0, 1] == vptr[r] and mine[-1, 2] == vptr[r + 1]
+            assert (mine[1:, 1] == mine[:-1, 2]).all() and (mine[:, 2] > mine[:, 1]).all()
+        conv_step = int((ch[:cp[R + 1], 2] - ch[:cp[R + 1], 1]).max())
+        dense_step = int((ch[cp[R + 1]:, 2] - ch[cp[R + 1]:, 1]).max())
+        assert dense_step % 32 == 0 and dense_step <= max(64, conv_step // 2)
