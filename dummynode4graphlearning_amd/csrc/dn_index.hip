@@ -748,6 +748,13 @@ __global__ void row_tables_kernel(int32_t Rt, const int32_t* __restrict__ rel_pt
 // the W workgroups of each of the 8 groups), then fills its entries (workgroup b = j * 8 + x, slot m).  Mirrors
 // tests/sweep_ref.py (wg_shares + the event ranks) line by line.
 constexpr int kSwGroups = 8, kSwMaxRel = 64, kSwMaxW = 64, kSwTile = 32;
+// Below this many tiles per workgroup no relation gets workgroups of its own: the group's whole tile line is cut into W segments
+// (sweep_ref.PURE_MIN_S).  With "pure" workgroups the two or three helpers of a group take the left-overs of ALL its relations,
+// one weight reload (~2.7 us) each -- 21 us on a launch whose median workgroup needs 39 (an eighth of config 5: 32 tiles each).
+int sw_pure_min() {
+    static const int v = dn_knob("DN_SW_PURE_MIN", 64);
+    return v;
+}
 
 struct SwDir {
     int32_t *table, *info;
@@ -760,7 +767,7 @@ struct SwPair {
 
 __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int32_t* __restrict__ rel_ptr,
                                                             const int32_t* __restrict__ row_in, const int32_t* __restrict__ row_out,
-                                                            int32_t N, int32_t W, int32_t S_cap, SwPair pr) {
+                                                            int32_t N, int32_t W, int32_t S_cap, SwPair pr, int32_t pure_min) {
     // blockIdx.y picks the table (dn_conv_index_build_i32 builds the orders of both transform launches in one launch)
     unsigned long long skip_mask = pr.d[blockIdx.y].skip_mask;
     int32_t* __restrict__ table = pr.d[blockIdx.y].table;
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
         for (int r = 0; r < R; ++r) {
             pure0[x][r] = j;
             crem[x][r] = acc;
-            const int32_t k = S > 0 ? T[x][r] / S : 0;
+            const int32_t k = (S > 0 && S >= pure_min) ? T[x][r] / S : 0;
             j += k;
             acc += T[x][r] - k * S;
         }
@@ -1084,7 +1091,7 @@ int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* 
         pr.d[k] = SwDir{table[q], info ? info[q] : nullptr, dyn ? dyn[q] : nullptr, (unsigned long long)skip_mask[q]};
     }
     hipLaunchKernelGGL(sweep_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)nd), dim3(256), 0, st, num_rels, rel_ptr,
-                       row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup, pr);
+                       row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup, pr, (int32_t)sw_pure_min());
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

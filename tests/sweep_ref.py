@@ -49,18 +49,24 @@ def group_bounds(rel_ptr, key, N, groups, skip_mask=0):
     return lo
 
 
-def wg_shares(T_row, W):
+PURE_MIN_S = 64      # below this many tiles per workgroup no relation gets workgroups of its own (kSwPureMinS in dn_index.hip)
+
+
+def wg_shares(T_row, W, pure_min=PURE_MIN_S):
     """Shares of one group's W workgroups: -> (S, shares) with shares[j] = [(relation, quota), ...] in processing order.
     S = ceil(T / W) tiles per workgroup.  Relation r first gets floor(T_r / S) workgroups of its own ("pure": quota S each, all of
     them in lock step); what is left of every relation (< S tiles each) is laid on a line, relation-major, and cut into balanced
-    segments for the remaining workgroups ("helpers": a few relations each, one after the other)."""
+    segments for the remaining workgroups ("helpers": a few relations each, one after the other).
+    S < pure_min (small launches: an eighth of BASELINE config 5 has S = 32): NO pure workgroups -- the whole line is cut into W
+    segments, a workgroup serves at most two relations when T_r >= S.  With pure workgroups the two or three helpers of a group
+    take the left-overs of ALL its relations, a weight reload (~2.7 us) each: 21 us on a launch whose median workgroup needs 39."""
     T_row = [int(v) for v in T_row]
     Tx = sum(T_row)
     S = (Tx + W - 1) // W
     shares = [[] for _ in range(W)]
     if Tx == 0:
         return 0, shares
-    pure = [t // S for t in T_row]
+    pure = [(t // S if S >= pure_min else 0) for t in T_row]
     j = 0
     for r, k in enumerate(pure):
         for _ in range(k):

@@ -958,18 +958,20 @@ def test_fold_is_refused_when_a_graph_is_not_a_contiguous_node_range():
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-2
 
 
-@pytest.mark.parametrize("seed,R,W,skew", [(0, 16, 32, False), (1, 5, 32, True), (2, 40, 16, False), (3, 3, 64, True), (4, 17, 32, False)])
-def test_sweep_tile_tables_match_the_host_restatement(seed, R, W, skew):
+@pytest.mark.parametrize("seed,R,W,skew,G", [(0, 16, 32, False, 3000), (1, 5, 32, True, 3000), (2, 40, 16, False, 3000),
+                                             (3, 3, 64, True, 3000), (4, 17, 32, False, 3000), (5, 6, 16, False, 40000),
+                                             (6, 16, 32, True, 40000)])
+def test_sweep_tile_tables_match_the_host_restatement(seed, R, W, skew, G):
     """dn_sweep_tables_build_i32 (L2-blocked tile order of the persistent transform launch) against tests/sweep_ref.py: the same
     table bit for bit; every row of every kept relation covered exactly once; keys that are not monotone (any cut is valid);
-    a table too small for a group falls back to the plain order (still a partition)."""
+    a table too small for a group falls back to the plain order (still a partition).  Both share rules: relations with workgroups
+    of their own (64 or more tiles per workgroup: the 40,000-graph cases) and the plain cut of the group's tile line (fewer)."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from sweep_ref import check_partition, sweep_tables
     ops = _ops()
     rng = np.random.default_rng(100 + seed)
-    G = 3000
     sizes = rng.integers(1, 40, size=G)
     node_ptr = np.concatenate([[0], np.cumsum(sizes)])
     N = int(node_ptr[-1])
@@ -997,6 +999,8 @@ def test_sweep_tile_tables_match_the_host_restatement(seed, R, W, skew):
     S = ntiles // (8 * W)
     plain, smax = (int(v) for v in info.cpu())
     assert plain == 0 and smax <= S
+    from sweep_ref import PURE_MIN_S
+    assert (smax >= PURE_MIN_S) == (G > 3000)                           # (which share rule the case exercises)
     got = table.cpu().numpy().reshape(8 * W, S, 4)
     want, _ = sweep_tables(rel_ptr, key, N, W, skip_mask=skip, s_cap=S)
     assert np.array_equal(got, want)
