@@ -755,6 +755,16 @@ int sw_pure_min() {
     static const int v = dn_knob("DN_SW_PURE_MIN", 64);
     return v;
 }
+// What a helper's share is weighed by (sweep_ref.HELP_PCT / HELP_SW): per cent a helper's tile costs more than a pure workgroup's,
+// tiles a change of relation costs.  The pure quota grows by delta so that both kinds finish together (sweep_ref.wg_shares).
+int sw_help_pct() {
+    static const int v = dn_knob("DN_SW_HELP_PCT", 5);
+    return v;
+}
+int sw_help_sw() {
+    static const int v = dn_knob("DN_SW_HELP_SW", 4);
+    return v;
+}
 
 struct SwDir {
     int32_t *table, *info;
@@ -767,7 +777,8 @@ struct SwPair {
 
 __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int32_t* __restrict__ rel_ptr,
                                                             const int32_t* __restrict__ row_in, const int32_t* __restrict__ row_out,
-                                                            int32_t N, int32_t W, int32_t S_cap, SwPair pr, int32_t pure_min) {
+                                                            int32_t N, int32_t W, int32_t S_cap, SwPair pr, int32_t pure_min,
+                                                            int32_t help_pct, int32_t help_sw) {
     // blockIdx.y picks the table (dn_conv_index_build_i32 builds the orders of both transform launches in one launch)
     unsigned long long skip_mask = pr.d[blockIdx.y].skip_mask;
     int32_t* __restrict__ table = pr.d[blockIdx.y].table;
@@ -816,7 +827,20 @@ __global__ __launch_bounds__(256) void sweep_tables_kernel(int32_t R, const int3
         const int x = tid;
         int64_t Tx = 0;
         for (int r = 0; r < R; ++r) Tx += T[x][r];
-        const int32_t S = (int32_t)((Tx + W - 1) / W);
+        int32_t S = (int32_t)((Tx + W - 1) / W);
+        if (S > 0 && S >= pure_min) {                             // the pure quota grows by what the helpers' slower tiles weigh
+            int32_t n_pure = 0, n_rem = 0;
+            for (int r = 0; r < R; ++r) {
+                const int32_t k = T[x][r] / S;
+                n_pure += k;
+                n_rem += (T[x][r] - k * S) > 0 ? 1 : 0;
+            }
+            const int32_t wh0 = W - n_pure;
+            if (n_pure > 0 && wh0 > 0 && n_rem > 0) {
+                const int32_t k = (n_rem + wh0 - 1) / wh0;
+                S += (int32_t)((((int64_t)S * help_pct) / 100 + (int64_t)help_sw * k) * wh0 / (wh0 + n_pure + ((int64_t)n_pure * help_pct) / 100));
+            }
+        }
         Sx[x] = S;
         int32_t j = 0, acc = 0;
         for (int r = 0; r < R; ++r) {
@@ -1091,7 +1115,8 @@ int sweep_tables_queue(int32_t num_rels, const int32_t* rel_ptr, const int32_t* 
         pr.d[k] = SwDir{table[q], info ? info[q] : nullptr, dyn ? dyn[q] : nullptr, (unsigned long long)skip_mask[q]};
     }
     hipLaunchKernelGGL(sweep_tables_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)nd), dim3(256), 0, st, num_rels, rel_ptr,
-                       row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup, pr, (int32_t)sw_pure_min());
+                       row_in, row_out, (int32_t)num_nodes, workgroups_per_group, tiles_per_workgroup, pr, (int32_t)sw_pure_min(),
+                       (int32_t)sw_help_pct(), (int32_t)sw_help_sw());
     DN_CHECK_LAUNCH();
     return DN_OK;
 }

@@ -102,9 +102,33 @@ __global__ __launch_bounds__(kThreads) void rows_transform_ring_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t_beg = (int)blockIdx.x * tiles_per_wg;
-    const int nt = min(t_beg + tiles_per_wg, num_tiles) - t_beg;
+    int nt = min(t_beg + tiles_per_wg, num_tiles) - t_beg;
     if (nt <= 0) return;
     tiles += t_beg;
+    // Trailing EMPTY slots of this workgroup's range are not walked (an empty tile costs a ring stage and a tile's MFMAs; the sweep
+    // order cuts its helper workgroups' shares short on purpose -- dn_index.hip): nt = last live slot + 1, found by every wave for
+    // itself from the same records (uniform), the loads of up to 512 slots in flight together.
+#ifdef DN_TUNING_ENV
+    if (nt <= 512 && !(flags & (128 << 3))) {                              // (DN_TF_ABL bit 7: every slot walked, as before round 6)
+#else
+    if (nt <= 512) {
+#endif
+        bool live[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 64 * c + lane;
+            live[c] = false;
+            if (k < nt) { const Tile tl = tiles[k]; live[c] = tl.end > tl.beg; }
+        }
+        int last = -1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const unsigned long long m = __ballot(live[c]);
+            if (m) last = 64 * c + 63 - __builtin_clzll(m);
+        }
+        nt = last + 1;
+        if (nt <= 0) return;
+    }
 
     if (wave >= kCompute) {
         // ------------------------------------------------------------------------------------------------ loaders

@@ -418,12 +418,13 @@ def build_sweep_tables(rel_ptr_dev, num_rels, row_in, row_out, num_nodes, num_ro
                        want_info=False):
     """L2-blocked tile order of relation-major rows for the persistent transform launch (dn_sweep_tables_build_i32; see
     include/dn_hip.h): (table [8 * wg_per_group * S, 4] int32, 8 * wg_per_group * S) -- the pair rows_transform takes.  S is
-    sized from what the host knows (rows / 32 + one partial tile per group and relation, 6 % head-room for uneven groups); when
+    sized from what the host knows (rows / 32 + one partial tile per group and relation, 10 % head-room for uneven groups and the
+    pure workgroups' quota); when
     a group needs more the builder writes the plain order into the same table (still valid), no read-back."""
     require_gpu(rel_ptr_dev, row_in, row_out)
     _i32(rel_ptr_dev, "rel_ptr"), _i32(row_in, "row_in"), _i32(row_out, "row_out")
     G = 8 * int(wg_per_group)
-    S = int(1.06 * (int(num_rows) // 32 + 8 * int(num_rels)) / G) + 2
+    S = int(1.10 * (int(num_rows) // 32 + 8 * int(num_rels)) / G) + 4     # (head-room: uneven groups, the pure workgroups' larger quota)
     table = torch.empty((G * S, 4), dtype=I32, device=rel_ptr_dev.device)
     info = torch.empty(2, dtype=I32, device=rel_ptr_dev.device) if want_info else None
     check(lib().dn_sweep_tables_build_i32(int(num_rels), ptr(rel_ptr_dev), ptr(row_in), ptr(row_out), int(num_nodes),
@@ -1415,7 +1416,7 @@ class RowIndex:
                     cus.append(cu)
                 Gw = 8 * SWEEP_WG_PER_GROUP
                 want_sweep = SWEEP_ENABLED and E // 32 >= Gw * SWEEP_MIN_TILES_PER_WG
-                S = int(1.06 * (E // 32 + 8 * R) / Gw) + 2 if want_sweep else 0
+                S = int(1.10 * (E // 32 + 8 * R) / Gw) + 4 if want_sweep else 0
                 sweeps = [torch.empty((Gw * S, 4), dtype=I32, device=dev) for _ in range(2)] if want_sweep else [None, None]
                 chunk_cap = (E + N) // 256 + R + 3
                 chunk_tab, chunk_pp = torch.empty((chunk_cap, 4), dtype=I32, device=dev), e32(R + 2)

@@ -371,7 +371,9 @@ int dn_row_tables_build_i32(int32_t num_rels, const int32_t* rel_ptr, int32_t st
  * is walked by the workgroups b = j * 8 + x (blocks b, b + 8, ... share an XCD and its L2).  Inside a group most workgroups serve
  * ONE relation for the whole launch (weights stay in registers) and take every k-th of its tiles, so all of them move through
  * the group's graphs at the same pace and a source row fetched for one relation is still in that XCD's L2 when the other
- * relations ask for it; a few helper workgroups take the left-overs of several relations one after the other.  Groups with fewer
+ * relations ask for it; a few helper workgroups take the left-overs of several relations one after the other (their tiles cost
+ * more -- rows out of phase with the group's sweep, a weight reload per relation -- so the quota of the others grows by a few tiles
+ * until both kinds finish together; the transform launch does not walk a workgroup's trailing empty slots).  Groups with fewer
  * than 64 tiles per workgroup (an eighth of BASELINE config 5: 32) have no such workgroups: the group's tile line, relation-major,
  * is cut into equal segments (at most two relations per workgroup when a relation has more tiles than a segment) -- a helper's
  * weight reloads, one per relation of the group, were a third of such a launch.

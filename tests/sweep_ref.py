@@ -49,7 +49,8 @@ def group_bounds(rel_ptr, key, N, groups, skip_mask=0):
     return lo
 
 
-PURE_MIN_S = 64      # below this many tiles per workgroup no relation gets workgroups of its own (kSwPureMinS in dn_index.hip)
+PURE_MIN_S = 64      # below this many tiles per workgroup no relation gets workgroups of its own (sw_pure_min in dn_index.hip)
+HELP_PCT, HELP_SW = 5, 4    # a helper's tile costs 5 % more than a pure workgroup's, a change of relation 4 tiles (sw_help_* there)
 
 
 def wg_shares(T_row, W, pure_min=PURE_MIN_S):
@@ -67,6 +68,16 @@ def wg_shares(T_row, W, pure_min=PURE_MIN_S):
     if Tx == 0:
         return 0, shares
     pure = [(t // S if S >= pure_min else 0) for t in T_row]
+    # Helpers are slower per tile (their share of a relation is spread over the group's whole node range while the pure workgroups
+    # are still at its beginning: L2 misses where those hit) and reload weights per relation -- 387-395 us against a median of 351 on
+    # BASELINE config 5.  The pure quota therefore grows by delta tiles, so that the helpers' line shrinks by (pure workgroups) x
+    # delta: balanced when S + delta = (1 + pct) x (helper tiles) + sw x (relations per helper).
+    n_pure, n_rem = sum(pure), sum(1 for t, k in zip(T_row, pure) if t - k * S > 0)
+    Wh0 = W - n_pure
+    if n_pure > 0 and Wh0 > 0 and n_rem > 0:
+        k = -(-n_rem // Wh0)
+        S += ((S * HELP_PCT) // 100 + HELP_SW * k) * Wh0 // (Wh0 + n_pure + (n_pure * HELP_PCT) // 100)
+        pure = [t // S for t in T_row]
     j = 0
     for r, k in enumerate(pure):
         for _ in range(k):
@@ -94,12 +105,13 @@ def sweep_tables(rel_ptr, key, N, W, skip_mask=0, groups=8, xcd_major=False, s_c
     T = np.zeros((groups, R), dtype=np.int64)
     for x in range(groups):
         T[x] = (lo[x + 1] - lo[x] + TILE - 1) // TILE
-    Sx = (T.sum(1) + W - 1) // W
+    all_shares = [wg_shares(T[x], W) for x in range(groups)]
+    Sx = np.asarray([sh[0] for sh in all_shares], dtype=np.int64)       # slots the fullest workgroup of a group needs
     S = int(Sx.max()) if s_cap is None else int(s_cap)
     assert S >= int(Sx.max())
     table = np.zeros((groups * W, max(S, 1), 4), dtype=np.int32)
     for x in range(groups):
-        _, shares = wg_shares(T[x], W)
+        _, shares = all_shares[x]
         parts = [[] for _ in range(R)]                       # participants of every relation, in workgroup order
         for j, sh in enumerate(shares):
             for r, a in sh:

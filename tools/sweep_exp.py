@@ -26,8 +26,11 @@ def main():
     ap.add_argument("--xcd-major", action="store_true", help="control: wrong placement (workgroup b -> group b // W)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", choices=["", "baseline", "sweep"])
+    ap.add_argument("--slow", type=int, default=0, help="tuning build with DN_RING_STATS: list the N slowest workgroups of a sweep launch")
     ap.add_argument("--ab", type=int, default=0, help="conv leg A/B only: plain and sweep tile order alternated this many times")
     a = ap.parse_args()
+    global SLOW
+    SLOW = a.slow
     import bench
     from dummynode4graphlearning_amd import ops
     dev = torch.device("cuda:0")
@@ -103,7 +106,7 @@ def main():
                 same = bool(torch.equal(Y0.view(torch.int16), Y1.view(torch.int16))) if Y0 is not None else None
                 print("dir %s sweep W=%3d %s %7.1f us   steps %d  identical %s"
                       % (direction, Wg, "xcd-major(control)" if xm else "round-robin", t1, S, same), flush=True)
-                ring_stats("sweep")
+                ring_stats("sweep", tab if a.slow else None)
                 if not xm:
                     fold.main_tiles = tt                  # (kept for the conv leg below)
     t_conv = conv_leg(ops, ix, x, gout, W, bias, dev)
@@ -137,7 +140,10 @@ def conv_leg(ops, ix, x, gout, W_all, bias, dev, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
-def ring_stats(tag):
+SLOW = 0
+
+
+def ring_stats(tag, table=None):
     """tuning build: cycle counters of the last ring launch (median over workgroups)."""
     import ctypes
     from dummynode4graphlearning_amd import _lib
@@ -156,6 +162,26 @@ def ring_stats(tag):
              " ".join("%.0f" % np.median(rt[x::8]) for x in range(8))), flush=True)
     print("   %s cycles/WG (median): compute loop %.0f = barrier wait %.0f + reads/mfma %.0f + epilogue %.0f | loader loop %.0f = "
           "vm wait %.0f + barrier wait %.0f + body %.0f" % ((tag,) + tuple(m)), flush=True)
+    if table is not None and SLOW:
+        # the slowest workgroups: (block, XCD group x = b % 8, j = b // 8), loop us, tiles, relations in processing order with tile counts
+        order = np.argsort(-rt)
+        def describe(b):
+            rows = table[b]
+            live = rows[rows[:, 2] > rows[:, 1]]
+            rels, cnt = [], []
+            for r in live[:, 0]:
+                if rels and rels[-1] == r:
+                    cnt[-1] += 1
+                else:
+                    rels.append(int(r)); cnt.append(1)
+            return "b %3d x %d j %2d  %.1f us  tiles %3d  cycles: bar %6.0f mfma %6.0f epi %6.0f  rels %s" % (
+                b, b % 8, b // 8, rt[b], live.shape[0], a[b, 1], a[b, 2], a[b, 3], " ".join("%d:%d" % rc for rc in zip(rels, cnt)))
+        for b in order[:SLOW]:
+            print("   slow  " + describe(int(b)), flush=True)
+        for b in order[-4:]:
+            print("   fast  " + describe(int(b)), flush=True)
+        mid = order[len(order) // 2]
+        print("   mid   " + describe(int(mid)), flush=True)
 
 
 if __name__ == "__main__":
