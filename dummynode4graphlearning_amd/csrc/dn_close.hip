@@ -482,6 +482,11 @@ constexpr int kRecRing = 32, kIdxRing = 16, kDescRing = 32, kMaskRing = 32, kFol
 constexpr int kFoldInfo = 12;                       // int32 words per tile of the fold table (dn_fold_tables_build_i32)
 
 __device__ int32_t g_close_zero[64];                // zeros (device globals are zero-initialised): the mask of a row past a unit's end
+#ifdef DN_CLOSE_TIMES
+// diagnostic build (-DDN_CLOSE_TIMES): wall ticks (100 MHz) of compute wave 0 of every workgroup of the last closing launch
+// {first tick, last tick, units} -- tools/close_exp.py --spread
+__device__ unsigned long long g_close_times[256][3];
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
@@ -662,6 +667,18 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
     }
 
     // ---------------------------------------------------------------------------------------------------- compute
+#ifdef DN_CLOSE_TIMES
+    struct WgTimes {
+        unsigned long long t0;
+        int wave, lane, nt;
+        __device__ ~WgTimes() {
+            if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+                g_close_times[blockIdx.x][0] = t0; g_close_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+                g_close_times[blockIdx.x][2] = (unsigned long long)nt;
+            }
+        }
+    } wg_times{__builtin_amdgcn_s_memrealtime(), wave, lane, nt};
+#endif
     const bool nt_store = (flags & 2) != 0;
     const int n0 = 32 * wave;
     const int j = lane & 15, g = lane >> 4;
@@ -966,6 +983,12 @@ __global__ __launch_bounds__(kThreads) void rows_close_ring_kernel(
 #undef DN_DS_READ128
 
 }  // namespace
+
+#ifdef DN_CLOSE_TIMES
+extern "C" int dn_debug_close_times(unsigned long long* out) {             // diagnostic build only: 256 x 3 words of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_close_times), sizeof(g_close_times)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 namespace dn_internal {
 
