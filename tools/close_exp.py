@@ -17,7 +17,8 @@ from dummynode4graphlearning_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 graphs = int(os.environ.get("GRAPHS", "32768"))
-g, raw, _ = bench.build_batch(dev, 5, graphs, "config5")
+workload = os.environ.get("WORKLOAD", "config5")          # WORKLOAD=proteins GRAPHS=16384: bench.py --workload proteins' batch
+g, raw, _ = bench.build_batch(dev, 5, graphs, workload)
 N, H, R = g.number_of_nodes(), 256, 16
 ix = g.row_index(g.edata["label"], R, True).parts[0][2]
 P = ix.num_edge_rows
