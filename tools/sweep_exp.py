@@ -34,7 +34,7 @@ def main():
     import bench
     from dummynode4graphlearning_amd import ops
     dev = torch.device("cuda:0")
-    g, raw, _ = bench.build_batch(dev, 5, a.graphs, "config5")
+    g, raw, _ = bench.build_batch(dev, 5, a.graphs, os.environ.get("WORKLOAD", "config5"))    # WORKLOAD=proteins --graphs 16384
     N, E, H, R = g.number_of_nodes(), g.number_of_edges(), 256, 16
     etype = g.edata["label"]
     iset = g.row_index(etype, R, True)
