@@ -81,11 +81,13 @@ __global__ __launch_bounds__(kThreads) void rows_gemm_kernel(const T* __restrict
 // product is formed (A operand = 16 columns of the weight, B operand = the wave's 16 rows), so a lane ends up with 4 consecutive
 // columns of one row = one 16-byte store.  Operands are staged through LDS in K-steps of 32 (zero-padded at the edges).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// KC: columns of k per step.  A step is a dependent chain (loads -> LDS -> barrier -> a few MFMAs -> barrier), so its cost is the
+// loads' latency whatever KC is: K >= 128 takes steps of 128 (a 256-wide readout Linear on 16 k rows: eight round trips -> two).
+template <int KC>
 __global__ __launch_bounds__(kThreads) void rows_gemm_mfma_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                                       const float* __restrict__ bias, int32_t K, int32_t N,
                                                                       int32_t transposed, const Piece* __restrict__ tiles,
                                                                       float* __restrict__ Y) {
-    constexpr int KC = 32;
     __shared__ float As[TM][KC + 1];                                     // [row][k]
     __shared__ float Ws[KC][TN + 1];                                     // [k][n]
     const Piece tl = tiles[blockIdx.x];
@@ -257,9 +259,14 @@ int rows_gemm(const T* A, const T* W, const T* bias, int32_t K, int32_t N, int32
     if constexpr (sizeof(T) == 4) {                                       // fp32: exact-f32 MFMA tiles
         static const int mfma = dn_knob("DN_GEMM_MFMA", 1);               // tuning build: 0 keeps the FMA tiles
         if (mfma) {
-            hipLaunchKernelGGL(rows_gemm_mfma_f32_kernel, dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st,
-                               (const float*)A, (const float*)W, (const float*)bias, K, N, transposed,
-                               reinterpret_cast<const Piece*>(tiles), (float*)Y);
+            if (K >= 128)
+                hipLaunchKernelGGL(rows_gemm_mfma_f32_kernel<128>, dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st,
+                                   (const float*)A, (const float*)W, (const float*)bias, K, N, transposed,
+                                   reinterpret_cast<const Piece*>(tiles), (float*)Y);
+            else
+                hipLaunchKernelGGL(rows_gemm_mfma_f32_kernel<32>, dim3((unsigned)num_tiles, (unsigned)dn_cdiv(N, TN)), dim3(kThreads), 0, st,
+                                   (const float*)A, (const float*)W, (const float*)bias, K, N, transposed,
+                                   reinterpret_cast<const Piece*>(tiles), (float*)Y);
             DN_CHECK_LAUNCH();
             return DN_OK;
         }
